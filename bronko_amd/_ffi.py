@@ -1,0 +1,80 @@
+"""ctypes binding of include/bronko_hip.h (libbronko_hip.so).  No fallbacks: a missing library is an error."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbronko_hip.so")
+
+
+class BucketInfo(C.Structure):  # include/bronko_hip.h bk_bucket_info == build.rs:52-60
+    _fields_ = [("file_id", C.c_uint16), ("seq_id", C.c_uint8), ("location", C.c_uint32),
+                ("idx", C.c_uint8), ("canonical", C.c_uint8)]
+
+
+class IndexDesc(C.Structure):
+    _fields_ = [("k", C.c_int32), ("n_buckets", C.c_uint64), ("bucket_ids", C.c_void_p), ("bucket_off", C.c_void_p),
+                ("entries", C.c_void_p), ("n_entries", C.c_uint64), ("n_files", C.c_int32), ("n_seqs", C.c_void_p),
+                ("seq_lens", C.c_void_p), ("seqs", C.c_void_p)]
+
+
+class Params(C.Structure):
+    _fields_ = [("n_fixed", C.c_int32), ("use_full_kmer", C.c_int32), ("ci", C.c_uint64), ("cs", C.c_uint64),
+                ("cx", C.c_uint64), ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+# every symbol include/bronko_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = ["bk_abi_version", "bk_last_error", "bk_params_default", "bk_engine_create", "bk_engine_destroy",
+           "bk_engine_set_stream", "bk_total_cells", "bk_n_files", "bk_n_slots", "bk_counter_len", "bk_sample_begin",
+           "bk_push_reads_packed", "bk_push_reads_packed_device", "bk_counters_device_ptr", "bk_sample_finalize",
+           "bk_pileup_device_ptr", "bk_sample_download", "bk_sample_finish", "bk_pack_reads", "bk_pack_reads_flat",
+           "bk_timing_enable", "bk_timing_read"]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("bronko_amd: %s is missing -- build it with `make -C bronko_amd/csrc` "
+                           "(or python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32, u32 = C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32
+    L.bk_abi_version.restype = C.c_int
+    L.bk_last_error.restype = C.c_char_p
+    L.bk_params_default.argtypes = [C.POINTER(Params)]
+    L.bk_engine_create.restype = C.c_int
+    L.bk_engine_create.argtypes = [C.POINTER(IndexDesc), C.POINTER(Params), C.POINTER(vp)]
+    L.bk_engine_destroy.argtypes = [vp]
+    L.bk_engine_set_stream.restype = C.c_int
+    L.bk_engine_set_stream.argtypes = [vp, vp]
+    for n, rt in (("bk_total_cells", u64), ("bk_n_files", i32), ("bk_n_slots", u64), ("bk_counter_len", u64)):
+        getattr(L, n).restype = rt
+        getattr(L, n).argtypes = [vp]
+    L.bk_sample_begin.restype = C.c_int
+    L.bk_sample_begin.argtypes = [vp]
+    L.bk_push_reads_packed.restype = C.c_int
+    L.bk_push_reads_packed.argtypes = [vp, C.c_int, vp, u32, vp, u64]
+    L.bk_push_reads_packed_device.restype = C.c_int
+    L.bk_push_reads_packed_device.argtypes = [vp, C.c_int, vp, u32, vp, u64]
+    L.bk_counters_device_ptr.restype = C.c_int
+    L.bk_counters_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.bk_sample_finalize.restype = C.c_int
+    L.bk_sample_finalize.argtypes = [vp, C.c_int]
+    L.bk_pileup_device_ptr.restype = C.c_int
+    L.bk_pileup_device_ptr.argtypes = [vp, C.POINTER(vp)]
+    L.bk_sample_download.restype = C.c_int
+    L.bk_sample_download.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    L.bk_sample_finish.restype = C.c_int
+    L.bk_sample_finish.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    L.bk_pack_reads.restype = u64
+    L.bk_pack_reads.argtypes = [vp, vp, u64, i32, u32, vp, vp, u64]
+    L.bk_pack_reads_flat.restype = u64
+    L.bk_pack_reads_flat.argtypes = [vp, vp, u64, i32, u32, vp, vp, u64]
+    L.bk_timing_enable.restype = C.c_int
+    L.bk_timing_enable.argtypes = [vp, C.c_int]
+    L.bk_timing_read.restype = C.c_int
+    L.bk_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), C.c_int]
+    _lib = L
+    return L

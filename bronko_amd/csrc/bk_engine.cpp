@@ -1,0 +1,481 @@
+// bk_engine.cpp -- host side of the C ABI declared in include/bronko_hip.h.
+//
+// Builds the device-resident window-bucket table from a decoded BronkoIndex, owns the HBM buffers
+// (table, counter planes, pileups) and sequences the kernels of bk_kernels.hip on one HIP stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/bronko_hip.h"
+#include "../host/lcb.hpp"
+#include "bk_device.h"
+#include "bk_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define BK_HIP(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) return fail(BK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        n = count;
+        return hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T>& h) {
+        hipError_t e = alloc(h.size());
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+struct TimedSpan { hipEvent_t a, b; int kind; };
+
+}  // namespace
+
+struct bk_engine {
+    bk_params params{};
+    int k = 0, wstart = 0, W = 0, n_files = 0;
+    uint64_t total_cells = 0, n_slots = 0;
+    uint32_t log2s = 4;
+    int device = 0;
+
+    DevBuf<bk::TableSlot> table;
+    DevBuf<uint64_t> slot_key;
+    DevBuf<uint8_t> slot_t;
+    DevBuf<uint32_t> ent_off, ent_len;
+    DevBuf<bk::DevEntry> entries;
+    DevBuf<unsigned long long> counters[2];
+    DevBuf<unsigned long long> pileup;      // 4 planes
+    DevBuf<unsigned long long> stats;       // [2][n_files][3]
+    DevBuf<unsigned char> present;          // [2][n_files]
+    DevBuf<unsigned long long> kstats;      // [2][4]
+    DevBuf<uint32_t> stage_words;
+    DevBuf<uint16_t> stage_lens;
+
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    bool in_sample = false;
+    uint64_t pushed_records[2] = {0, 0};
+
+    bool timing = false;
+    std::vector<TimedSpan> spans;
+    std::vector<hipEvent_t> free_events;
+
+    bk::IndexView view() const {
+        bk::IndexView v{};
+        v.table = table.p; v.slot_key = slot_key.p; v.slot_t = slot_t.p; v.ent_off = ent_off.p; v.ent_len = ent_len.p;
+        v.entries = entries.p; v.n_slots = n_slots; v.log2s = log2s; v.k = k; v.wstart = wstart; v.W = W; v.n_files = n_files;
+        return v;
+    }
+
+    hipEvent_t get_event() {
+        if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    struct Span {
+        bk_engine* e; int kind; hipEvent_t a = nullptr;
+        Span(bk_engine* eng, int k) : e(eng), kind(k) {
+            if (e->timing) { a = e->get_event(); (void)hipEventRecord(a, e->stream); }
+        }
+        ~Span() {
+            if (a) { hipEvent_t b = e->get_event(); (void)hipEventRecord(b, e->stream); e->spans.push_back({a, b, kind}); }
+        }
+    };
+};
+
+extern "C" {
+
+int bk_abi_version(void) { return BK_ABI_VERSION; }
+const char* bk_last_error(void) { return g_err.c_str(); }
+
+void bk_params_default(bk_params* p) {
+    if (!p) return;
+    p->n_fixed = 2;           // consts.rs:17
+    p->use_full_kmer = 0;     // consts.rs:18
+    p->ci = 3;                // consts.rs:5
+    p->cs = 1000000;          // call.rs:1173
+    p->cx = 1000000000ull;    // KMC default -cx
+    p->device = 0;
+    p->reserved = 0;
+}
+
+int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** out) {
+    if (!ix || !prm || !out) return fail(BK_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const int k = ix->k;
+    if (k < 3 || k > bk::kMaxK || (k & 1) == 0) return fail(BK_ERR_INVALID, "Invalid kmer size %d, must be odd and <= %d", k, bk::kMaxK);
+    if (prm->n_fixed < 0) return fail(BK_ERR_INVALID, "n_fixed must be >= 0");
+    if (ix->n_files <= 0 || ix->n_files > 65536) return fail(BK_ERR_INVALID, "n_files out of range");
+    if (ix->n_buckets && (!ix->bucket_ids || !ix->bucket_off || !ix->entries)) return fail(BK_ERR_INVALID, "null index arrays");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(BK_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (prm->device < 0 || prm->device >= ndev) return fail(BK_ERR_NO_DEVICE, "device %d not present (%d visible)", prm->device, ndev);
+    BK_HIP(hipSetDevice(prm->device));
+
+    std::unique_ptr<bk_engine> e(new bk_engine());
+    e->params = *prm;
+    e->k = k;
+    e->device = prm->device;
+    e->n_files = ix->n_files;
+    // window slice of call.rs:1291-1300
+    if (prm->use_full_kmer) { e->wstart = 0; e->W = k; }
+    else if (prm->n_fixed * 2 + 1 >= k) { e->wstart = 0; e->W = 0; }
+    else { e->wstart = prm->n_fixed; e->W = k - 2 * prm->n_fixed - 1; }
+
+    // cell offsets in (file, seq) order = layout of initialize_output_maps (call.rs:1437-1480)
+    std::vector<std::vector<uint64_t>> cell_off(ix->n_files);
+    std::vector<size_t> seq_base(ix->n_files);
+    uint64_t cells = 0;
+    size_t q = 0;
+    for (int f = 0; f < ix->n_files; f++) {
+        if (ix->n_seqs[f] < 0 || ix->n_seqs[f] > 256) return fail(BK_ERR_INVALID, "file %d: n_seqs out of range (seq_id is u8)", f);
+        seq_base[f] = q;
+        cell_off[f].resize(ix->n_seqs[f]);
+        for (int s = 0; s < ix->n_seqs[f]; s++, q++) { cell_off[f][s] = cells; cells += ix->seq_lens[q]; }
+    }
+    if (cells >= (1ull << 32)) return fail(BK_ERR_UNSUPPORTED, "more than 2^32 reference positions");
+    e->total_cells = cells;
+
+    // ---- window buckets -> device slots ------------------------------------------------------------------
+    // Device key of a bucket = (wildcard position j, canonical reference k-mer with position j zeroed).  It is
+    // recomputed from the metadata sequence at (file, seq, location) and checked against the stored bucket id
+    // with assign_buckets, so an index that disagrees with its own metadata is rejected instead of miscounted.
+    std::vector<uint64_t> h_slot_key;
+    std::vector<uint8_t> h_slot_t;
+    std::vector<uint32_t> h_off, h_len;
+    std::vector<bk::DevEntry> h_ent;
+    std::vector<uint64_t> per_t(e->W > 0 ? e->W : 1, 0);
+    uint64_t ids[32];
+    for (uint64_t b = 0; b < ix->n_buckets && e->W > 0; b++) {
+        const uint64_t lo = ix->bucket_off[b], hi = ix->bucket_off[b + 1];
+        if (hi <= lo) continue;
+        if (hi > ix->n_entries) return fail(BK_ERR_INVALID, "bucket_off out of range");
+        // distinct (j, masked) keys present in this bucket: exactly one unless k = 31 ids wrapped onto each other
+        std::vector<std::pair<int, uint64_t>> keys;
+        bool any_in_window = false;
+        for (uint64_t i = lo; i < hi; i++) {
+            const bk_bucket_info& bi = ix->entries[i];
+            if (bi.file_id >= ix->n_files || bi.seq_id >= ix->n_seqs[bi.file_id]) return fail(BK_ERR_INVALID, "entry %llu references a missing sequence", (unsigned long long)i);
+            const size_t sq = seq_base[bi.file_id] + bi.seq_id;
+            if ((uint64_t)bi.location + k > ix->seq_lens[sq] || bi.idx >= k) return fail(BK_ERR_INVALID, "entry %llu lies outside its sequence", (unsigned long long)i);
+            const bronko::Canon cn = bronko::canonical_kmer(ix->seqs[sq] + bi.location, k);
+            if (cn.rc != (bi.canonical != 0)) return fail(BK_ERR_INVALID, "entry %llu: canonical flag disagrees with the metadata sequence", (unsigned long long)i);
+            const int j = bi.idx;
+            const uint64_t masked = cn.kmer & ~(3ull << (2 * (k - 1 - j)));
+            if (std::find(keys.begin(), keys.end(), std::make_pair(j, masked)) == keys.end()) {
+                bronko::assign_buckets(cn.kmer, k, ids);
+                if (ids[j] != ix->bucket_ids[b]) return fail(BK_ERR_INVALID, "bucket %llu: id does not match assign_buckets of its entries", (unsigned long long)ix->bucket_ids[b]);
+                keys.emplace_back(j, masked);
+            }
+            if (j >= e->wstart && j < e->wstart + e->W) any_in_window = true;
+        }
+        if (!any_in_window) continue;
+        // every entry of the bucket is voted for by a probe of any of its keys (call.rs:1307-1309 iterates the
+        // whole Vec<BucketInfo>), using each entry's own idx (call.rs:1329)
+        const uint32_t off = (uint32_t)h_ent.size();
+        for (uint64_t i = lo; i < hi; i++) {
+            const bk_bucket_info& bi = ix->entries[i];
+            bk::DevEntry de;
+            de.cell = (uint32_t)(cell_off[bi.file_id][bi.seq_id] + bi.location + bi.idx);
+            de.file = bi.file_id; de.idx = bi.idx; de.canonical = bi.canonical ? 1 : 0;
+            h_ent.push_back(de);
+        }
+        for (auto& kv : keys) {
+            if (kv.first < e->wstart || kv.first >= e->wstart + e->W) continue;
+            h_slot_key.push_back(kv.second);
+            h_slot_t.push_back((uint8_t)(kv.first - e->wstart));
+            h_off.push_back(off);
+            h_len.push_back((uint32_t)(hi - lo));
+            per_t[kv.first - e->wstart]++;
+        }
+        if (h_ent.size() >= (1ull << 32)) return fail(BK_ERR_UNSUPPORTED, "more than 2^32 index entries in the window");
+    }
+    e->n_slots = h_slot_key.size();
+    if (e->n_slots >= (1ull << 31)) return fail(BK_ERR_UNSUPPORTED, "too many window buckets");
+
+    uint64_t max_t = 1;
+    for (uint64_t c : per_t) max_t = std::max(max_t, c);
+    e->log2s = 4;
+    while ((1ull << e->log2s) < 2 * max_t) e->log2s++;   // load factor <= 0.5
+    const size_t S = (size_t)1 << e->log2s;
+    std::vector<bk::TableSlot> h_table((size_t)std::max(e->W, 1) * S, bk::TableSlot{bk::kEmptyKey, 0u, 0u});
+    for (uint64_t s = 0; s < e->n_slots; s++) {
+        bk::TableSlot* sub = h_table.data() + (size_t)h_slot_t[s] * S;
+        uint32_t h = bk::hash_key(h_slot_key[s], e->log2s);
+        while (sub[h].key != bk::kEmptyKey) {
+            if (sub[h].key == h_slot_key[s]) return fail(BK_ERR_INVALID, "duplicate window bucket in the index");
+            h = (h + 1) & (uint32_t)(S - 1);
+        }
+        sub[h].key = h_slot_key[s];
+        sub[h].slot = (uint32_t)s;
+    }
+
+    if (bk::finalize_lds_bytes(e->n_files) > 160 * 1024) return fail(BK_ERR_UNSUPPORTED, "more than ~20000 genome files are not supported by the finalize kernel");
+
+    BK_HIP(e->table.upload(h_table));
+    BK_HIP(e->slot_key.upload(h_slot_key));
+    BK_HIP(e->slot_t.upload(h_slot_t));
+    BK_HIP(e->ent_off.upload(h_off));
+    BK_HIP(e->ent_len.upload(h_len));
+    BK_HIP(e->entries.upload(h_ent));
+    for (int m = 0; m < 2; m++) BK_HIP(e->counters[m].alloc(e->n_slots * bk::kCountersPerSlot));
+    BK_HIP(e->pileup.alloc(e->total_cells * 4 * 4));
+    BK_HIP(e->stats.alloc((size_t)2 * e->n_files * 3));
+    BK_HIP(e->present.alloc((size_t)2 * e->n_files));
+    BK_HIP(e->kstats.alloc(8));
+    BK_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    e->stream = e->own_stream;
+    *out = e.release();
+    return BK_OK;
+}
+
+void bk_engine_destroy(bk_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    for (auto& s : e->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto ev : e->free_events) (void)hipEventDestroy(ev);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+int bk_engine_set_stream(bk_engine* e, void* hip_stream) {
+    if (!e) return fail(BK_ERR_INVALID, "null engine");
+    BK_HIP(hipStreamSynchronize(e->stream));
+    e->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : e->own_stream;
+    return BK_OK;
+}
+
+uint64_t bk_total_cells(const bk_engine* e) { return e ? e->total_cells : 0; }
+int32_t bk_n_files(const bk_engine* e) { return e ? e->n_files : 0; }
+uint64_t bk_n_slots(const bk_engine* e) { return e ? e->n_slots : 0; }
+uint64_t bk_counter_len(const bk_engine* e) { return e ? e->n_slots * bk::kCountersPerSlot : 0; }
+
+int bk_sample_begin(bk_engine* e) {
+    if (!e) return fail(BK_ERR_INVALID, "null engine");
+    BK_HIP(hipSetDevice(e->device));
+    bk_engine::Span sp(e, 2);
+    for (int m = 0; m < 2; m++)
+        BK_HIP(hipMemsetAsync(e->counters[m].p, 0, std::max<size_t>(e->counters[m].n, 1) * sizeof(unsigned long long), e->stream));
+    BK_HIP(hipMemsetAsync(e->pileup.p, 0, std::max<size_t>(e->pileup.n, 1) * sizeof(unsigned long long), e->stream));
+    BK_HIP(hipMemsetAsync(e->stats.p, 0, e->stats.n * sizeof(unsigned long long), e->stream));
+    BK_HIP(hipMemsetAsync(e->present.p, 0, e->present.n, e->stream));
+    BK_HIP(hipMemsetAsync(e->kstats.p, 0, e->kstats.n * sizeof(unsigned long long), e->stream));
+    e->pushed_records[0] = e->pushed_records[1] = 0;
+    e->in_sample = true;
+    return BK_OK;
+}
+
+static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t stride_words, const uint16_t* d_lens, uint64_t n) {
+    bk::ScanArgs a{};
+    a.ix = e->view();
+    a.words = d_words; a.lens = d_lens; a.n_records = n; a.stride_words = stride_words;
+    a.counters = e->counters[mate].p;
+    a.kmer_total = e->kstats.p + mate * 4 + 1;
+    {
+        bk_engine::Span sp(e, 0);
+        bk::launch_scan_count(a, e->stream);
+    }
+    BK_HIP(hipGetLastError());
+    e->pushed_records[mate] += n;
+    return BK_OK;
+}
+
+int bk_push_reads_packed_device(bk_engine* e, int mate, const void* d_words, uint32_t stride_words, const void* d_lens, uint64_t n) {
+    if (!e) return fail(BK_ERR_INVALID, "null engine");
+    if (!e->in_sample) return fail(BK_ERR_STATE, "bk_push_reads_* called before bk_sample_begin");
+    if (mate < 0 || mate > 1) return fail(BK_ERR_INVALID, "mate must be 0 or 1");
+    if (n == 0) return BK_OK;
+    if (!d_words || !d_lens || stride_words == 0 || stride_words > 4096) return fail(BK_ERR_INVALID, "bad record batch");
+    BK_HIP(hipSetDevice(e->device));
+    return push_device(e, mate, static_cast<const uint32_t*>(d_words), stride_words, static_cast<const uint16_t*>(d_lens), n);
+}
+
+int bk_push_reads_packed(bk_engine* e, int mate, const uint32_t* words, uint32_t stride_words, const uint16_t* lens, uint64_t n) {
+    if (!e) return fail(BK_ERR_INVALID, "null engine");
+    if (!e->in_sample) return fail(BK_ERR_STATE, "bk_push_reads_* called before bk_sample_begin");
+    if (mate < 0 || mate > 1) return fail(BK_ERR_INVALID, "mate must be 0 or 1");
+    if (n == 0) return BK_OK;
+    if (!words || !lens || stride_words == 0 || stride_words > 4096) return fail(BK_ERR_INVALID, "bad record batch");
+    BK_HIP(hipSetDevice(e->device));
+    const size_t nw = (size_t)n * stride_words;
+    if (e->stage_words.n < nw) { BK_HIP(hipStreamSynchronize(e->stream)); BK_HIP(e->stage_words.alloc(nw + nw / 4)); }
+    if (e->stage_lens.n < n) { BK_HIP(hipStreamSynchronize(e->stream)); BK_HIP(e->stage_lens.alloc(n + n / 4)); }
+    BK_HIP(hipStreamSynchronize(e->stream));   // staging buffers are reused: wait for the scan that reads them
+    {
+        bk_engine::Span sp(e, 2);
+        BK_HIP(hipMemcpyAsync(e->stage_words.p, words, nw * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        BK_HIP(hipMemcpyAsync(e->stage_lens.p, lens, n * sizeof(uint16_t), hipMemcpyHostToDevice, e->stream));
+    }
+    int rc = push_device(e, mate, e->stage_words.p, stride_words, e->stage_lens.p, n);
+    if (rc != BK_OK) return rc;
+    BK_HIP(hipStreamSynchronize(e->stream));   // host buffer (and staging) free on return
+    return BK_OK;
+}
+
+int bk_counters_device_ptr(bk_engine* e, int mate, void** d_ptr) {
+    if (!e || !d_ptr || mate < 0 || mate > 1) return fail(BK_ERR_INVALID, "bad argument");
+    *d_ptr = e->counters[mate].p;
+    return BK_OK;
+}
+
+int bk_pileup_device_ptr(bk_engine* e, void** d_ptr) {
+    if (!e || !d_ptr) return fail(BK_ERR_INVALID, "bad argument");
+    *d_ptr = e->pileup.p;
+    return BK_OK;
+}
+
+int bk_sample_finalize(bk_engine* e, int n_mates) {
+    if (!e) return fail(BK_ERR_INVALID, "null engine");
+    if (!e->in_sample) return fail(BK_ERR_STATE, "bk_sample_finalize called before bk_sample_begin");
+    if (n_mates < 1 || n_mates > 2) return fail(BK_ERR_INVALID, "n_mates must be 1 or 2");
+    BK_HIP(hipSetDevice(e->device));
+    for (int m = 0; m < n_mates; m++) {   // R1 then R2 into the same arrays (call.rs:316-317)
+        bk::FinalizeArgs a{};
+        a.ix = e->view();
+        a.counters = e->counters[m].p;
+        a.ci = e->params.ci; a.cs = e->params.cs; a.cx = e->params.cx;
+        a.pileup = e->pileup.p;
+        a.plane = (size_t)e->total_cells * 4;
+        a.stats = e->stats.p + (size_t)m * e->n_files * 3;
+        a.present = e->present.p + (size_t)m * e->n_files;
+        a.kept_total = e->kstats.p + m * 4 + 3;
+        bk_engine::Span sp(e, 1);
+        bk::launch_finalize(a, e->stream);
+    }
+    BK_HIP(hipGetLastError());
+    e->in_sample = false;
+    return BK_OK;
+}
+
+int bk_sample_download(bk_engine* e, int n_mates, uint64_t* fwd_depth, uint64_t* rev_depth, uint64_t* fwd_nk, uint64_t* rev_nk,
+                       uint64_t* stats, uint8_t* present, uint64_t* kmer_stats) {
+    if (!e) return fail(BK_ERR_INVALID, "null engine");
+    if (n_mates < 1 || n_mates > 2) return fail(BK_ERR_INVALID, "n_mates must be 1 or 2");
+    BK_HIP(hipSetDevice(e->device));
+    const size_t plane = (size_t)e->total_cells * 4;
+    uint64_t* dst[4] = {fwd_depth, rev_depth, fwd_nk, rev_nk};
+    {
+        bk_engine::Span sp(e, 2);
+        for (int i = 0; i < 4; i++)
+            if (dst[i] && plane) BK_HIP(hipMemcpyAsync(dst[i], e->pileup.p + (size_t)i * plane, plane * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+        if (stats) BK_HIP(hipMemcpyAsync(stats, e->stats.p, (size_t)n_mates * e->n_files * 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+        if (present) BK_HIP(hipMemcpyAsync(present, e->present.p, (size_t)n_mates * e->n_files, hipMemcpyDeviceToHost, e->stream));
+        if (kmer_stats) BK_HIP(hipMemcpyAsync(kmer_stats, e->kstats.p, (size_t)n_mates * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+    }
+    BK_HIP(hipStreamSynchronize(e->stream));
+    if (kmer_stats) for (int m = 0; m < n_mates; m++) kmer_stats[m * 4 + 0] = e->pushed_records[m];
+    return BK_OK;
+}
+
+int bk_sample_finish(bk_engine* e, int n_mates, uint64_t* fwd_depth, uint64_t* rev_depth, uint64_t* fwd_nk, uint64_t* rev_nk,
+                     uint64_t* stats, uint8_t* present, uint64_t* kmer_stats) {
+    int rc = bk_sample_finalize(e, n_mates);
+    if (rc != BK_OK) return rc;
+    return bk_sample_download(e, n_mates, fwd_depth, rev_depth, fwd_nk, rev_nk, stats, present, kmer_stats);
+}
+
+// ---- K0 host packer ------------------------------------------------------------------------------------------
+namespace {
+struct Packer {
+    int k; uint32_t stride; uint32_t* words; uint16_t* lens; uint64_t cap; uint64_t n = 0;
+    void emit(const uint8_t* s, uint64_t len) {   // one record of <= 16*stride ACGT symbols
+        if (n < cap) {
+            uint32_t* w = words + n * stride;
+            std::memset(w, 0, (size_t)stride * 4);
+            for (uint64_t i = 0; i < len; i++) w[i >> 4] |= (uint32_t)bronko::acgt_code(s[i]) << (2 * (i & 15));
+            lens[n] = (uint16_t)len;
+        }
+        n++;
+    }
+    void run(const uint8_t* s, uint64_t len) {    // one maximal ACGT run
+        if (len < (uint64_t)k) return;
+        const uint64_t maxb = std::min<uint64_t>((uint64_t)stride * 16, 65535);
+        uint64_t pos = 0;
+        for (;;) {
+            const uint64_t take = std::min(maxb, len - pos);
+            emit(s + pos, take);
+            if (pos + take >= len) break;
+            pos += take - (uint64_t)(k - 1);      // next chunk re-reads k-1 bases: no k-mer lost or doubled
+        }
+    }
+    void read(const uint8_t* s, uint64_t len) {
+        uint64_t start = 0;
+        for (uint64_t i = 0; i <= len; i++) {
+            if (i == len || bronko::acgt_code(s[i]) < 0) { run(s + start, i - start); start = i + 1; }
+        }
+    }
+};
+}  // namespace
+
+uint64_t bk_pack_reads(const uint8_t* const* reads, const uint64_t* read_lens, uint64_t n_reads, int32_t k, uint32_t stride_words,
+                       uint32_t* out_words, uint16_t* out_lens, uint64_t cap_records) {
+    if (k < 1 || stride_words == 0 || (uint64_t)stride_words * 16 < (uint64_t)k) return 0;
+    Packer p{k, stride_words, out_words, out_lens, (out_words && out_lens) ? cap_records : 0};
+    for (uint64_t r = 0; r < n_reads; r++) p.read(reads[r], read_lens[r]);
+    return p.n;
+}
+
+uint64_t bk_pack_reads_flat(const uint8_t* buf, const uint64_t* offsets, uint64_t n_reads, int32_t k, uint32_t stride_words,
+                            uint32_t* out_words, uint16_t* out_lens, uint64_t cap_records) {
+    if (k < 1 || stride_words == 0 || (uint64_t)stride_words * 16 < (uint64_t)k) return 0;
+    Packer p{k, stride_words, out_words, out_lens, (out_words && out_lens) ? cap_records : 0};
+    for (uint64_t r = 0; r < n_reads; r++) p.read(buf + offsets[r], offsets[r + 1] - offsets[r]);
+    return p.n;
+}
+
+// ---- measurement ---------------------------------------------------------------------------------------------
+int bk_timing_enable(bk_engine* e, int on) {
+    if (!e) return fail(BK_ERR_INVALID, "null engine");
+    e->timing = on != 0;
+    return BK_OK;
+}
+
+int bk_timing_read(bk_engine* e, double ms[3], uint64_t n[3], int reset) {
+    if (!e || !ms || !n) return fail(BK_ERR_INVALID, "bad argument");
+    BK_HIP(hipSetDevice(e->device));
+    BK_HIP(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < 3; i++) { ms[i] = 0.0; n[i] = 0; }
+    for (auto& s : e->spans) {
+        float t = 0.f;
+        BK_HIP(hipEventElapsedTime(&t, s.a, s.b));
+        ms[s.kind] += t;
+        n[s.kind] += 1;
+    }
+    if (reset) {
+        for (auto& s : e->spans) { e->free_events.push_back(s.a); e->free_events.push_back(s.b); }
+        e->spans.clear();
+    }
+    return BK_OK;
+}
+
+}  // extern "C"

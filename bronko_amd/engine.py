@@ -1,0 +1,170 @@
+"""Python mirror of the C ABI (include/bronko_hip.h): same call order, same argument meaning, same errors.
+
+    eng = Engine(k, bucket_ids, bucket_off, entries, files, Params(...))   # = bk_engine_create
+    eng.sample_begin()                                                      # = initialize_output_maps
+    eng.push_reads(mate, words, lens)                                       # = reads of one mate file
+    res = eng.sample_finish(n_mates)                                        # = KMC thresholds + map_kmers
+
+A non-zero status raises BronkoError with bk_last_error(); the reference's convention for the same
+conditions is `error!(..); exit(1)`.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+
+BUCKET_INFO_DTYPE = np.dtype({"names": ["file_id", "seq_id", "location", "idx", "canonical"],
+                              "formats": [np.uint16, np.uint8, np.uint32, np.uint8, np.uint8],
+                              "offsets": [0, 2, 4, 8, 9], "itemsize": 12})
+
+
+class BronkoError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("bronko_hip status %d: %s" % (status, msg))
+        self.status = status
+
+
+def lib_path():
+    return _ffi.LIB_PATH
+
+
+def _check(rc):
+    if rc != 0:
+        raise BronkoError(rc, _ffi.load().bk_last_error().decode(errors="replace"))
+
+
+def Params(n_fixed=2, use_full_kmer=False, ci=3, cs=1000000, cx=1000000000, device=0):
+    p = _ffi.Params()
+    _ffi.load().bk_params_default(C.byref(p))
+    p.n_fixed, p.use_full_kmer, p.ci, p.cs, p.cx, p.device = n_fixed, int(use_full_kmer), ci, cs, cx, device
+    return p
+
+
+def pack_reads(reads, k, stride_words=None):
+    """K0 (bk_pack_reads): list of ASCII reads -> (words u32[n][stride], lens u16[n]) fixed-stride 2-bit records."""
+    L = _ffi.load()
+    reads = [bytes(r) for r in reads]
+    if stride_words is None:
+        longest = max([len(r) for r in reads] + [k])
+        stride_words = min((longest + 15) // 16, 4095)
+    flat = np.frombuffer(b"".join(reads), np.uint8) if reads else np.zeros(0, np.uint8)
+    flat = np.ascontiguousarray(flat) if len(flat) else np.zeros(1, np.uint8)
+    off = np.zeros(len(reads) + 1, np.uint64)
+    if reads:
+        off[1:] = np.cumsum([len(r) for r in reads])
+    n = L.bk_pack_reads_flat(flat.ctypes.data, off.ctypes.data, len(reads), k, stride_words, None, None, 0)
+    words = np.zeros((max(n, 1), stride_words), np.uint32)
+    lens = np.zeros(max(n, 1), np.uint16)
+    L.bk_pack_reads_flat(flat.ctypes.data, off.ctypes.data, len(reads), k, stride_words, words.ctypes.data,
+                         lens.ctypes.data, n)
+    return words[:n], lens[:n]
+
+
+class SampleResult:
+    """Outputs of one sample: the four OutputData arrays (call.rs:1235-1239,1451-1454) + map_kmers' stats."""
+
+    def __init__(self, n_mates, n_files, total_cells):
+        n = total_cells * 4
+        self.fwd_depth = np.zeros(n, np.uint64)
+        self.rev_depth = np.zeros(n, np.uint64)
+        self.fwd_nk = np.zeros(n, np.uint64)
+        self.rev_nk = np.zeros(n, np.uint64)
+        self.stats = np.zeros((n_mates, n_files, 3), np.uint64)
+        self.present = np.zeros((n_mates, n_files), np.uint8)
+        self.kmer_stats = np.zeros((n_mates, 4), np.uint64)
+
+    def arrays(self):
+        return self.fwd_depth, self.rev_depth, self.fwd_nk, self.rev_nk
+
+
+class Engine:
+    def __init__(self, k, bucket_ids, bucket_off, entries, files, params=None):
+        """files: [(file_name, [(seq_name, seq_bytes), ...]), ...] = ViralMetadata (build.rs:46-50)"""
+        L = _ffi.load()
+        self._L = L
+        self.h = None
+        params = params or Params()
+        ids = np.ascontiguousarray(bucket_ids, np.uint64)
+        off = np.ascontiguousarray(bucket_off, np.uint64)
+        ent = np.ascontiguousarray(entries)
+        if ent.dtype != BUCKET_INFO_DTYPE:
+            raise TypeError("entries must have the 12-byte BucketInfo dtype")
+        n_seqs = np.array([len(f[1]) for f in files] + [0], np.int32)
+        seqs = [bytes(s[1]) for f in files for s in f[1]]
+        seq_lens = np.array([len(s) for s in seqs] + [0], np.uint64)
+        bufs = [C.create_string_buffer(s, max(len(s), 1)) for s in seqs]
+        ptrs = (C.c_void_p * max(len(bufs), 1))(*[C.addressof(b) for b in bufs])
+        d = _ffi.IndexDesc(k, len(ids), ids.ctypes.data, off.ctypes.data, ent.ctypes.data, len(ent), len(files),
+                           n_seqs.ctypes.data, seq_lens.ctypes.data, C.addressof(ptrs))
+        h = C.c_void_p()
+        _check(L.bk_engine_create(C.byref(d), C.byref(params), C.byref(h)))
+        self.h = h
+        self.k = k
+        self.params = params
+        self.n_files = L.bk_n_files(h)
+        self.total_cells = L.bk_total_cells(h)
+        self.n_slots = L.bk_n_slots(h)
+        self.counter_len = L.bk_counter_len(h)
+
+    def close(self):
+        if self.h:
+            self._L.bk_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        _check(self._L.bk_engine_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def sample_begin(self):
+        _check(self._L.bk_sample_begin(self.h))
+
+    def push_reads(self, mate, words, lens):
+        words = np.ascontiguousarray(words, np.uint32)
+        lens = np.ascontiguousarray(lens, np.uint16)
+        if len(lens) == 0:
+            return
+        assert words.ndim == 2 and words.shape[0] == len(lens)
+        _check(self._L.bk_push_reads_packed(self.h, mate, words.ctypes.data, words.shape[1], lens.ctypes.data, len(lens)))
+
+    def push_reads_device(self, mate, d_words_ptr, stride_words, d_lens_ptr, n_records):
+        _check(self._L.bk_push_reads_packed_device(self.h, mate, C.c_void_p(d_words_ptr), stride_words,
+                                                   C.c_void_p(d_lens_ptr), n_records))
+
+    def counters_ptr(self, mate):
+        p = C.c_void_p()
+        _check(self._L.bk_counters_device_ptr(self.h, mate, C.byref(p)))
+        return p.value
+
+    def pileup_ptr(self):
+        p = C.c_void_p()
+        _check(self._L.bk_pileup_device_ptr(self.h, C.byref(p)))
+        return p.value
+
+    def sample_finalize(self, n_mates=1):
+        _check(self._L.bk_sample_finalize(self.h, n_mates))
+
+    def sample_download(self, n_mates=1, arrays=True):
+        r = SampleResult(n_mates, self.n_files, self.total_cells)
+        a = [x.ctypes.data if arrays else None for x in (r.fwd_depth, r.rev_depth, r.fwd_nk, r.rev_nk)]
+        _check(self._L.bk_sample_download(self.h, n_mates, a[0], a[1], a[2], a[3], r.stats.ctypes.data,
+                                          r.present.ctypes.data, r.kmer_stats.ctypes.data))
+        return r
+
+    def sample_finish(self, n_mates=1):
+        self.sample_finalize(n_mates)
+        return self.sample_download(n_mates)
+
+    def timing_enable(self, on=True):
+        _check(self._L.bk_timing_enable(self.h, int(on)))
+
+    def timing_read(self, reset=True):
+        ms = (C.c_double * 3)()
+        n = (C.c_uint64 * 3)()
+        _check(self._L.bk_timing_read(self.h, ms, n, int(reset)))
+        return list(ms), list(n)

@@ -1,0 +1,55 @@
+// fastx.hpp -- line reader over plain or gzip files (zlib) for FASTA / FASTQ input (host side).
+#pragma once
+#include <zlib.h>
+
+#include <stdexcept>
+#include <string>
+
+namespace bronko {
+
+class GzLineReader {
+public:
+    explicit GzLineReader(const std::string& path) : path_(path) {
+        g_ = gzopen(path.c_str(), "rb");
+        if (!g_) throw std::runtime_error("cannot open " + path);
+        gzbuffer(g_, 1 << 20);
+    }
+    ~GzLineReader() { if (g_) gzclose(g_); }
+    GzLineReader(const GzLineReader&) = delete;
+    GzLineReader& operator=(const GzLineReader&) = delete;
+
+    // Next line without its terminator ("\n" or "\r\n"); false at end of file.
+    bool next(std::string& line) {
+        line.clear();
+        bool any = false;
+        for (;;) {
+            if (pos_ == len_) {
+                const int n = gzread(g_, buf_, sizeof buf_);
+                if (n < 0) throw std::runtime_error("read error in " + path_);
+                if (n == 0) break;
+                pos_ = 0; len_ = (size_t)n;
+            }
+            any = true;
+            const char* p = buf_ + pos_;
+            const char* nl = (const char*)memchr(p, '\n', len_ - pos_);
+            if (nl) {
+                line.append(p, nl - p);
+                pos_ += (size_t)(nl - p) + 1;
+                break;
+            }
+            line.append(p, len_ - pos_);
+            pos_ = len_;
+        }
+        if (!any) return false;
+        while (!line.empty() && line.back() == '\r') line.pop_back();
+        return true;
+    }
+
+private:
+    std::string path_;
+    gzFile g_ = nullptr;
+    char buf_[1 << 16];
+    size_t pos_ = 0, len_ = 0;
+};
+
+}  // namespace bronko

@@ -1,0 +1,166 @@
+/*
+ * bronko_hip.h -- C ABI of the MI355X (gfx950) k-mer -> pileup engine.
+ *
+ * This is the seam a host program binds (Rust `extern "C"` block, C++, ctypes ...).  It replaces, inside
+ * bronko's `call()` per-sample loop, the stages
+ *
+ *     get_kmers        /root/reference/src/call.rs:630-646   (external KMC3: count_kmers_kmc :1152-1233,
+ *                                                             load_kmers :1241-1255)
+ *     initialize_output_maps                  call.rs:1437-1480
+ *     map_kmers                               call.rs:1257-1434
+ *
+ * i.e. everything between "a FASTQ record was parsed" and "four pileup arrays + per-genome
+ * (perfect, variant, unique) statistics exist" (call sites: call.rs:217-226 single-end, :301-317 paired).
+ * The reference has no FFI of its own for this path; INTEGRATION.md shows the Rust binding a maintainer
+ * would add.  Plain pointers and sizes only; every function returns 0 on success and a negative bk_status on
+ * failure (message via bk_last_error(), thread-local).  The library never calls exit(); the host maps a
+ * non-zero status to the reference's `error!(..); std::process::exit(1)` convention.  An engine is
+ * thread-compatible (one engine per host thread / per GPU); there is no global state.
+ *
+ * There is NO CPU fallback: if no gfx950 device is visible every entry point that needs one fails with
+ * BK_ERR_NO_DEVICE.
+ */
+#ifndef BRONKO_HIP_H
+#define BRONKO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BK_ABI_VERSION 1
+
+typedef enum {
+    BK_OK = 0,
+    BK_ERR_INVALID = -1,   /* bad argument / inconsistent index            */
+    BK_ERR_NO_DEVICE = -2, /* no HIP device / not gfx950                   */
+    BK_ERR_HIP = -3,       /* a HIP runtime call failed                    */
+    BK_ERR_UNSUPPORTED = -4,
+    BK_ERR_STATE = -5      /* call order violated (e.g. push before begin) */
+} bk_status;
+
+/* build.rs:52-60  `#[repr(C)] struct BucketInfo` -- same field order, same layout (12 bytes) */
+typedef struct {
+    uint16_t file_id;   /* index of the genome file in ViralMetadata.files             */
+    uint8_t  seq_id;    /* index of the sequence inside that file                      */
+    uint32_t location;  /* 0-based start of the reference k-mer in the forward sequence */
+    uint8_t  idx;       /* wildcard position inside the canonical k-mer                */
+    uint8_t  canonical; /* 1 = the reference k-mer was reverse-complemented            */
+} bk_bucket_info;
+
+/* A decoded BronkoIndex (build.rs:23-50), flattened.  All pointers are host memory, borrowed for the
+ * duration of bk_engine_create() only.
+ *   global_index: FxHashMap<u64, Vec<BucketInfo>>  ->  bucket_ids[n_buckets] (any order, unique),
+ *                 bucket_off[n_buckets + 1] into entries[n_entries]
+ *   metadata    : files -> n_seqs[n_files]; sequences of all files concatenated in (file, seq) order:
+ *                 seq_lens[total], seqs[total] (raw FASTA bytes as stored in SeqMeta.seq)               */
+typedef struct {
+    int32_t  k;
+    uint64_t n_buckets;
+    const uint64_t* bucket_ids;
+    const uint64_t* bucket_off;
+    const bk_bucket_info* entries;
+    uint64_t n_entries;
+    int32_t  n_files;
+    const int32_t*  n_seqs;
+    const uint64_t* seq_lens;
+    const uint8_t* const* seqs;
+} bk_index_desc;
+
+/* Parameters that reach the hot path from CallArgs (cli.rs:61-166) and the KMC command line (call.rs:1166-1177) */
+typedef struct {
+    int32_t  n_fixed;        /* --n-fixed        (consts.rs:17, default 2)                                  */
+    int32_t  use_full_kmer;  /* --use-full-kmer  (consts.rs:18, default 0)                                  */
+    uint64_t ci;             /* --min-kmers -> kmc -ci (consts.rs:5, default 3): keep count >= ci           */
+    uint64_t cs;             /* kmc -cs1000000 (call.rs:1173): reported count saturates at cs               */
+    uint64_t cx;             /* kmc -cx default 1e9: drop k-mers whose true count exceeds cx                */
+    int32_t  device;         /* HIP device ordinal                                                          */
+    int32_t  reserved;
+} bk_params;
+
+typedef struct bk_engine bk_engine;
+
+int         bk_abi_version(void);
+const char* bk_last_error(void);
+void        bk_params_default(bk_params* p);
+
+/* Uploads the index as a device-resident bucket table (see DESIGN.md "HBM layout") and allocates the
+ * counter planes (one per mate file) and the four pileup arrays. */
+int  bk_engine_create(const bk_index_desc* index, const bk_params* params, bk_engine** out);
+void bk_engine_destroy(bk_engine* e);
+
+/* Launch all work of this engine on an existing HIP stream (hipStream_t passed as void*); NULL restores the
+ * engine's own stream.  Lets a host that already owns a stream (e.g. PyTorch's current stream) order and
+ * time the engine's kernels. */
+int bk_engine_set_stream(bk_engine* e, void* hip_stream);
+
+/* Geometry of the outputs */
+uint64_t bk_total_cells(const bk_engine* e);     /* sum of all sequence lengths = rows of each pileup array */
+int32_t  bk_n_files(const bk_engine* e);
+uint64_t bk_n_slots(const bk_engine* e);         /* distinct window buckets on the device                   */
+uint64_t bk_counter_len(const bk_engine* e);     /* u64 elements in one counter plane (= 8 * n_slots)       */
+
+/* ---- per-sample protocol (mirrors one iteration of call.rs:213-293 / :298-386) ---------------------------
+ * bk_sample_begin      = initialize_output_maps (call.rs:224,314): zero pileups, stats and counter planes.
+ * bk_push_reads_*      = the reads of mate file `mate` (0 = -r file or R1, 1 = R2); callable repeatedly.
+ * bk_sample_finish     = KMC thresholds (ci/cs/cx, per mate file) + map_kmers for mate 0 then mate 1 into the
+ *                        shared arrays (call.rs:316-317), then copy-out.
+ *
+ * Read batches are 2-bit packed fixed-stride records (produced by bk_pack_reads or by the host itself):
+ *   record r = words[r*stride_words .. +stride_words), base i in word i/16 at bits [2*(i%16), 2*(i%16)+2),
+ *   A=0 C=1 G=2 T=3; lens[r] = number of valid bases (<= 16*stride_words).  A record holds one maximal
+ *   ACGT run (KMC splits reads at any other symbol) or an overlapping chunk of one.
+ * The host buffer may be reused as soon as the call returns. */
+int bk_sample_begin(bk_engine* e);
+int bk_push_reads_packed(bk_engine* e, int mate, const uint32_t* words, uint32_t stride_words,
+                         const uint16_t* lens, uint64_t n_records);
+/* Same, for a batch that is already resident in device memory (no copy; asynchronous on the engine stream). */
+int bk_push_reads_packed_device(bk_engine* e, int mate, const void* d_words, uint32_t stride_words,
+                                const void* d_lens, uint64_t n_records);
+
+/* Multi-GPU hook: the only additive quantity is the per-k-mer occurrence counter plane.
+ * A host that shards one sample's reads over several GPUs all-reduces (sum, u64) each plane in place between
+ * the last push and bk_sample_finish.  The pointer is device memory of bk_counter_len() u64. */
+int bk_counters_device_ptr(bk_engine* e, int mate, void** d_ptr);
+
+/* Runs the threshold + map_kmers kernels for mates [0, n_mates) on the device (asynchronous). */
+int bk_sample_finalize(bk_engine* e, int n_mates);
+/* Device pointers of the finalized arrays: 4 planes (fwd depth, rev depth, fwd #kmers, rev #kmers) of
+ * total_cells*4 u64 each, contiguous, in (file, seq, pos, base) order. */
+int bk_pileup_device_ptr(bk_engine* e, void** d_ptr);
+/* Synchronises and copies results to host memory.  Any pointer may be NULL (skipped).
+ *   fwd_depth/rev_depth/fwd_nk/rev_nk : total_cells*4 u64 each    (OutputData.counts, call.rs:1235-1239)
+ *   stats   : n_mates * n_files * 3 u64  (perfect, variant, unique) per mate file (call.rs:1272)
+ *   present : n_mates * n_files bytes, 1 iff the file has a key in map_kmers' returned map
+ *   kmer_stats : n_mates * 4 u64 = records pushed, k-mer occurrences scanned, 0, distinct table-hitting
+ *                k-mers kept (KMC's "unique counted k-mers" restricted to k-mers that touch the table)   */
+int bk_sample_download(bk_engine* e, int n_mates, uint64_t* fwd_depth, uint64_t* rev_depth, uint64_t* fwd_nk,
+                       uint64_t* rev_nk, uint64_t* stats, uint8_t* present, uint64_t* kmer_stats);
+/* bk_sample_finalize + bk_sample_download */
+int bk_sample_finish(bk_engine* e, int n_mates, uint64_t* fwd_depth, uint64_t* rev_depth, uint64_t* fwd_nk,
+                     uint64_t* rev_nk, uint64_t* stats, uint8_t* present, uint64_t* kmer_stats);
+
+/* ---- K0: host-side read packer (the step KMC's FASTQ reader performs before counting) ---------------------
+ * Splits each ASCII read at every non-ACGT/acgt symbol, drops runs shorter than k, cuts runs longer than
+ * 16*stride_words into chunks overlapping by k-1 bases (so every k-mer occurrence is kept exactly once), and
+ * writes fixed-stride 2-bit records.  Returns the number of records that the input produces; writes at most
+ * `cap_records` of them (call with cap_records = 0 to size the buffers). */
+uint64_t bk_pack_reads(const uint8_t* const* reads, const uint64_t* read_lens, uint64_t n_reads, int32_t k,
+                       uint32_t stride_words, uint32_t* out_words, uint16_t* out_lens, uint64_t cap_records);
+/* Same for reads stored back to back in one buffer: read i = buf[offsets[i] .. offsets[i+1]) */
+uint64_t bk_pack_reads_flat(const uint8_t* buf, const uint64_t* offsets, uint64_t n_reads, int32_t k,
+                            uint32_t stride_words, uint32_t* out_words, uint16_t* out_lens, uint64_t cap_records);
+
+/* ---- measurement ------------------------------------------------------------------------------------------
+ * When enabled, every kernel launch is bracketed by HIP events on the launch stream.  bk_timing_read
+ * synchronises and returns accumulated milliseconds and launch counts since the last reset:
+ *   ms[0]/n[0] = scan_count kernel, ms[1]/n[1] = finalize kernel, ms[2]/n[2] = memsets + H2D/D2H copies. */
+int bk_timing_enable(bk_engine* e, int on);
+int bk_timing_read(bk_engine* e, double ms[3], uint64_t n[3], int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,58 @@
+"""Shared helpers for the parity tests (tests/ only)."""
+import os
+
+import numpy as np
+
+from bronko_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def engine_from_oracle_index(ix, params=None):
+    """Feed the HIP engine with the flattened arrays of an oracle-held index (same data a .bkdb decodes to)."""
+    from bronko_amd import Engine
+    return Engine(ix.k, ix.bucket_ids(), ix.bucket_off(), ix.entries(), ix.files(), params)
+
+
+def hip_sample(eng, mates_ascii, k, stride_words=None, batch=None):
+    """Run one sample through the C ABI: pack (K0) -> push per mate -> finish."""
+    from bronko_amd import pack_reads
+    eng.sample_begin()
+    for m, reads in enumerate(mates_ascii):
+        words, lens = pack_reads(reads, k, stride_words)
+        if batch:
+            for i in range(0, len(lens), batch):
+                eng.push_reads(m, words[i:i + batch], lens[i:i + batch])
+        else:
+            eng.push_reads(m, words, lens)
+    return eng.sample_finish(len(mates_ascii))
+
+
+def assert_same_pileup(res, pile):
+    for name in ("fwd_depth", "rev_depth", "fwd_nk", "rev_nk"):
+        a, b = getattr(res, name), getattr(pile, name)
+        if not np.array_equal(a, b):
+            bad = np.nonzero(a != b)[0]
+            raise AssertionError("%s differs in %d of %d cells; first at %d: hip=%d oracle=%d" %
+                                 (name, len(bad), len(a), bad[0], a[bad[0]], b[bad[0]]))
+    assert np.array_equal(res.stats, pile.stats), (res.stats, pile.stats)
+    assert np.array_equal(res.present, pile.present)
+
+
+def hpv_reads(n, seed, read_len=150, err=0.005, with_n=False, ragged=False):
+    g = synth.read_fasta_bytes(os.path.join(GOLDEN, "HPV16.fa"))
+    gm, isnv = synth.sample_genome(g, seed)
+    codes = synth.single_end_codes(gm, n, read_len, seed + 100, err=err, isnv=isnv)
+    reads = synth.codes_to_ascii(codes)
+    if with_n or ragged:
+        r = synth.splitmix64(seed + 999, 3 * n)
+        out = []
+        for i, rd in enumerate(reads):
+            rd = bytearray(rd)
+            if with_n and r[3 * i] % np.uint64(10) == 0:
+                rd[int(r[3 * i + 1] % np.uint64(len(rd)))] = ord("N")
+            if ragged:
+                rd = rd[: int(r[3 * i + 2] % np.uint64(len(rd) + 1))]
+            out.append(bytes(rd))
+        reads = out
+    return reads

@@ -141,7 +141,8 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "avg_kernel_ms": scan_ms, "launches": kn[0],
                      "algorithmic_bytes_per_launch": ALGO_BYTES_PER_READ * args.reads},
-        "kernels_ms": {"scan_count": scan_ms, "finalize": fin_ms, "memset_copy": kms[2] / max(kn[2], 1)},
+        "kernels_ms": {"scan_count": scan_ms, "finalize": fin_ms, "memset_copy": kms[2] / max(kn[2], 1),
+                       "fold": kms[3] / max(kn[3], 1)},
         "check": {"perfect_kmers": int(res.stats[0, 0, 0]), "variant_kmers": int(res.stats[0, 0, 1]),
                   "kmers_scanned": int(res.kmer_stats[0, 1])},
     }

@@ -11,14 +11,15 @@
 namespace bk {
 
 constexpr uint64_t kEmptyKey = ~0ull;
-constexpr int kMaxK = 31;          // consts.rs:4 MAX_KMER_SIZE
-constexpr int kCountersPerSlot = 8; // 4 bases x 2 read orientations
+constexpr int kMaxK = 31;            // consts.rs:4 MAX_KMER_SIZE
+constexpr int kCountersPerSlot = 8;  // 4 bases x 2 read orientations
+constexpr int kXcdPlanes = 8;        // MI355X: 8 XCDs, each with a private L2
 
 // One position of a window sub-table (open addressing, linear probing).  16 B so that a probe is one
 // global_load_dwordx4.  key = canonical k-mer with the sub-table's wildcard position zeroed.
 struct alignas(16) TableSlot {
     uint64_t key;
-    uint32_t slot;   // dense id of the window bucket: indexes counters, slot_key, slot_t, ent_off/ent_len
+    uint32_t slot;   // dense id of the window bucket: indexes the V counters, slot_key, slot_t, ent_off/ent_len
     uint32_t pad;
 };
 
@@ -30,25 +31,60 @@ struct alignas(8) DevEntry {
     uint8_t  canonical;
 };
 
-// Multiplicative hash of a masked canonical k-mer into a sub-table of 2^log2s positions.
+// Multiplicative hash into a table of 2^log2s positions.
 BK_HD uint32_t hash_key(uint64_t key, uint32_t log2s) {
     return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - log2s));
 }
 
+// Perfect hash of the reference k-mer set U ("hash and displace" with per-bucket pilots): position of k-mer x
+// in kmer_pos[m] = phf_pos(x, pilots[phf_bucket(x)], m).  The host searches, bucket by bucket (largest first),
+// the smallest pilot that sends all keys of the bucket to free positions, so every u in U has a private
+// position and a lookup is exactly two loads (pilot, key) with no probe chain -- no lane of a wave waits for
+// another lane's collisions.
+BK_HD uint32_t phf_bucket(uint64_t x, uint32_t log2nb) { return hash_key(x, log2nb); }
+BK_HD uint32_t phf_pos(uint64_t x, uint32_t pilot, uint32_t m) {
+    uint32_t h = (uint32_t)((x * 0xD6E8FEB86659FD93ull) >> 32) ^ (pilot * 0x9E3779B1u);
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return (uint32_t)(((uint64_t)h * m) >> 32);
+}
+
 // Everything the kernels need to know about the index; passed by value.
+//
+// Two views of the same reference k-mer set U (distinct canonical reference k-mers whose buckets intersect
+// the window):
+//  * exact / neighbour search: kmer_lo and kmer_hi hold every u in U, open-addressed by the hash of its low
+//    half (lo_bases bases) resp. high half.  Two k-mers at Hamming distance <= 1 agree on at least one half
+//    (pigeonhole), so walking the two chains of a read k-mer finds every reference k-mer it can vote for.
+//  * window sub-tables (table): (wildcard position, masked k-mer) -> slot, used to name the counter of a
+//    variant k-mer and by finalize to replay map_kmers.
 struct IndexView {
-    const TableSlot* table;   // [W][S]
+    const uint64_t*  kmer_pos; // [m] perfect-hash table of U; position p owns E counters 2p, 2p+1
+    const uint16_t*  pilots;   // [1 << log2nb]
+    const uint64_t*  kmer_lo;  // [1 << log2u] every u in U, open-addressed by hash(u & lo_mask)
+    const uint64_t*  kmer_hi;  // [1 << log2u] every u in U, open-addressed by hash(u >> lo_bits)
+    const TableSlot* table;    // [W][S]
     const uint64_t*  slot_key; // [n_slots] masked canonical k-mer of the slot
     const uint8_t*   slot_t;   // [n_slots] window-relative wildcard position t (absolute = wstart + t)
     const uint32_t*  ent_off;  // [n_slots]
     const uint32_t*  ent_len;  // [n_slots]
     const DevEntry*  entries;  // [n_entries in window]
     uint64_t n_slots;
-    uint32_t log2s;            // S = 1 << log2s positions per sub-table
+    uint32_t m;                // positions of kmer_pos (>= |U|)
+    uint32_t log2nb;           // pilots has 1 << log2nb buckets
+    uint32_t log2u;            // kmer_lo / kmer_hi have 1 << log2u positions
+    uint32_t log2s;            // S = 1 << log2s positions per window sub-table
+    int32_t  lo_bases;         // bases in the low half (k / 2)
     int32_t  k;
     int32_t  wstart;           // first wildcard position of the window (call.rs:1291-1300)
     int32_t  W;                // number of window buckets per k-mer = num_buckets_perfect (call.rs:1302)
     int32_t  n_files;
 };
+
+// Counter plane of one mate file, u64: [ E : 2 * m ][ V : n_slots * 8 ]
+//   E[2p + rc]              occurrences of the reference k-mer kmer_pos[p] read as-is (rc=0) / as its reverse
+//                           complement (rc=1)
+//   V[slot*8 + base*2 + rc] occurrences of the non-reference k-mer (slot's masked k-mer with `base` at the
+//                           wildcard position)
+BK_HD uint64_t e_plane_len(uint32_t m) { return 2ull * m; }
 
 }  // namespace bk

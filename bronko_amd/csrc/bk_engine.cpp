@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -63,9 +64,16 @@ struct bk_engine {
     bk_params params{};
     int k = 0, wstart = 0, W = 0, n_files = 0;
     uint64_t total_cells = 0, n_slots = 0;
-    uint32_t log2s = 4;
+    uint32_t log2s = 4, log2u = 4, log2nb = 0, m = 1, n_lds_bins = 0;
+    int lo_bases = 0, n_cus = 256;
     int device = 0;
 
+    DevBuf<uint64_t> kmer_pos, kmer_lo, kmer_hi;
+    DevBuf<uint16_t> pilots;
+    DevBuf<unsigned int> slabs;             // [n_cus][n_lds_bins] workgroup histograms of the last scan launch
+    DevBuf<unsigned int> e_planes;          // [8][E] u32, XCD-private planes for positions >= n_lds_bins
+    bool use_xcd_planes = true;
+    uint64_t kmers_since_fold = 0;
     DevBuf<bk::TableSlot> table;
     DevBuf<uint64_t> slot_key;
     DevBuf<uint8_t> slot_t;
@@ -83,12 +91,15 @@ struct bk_engine {
     bool in_sample = false;
     uint64_t pushed_records[2] = {0, 0};
 
+    int ablate = 0;   // BK_SCAN_ABLATE (measurement aid): see scan_count_kernel
     bool timing = false;
     std::vector<TimedSpan> spans;
     std::vector<hipEvent_t> free_events;
 
     bk::IndexView view() const {
         bk::IndexView v{};
+        v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb;
+        v.kmer_lo = kmer_lo.p; v.kmer_hi = kmer_hi.p; v.log2u = log2u; v.lo_bases = lo_bases;
         v.table = table.p; v.slot_key = slot_key.p; v.slot_t = slot_t.p; v.ent_off = ent_off.p; v.ent_len = ent_len.p;
         v.entries = entries.p; v.n_slots = n_slots; v.log2s = log2s; v.k = k; v.wstart = wstart; v.W = W; v.n_files = n_files;
         return v;
@@ -174,6 +185,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     std::vector<uint32_t> h_off, h_len;
     std::vector<bk::DevEntry> h_ent;
     std::vector<uint64_t> per_t(e->W > 0 ? e->W : 1, 0);
+    std::vector<uint64_t> h_u;   // canonical reference k-mers that own at least one window bucket (with repeats)
     uint64_t ids[32];
     for (uint64_t b = 0; b < ix->n_buckets && e->W > 0; b++) {
         const uint64_t lo = ix->bucket_off[b], hi = ix->bucket_off[b + 1];
@@ -196,7 +208,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 if (ids[j] != ix->bucket_ids[b]) return fail(BK_ERR_INVALID, "bucket %llu: id does not match assign_buckets of its entries", (unsigned long long)ix->bucket_ids[b]);
                 keys.emplace_back(j, masked);
             }
-            if (j >= e->wstart && j < e->wstart + e->W) any_in_window = true;
+            if (j >= e->wstart && j < e->wstart + e->W) { any_in_window = true; h_u.push_back(cn.kmer); }
         }
         if (!any_in_window) continue;
         // every entry of the bucket is voted for by a probe of any of its keys (call.rs:1307-1309 iterates the
@@ -239,7 +251,84 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         sub[h].slot = (uint32_t)s;
     }
 
-    if (bk::finalize_lds_bytes(e->n_files) > 160 * 1024) return fail(BK_ERR_UNSUPPORTED, "more than ~20000 genome files are not supported by the finalize kernel");
+    // ---- reference k-mer set U, open-addressed by low half and by high half (bk_device.h) -------------------
+    std::sort(h_u.begin(), h_u.end());
+    h_u.erase(std::unique(h_u.begin(), h_u.end()), h_u.end());
+    e->lo_bases = k / 2;
+    e->log2u = 4;
+    while ((1ull << e->log2u) < 2 * std::max<size_t>(h_u.size(), 1)) e->log2u++;   // load factor <= 0.5
+    if (e->log2u > 30) return fail(BK_ERR_UNSUPPORTED, "too many distinct reference k-mers");
+    {
+        const size_t U = (size_t)1 << e->log2u;
+        const uint64_t lo_mask = (1ull << (2 * e->lo_bases)) - 1ull;
+        std::vector<uint64_t> t_lo(U, bk::kEmptyKey), t_hi(U, bk::kEmptyKey);
+        for (uint64_t u : h_u) {
+            uint32_t h = bk::hash_key(u & lo_mask, e->log2u);
+            while (t_lo[h] != bk::kEmptyKey) h = (h + 1) & (uint32_t)(U - 1);
+            t_lo[h] = u;
+            h = bk::hash_key(u >> (2 * e->lo_bases), e->log2u);
+            while (t_hi[h] != bk::kEmptyKey) h = (h + 1) & (uint32_t)(U - 1);
+            t_hi[h] = u;
+        }
+        BK_HIP(e->kmer_lo.upload(t_lo));
+        BK_HIP(e->kmer_hi.upload(t_hi));
+    }
+    // ---- perfect hash of U (bk_device.h phf_*): buckets of ~4 keys, largest first, smallest free pilot -------
+    {
+        const size_t n = h_u.size();
+        e->log2nb = 0;
+        while ((4ull << e->log2nb) < n) e->log2nb++;
+        const size_t nb = (size_t)1 << e->log2nb;
+        std::vector<std::vector<uint64_t>> bucket(nb);
+        for (uint64_t u : h_u) bucket[bk::phf_bucket(u, e->log2nb)].push_back(u);
+        std::vector<uint32_t> order(nb);
+        for (size_t i = 0; i < nb; i++) order[i] = (uint32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return bucket[a].size() > bucket[b].size(); });
+        uint64_t m = std::max<uint64_t>(64, (uint64_t)((double)n / 0.97) + 1);
+        std::vector<uint64_t> t_pos;
+        std::vector<uint16_t> h_pilots;
+        for (int attempt = 0;; attempt++) {
+            if (attempt > 20 || m >= (1ull << 31)) return fail(BK_ERR_UNSUPPORTED, "perfect hash construction failed");
+            t_pos.assign(m, bk::kEmptyKey);
+            h_pilots.assign(nb, 0);
+            bool ok = true;
+            std::vector<uint32_t> pos;
+            for (uint32_t b : order) {
+                const auto& keys = bucket[b];
+                if (keys.empty()) break;
+                uint32_t pilot = 0;
+                for (; pilot < 65536; pilot++) {
+                    pos.clear();
+                    bool good = true;
+                    for (uint64_t u : keys) {
+                        const uint32_t p = bk::phf_pos(u, pilot, (uint32_t)m);
+                        if (t_pos[p] != bk::kEmptyKey || std::find(pos.begin(), pos.end(), p) != pos.end()) { good = false; break; }
+                        pos.push_back(p);
+                    }
+                    if (good) break;
+                }
+                if (pilot == 65536) { ok = false; break; }
+                h_pilots[b] = (uint16_t)pilot;
+                for (size_t i = 0; i < keys.size(); i++) t_pos[pos[i]] = keys[i];
+            }
+            if (ok) break;
+            m += m / 16 + 1;   // rare: loosen the table and retry
+        }
+        e->m = (uint32_t)m;
+        BK_HIP(e->kmer_pos.upload(t_pos));
+        BK_HIP(e->pilots.upload(h_pilots));
+    }
+    {
+        hipDeviceProp_t prop;
+        BK_HIP(hipGetDeviceProperties(&prop, prm->device));
+        e->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        e->n_lds_bins = std::min<uint32_t>(e->m, bk::scan_max_lds_bins());
+        if (const char* nl = getenv("BK_LDS_BINS")) e->n_lds_bins = std::min<uint32_t>(e->n_lds_bins, (uint32_t)atol(nl));
+        BK_HIP(e->slabs.alloc((size_t)e->n_cus * std::max<uint32_t>(e->n_lds_bins, 1)));
+    }
+    if (const char* nx = getenv("BK_NO_XCD_PLANES")) e->use_xcd_planes = atoi(nx) == 0;
+
+    if (bk::finalize_lds_bytes(e->n_files) > 160 * 1024) return fail(BK_ERR_UNSUPPORTED, "more than ~8000 genome files are not supported by the finalize kernel");
 
     BK_HIP(e->table.upload(h_table));
     BK_HIP(e->slot_key.upload(h_slot_key));
@@ -247,13 +336,19 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     BK_HIP(e->ent_off.upload(h_off));
     BK_HIP(e->ent_len.upload(h_len));
     BK_HIP(e->entries.upload(h_ent));
-    for (int m = 0; m < 2; m++) BK_HIP(e->counters[m].alloc(e->n_slots * bk::kCountersPerSlot));
+    for (int m = 0; m < 2; m++) BK_HIP(e->counters[m].alloc(bk::e_plane_len(e->m) + e->n_slots * bk::kCountersPerSlot));
+    if (e->n_lds_bins >= e->m) e->use_xcd_planes = false;   // every reference k-mer has an LDS bin
+    if (e->use_xcd_planes) {
+        BK_HIP(e->e_planes.alloc((size_t)bk::kXcdPlanes * bk::e_plane_len(e->m)));
+        BK_HIP(hipMemset(e->e_planes.p, 0, e->e_planes.n * sizeof(unsigned int)));
+    }
     BK_HIP(e->pileup.alloc(e->total_cells * 4 * 4));
     BK_HIP(e->stats.alloc((size_t)2 * e->n_files * 3));
     BK_HIP(e->present.alloc((size_t)2 * e->n_files));
     BK_HIP(e->kstats.alloc(8));
     BK_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
+    if (const char* ab = getenv("BK_SCAN_ABLATE")) e->ablate = atoi(ab);
     *out = e.release();
     return BK_OK;
 }
@@ -278,7 +373,7 @@ int bk_engine_set_stream(bk_engine* e, void* hip_stream) {
 uint64_t bk_total_cells(const bk_engine* e) { return e ? e->total_cells : 0; }
 int32_t bk_n_files(const bk_engine* e) { return e ? e->n_files : 0; }
 uint64_t bk_n_slots(const bk_engine* e) { return e ? e->n_slots : 0; }
-uint64_t bk_counter_len(const bk_engine* e) { return e ? e->n_slots * bk::kCountersPerSlot : 0; }
+uint64_t bk_counter_len(const bk_engine* e) { return e ? bk::e_plane_len(e->m) + e->n_slots * bk::kCountersPerSlot : 0; }
 
 int bk_sample_begin(bk_engine* e) {
     if (!e) return fail(BK_ERR_INVALID, "null engine");
@@ -301,9 +396,22 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.words = d_words; a.lens = d_lens; a.n_records = n; a.stride_words = stride_words;
     a.counters = e->counters[mate].p;
     a.kmer_total = e->kstats.p + mate * 4 + 1;
+    a.ablate = e->ablate;
+    a.e_planes = e->use_xcd_planes ? e->e_planes.p : nullptr;
+    a.slabs = e->slabs.p;
+    a.n_lds_bins = e->n_lds_bins;
+    const uint32_t grid = bk::scan_grid(n, e->n_cus);
     {
         bk_engine::Span sp(e, 0);
-        bk::launch_scan_count(a, e->stream);
+        BK_HIP(bk::launch_scan_count(a, grid, e->stream));
+    }
+    if (e->W > 0 && e->ablate == 0) {
+        // histogram slabs (and the u32 overflow planes: a batch of < 2^32 k-mers cannot wrap them) -> u64 plane
+        bk::FoldArgs f{};
+        f.slabs = e->slabs.p; f.n_slabs = grid; f.n_lds_bins = e->n_lds_bins;
+        f.e_planes = a.e_planes; f.n_e = bk::e_plane_len(e->m); f.counters = e->counters[mate].p;
+        bk_engine::Span sp(e, 3);
+        bk::launch_fold(f, e->stream);
     }
     BK_HIP(hipGetLastError());
     e->pushed_records[mate] += n;
@@ -316,6 +424,7 @@ int bk_push_reads_packed_device(bk_engine* e, int mate, const void* d_words, uin
     if (mate < 0 || mate > 1) return fail(BK_ERR_INVALID, "mate must be 0 or 1");
     if (n == 0) return BK_OK;
     if (!d_words || !d_lens || stride_words == 0 || stride_words > 4096) return fail(BK_ERR_INVALID, "bad record batch");
+    if (n > (1ull << 32) / ((uint64_t)stride_words * 16)) return fail(BK_ERR_INVALID, "batch too large: push at most 2^32 bases per call");
     BK_HIP(hipSetDevice(e->device));
     return push_device(e, mate, static_cast<const uint32_t*>(d_words), stride_words, static_cast<const uint16_t*>(d_lens), n);
 }
@@ -326,6 +435,7 @@ int bk_push_reads_packed(bk_engine* e, int mate, const uint32_t* words, uint32_t
     if (mate < 0 || mate > 1) return fail(BK_ERR_INVALID, "mate must be 0 or 1");
     if (n == 0) return BK_OK;
     if (!words || !lens || stride_words == 0 || stride_words > 4096) return fail(BK_ERR_INVALID, "bad record batch");
+    if (n > (1ull << 32) / ((uint64_t)stride_words * 16)) return fail(BK_ERR_INVALID, "batch too large: push at most 2^32 bases per call");
     BK_HIP(hipSetDevice(e->device));
     const size_t nw = (size_t)n * stride_words;
     if (e->stage_words.n < nw) { BK_HIP(hipStreamSynchronize(e->stream)); BK_HIP(e->stage_words.alloc(nw + nw / 4)); }
@@ -460,11 +570,11 @@ int bk_timing_enable(bk_engine* e, int on) {
     return BK_OK;
 }
 
-int bk_timing_read(bk_engine* e, double ms[3], uint64_t n[3], int reset) {
+int bk_timing_read(bk_engine* e, double ms[4], uint64_t n[4], int reset) {
     if (!e || !ms || !n) return fail(BK_ERR_INVALID, "bad argument");
     BK_HIP(hipSetDevice(e->device));
     BK_HIP(hipStreamSynchronize(e->stream));
-    for (int i = 0; i < 3; i++) { ms[i] = 0.0; n[i] = 0; }
+    for (int i = 0; i < 4; i++) { ms[i] = 0.0; n[i] = 0; }
     for (auto& s : e->spans) {
         float t = 0.f;
         BK_HIP(hipEventElapsedTime(&t, s.a, s.b));

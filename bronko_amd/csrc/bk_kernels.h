@@ -12,8 +12,12 @@ struct ScanArgs {
     const uint16_t* lens;           // [n_records] valid bases
     uint64_t n_records;
     uint32_t stride_words;
-    unsigned long long* counters;   // [n_slots][4 bases][2 orientations]
+    unsigned long long* counters;   // u64 plane [E | V] (bk_device.h)
+    unsigned int* slabs;            // [grid][n_lds_bins] packed (rc<<16 | fwd) histogram of each workgroup
+    uint32_t n_lds_bins;            // reference k-mers at positions < n_lds_bins are counted in LDS
+    unsigned int* e_planes;         // [8 XCDs][E] u32 planes for positions >= n_lds_bins; null if none / disabled
     unsigned long long* kmer_total; // optional: += k-mer occurrences scanned
+    int ablate;                     // measurement aid, 0 in production (see scan_count_kernel)
 };
 
 struct FinalizeArgs {
@@ -27,7 +31,20 @@ struct FinalizeArgs {
     unsigned long long* kept_total; // optional: += distinct k-mers that passed the thresholds
 };
 
-void launch_scan_count(const ScanArgs& a, hipStream_t stream);
+struct FoldArgs {
+    const unsigned int* slabs;
+    uint32_t n_slabs;               // = grid of the scan launch
+    uint32_t n_lds_bins;
+    unsigned int* e_planes;         // may be null
+    uint64_t n_e;                   // 2 * m
+    unsigned long long* counters;
+};
+
+uint32_t scan_grid(uint64_t n_records, int n_cus);
+uint32_t scan_max_lds_bins();
+size_t scan_lds_bytes(uint32_t n_lds_bins);
+hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t stream);
+void launch_fold(const FoldArgs& f, hipStream_t stream);
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
 size_t finalize_lds_bytes(int n_files);
 

@@ -164,7 +164,7 @@ class Engine:
         _check(self._L.bk_timing_enable(self.h, int(on)))
 
     def timing_read(self, reset=True):
-        ms = (C.c_double * 3)()
-        n = (C.c_uint64 * 3)()
+        ms = (C.c_double * 4)()
+        n = (C.c_uint64 * 4)()
         _check(self._L.bk_timing_read(self.h, ms, n, int(reset)))
         return list(ms), list(n)

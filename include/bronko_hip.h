@@ -100,7 +100,7 @@ int bk_engine_set_stream(bk_engine* e, void* hip_stream);
 uint64_t bk_total_cells(const bk_engine* e);     /* sum of all sequence lengths = rows of each pileup array */
 int32_t  bk_n_files(const bk_engine* e);
 uint64_t bk_n_slots(const bk_engine* e);         /* distinct window buckets on the device                   */
-uint64_t bk_counter_len(const bk_engine* e);     /* u64 elements in one counter plane (= 8 * n_slots)       */
+uint64_t bk_counter_len(const bk_engine* e);     /* u64 elements in one counter plane                       */
 
 /* ---- per-sample protocol (mirrors one iteration of call.rs:213-293 / :298-386) ---------------------------
  * bk_sample_begin      = initialize_output_maps (call.rs:224,314): zero pileups, stats and counter planes.
@@ -156,9 +156,9 @@ uint64_t bk_pack_reads_flat(const uint8_t* buf, const uint64_t* offsets, uint64_
 /* ---- measurement ------------------------------------------------------------------------------------------
  * When enabled, every kernel launch is bracketed by HIP events on the launch stream.  bk_timing_read
  * synchronises and returns accumulated milliseconds and launch counts since the last reset:
- *   ms[0]/n[0] = scan_count kernel, ms[1]/n[1] = finalize kernel, ms[2]/n[2] = memsets + H2D/D2H copies. */
+ *   [0] scan_count kernel, [1] finalize kernel, [2] memsets + H2D/D2H copies, [3] fold kernel. */
 int bk_timing_enable(bk_engine* e, int on);
-int bk_timing_read(bk_engine* e, double ms[3], uint64_t n[3], int reset);
+int bk_timing_read(bk_engine* e, double ms[4], uint64_t n[4], int reset);
 
 #ifdef __cplusplus
 }

@@ -123,3 +123,35 @@ def test_k_variants(oracle, golden_dir):
         helpers.assert_same_pileup(res, pile)
         eng.close()
         ix.close()
+
+
+def test_degenerate_identical_reads_spill_the_lds_histogram(oracle, hpv):
+    """Millions of occurrences of the same reference k-mers: the packed 16-bit LDS bins must spill, not wrap.
+    300k copies of one 150 bp reference window (+ its reverse complement) and an all-A homopolymer read set."""
+    ix, eng = hpv
+    g = synth.read_fasta_bytes(os.path.join(helpers.GOLDEN, "HPV16.fa"))
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    w = g[1000:1150]
+    reads = [w] * 200000 + [w.translate(comp)[::-1]] * 100000 + [b"A" * 150] * 1000
+    res = helpers.hip_sample(eng, [reads], 21)
+    pile = oracle.sample_pileup(ix, [reads])
+    helpers.assert_same_pileup(res, pile)
+    assert int(res.fwd_depth.max()) == 200000 and int(res.rev_depth.max()) == 100000
+
+
+def test_overflow_planes_when_lds_histogram_is_smaller_than_the_reference(oracle, golden_dir, monkeypatch):
+    """BK_LDS_BINS caps the LDS histogram so that most reference k-mers take the XCD-private plane path (the
+    path large multi-genome indexes use); BK_NO_XCD_PLANES=1 then forces plain agent-scope atomics."""
+    ix = oracle.Index.load(os.path.join(golden_dir, "hpv.bkdb"))
+    reads = helpers.hpv_reads(6000, seed=8)
+    pile = oracle.sample_pileup(ix, [reads])
+    for env in ({"BK_LDS_BINS": "1000"}, {"BK_LDS_BINS": "0"}, {"BK_LDS_BINS": "500", "BK_NO_XCD_PLANES": "1"}):
+        for kk, vv in env.items():
+            monkeypatch.setenv(kk, vv)
+        eng = helpers.engine_from_oracle_index(ix)
+        res = helpers.hip_sample(eng, [reads], 21, batch=2500)
+        helpers.assert_same_pileup(res, pile)
+        eng.close()
+        for kk in env:
+            monkeypatch.delenv(kk)
+    ix.close()

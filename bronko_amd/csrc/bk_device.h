@@ -48,30 +48,51 @@ BK_HD uint32_t phf_pos(uint64_t x, uint32_t pilot, uint32_t m) {
     return (uint32_t)(((uint64_t)h * m) >> 32);
 }
 
+// A reference k-mer in a neighbour list: 16 B so that one candidate is one global_load_dwordx4.
+struct alignas(16) NbEntry {
+    uint64_t u;      // canonical reference k-mer
+    uint32_t p;      // its position in kmer_pos (names its E and V counters)
+    uint32_t pad;
+};
+
+// Directory entry of a half-key: the reference k-mers sharing that half are cand[off .. off + cnt).
+struct alignas(16) HalfDir {
+    uint32_t key;    // the half-key itself (<= 16 bases = 32 bits)
+    uint32_t off;
+    uint32_t cnt;    // 0 = free position
+    uint32_t pad;
+};
+
+// One half (low or high) of the neighbour search: perfect hash over the distinct half-keys -> HalfDir -> list.
+struct HalfView {
+    const uint16_t* pilots;   // [1 << log2nb]
+    const HalfDir*  dir;      // [m]
+    const NbEntry*  cand;     // reference k-mers sorted by this half
+    uint32_t m;
+    uint32_t log2nb;
+};
+
 // Everything the kernels need to know about the index; passed by value.
 //
-// Two views of the same reference k-mer set U (distinct canonical reference k-mers whose buckets intersect
-// the window):
-//  * exact / neighbour search: kmer_lo and kmer_hi hold every u in U, open-addressed by the hash of its low
-//    half (lo_bases bases) resp. high half.  Two k-mers at Hamming distance <= 1 agree on at least one half
-//    (pigeonhole), so walking the two chains of a read k-mer finds every reference k-mer it can vote for.
-//  * window sub-tables (table): (wildcard position, masked k-mer) -> slot, used to name the counter of a
-//    variant k-mer and by finalize to replay map_kmers.
+// Views of the reference k-mer set U (distinct canonical reference k-mers that own a window bucket):
+//  * kmer_pos / pilots : perfect hash, "is this read k-mer a reference k-mer, and which one" in two loads.
+//  * lo / hi           : every u in U listed under its low half (lo_bases bases) resp. high half, the half-keys
+//                        perfect-hashed.  Two k-mers at Hamming distance 1 agree on one half (pigeonhole), so
+//                        the two lists of a k-mer contain every reference k-mer it can vote for; a lookup is
+//                        pilot -> directory entry -> candidates, three dependent loads whatever the table load.
+//  * table (+ slot_key, slot_t, ent_off, ent_len, entries): the index itself, window buckets keyed by
+//    (wildcard position, masked k-mer) with their BucketInfo lists; used by finalize to replay map_kmers.
 struct IndexView {
     const uint64_t*  kmer_pos; // [m] perfect-hash table of U; position p owns E counters 2p, 2p+1
     const uint16_t*  pilots;   // [1 << log2nb]
-    const uint64_t*  kmer_lo;  // [1 << log2u] every u in U, open-addressed by hash(u & lo_mask)
-    const uint64_t*  kmer_hi;  // [1 << log2u] every u in U, open-addressed by hash(u >> lo_bits)
+    HalfView         lo, hi;
     const TableSlot* table;    // [W][S]
-    const uint64_t*  slot_key; // [n_slots] masked canonical k-mer of the slot
-    const uint8_t*   slot_t;   // [n_slots] window-relative wildcard position t (absolute = wstart + t)
     const uint32_t*  ent_off;  // [n_slots]
     const uint32_t*  ent_len;  // [n_slots]
     const DevEntry*  entries;  // [n_entries in window]
     uint64_t n_slots;
     uint32_t m;                // positions of kmer_pos (>= |U|)
     uint32_t log2nb;           // pilots has 1 << log2nb buckets
-    uint32_t log2u;            // kmer_lo / kmer_hi have 1 << log2u positions
     uint32_t log2s;            // S = 1 << log2s positions per window sub-table
     int32_t  lo_bases;         // bases in the low half (k / 2)
     int32_t  k;
@@ -80,11 +101,14 @@ struct IndexView {
     int32_t  n_files;
 };
 
-// Counter plane of one mate file, u64: [ E : 2 * m ][ V : n_slots * 8 ]
-//   E[2p + rc]              occurrences of the reference k-mer kmer_pos[p] read as-is (rc=0) / as its reverse
-//                           complement (rc=1)
-//   V[slot*8 + base*2 + rc] occurrences of the non-reference k-mer (slot's masked k-mer with `base` at the
-//                           wildcard position)
+// Counter plane of one mate file, u64: [ E : 2 * m ][ V : m * W * 8 ]
+//   E[2p + rc]                        occurrences of the reference k-mer u = kmer_pos[p] read as-is (rc=0) / as
+//                                     its reverse complement (rc=1)
+//   V[((p*W + t)*4 + b)*2 + rc]       occurrences of the non-reference k-mer "u with base b at window position
+//                                     wstart+t".  A non-reference k-mer may neighbour several reference k-mers;
+//                                     it is always counted under the smallest (t, p) -- a function of the k-mer
+//                                     alone, so all its occurrences share one counter and it owns no other.
 BK_HD uint64_t e_plane_len(uint32_t m) { return 2ull * m; }
+BK_HD uint64_t v_plane_len(uint32_t m, int W) { return (uint64_t)m * (uint64_t)(W > 0 ? W : 0) * 8ull; }
 
 }  // namespace bk

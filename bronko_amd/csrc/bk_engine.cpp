@@ -60,23 +60,71 @@ struct TimedSpan { hipEvent_t a, b; int kind; };
 
 }  // namespace
 
+namespace {
+
+// Perfect hash of distinct keys (bk_device.h phf_*): buckets of ~4 keys, largest first, smallest free pilot.
+// On success pos[i] is the position of keys[i] in a table of m >= n positions.
+bool build_phf(const std::vector<uint64_t>& keys, std::vector<uint16_t>& pilots, uint32_t& log2nb, uint32_t& m_out, std::vector<uint32_t>& pos) {
+    const size_t n = keys.size();
+    log2nb = 0;
+    while ((4ull << log2nb) < n) log2nb++;
+    const size_t nb = (size_t)1 << log2nb;
+    std::vector<std::vector<uint32_t>> bucket(nb);
+    for (size_t i = 0; i < n; i++) bucket[bk::phf_bucket(keys[i], log2nb)].push_back((uint32_t)i);
+    std::vector<uint32_t> order(nb);
+    for (size_t i = 0; i < nb; i++) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return bucket[a].size() > bucket[b].size(); });
+    uint64_t m = std::max<uint64_t>(64, (uint64_t)((double)n / 0.97) + 1);
+    pos.assign(n, 0);
+    std::vector<uint8_t> used;
+    std::vector<uint32_t> trial;
+    for (int attempt = 0; attempt <= 20 && m < (1ull << 31); attempt++, m += m / 16 + 1) {
+        used.assign(m, 0);
+        pilots.assign(nb, 0);
+        bool ok = true;
+        for (uint32_t b : order) {
+            const auto& members = bucket[b];
+            if (members.empty()) break;
+            uint32_t pilot = 0;
+            for (; pilot < 65536; pilot++) {
+                trial.clear();
+                bool good = true;
+                for (uint32_t i : members) {
+                    const uint32_t p = bk::phf_pos(keys[i], pilot, (uint32_t)m);
+                    if (used[p] || std::find(trial.begin(), trial.end(), p) != trial.end()) { good = false; break; }
+                    trial.push_back(p);
+                }
+                if (good) break;
+            }
+            if (pilot == 65536) { ok = false; break; }
+            pilots[b] = (uint16_t)pilot;
+            for (size_t q = 0; q < members.size(); q++) { pos[members[q]] = trial[q]; used[trial[q]] = 1; }
+        }
+        if (ok) { m_out = (uint32_t)m; return true; }
+    }
+    return false;
+}
+
+}  // namespace
+
 struct bk_engine {
     bk_params params{};
     int k = 0, wstart = 0, W = 0, n_files = 0;
     uint64_t total_cells = 0, n_slots = 0;
-    uint32_t log2s = 4, log2u = 4, log2nb = 0, m = 1, n_lds_bins = 0;
+    uint32_t log2s = 4, log2nb = 0, m = 1, n_lds_bins = 0;
+    bool pilots_in_lds = false;
     int lo_bases = 0, n_cus = 256;
     int device = 0;
 
-    DevBuf<uint64_t> kmer_pos, kmer_lo, kmer_hi;
+    DevBuf<uint64_t> kmer_pos;
+    struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0; } half_lo, half_hi;
+    DevBuf<unsigned int> deferred, n_deferred;
     DevBuf<uint16_t> pilots;
     DevBuf<unsigned int> slabs;             // [n_cus][n_lds_bins] workgroup histograms of the last scan launch
     DevBuf<unsigned int> e_planes;          // [8][E] u32, XCD-private planes for positions >= n_lds_bins
     bool use_xcd_planes = true;
     uint64_t kmers_since_fold = 0;
     DevBuf<bk::TableSlot> table;
-    DevBuf<uint64_t> slot_key;
-    DevBuf<uint8_t> slot_t;
     DevBuf<uint32_t> ent_off, ent_len;
     DevBuf<bk::DevEntry> entries;
     DevBuf<unsigned long long> counters[2];
@@ -99,8 +147,10 @@ struct bk_engine {
     bk::IndexView view() const {
         bk::IndexView v{};
         v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb;
-        v.kmer_lo = kmer_lo.p; v.kmer_hi = kmer_hi.p; v.log2u = log2u; v.lo_bases = lo_bases;
-        v.table = table.p; v.slot_key = slot_key.p; v.slot_t = slot_t.p; v.ent_off = ent_off.p; v.ent_len = ent_len.p;
+        v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb};
+        v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb};
+        v.lo_bases = lo_bases;
+        v.table = table.p; v.ent_off = ent_off.p; v.ent_len = ent_len.p;
         v.entries = entries.p; v.n_slots = n_slots; v.log2s = log2s; v.k = k; v.wstart = wstart; v.W = W; v.n_files = n_files;
         return v;
     }
@@ -221,6 +271,9 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             de.file = bi.file_id; de.idx = bi.idx; de.canonical = bi.canonical ? 1 : 0;
             h_ent.push_back(de);
         }
+        // finalize_variant counts hits per file as run lengths: keep each bucket grouped by file (build_indexes
+        // already appends file by file, build.rs:223-228; votes are order-independent)
+        std::stable_sort(h_ent.begin() + off, h_ent.end(), [](const bk::DevEntry& x, const bk::DevEntry& y) { return x.file < y.file; });
         for (auto& kv : keys) {
             if (kv.first < e->wstart || kv.first >= e->wstart + e->W) continue;
             h_slot_key.push_back(kv.second);
@@ -251,79 +304,58 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         sub[h].slot = (uint32_t)s;
     }
 
-    // ---- reference k-mer set U, open-addressed by low half and by high half (bk_device.h) -------------------
+    // ---- reference k-mer set U: perfect hash (exact lookup) + half-key directories (neighbour lookup) --------
     std::sort(h_u.begin(), h_u.end());
     h_u.erase(std::unique(h_u.begin(), h_u.end()), h_u.end());
     e->lo_bases = k / 2;
-    e->log2u = 4;
-    while ((1ull << e->log2u) < 2 * std::max<size_t>(h_u.size(), 1)) e->log2u++;   // load factor <= 0.5
-    if (e->log2u > 30) return fail(BK_ERR_UNSUPPORTED, "too many distinct reference k-mers");
     {
-        const size_t U = (size_t)1 << e->log2u;
-        const uint64_t lo_mask = (1ull << (2 * e->lo_bases)) - 1ull;
-        std::vector<uint64_t> t_lo(U, bk::kEmptyKey), t_hi(U, bk::kEmptyKey);
-        for (uint64_t u : h_u) {
-            uint32_t h = bk::hash_key(u & lo_mask, e->log2u);
-            while (t_lo[h] != bk::kEmptyKey) h = (h + 1) & (uint32_t)(U - 1);
-            t_lo[h] = u;
-            h = bk::hash_key(u >> (2 * e->lo_bases), e->log2u);
-            while (t_hi[h] != bk::kEmptyKey) h = (h + 1) & (uint32_t)(U - 1);
-            t_hi[h] = u;
-        }
-        BK_HIP(e->kmer_lo.upload(t_lo));
-        BK_HIP(e->kmer_hi.upload(t_hi));
-    }
-    // ---- perfect hash of U (bk_device.h phf_*): buckets of ~4 keys, largest first, smallest free pilot -------
-    {
-        const size_t n = h_u.size();
-        e->log2nb = 0;
-        while ((4ull << e->log2nb) < n) e->log2nb++;
-        const size_t nb = (size_t)1 << e->log2nb;
-        std::vector<std::vector<uint64_t>> bucket(nb);
-        for (uint64_t u : h_u) bucket[bk::phf_bucket(u, e->log2nb)].push_back(u);
-        std::vector<uint32_t> order(nb);
-        for (size_t i = 0; i < nb; i++) order[i] = (uint32_t)i;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return bucket[a].size() > bucket[b].size(); });
-        uint64_t m = std::max<uint64_t>(64, (uint64_t)((double)n / 0.97) + 1);
-        std::vector<uint64_t> t_pos;
         std::vector<uint16_t> h_pilots;
-        for (int attempt = 0;; attempt++) {
-            if (attempt > 20 || m >= (1ull << 31)) return fail(BK_ERR_UNSUPPORTED, "perfect hash construction failed");
-            t_pos.assign(m, bk::kEmptyKey);
-            h_pilots.assign(nb, 0);
-            bool ok = true;
-            std::vector<uint32_t> pos;
-            for (uint32_t b : order) {
-                const auto& keys = bucket[b];
-                if (keys.empty()) break;
-                uint32_t pilot = 0;
-                for (; pilot < 65536; pilot++) {
-                    pos.clear();
-                    bool good = true;
-                    for (uint64_t u : keys) {
-                        const uint32_t p = bk::phf_pos(u, pilot, (uint32_t)m);
-                        if (t_pos[p] != bk::kEmptyKey || std::find(pos.begin(), pos.end(), p) != pos.end()) { good = false; break; }
-                        pos.push_back(p);
-                    }
-                    if (good) break;
-                }
-                if (pilot == 65536) { ok = false; break; }
-                h_pilots[b] = (uint16_t)pilot;
-                for (size_t i = 0; i < keys.size(); i++) t_pos[pos[i]] = keys[i];
-            }
-            if (ok) break;
-            m += m / 16 + 1;   // rare: loosen the table and retry
-        }
-        e->m = (uint32_t)m;
+        std::vector<uint32_t> u_pos;
+        if (!build_phf(h_u, h_pilots, e->log2nb, e->m, u_pos)) return fail(BK_ERR_UNSUPPORTED, "perfect hash construction failed");
+        std::vector<uint64_t> t_pos(e->m, bk::kEmptyKey);
+        for (size_t i = 0; i < h_u.size(); i++) t_pos[u_pos[i]] = h_u[i];
         BK_HIP(e->kmer_pos.upload(t_pos));
         BK_HIP(e->pilots.upload(h_pilots));
+
+        const int lo_bits = 2 * e->lo_bases;
+        const uint64_t lo_mask = (1ull << lo_bits) - 1ull;
+        for (int which = 0; which < 2; which++) {
+            auto half_of = [&](uint64_t u) { return which == 0 ? (u & lo_mask) : (u >> lo_bits); };
+            std::vector<uint32_t> order(h_u.size());
+            for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+            std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+                const uint64_t hx = half_of(h_u[x]), hy = half_of(h_u[y]);
+                return hx != hy ? hx < hy : h_u[x] < h_u[y];
+            });
+            std::vector<bk::NbEntry> cand(order.size());
+            std::vector<uint64_t> halves;
+            std::vector<uint32_t> first, count;
+            for (size_t i = 0; i < order.size(); i++) {
+                const uint64_t u = h_u[order[i]];
+                cand[i] = bk::NbEntry{u, u_pos[order[i]], 0u};
+                if (halves.empty() || halves.back() != half_of(u)) { halves.push_back(half_of(u)); first.push_back((uint32_t)i); count.push_back(0); }
+                count.back()++;
+            }
+            bk_engine::HalfBufs& hb = which == 0 ? e->half_lo : e->half_hi;
+            std::vector<uint16_t> hp;
+            std::vector<uint32_t> hpos;
+            if (!build_phf(halves, hp, hb.log2nb, hb.m, hpos)) return fail(BK_ERR_UNSUPPORTED, "perfect hash construction failed");
+            std::vector<bk::HalfDir> dir(hb.m, bk::HalfDir{0u, 0u, 0u, 0u});
+            for (size_t i = 0; i < halves.size(); i++) dir[hpos[i]] = bk::HalfDir{(uint32_t)halves[i], first[i], count[i], 0u};
+            BK_HIP(hb.pilots.upload(hp));
+            BK_HIP(hb.dir.upload(dir));
+            BK_HIP(hb.cand.upload(cand));
+        }
     }
     {
         hipDeviceProp_t prop;
         BK_HIP(hipGetDeviceProperties(&prop, prm->device));
         e->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        e->n_lds_bins = std::min<uint32_t>(e->m, bk::scan_max_lds_bins());
+        const size_t budget = bk::scan_lds_budget();
+        e->n_lds_bins = (uint32_t)std::min<size_t>(e->m, budget / sizeof(unsigned int));
         if (const char* nl = getenv("BK_LDS_BINS")) e->n_lds_bins = std::min<uint32_t>(e->n_lds_bins, (uint32_t)atol(nl));
+        e->pilots_in_lds = (size_t)e->n_lds_bins * sizeof(unsigned int) + ((size_t)2 << e->log2nb) <= budget;
+        if (const char* pl = getenv("BK_PILOTS_IN_LDS")) e->pilots_in_lds = e->pilots_in_lds && atoi(pl) != 0;
         BK_HIP(e->slabs.alloc((size_t)e->n_cus * std::max<uint32_t>(e->n_lds_bins, 1)));
     }
     if (const char* nx = getenv("BK_NO_XCD_PLANES")) e->use_xcd_planes = atoi(nx) == 0;
@@ -331,12 +363,13 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     if (bk::finalize_lds_bytes(e->n_files) > 160 * 1024) return fail(BK_ERR_UNSUPPORTED, "more than ~8000 genome files are not supported by the finalize kernel");
 
     BK_HIP(e->table.upload(h_table));
-    BK_HIP(e->slot_key.upload(h_slot_key));
-    BK_HIP(e->slot_t.upload(h_slot_t));
     BK_HIP(e->ent_off.upload(h_off));
     BK_HIP(e->ent_len.upload(h_len));
     BK_HIP(e->entries.upload(h_ent));
-    for (int m = 0; m < 2; m++) BK_HIP(e->counters[m].alloc(bk::e_plane_len(e->m) + e->n_slots * bk::kCountersPerSlot));
+    if (bk::v_plane_len(e->m, e->W) >= (1ull << 32)) return fail(BK_ERR_UNSUPPORTED, "index too large: variant counter plane exceeds 2^32 counters");
+    for (int m = 0; m < 2; m++) BK_HIP(e->counters[m].alloc(bk::e_plane_len(e->m) + bk::v_plane_len(e->m, e->W)));
+    BK_HIP(e->deferred.alloc(bk::v_plane_len(e->m, e->W)));
+    BK_HIP(e->n_deferred.alloc(1));
     if (e->n_lds_bins >= e->m) e->use_xcd_planes = false;   // every reference k-mer has an LDS bin
     if (e->use_xcd_planes) {
         BK_HIP(e->e_planes.alloc((size_t)bk::kXcdPlanes * bk::e_plane_len(e->m)));
@@ -373,7 +406,7 @@ int bk_engine_set_stream(bk_engine* e, void* hip_stream) {
 uint64_t bk_total_cells(const bk_engine* e) { return e ? e->total_cells : 0; }
 int32_t bk_n_files(const bk_engine* e) { return e ? e->n_files : 0; }
 uint64_t bk_n_slots(const bk_engine* e) { return e ? e->n_slots : 0; }
-uint64_t bk_counter_len(const bk_engine* e) { return e ? bk::e_plane_len(e->m) + e->n_slots * bk::kCountersPerSlot : 0; }
+uint64_t bk_counter_len(const bk_engine* e) { return e ? bk::e_plane_len(e->m) + bk::v_plane_len(e->m, e->W) : 0; }
 
 int bk_sample_begin(bk_engine* e) {
     if (!e) return fail(BK_ERR_INVALID, "null engine");
@@ -400,6 +433,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.e_planes = e->use_xcd_planes ? e->e_planes.p : nullptr;
     a.slabs = e->slabs.p;
     a.n_lds_bins = e->n_lds_bins;
+    a.pilots_in_lds = e->pilots_in_lds ? 1 : 0;
     const uint32_t grid = bk::scan_grid(n, e->n_cus);
     {
         bk_engine::Span sp(e, 0);
@@ -479,6 +513,9 @@ int bk_sample_finalize(bk_engine* e, int n_mates) {
         a.stats = e->stats.p + (size_t)m * e->n_files * 3;
         a.present = e->present.p + (size_t)m * e->n_files;
         a.kept_total = e->kstats.p + m * 4 + 3;
+        a.deferred = e->deferred.p;
+        a.n_deferred = e->n_deferred.p;
+        BK_HIP(hipMemsetAsync(e->n_deferred.p, 0, sizeof(unsigned int), e->stream));
         bk_engine::Span sp(e, 1);
         bk::launch_finalize(a, e->stream);
     }

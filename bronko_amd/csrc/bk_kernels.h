@@ -16,6 +16,7 @@ struct ScanArgs {
     unsigned int* slabs;            // [grid][n_lds_bins] packed (rc<<16 | fwd) histogram of each workgroup
     uint32_t n_lds_bins;            // reference k-mers at positions < n_lds_bins are counted in LDS
     unsigned int* e_planes;         // [8 XCDs][E] u32 planes for positions >= n_lds_bins; null if none / disabled
+    int pilots_in_lds;              // stage the perfect-hash pilots in LDS (they fit next to the histogram)
     unsigned long long* kmer_total; // optional: += k-mer occurrences scanned
     int ablate;                     // measurement aid, 0 in production (see scan_count_kernel)
 };
@@ -29,6 +30,8 @@ struct FinalizeArgs {
     unsigned long long* stats;      // [n_files][3]
     unsigned char* present;         // [n_files]
     unsigned long long* kept_total; // optional: += distinct k-mers that passed the thresholds
+    unsigned int* deferred;         // [v_plane_len] V counter indices K2a hands to K2b
+    unsigned int* n_deferred;       // [1], zeroed before each finalize
 };
 
 struct FoldArgs {
@@ -41,8 +44,8 @@ struct FoldArgs {
 };
 
 uint32_t scan_grid(uint64_t n_records, int n_cus);
-uint32_t scan_max_lds_bins();
-size_t scan_lds_bytes(uint32_t n_lds_bins);
+size_t scan_lds_budget();   // bytes available for histogram bins (4 B each) + pilots (2 B each)
+size_t scan_lds_bytes(uint32_t n_lds_bins, bool pilots_in_lds, uint32_t log2nb);
 hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t stream);
 void launch_fold(const FoldArgs& f, hipStream_t stream);
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);

@@ -1,0 +1,418 @@
+// cli.cpp -- the `bronko` command line: `bronko build` and `bronko call` with the reference's flag names,
+// defaults, validations, exit codes and output files (drop-in surface).
+//
+// Reference: /root/reference/src/main.rs:14-29 (banner, dispatch, elapsed), src/cli.rs:29-166 (flags),
+// src/consts.rs (defaults), src/build.rs:62-120 (build + its checks), src/call.rs:30-136 (call checks),
+// src/call.rs:151-402 (per-sample orchestration).  The k-mer counting + map_kmers stages of the per-sample loop
+// run on the GPU through the C ABI of include/bronko_hip.h; everything else here is host code.
+#include <zlib.h>
+
+#include <cerrno>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <sys/stat.h>
+
+#include "../../include/bronko_hip.h"
+#include "caller.hpp"
+#include "fastx.hpp"
+#include "index.hpp"
+
+namespace {
+
+using namespace bronko;
+
+const char* kVersion = "0.1.0";   // Cargo.toml:3 / consts.rs:1
+
+int g_level = 2;   // 0 error, 1 warn, 2 info, 3 debug, 4 trace (simple_logger levels, call.rs:31-43)
+void logf(int lvl, const char* tag, const char* target, const std::string& msg) {
+    if (lvl > g_level) return;
+    printf("%-5s [%s] %s\n", tag, target, msg.c_str());
+    fflush(stdout);
+}
+#define LOG_ERROR(t, m) logf(0, "ERROR", t, m)
+#define LOG_WARN(t, m) logf(1, "WARN", t, m)
+#define LOG_INFO(t, m) logf(2, "INFO", t, m)
+#define LOG_TRACE(t, m) logf(4, "TRACE", t, m)
+
+[[noreturn]] void die(const char* target, const std::string& msg) {   // `error!(..); std::process::exit(1)`
+    LOG_ERROR(target, msg);
+    exit(1);
+}
+
+bool ends_with(const std::string& s, const char* suf) {
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+bool check_fastq(const std::string& f) {   // util.rs:4-15
+    return ends_with(f, ".fq") || ends_with(f, ".fastq") || ends_with(f, ".fq.gz") || ends_with(f, "fastq.gz") ||
+           ends_with(f, "fnq") || ends_with(f, "fnq.gz");
+}
+bool check_fasta(const std::string& f) {   // util.rs:17-28
+    return ends_with(f, ".fa") || ends_with(f, ".fasta") || ends_with(f, ".fa.gz") || ends_with(f, "fasta.gz") ||
+           ends_with(f, "fna") || ends_with(f, "fna.gz");
+}
+
+// ---- argument parsing (clap derive surface of cli.rs) -------------------------------------------------------
+struct Args {
+    std::string mode;
+    std::vector<std::string> genomes, reads, first_pairs, second_pairs;
+    bool has_genomes = false;
+    std::string db;
+    bool has_db = false;
+    long kmer = 21;                 // consts.rs:3
+    long min_kmers = 3;             // consts.rs:5
+    bool use_full_kmer = false;
+    long n_fixed = 2;               // consts.rs:17
+    double min_af = 0.03;
+    bool no_end_filter = false, no_strand_filter = false, no_strand_balance_filter = false;
+    double balance_ratio = 0.1;
+    long n_per_strand = 2;
+    double strand_odds = 6.0;
+    long min_depth = 300;
+    long min_variant_depth = 3;
+    double noise_multiplier = 1.5;
+    std::string output;             // default depends on the mode
+    bool pileup = false, alignment = false, keep_kmer_info = false;
+    long threads = 4;
+    bool debug = false, verbose = false;
+};
+
+[[noreturn]] void usage(int code) {
+    fputs("Usage: bronko <COMMAND>\n\nCommands:\n"
+          "  build  Create an bronko index of existing viral references for a given species\n"
+          "  call   Perform rapid viral variant calling of viral sequencing data\n\n"
+          "bronko build -g <GENOMES>... [-k <KMER>] [-o <OUTPUT>] [-t <THREADS>] [--debug] [--verbose]\n"
+          "bronko call (-g <GENOMES>... | -d <DB>) [-r <READS>...] [-1 <R1>... -2 <R2>...] [-k <KMER>] [--min-kmers N]\n"
+          "            [--use-full-kmer] [--n-fixed N] [--min-af F] [--no-end-filter] [--no-strand-filter]\n"
+          "            [--no-strand-balance-filter] [--balance-ratio F] [--n-per-strand N] [--strand_odds F]\n"
+          "            [--min-depth N] [--min-variant-depth N] [--noise-multiplier F] [-o <DIR>] [--pileup]\n"
+          "            [--alignment] [--keep-kmer-info] [-t <THREADS>] [--debug] [--verbose]\n", stderr);
+    exit(code);
+}
+
+long to_long(const std::string& opt, const std::string& v) {
+    char* end = nullptr;
+    const long x = strtol(v.c_str(), &end, 10);
+    if (v.empty() || *end || x < 0) { fprintf(stderr, "error: invalid value '%s' for '%s'\n", v.c_str(), opt.c_str()); exit(2); }
+    return x;
+}
+double to_double(const std::string& opt, const std::string& v) {
+    char* end = nullptr;
+    const double x = strtod(v.c_str(), &end);
+    if (v.empty() || *end) { fprintf(stderr, "error: invalid value '%s' for '%s'\n", v.c_str(), opt.c_str()); exit(2); }
+    return x;
+}
+
+Args parse_args(int argc, char** argv) {
+    if (argc < 2) usage(2);
+    Args a;
+    a.mode = argv[1];
+    if (a.mode == "--help" || a.mode == "-h" || a.mode == "help") usage(0);
+    if (a.mode == "--version" || a.mode == "-V") { printf("bronko %s\n", kVersion); exit(0); }
+    if (a.mode != "build" && a.mode != "call") { fprintf(stderr, "error: unrecognized subcommand '%s'\n", a.mode.c_str()); usage(2); }
+    if (argc < 3) usage(2);   // arg_required_else_help
+    const bool call = a.mode == "call";
+    a.output = call ? "bronko_output" : "bronko";   // consts.rs:20-21
+
+    std::vector<std::string> tok;
+    for (int i = 2; i < argc; i++) tok.push_back(argv[i]);
+    size_t i = 0;
+    auto is_flag = [](const std::string& s) { return s.size() >= 2 && s[0] == '-' && !(isdigit((unsigned char)s[1]) && s.size() > 2 && s[1] != '1' && s[1] != '2'); };
+    while (i < tok.size()) {
+        std::string opt = tok[i++], inline_val;
+        bool has_inline = false;
+        if (opt.rfind("--", 0) == 0) {
+            const size_t eq = opt.find('=');
+            if (eq != std::string::npos) { inline_val = opt.substr(eq + 1); opt.resize(eq); has_inline = true; }
+        } else if (opt.size() > 2 && opt[0] == '-') {   // -k21 / -k=21
+            inline_val = opt.substr(opt[2] == '=' ? 3 : 2);
+            opt.resize(2);
+            has_inline = true;
+        }
+        if (opt == "-h" || opt == "--help") usage(0);
+        if (opt == "-V" || opt == "--version") { printf("bronko %s\n", kVersion); exit(0); }
+        auto one = [&]() -> std::string {
+            if (has_inline) return inline_val;
+            if (i >= tok.size()) { fprintf(stderr, "error: a value is required for '%s'\n", opt.c_str()); exit(2); }
+            return tok[i++];
+        };
+        auto many = [&](std::vector<std::string>& dst) {   // num_args = 1..
+            if (has_inline) dst.push_back(inline_val);
+            const size_t before = dst.size();
+            while (i < tok.size() && !(tok[i].size() >= 2 && tok[i][0] == '-')) dst.push_back(tok[i++]);
+            if (!has_inline && dst.size() == before) { fprintf(stderr, "error: a value is required for '%s'\n", opt.c_str()); exit(2); }
+        };
+        (void)is_flag;
+        if (opt == "-g" || opt == "--genomes") { many(a.genomes); a.has_genomes = true; }
+        else if (opt == "-k" || opt == "--kmer-size") a.kmer = to_long(opt, one());
+        else if (opt == "-o" || opt == "--output") a.output = one();
+        else if (opt == "-t" || opt == "--threads") a.threads = to_long(opt, one());
+        else if (opt == "--debug") a.debug = true;
+        else if (opt == "--verbose") a.verbose = true;
+        else if (!call) { fprintf(stderr, "error: unexpected argument '%s' found\n", opt.c_str()); exit(2); }
+        else if (opt == "-d" || opt == "--db") { a.db = one(); a.has_db = true; }
+        else if (opt == "-r" || opt == "--reads") many(a.reads);
+        else if (opt == "-1" || opt == "--first-pairs") many(a.first_pairs);
+        else if (opt == "-2" || opt == "--second-pairs") many(a.second_pairs);
+        else if (opt == "--min-kmers") a.min_kmers = to_long(opt, one());
+        else if (opt == "--use-full-kmer") a.use_full_kmer = true;
+        else if (opt == "--n-fixed") a.n_fixed = to_long(opt, one());
+        else if (opt == "--min-af") a.min_af = to_double(opt, one());
+        else if (opt == "--no-end-filter") a.no_end_filter = true;
+        else if (opt == "--no-strand-filter") a.no_strand_filter = true;
+        else if (opt == "--no-strand-balance-filter") a.no_strand_balance_filter = true;
+        else if (opt == "--balance-ratio") a.balance_ratio = to_double(opt, one());
+        else if (opt == "--n-per-strand") a.n_per_strand = to_long(opt, one());
+        else if (opt == "--strand_odds") a.strand_odds = to_double(opt, one());
+        else if (opt == "--min-depth") a.min_depth = to_long(opt, one());
+        else if (opt == "--min-variant-depth") a.min_variant_depth = to_long(opt, one());
+        else if (opt == "--noise-multiplier") a.noise_multiplier = to_double(opt, one());
+        else if (opt == "--pileup") a.pileup = true;
+        else if (opt == "--alignment") a.alignment = true;
+        else if (opt == "--keep-kmer-info") a.keep_kmer_info = true;
+        else { fprintf(stderr, "error: unexpected argument '%s' found\n", opt.c_str()); exit(2); }
+    }
+    return a;
+}
+
+void init_logging(const Args& a) { g_level = a.verbose ? 4 : a.debug ? 3 : 2; }
+
+void check_common(const Args& a, const char* target) {
+    if (a.kmer % 2 != 1 || a.kmer > 31 || a.kmer < 15)   // build.rs:79, call.rs:46
+        die(target, "Invalid kmer size, must be odd and between [15-31]");
+    const long avail = (long)std::thread::hardware_concurrency();
+    if (a.threads <= 0) die(target, "Number of threads must be greater than 0");
+    if (avail > 0 && a.threads > avail)
+        die(target, "You requested " + std::to_string(a.threads) + " threads but only have " + std::to_string(avail) + " available on your system");
+}
+
+// ---- bronko build (build.rs:102-120) ------------------------------------------------------------------------
+int run_build(const Args& a) {
+    const char* T = "bronko::build";
+    init_logging(a);
+    if (a.kmer % 2 != 1 || a.kmer > 31 || a.kmer < 15) die(T, "Invalid kmer size, must be odd and between [15-31]");
+    for (const auto& g : a.genomes)
+        if (!check_fasta(g)) die(T, g + " does not appear to be a fasta file (must be .fa(.gz)/.fasta(.gz)/.fna(.gz))");
+    check_common(a, T);
+    LOG_INFO(T, "Building indexes from fasta files");
+    Index ix;
+    try { ix = build_indexes((int)a.kmer, a.genomes, (int)a.threads); }
+    catch (const std::exception& e) { die(T, std::string(e.what()) + " | Reference failed to build"); }
+    const std::string out = a.output + ".bkdb";
+    LOG_INFO(T, "Saving index to " + out);
+    try { save_index(ix, out); }
+    catch (const std::exception& e) { die(T, std::string(e.what()) + " | Unable to save index"); }
+    return 0;
+}
+
+// ---- bronko call ----------------------------------------------------------------------------------------------
+void check_call_args(const Args& a) {   // call.rs:30-136
+    const char* T = "bronko::call";
+    if (a.kmer % 2 != 1 || a.kmer > 31 || a.kmer < 15) die(T, "Invalid kmer size, must be odd and between [15-31]");
+    for (const auto& f : a.reads)
+        if (!check_fastq(f)) die(T, f + " does not appear to be a fastq file (must be .fq(.gz)/.fastq(.gz)/.fnq(.gz))");
+    if (a.has_genomes && a.has_db) die(T, "Please provide either a db or the genomes you would like to index, not both.");
+    if (!a.has_genomes && !a.has_db) die(T, "Please provide either a db or the genomes you would like to index.");
+    for (const auto& g : a.genomes)
+        if (!check_fasta(g)) die(T, g + " does not appear to be a fasta file (must be .fa(.gz)/.fasta(.gz)/.fna(.gz))");
+    check_common(a, T);
+    if (a.min_af < 0.01) LOG_WARN(T, "Minimum allele frequency set below 0.01, more false positive variants will be returned. We suggest setting this to a more realistic threshold (0.01-0.05)");
+    else if (a.min_af > 1.0) die(T, "Minimum allele frequency set above 1, please set between 0-1 (recommended between 0.01-0.05)");
+    else if (a.min_af >= 0.5) LOG_WARN(T, "Minimum allele frequency set equal to or greater than 0.5, no minor variants will be returned");
+    if (a.n_per_strand <= 0) LOG_WARN(T, "Number of kmers per strand set to 0, this is equivalent to no strand filtering");
+    else if (a.n_per_strand >= a.kmer) die(T, "Number of kmers per strand set >= k, please set lower value (recommended 2-4, default 2)");
+    else if (a.n_per_strand >= 5) LOG_WARN(T, "Number of kmers per strand set very high, only strongly supported variants will be returned");
+    if (a.balance_ratio < 0.0) die(T, "Strand balance ratio is set to below 0, must be between 0.0 and 1.0");
+    else if (a.balance_ratio > 1.0) die(T, "Strand balance ratio is set above 1, must be between 0.0 and 1.0");
+    else if (a.balance_ratio == 1.0) LOG_WARN(T, "Strand balance ratio is set to 1, all variants will pass this filter");
+    if (a.noise_multiplier < 1.0) die(T, "Noise multiplier for variant detection is set to below 1.0, must be greater than 1.0 (recommended between 1.3-2.0)");
+    else if (a.noise_multiplier > 2.0) LOG_WARN(T, "Strand balance ratio is set above 2, may experience a drop in recall (we recommend ~1.5)");
+    else if (a.noise_multiplier == 1.0) LOG_WARN(T, "Noise multiplier for variant detection set to 1.0, all variants will pass this filter");
+    if (a.first_pairs.size() != a.second_pairs.size()) die(T, "Number of paired end sequences do not match, exiting.");
+}
+
+struct Engine {
+    bk_engine* e = nullptr;
+    ~Engine() { if (e) bk_engine_destroy(e); }
+};
+
+void hip_check(int rc, const char* what) {
+    if (rc != 0) die("bronko::call", std::string(what) + ": " + bk_last_error());
+}
+
+// One mate file: FASTQ(.gz) -> 2-bit records (K0) -> bk_push_reads_packed, in batches.  Returns reads seen.
+uint64_t push_fastq(bk_engine* e, int mate, const std::string& path, int k) {
+    constexpr uint64_t kBatchReads = 1u << 19;
+    GzLineReader in(path);
+    std::string line, buf;
+    std::vector<uint64_t> off{0};
+    std::vector<uint32_t> words;
+    std::vector<uint16_t> lens;
+    uint64_t n_reads = 0, ln = 0;
+    size_t longest = (size_t)k;
+    auto flush = [&]() {
+        if (off.size() <= 1) return;
+        const uint32_t stride = (uint32_t)std::min<size_t>((longest + 15) / 16, 4095);
+        const uint8_t* base = reinterpret_cast<const uint8_t*>(buf.data());
+        const uint64_t n_rec = bk_pack_reads_flat(base, off.data(), off.size() - 1, k, stride, nullptr, nullptr, 0);
+        words.assign((size_t)n_rec * stride + 1, 0u);
+        lens.assign((size_t)n_rec + 1, 0);
+        bk_pack_reads_flat(base, off.data(), off.size() - 1, k, stride, words.data(), lens.data(), n_rec);
+        hip_check(bk_push_reads_packed(e, mate, words.data(), stride, lens.data(), n_rec), "bk_push_reads_packed");
+        buf.clear(); off.assign(1, 0); longest = (size_t)k;
+    };
+    while (in.next(line)) {
+        if ((ln++ & 3) != 1) continue;           // 4-line FASTQ records: @id / sequence / + / quality
+        buf += line;
+        off.push_back(buf.size());
+        longest = std::max(longest, line.size());
+        if (++n_reads % kBatchReads == 0) flush();
+    }
+    flush();
+    return n_reads;
+}
+
+int run_call(const Args& a) {
+    const char* T = "bronko::call";
+    init_logging(a);
+    check_call_args(a);
+    LOG_TRACE(T, "k=" + std::to_string(a.kmer) + ", threads=" + std::to_string(a.threads));
+    if (mkdir(a.output.c_str(), 0777) != 0 && errno != EEXIST) {
+        // create_dir_all: create missing parents too
+        std::string partial;
+        for (size_t i = 0; i <= a.output.size(); i++) {
+            if (i == a.output.size() || a.output[i] == '/') { if (!partial.empty()) mkdir(partial.c_str(), 0777); }
+            if (i < a.output.size()) partial += a.output[i];
+        }
+        struct stat st;
+        if (stat(a.output.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) die(T, "Unable to create outputs in output directory 2");
+    }
+
+    Index ix;
+    if (a.has_genomes) {                                            // call.rs:170-178
+        LOG_INFO(T, "Creating bronko index from provided reference genomes");
+        try { ix = build_indexes((int)a.kmer, a.genomes, (int)a.threads); }
+        catch (const std::exception& e) { die(T, std::string(e.what()) + " | Reference failed to build"); }
+    } else {                                                        // call.rs:179-200
+        LOG_INFO(T, "Reading in provided bronko index");
+        try { ix = load_index(a.db); }
+        catch (const std::exception& e) { die(T, e.what()); }
+        if (ix.k != a.kmer)
+            die(T, "Database k is not the same as provided, please set -k to " + std::to_string(ix.k) + " or build a new index");
+    }
+
+    // decoded index -> GPU engine (include/bronko_hip.h)
+    Engine eng;
+    {
+        std::vector<int32_t> n_seqs;
+        std::vector<uint64_t> seq_lens;
+        std::vector<const uint8_t*> seqs;
+        for (const auto& f : ix.files) {
+            n_seqs.push_back((int32_t)f.sequences.size());
+            for (const auto& s : f.sequences) { seq_lens.push_back(s.len); seqs.push_back(s.seq.data()); }
+        }
+        bk_index_desc d{};
+        d.k = ix.k; d.n_buckets = ix.ids.size(); d.bucket_ids = ix.ids.data(); d.bucket_off = ix.off.data();
+        d.entries = reinterpret_cast<const bk_bucket_info*>(ix.entries.data()); d.n_entries = ix.entries.size();
+        d.n_files = (int32_t)ix.files.size(); d.n_seqs = n_seqs.data(); d.seq_lens = seq_lens.data(); d.seqs = seqs.data();
+        bk_params p;
+        bk_params_default(&p);
+        p.n_fixed = (int32_t)a.n_fixed; p.use_full_kmer = a.use_full_kmer ? 1 : 0; p.ci = (uint64_t)a.min_kmers;
+        if (const char* dv = getenv("BRONKO_DEVICE")) p.device = atoi(dv);
+        hip_check(bk_engine_create(&d, &p, &eng.e), "bk_engine_create");
+    }
+
+    CallParams cp;
+    cp.k = (int)a.kmer; cp.min_af = a.min_af; cp.no_end_filter = a.no_end_filter; cp.no_strand_filter = a.no_strand_filter;
+    cp.no_strand_balance_filter = a.no_strand_balance_filter; cp.strand_balance_ratio = a.balance_ratio;
+    cp.n_per_strand = (uint64_t)a.n_per_strand; cp.strand_odds_max = a.strand_odds; cp.min_depth = (uint64_t)a.min_depth;
+    cp.min_variant_depth = (uint64_t)a.min_variant_depth; cp.variant_multiplier = a.noise_multiplier;
+
+    const size_t n_files = ix.files.size();
+    const uint64_t cells4 = ix.total_cells() * 4;
+    std::vector<OverviewRow> overview;
+
+    // one sample = one -r file (call.rs:213-293) or one R1/R2 pair (call.rs:298-386); outputs are named after R1
+    auto process = [&](const std::vector<std::string>& mates) {
+        const int n_mates = (int)mates.size();
+        hip_check(bk_sample_begin(eng.e), "bk_sample_begin");
+        uint64_t total_reads = 0;
+        for (int m = 0; m < n_mates; m++) {
+            try { total_reads += push_fastq(eng.e, m, mates[m], ix.k); }
+            catch (const std::exception& e) { die(T, e.what()); }
+        }
+        LOG_INFO(T, std::to_string(total_reads) + " reads counted from " + mates[0]);
+        Pileup p;
+        p.fwd_depth.resize(cells4); p.rev_depth.resize(cells4); p.fwd_nk.resize(cells4); p.rev_nk.resize(cells4);
+        std::vector<uint64_t> stats((size_t)n_mates * n_files * 3), kstats((size_t)n_mates * 4);
+        std::vector<uint8_t> present((size_t)n_mates * n_files);
+        LOG_INFO(T, "Mapping kmers to all genomes");
+        hip_check(bk_sample_finish(eng.e, n_mates, p.fwd_depth.data(), p.rev_depth.data(), p.fwd_nk.data(), p.rev_nk.data(),
+                                   stats.data(), present.data(), kstats.data()), "bk_sample_finish");
+        p.stats.assign(n_files * 3, 0);
+        p.present.assign(n_files, 0);
+        uint64_t kept = 0;
+        for (int m = 0; m < n_mates; m++) {                          // pick_best_genome_paired sums R1 + R2 (call.rs:457-474)
+            for (size_t i = 0; i < n_files * 3; i++) p.stats[i] += stats[(size_t)m * n_files * 3 + i];
+            for (size_t f = 0; f < n_files; f++) p.present[f] |= present[(size_t)m * n_files + f];
+            kept += kstats[(size_t)m * 4 + 3];
+        }
+        LOG_INFO(T, "Selecting the most representative genome");
+        const int best = pick_best_genome(ix, p.stats, p.present);
+        if (best < 0) die(T, "Unable to pick a best genome");
+        const std::string& gname = ix.files[best].name;
+        LOG_INFO(T, "Selected a representative genome: " + gname);
+        const uint64_t n_perfect = p.stats[(size_t)best * 3], n_variant = p.stats[(size_t)best * 3 + 1];
+        // KMC's "unique counted k-mers" over ALL k-mers is not produced by the GPU path; the
+        // count of kept k-mers that touch the index stands in, so "unmapped" = kept k-mers that only hit other genomes
+        const uint64_t n_unmapped = kept >= n_perfect + n_variant ? kept - n_perfect - n_variant : 0;
+        LOG_INFO(T, "Mapped " + std::to_string(n_perfect) + "/" + std::to_string(kept) + " kmers perfectly (" +
+                        std::to_string(p.stats[(size_t)best * 3 + 2]) + " unique among refs), " + std::to_string(n_variant) + "/" +
+                        std::to_string(kept) + " had a variant");
+        LOG_INFO(T, "Calling variants for " + gname);
+        const CallSummary cs = call_variants(ix, best, p, cp);
+        LOG_INFO(T, "Called " + std::to_string(cs.n_major) + " major variants, " + std::to_string(cs.n_minor) + " minor above maf = " + std::to_string(a.min_af));
+        const std::string stem = clean_sample_id(mates[0]);
+        try {
+            if (a.pileup) { LOG_INFO(T, "Writing output to pileup"); write_pileup_tsv(a.output + "/" + stem + ".tsv", ix, best, p); }
+            LOG_INFO(T, "Writing output to VCF");
+            write_vcf(a.output + "/" + stem + ".vcf", mates[0], ix, best, cs.records);
+        } catch (const std::exception& e) { die(T, e.what()); }
+        overview.push_back(OverviewRow{mates[0], gname, cs.n_major, cs.n_minor, cs.breadth, cs.depth, n_perfect, n_variant, n_unmapped});
+    };
+
+    for (const auto& r : a.reads) { LOG_INFO(T, "Processing " + r); process({r}); }
+    for (size_t i = 0; i < a.first_pairs.size(); i++) {
+        LOG_INFO(T, "Processing paired reads " + a.first_pairs[i] + ", " + a.second_pairs[i]);
+        process({a.first_pairs[i], a.second_pairs[i]});
+    }
+    LOG_INFO(T, "Printing overview");
+    try { write_overview_tsv(a.output + "/bronko_overview.tsv", overview); }
+    catch (const std::exception& e) { die(T, e.what()); }
+    LOG_INFO(T, "All samples processed successfully");
+    if (a.alignment) LOG_WARN(T, "--alignment (.mfa output, call.rs:504-628) is not implemented in this build");
+    LOG_INFO(T, "");
+    LOG_INFO(T, "bronko complete!");
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    printf("bronko v%s\nMI355X (gfx950) k-mer -> pileup engine; drop-in for treangenlab/bronko's build / call\n\n", kVersion);
+    fflush(stdout);
+    const auto t0 = std::chrono::steady_clock::now();
+    const Args a = parse_args(argc, argv);
+    const int rc = a.mode == "build" ? run_build(a) : run_call(a);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "\nbronko v%s finished in %gs\n", kVersion, dt);   // main.rs:28
+    return rc;
+}

@@ -1,10 +1,12 @@
 // host_api.cpp -- flat C entry points over the C++ host code (index build / .bkdb codec) so that the Python
 // test + bench harness can drive the same code the `bronko` binary runs.  Not the drop-in boundary (that is
 // include/bronko_hip.h); errors are returned as NULL / non-zero with bh_last_error().
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
 
+#include "caller.hpp"
 #include "index.hpp"
 
 namespace {
@@ -70,5 +72,51 @@ uint64_t bh_index_seq_len(const void* h, int f, int s) { return IX->files[f].seq
 const uint8_t* bh_index_seq(const void* h, int f, int s) { return IX->files[f].sequences[s].seq.data(); }
 uint64_t bh_index_total_cells(const void* h) { return IX->total_cells(); }
 #undef IX
+
+// ---- caller stages (so that tests can drive the same code the `bronko` binary runs) ---------------------------
+struct bh_call_params {   // mirrors bronko::CallParams
+    int32_t k; double min_af; int32_t no_end_filter, no_strand_filter, no_strand_balance_filter; double strand_balance_ratio;
+    uint64_t n_per_strand; double strand_odds_max; uint64_t min_depth, min_variant_depth; double variant_multiplier;
+};
+
+int bh_pick_best_genome(const void* h, const uint64_t* stats, const uint8_t* present) {
+    const auto* ix = static_cast<const bronko::Index*>(h);
+    const size_t nf = ix->files.size();
+    return bronko::pick_best_genome(*ix, std::vector<uint64_t>(stats, stats + nf * 3), std::vector<uint8_t>(present, present + nf));
+}
+
+void bh_baseline_noise_max(const uint64_t* fwd4, const uint64_t* rev4, uint64_t len, double* out) {
+    const std::vector<double> v = bronko::baseline_noise_max(fwd4, rev4, len);
+    std::memcpy(out, v.data(), v.size() * sizeof(double));
+}
+
+// call_variants on the given arrays + writers.  summary = {n_records, n_major, n_minor}; cov = {breadth, depth}.
+int bh_call_and_write(const void* h, int file_id, const uint64_t* fwd_depth, const uint64_t* rev_depth, const uint64_t* fwd_nk,
+                      const uint64_t* rev_nk, const bh_call_params* cp, const char* vcf_path, const char* reads_path,
+                      const char* pileup_path, uint64_t* summary, double* cov) {
+    try {
+        const auto* ix = static_cast<const bronko::Index*>(h);
+        const size_t n = ix->total_cells() * 4;
+        bronko::Pileup p;
+        p.fwd_depth.assign(fwd_depth, fwd_depth + n); p.rev_depth.assign(rev_depth, rev_depth + n);
+        p.fwd_nk.assign(fwd_nk, fwd_nk + n); p.rev_nk.assign(rev_nk, rev_nk + n);
+        bronko::CallParams c;
+        c.k = cp->k; c.min_af = cp->min_af; c.no_end_filter = cp->no_end_filter; c.no_strand_filter = cp->no_strand_filter;
+        c.no_strand_balance_filter = cp->no_strand_balance_filter; c.strand_balance_ratio = cp->strand_balance_ratio;
+        c.n_per_strand = cp->n_per_strand; c.strand_odds_max = cp->strand_odds_max; c.min_depth = cp->min_depth;
+        c.min_variant_depth = cp->min_variant_depth; c.variant_multiplier = cp->variant_multiplier;
+        const bronko::CallSummary cs = bronko::call_variants(*ix, file_id, p, c);
+        if (vcf_path) bronko::write_vcf(vcf_path, reads_path ? reads_path : "", *ix, file_id, cs.records);
+        if (pileup_path) bronko::write_pileup_tsv(pileup_path, *ix, file_id, p);
+        if (summary) { summary[0] = cs.records.size(); summary[1] = cs.n_major; summary[2] = cs.n_minor; }
+        if (cov) { cov[0] = cs.breadth; cov[1] = cs.depth; }
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
+void bh_clean_sample_id(const char* path, char* buf, size_t n) {
+    const std::string s = bronko::clean_sample_id(path);
+    snprintf(buf, n, "%s", s.c_str());
+}
 
 }  // extern "C"

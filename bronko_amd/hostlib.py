@@ -125,3 +125,64 @@ class HostIndex:
         """bk_engine_create on this index."""
         from .engine import Engine
         return Engine(self.k, self.bucket_ids(), self.bucket_off(), self.entries(), self.files(), params)
+
+
+class CallParams(C.Structure):  # bh_call_params == bronko::CallParams (cli.rs:92-135 defaults from consts.rs)
+    _fields_ = [("k", C.c_int32), ("min_af", C.c_double), ("no_end_filter", C.c_int32), ("no_strand_filter", C.c_int32),
+                ("no_strand_balance_filter", C.c_int32), ("strand_balance_ratio", C.c_double), ("n_per_strand", C.c_uint64),
+                ("strand_odds_max", C.c_double), ("min_depth", C.c_uint64), ("min_variant_depth", C.c_uint64),
+                ("variant_multiplier", C.c_double)]
+
+
+def default_call_params(k=21):
+    return CallParams(k, 0.03, 0, 0, 0, 0.1, 2, 6.0, 300, 3, 1.5)
+
+
+def _caller_lib():
+    L = load()
+    if not hasattr(L, "_caller_ready"):
+        vp = C.c_void_p
+        L.bh_pick_best_genome.restype = C.c_int
+        L.bh_pick_best_genome.argtypes = [vp, vp, vp]
+        L.bh_baseline_noise_max.restype = None
+        L.bh_baseline_noise_max.argtypes = [vp, vp, C.c_uint64, vp]
+        L.bh_call_and_write.restype = C.c_int
+        L.bh_call_and_write.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.POINTER(CallParams), C.c_char_p, C.c_char_p, C.c_char_p, vp, vp]
+        L.bh_clean_sample_id.restype = None
+        L.bh_clean_sample_id.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L._caller_ready = True
+    return L
+
+
+def pick_best_genome(ix, stats, present):
+    stats = np.ascontiguousarray(stats, np.uint64)
+    present = np.ascontiguousarray(present, np.uint8)
+    return _caller_lib().bh_pick_best_genome(ix.h, stats.ctypes.data, present.ctypes.data)
+
+
+def baseline_noise_max(fwd4, rev4):
+    fwd4 = np.ascontiguousarray(fwd4, np.uint64)
+    rev4 = np.ascontiguousarray(rev4, np.uint64)
+    out = np.zeros(len(fwd4) // 4)
+    _caller_lib().bh_baseline_noise_max(fwd4.ctypes.data, rev4.ctypes.data, len(out), out.ctypes.data)
+    return out
+
+
+def call_and_write(ix, file_id, arrays, params, vcf_path=None, reads_path="", pileup_path=None):
+    """call_variants + writers on four pileup arrays.  Returns (n_records, n_major, n_minor, breadth, depth)."""
+    a = [np.ascontiguousarray(x, np.uint64) for x in arrays]
+    summary = np.zeros(3, np.uint64)
+    cov = np.zeros(2)
+    L = _caller_lib()
+    rc = L.bh_call_and_write(ix.h, file_id, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data,
+                             C.byref(params), vcf_path.encode() if vcf_path else None, reads_path.encode(),
+                             pileup_path.encode() if pileup_path else None, summary.ctypes.data, cov.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("bronko host: " + L.bh_last_error().decode(errors="replace"))
+    return int(summary[0]), int(summary[1]), int(summary[2]), float(cov[0]), float(cov[1])
+
+
+def clean_sample_id(path):
+    buf = C.create_string_buffer(4096)
+    _caller_lib().bh_clean_sample_id(path.encode(), buf, 4096)
+    return buf.value.decode()

@@ -1,0 +1,103 @@
+"""End-to-end drop-in check (BASELINE config 1 shape): the `bronko` binary on real .fastq.gz files against the
+oracle's orchestration of call.rs:212-387 -- VCF and pileup TSV must be byte-identical."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from bronko_amd import synth
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BRONKO = os.path.join(ROOT, "bronko_amd", "bin", "bronko")
+
+
+def write_fastq_gz(path, reads, tag):
+    with gzip.open(path, "wb", compresslevel=1) as f:
+        for i, r in enumerate(reads):
+            f.write(b"@%s_%d\n%s\n+\n%s\n" % (tag.encode(), i, r, b"I" * len(r)))
+
+
+def oracle_outputs(oracle, ix, mates, out_dir, reads_path, k=21, **kw):
+    pile = oracle.sample_pileup(ix, mates, **kw)
+    stats = pile.stats.sum(axis=0)
+    best = oracle.pick_best_genome(ix, stats, pile.present.max(axis=0))
+    recs, ptr, n, nmaj, nmin, br, dc = oracle.call_variants(ix, best, pile, oracle.default_call_params(k))
+    stem = oracle.clean_sample_id(reads_path)
+    oracle.write_vcf(os.path.join(out_dir, stem + ".vcf"), reads_path, ix, best, ptr, n)
+    oracle.write_pileup(os.path.join(out_dir, stem + ".tsv"), ix, best, pile)
+    return stem, best, n
+
+
+def test_call_paired_hpv_fastq_gz(oracle, golden_dir, tmp_path):
+    """2 x 20,000 synthetic HPV16 pairs (+N symbols in some reads) as .fastq.gz, prebuilt golden hpv.bkdb."""
+    g = synth.read_fasta_bytes(os.path.join(golden_dir, "HPV16.fa"))
+    gm, isnv = synth.sample_genome(g, 1, n_snp=5, n_isnv=5)
+    c1, c2 = synth.paired_codes(gm, 20000, 150, 1, isnv=isnv)
+    r1, r2 = synth.codes_to_ascii(c1), synth.codes_to_ascii(c2)
+    r1[7] = r1[7][:40] + b"N" + r1[7][41:]
+    r2[9] = b"n" * 150
+    p1, p2 = str(tmp_path / "rep1_R1.fastq.gz"), str(tmp_path / "rep1_R2.fastq.gz")
+    write_fastq_gz(p1, r1, "r1")
+    write_fastq_gz(p2, r2, "r2")
+    out = str(tmp_path / "out")
+    res = subprocess.run([BRONKO, "call", "-d", os.path.join(golden_dir, "hpv.bkdb"), "-1", p1, "-2", p2, "--pileup",
+                          "-o", out, "-t", "2"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    ix = oracle.Index.load(os.path.join(golden_dir, "hpv.bkdb"))
+    odir = str(tmp_path / "oracle")
+    os.makedirs(odir)
+    stem, best, n = oracle_outputs(oracle, ix, [r1, r2], odir, p1)
+    assert stem == "rep1_R1" and n >= 5
+    for ext in (".vcf", ".tsv"):
+        assert open(os.path.join(out, stem + ext), "rb").read() == open(os.path.join(odir, stem + ext), "rb").read(), ext
+    ov = open(os.path.join(out, "bronko_overview.tsv")).read().splitlines()
+    assert ov[0].split("\t")[:2] == ["filename", "selected_genome"] and ov[1].split("\t")[:2] == [p1, "HPV16"]
+    ix.close()
+
+
+def test_call_single_end_with_genomes_flag(oracle, sars_paths, tmp_path):
+    """`-g` builds the index on the fly (call.rs:170-178); 4 strains, sample derived from strain 1 (OM223929.1)."""
+    g = synth.read_fasta_bytes(sars_paths[1])
+    gm, isnv = synth.sample_genome(g, 4)
+    reads = synth.codes_to_ascii(synth.single_end_codes(gm, 30000, 150, 4, isnv=isnv))
+    fq = str(tmp_path / "s1.fq")
+    with open(fq, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b"@s_%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)))
+    out = str(tmp_path / "o")
+    res = subprocess.run([BRONKO, "call", "-g"] + sars_paths + ["-r", fq, "--pileup", "-o", out, "-t", "2"],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    ix = oracle.Index.build(21, sars_paths)
+    odir = str(tmp_path / "oracle")
+    os.makedirs(odir)
+    stem, best, n = oracle_outputs(oracle, ix, [reads], odir, fq)
+    assert best == 1 and stem == "s1"
+    for ext in (".vcf", ".tsv"):
+        assert open(os.path.join(out, stem + ext), "rb").read() == open(os.path.join(odir, stem + ext), "rb").read(), ext
+    ix.close()
+
+
+def test_cli_error_conventions(golden_dir, tmp_path):
+    """exit code 1 + a log line for the reference's error cases (call.rs:46-134, :193-197)."""
+    db = os.path.join(golden_dir, "hpv.bkdb")
+    fq = str(tmp_path / "x.fastq")
+    open(fq, "w").write("@a\nACGT\n+\nIIII\n")
+    cases = [
+        ["call", "-d", db, "-r", fq, "-k", "20"],                       # even k
+        ["call", "-d", db, "-r", str(tmp_path / "x.txt")],              # not a fastq suffix
+        ["call", "-r", fq],                                             # neither -d nor -g
+        ["call", "-d", db, "-g", os.path.join(golden_dir, "HPV16.fa"), "-r", fq],   # both
+        ["call", "-d", db, "-r", fq, "-k", "19"],                       # db k mismatch
+        ["call", "-d", db, "-1", fq],                                   # unpaired pairs
+        ["call", "-d", db, "-r", fq, "--min-af", "1.5"],
+        ["build", "-g", str(tmp_path / "x.txt")],                       # not a fasta suffix
+    ]
+    for c in cases:
+        res = subprocess.run([BRONKO] + c + ["-o", str(tmp_path / "e")], capture_output=True, text=True)
+        assert res.returncode == 1, (c, res.stdout, res.stderr)
+        assert "ERROR" in res.stdout

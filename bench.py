@@ -60,6 +60,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from bronko_amd import Params, synth
+    from bronko_amd.dist import allreduce_counters
     from bronko_amd.hostlib import HostIndex
 
     k = 21
@@ -85,7 +86,7 @@ def main():
         eng.sample_begin()
         eng.push_reads_device(0, d_words.data_ptr(), stride, d_lens.data_ptr(), n_rec)
         if world > 1:
-            dist.all_reduce(counters, op=dist.ReduceOp.SUM)   # RCCL over xGMI: u64 k-mer occurrence counters
+            allreduce_counters(counters)   # RCCL over xGMI: ONE all-reduce(sum) of the u64 k-mer occurrence counters
         eng.sample_finalize(1)
 
     def fence():

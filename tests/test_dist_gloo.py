@@ -1,0 +1,78 @@
+"""N>1 path on CPU (gloo, world_size 2): shard the reads of one sample, count per shard, all-reduce(sum) the
+occurrence counters through bronko_amd.dist, THEN threshold + map.  Must equal the single-process oracle.
+The same test shows why pileups themselves must not be reduced."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import helpers
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    from bronko_amd.dist import allreduce_counters, shard_bounds
+    from oracle import oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ix = orc.Index.load(os.path.join(helpers.GOLDEN, "hpv.bkdb"))
+        reads = helpers.hpv_reads(6000, seed=31, err=0.01)
+        # common key space = every distinct k-mer of the sample (stand-in for the engine's counter plane layout)
+        keys, _, _ = orc.count_kmers(21, reads, ci=1, cs=2 ** 62, cx=2 ** 62)
+        keys = np.sort(keys)
+        lo, hi = shard_bounds(len(reads), rank, world)
+        km, ct, _ = orc.count_kmers(21, reads[lo:hi], ci=1, cs=2 ** 62, cx=2 ** 62)
+        plane = np.zeros(len(keys), np.int64)
+        plane[np.searchsorted(keys, km)] = ct.astype(np.int64)
+        t = torch.from_numpy(plane)
+        allreduce_counters(t)                                    # the one exchange step
+        total = t.numpy().astype(np.uint64)
+        keep = (total >= 3) & (total <= 1000000000)              # -ci3 / -cx on the TRUE (reduced) count
+        pile = orc.Pileup(ix)
+        orc.map_kmers(ix, keys[keep], np.minimum(total[keep], 1000000), pile)
+        # the wrong way round: per-shard thresholds + map, pileups summed afterwards
+        shard_pile = orc.sample_pileup(ix, [reads[lo:hi]])
+        wrong = torch.from_numpy(shard_pile.fwd_depth.astype(np.int64))
+        dist.all_reduce(wrong)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "r0.npz"), fd=pile.fwd_depth, rd=pile.rev_depth, fk=pile.fwd_nk, rk=pile.rev_nk,
+                     stats=pile.stats, wrong=wrong.numpy().astype(np.uint64))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_bounds():
+    from bronko_amd.dist import shard_bounds
+    for n in (0, 1, 7, 1000003):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+def test_counter_allreduce_then_finalize_equals_single_process(oracle, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "r0.npz"))
+    ix = oracle.Index.load(os.path.join(helpers.GOLDEN, "hpv.bkdb"))
+    want = oracle.sample_pileup(ix, [helpers.hpv_reads(6000, seed=31, err=0.01)])
+    assert np.array_equal(got["fd"], want.fwd_depth) and np.array_equal(got["rd"], want.rev_depth)
+    assert np.array_equal(got["fk"], want.fwd_nk) and np.array_equal(got["rk"], want.rev_nk)
+    assert np.array_equal(got["stats"], want.stats)
+    # summing per-shard pileups is NOT the pileup of the sample
+    assert (got["wrong"] != want.fwd_depth).sum() > 100
+    ix.close()

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--cpu-sample", type=int, default=200000, help="reads timed through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ref-len", type=int, default=0, help="experiment: truncate the reference to its first N bases")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -65,11 +66,15 @@ def main():
 
     k = 21
     ref_path = os.path.join(ROOT, "tests", "golden", "4_sarscov2", "wuhan_ref.fasta")
-    ix = HostIndex.build(k, [ref_path], threads=4)
+    ref = synth.read_fasta_bytes(ref_path)
+    if args.ref_len:
+        ref = ref[:args.ref_len]
+        ix = HostIndex.build_mem(k, [("wuhan_ref", [("trunc", ref)])], threads=4)
+    else:
+        ix = HostIndex.build(k, [ref_path], threads=4)
     eng = ix.engine(Params(device=local_rank))
 
     # synthetic sample: reference + 20 SNPs + 20 iSNVs, 0.5 % substitution errors
-    ref = synth.read_fasta_bytes(ref_path)
     genome, isnv = synth.sample_genome(ref, 2)
     codes = synth.single_end_codes(genome, args.reads, args.read_len, 2 * 1000003 + rank, err=0.005, isnv=isnv)
     words, lens = synth.pack_codes(codes)

@@ -48,10 +48,21 @@ BK_HD uint32_t phf_pos(uint64_t x, uint32_t pilot, uint32_t m) {
     return (uint32_t)(((uint64_t)h * m) >> 32);
 }
 
+// Perfect-hash table entry of a reference k-mer: key, where it first occurs in the reference, and its id.
+// Reference k-mers are numbered ("id") in order of first occurrence in reference order, so that the k-mers
+// along a stretch of reference have consecutive ids; the id names the k-mer's E and V counters.
+struct alignas(16) KmerPos {
+    uint64_t key;      // canonical reference k-mer (kEmptyKey = free position)
+    uint32_t refcell;  // cell of its first occurrence (cells = positions of all sequences concatenated in
+                       // (file, seq) order = the pileup row order)
+    uint32_t idflags;  // id | (1u << 31 if that occurrence was reverse-complemented to become canonical)
+};
+constexpr uint32_t kIdMask = 0x7fffffffu;
+
 // A reference k-mer in a neighbour list: 16 B so that one candidate is one global_load_dwordx4.
 struct alignas(16) NbEntry {
     uint64_t u;      // canonical reference k-mer
-    uint32_t p;      // its position in kmer_pos (names its E and V counters)
+    uint32_t p;      // its id (names its E and V counters)
     uint32_t pad;
 };
 
@@ -83,9 +94,21 @@ struct HalfView {
 //  * table (+ slot_key, slot_t, ent_off, ent_len, entries): the index itself, window buckets keyed by
 //    (wildcard position, masked k-mer) with their BucketInfo lists; used by finalize to replay map_kmers.
 struct IndexView {
-    const uint64_t*  kmer_pos; // [m] perfect-hash table of U; position p owns E counters 2p, 2p+1
+    const KmerPos*   kmer_pos; // [m] perfect-hash table of U (membership test, diagonal seeding)
+    const uint64_t*  kmer_of;  // [n_u] id -> canonical k-mer
+    // the reference in reference order, for the diagonal walk of scan_count (staged in LDS when it fits):
+    const uint32_t*  ref_words;   // 2-bit packed bases of all cells (nt_to_bits, 16 per word, LSB first), padded
+    const uint32_t*  bits_clean;  // bit q: a k-mer starts at cell q, it is in U and it is "clean" (see amb)
+    const uint32_t*  bits_follow; // bit q: id(k-mer at q+1) == id(k-mer at q) + 1
+    const uint32_t*  bits_rc;     // bit q: the k-mer at q was reverse-complemented to become canonical
+    const uint32_t*  id_at;       // [total_cells] id of the k-mer starting at cell q (0xffffffff: none)
+    uint32_t total_cells;
+    uint32_t n_u;                 // |U| = number of ids
     const uint16_t*  pilots;   // [1 << log2nb]
     HalfView         lo, hi;
+    const uint32_t*  slot_of;  // [n_u][W] window bucket (slot) of reference k-mer id at window position t
+    const uint8_t*   amb;      // [n_u] 1 = "dirty": another reference k-mer (either strand) lies within Hamming
+                               //       distance 2 of it, or it is within distance 2 of its own reverse complement
     const TableSlot* table;    // [W][S]
     const uint32_t*  ent_off;  // [n_slots]
     const uint32_t*  ent_len;  // [n_slots]
@@ -101,14 +124,14 @@ struct IndexView {
     int32_t  n_files;
 };
 
-// Counter plane of one mate file, u64: [ E : 2 * m ][ V : m * W * 8 ]
-//   E[2p + rc]                        occurrences of the reference k-mer u = kmer_pos[p] read as-is (rc=0) / as
+// Counter plane of one mate file, u64: [ E : 2 * n_u ][ V : n_u * W * 8 ]
+//   E[2id + rc]                       occurrences of the reference k-mer u = kmer_of[id] read as-is (rc=0) / as
 //                                     its reverse complement (rc=1)
-//   V[((p*W + t)*4 + b)*2 + rc]       occurrences of the non-reference k-mer "u with base b at window position
+//   V[((id*W + t)*4 + b)*2 + rc]      occurrences of the non-reference k-mer "u with base b at window position
 //                                     wstart+t".  A non-reference k-mer may neighbour several reference k-mers;
-//                                     it is always counted under the smallest (t, p) -- a function of the k-mer
+//                                     it is always counted under the smallest (t, id) -- a function of the k-mer
 //                                     alone, so all its occurrences share one counter and it owns no other.
-BK_HD uint64_t e_plane_len(uint32_t m) { return 2ull * m; }
-BK_HD uint64_t v_plane_len(uint32_t m, int W) { return (uint64_t)m * (uint64_t)(W > 0 ? W : 0) * 8ull; }
+BK_HD uint64_t e_plane_len(uint32_t n_u) { return 2ull * n_u; }
+BK_HD uint64_t v_plane_len(uint32_t n_u, int W) { return (uint64_t)n_u * (uint64_t)(W > 0 ? W : 0) * 8ull; }
 
 }  // namespace bk

@@ -111,14 +111,19 @@ struct bk_engine {
     bk_params params{};
     int k = 0, wstart = 0, W = 0, n_files = 0;
     uint64_t total_cells = 0, n_slots = 0;
-    uint32_t log2s = 4, log2nb = 0, m = 1, n_lds_bins = 0;
-    bool pilots_in_lds = false;
+    uint32_t log2s = 4, log2nb = 0, m = 1, n_u = 0, n_lds_bins = 0;
+    bool ref_in_lds = false;
     int lo_bases = 0, n_cus = 256;
     int device = 0;
 
-    DevBuf<uint64_t> kmer_pos;
+    DevBuf<bk::KmerPos> kmer_pos;
+    DevBuf<bk::IndexView> d_view;   // device copy of view()
+    DevBuf<uint64_t> kmer_of;
+    DevBuf<uint32_t> ref_words, bits_clean, bits_follow, bits_rc, id_at;
     struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0; } half_lo, half_hi;
     DevBuf<unsigned int> deferred, n_deferred;
+    DevBuf<uint32_t> slot_of;
+    DevBuf<uint8_t> amb;
     DevBuf<uint16_t> pilots;
     DevBuf<unsigned int> slabs;             // [n_cus][n_lds_bins] workgroup histograms of the last scan launch
     DevBuf<unsigned int> e_planes;          // [8][E] u32, XCD-private planes for positions >= n_lds_bins
@@ -147,9 +152,11 @@ struct bk_engine {
     bk::IndexView view() const {
         bk::IndexView v{};
         v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb;
+        v.kmer_of = kmer_of.p; v.ref_words = ref_words.p; v.bits_clean = bits_clean.p; v.bits_follow = bits_follow.p;
+        v.bits_rc = bits_rc.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb};
-        v.lo_bases = lo_bases;
+        v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.amb = amb.p;
         v.table = table.p; v.ent_off = ent_off.p; v.ent_len = ent_len.p;
         v.entries = entries.p; v.n_slots = n_slots; v.log2s = log2s; v.k = k; v.wstart = wstart; v.W = W; v.n_files = n_files;
         return v;
@@ -304,19 +311,114 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         sub[h].slot = (uint32_t)s;
     }
 
-    // ---- reference k-mer set U: perfect hash (exact lookup) + half-key directories (neighbour lookup) --------
+    // ---- reference k-mer set U ------------------------------------------------------------------------------
+    // ids in order of first occurrence in reference order; perfect hash (membership + diagonal seeding);
+    // half-key directories (neighbour search); the reference in reference order (diagonal walk); per-id tables.
     std::sort(h_u.begin(), h_u.end());
     h_u.erase(std::unique(h_u.begin(), h_u.end()), h_u.end());
     e->lo_bases = k / 2;
+    if (h_u.size() >= (1ull << 31)) return fail(BK_ERR_UNSUPPORTED, "too many distinct reference k-mers");
+    e->n_u = (uint32_t)h_u.size();
     {
+        // walk the metadata sequences: ids, first occurrences, packed bases and the per-cell flag bits
+        std::unordered_map<uint64_t, uint32_t> idx_of;   // k-mer -> index into h_u
+        idx_of.reserve(h_u.size() * 2);
+        for (size_t i = 0; i < h_u.size(); i++) idx_of.emplace(h_u[i], (uint32_t)i);
+        const uint32_t kNone = 0xffffffffu;
+        std::vector<uint32_t> id_of(h_u.size(), kNone), first_cell(h_u.size(), kNone);
+        std::vector<uint8_t> first_rc(h_u.size(), 0);
+        const uint64_t cells = e->total_cells;
+        std::vector<uint32_t> h_id_at(std::max<uint64_t>(cells, 1), kNone);
+        std::vector<uint32_t> h_refw((cells + 15) / 16 + 4, 0u), h_brc((cells + 31) / 32 + 1, 0u);
+        uint32_t next_id = 0;
+        size_t sq = 0;
+        for (int f = 0; f < ix->n_files; f++) {
+            for (int sidx = 0; sidx < ix->n_seqs[f]; sidx++, sq++) {
+                const uint64_t len = ix->seq_lens[sq];
+                const uint8_t* seq = ix->seqs[sq];
+                const uint64_t c0 = cell_off[f][sidx];
+                for (uint64_t i = 0; i < len; i++) h_refw[(c0 + i) >> 4] |= (uint32_t)bronko::nt_to_bits(seq[i]) << (2 * ((c0 + i) & 15));
+                if (len < (uint64_t)k) continue;
+                const uint64_t mask = bronko::kmer_mask(k);
+                uint64_t fwd = 0;
+                for (int i = 0; i < k - 1; i++) fwd = (fwd << 2) | bronko::nt_to_bits(seq[i]);
+                for (uint64_t i = 0; i + k <= len; i++) {
+                    fwd = ((fwd << 2) | bronko::nt_to_bits(seq[i + k - 1])) & mask;
+                    const bronko::Canon cn = bronko::canonical_u64(fwd, k);
+                    const auto it = idx_of.find(cn.kmer);
+                    if (it == idx_of.end()) continue;   // not in the index: never predicted, never counted
+                    const uint32_t ui = it->second;
+                    const uint64_t cell = c0 + i;
+                    if (id_of[ui] == kNone) { id_of[ui] = next_id++; first_cell[ui] = (uint32_t)cell; first_rc[ui] = cn.rc ? 1 : 0; }
+                    h_id_at[cell] = id_of[ui];
+                    if (cn.rc) h_brc[cell >> 5] |= 1u << (cell & 31);
+                }
+            }
+        }
+        for (size_t i = 0; i < h_u.size(); i++)   // k-mers known only through index entries: ids after the others
+            if (id_of[i] == kNone) id_of[i] = next_id++;
+
+        // dirty flags (bk_device.h amb): another reference k-mer, on either strand, within Hamming distance 2, or
+        // the k-mer within distance 2 of its own reverse complement.  Any two 2k-bit words at distance <= 2 agree
+        // on at least one of three parts, so group all forms (u and rc(u)) by each part and compare inside groups.
+        std::vector<uint8_t> h_amb(h_u.size(), 0);   // by id
+        {
+            struct Form { uint64_t w; uint32_t id; };
+            std::vector<Form> forms;
+            forms.reserve(h_u.size() * 2);
+            for (size_t i = 0; i < h_u.size(); i++) {
+                forms.push_back(Form{h_u[i], id_of[i]});
+                forms.push_back(Form{bronko::reverse_complement_u64(h_u[i], k), id_of[i]});
+            }
+            const int cut[4] = {0, k / 3, (2 * k) / 3, k};
+            for (int part = 0; part < 3; part++) {
+                const uint64_t mask = (((1ull << (2 * (cut[part + 1] - cut[part]))) - 1ull) << (2 * cut[part]));
+                std::sort(forms.begin(), forms.end(), [&](const Form& x, const Form& y) { return (x.w & mask) < (y.w & mask); });
+                for (size_t a0 = 0; a0 < forms.size();) {
+                    size_t a1 = a0 + 1;
+                    while (a1 < forms.size() && (forms[a1].w & mask) == (forms[a0].w & mask)) a1++;
+                    if (a1 - a0 > 4096) {   // pathological low-complexity group: flag all, skip the quadratic pass
+                        for (size_t x = a0; x < a1; x++) h_amb[forms[x].id] = 1;
+                    } else {
+                        for (size_t x = a0; x < a1; x++)
+                            for (size_t y = x + 1; y < a1; y++) {
+                                const uint64_t d = forms[x].w ^ forms[y].w;
+                                if (__builtin_popcountll((d | (d >> 1)) & 0x5555555555555555ull) <= 2)
+                                    h_amb[forms[x].id] = h_amb[forms[y].id] = 1;   // also catches u vs rc(u) (same id)
+                            }
+                    }
+                    a0 = a1;
+                }
+            }
+        }
+        std::vector<uint32_t> h_bclean((cells + 31) / 32 + 1, 0u), h_bfollow((cells + 31) / 32 + 1, 0u);
+        for (uint64_t c = 0; c < cells; c++) {
+            if (h_id_at[c] == kNone) continue;
+            if (!h_amb[h_id_at[c]]) h_bclean[c >> 5] |= 1u << (c & 31);
+            if (c + 1 < cells && h_id_at[c + 1] != kNone && h_id_at[c + 1] == h_id_at[c] + 1) h_bfollow[c >> 5] |= 1u << (c & 31);
+        }
+
+        // perfect hash over U
         std::vector<uint16_t> h_pilots;
         std::vector<uint32_t> u_pos;
         if (!build_phf(h_u, h_pilots, e->log2nb, e->m, u_pos)) return fail(BK_ERR_UNSUPPORTED, "perfect hash construction failed");
-        std::vector<uint64_t> t_pos(e->m, bk::kEmptyKey);
-        for (size_t i = 0; i < h_u.size(); i++) t_pos[u_pos[i]] = h_u[i];
-        BK_HIP(e->kmer_pos.upload(t_pos));
+        std::vector<bk::KmerPos> t_pos(e->m, bk::KmerPos{bk::kEmptyKey, kNone, 0u});
+        std::vector<uint64_t> h_kmer_of(std::max<size_t>(h_u.size(), 1), bk::kEmptyKey);
+        for (size_t i = 0; i < h_u.size(); i++) {
+            t_pos[u_pos[i]] = bk::KmerPos{h_u[i], first_cell[i], id_of[i] | (first_rc[i] ? 0x80000000u : 0u)};
+            h_kmer_of[id_of[i]] = h_u[i];
+        }
         BK_HIP(e->pilots.upload(h_pilots));
+        BK_HIP(e->kmer_pos.upload(t_pos));
+        BK_HIP(e->kmer_of.upload(h_kmer_of));
+        BK_HIP(e->ref_words.upload(h_refw));
+        BK_HIP(e->bits_clean.upload(h_bclean));
+        BK_HIP(e->bits_follow.upload(h_bfollow));
+        BK_HIP(e->bits_rc.upload(h_brc));
+        BK_HIP(e->id_at.upload(h_id_at));
+        BK_HIP(e->amb.upload(h_amb));
 
+        // half-key directories (neighbour search)
         const int lo_bits = 2 * e->lo_bases;
         const uint64_t lo_mask = (1ull << lo_bits) - 1ull;
         for (int which = 0; which < 2; which++) {
@@ -332,7 +434,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             std::vector<uint32_t> first, count;
             for (size_t i = 0; i < order.size(); i++) {
                 const uint64_t u = h_u[order[i]];
-                cand[i] = bk::NbEntry{u, u_pos[order[i]], 0u};
+                cand[i] = bk::NbEntry{u, id_of[order[i]], 0u};
                 if (halves.empty() || halves.back() != half_of(u)) { halves.push_back(half_of(u)); first.push_back((uint32_t)i); count.push_back(0); }
                 count.back()++;
             }
@@ -346,16 +448,34 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             BK_HIP(hb.dir.upload(dir));
             BK_HIP(hb.cand.upload(cand));
         }
+
+        // slot_of[id*W + t]: the window bucket (wstart+t, u masked) of reference k-mer id -- every reference k-mer
+        // owns all of its buckets, so finalize needs no table probe for them.
+        std::vector<uint32_t> h_slot_of((size_t)std::max<size_t>(h_u.size(), 1) * std::max(e->W, 1), 0u);
+        for (size_t i = 0; i < h_u.size(); i++) {
+            for (int t = 0; t < e->W; t++) {
+                const uint64_t key = h_u[i] & ~(3ull << (2 * (k - 1 - (e->wstart + t))));
+                const bk::TableSlot* sub = h_table.data() + (size_t)t * S;
+                uint32_t h = bk::hash_key(key, e->log2s);
+                while (sub[h].key != key) {
+                    if (sub[h].key == bk::kEmptyKey) return fail(BK_ERR_INVALID, "index lacks a window bucket of one of its own reference k-mers");
+                    h = (h + 1) & (uint32_t)(S - 1);
+                }
+                h_slot_of[(size_t)id_of[i] * e->W + t] = sub[h].slot;
+            }
+        }
+        BK_HIP(e->slot_of.upload(h_slot_of));
     }
     {
         hipDeviceProp_t prop;
         BK_HIP(hipGetDeviceProperties(&prop, prm->device));
         e->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         const size_t budget = bk::scan_lds_budget();
-        e->n_lds_bins = (uint32_t)std::min<size_t>(e->m, budget / sizeof(unsigned int));
+        const size_t ref_bytes = bk::scan_ref_lds_bytes((uint32_t)e->total_cells);
+        e->ref_in_lds = ref_bytes + std::min<size_t>((size_t)e->n_u * sizeof(unsigned int), budget / 2) <= budget;
+        if (const char* rl = getenv("BK_REF_IN_LDS")) e->ref_in_lds = e->ref_in_lds && atoi(rl) != 0;
+        e->n_lds_bins = (uint32_t)std::min<size_t>(e->n_u, (budget - (e->ref_in_lds ? ref_bytes : 0)) / sizeof(unsigned int));
         if (const char* nl = getenv("BK_LDS_BINS")) e->n_lds_bins = std::min<uint32_t>(e->n_lds_bins, (uint32_t)atol(nl));
-        e->pilots_in_lds = (size_t)e->n_lds_bins * sizeof(unsigned int) + ((size_t)2 << e->log2nb) <= budget;
-        if (const char* pl = getenv("BK_PILOTS_IN_LDS")) e->pilots_in_lds = e->pilots_in_lds && atoi(pl) != 0;
         BK_HIP(e->slabs.alloc((size_t)e->n_cus * std::max<uint32_t>(e->n_lds_bins, 1)));
     }
     if (const char* nx = getenv("BK_NO_XCD_PLANES")) e->use_xcd_planes = atoi(nx) == 0;
@@ -366,19 +486,20 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     BK_HIP(e->ent_off.upload(h_off));
     BK_HIP(e->ent_len.upload(h_len));
     BK_HIP(e->entries.upload(h_ent));
-    if (bk::v_plane_len(e->m, e->W) >= (1ull << 32)) return fail(BK_ERR_UNSUPPORTED, "index too large: variant counter plane exceeds 2^32 counters");
-    for (int m = 0; m < 2; m++) BK_HIP(e->counters[m].alloc(bk::e_plane_len(e->m) + bk::v_plane_len(e->m, e->W)));
-    BK_HIP(e->deferred.alloc(bk::v_plane_len(e->m, e->W)));
+    if (bk::v_plane_len(e->n_u, e->W) >= (1ull << 32)) return fail(BK_ERR_UNSUPPORTED, "index too large: variant counter plane exceeds 2^32 counters");
+    for (int m = 0; m < 2; m++) BK_HIP(e->counters[m].alloc(bk::e_plane_len(e->n_u) + bk::v_plane_len(e->n_u, e->W)));
+    BK_HIP(e->deferred.alloc(bk::v_plane_len(e->n_u, e->W)));
     BK_HIP(e->n_deferred.alloc(1));
-    if (e->n_lds_bins >= e->m) e->use_xcd_planes = false;   // every reference k-mer has an LDS bin
+    if (e->n_lds_bins >= e->n_u) e->use_xcd_planes = false;   // every reference k-mer has an LDS bin
     if (e->use_xcd_planes) {
-        BK_HIP(e->e_planes.alloc((size_t)bk::kXcdPlanes * bk::e_plane_len(e->m)));
+        BK_HIP(e->e_planes.alloc((size_t)bk::kXcdPlanes * bk::e_plane_len(e->n_u)));
         BK_HIP(hipMemset(e->e_planes.p, 0, e->e_planes.n * sizeof(unsigned int)));
     }
     BK_HIP(e->pileup.alloc(e->total_cells * 4 * 4));
     BK_HIP(e->stats.alloc((size_t)2 * e->n_files * 3));
     BK_HIP(e->present.alloc((size_t)2 * e->n_files));
     BK_HIP(e->kstats.alloc(8));
+    BK_HIP(e->d_view.upload(std::vector<bk::IndexView>(1, e->view())));
     BK_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
     if (const char* ab = getenv("BK_SCAN_ABLATE")) e->ablate = atoi(ab);
@@ -406,7 +527,7 @@ int bk_engine_set_stream(bk_engine* e, void* hip_stream) {
 uint64_t bk_total_cells(const bk_engine* e) { return e ? e->total_cells : 0; }
 int32_t bk_n_files(const bk_engine* e) { return e ? e->n_files : 0; }
 uint64_t bk_n_slots(const bk_engine* e) { return e ? e->n_slots : 0; }
-uint64_t bk_counter_len(const bk_engine* e) { return e ? bk::e_plane_len(e->m) + bk::v_plane_len(e->m, e->W) : 0; }
+uint64_t bk_counter_len(const bk_engine* e) { return e ? bk::e_plane_len(e->n_u) + bk::v_plane_len(e->n_u, e->W) : 0; }
 
 int bk_sample_begin(bk_engine* e) {
     if (!e) return fail(BK_ERR_INVALID, "null engine");
@@ -425,7 +546,10 @@ int bk_sample_begin(bk_engine* e) {
 
 static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t stride_words, const uint16_t* d_lens, uint64_t n) {
     bk::ScanArgs a{};
-    a.ix = e->view();
+    a.ixp = e->d_view.p;
+    a.k = e->k; a.wstart = e->wstart; a.W = e->W; a.total_cells = (uint32_t)e->total_cells; a.n_u = e->n_u;
+    a.ref_words = e->ref_words.p; a.bits_clean = e->bits_clean.p; a.bits_follow = e->bits_follow.p;
+    a.bits_rc = e->bits_rc.p; a.id_at = e->id_at.p;
     a.words = d_words; a.lens = d_lens; a.n_records = n; a.stride_words = stride_words;
     a.counters = e->counters[mate].p;
     a.kmer_total = e->kstats.p + mate * 4 + 1;
@@ -433,7 +557,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.e_planes = e->use_xcd_planes ? e->e_planes.p : nullptr;
     a.slabs = e->slabs.p;
     a.n_lds_bins = e->n_lds_bins;
-    a.pilots_in_lds = e->pilots_in_lds ? 1 : 0;
+    a.ref_in_lds = e->ref_in_lds ? 1 : 0;
     const uint32_t grid = bk::scan_grid(n, e->n_cus);
     {
         bk_engine::Span sp(e, 0);
@@ -443,7 +567,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
         // histogram slabs (and the u32 overflow planes: a batch of < 2^32 k-mers cannot wrap them) -> u64 plane
         bk::FoldArgs f{};
         f.slabs = e->slabs.p; f.n_slabs = grid; f.n_lds_bins = e->n_lds_bins;
-        f.e_planes = a.e_planes; f.n_e = bk::e_plane_len(e->m); f.counters = e->counters[mate].p;
+        f.e_planes = a.e_planes; f.n_e = bk::e_plane_len(e->n_u); f.counters = e->counters[mate].p;
         bk_engine::Span sp(e, 3);
         bk::launch_fold(f, e->stream);
     }

@@ -7,7 +7,15 @@
 namespace bk {
 
 struct ScanArgs {
-    IndexView ix;
+    const IndexView* ixp;           // device copy of the index view: only the rare paths of scan_count read it
+    // what the hot path needs (kept in kernel-argument registers)
+    int32_t k, wstart, W;
+    uint32_t total_cells, n_u;
+    const uint32_t* ref_words;      // IndexView::ref_words / bits_* / id_at
+    const uint32_t* bits_clean;
+    const uint32_t* bits_follow;
+    const uint32_t* bits_rc;
+    const uint32_t* id_at;
     const uint32_t* words;          // [n_records][stride_words] 2-bit packed, 16 bases per word, LSB first
     const uint16_t* lens;           // [n_records] valid bases
     uint64_t n_records;
@@ -16,7 +24,7 @@ struct ScanArgs {
     unsigned int* slabs;            // [grid][n_lds_bins] packed (rc<<16 | fwd) histogram of each workgroup
     uint32_t n_lds_bins;            // reference k-mers at positions < n_lds_bins are counted in LDS
     unsigned int* e_planes;         // [8 XCDs][E] u32 planes for positions >= n_lds_bins; null if none / disabled
-    int pilots_in_lds;              // stage the perfect-hash pilots in LDS (they fit next to the histogram)
+    int ref_in_lds;                 // stage the packed reference + flag bits in LDS (they fit next to the histogram)
     unsigned long long* kmer_total; // optional: += k-mer occurrences scanned
     int ablate;                     // measurement aid, 0 in production (see scan_count_kernel)
 };
@@ -44,8 +52,9 @@ struct FoldArgs {
 };
 
 uint32_t scan_grid(uint64_t n_records, int n_cus);
-size_t scan_lds_budget();   // bytes available for histogram bins (4 B each) + pilots (2 B each)
-size_t scan_lds_bytes(uint32_t n_lds_bins, bool pilots_in_lds, uint32_t log2nb);
+size_t scan_lds_budget();   // bytes available for histogram bins (4 B each) + the staged reference
+size_t scan_ref_lds_bytes(uint32_t total_cells);
+size_t scan_lds_bytes(uint32_t n_lds_bins, bool ref_in_lds, uint32_t total_cells);
 hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t stream);
 void launch_fold(const FoldArgs& f, hipStream_t stream);
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);

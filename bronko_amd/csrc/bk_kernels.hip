@@ -85,23 +85,37 @@ __device__ __forceinline__ void for_each_neighbour(const IndexView& ix, uint64_t
 // takes tiles of 64 records, one record per lane.  The k-mer loop is wave-uniform (trip count = longest record
 // of the tile) so that ballots and the LDS miss queue always see the whole wave.
 //
-// Fast path -- is the read k-mer a reference k-mer?  Perfect hash: pilot load (LDS when it fits, else L1/L2) +
-// one 8-byte key load from an L2-resident table, no probe chain, so no lane waits for another lane's
-// collisions.  A hit (the overwhelmingly common case) is counted in the workgroup's private LDS histogram:
-// one 32-bit word per reference k-mer, low half = read as-is, high half = read as reverse complement.  A half
-// that reaches 0x8000 is spilled (by the one lane that saw 0x7fff -> 0x8000) as 0x8000 into the u64 plane, so
-// degenerate inputs (millions of identical k-mers) cannot overflow 16 bits.  At the end the histogram is
-// written as one coalesced slab per workgroup; fold adds the slabs into the u64 plane.  This replaces one
-// global atomic per k-mer occurrence by an LDS atomic plus |U| stores per workgroup.
+// Fast path -- a read follows the reference, so each lane walks its read along a reference diagonal.  The
+// reference itself (2 bits per base) and three bit-per-position flag arrays live in LDS; per k-mer step the
+// lane fetches ONE reference base, rolls a mismatch mask `diff` (read k-mer XOR reference k-mer, 2 bits per
+// base) and never touches global memory:
+//   diff == 0                      the read k-mer IS the reference k-mer at this cell: +1 on its E counter (LDS
+//                                  histogram); its id is the previous id +-1 when the follow bit says so.
+//   one base differs, cell "clean" clean = no reference k-mer of either strand within Hamming distance 2 (host
+//                                  precomputed).  Then the read k-mer is provably not a reference k-mer and the
+//                                  reference k-mer here is its only possible neighbour: if both have the same
+//                                  canonical orientation and the differing base lies in the window, its V
+//                                  counter is known on the spot (one fire-and-forget global atomic); otherwise
+//                                  it touches nothing.
+//   anything else                  (read start, two errors within one k-mer, strain-specific or repetitive
+//                                  neighbourhoods, sequence ends): perfect-hash membership test -- pilot + one
+//                                  16-byte key load, no probe chain; a hit re-seeds the diagonal, a miss goes
+//                                  to the slow path.
+// Exact hits are counted in the workgroup's private LDS histogram: one 32-bit word per reference k-mer, low
+// half = read as-is, high half = read as reverse complement.  A half that reaches 0x8000 is spilled (by the one
+// lane that saw 0x7fff -> 0x8000) as 0x8000 into the u64 plane, so degenerate inputs (millions of identical
+// k-mers) cannot overflow 16 bits.  At the end the histogram is written as one coalesced slab per workgroup;
+// fold adds the slabs into the u64 plane.
 //
-// Slow path -- k-mers that are not reference k-mers are compacted (ballot + prefix popcount) into a per-wave
-// LDS queue; whenever 64 are pending the wave drains them together, each lane looking up the neighbours of
-// one queued k-mer and adding to the V counter of the smallest (position, reference k-mer).  Without the queue
-// every wave step would pay for its slowest lane.
+// Slow path -- k-mers that are not reference k-mers and were not resolved on the diagonal are compacted
+// (ballot + prefix popcount) into a per-wave LDS queue; whenever 64 are pending they become a batch of the
+// SlowPipe (one k-mer per lane), which looks up the neighbours of each and adds to the V counter of the
+// smallest (position, reference k-mer) while the fast path keeps going.
 //
 // Reference k-mers beyond the LDS histogram's capacity (large multi-genome indexes) are counted with
 // workgroup-scope (non-sc1) atomics in a u32 plane private to the XCD the workgroup runs on (HW_REG_XCC_ID,
 // read at run time, so nothing depends on how workgroups are placed); fold adds the planes up afterwards.
+// A reference too large for LDS is walked from global memory instead (REF_LDS = false).
 constexpr int kScanBlock = 1024;
 constexpr int kScanWaves = kScanBlock / 64;
 constexpr int kQueueCap = 128;
@@ -110,60 +124,155 @@ constexpr size_t kScanLdsFixed = kQueueBytes + 16;
 
 struct QueueView { unsigned long long* c; unsigned char* meta; };
 
-template <bool COUNT = true>
-__device__ __forceinline__ void drain_queue(const QueueView& q, uint32_t n, int lane, const IndexView& ix,
-                                            unsigned long long* __restrict__ v_counters) {
-    if ((uint32_t)lane < n) {
-        const uint64_t c = q.c[lane];
-        const uint32_t isrc = q.meta[lane];
-        uint64_t best = ~0ull;   // (j << 32) | p, smallest wins
-        for_each_neighbour(ix, c, [&](int j, uint32_t p) {
-            const uint64_t key = ((uint64_t)j << 32) | p;
-            if (key < best) best = key;
-        });
-        if (best != ~0ull) {
-            const int j = (int)(best >> 32);
-            const uint32_t p = (uint32_t)best;
-            const uint32_t b = (uint32_t)(c >> (2 * (ix.k - 1 - j))) & 3u;
-            unsigned long long* ctr = v_counters + (((uint64_t)p * ix.W + (uint32_t)(j - ix.wstart)) * 4 + b) * 2 + isrc;
-            if (COUNT) atomicAdd(ctr, 1ull);
-            else if (best == 0x123456789ull) *ctr = 1;   // measurement aid: keep the lookup alive without the atomic
+// The slow path as a software pipeline.  A batch of up to 64 queued k-mers (one per lane) advances one stage per
+// k-mer step of the fast path: stage 1 has the three pilots in flight (reference k-mer set, low half, high half),
+// stage 2 the perfect-hash entry and the two directory entries, stage 3 the first candidate of each list (unless
+// the k-mer turned out to be a reference k-mer: then it is counted and done); stage 4 resolves the V counter
+// and issues the atomic.  Each stage only *issues* its loads; they are consumed one fast-path step later, so the
+// slow path's memory latency hides behind the fast path's work instead of stalling the wave.
+struct SlowPipe {
+    int stage = 0;          // wave-uniform: 0 = empty
+    bool have = false;      // this lane holds a k-mer of the batch
+    uint64_t c = 0, lo = 0, hi = 0;
+    uint32_t isrc = 0, pil_u = 0, pil_lo = 0, pil_hi = 0, cnt_lo = 0, cnt_hi = 0;
+    uint4 e_u{}, d_lo{}, d_hi{}, e_lo{}, e_hi{};
+
+    __device__ __forceinline__ void start(const QueueView& q, uint32_t n, int lane, const IndexView& ix) {
+        have = (uint32_t)lane < n;
+        c = have ? q.c[lane] : 0ull;
+        isrc = have ? q.meta[lane] : 0u;
+        const int lo_bits = 2 * ix.lo_bases;
+        lo = c & ((1ull << lo_bits) - 1ull);
+        hi = c >> lo_bits;
+        pil_u = ix.pilots[phf_bucket(c, ix.log2nb)];
+        pil_lo = ix.lo.pilots[phf_bucket(lo, ix.lo.log2nb)];
+        pil_hi = ix.hi.pilots[phf_bucket(hi, ix.hi.log2nb)];
+        stage = 1;
+    }
+
+    template <bool COUNT, typename CountExact>
+    __device__ __forceinline__ void advance(const IndexView& ix, unsigned long long* __restrict__ v_counters, CountExact&& count_exact) {
+        if (stage == 1) {
+            e_u = *reinterpret_cast<const uint4*>(ix.kmer_pos + phf_pos(c, pil_u, ix.m));
+            d_lo = *reinterpret_cast<const uint4*>(ix.lo.dir + phf_pos(lo, pil_lo, ix.lo.m));
+            d_hi = *reinterpret_cast<const uint4*>(ix.hi.dir + phf_pos(hi, pil_hi, ix.hi.m));
+            stage = 2;
+        } else if (stage == 2) {
+            if (have && ((uint64_t)e_u.x | ((uint64_t)e_u.y << 32)) == c) {   // a reference k-mer after all
+                count_exact(e_u.w & kIdMask, isrc);
+                have = false;
+            }
+            cnt_lo = (have && d_lo.x == (uint32_t)lo) ? d_lo.z : 0u;
+            cnt_hi = (have && d_hi.x == (uint32_t)hi) ? d_hi.z : 0u;
+            if (cnt_lo) e_lo = *reinterpret_cast<const uint4*>(ix.lo.cand + d_lo.y);
+            if (cnt_hi) e_hi = *reinterpret_cast<const uint4*>(ix.hi.cand + d_hi.y);
+            stage = 3;
+        } else if (stage == 3) {
+            const int k = ix.k, wlo = ix.wstart, whi = ix.wstart + ix.W;
+            uint64_t best = ~0ull;   // (j << 32) | id, smallest wins
+            auto consider = [&](const uint4& e) {
+                const int j = single_diff_pos((uint64_t)e.x | ((uint64_t)e.y << 32), c, k);
+                if (j >= wlo && j < whi) {
+                    const uint64_t key = ((uint64_t)j << 32) | e.z;
+                    if (key < best) best = key;
+                }
+            };
+            if (cnt_lo) consider(e_lo);
+            for (uint32_t i = 1; i < cnt_lo; ++i) consider(*reinterpret_cast<const uint4*>(ix.lo.cand + d_lo.y + i));   // rare
+            if (cnt_hi) consider(e_hi);
+            for (uint32_t i = 1; i < cnt_hi; ++i) consider(*reinterpret_cast<const uint4*>(ix.hi.cand + d_hi.y + i));   // rare
+            if (best != ~0ull) {
+                const int j = (int)(best >> 32);
+                const uint32_t p = (uint32_t)best;
+                const uint32_t b = (uint32_t)(c >> (2 * (k - 1 - j))) & 3u;
+                unsigned long long* ctr = v_counters + (((uint64_t)p * ix.W + (uint32_t)(j - ix.wstart)) * 4 + b) * 2 + isrc;
+                if (COUNT) atomicAdd(ctr, 1ull);
+                else if (best == 0x123456789ull) *ctr = 1;   // measurement aid: keep the lookup alive without the atomic
+            }
+            stage = 0;
         }
     }
-}
 
-// MODE is a measurement aid (BK_SCAN_ABLATE): 0 = product kernel; 1 = exact-match counting replaced by a
-// register sink; 2 = lookups and counting replaced by a register sink; 3 = product fast path, slow path
-// dropped; 4 = slow path without its final atomic.  Modes 1-4 produce incomplete counts.
-template <int MODE>
+    template <bool COUNT, typename CountExact>
+    __device__ __forceinline__ void finish(const IndexView& ix, unsigned long long* __restrict__ v_counters, CountExact&& count_exact) {
+        while (stage) advance<COUNT>(ix, v_counters, count_exact);
+    }
+};
+
+// MODE is a measurement aid (BK_SCAN_ABLATE): 0 = product kernel; 1 = exact-match counting dropped; 2 = only the
+// rolling k-mer extraction; 3 = slow path and variant atomics dropped; 4 = variant atomics dropped.  Modes 1-4
+// produce incomplete counts.
+template <int MODE, bool REF_LDS>
 __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* queue_c = reinterpret_cast<unsigned long long*>(smem);
     unsigned char* queue_m = smem + (size_t)kScanWaves * kQueueCap * sizeof(unsigned long long);
     unsigned int* block_kmers = reinterpret_cast<unsigned int*>(smem + kQueueBytes);   // 16 B reserved
     unsigned int* bins = block_kmers + 4;
-    unsigned short* lds_pilots = reinterpret_cast<unsigned short*>(bins + a.n_lds_bins);
+    unsigned int* lds_ref = bins + a.n_lds_bins;   // REF_LDS: ref words, then clean / follow / rc bit words
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const QueueView q{queue_c + wave * kQueueCap, queue_m + wave * kQueueCap};
-    const IndexView& ix = a.ix;
 
+    const uint32_t total = a.total_cells;
+    const uint32_t n_refw = (total + 15) / 16 + 4;   // padded by the host (>= k bases past the end)
+    const uint32_t n_bitw = (total + 31) / 32 + 1;
     for (uint32_t i = threadIdx.x; i < a.n_lds_bins; i += kScanBlock) bins[i] = 0u;
-    if (a.pilots_in_lds)
-        for (uint32_t i = threadIdx.x; i < (1u << ix.log2nb); i += kScanBlock) lds_pilots[i] = ix.pilots[i];
+    if (REF_LDS) {
+        for (uint32_t i = threadIdx.x; i < n_refw; i += kScanBlock) lds_ref[i] = a.ref_words[i];
+        for (uint32_t i = threadIdx.x; i < n_bitw; i += kScanBlock) {
+            lds_ref[n_refw + i] = a.bits_clean[i];
+            lds_ref[n_refw + n_bitw + i] = a.bits_follow[i];
+            lds_ref[n_refw + 2 * n_bitw + i] = a.bits_rc[i];
+        }
+    }
     __syncthreads();
+    const unsigned int* refw = REF_LDS ? lds_ref : a.ref_words;
+    const unsigned int* bclean = REF_LDS ? lds_ref + n_refw : a.bits_clean;
+    const unsigned int* bfollow = REF_LDS ? lds_ref + n_refw + n_bitw : a.bits_follow;
+    const unsigned int* brc = REF_LDS ? lds_ref + n_refw + 2 * n_bitw : a.bits_rc;
 
-    const int k = ix.k;
+    const int k = a.k;
+    const uint32_t W = (uint32_t)a.W;
+    const int wlo = a.wstart, whi = a.wstart + a.W;
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;  // k <= 31
+    // 2k-bit values are kept as explicit 32-bit halves: 64-bit shifts and compares are slow-rate VALU ops
+    const uint32_t kmask_lo = (uint32_t)kmask, kmask_hi = (uint32_t)(kmask >> 32);
     const int rcshift = 2 * (k - 1);
-    const uint64_t n_e = e_plane_len(ix.m);
+    const uint32_t rc_sh = (uint32_t)rcshift & 31u;
+    const uint32_t rc_in_hi = rcshift >= 32 ? 0xffffffffu : 0u;   // which half receives the new complemented base
+    const uint32_t km1 = (uint32_t)k - 1u;
+    const uint64_t n_e = e_plane_len(a.n_u);
     unsigned int* const e_local = a.e_planes ? a.e_planes + (size_t)xcc_id() * n_e : nullptr;
     unsigned long long* const v_counters = a.counters + n_e;
 
+    // +1 on the E counter of reference k-mer `id` read in orientation `isrc`
+    auto count_exact = [&](uint32_t id, uint32_t isrc) {
+        if (MODE == 1) return;
+        if (id < a.n_lds_bins) {
+            const unsigned int old = atomicAdd(&bins[id], isrc ? 0x10000u : 1u);
+            if (((isrc ? old >> 16 : old) & 0xffffu) == 0x7fffu) {   // this add made the half 0x8000: spill it
+                atomicSub(&bins[id], isrc ? 0x80000000u : 0x8000u);
+                atomicAdd(a.counters + 2 * (size_t)id + isrc, 0x8000ull);
+            }
+        } else if (e_local) {
+            __hip_atomic_fetch_add(e_local + 2 * (size_t)id + isrc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            atomicAdd(a.counters + 2 * (size_t)id + isrc, 1ull);
+        }
+    };
+    // +1 on the V counter of "reference k-mer id with base bb at canonical position j"
+    auto count_variant = [&](uint32_t id, int j, uint32_t bb, uint32_t isrc) {
+        unsigned long long* ctr = v_counters + (((uint64_t)id * W + (uint32_t)(j - wlo)) * 4 + bb) * 2 + isrc;
+        if (MODE != 4 && MODE != 3) atomicAdd(ctr, 1ull);           // no return value: fire and forget
+        else if (id == 0x12345678u) *ctr = 1;
+    };
+
     uint32_t nkm = 0;  // k-mer occurrences seen by this lane
     uint32_t qn = 0;   // wave-uniform queue fill
-    uint64_t sink = 0; // MODE 1/2 only
+    uint32_t sink = 0; // MODE 2 only
+    SlowPipe pipe;
 
     const uint64_t n_tiles = (a.n_records + 63) / 64;
     for (uint64_t tile = (uint64_t)blockIdx.x * kScanWaves + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * kScanWaves) {
@@ -175,7 +284,13 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
         for (int off = 32; off; off >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, off));
         const uint32_t* __restrict__ w = a.words + (live ? r : 0) * a.stride_words;
 
-        uint64_t fwd = 0, rc = 0;
+        uint32_t f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;   // rolling forward / reverse-complement k-mer
+        // diagonal state: cell of the reference k-mer the previous read k-mer was aligned with (>= total: lost),
+        // walking direction (+1 along the reference, 0xffffffff = -1 against it), id of that reference k-mer
+        // (valid if id_ok), mismatch mask of the current alignment (2 bits per base, read orientation)
+        uint32_t cell = 0xffffffffu, ddir = 1u, id = 0, d_lo = 0, d_hi = 0;
+        uint32_t bad = 0;   // consecutive steps on this diagonal that needed the full search
+        bool id_ok = false;
         for (uint32_t i0 = 0; i0 < maxlen; i0 += 16) {
             uint32_t x = (i0 < len) ? w[i0 >> 4] : 0u;
             const uint32_t nb = min(16u, maxlen - i0);
@@ -183,48 +298,124 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 const uint32_t i = i0 + b;
                 const uint32_t base = x & 3u;
                 x >>= 2;
-                fwd = ((fwd << 2) | base) & kmask;
-                rc = (rc >> 2) | ((uint64_t)(3u - base) << rcshift);
-                bool miss = false;
-                uint64_t c = 0;
-                uint32_t isrc = 0;
-                if (i < len && i + 1 >= (uint32_t)k) {
-                    ++nkm;
-                    isrc = fwd < rc ? 0u : 1u;  // lcb.rs:90-94
-                    c = isrc ? rc : fwd;
-                    if (MODE == 2) {
-                        sink += c;
-                    } else {
-                        const uint32_t bkt = phf_bucket(c, ix.log2nb);
-                        const uint32_t pilot = a.pilots_in_lds ? lds_pilots[bkt] : ix.pilots[bkt];
-                        const uint32_t pos = phf_pos(c, pilot, ix.m);
-                        if (ix.kmer_pos[pos] == c) {
-                            if (MODE == 1) {
-                                sink += pos;
-                            } else if (pos < a.n_lds_bins) {
-                                const unsigned int old = atomicAdd(&bins[pos], isrc ? 0x10000u : 1u);
-                                if (((isrc ? old >> 16 : old) & 0xffffu) == 0x7fffu) {   // this add made the half 0x8000: spill it
-                                    atomicSub(&bins[pos], isrc ? 0x80000000u : 0x8000u);
-                                    atomicAdd(a.counters + 2 * (size_t)pos + isrc, 0x8000ull);
+                // ---- tier 1: branch-free, what every lane needs on every step ------------------------------------
+                f_hi = ((f_hi << 2) | (f_lo >> 30)) & kmask_hi;
+                f_lo = ((f_lo << 2) | base) & kmask_lo;
+                const uint32_t cb = (3u - base) << rc_sh;
+                r_lo = ((r_lo >> 2) | (r_hi << 30)) | (cb & ~rc_in_hi);
+                r_hi = (r_hi >> 2) | (cb & rc_in_hi);
+                const bool valid = i < len && i + 1 >= (uint32_t)k;
+                nkm += valid ? 1u : 0u;
+                if (MODE == 2) { sink += f_lo ^ r_hi; continue; }
+
+                const bool fwd_dir = ddir == 1u;
+                const uint32_t ncell = cell + ddir;                          // the diagonal's next cell
+                const bool tracking = cell < total;
+                const bool ok = valid && tracking && ncell < total;
+                const uint32_t nc = ok ? ncell : 0u;                         // clamped: the loads below are unconditional
+                const uint32_t bpos = fwd_dir ? nc + km1 : nc;               // reference base aligned with the new read base
+                const uint32_t rb = ((refw[bpos >> 4] >> (2 * (bpos & 15))) & 3u) ^ (fwd_dir ? 0u : 3u);
+                const uint32_t nd_hi = ((d_hi << 2) | (d_lo >> 30)) & kmask_hi;
+                const uint32_t nd_lo = ((d_lo << 2) | (base ^ rb)) & kmask_lo;
+                d_hi = ok ? nd_hi : d_hi;
+                d_lo = ok ? nd_lo : d_lo;
+                const uint32_t fcell = fwd_dir ? (ok ? cell : 0u) : nc;     // follow bit: id(fcell + 1) == id(fcell) + 1
+                const bool clean = ok && ((bclean[nc >> 5] >> (nc & 31)) & 1u);
+                const bool follow = (bfollow[fcell >> 5] >> (fcell & 31)) & 1u;
+                const uint32_t ref_isrc = ((brc[nc >> 5] >> (nc & 31)) & 1u) ^ (fwd_dir ? 0u : 1u);   // orientation of the reference k-mer as the read sees it
+                cell = tracking ? ncell : cell;                              // once out of range the lane stays lost
+                const bool id_known = ok && id_ok && follow;                 // previous id +-1 along an unbroken stretch
+                id = id_known ? id + ddir : id;
+                id_ok = id_known;
+                const uint32_t dbits = (d_lo | (d_lo >> 1)) & 0x55555555u, dbits_hi = (d_hi | (d_hi >> 1)) & 0x55555555u;
+                const uint32_t n_diff = (uint32_t)__popc(dbits) + (uint32_t)__popc(dbits_hi);
+                const bool exact = id_known && n_diff == 0;                  // follow => a k-mer starts here; diff == 0 => it is this one
+                if (exact) { count_exact(id, ref_isrc); bad = 0; }          // read orientation == the reference k-mer's
+                // ---- tier 2: one base differs from a clean reference k-mer whose id is known (the sequencing-error
+                //      case: ~one lane in ten).  Provably not a reference k-mer, and that k-mer is its only possible
+                //      neighbour (bk_device.h, amb): name its V counter on the spot, or it touches nothing.
+                const bool simple = id_known && clean && n_diff == 1;
+                if (simple) {
+                    const bool lt = f_hi < r_hi || (f_hi == r_hi && f_lo < r_lo);   // lcb.rs:90-94
+                    const uint32_t isrc = lt ? 0u : 1u;
+                    const int from_right = dbits ? (__builtin_ctz(dbits) >> 1) : 16 + (__builtin_ctz(dbits_hi) >> 1);
+                    const int j = isrc ? from_right : k - 1 - from_right;    // differing position in canonical orientation
+                    if (ref_isrc == isrc && j >= wlo && j < whi) {
+                        const int sh = 2 * (k - 1 - j);                     // base of the canonical k-mer at j
+                        const uint32_t c_lo = lt ? f_lo : r_lo, c_hi = lt ? f_hi : r_hi;
+                        const uint32_t bb = (sh >= 32 ? c_hi >> (sh - 32) : c_lo >> sh) & 3u;
+                        count_variant(id, j, bb, isrc);
+                    }
+                }
+                // ---- tier 3: everything else -- unknown id, several differences, dirty neighbourhoods, lost lanes,
+                //      the miss queue and the slow pipeline ---------------------------------------------------------
+                const bool slow = valid && !exact && !simple;
+                if (__ballot(slow) || qn >= 64 || pipe.stage) {
+                    const IndexView& ix = *a.ixp;
+                    bool lookup = false, miss = false;
+                    uint64_t c = 0;
+                    uint32_t isrc = 0;
+                    if (slow) {
+                        const bool lt = f_hi < r_hi || (f_hi == r_hi && f_lo < r_lo);
+                        isrc = lt ? 0u : 1u;
+                        c = lt ? (((uint64_t)f_hi << 32) | f_lo) : (((uint64_t)r_hi << 32) | r_lo);
+                        if (!ok) {
+                            lookup = true;                                   // no diagonal: perfect-hash lookup, may re-seed
+                        } else {
+                            bool done = false;
+                            if (n_diff == 0 || (n_diff == 1 && clean)) {
+                                id = a.id_at[nc];                            // repeat, or first step on this stretch
+                                id_ok = id != 0xffffffffu;
+                                if (id_ok && n_diff == 0) {
+                                    count_exact(id, ref_isrc);
+                                    bad = 0;
+                                    done = true;
+                                } else if (id_ok) {
+                                    done = true;
+                                    const int from_right = dbits ? (__builtin_ctz(dbits) >> 1) : 16 + (__builtin_ctz(dbits_hi) >> 1);
+                                    const int j = isrc ? from_right : k - 1 - from_right;
+                                    if (ref_isrc == isrc && j >= wlo && j < whi)
+                                        count_variant(id, j, (uint32_t)(c >> (2 * (k - 1 - j))) & 3u, isrc);
                                 }
-                            } else if (e_local) {
-                                __hip_atomic_fetch_add(e_local + 2 * (size_t)pos + isrc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            } else {
-                                atomicAdd(a.counters + 2 * (size_t)pos + isrc, 1ull);
                             }
+                            if (!done) {
+                                // several differences, a dirty neighbourhood or no k-mer at this cell: full search,
+                                // asynchronously; the lane keeps walking its diagonal and gives it up only after more
+                                // than a k-mer of such steps
+                                miss = MODE != 3;
+                                bad += 1;
+                                if (bad > (uint32_t)k + 4u) cell = 0xffffffffu;
+                            }
+                        }
+                    }
+                    if (lookup) {
+                        // perfect-hash membership test; a hit (re-)seeds the diagonal
+                        const uint32_t pilot = ix.pilots[phf_bucket(c, ix.log2nb)];
+                        const uint4 e = *reinterpret_cast<const uint4*>(ix.kmer_pos + phf_pos(c, pilot, ix.m));
+                        if (((uint64_t)e.x | ((uint64_t)e.y << 32)) == c) {
+                            id = e.w & kIdMask;
+                            id_ok = true;
+                            count_exact(id, isrc);
+                            ddir = (isrc == (e.w >> 31)) ? 1u : 0xffffffffu;   // same strand as the reference?
+                            cell = e.z;
+                            d_lo = d_hi = 0;
+                            bad = 0;
                         } else {
                             miss = MODE != 3;
                         }
                     }
-                }
-                const unsigned long long mm = __ballot(miss);
-                if (mm) {
-                    const uint32_t pos = qn + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
-                    if (miss) { q.c[pos] = c; q.meta[pos] = (unsigned char)isrc; }
-                    qn += (uint32_t)__popcll(mm);
-                    __builtin_amdgcn_wave_barrier();
+                    const unsigned long long mm = __ballot(miss);
+                    if (mm) {
+                        const uint32_t pos = qn + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+                        if (miss) { q.c[pos] = c; q.meta[pos] = (unsigned char)isrc; }
+                        qn += (uint32_t)__popcll(mm);
+                        __builtin_amdgcn_wave_barrier();
+                    }
                     if (qn >= 64) {
-                        drain_queue<MODE != 4>(q, 64, lane, ix, v_counters);
+                        // a full batch is waiting: retire the batch in flight (its loads were issued steps ago), then
+                        // take 64 k-mers off the queue and issue the first loads of the new batch
+                        pipe.template finish<MODE != 4>(ix, v_counters, count_exact);
+                        pipe.start(q, 64, lane, ix);
                         const uint32_t rest = qn - 64;
                         const unsigned long long tc = ((uint32_t)lane < rest) ? q.c[64 + lane] : 0ull;
                         const unsigned char tm = ((uint32_t)lane < rest) ? q.meta[64 + lane] : (unsigned char)0;
@@ -232,13 +423,22 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                         if ((uint32_t)lane < rest) { q.c[lane] = tc; q.meta[lane] = tm; }
                         __builtin_amdgcn_wave_barrier();
                         qn = rest;
+                    } else if (pipe.stage) {
+                        pipe.template advance<MODE != 4>(ix, v_counters, count_exact);
                     }
                 }
             }
         }
     }
-    if (qn) drain_queue<MODE != 4>(q, qn, lane, ix, v_counters);
-    if ((MODE == 1 || MODE == 2) && sink == 0x1234567) a.counters[0] = sink;   // keeps the sink alive, never true in practice
+    {
+        const IndexView& ix = *a.ixp;
+        pipe.template finish<MODE != 4>(ix, v_counters, count_exact);
+        if (qn) {
+            pipe.start(q, qn, lane, ix);
+            pipe.template finish<MODE != 4>(ix, v_counters, count_exact);
+        }
+    }
+    if (MODE == 2 && sink == 0x1234567) a.counters[0] = sink;   // keeps the sink alive, never true in practice
 
     // histogram -> this workgroup's slab (coalesced); k-mer tally -> one atomic per workgroup
     if (threadIdx.x == 0) *block_kmers = 0;
@@ -253,8 +453,11 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
 }
 
 size_t scan_lds_budget() { return 160u * 1024u - 64u - kScanLdsFixed; }
-size_t scan_lds_bytes(uint32_t n_lds_bins, bool pilots_in_lds, uint32_t log2nb) {
-    return kScanLdsFixed + (size_t)n_lds_bins * sizeof(unsigned int) + (pilots_in_lds ? ((size_t)2 << log2nb) : 0);
+size_t scan_ref_lds_bytes(uint32_t total_cells) {
+    return ((size_t)((total_cells + 15) / 16 + 4) + 3 * (size_t)((total_cells + 31) / 32 + 1)) * sizeof(unsigned int);
+}
+size_t scan_lds_bytes(uint32_t n_lds_bins, bool ref_in_lds, uint32_t total_cells) {
+    return kScanLdsFixed + (size_t)n_lds_bins * sizeof(unsigned int) + (ref_in_lds ? scan_ref_lds_bytes(total_cells) : 0);
 }
 
 uint32_t scan_grid(uint64_t n_records, int n_cus) {
@@ -262,11 +465,21 @@ uint32_t scan_grid(uint64_t n_records, int n_cus) {
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)n_cus));
 }
 
+template <bool REF_LDS>
+static void (*pick_scan_kernel(int ablate))(ScanArgs) {
+    switch (ablate) {
+        case 1: return scan_count_kernel<1, REF_LDS>;
+        case 2: return scan_count_kernel<2, REF_LDS>;
+        case 3: return scan_count_kernel<3, REF_LDS>;
+        case 4: return scan_count_kernel<4, REF_LDS>;
+        default: return scan_count_kernel<0, REF_LDS>;
+    }
+}
+
 hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t stream) {
-    if (a.n_records == 0 || a.ix.W <= 0) return hipSuccess;
-    const size_t lds = scan_lds_bytes(a.n_lds_bins, a.pilots_in_lds != 0, a.ix.log2nb);
-    void (*kern)(ScanArgs) = a.ablate == 1 ? scan_count_kernel<1> : a.ablate == 2 ? scan_count_kernel<2>
-                           : a.ablate == 3 ? scan_count_kernel<3> : a.ablate == 4 ? scan_count_kernel<4> : scan_count_kernel<0>;
+    if (a.n_records == 0 || a.W <= 0) return hipSuccess;
+    const size_t lds = scan_lds_bytes(a.n_lds_bins, a.ref_in_lds != 0, a.total_cells);
+    void (*kern)(ScanArgs) = a.ref_in_lds ? pick_scan_kernel<true>(a.ablate) : pick_scan_kernel<false>(a.ablate);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kScanBlock), lds, stream, a);
@@ -279,17 +492,21 @@ hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t strea
 __global__ __launch_bounds__(256) void fold_kernel(FoldArgs f) {
     const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * 256;
-    for (uint64_t i = tid; i < f.n_lds_bins; i += nthreads) {
+    // blockIdx.y splits the slabs into groups so that the 31 MB of slabs are streamed by the whole chip; each
+    // group adds its partial sums with one u64 atomic per non-zero bin half
+    const uint32_t per = (f.n_slabs + gridDim.y - 1) / gridDim.y;
+    const uint32_t b0 = blockIdx.y * per, b1 = min(f.n_slabs, b0 + per);
+    for (uint64_t i = tid; i < f.n_lds_bins && b0 < b1; i += nthreads) {
         unsigned long long s0 = 0, s1 = 0;
-        for (uint32_t b = 0; b < f.n_slabs; ++b) {
+        for (uint32_t b = b0; b < b1; ++b) {
             const unsigned int v = f.slabs[(size_t)b * f.n_lds_bins + i];
             s0 += v & 0xffffu;
             s1 += v >> 16;
         }
-        if (s0) f.counters[2 * i] += s0;
-        if (s1) f.counters[2 * i + 1] += s1;
+        if (s0) atomicAdd(f.counters + 2 * i, s0);
+        if (s1) atomicAdd(f.counters + 2 * i + 1, s1);
     }
-    if (f.e_planes) {
+    if (f.e_planes && blockIdx.y == 0) {
         for (uint64_t i = 2ull * f.n_lds_bins + tid; i < f.n_e; i += nthreads) {
             unsigned long long s = 0;
 #pragma unroll
@@ -297,7 +514,7 @@ __global__ __launch_bounds__(256) void fold_kernel(FoldArgs f) {
                 const unsigned int v = f.e_planes[(size_t)x * f.n_e + i];
                 if (v) { s += v; f.e_planes[(size_t)x * f.n_e + i] = 0u; }
             }
-            if (s) f.counters[i] += s;
+            if (s) atomicAdd(f.counters + i, s);
         }
     }
 }
@@ -306,8 +523,9 @@ void launch_fold(const FoldArgs& f, hipStream_t stream) {
     const uint64_t work = std::max<uint64_t>(f.n_lds_bins, f.e_planes ? f.n_e : 0);
     if (work == 0) return;
     uint64_t blocks = (work + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(fold_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, f);
+    if (blocks > 1024) blocks = 1024;
+    const unsigned groups = std::max(1u, std::min(16u, f.n_slabs / 8));
+    hipLaunchKernelGGL(fold_kernel, dim3((unsigned)blocks, groups), dim3(256), 0, stream, f);
 }
 
 // ------------------------------------------------------------------------------------------------ K2
@@ -340,10 +558,9 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
     __syncthreads();
 
     const int k = ix.k;
-    const uint64_t n_e = e_plane_len(ix.m);
-    const uint64_t n_v = v_plane_len(ix.m, ix.W);
+    const uint64_t n_e = e_plane_len(ix.n_u);
+    const uint64_t n_v = v_plane_len(ix.n_u, ix.W);
     const unsigned long long* __restrict__ vc = a.counters + n_e;
-    const size_t S = (size_t)1 << ix.log2s;
     unsigned int kept = 0;
 
     for (uint64_t vi = (uint64_t)blockIdx.x * 256 + threadIdx.x; vi < n_v; vi += (uint64_t)gridDim.x * 256) {
@@ -358,17 +575,21 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         const uint32_t p = (uint32_t)(pt / (uint32_t)ix.W);
         const int j = ix.wstart + (int)t;
         const int sh = 2 * (k - 1 - j);
-        const uint64_t c = (ix.kmer_pos[p] & ~(3ull << sh)) | ((uint64_t)bb << sh);
+        const uint64_t c = (ix.kmer_of[p] & ~(3ull << sh)) | ((uint64_t)bb << sh);
 
-        uint32_t jmask = 0;   // window positions at which c has a neighbouring reference k-mer
-        for_each_neighbour(ix, c, [&](int jj, uint32_t) { jmask |= 1u << (jj - ix.wstart); });
-        if (jmask != (1u << t)) {   // several buckets (or, defensively, an unexpected set): general path
-            const unsigned int at = atomicAdd(a.n_deferred, 1u);
-            a.deferred[at] = (uint32_t)vi;
-            continue;
+        // c = u with one base changed at window position j.  It can touch a second window bucket only if another
+        // reference k-mer lies at Hamming distance 2 from u (amb[p], precomputed); otherwise its one bucket is
+        // u's own bucket at j.  Ambiguous u: enumerate the neighbours; several buckets -> general path (K2b).
+        if (ix.amb[p]) {
+            uint32_t jmask = 0;   // window positions at which c has a neighbouring reference k-mer
+            for_each_neighbour(ix, c, [&](int jj, uint32_t) { jmask |= 1u << (jj - ix.wstart); });
+            if (jmask != (1u << t)) {
+                const unsigned int at = atomicAdd(a.n_deferred, 1u);
+                a.deferred[at] = (uint32_t)vi;
+                continue;
+            }
         }
-        const int s = probe_table(ix.table + (size_t)t * S, ix.log2s, c & ~(3ull << sh));
-        if (s < 0) continue;   // cannot happen: the neighbour owns this bucket
+        const uint32_t s = ix.slot_of[(size_t)p * ix.W + t];
         const uint32_t off = ix.ent_off[s], cnt = ix.ent_len[s];
         // entries of one bucket are grouped by file (index build appends file by file): run lengths = hits per file
         uint32_t n_perfect = 0, perfect_file = 0;
@@ -417,7 +638,7 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
 
     const int k = ix.k;
     const size_t S = (size_t)1 << ix.log2s;
-    const uint64_t n_e = e_plane_len(ix.m);
+    const uint64_t n_e = e_plane_len(ix.n_u);
     const uint64_t n_def = *a.n_deferred;
     const uint64_t n_items = n_e + n_def;
     unsigned long long kept = 0;
@@ -440,7 +661,7 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
             uint64_t c;
             uint32_t isrc;
             if (ci < n_e) {                                       // E: a reference k-mer itself
-                c = ix.kmer_pos[ci >> 1];
+                c = ix.kmer_of[ci >> 1];
                 isrc = (uint32_t)ci & 1u;
             } else {                                              // V: reference k-mer p with base bb at window position t
                 const uint64_t vi = ci - n_e;
@@ -448,12 +669,17 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
                 const uint32_t bb = (uint32_t)(vi >> 1) & 3u;
                 const uint64_t pt = vi >> 3;
                 const int sh = 2 * (k - 1 - (ix.wstart + (int)(pt % (uint32_t)ix.W)));
-                c = (ix.kmer_pos[pt / (uint32_t)ix.W] & ~(3ull << sh)) | ((uint64_t)bb << sh);
+                c = (ix.kmer_of[pt / (uint32_t)ix.W] & ~(3ull << sh)) | ((uint64_t)bb << sh);
             }
 
             if (lane < ix.W) {
-                const int sh = 2 * (k - 1 - (ix.wstart + lane));
-                const int s = probe_table(ix.table + (size_t)lane * S, ix.log2s, c & ~(3ull << sh));
+                int s;
+                if (ci < n_e) {
+                    s = (int)ix.slot_of[(size_t)(ci >> 1) * ix.W + lane];   // a reference k-mer owns all its buckets
+                } else {
+                    const int sh = 2 * (k - 1 - (ix.wstart + lane));
+                    s = probe_table(ix.table + (size_t)lane * S, ix.log2s, c & ~(3ull << sh));
+                }
                 if (s >= 0) {
                     const uint32_t off = ix.ent_off[s], cnt = ix.ent_len[s];
                     for (uint32_t q = 0; q < cnt; ++q) {
@@ -504,7 +730,7 @@ void launch_finalize(const FinalizeArgs& a, hipStream_t stream) {
     if (a.ix.W <= 0) return;
     // K2a
     {
-        const uint64_t n_v = v_plane_len(a.ix.m, a.ix.W);
+        const uint64_t n_v = v_plane_len(a.ix.n_u, a.ix.W);
         uint64_t blocks = (n_v + 255) / 256;
         if (blocks > 256 * 8) blocks = 256 * 8;
         if (blocks < 1) blocks = 1;

@@ -109,6 +109,8 @@ struct IndexView {
     const uint32_t*  slot_of;  // [n_u][W] window bucket (slot) of reference k-mer id at window position t
     const uint8_t*   amb;      // [n_u] 1 = "dirty": another reference k-mer (either strand) lies within Hamming
                                //       distance 2 of it, or it is within distance 2 of its own reverse complement
+    const uint32_t*  estat_off;// [n_u + 1] per reference k-mer: its genomes, precomputed from the index alone
+    const uint32_t*  estat;    //   (file << 1) | 1 if hits == W ("perfect"), | 0 otherwise ("variant")
     const TableSlot* table;    // [W][S]
     const uint32_t*  ent_off;  // [n_slots]
     const uint32_t*  ent_len;  // [n_slots]

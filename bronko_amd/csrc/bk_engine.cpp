@@ -122,7 +122,7 @@ struct bk_engine {
     DevBuf<uint32_t> ref_words, bits_clean, bits_follow, bits_rc, id_at;
     struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0; } half_lo, half_hi;
     DevBuf<unsigned int> deferred, n_deferred;
-    DevBuf<uint32_t> slot_of;
+    DevBuf<uint32_t> slot_of, estat_off, estat;
     DevBuf<uint8_t> amb;
     DevBuf<uint16_t> pilots;
     DevBuf<unsigned int> slabs;             // [n_cus][n_lds_bins] workgroup histograms of the last scan launch
@@ -156,7 +156,7 @@ struct bk_engine {
         v.bits_rc = bits_rc.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb};
-        v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.amb = amb.p;
+        v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
         v.table = table.p; v.ent_off = ent_off.p; v.ent_len = ent_len.p;
         v.entries = entries.p; v.n_slots = n_slots; v.log2s = log2s; v.k = k; v.wstart = wstart; v.W = W; v.n_files = n_files;
         return v;
@@ -465,6 +465,30 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             }
         }
         BK_HIP(e->slot_of.upload(h_slot_of));
+
+        // estat: per reference k-mer, its per-genome hit totals over its W window buckets (call.rs:1316-1318) and
+        // hence perfect (== W) / variant -- a property of the index alone
+        std::vector<uint32_t> h_estat_off(h_u.size() + 1, 0u), h_estat;
+        {
+            std::vector<uint32_t> hits(e->n_files, 0u), touched;
+            for (size_t id = 0; id < h_u.size(); id++) {
+                touched.clear();
+                for (int t = 0; t < e->W; t++) {
+                    const uint32_t sl = h_slot_of[id * e->W + t];
+                    for (uint32_t q = 0; q < h_len[sl]; q++) {
+                        const uint32_t file = h_ent[h_off[sl] + q].file;
+                        if (hits[file]++ == 0) touched.push_back(file);
+                    }
+                }
+                for (uint32_t file : touched) {
+                    h_estat.push_back((file << 1) | (hits[file] == (uint32_t)e->W ? 1u : 0u));
+                    hits[file] = 0;
+                }
+                h_estat_off[id + 1] = (uint32_t)h_estat.size();
+            }
+        }
+        BK_HIP(e->estat_off.upload(h_estat_off));
+        BK_HIP(e->estat.upload(h_estat));
     }
     {
         hipDeviceProp_t prop;

@@ -6,8 +6,9 @@
 //                        k-mer that can touch the index.
 // K1b fold             : adds the workgroup histogram slabs (and the per-XCD overflow planes) into the u64 plane.
 // K2a finalize_variant : V counters -> KMC thresholds -> map_kmers vote, one thread per non-reference k-mer.
-// K2b finalize_general : E counters (+ the k-mers K2a defers) -> thresholds -> map_kmers vote, one wave per k-mer.
-//                        K2a/K2b together are call.rs:1286-1418 applied to KMC's kept k-mers (-ci/-cs/-cx).
+// K2e finalize_exact   : E counters -> thresholds -> map_kmers vote, one thread per (reference k-mer, bucket).
+// K2b finalize_general : the k-mers K2a defers -> map_kmers vote, one wave per k-mer.
+//                        K2a/K2e/K2b together are call.rs:1286-1418 applied to KMC's kept k-mers (-ci/-cs/-cx).
 //
 // Counter naming (bk_device.h): a read k-mer equal to a reference k-mer u owns E[2*pos(u) + rc]; a read k-mer
 // at Hamming distance 1 from reference k-mers, differing at a window position, owns the V counter of the
@@ -617,8 +618,58 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
     if ((threadIdx.x & 63) == 0 && tot && a.kept_total) atomicAdd(a.kept_total, (unsigned long long)tot);
 }
 
-// K2b: one wave per workgroup and per k-mer.  Items are the E counters (reference k-mers: all W buckets are
-// non-empty) followed by the deferred V counters.  Lane t probes the k-mer's t-th window bucket and votes once
+// K2e: the E counters (reference k-mers).  A reference k-mer owns all W of its window buckets (slot_of), and its
+// per-genome hit totals -- hence perfect / variant / unique -- depend on the index alone, so the host precomputed
+// them (estat).  That makes the map embarrassingly parallel: one thread per (E counter, window bucket) votes for
+// the BucketInfos of that bucket; the bucket-0 thread also tallies the statistics.
+__global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const IndexView& ix = a.ix;
+    uint32_t* lstats = reinterpret_cast<uint32_t*>(smem);   // [n_files][3] block-local tallies
+    for (int g = threadIdx.x; g < ix.n_files * 3; g += 256) lstats[g] = 0;
+    __syncthreads();
+    const int k = ix.k;
+    const uint32_t W = (uint32_t)ix.W;
+    const uint64_t n_work = e_plane_len(ix.n_u) * W;
+    unsigned int kept = 0;
+    for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < n_work; g += (uint64_t)gridDim.x * 256) {
+        const uint64_t cidx = g / W;
+        const uint32_t t = (uint32_t)(g % W);
+        const unsigned long long n = a.counters[cidx];
+        if (n == 0 || n < a.ci || n > a.cx) continue;           // kmc -ci / -cx act on the true count
+        const unsigned long long v = n > a.cs ? a.cs : n;       // kmc -cs: reported count saturates
+        const uint32_t id = (uint32_t)(cidx >> 1), isrc = (uint32_t)cidx & 1u;
+        const uint64_t c = ix.kmer_of[id];
+        const uint32_t s = ix.slot_of[(size_t)id * W + t];
+        const uint32_t off = ix.ent_off[s], cnt = ix.ent_len[s];
+        for (uint32_t q = 0; q < cnt; ++q) vote(a, ix.entries[off + q], c, isrc, k, v);
+        if (t == 0) {
+            ++kept;
+            uint32_t n_perfect = 0, perfect_file = 0;
+            for (uint32_t q = ix.estat_off[id]; q < ix.estat_off[id + 1]; ++q) {   // (file << 1) | perfect
+                const uint32_t e = ix.estat[q];
+                atomicAdd(&lstats[(e >> 1) * 3 + ((e & 1u) ? 0 : 1)], 1u);
+                if (e & 1u) { ++n_perfect; perfect_file = e >> 1; }
+            }
+            if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
+        }
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < ix.n_files; g += 256) {
+        const uint32_t pf = lstats[g * 3], vr = lstats[g * 3 + 1], un = lstats[g * 3 + 2];
+        if (pf) atomicAdd(a.stats + (size_t)g * 3 + 0, (unsigned long long)pf);
+        if (vr) atomicAdd(a.stats + (size_t)g * 3 + 1, (unsigned long long)vr);
+        if (un) atomicAdd(a.stats + (size_t)g * 3 + 2, (unsigned long long)un);
+        if (pf | vr) a.present[g] = 1;
+    }
+    unsigned int tot = kept;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) tot += (unsigned int)__shfl_xor((int)tot, off);
+    if ((threadIdx.x & 63) == 0 && tot && a.kept_total) atomicAdd(a.kept_total, (unsigned long long)tot);
+}
+
+// K2b: one wave per workgroup and per k-mer, for the V counters K2a deferred (k-mers that touch several window
+// buckets; rare).  Lane t probes the k-mer's t-th window bucket and votes once
 // per BucketInfo found there.  Per-genome hit totals live in LDS (hits[n_files]); genomes touched by the
 // current k-mer are listed so that only they are classified and re-zeroed.  Per-genome statistics are tallied
 // in LDS and flushed once per workgroup (millions of k-mers voting for the same genome would otherwise
@@ -639,19 +690,17 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
     const int k = ix.k;
     const size_t S = (size_t)1 << ix.log2s;
     const uint64_t n_e = e_plane_len(ix.n_u);
-    const uint64_t n_def = *a.n_deferred;
-    const uint64_t n_items = n_e + n_def;
+    const uint64_t n_items = *a.n_deferred;   // the E counters are mapped by K2e
     unsigned long long kept = 0;
 
     for (uint64_t base = (uint64_t)blockIdx.x * 64; base < n_items; base += (uint64_t)gridDim.x * 64) {
         const uint64_t item = base + lane;
         uint64_t cidx = ~0ull;                                   // index into the counter plane
-        if (item < n_e) cidx = item;
-        else if (item < n_items) cidx = n_e + a.deferred[item - n_e];
+        if (item < n_items) cidx = n_e + a.deferred[item];
         const unsigned long long n = cidx != ~0ull ? a.counters[cidx] : 0ull;
         const bool pass = n >= a.ci && n <= a.cx && n != 0;     // kmc -ci / -cx act on the true count
         unsigned long long todo = __ballot(pass);
-        kept += __popcll(__ballot(pass && item < n_e));          // deferred items were already tallied by K2a
+        // (kept k-mers were already tallied by K2a)
         while (todo) {
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
@@ -737,11 +786,20 @@ void launch_finalize(const FinalizeArgs& a, hipStream_t stream) {
         const size_t lds = std::max<size_t>((size_t)a.ix.n_files * 3 * sizeof(uint32_t), 16);
         hipLaunchKernelGGL(finalize_variant_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
     }
-    // K2b
+    // K2e
+    {
+        const uint64_t n_work = e_plane_len(a.ix.n_u) * (uint64_t)a.ix.W;
+        uint64_t blocks = (n_work + 255) / 256;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        if (blocks < 1) blocks = 1;
+        const size_t lds = std::max<size_t>((size_t)a.ix.n_files * 3 * sizeof(uint32_t), 16);
+        hipLaunchKernelGGL(finalize_exact_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    }
+    // K2b (deferred k-mers only; the grid is small, the kernel reads the count on the device)
     {
         const size_t lds = finalize_lds_bytes(a.ix.n_files);
-        uint64_t per_cu = (160u * 1024u) / lds;      // resident single-wave workgroups per CU: LDS-limited ...
-        if (per_cu > 16) per_cu = 16;                // ... and capped so the end-of-block flush stays small
+        uint64_t per_cu = (160u * 1024u) / lds;
+        if (per_cu > 16) per_cu = 16;
         if (per_cu < 1) per_cu = 1;
         hipLaunchKernelGGL(finalize_general_kernel, dim3((unsigned)(256 * per_cu)), dim3(64), lds, stream, a);
     }

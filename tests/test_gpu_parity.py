@@ -155,3 +155,82 @@ def test_overflow_planes_when_lds_histogram_is_smaller_than_the_reference(oracle
         for kk in env:
             monkeypatch.delenv(kk)
     ix.close()
+
+
+def _mutated_strains(base, n, seed, n_sub):
+    """n variants of `base` with n_sub seeded substitutions each (config-5 style strain set)."""
+    import numpy as np
+    out = []
+    for s in range(n):
+        g = np.frombuffer(base, np.uint8).copy()
+        r = synth.splitmix64(seed * 1000 + s, 2 * n_sub)
+        pos = (r[0::2] % np.uint64(len(g))).astype(np.int64)
+        sh = (r[1::2] % np.uint64(3)).astype(np.int64) + 1
+        for p, d in zip(pos, sh):
+            g[p] = synth.BASES[(int(synth.CODE[g[p]]) + int(d)) & 3]
+        out.append(("strain%02d" % s, [("seq%02d" % s, g.tobytes())]))
+    return out
+
+
+def test_many_strains_k31_selection_and_dirty_neighbourhoods(oracle):
+    """BASELINE config 5 in miniature: 12 synthetic strains (HPV16 + ~1 % substitutions each), k = 31 (u64-wrapping
+    bucket ids), reads from strain 7.  Strain-specific SNPs put most reference k-mers within Hamming distance 2 of
+    another strain's k-mer, so this exercises the dirty / deferred paths of scan and finalize, and selection."""
+    from bronko_amd import Params
+    base = synth.read_fasta_bytes(os.path.join(helpers.GOLDEN, "HPV16.fa"))
+    files = _mutated_strains(base, 12, seed=5, n_sub=80)
+    ix = oracle.Index.build_mem(31, files)
+    eng = helpers.engine_from_oracle_index(ix)
+    gm, isnv = synth.sample_genome(files[7][1][0][1], 5)
+    c1, c2 = synth.paired_codes(gm, 12000, 150, 5, isnv=isnv)
+    mates = [synth.codes_to_ascii(c1), synth.codes_to_ascii(c2)]
+    res = helpers.hip_sample(eng, mates, 31)
+    pile = oracle.sample_pileup(ix, mates)
+    helpers.assert_same_pileup(res, pile)
+    assert oracle.pick_best_genome(ix, res.stats.sum(axis=0), res.present.max(axis=0)) == 7
+    eng.close()
+    ix.close()
+
+
+def test_multi_sequence_genomes_and_short_sequences(oracle):
+    """Segmented genomes: several sequences per file, one shorter than k (no k-mers), diagonals must not cross
+    sequence boundaries."""
+    base = synth.read_fasta_bytes(os.path.join(helpers.GOLDEN, "HPV16.fa"))
+    files = [("segA", [("a1", base[:3000]), ("a2", base[3000:3010]), ("a3", base[3010:6000])]),
+             ("segB", [("b1", base[5000:7906]), ("b2", base[100:1500])])]
+    ix = oracle.Index.build_mem(21, files)
+    eng = helpers.engine_from_oracle_index(ix)
+    reads = helpers.hpv_reads(15000, seed=12)
+    res = helpers.hip_sample(eng, [reads], 21)
+    pile = oracle.sample_pileup(ix, [reads])
+    helpers.assert_same_pileup(res, pile)
+    eng.close()
+    ix.close()
+
+
+def test_config2_full_size_one_million_reads(oracle, sars_paths):
+    """BASELINE config 2 at full size: 1,000,000 x 150 bp single-end reads vs wuhan_ref k=21 (the bench workload),
+    compared cell for cell with the oracle; plus the order / batching invariance the max / + votes imply."""
+    ix = oracle.Index.build(21, sars_paths[:1])
+    eng = helpers.engine_from_oracle_index(ix)
+    ref = synth.read_fasta_bytes(sars_paths[0])
+    gm, isnv = synth.sample_genome(ref, 2)
+    codes = synth.single_end_codes(gm, 1000000, 150, 2 * 1000003, err=0.005, isnv=isnv)
+    words, lens = synth.pack_codes(codes)
+    eng.sample_begin()
+    eng.push_reads(0, words, lens)
+    res = eng.sample_finish(1)
+    pile = oracle.sample_pileup(ix, [synth.codes_to_ascii(codes)])
+    helpers.assert_same_pileup(res, pile)
+    assert res.kmer_stats[0, 1] == 130000000
+    # same reads, reversed and pushed in 7 uneven batches
+    eng.sample_begin()
+    bounds = [0, 10, 99999, 100000, 333333, 800001, 999999, 1000000]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        eng.push_reads(0, words[::-1][a:b], lens[::-1][a:b])
+    res2 = eng.sample_finish(1)
+    for x, y in zip(res.arrays(), res2.arrays()):
+        assert np.array_equal(x, y)
+    assert np.array_equal(res.stats, res2.stats)
+    eng.close()
+    ix.close()

@@ -19,7 +19,8 @@ class IndexDesc(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [("n_fixed", C.c_int32), ("use_full_kmer", C.c_int32), ("ci", C.c_uint64), ("cs", C.c_uint64),
-                ("cx", C.c_uint64), ("device", C.c_int32), ("reserved", C.c_int32)]
+                ("cx", C.c_uint64), ("device", C.c_int32), ("full_kmer_stats", C.c_int32),
+                ("kmer_table_log2", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 # every symbol include/bronko_hip.h declares (checked by tests/test_abi.py)

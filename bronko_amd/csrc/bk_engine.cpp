@@ -122,6 +122,10 @@ struct bk_engine {
     DevBuf<uint32_t> ref_words, bits_clean, bits_follow, bits_rc, id_at;
     struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0; } half_lo, half_hi;
     DevBuf<unsigned int> deferred, n_deferred;
+    DevBuf<unsigned int> fin_partials;      // per-workgroup finalize tallies (small genome sets only)
+    DevBuf<unsigned long long> ktab_keys;   // full_kmer_stats: open-addressing table of non-index-touching k-mers
+    DevBuf<unsigned int> ktab_cnt;
+    DevBuf<unsigned long long> ktab_out;    // [2 mates][2] distinct, kept  + [4] overflow flag
     DevBuf<uint32_t> slot_of, estat_off, estat;
     DevBuf<uint8_t> amb;
     DevBuf<uint16_t> pilots;
@@ -192,6 +196,8 @@ void bk_params_default(bk_params* p) {
     p->cs = 1000000;          // call.rs:1173
     p->cx = 1000000000ull;    // KMC default -cx
     p->device = 0;
+    p->full_kmer_stats = 0;
+    p->kmer_table_log2 = 26;
     p->reserved = 0;
 }
 
@@ -512,6 +518,13 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     BK_HIP(e->entries.upload(h_ent));
     if (bk::v_plane_len(e->n_u, e->W) >= (1ull << 32)) return fail(BK_ERR_UNSUPPORTED, "index too large: variant counter plane exceeds 2^32 counters");
     for (int m = 0; m < 2; m++) BK_HIP(e->counters[m].alloc(bk::e_plane_len(e->n_u) + bk::v_plane_len(e->n_u, e->W)));
+    if (prm->full_kmer_stats) {
+        if (prm->kmer_table_log2 < 10 || prm->kmer_table_log2 > 31) return fail(BK_ERR_INVALID, "kmer_table_log2 out of range");
+        BK_HIP(e->ktab_keys.alloc((size_t)1 << prm->kmer_table_log2));
+        BK_HIP(e->ktab_cnt.alloc((size_t)1 << prm->kmer_table_log2));
+    }
+    BK_HIP(e->ktab_out.alloc(8));
+    if (e->n_files <= 64) BK_HIP(e->fin_partials.alloc(bk::finalize_partial_rows() * ((size_t)e->n_files * 3 + 2)));
     BK_HIP(e->deferred.alloc(bk::v_plane_len(e->n_u, e->W)));
     BK_HIP(e->n_deferred.alloc(1));
     if (e->n_lds_bins >= e->n_u) e->use_xcd_planes = false;   // every reference k-mer has an LDS bin
@@ -563,6 +576,11 @@ int bk_sample_begin(bk_engine* e) {
     BK_HIP(hipMemsetAsync(e->stats.p, 0, e->stats.n * sizeof(unsigned long long), e->stream));
     BK_HIP(hipMemsetAsync(e->present.p, 0, e->present.n, e->stream));
     BK_HIP(hipMemsetAsync(e->kstats.p, 0, e->kstats.n * sizeof(unsigned long long), e->stream));
+    BK_HIP(hipMemsetAsync(e->ktab_out.p, 0, e->ktab_out.n * sizeof(unsigned long long), e->stream));
+    if (e->ktab_keys.p) {
+        BK_HIP(hipMemsetAsync(e->ktab_keys.p, 0xff, e->ktab_keys.n * sizeof(unsigned long long), e->stream));
+        BK_HIP(hipMemsetAsync(e->ktab_cnt.p, 0, e->ktab_cnt.n * sizeof(unsigned int), e->stream));
+    }
     e->pushed_records[0] = e->pushed_records[1] = 0;
     e->in_sample = true;
     return BK_OK;
@@ -582,6 +600,8 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.slabs = e->slabs.p;
     a.n_lds_bins = e->n_lds_bins;
     a.ref_in_lds = e->ref_in_lds ? 1 : 0;
+    a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->params.kmer_table_log2;
+    a.ktab_overflow = e->ktab_out.p + 4; a.mate = (uint32_t)mate;
     const uint32_t grid = bk::scan_grid(n, e->n_cus);
     {
         bk_engine::Span sp(e, 0);
@@ -661,11 +681,17 @@ int bk_sample_finalize(bk_engine* e, int n_mates) {
         a.stats = e->stats.p + (size_t)m * e->n_files * 3;
         a.present = e->present.p + (size_t)m * e->n_files;
         a.kept_total = e->kstats.p + m * 4 + 3;
+        a.distinct_total = e->kstats.p + m * 4 + 2;
+        a.partials = e->fin_partials.p;
         a.deferred = e->deferred.p;
         a.n_deferred = e->n_deferred.p;
         BK_HIP(hipMemsetAsync(e->n_deferred.p, 0, sizeof(unsigned int), e->stream));
         bk_engine::Span sp(e, 1);
         bk::launch_finalize(a, e->stream);
+    }
+    if (e->ktab_keys.p) {
+        bk_engine::Span sp(e, 1);
+        bk::launch_ktab_stats(e->ktab_keys.p, e->ktab_cnt.p, e->params.kmer_table_log2, e->params.ci, e->params.cx, e->ktab_out.p, e->stream);
     }
     BK_HIP(hipGetLastError());
     e->in_sample = false;
@@ -687,8 +713,22 @@ int bk_sample_download(bk_engine* e, int n_mates, uint64_t* fwd_depth, uint64_t*
         if (present) BK_HIP(hipMemcpyAsync(present, e->present.p, (size_t)n_mates * e->n_files, hipMemcpyDeviceToHost, e->stream));
         if (kmer_stats) BK_HIP(hipMemcpyAsync(kmer_stats, e->kstats.p, (size_t)n_mates * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
     }
+    unsigned long long kt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (kmer_stats) BK_HIP(hipMemcpyAsync(kt, e->ktab_out.p, sizeof kt, hipMemcpyDeviceToHost, e->stream));
     BK_HIP(hipStreamSynchronize(e->stream));
-    if (kmer_stats) for (int m = 0; m < n_mates; m++) kmer_stats[m * 4 + 0] = e->pushed_records[m];
+    if (kmer_stats) {
+        for (int m = 0; m < n_mates; m++) {
+            kmer_stats[m * 4 + 0] = e->pushed_records[m];
+            if (e->ktab_keys.p) {
+                // index-touching k-mers are in the counter plane (kept tally in [3], distinct tally in [2] by finalize);
+                // the rest are in the hash table
+                if (kt[4]) { kmer_stats[m * 4 + 2] = kmer_stats[m * 4 + 3] = ~0ull; }
+                else { kmer_stats[m * 4 + 2] += kt[m * 2 + 0]; kmer_stats[m * 4 + 3] += kt[m * 2 + 1]; }
+            } else {
+                kmer_stats[m * 4 + 2] = 0;
+            }
+        }
+    }
     return BK_OK;
 }
 

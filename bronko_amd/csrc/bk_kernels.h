@@ -26,6 +26,12 @@ struct ScanArgs {
     unsigned int* e_planes;         // [8 XCDs][E] u32 planes for positions >= n_lds_bins; null if none / disabled
     int ref_in_lds;                 // stage the packed reference + flag bits in LDS (they fit next to the histogram)
     unsigned long long* kmer_total; // optional: += k-mer occurrences scanned
+    // full_kmer_stats: k-mers that do not touch the index are counted in this open-addressing table (null = off)
+    unsigned long long* ktab_keys;  // [1 << ktab_log2] canonical k-mer | orientation << 63 | mate << 62; ~0 = free
+    unsigned int* ktab_cnt;
+    uint32_t ktab_log2;
+    unsigned long long* ktab_overflow;
+    uint32_t mate;
     int ablate;                     // measurement aid, 0 in production (see scan_count_kernel)
 };
 
@@ -38,6 +44,9 @@ struct FinalizeArgs {
     unsigned long long* stats;      // [n_files][3]
     unsigned char* present;         // [n_files]
     unsigned long long* kept_total; // optional: += distinct k-mers that passed the thresholds
+    unsigned long long* distinct_total; // optional: += distinct k-mers seen at all (non-zero counters)
+    unsigned int* partials;         // [finalize_partial_rows()][n_files*3 + 2] per-workgroup tallies, or null: use atomics
+    int row_exact, row_general;     // first partials row of K2e / K2b (set by launch_finalize)
     unsigned int* deferred;         // [v_plane_len] V counter indices K2a hands to K2b
     unsigned int* n_deferred;       // [1], zeroed before each finalize
 };
@@ -57,7 +66,10 @@ size_t scan_ref_lds_bytes(uint32_t total_cells);
 size_t scan_lds_bytes(uint32_t n_lds_bins, bool ref_in_lds, uint32_t total_cells);
 hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t stream);
 void launch_fold(const FoldArgs& f, hipStream_t stream);
+void launch_ktab_stats(const unsigned long long* keys, const unsigned int* cnt, uint32_t log2n, unsigned long long ci,
+                       unsigned long long cx, unsigned long long* out, hipStream_t stream);
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
 size_t finalize_lds_bytes(int n_files);
+size_t finalize_partial_rows();
 
 }  // namespace bk

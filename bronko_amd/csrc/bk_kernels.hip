@@ -81,6 +81,62 @@ __device__ __forceinline__ void for_each_neighbour(const IndexView& ix, uint64_t
     }
 }
 
+// full_kmer_stats: +1 on a k-mer that does not touch the index, in an open-addressing table keyed by
+// (canonical k-mer, read orientation, mate file) -- i.e. by the strand-specific k-mer KMC -b counts.
+struct KmerTable {
+    unsigned long long* keys;
+    unsigned int* cnt;
+    uint32_t log2n;
+    unsigned long long* overflow;
+    uint32_t mate;
+};
+
+__device__ __forceinline__ void ktab_insert(const KmerTable& t, uint64_t c, uint32_t isrc) {
+    const unsigned long long key = c | ((unsigned long long)isrc << 63) | ((unsigned long long)t.mate << 62);
+    const uint32_t mask = (1u << t.log2n) - 1u;   // log2n <= 32 handled by the host (<= 34 uses 64-bit below)
+    uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> (64 - t.log2n);
+    for (uint32_t probes = 0; probes < 4096; ++probes) {
+        const unsigned long long old = atomicCAS(t.keys + h, ~0ull, key);
+        if (old == ~0ull || old == key) {
+            if (t.cnt[h] < 0xfffffff0u) atomicAdd(t.cnt + h, 1u);   // saturates far above any -cx
+            return;
+        }
+        h = (h + 1) & (uint64_t)mask;
+    }
+    *t.overflow = 1ull;   // table (nearly) full: statistics are reported as unavailable
+}
+
+__global__ __launch_bounds__(256) void ktab_stats_kernel(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ cnt,
+                                                         uint64_t n, unsigned long long ci, unsigned long long cx, unsigned long long* out) {
+    unsigned int d0 = 0, d1 = 0, k0 = 0, k1 = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const unsigned long long key = keys[i];
+        if (key == ~0ull) continue;
+        const unsigned int c = cnt[i];
+        const bool kept = c >= ci && c <= cx;
+        if ((key >> 62) & 1ull) { ++d1; k1 += kept; } else { ++d0; k0 += kept; }
+    }
+    auto wave_sum = [](unsigned int v) {
+#pragma unroll
+        for (int off = 32; off; off >>= 1) v += (unsigned int)__shfl_xor((int)v, off);
+        return v;
+    };
+    d0 = wave_sum(d0); d1 = wave_sum(d1); k0 = wave_sum(k0); k1 = wave_sum(k1);
+    if ((threadIdx.x & 63) == 0) {
+        if (d0) atomicAdd(out + 0, (unsigned long long)d0);
+        if (k0) atomicAdd(out + 1, (unsigned long long)k0);
+        if (d1) atomicAdd(out + 2, (unsigned long long)d1);
+        if (k1) atomicAdd(out + 3, (unsigned long long)k1);
+    }
+}
+
+void launch_ktab_stats(const unsigned long long* keys, const unsigned int* cnt, uint32_t log2n, unsigned long long ci,
+                       unsigned long long cx, unsigned long long* out, hipStream_t stream) {
+    const uint64_t n = 1ull << log2n;
+    uint64_t blocks = std::min<uint64_t>((n + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(ktab_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, keys, cnt, n, ci, cx, out);
+}
+
 // ------------------------------------------------------------------------------------------------ K1
 // Persistent workgroups of 16 waves (one per CU: the LDS histogram takes most of the CU's 160 KB); each wave
 // takes tiles of 64 records, one record per lane.  The k-mer loop is wave-uniform (trip count = longest record
@@ -136,12 +192,15 @@ struct SlowPipe {
     bool have = false;      // this lane holds a k-mer of the batch
     uint64_t c = 0, lo = 0, hi = 0;
     uint32_t isrc = 0, pil_u = 0, pil_lo = 0, pil_hi = 0, cnt_lo = 0, cnt_hi = 0;
+    bool stat_only = false; // known not to touch the index: only the k-mer statistics table wants it
     uint4 e_u{}, d_lo{}, d_hi{}, e_lo{}, e_hi{};
 
     __device__ __forceinline__ void start(const QueueView& q, uint32_t n, int lane, const IndexView& ix) {
         have = (uint32_t)lane < n;
         c = have ? q.c[lane] : 0ull;
-        isrc = have ? q.meta[lane] : 0u;
+        const uint32_t meta = have ? q.meta[lane] : 0u;
+        isrc = meta & 1u;
+        stat_only = (meta & 2u) != 0;
         const int lo_bits = 2 * ix.lo_bases;
         lo = c & ((1ull << lo_bits) - 1ull);
         hi = c >> lo_bits;
@@ -152,19 +211,20 @@ struct SlowPipe {
     }
 
     template <bool COUNT, typename CountExact>
-    __device__ __forceinline__ void advance(const IndexView& ix, unsigned long long* __restrict__ v_counters, CountExact&& count_exact) {
+    __device__ __forceinline__ void advance(const IndexView& ix, unsigned long long* __restrict__ v_counters, CountExact&& count_exact,
+                                            const KmerTable& kt) {
         if (stage == 1) {
             e_u = *reinterpret_cast<const uint4*>(ix.kmer_pos + phf_pos(c, pil_u, ix.m));
             d_lo = *reinterpret_cast<const uint4*>(ix.lo.dir + phf_pos(lo, pil_lo, ix.lo.m));
             d_hi = *reinterpret_cast<const uint4*>(ix.hi.dir + phf_pos(hi, pil_hi, ix.hi.m));
             stage = 2;
         } else if (stage == 2) {
-            if (have && ((uint64_t)e_u.x | ((uint64_t)e_u.y << 32)) == c) {   // a reference k-mer after all
+            if (have && !stat_only && ((uint64_t)e_u.x | ((uint64_t)e_u.y << 32)) == c) {   // a reference k-mer after all
                 count_exact(e_u.w & kIdMask, isrc);
                 have = false;
             }
-            cnt_lo = (have && d_lo.x == (uint32_t)lo) ? d_lo.z : 0u;
-            cnt_hi = (have && d_hi.x == (uint32_t)hi) ? d_hi.z : 0u;
+            cnt_lo = (have && !stat_only && d_lo.x == (uint32_t)lo) ? d_lo.z : 0u;
+            cnt_hi = (have && !stat_only && d_hi.x == (uint32_t)hi) ? d_hi.z : 0u;
             if (cnt_lo) e_lo = *reinterpret_cast<const uint4*>(ix.lo.cand + d_lo.y);
             if (cnt_hi) e_hi = *reinterpret_cast<const uint4*>(ix.hi.cand + d_hi.y);
             stage = 3;
@@ -189,21 +249,24 @@ struct SlowPipe {
                 unsigned long long* ctr = v_counters + (((uint64_t)p * ix.W + (uint32_t)(j - ix.wstart)) * 4 + b) * 2 + isrc;
                 if (COUNT) atomicAdd(ctr, 1ull);
                 else if (best == 0x123456789ull) *ctr = 1;   // measurement aid: keep the lookup alive without the atomic
+            } else if (have && kt.keys) {
+                ktab_insert(kt, c, isrc);   // touches no window bucket: only KMC's distinct / counted totals see it
             }
             stage = 0;
         }
     }
 
     template <bool COUNT, typename CountExact>
-    __device__ __forceinline__ void finish(const IndexView& ix, unsigned long long* __restrict__ v_counters, CountExact&& count_exact) {
-        while (stage) advance<COUNT>(ix, v_counters, count_exact);
+    __device__ __forceinline__ void finish(const IndexView& ix, unsigned long long* __restrict__ v_counters, CountExact&& count_exact,
+                                           const KmerTable& kt) {
+        while (stage) advance<COUNT>(ix, v_counters, count_exact, kt);
     }
 };
 
 // MODE is a measurement aid (BK_SCAN_ABLATE): 0 = product kernel; 1 = exact-match counting dropped; 2 = only the
 // rolling k-mer extraction; 3 = slow path and variant atomics dropped; 4 = variant atomics dropped.  Modes 1-4
 // produce incomplete counts.
-template <int MODE, bool REF_LDS>
+template <int MODE, bool REF_LDS, bool STATS>
 __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* queue_c = reinterpret_cast<unsigned long long*>(smem);
@@ -270,6 +333,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
         else if (id == 0x12345678u) *ctr = 1;
     };
 
+    const KmerTable kt{STATS ? a.ktab_keys : nullptr, a.ktab_cnt, a.ktab_log2, a.ktab_overflow, a.mate};   // STATS = full_kmer_stats
     uint32_t nkm = 0;  // k-mer occurrences seen by this lane
     uint32_t qn = 0;   // wave-uniform queue fill
     uint32_t sink = 0; // MODE 2 only
@@ -336,6 +400,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 //      case: ~one lane in ten).  Provably not a reference k-mer, and that k-mer is its only possible
                 //      neighbour (bk_device.h, amb): name its V counter on the spot, or it touches nothing.
                 const bool simple = id_known && clean && n_diff == 1;
+                bool stat_only = false;   // full_kmer_stats: a k-mer known to touch nothing still has to be counted somewhere
                 if (simple) {
                     const bool lt = f_hi < r_hi || (f_hi == r_hi && f_lo < r_lo);   // lcb.rs:90-94
                     const uint32_t isrc = lt ? 0u : 1u;
@@ -346,20 +411,25 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                         const uint32_t c_lo = lt ? f_lo : r_lo, c_hi = lt ? f_hi : r_hi;
                         const uint32_t bb = (sh >= 32 ? c_hi >> (sh - 32) : c_lo >> sh) & 3u;
                         count_variant(id, j, bb, isrc);
+                    } else {
+                        stat_only = STATS;
                     }
                 }
                 // ---- tier 3: everything else -- unknown id, several differences, dirty neighbourhoods, lost lanes,
                 //      the miss queue and the slow pipeline ---------------------------------------------------------
                 const bool slow = valid && !exact && !simple;
-                if (__ballot(slow) || qn >= 64 || pipe.stage) {
+                if (__ballot(slow | stat_only) || qn >= 64 || pipe.stage) {
                     const IndexView& ix = *a.ixp;
                     bool lookup = false, miss = false;
                     uint64_t c = 0;
                     uint32_t isrc = 0;
-                    if (slow) {
+                    if (slow | stat_only) {
                         const bool lt = f_hi < r_hi || (f_hi == r_hi && f_lo < r_lo);
                         isrc = lt ? 0u : 1u;
                         c = lt ? (((uint64_t)f_hi << 32) | f_lo) : (((uint64_t)r_hi << 32) | r_lo);
+                        miss = stat_only;
+                    }
+                    if (slow) {
                         if (!ok) {
                             lookup = true;                                   // no diagonal: perfect-hash lookup, may re-seed
                         } else {
@@ -377,6 +447,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                                     const int j = isrc ? from_right : k - 1 - from_right;
                                     if (ref_isrc == isrc && j >= wlo && j < whi)
                                         count_variant(id, j, (uint32_t)(c >> (2 * (k - 1 - j))) & 3u, isrc);
+                                    else if (STATS) { miss = true; stat_only = true; }
                                 }
                             }
                             if (!done) {
@@ -408,14 +479,14 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                     const unsigned long long mm = __ballot(miss);
                     if (mm) {
                         const uint32_t pos = qn + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
-                        if (miss) { q.c[pos] = c; q.meta[pos] = (unsigned char)isrc; }
+                        if (miss) { q.c[pos] = c; q.meta[pos] = (unsigned char)(isrc | (stat_only ? 2u : 0u)); }
                         qn += (uint32_t)__popcll(mm);
                         __builtin_amdgcn_wave_barrier();
                     }
                     if (qn >= 64) {
                         // a full batch is waiting: retire the batch in flight (its loads were issued steps ago), then
                         // take 64 k-mers off the queue and issue the first loads of the new batch
-                        pipe.template finish<MODE != 4>(ix, v_counters, count_exact);
+                        pipe.template finish<MODE != 4>(ix, v_counters, count_exact, kt);
                         pipe.start(q, 64, lane, ix);
                         const uint32_t rest = qn - 64;
                         const unsigned long long tc = ((uint32_t)lane < rest) ? q.c[64 + lane] : 0ull;
@@ -425,7 +496,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                         __builtin_amdgcn_wave_barrier();
                         qn = rest;
                     } else if (pipe.stage) {
-                        pipe.template advance<MODE != 4>(ix, v_counters, count_exact);
+                        pipe.template advance<MODE != 4>(ix, v_counters, count_exact, kt);
                     }
                 }
             }
@@ -433,10 +504,10 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     }
     {
         const IndexView& ix = *a.ixp;
-        pipe.template finish<MODE != 4>(ix, v_counters, count_exact);
+        pipe.template finish<MODE != 4>(ix, v_counters, count_exact, kt);
         if (qn) {
             pipe.start(q, qn, lane, ix);
-            pipe.template finish<MODE != 4>(ix, v_counters, count_exact);
+            pipe.template finish<MODE != 4>(ix, v_counters, count_exact, kt);
         }
     }
     if (MODE == 2 && sink == 0x1234567) a.counters[0] = sink;   // keeps the sink alive, never true in practice
@@ -467,20 +538,21 @@ uint32_t scan_grid(uint64_t n_records, int n_cus) {
 }
 
 template <bool REF_LDS>
-static void (*pick_scan_kernel(int ablate))(ScanArgs) {
+static void (*pick_scan_kernel(int ablate, bool stats))(ScanArgs) {
     switch (ablate) {
-        case 1: return scan_count_kernel<1, REF_LDS>;
-        case 2: return scan_count_kernel<2, REF_LDS>;
-        case 3: return scan_count_kernel<3, REF_LDS>;
-        case 4: return scan_count_kernel<4, REF_LDS>;
-        default: return scan_count_kernel<0, REF_LDS>;
+        case 1: return scan_count_kernel<1, REF_LDS, false>;
+        case 2: return scan_count_kernel<2, REF_LDS, false>;
+        case 3: return scan_count_kernel<3, REF_LDS, false>;
+        case 4: return scan_count_kernel<4, REF_LDS, false>;
+        default: return stats ? scan_count_kernel<0, REF_LDS, true> : scan_count_kernel<0, REF_LDS, false>;
     }
 }
 
 hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t stream) {
     if (a.n_records == 0 || a.W <= 0) return hipSuccess;
     const size_t lds = scan_lds_bytes(a.n_lds_bins, a.ref_in_lds != 0, a.total_cells);
-    void (*kern)(ScanArgs) = a.ref_in_lds ? pick_scan_kernel<true>(a.ablate) : pick_scan_kernel<false>(a.ablate);
+    const bool stats = a.ktab_keys != nullptr;
+    void (*kern)(ScanArgs) = a.ref_in_lds ? pick_scan_kernel<true>(a.ablate, stats) : pick_scan_kernel<false>(a.ablate, stats);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kScanBlock), lds, stream, a);
@@ -546,6 +618,54 @@ __device__ __forceinline__ void vote(const FinalizeArgs& a, const DevEntry& e, u
     atomicMax(a.pileup + (forward ? 0 : 1) * a.plane + cell, v);      // depth = max(depth, n)
 }
 
+// End of a finalize workgroup: per-genome tallies (LDS) and the kept / distinct k-mer tallies either go to this
+// workgroup's row of `partials` (no atomics; finalize_reduce adds the rows up) or, without a partials buffer, straight
+// to the global words.  Thousands of workgroups doing same-address atomics would serialise at ~12 ns each.
+__device__ __forceinline__ void finalize_epilogue(const FinalizeArgs& a, const uint32_t* lstats, unsigned int kept, unsigned int distinct,
+                                                  uint32_t* scratch2 /* LDS, 2 words, zeroed */, int row) {
+    const int n3 = a.ix.n_files * 3;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) { kept += (unsigned int)__shfl_xor((int)kept, off); distinct += (unsigned int)__shfl_xor((int)distinct, off); }
+    if ((threadIdx.x & 63) == 0) { if (kept) atomicAdd(&scratch2[0], kept); if (distinct) atomicAdd(&scratch2[1], distinct); }
+    __syncthreads();
+    if (a.partials) {
+        uint32_t* out = a.partials + (size_t)row * (n3 + 2);
+        for (int g = threadIdx.x; g < n3; g += blockDim.x) out[g] = lstats[g];
+        if (threadIdx.x == 0) { out[n3] = scratch2[0]; out[n3 + 1] = scratch2[1]; }
+    } else {
+        for (int g = threadIdx.x; g < a.ix.n_files; g += blockDim.x) {
+            const uint32_t pf = lstats[g * 3], vr = lstats[g * 3 + 1], un = lstats[g * 3 + 2];
+            if (pf) atomicAdd(a.stats + (size_t)g * 3 + 0, (unsigned long long)pf);
+            if (vr) atomicAdd(a.stats + (size_t)g * 3 + 1, (unsigned long long)vr);
+            if (un) atomicAdd(a.stats + (size_t)g * 3 + 2, (unsigned long long)un);
+            if (pf | vr) a.present[g] = 1;
+        }
+        if (threadIdx.x == 0) {
+            if (scratch2[0] && a.kept_total) atomicAdd(a.kept_total, (unsigned long long)scratch2[0]);
+            if (scratch2[1] && a.distinct_total) atomicAdd(a.distinct_total, (unsigned long long)scratch2[1]);
+        }
+    }
+}
+
+// stats / present / kept / distinct += column sums of the partials rows written by the finalize workgroups
+__global__ __launch_bounds__(256) void finalize_reduce_kernel(FinalizeArgs a, int n_rows) {
+    __shared__ unsigned long long wave_sums[4];
+    const int n3 = a.ix.n_files * 3, cols = n3 + 2;
+    const int col = blockIdx.x;   // one workgroup per column, rows strided over its threads
+    unsigned long long s = 0;
+    for (int r = threadIdx.x; r < n_rows; r += 256) s += a.partials[(size_t)r * cols + col];
+#pragma unroll
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    s = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+    if (!s) return;
+    if (col < n3) { a.stats[col] += s; if (col % 3 != 2) a.present[col / 3] = 1; }
+    else if (col == n3) { if (a.kept_total) *a.kept_total += s; }
+    else if (a.distinct_total) *a.distinct_total += s;
+}
+
 // K2a: one thread per V counter.  A kept non-reference k-mer almost always touches exactly one window bucket
 // (the one its name says); then the whole of map_kmers for it is: vote once per BucketInfo of that bucket,
 // and per genome file "variant" (or "perfect" if the file has exactly W entries there, which needs W == 1 or
@@ -554,18 +674,19 @@ __device__ __forceinline__ void vote(const FinalizeArgs& a, const DevEntry& e, u
 __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const IndexView& ix = a.ix;
-    uint32_t* lstats = reinterpret_cast<uint32_t*>(smem);   // [n_files][3] block-local tallies
-    for (int g = threadIdx.x; g < ix.n_files * 3; g += 256) lstats[g] = 0;
+    uint32_t* lstats = reinterpret_cast<uint32_t*>(smem);   // [n_files][3] block-local tallies + 2 scratch words
+    for (int g = threadIdx.x; g < ix.n_files * 3 + 2; g += 256) lstats[g] = 0;
     __syncthreads();
 
     const int k = ix.k;
     const uint64_t n_e = e_plane_len(ix.n_u);
     const uint64_t n_v = v_plane_len(ix.n_u, ix.W);
     const unsigned long long* __restrict__ vc = a.counters + n_e;
-    unsigned int kept = 0;
+    unsigned int kept = 0, distinct = 0;
 
     for (uint64_t vi = (uint64_t)blockIdx.x * 256 + threadIdx.x; vi < n_v; vi += (uint64_t)gridDim.x * 256) {
         const unsigned long long n = vc[vi];
+        distinct += n != 0;
         if (n == 0 || n < a.ci || n > a.cx) continue;           // kmc -ci / -cx act on the true count
         ++kept;
         const unsigned long long v = n > a.cs ? a.cs : n;       // kmc -cs: reported count saturates
@@ -604,18 +725,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
     }
     __syncthreads();
-    for (int g = threadIdx.x; g < ix.n_files; g += 256) {
-        const uint32_t pf = lstats[g * 3], vr = lstats[g * 3 + 1], un = lstats[g * 3 + 2];
-        if (pf) atomicAdd(a.stats + (size_t)g * 3 + 0, (unsigned long long)pf);
-        if (vr) atomicAdd(a.stats + (size_t)g * 3 + 1, (unsigned long long)vr);
-        if (un) atomicAdd(a.stats + (size_t)g * 3 + 2, (unsigned long long)un);
-        if (pf | vr) a.present[g] = 1;
-    }
-    // kept tally: wave reduce, one atomic per wave
-    unsigned int tot = kept;
-#pragma unroll
-    for (int off = 32; off; off >>= 1) tot += (unsigned int)__shfl_xor((int)tot, off);
-    if ((threadIdx.x & 63) == 0 && tot && a.kept_total) atomicAdd(a.kept_total, (unsigned long long)tot);
+    finalize_epilogue(a, lstats, kept, distinct, lstats + ix.n_files * 3, (int)blockIdx.x);
 }
 
 // K2e: the E counters (reference k-mers).  A reference k-mer owns all W of its window buckets (slot_of), and its
@@ -625,17 +735,18 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
 __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const IndexView& ix = a.ix;
-    uint32_t* lstats = reinterpret_cast<uint32_t*>(smem);   // [n_files][3] block-local tallies
-    for (int g = threadIdx.x; g < ix.n_files * 3; g += 256) lstats[g] = 0;
+    uint32_t* lstats = reinterpret_cast<uint32_t*>(smem);   // [n_files][3] block-local tallies + 2 scratch words
+    for (int g = threadIdx.x; g < ix.n_files * 3 + 2; g += 256) lstats[g] = 0;
     __syncthreads();
     const int k = ix.k;
     const uint32_t W = (uint32_t)ix.W;
     const uint64_t n_work = e_plane_len(ix.n_u) * W;
-    unsigned int kept = 0;
+    unsigned int kept = 0, distinct = 0;
     for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < n_work; g += (uint64_t)gridDim.x * 256) {
         const uint64_t cidx = g / W;
         const uint32_t t = (uint32_t)(g % W);
         const unsigned long long n = a.counters[cidx];
+        distinct += (n != 0 && t == 0);
         if (n == 0 || n < a.ci || n > a.cx) continue;           // kmc -ci / -cx act on the true count
         const unsigned long long v = n > a.cs ? a.cs : n;       // kmc -cs: reported count saturates
         const uint32_t id = (uint32_t)(cidx >> 1), isrc = (uint32_t)cidx & 1u;
@@ -655,17 +766,7 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
         }
     }
     __syncthreads();
-    for (int g = threadIdx.x; g < ix.n_files; g += 256) {
-        const uint32_t pf = lstats[g * 3], vr = lstats[g * 3 + 1], un = lstats[g * 3 + 2];
-        if (pf) atomicAdd(a.stats + (size_t)g * 3 + 0, (unsigned long long)pf);
-        if (vr) atomicAdd(a.stats + (size_t)g * 3 + 1, (unsigned long long)vr);
-        if (un) atomicAdd(a.stats + (size_t)g * 3 + 2, (unsigned long long)un);
-        if (pf | vr) a.present[g] = 1;
-    }
-    unsigned int tot = kept;
-#pragma unroll
-    for (int off = 32; off; off >>= 1) tot += (unsigned int)__shfl_xor((int)tot, off);
-    if ((threadIdx.x & 63) == 0 && tot && a.kept_total) atomicAdd(a.kept_total, (unsigned long long)tot);
+    finalize_epilogue(a, lstats, kept, distinct, lstats + ix.n_files * 3, a.row_exact + (int)blockIdx.x);
 }
 
 // K2b: one wave per workgroup and per k-mer, for the V counters K2a deferred (k-mers that touch several window
@@ -691,21 +792,13 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
     const size_t S = (size_t)1 << ix.log2s;
     const uint64_t n_e = e_plane_len(ix.n_u);
     const uint64_t n_items = *a.n_deferred;   // the E counters are mapped by K2e
-    unsigned long long kept = 0;
 
-    for (uint64_t base = (uint64_t)blockIdx.x * 64; base < n_items; base += (uint64_t)gridDim.x * 64) {
-        const uint64_t item = base + lane;
-        uint64_t cidx = ~0ull;                                   // index into the counter plane
-        if (item < n_items) cidx = n_e + a.deferred[item];
-        const unsigned long long n = cidx != ~0ull ? a.counters[cidx] : 0ull;
-        const bool pass = n >= a.ci && n <= a.cx && n != 0;     // kmc -ci / -cx act on the true count
-        unsigned long long todo = __ballot(pass);
-        // (kept k-mers were already tallied by K2a)
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const uint64_t ci = __shfl(cidx, src);
-            unsigned long long v = __shfl(n, src);
+    // deferred items all passed the thresholds in K2a; one item per wave at a time, dealt round-robin so that a few
+    // thousand items spread over the whole grid
+    for (uint64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        {
+            const uint64_t ci = n_e + a.deferred[item];
+            unsigned long long v = a.counters[ci];
             v = v > a.cs ? a.cs : v;                              // kmc -cs: reported count saturates
             uint64_t c;
             uint32_t isrc;
@@ -763,45 +856,36 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
         }
     }
     __syncthreads();
-    for (int g = lane; g < ix.n_files; g += 64) {
-        const uint32_t p = lstats[g * 3], v = lstats[g * 3 + 1], u = lstats[g * 3 + 2];
-        if (p) atomicAdd(a.stats + (size_t)g * 3 + 0, (unsigned long long)p);
-        if (v) atomicAdd(a.stats + (size_t)g * 3 + 1, (unsigned long long)v);
-        if (u) atomicAdd(a.stats + (size_t)g * 3 + 2, (unsigned long long)u);
-        if (p | v) a.present[g] = 1;
-    }
-    if (lane == 0 && kept && a.kept_total) atomicAdd(a.kept_total, kept);
+    if (lane == 0) { ntouched[0] = 0; ntouched[1] = 0; }
+    __syncthreads();
+    finalize_epilogue(a, lstats, 0u, 0u, ntouched, a.row_general + (int)blockIdx.x);
 }
 
 size_t finalize_lds_bytes(int n_files) { return ((size_t)n_files * 5 + 4) * sizeof(uint32_t); }
+constexpr unsigned kFinVariantBlocks = 256 * 8, kFinExactBlocks = 256 * 8, kFinGeneralBlocks = 256 * 4;
+size_t finalize_partial_rows() { return (size_t)kFinVariantBlocks + kFinExactBlocks + kFinGeneralBlocks; }
 
-void launch_finalize(const FinalizeArgs& a, hipStream_t stream) {
-    if (a.ix.W <= 0) return;
+void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
+    if (a0.ix.W <= 0) return;
+    FinalizeArgs a = a0;
+    const size_t lds_stats = ((size_t)a.ix.n_files * 3 + 2) * sizeof(uint32_t);
     // K2a
-    {
-        const uint64_t n_v = v_plane_len(a.ix.n_u, a.ix.W);
-        uint64_t blocks = (n_v + 255) / 256;
-        if (blocks > 256 * 8) blocks = 256 * 8;
-        if (blocks < 1) blocks = 1;
-        const size_t lds = std::max<size_t>((size_t)a.ix.n_files * 3 * sizeof(uint32_t), 16);
-        hipLaunchKernelGGL(finalize_variant_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
-    }
+    const uint64_t n_v = v_plane_len(a.ix.n_u, a.ix.W);
+    const unsigned b_var = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_v + 255) / 256, kFinVariantBlocks));
+    hipLaunchKernelGGL(finalize_variant_kernel, dim3(b_var), dim3(256), lds_stats, stream, a);
     // K2e
-    {
-        const uint64_t n_work = e_plane_len(a.ix.n_u) * (uint64_t)a.ix.W;
-        uint64_t blocks = (n_work + 255) / 256;
-        if (blocks > 256 * 8) blocks = 256 * 8;
-        if (blocks < 1) blocks = 1;
-        const size_t lds = std::max<size_t>((size_t)a.ix.n_files * 3 * sizeof(uint32_t), 16);
-        hipLaunchKernelGGL(finalize_exact_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
-    }
-    // K2b (deferred k-mers only; the grid is small, the kernel reads the count on the device)
-    {
-        const size_t lds = finalize_lds_bytes(a.ix.n_files);
-        uint64_t per_cu = (160u * 1024u) / lds;
-        if (per_cu > 16) per_cu = 16;
-        if (per_cu < 1) per_cu = 1;
-        hipLaunchKernelGGL(finalize_general_kernel, dim3((unsigned)(256 * per_cu)), dim3(64), lds, stream, a);
+    const uint64_t n_work = e_plane_len(a.ix.n_u) * (uint64_t)a.ix.W;
+    const unsigned b_ex = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_work + 255) / 256, kFinExactBlocks));
+    a.row_exact = (int)b_var;
+    hipLaunchKernelGGL(finalize_exact_kernel, dim3(b_ex), dim3(256), lds_stats, stream, a);
+    // K2b (deferred k-mers only; the kernel reads their number on the device)
+    const size_t lds = finalize_lds_bytes(a.ix.n_files);
+    unsigned b_gen = (unsigned)std::min<size_t>(kFinGeneralBlocks, 256 * std::max<size_t>(1, (160u * 1024u) / lds));
+    a.row_general = (int)(b_var + b_ex);
+    hipLaunchKernelGGL(finalize_general_kernel, dim3(b_gen), dim3(64), lds, stream, a);
+    if (a.partials) {
+        const int cols = a.ix.n_files * 3 + 2;
+        hipLaunchKernelGGL(finalize_reduce_kernel, dim3((unsigned)cols), dim3(256), 0, stream, a, (int)(b_var + b_ex + b_gen));
     }
 }
 

@@ -326,6 +326,8 @@ int run_call(const Args& a) {
         bk_params p;
         bk_params_default(&p);
         p.n_fixed = (int32_t)a.n_fixed; p.use_full_kmer = a.use_full_kmer ? 1 : 0; p.ci = (uint64_t)a.min_kmers;
+        p.full_kmer_stats = 1;   // KMC's "unique counted k-mers" feeds num_unmapped_kmers and the <0.2 warning (call.rs:242-248)
+        if (const char* tl = getenv("BRONKO_KMER_TABLE_LOG2")) p.kmer_table_log2 = (uint32_t)atoi(tl);
         if (const char* dv = getenv("BRONKO_DEVICE")) p.device = atoi(dv);
         hip_check(bk_engine_create(&d, &p, &eng.e), "bk_engine_create");
     }
@@ -359,21 +361,23 @@ int run_call(const Args& a) {
                                    stats.data(), present.data(), kstats.data()), "bk_sample_finish");
         p.stats.assign(n_files * 3, 0);
         p.present.assign(n_files, 0);
-        uint64_t kept = 0;
+        uint64_t kept = 0;   // KMC "No. of unique counted k-mers", summed over mate files (call.rs:336)
+        bool kept_exact = true;
         for (int m = 0; m < n_mates; m++) {                          // pick_best_genome_paired sums R1 + R2 (call.rs:457-474)
             for (size_t i = 0; i < n_files * 3; i++) p.stats[i] += stats[(size_t)m * n_files * 3 + i];
             for (size_t f = 0; f < n_files; f++) p.present[f] |= present[(size_t)m * n_files + f];
-            kept += kstats[(size_t)m * 4 + 3];
+            if (kstats[(size_t)m * 4 + 3] == ~0ull) kept_exact = false; else kept += kstats[(size_t)m * 4 + 3];
         }
+        if (!kept_exact) LOG_WARN(T, "k-mer statistics table overflowed (raise BRONKO_KMER_TABLE_LOG2): num_unmapped_kmers is not available for this sample");
         LOG_INFO(T, "Selecting the most representative genome");
         const int best = pick_best_genome(ix, p.stats, p.present);
         if (best < 0) die(T, "Unable to pick a best genome");
         const std::string& gname = ix.files[best].name;
         LOG_INFO(T, "Selected a representative genome: " + gname);
         const uint64_t n_perfect = p.stats[(size_t)best * 3], n_variant = p.stats[(size_t)best * 3 + 1];
-        // KMC's "unique counted k-mers" over ALL k-mers is not produced by the GPU path; the
-        // count of kept k-mers that touch the index stands in, so "unmapped" = kept k-mers that only hit other genomes
-        const uint64_t n_unmapped = kept >= n_perfect + n_variant ? kept - n_perfect - n_variant : 0;
+        const uint64_t n_unmapped = (kept_exact && kept >= n_perfect + n_variant) ? kept - n_perfect - n_variant : 0;   // call.rs:242,336
+        if (kept_exact && kept > 0 && (double)(n_variant + n_perfect) / (double)kept < 0.2)                              // call.rs:246-248
+            LOG_WARN(T, "Percent of kmers found is very low for this reference, suggesting lack of a representative reference, a bad sequencing run, contamination in sample, or some other issue");
         LOG_INFO(T, "Mapped " + std::to_string(n_perfect) + "/" + std::to_string(kept) + " kmers perfectly (" +
                         std::to_string(p.stats[(size_t)best * 3 + 2]) + " unique among refs), " + std::to_string(n_variant) + "/" +
                         std::to_string(kept) + " had a variant");

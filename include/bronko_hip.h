@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BK_ABI_VERSION 1
+#define BK_ABI_VERSION 2
 
 typedef enum {
     BK_OK = 0,
@@ -77,7 +77,11 @@ typedef struct {
     uint64_t cs;             /* kmc -cs1000000 (call.rs:1173): reported count saturates at cs               */
     uint64_t cx;             /* kmc -cx default 1e9: drop k-mers whose true count exceeds cx                */
     int32_t  device;         /* HIP device ordinal                                                          */
-    int32_t  reserved;
+    int32_t  full_kmer_stats;/* 1: also count every k-mer that does NOT touch the index in a device hash table, so
+                                that KMC's "No. of unique k-mers" / "No. of unique counted k-mers" (call.rs:1190-1199)
+                                are exact; 0 (default): only index-touching k-mers are counted (pileups identical) */
+    uint32_t kmer_table_log2;/* capacity of that table = 2^kmer_table_log2 distinct k-mers per sample (default 26)  */
+    uint32_t reserved;
 } bk_params;
 
 typedef struct bk_engine bk_engine;
@@ -134,8 +138,10 @@ int bk_pileup_device_ptr(bk_engine* e, void** d_ptr);
  *   fwd_depth/rev_depth/fwd_nk/rev_nk : total_cells*4 u64 each    (OutputData.counts, call.rs:1235-1239)
  *   stats   : n_mates * n_files * 3 u64  (perfect, variant, unique) per mate file (call.rs:1272)
  *   present : n_mates * n_files bytes, 1 iff the file has a key in map_kmers' returned map
- *   kmer_stats : n_mates * 4 u64 = records pushed, k-mer occurrences scanned, 0, distinct table-hitting
- *                k-mers kept (KMC's "unique counted k-mers" restricted to k-mers that touch the table)   */
+ *   kmer_stats : n_mates * 4 u64 = [0] records pushed, [1] k-mer occurrences scanned (KMC "Total no. of k-mers"),
+ *                [2] distinct k-mers ("No. of unique k-mers"), [3] distinct k-mers kept by -ci/-cx ("No. of unique
+ *                counted k-mers").  With full_kmer_stats = 0, [2] = 0 and [3] counts index-touching k-mers only;
+ *                if the k-mer table overflowed, [2] = [3] = UINT64_MAX.                                         */
 int bk_sample_download(bk_engine* e, int n_mates, uint64_t* fwd_depth, uint64_t* rev_depth, uint64_t* fwd_nk,
                        uint64_t* rev_nk, uint64_t* stats, uint8_t* present, uint64_t* kmer_stats);
 /* bk_sample_finalize + bk_sample_download */

@@ -29,7 +29,9 @@ def oracle_outputs(oracle, ix, mates, out_dir, reads_path, k=21, **kw):
     stem = oracle.clean_sample_id(reads_path)
     oracle.write_vcf(os.path.join(out_dir, stem + ".vcf"), reads_path, ix, best, ptr, n)
     oracle.write_pileup(os.path.join(out_dir, stem + ".tsv"), ix, best, pile)
-    return stem, best, n
+    kept = int(pile.kmc_stats[:, 3].sum())
+    unmapped = kept - int(stats[best, 0]) - int(stats[best, 1])     # call.rs:242 / :336
+    return stem, best, n, (int(stats[best, 0]), int(stats[best, 1]), unmapped, nmaj, nmin, br, dc)
 
 
 def test_call_paired_hpv_fastq_gz(oracle, golden_dir, tmp_path):
@@ -50,12 +52,15 @@ def test_call_paired_hpv_fastq_gz(oracle, golden_dir, tmp_path):
     ix = oracle.Index.load(os.path.join(golden_dir, "hpv.bkdb"))
     odir = str(tmp_path / "oracle")
     os.makedirs(odir)
-    stem, best, n = oracle_outputs(oracle, ix, [r1, r2], odir, p1)
+    stem, best, n, ov_want = oracle_outputs(oracle, ix, [r1, r2], odir, p1)
     assert stem == "rep1_R1" and n >= 5
     for ext in (".vcf", ".tsv"):
         assert open(os.path.join(out, stem + ext), "rb").read() == open(os.path.join(odir, stem + ext), "rb").read(), ext
     ov = open(os.path.join(out, "bronko_overview.tsv")).read().splitlines()
     assert ov[0].split("\t")[:2] == ["filename", "selected_genome"] and ov[1].split("\t")[:2] == [p1, "HPV16"]
+    # bronko_overview.tsv (call.rs:698-732) incl. num_unmapped_kmers, which needs KMC's "unique counted k-mers"
+    perfect, variant, unmapped, nmaj, nmin, br, dc = ov_want
+    assert ov[1].split("\t")[2:] == [str(nmaj), str(nmin), "%.4f" % br, "%.4f" % dc, str(perfect), str(variant), str(unmapped)]
     ix.close()
 
 
@@ -75,7 +80,7 @@ def test_call_single_end_with_genomes_flag(oracle, sars_paths, tmp_path):
     ix = oracle.Index.build(21, sars_paths)
     odir = str(tmp_path / "oracle")
     os.makedirs(odir)
-    stem, best, n = oracle_outputs(oracle, ix, [reads], odir, fq)
+    stem, best, n, _ = oracle_outputs(oracle, ix, [reads], odir, fq)
     assert best == 1 and stem == "s1"
     for ext in (".vcf", ".tsv"):
         assert open(os.path.join(out, stem + ext), "rb").read() == open(os.path.join(odir, stem + ext), "rb").read(), ext

@@ -234,3 +234,31 @@ def test_config2_full_size_one_million_reads(oracle, sars_paths):
     assert np.array_equal(res.stats, res2.stats)
     eng.close()
     ix.close()
+
+
+def test_full_kmer_statistics_match_the_kmc_contract(oracle, golden_dir):
+    """bk_params.full_kmer_stats: KMC's four statistics (call.rs:1190-1199) over ALL read k-mers -- including the
+    ones that never touch the index (errors outside the window, flipped orientation, contamination) -- per mate."""
+    from bronko_amd import Params
+    ix = oracle.Index.load(os.path.join(golden_dir, "hpv.bkdb"))
+    eng = helpers.engine_from_oracle_index(ix, Params(full_kmer_stats=True, kmer_table_log2=22))
+    g = synth.read_fasta_bytes(os.path.join(helpers.GOLDEN, "HPV16.fa"))
+    gm, isnv = synth.sample_genome(g, 6)
+    c1, c2 = synth.paired_codes(gm, 9000, 150, 6, err=0.01, isnv=isnv)
+    junk = synth.codes_to_ascii(np.ascontiguousarray(synth.splitmix64(77, 500 * 150).astype(np.uint8).reshape(500, 150) & 3))
+    mates = [synth.codes_to_ascii(c1) + junk + [b"ACGTNNACGT" * 12], synth.codes_to_ascii(c2)]
+    res = helpers.hip_sample(eng, mates, 21)
+    pile = oracle.sample_pileup(ix, mates)
+    helpers.assert_same_pileup(res, pile)
+    assert res.kmer_stats[:, 1].tolist() == pile.kmc_stats[:, 1].tolist()     # total k-mers
+    assert res.kmer_stats[:, 2].tolist() == pile.kmc_stats[:, 2].tolist()     # unique k-mers
+    assert res.kmer_stats[:, 3].tolist() == pile.kmc_stats[:, 3].tolist()     # unique counted k-mers
+    assert res.kmer_stats[0, 2] > res.kmer_stats[0, 3] > 10000
+    eng.close()
+    # a table that is too small reports "unavailable" instead of a wrong number; pileups are unaffected
+    eng = helpers.engine_from_oracle_index(ix, Params(full_kmer_stats=True, kmer_table_log2=10))
+    res = helpers.hip_sample(eng, mates, 21)
+    helpers.assert_same_pileup(res, pile)
+    assert res.kmer_stats[0, 3] == np.iinfo(np.uint64).max
+    eng.close()
+    ix.close()

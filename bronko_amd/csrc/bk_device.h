@@ -98,9 +98,9 @@ struct IndexView {
     const uint64_t*  kmer_of;  // [n_u] id -> canonical k-mer
     // the reference in reference order, for the diagonal walk of scan_count (staged in LDS when it fits):
     const uint32_t*  ref_words;   // 2-bit packed bases of all cells (nt_to_bits, 16 per word, LSB first), padded
-    const uint32_t*  bits_clean;  // bit q: a k-mer starts at cell q, it is in U and it is "clean" (see amb)
-    const uint32_t*  bits_follow; // bit q: id(k-mer at q+1) == id(k-mer at q) + 1
-    const uint32_t*  bits_rc;     // bit q: the k-mer at q was reverse-complemented to become canonical
+    const uint32_t*  cell_flags;  // 4 bits per cell q (8 cells per word): bit 0 = a k-mer starts at q, it is in U and it
+                                  // is "clean" (see amb); bit 1 = it was reverse-complemented to become canonical;
+                                  // bit 2 = id(q) == id(q-1) + 1; bit 3 = id(q+1) == id(q) + 1
     const uint32_t*  id_at;       // [total_cells] id of the k-mer starting at cell q (0xffffffff: none)
     uint32_t total_cells;
     uint32_t n_u;                 // |U| = number of ids

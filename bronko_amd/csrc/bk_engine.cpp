@@ -119,7 +119,7 @@ struct bk_engine {
     DevBuf<bk::KmerPos> kmer_pos;
     DevBuf<bk::IndexView> d_view;   // device copy of view()
     DevBuf<uint64_t> kmer_of;
-    DevBuf<uint32_t> ref_words, bits_clean, bits_follow, bits_rc, id_at;
+    DevBuf<uint32_t> ref_words, cell_flags, id_at;
     struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0; } half_lo, half_hi;
     DevBuf<unsigned int> deferred, n_deferred;
     DevBuf<unsigned int> fin_partials;      // per-workgroup finalize tallies (small genome sets only)
@@ -156,8 +156,7 @@ struct bk_engine {
     bk::IndexView view() const {
         bk::IndexView v{};
         v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb;
-        v.kmer_of = kmer_of.p; v.ref_words = ref_words.p; v.bits_clean = bits_clean.p; v.bits_follow = bits_follow.p;
-        v.bits_rc = bits_rc.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
+        v.kmer_of = kmer_of.p; v.ref_words = ref_words.p; v.cell_flags = cell_flags.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb};
         v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
@@ -397,11 +396,15 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 }
             }
         }
-        std::vector<uint32_t> h_bclean((cells + 31) / 32 + 1, 0u), h_bfollow((cells + 31) / 32 + 1, 0u);
+        std::vector<uint32_t> h_flags((cells + 7) / 8 + 1, 0u);   // bk_device.h cell_flags
         for (uint64_t c = 0; c < cells; c++) {
             if (h_id_at[c] == kNone) continue;
-            if (!h_amb[h_id_at[c]]) h_bclean[c >> 5] |= 1u << (c & 31);
-            if (c + 1 < cells && h_id_at[c + 1] != kNone && h_id_at[c + 1] == h_id_at[c] + 1) h_bfollow[c >> 5] |= 1u << (c & 31);
+            uint32_t fl = 0;
+            if (!h_amb[h_id_at[c]]) fl |= 1u;
+            if ((h_brc[c >> 5] >> (c & 31)) & 1u) fl |= 2u;
+            if (c > 0 && h_id_at[c - 1] != kNone && h_id_at[c] == h_id_at[c - 1] + 1) fl |= 4u;
+            if (c + 1 < cells && h_id_at[c + 1] != kNone && h_id_at[c + 1] == h_id_at[c] + 1) fl |= 8u;
+            h_flags[c >> 3] |= fl << (4 * (c & 7));
         }
 
         // perfect hash over U
@@ -418,9 +421,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         BK_HIP(e->kmer_pos.upload(t_pos));
         BK_HIP(e->kmer_of.upload(h_kmer_of));
         BK_HIP(e->ref_words.upload(h_refw));
-        BK_HIP(e->bits_clean.upload(h_bclean));
-        BK_HIP(e->bits_follow.upload(h_bfollow));
-        BK_HIP(e->bits_rc.upload(h_brc));
+        BK_HIP(e->cell_flags.upload(h_flags));
         BK_HIP(e->id_at.upload(h_id_at));
         BK_HIP(e->amb.upload(h_amb));
 
@@ -590,8 +591,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     bk::ScanArgs a{};
     a.ixp = e->d_view.p;
     a.k = e->k; a.wstart = e->wstart; a.W = e->W; a.total_cells = (uint32_t)e->total_cells; a.n_u = e->n_u;
-    a.ref_words = e->ref_words.p; a.bits_clean = e->bits_clean.p; a.bits_follow = e->bits_follow.p;
-    a.bits_rc = e->bits_rc.p; a.id_at = e->id_at.p;
+    a.ref_words = e->ref_words.p; a.cell_flags = e->cell_flags.p; a.id_at = e->id_at.p;
     a.words = d_words; a.lens = d_lens; a.n_records = n; a.stride_words = stride_words;
     a.counters = e->counters[mate].p;
     a.kmer_total = e->kstats.p + mate * 4 + 1;

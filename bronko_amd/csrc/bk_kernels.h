@@ -11,10 +11,8 @@ struct ScanArgs {
     // what the hot path needs (kept in kernel-argument registers)
     int32_t k, wstart, W;
     uint32_t total_cells, n_u;
-    const uint32_t* ref_words;      // IndexView::ref_words / bits_* / id_at
-    const uint32_t* bits_clean;
-    const uint32_t* bits_follow;
-    const uint32_t* bits_rc;
+    const uint32_t* ref_words;      // IndexView::ref_words / cell_flags / id_at
+    const uint32_t* cell_flags;
     const uint32_t* id_at;
     const uint32_t* words;          // [n_records][stride_words] 2-bit packed, 16 bases per word, LSB first
     const uint16_t* lens;           // [n_records] valid bases

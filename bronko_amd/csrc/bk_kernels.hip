@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     unsigned char* queue_m = smem + (size_t)kScanWaves * kQueueCap * sizeof(unsigned long long);
     unsigned int* block_kmers = reinterpret_cast<unsigned int*>(smem + kQueueBytes);   // 16 B reserved
     unsigned int* bins = block_kmers + 4;
-    unsigned int* lds_ref = bins + a.n_lds_bins;   // REF_LDS: ref words, then clean / follow / rc bit words
+    unsigned int* lds_ref = bins + a.n_lds_bins;   // REF_LDS: ref words, then the per-cell flag nibbles
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -281,21 +281,15 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
 
     const uint32_t total = a.total_cells;
     const uint32_t n_refw = (total + 15) / 16 + 4;   // padded by the host (>= k bases past the end)
-    const uint32_t n_bitw = (total + 31) / 32 + 1;
+    const uint32_t n_flagw = (total + 7) / 8 + 1;
     for (uint32_t i = threadIdx.x; i < a.n_lds_bins; i += kScanBlock) bins[i] = 0u;
     if (REF_LDS) {
         for (uint32_t i = threadIdx.x; i < n_refw; i += kScanBlock) lds_ref[i] = a.ref_words[i];
-        for (uint32_t i = threadIdx.x; i < n_bitw; i += kScanBlock) {
-            lds_ref[n_refw + i] = a.bits_clean[i];
-            lds_ref[n_refw + n_bitw + i] = a.bits_follow[i];
-            lds_ref[n_refw + 2 * n_bitw + i] = a.bits_rc[i];
-        }
+        for (uint32_t i = threadIdx.x; i < n_flagw; i += kScanBlock) lds_ref[n_refw + i] = a.cell_flags[i];
     }
     __syncthreads();
     const unsigned int* refw = REF_LDS ? lds_ref : a.ref_words;
-    const unsigned int* bclean = REF_LDS ? lds_ref + n_refw : a.bits_clean;
-    const unsigned int* bfollow = REF_LDS ? lds_ref + n_refw + n_bitw : a.bits_follow;
-    const unsigned int* brc = REF_LDS ? lds_ref + n_refw + 2 * n_bitw : a.bits_rc;
+    const unsigned int* cflags = REF_LDS ? lds_ref + n_refw : a.cell_flags;
 
     const int k = a.k;
     const uint32_t W = (uint32_t)a.W;
@@ -312,9 +306,10 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     unsigned long long* const v_counters = a.counters + n_e;
 
     // +1 on the E counter of reference k-mer `id` read in orientation `isrc`
+    const bool all_lds = a.n_lds_bins >= a.n_u;   // every reference k-mer has an LDS bin (wave-uniform)
     auto count_exact = [&](uint32_t id, uint32_t isrc) {
         if (MODE == 1) return;
-        if (id < a.n_lds_bins) {
+        if (all_lds || id < a.n_lds_bins) {
             const unsigned int old = atomicAdd(&bins[id], isrc ? 0x10000u : 1u);
             if (((isrc ? old >> 16 : old) & 0xffffu) == 0x7fffu) {   // this add made the half 0x8000: spill it
                 atomicSub(&bins[id], isrc ? 0x80000000u : 0x8000u);
@@ -384,10 +379,10 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 const uint32_t nd_lo = ((d_lo << 2) | (base ^ rb)) & kmask_lo;
                 d_hi = ok ? nd_hi : d_hi;
                 d_lo = ok ? nd_lo : d_lo;
-                const uint32_t fcell = fwd_dir ? (ok ? cell : 0u) : nc;     // follow bit: id(fcell + 1) == id(fcell) + 1
-                const bool clean = ok && ((bclean[nc >> 5] >> (nc & 31)) & 1u);
-                const bool follow = (bfollow[fcell >> 5] >> (fcell & 31)) & 1u;
-                const uint32_t ref_isrc = ((brc[nc >> 5] >> (nc & 31)) & 1u) ^ (fwd_dir ? 0u : 1u);   // orientation of the reference k-mer as the read sees it
+                const uint32_t fl = (cflags[nc >> 3] >> (4 * (nc & 7))) & 15u;   // this cell's clean / rc / follow bits
+                const bool clean = ok && (fl & 1u);
+                const bool follow = fl & (fwd_dir ? 4u : 8u);                   // id continues from the cell we came from
+                const uint32_t ref_isrc = ((fl >> 1) & 1u) ^ (fwd_dir ? 0u : 1u); // orientation of the reference k-mer as the read sees it
                 cell = tracking ? ncell : cell;                              // once out of range the lane stays lost
                 const bool id_known = ok && id_ok && follow;                 // previous id +-1 along an unbroken stretch
                 id = id_known ? id + ddir : id;
@@ -526,7 +521,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
 
 size_t scan_lds_budget() { return 160u * 1024u - 64u - kScanLdsFixed; }
 size_t scan_ref_lds_bytes(uint32_t total_cells) {
-    return ((size_t)((total_cells + 15) / 16 + 4) + 3 * (size_t)((total_cells + 31) / 32 + 1)) * sizeof(unsigned int);
+    return ((size_t)((total_cells + 15) / 16 + 4) + (size_t)((total_cells + 7) / 8 + 1)) * sizeof(unsigned int);
 }
 size_t scan_lds_bytes(uint32_t n_lds_bins, bool ref_in_lds, uint32_t total_cells) {
     return kScanLdsFixed + (size_t)n_lds_bins * sizeof(unsigned int) + (ref_in_lds ? scan_ref_lds_bytes(total_cells) : 0);

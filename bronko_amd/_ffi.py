@@ -26,7 +26,7 @@ class Params(C.Structure):
 # every symbol include/bronko_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = ["bk_abi_version", "bk_last_error", "bk_params_default", "bk_engine_create", "bk_engine_destroy",
            "bk_engine_set_stream", "bk_total_cells", "bk_n_files", "bk_n_slots", "bk_counter_len", "bk_sample_begin",
-           "bk_push_reads_packed", "bk_push_reads_packed_device", "bk_counters_device_ptr", "bk_sample_finalize",
+           "bk_push_reads_packed", "bk_push_reads_packed_device", "bk_push_reads_ascii", "bk_counters_device_ptr", "bk_sample_finalize",
            "bk_pileup_device_ptr", "bk_sample_download", "bk_sample_finish", "bk_pack_reads", "bk_pack_reads_flat",
            "bk_timing_enable", "bk_timing_read"]
 
@@ -59,6 +59,8 @@ def load():
     L.bk_push_reads_packed.argtypes = [vp, C.c_int, vp, u32, vp, u64]
     L.bk_push_reads_packed_device.restype = C.c_int
     L.bk_push_reads_packed_device.argtypes = [vp, C.c_int, vp, u32, vp, u64]
+    L.bk_push_reads_ascii.restype = C.c_int
+    L.bk_push_reads_ascii.argtypes = [vp, C.c_int, vp, vp, u64]
     L.bk_counters_device_ptr.restype = C.c_int
     L.bk_counters_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.bk_sample_finalize.restype = C.c_int

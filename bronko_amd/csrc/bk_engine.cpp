@@ -144,6 +144,21 @@ struct bk_engine {
     DevBuf<uint32_t> stage_words;
     DevBuf<uint16_t> stage_lens;
 
+    // asynchronous ASCII ingest (bk_push_reads_ascii): pinned staging + device buffers per slot
+    struct IngestSlot {
+        uint8_t* h_bases = nullptr; size_t h_bases_cap = 0;
+        unsigned long long* h_off = nullptr; size_t h_off_cap = 0;
+        DevBuf<uint8_t> d_bases;
+        DevBuf<unsigned long long> d_off, d_nrec;
+        DevBuf<uint32_t> d_words;
+        DevBuf<uint16_t> d_lens;
+        hipEvent_t uploaded = nullptr, done = nullptr;
+        bool busy = false;
+    };
+    IngestSlot slots[3];
+    int next_slot = 0;
+    hipStream_t copy_stream = nullptr;
+
     hipStream_t own_stream = nullptr, stream = nullptr;
     bool in_sample = false;
     uint64_t pushed_records[2] = {0, 0};
@@ -551,6 +566,13 @@ void bk_engine_destroy(bk_engine* e) {
     (void)hipStreamSynchronize(e->stream);
     for (auto& s : e->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto ev : e->free_events) (void)hipEventDestroy(ev);
+    for (auto& sl : e->slots) {
+        if (sl.h_bases) (void)hipHostFree(sl.h_bases);
+        if (sl.h_off) (void)hipHostFree(sl.h_off);
+        if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -587,8 +609,10 @@ int bk_sample_begin(bk_engine* e) {
     return BK_OK;
 }
 
-static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t stride_words, const uint16_t* d_lens, uint64_t n) {
+static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t stride_words, const uint16_t* d_lens, uint64_t n,
+                       const unsigned long long* n_records_dev = nullptr) {
     bk::ScanArgs a{};
+    a.n_records_dev = n_records_dev;
     a.ixp = e->d_view.p;
     a.k = e->k; a.wstart = e->wstart; a.W = e->W; a.total_cells = (uint32_t)e->total_cells; a.n_u = e->n_u;
     a.ref_words = e->ref_words.p; a.cell_flags = e->cell_flags.p; a.id_at = e->id_at.p;
@@ -616,7 +640,69 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
         bk::launch_fold(f, e->stream);
     }
     BK_HIP(hipGetLastError());
-    e->pushed_records[mate] += n;
+    if (!n_records_dev) e->pushed_records[mate] += n;
+    return BK_OK;
+}
+
+int bk_push_reads_ascii(bk_engine* e, int mate, const uint8_t* buf, const uint64_t* offsets, uint64_t n_reads) {
+    if (!e) return fail(BK_ERR_INVALID, "null engine");
+    if (!e->in_sample) return fail(BK_ERR_STATE, "bk_push_reads_* called before bk_sample_begin");
+    if (mate < 0 || mate > 1) return fail(BK_ERR_INVALID, "mate must be 0 or 1");
+    if (n_reads == 0) return BK_OK;
+    if (!buf || !offsets) return fail(BK_ERR_INVALID, "bad read batch");
+    const uint64_t base0 = offsets[0], total = offsets[n_reads] - base0;
+    if (total >= (1ull << 32)) return fail(BK_ERR_INVALID, "batch too large: push at most 2^32 bases per call");
+    BK_HIP(hipSetDevice(e->device));
+    if (!e->copy_stream) BK_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    bk_engine::IngestSlot& sl = e->slots[e->next_slot];
+    e->next_slot = (e->next_slot + 1) % 3;
+    if (!sl.done) { BK_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)); BK_HIP(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming)); }
+    if (sl.busy) { BK_HIP(hipEventSynchronize(sl.done)); sl.busy = false; }   // slot still owned by an earlier batch
+
+    // staging copy (the caller's buffer is free as soon as we return) + longest read of the batch
+    if (sl.h_bases_cap < total + 1) {
+        if (sl.h_bases) BK_HIP(hipHostFree(sl.h_bases));
+        sl.h_bases_cap = total + total / 4 + 4096;
+        BK_HIP(hipHostMalloc(reinterpret_cast<void**>(&sl.h_bases), sl.h_bases_cap, hipHostMallocDefault));
+    }
+    if (sl.h_off_cap < n_reads + 1) {
+        if (sl.h_off) BK_HIP(hipHostFree(sl.h_off));
+        sl.h_off_cap = n_reads + n_reads / 4 + 1024;
+        BK_HIP(hipHostMalloc(reinterpret_cast<void**>(&sl.h_off), sl.h_off_cap * sizeof(unsigned long long), hipHostMallocDefault));
+    }
+    std::memcpy(sl.h_bases, buf + base0, total);
+    uint64_t longest = (uint64_t)e->k;
+    for (uint64_t i = 0; i <= n_reads; i++) {
+        sl.h_off[i] = offsets[i] - base0;
+        if (i) longest = std::max(longest, offsets[i] - offsets[i - 1]);
+    }
+    const uint32_t stride = (uint32_t)std::min<uint64_t>((longest + 15) / 16, 4095);
+    const uint64_t maxb = std::min<uint64_t>((uint64_t)stride * 16, 65535);
+    const uint64_t cap = n_reads + total / (uint64_t)e->k + total / (maxb - (uint64_t)(e->k - 1)) + 16;   // bound on the records
+
+    if (sl.d_bases.n < total + 1) BK_HIP(sl.d_bases.alloc(total + total / 4 + 4096));
+    if (sl.d_off.n < n_reads + 1) BK_HIP(sl.d_off.alloc(n_reads + n_reads / 4 + 1024));
+    if (sl.d_words.n < cap * stride) BK_HIP(sl.d_words.alloc(cap * stride + cap * stride / 4));
+    if (sl.d_lens.n < cap) BK_HIP(sl.d_lens.alloc(cap + cap / 4));
+    if (!sl.d_nrec.p) BK_HIP(sl.d_nrec.alloc(1));
+
+    BK_HIP(hipMemcpyAsync(sl.d_bases.p, sl.h_bases, total, hipMemcpyHostToDevice, e->copy_stream));
+    BK_HIP(hipMemcpyAsync(sl.d_off.p, sl.h_off, (n_reads + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, e->copy_stream));
+    BK_HIP(hipEventRecord(sl.uploaded, e->copy_stream));
+    BK_HIP(hipStreamWaitEvent(e->stream, sl.uploaded, 0));
+    BK_HIP(hipMemsetAsync(sl.d_nrec.p, 0, sizeof(unsigned long long), e->stream));
+    {
+        bk::PackArgs pa{};
+        pa.bases = sl.d_bases.p; pa.offsets = sl.d_off.p; pa.n_reads = n_reads; pa.k = e->k; pa.stride_words = stride;
+        pa.words = sl.d_words.p; pa.lens = sl.d_lens.p; pa.cap = cap; pa.n_records = sl.d_nrec.p;
+        bk_engine::Span sp(e, 2);
+        bk::launch_pack_reads(pa, e->stream);
+        bk::launch_add_u64(e->kstats.p + mate * 4 + 0, sl.d_nrec.p, e->stream);   // records pushed, tallied on the device
+    }
+    int rc = push_device(e, mate, sl.d_words.p, stride, sl.d_lens.p, cap, sl.d_nrec.p);
+    if (rc != BK_OK) return rc;
+    BK_HIP(hipEventRecord(sl.done, e->stream));
+    sl.busy = true;
     return BK_OK;
 }
 
@@ -718,7 +804,7 @@ int bk_sample_download(bk_engine* e, int n_mates, uint64_t* fwd_depth, uint64_t*
     BK_HIP(hipStreamSynchronize(e->stream));
     if (kmer_stats) {
         for (int m = 0; m < n_mates; m++) {
-            kmer_stats[m * 4 + 0] = e->pushed_records[m];
+            kmer_stats[m * 4 + 0] += e->pushed_records[m];   // + the device-side tally of bk_push_reads_ascii batches
             if (e->ktab_keys.p) {
                 // index-touching k-mers are in the counter plane (kept tally in [3], distinct tally in [2] by finalize);
                 // the rest are in the hash table

@@ -16,7 +16,8 @@ struct ScanArgs {
     const uint32_t* id_at;
     const uint32_t* words;          // [n_records][stride_words] 2-bit packed, 16 bases per word, LSB first
     const uint16_t* lens;           // [n_records] valid bases
-    uint64_t n_records;
+    uint64_t n_records;             // upper bound when n_records_dev is set (sizes nothing but the tile loop)
+    const unsigned long long* n_records_dev;   // optional: actual record count written by pack_reads_kernel
     uint32_t stride_words;
     unsigned long long* counters;   // u64 plane [E | V] (bk_device.h)
     unsigned int* slabs;            // [grid][n_lds_bins] packed (rc<<16 | fwd) histogram of each workgroup
@@ -58,6 +59,19 @@ struct FoldArgs {
     unsigned long long* counters;
 };
 
+struct PackArgs {
+    const uint8_t* bases;           // sequence lines back to back
+    const unsigned long long* offsets;   // [n_reads + 1]
+    uint64_t n_reads;
+    int32_t k;
+    uint32_t stride_words;
+    uint32_t* words;                // out: [cap][stride_words]
+    uint16_t* lens;                 // out: [cap]
+    uint64_t cap;
+    unsigned long long* n_records;  // out (device): number of records written; zeroed by the launcher
+};
+void launch_pack_reads(const PackArgs& a, hipStream_t stream);
+void launch_add_u64(unsigned long long* dst, const unsigned long long* src, hipStream_t stream);   // *dst += *src
 uint32_t scan_grid(uint64_t n_records, int n_cus);
 size_t scan_lds_budget();   // bytes available for histogram bins (4 B each) + the staged reference
 size_t scan_ref_lds_bytes(uint32_t total_cells);

@@ -81,6 +81,64 @@ __device__ __forceinline__ void for_each_neighbour(const IndexView& ix, uint64_t
     }
 }
 
+// ------------------------------------------------------------------------------------------------ K0
+// ASCII reads -> fixed-stride 2-bit records, one thread per read (the host-side twin is bk_pack_reads): split at
+// every non-ACGT/acgt symbol (KMC contract), drop runs shorter than k, cut runs longer than the stride into chunks
+// overlapping by k-1 bases.  Records are appended through one device counter (their order is irrelevant).
+__device__ __forceinline__ int acgt_code(unsigned char c) {
+    switch (c | 0x20) {
+        case 'a': return 0;
+        case 'c': return 1;
+        case 'g': return 2;
+        case 't': return 3;
+        default: return -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_reads_kernel(PackArgs a) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.n_reads) return;
+    const uint8_t* s = a.bases + a.offsets[r];
+    const uint64_t len = a.offsets[r + 1] - a.offsets[r];
+    const uint64_t maxb = min((uint64_t)a.stride_words * 16, (uint64_t)65535);
+    uint64_t start = 0;
+    for (uint64_t i = 0; i <= len; ++i) {
+        if (i < len && acgt_code(s[i]) >= 0) continue;
+        const uint64_t run = i - start;            // maximal ACGT run [start, i)
+        if (run >= (uint64_t)a.k) {
+            uint64_t pos = 0;
+            for (;;) {
+                const uint64_t take = min(maxb, run - pos);
+                const unsigned long long rec = atomicAdd(a.n_records, 1ull);
+                if (rec < a.cap) {
+                    uint32_t* w = a.words + rec * a.stride_words;
+                    uint32_t acc = 0;
+                    for (uint64_t j = 0; j < take; ++j) {
+                        acc |= (uint32_t)acgt_code(s[start + pos + j]) << (2 * (j & 15));
+                        if ((j & 15) == 15) { w[j >> 4] = acc; acc = 0; }
+                    }
+                    if (take & 15) w[take >> 4] = acc;
+                    for (uint64_t j = (take + 15) >> 4; j < a.stride_words; ++j) w[j] = 0;
+                    a.lens[rec] = (uint16_t)take;
+                }
+                if (pos + take >= run) break;
+                pos += take - (uint64_t)(a.k - 1);
+            }
+        }
+        start = i + 1;
+    }
+}
+
+__global__ void add_u64_kernel(unsigned long long* dst, const unsigned long long* src) { *dst += *src; }
+void launch_add_u64(unsigned long long* dst, const unsigned long long* src, hipStream_t stream) {
+    hipLaunchKernelGGL(add_u64_kernel, dim3(1), dim3(1), 0, stream, dst, src);
+}
+
+void launch_pack_reads(const PackArgs& a, hipStream_t stream) {
+    if (a.n_reads == 0) return;
+    hipLaunchKernelGGL(pack_reads_kernel, dim3((unsigned)((a.n_reads + 255) / 256)), dim3(256), 0, stream, a);
+}
+
 // full_kmer_stats: +1 on a k-mer that does not touch the index, in an open-addressing table keyed by
 // (canonical k-mer, read orientation, mate file) -- i.e. by the strand-specific k-mer KMC -b counts.
 struct KmerTable {
@@ -334,10 +392,11 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     uint32_t sink = 0; // MODE 2 only
     SlowPipe pipe;
 
-    const uint64_t n_tiles = (a.n_records + 63) / 64;
+    const uint64_t n_records = a.n_records_dev ? min((uint64_t)*a.n_records_dev, a.n_records) : a.n_records;
+    const uint64_t n_tiles = (n_records + 63) / 64;
     for (uint64_t tile = (uint64_t)blockIdx.x * kScanWaves + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * kScanWaves) {
         const uint64_t r = tile * 64 + lane;
-        const bool live = r < a.n_records;
+        const bool live = r < n_records;
         const uint32_t len = live ? (uint32_t)a.lens[r] : 0u;
         uint32_t maxlen = len;
 #pragma unroll

@@ -136,6 +136,17 @@ class Engine:
         assert words.ndim == 2 and words.shape[0] == len(lens)
         _check(self._L.bk_push_reads_packed(self.h, mate, words.ctypes.data, words.shape[1], lens.ctypes.data, len(lens)))
 
+    def push_reads_ascii(self, mate, reads):
+        """bk_push_reads_ascii: list of ASCII reads, packed on the GPU, asynchronous."""
+        reads = [bytes(r) for r in reads]
+        if not reads:
+            return
+        flat = np.frombuffer(b"".join(reads), np.uint8)
+        flat = np.ascontiguousarray(flat) if len(flat) else np.zeros(1, np.uint8)
+        off = np.zeros(len(reads) + 1, np.uint64)
+        off[1:] = np.cumsum([len(r) for r in reads])
+        _check(self._L.bk_push_reads_ascii(self.h, mate, flat.ctypes.data, off.ctypes.data, len(reads)))
+
     def push_reads_device(self, mate, d_words_ptr, stride_words, d_lens_ptr, n_records):
         _check(self._L.bk_push_reads_packed_device(self.h, mate, C.c_void_p(d_words_ptr), stride_words,
                                                    C.c_void_p(d_lens_ptr), n_records))

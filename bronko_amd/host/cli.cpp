@@ -248,32 +248,23 @@ void hip_check(int rc, const char* what) {
     if (rc != 0) die("bronko::call", std::string(what) + ": " + bk_last_error());
 }
 
-// One mate file: FASTQ(.gz) -> 2-bit records (K0) -> bk_push_reads_packed, in batches.  Returns reads seen.
-uint64_t push_fastq(bk_engine* e, int mate, const std::string& path, int k) {
-    constexpr uint64_t kBatchReads = 1u << 19;
+// One mate file: FASTQ(.gz) -> batches of sequence lines -> bk_push_reads_ascii (packed on the GPU, asynchronous: the
+// next batch is parsed while the previous ones are copied, packed and scanned).  Returns reads seen.
+uint64_t push_fastq(bk_engine* e, int mate, const std::string& path) {
+    constexpr uint64_t kBatchReads = 1u << 18;
     GzLineReader in(path);
     std::string line, buf;
     std::vector<uint64_t> off{0};
-    std::vector<uint32_t> words;
-    std::vector<uint16_t> lens;
     uint64_t n_reads = 0, ln = 0;
-    size_t longest = (size_t)k;
     auto flush = [&]() {
         if (off.size() <= 1) return;
-        const uint32_t stride = (uint32_t)std::min<size_t>((longest + 15) / 16, 4095);
-        const uint8_t* base = reinterpret_cast<const uint8_t*>(buf.data());
-        const uint64_t n_rec = bk_pack_reads_flat(base, off.data(), off.size() - 1, k, stride, nullptr, nullptr, 0);
-        words.assign((size_t)n_rec * stride + 1, 0u);
-        lens.assign((size_t)n_rec + 1, 0);
-        bk_pack_reads_flat(base, off.data(), off.size() - 1, k, stride, words.data(), lens.data(), n_rec);
-        hip_check(bk_push_reads_packed(e, mate, words.data(), stride, lens.data(), n_rec), "bk_push_reads_packed");
-        buf.clear(); off.assign(1, 0); longest = (size_t)k;
+        hip_check(bk_push_reads_ascii(e, mate, reinterpret_cast<const uint8_t*>(buf.data()), off.data(), off.size() - 1), "bk_push_reads_ascii");
+        buf.clear(); off.assign(1, 0);
     };
     while (in.next(line)) {
         if ((ln++ & 3) != 1) continue;           // 4-line FASTQ records: @id / sequence / + / quality
         buf += line;
         off.push_back(buf.size());
-        longest = std::max(longest, line.size());
         if (++n_reads % kBatchReads == 0) flush();
     }
     flush();
@@ -348,7 +339,7 @@ int run_call(const Args& a) {
         hip_check(bk_sample_begin(eng.e), "bk_sample_begin");
         uint64_t total_reads = 0;
         for (int m = 0; m < n_mates; m++) {
-            try { total_reads += push_fastq(eng.e, m, mates[m], ix.k); }
+            try { total_reads += push_fastq(eng.e, m, mates[m]); }
             catch (const std::exception& e) { die(T, e.what()); }
         }
         LOG_INFO(T, std::to_string(total_reads) + " reads counted from " + mates[0]);

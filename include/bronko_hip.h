@@ -124,6 +124,13 @@ int bk_push_reads_packed(bk_engine* e, int mate, const uint32_t* words, uint32_t
 int bk_push_reads_packed_device(bk_engine* e, int mate, const void* d_words, uint32_t stride_words,
                                 const void* d_lens, uint64_t n_records);
 
+/* K0 on the device + asynchronous ingest.  `buf` holds the sequence lines of n_reads reads back to back (read i =
+ * buf[offsets[i] .. offsets[i+1]), any symbols); the engine copies them into a pinned staging slot, uploads them,
+ * packs them into 2-bit records on the GPU (same splitting / chunking rules as bk_pack_reads) and scans them.  The
+ * call returns as soon as the staging copy is made -- `buf` may be reused immediately -- and up to three batches
+ * are in flight, so FASTQ parsing overlaps the copy, the packing and the scan.  bk_sample_finish waits for all. */
+int bk_push_reads_ascii(bk_engine* e, int mate, const uint8_t* buf, const uint64_t* offsets, uint64_t n_reads);
+
 /* Multi-GPU hook: the only additive quantity is the per-k-mer occurrence counter plane.
  * A host that shards one sample's reads over several GPUs all-reduces (sum, u64) each plane in place between
  * the last push and bk_sample_finish.  The pointer is device memory of bk_counter_len() u64. */

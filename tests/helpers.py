@@ -14,10 +14,16 @@ def engine_from_oracle_index(ix, params=None):
     return Engine(ix.k, ix.bucket_ids(), ix.bucket_off(), ix.entries(), ix.files(), params)
 
 
-def hip_sample(eng, mates_ascii, k, stride_words=None, batch=None):
-    """Run one sample through the C ABI: pack (K0) -> push per mate -> finish."""
+def hip_sample(eng, mates_ascii, k, stride_words=None, batch=None, ascii_path=False):
+    """Run one sample through the C ABI: pack (K0, host or -- ascii_path -- on the GPU) -> push per mate -> finish."""
     from bronko_amd import pack_reads
     eng.sample_begin()
+    if ascii_path:
+        for m, reads in enumerate(mates_ascii):
+            step = batch or max(len(reads), 1)
+            for i in range(0, len(reads), step):
+                eng.push_reads_ascii(m, reads[i:i + step])
+        return eng.sample_finish(len(mates_ascii))
     for m, reads in enumerate(mates_ascii):
         words, lens = pack_reads(reads, k, stride_words)
         if batch:

@@ -262,3 +262,21 @@ def test_full_kmer_statistics_match_the_kmc_contract(oracle, golden_dir):
     assert res.kmer_stats[0, 3] == np.iinfo(np.uint64).max
     eng.close()
     ix.close()
+
+
+def test_device_side_packing_and_async_ingest(oracle, hpv):
+    """bk_push_reads_ascii: K0 on the GPU (N splitting, short runs, chunking of long reads) + the 3-slot asynchronous
+    ingest ring; many small batches so that slots are reused while earlier batches are still in flight."""
+    ix, eng = hpv
+    g = synth.read_fasta_bytes(os.path.join(helpers.GOLDEN, "HPV16.fa"))
+    long_read = g[500:7000]                                   # 6.5 kb read: chunked with k-1 overlap on the device
+    reads = helpers.hpv_reads(9000, seed=14, with_n=True, ragged=True) + [b"", b"NNNN", b"ACGT", long_read,
+                                                                            long_read[:3000] + b"N" + long_read[3000:]]
+    pile = oracle.sample_pileup(ix, [reads])
+    for batch in (None, 1000, 37):
+        res = helpers.hip_sample(eng, [reads], 21, batch=batch, ascii_path=True)
+        helpers.assert_same_pileup(res, pile)
+        assert res.kmer_stats[0, 1] == pile.kmc_stats[0, 1]
+    # host packing and device packing produce the same number of records
+    host = helpers.hip_sample(eng, [reads], 21)
+    assert host.kmer_stats[0, 0] == res.kmer_stats[0, 0]

@@ -62,8 +62,9 @@ constexpr uint32_t kIdMask = 0x7fffffffu;
 // A reference k-mer in a neighbour list: 16 B so that one candidate is one global_load_dwordx4.
 struct alignas(16) NbEntry {
     uint64_t u;      // canonical reference k-mer
-    uint32_t p;      // its id (names its E and V counters)
-    uint32_t pad;
+    uint32_t p;      // first V row of the k-mer (bk_device.h "V rows"); unique per k-mer, so it also orders neighbours
+    uint32_t valid;  // bit t: the k-mer owns a bucket at window position wstart+t (all ones for a reference k-mer;
+                     // k = 31 "pseudo" k-mers own only the positions where a wrapped bucket id aliases, see bk_engine.cpp)
 };
 
 // Directory entry of a half-key: the reference k-mers sharing that half are cand[off .. off + cnt).
@@ -104,6 +105,10 @@ struct IndexView {
     const uint32_t*  id_at;       // [total_cells] id of the k-mer starting at cell q (0xffffffff: none)
     uint32_t total_cells;
     uint32_t n_u;                 // |U| = number of ids
+    uint32_t n_full;              // ids < n_full are reference k-mers (W V rows each); the rest are k = 31 pseudo k-mers
+    uint64_t n_rows;              // V rows in all (8 counters each)
+    const uint32_t*  prow_id;     // [n_rows - n_full*W] id of the pseudo k-mer that owns V row n_full*W + i
+    const uint8_t*   prow_t;      //   ... and the window position t of that row
     const uint16_t*  pilots;   // [1 << log2nb]
     HalfView         lo, hi;
     const uint32_t*  slot_of;  // [n_u][W] window bucket (slot) of reference k-mer id at window position t
@@ -126,14 +131,24 @@ struct IndexView {
     int32_t  n_files;
 };
 
-// Counter plane of one mate file, u64: [ E : 2 * n_u ][ V : n_u * W * 8 ]
+// Counter plane of one mate file, u64: [ E : 2 * n_u ][ V : n_rows * 8 ]
 //   E[2id + rc]                       occurrences of the reference k-mer u = kmer_of[id] read as-is (rc=0) / as
 //                                     its reverse complement (rc=1)
-//   V[((id*W + t)*4 + b)*2 + rc]      occurrences of the non-reference k-mer "u with base b at window position
+//   V[(row(id,t)*4 + b)*2 + rc]       occurrences of the non-reference k-mer "u with base b at window position
 //                                     wstart+t".  A non-reference k-mer may neighbour several reference k-mers;
-//                                     it is always counted under the smallest (t, id) -- a function of the k-mer
+//                                     it is always counted under the smallest (t, row) -- a function of the k-mer
 //                                     alone, so all its occurrences share one counter and it owns no other.
+// V rows: a reference k-mer (id < n_full) has rows id*W + t; a pseudo k-mer has one row per window position at which
+// it owns a bucket, numbered after those (NbEntry::p = its first row; row = p + popcount(valid below t)).
 BK_HD uint64_t e_plane_len(uint32_t n_u) { return 2ull * n_u; }
-BK_HD uint64_t v_plane_len(uint32_t n_u, int W) { return (uint64_t)n_u * (uint64_t)(W > 0 ? W : 0) * 8ull; }
+BK_HD uint64_t v_plane_len(uint64_t n_rows) { return n_rows * 8ull; }
+// (id, t) of V row `row`
+BK_HD void row_owner(const struct IndexView& ix, uint64_t row, uint32_t& id, uint32_t& t);
+
+BK_HD void row_owner(const IndexView& ix, uint64_t row, uint32_t& id, uint32_t& t) {
+    const uint64_t full_rows = (uint64_t)ix.n_full * (uint32_t)ix.W;
+    if (row < full_rows) { id = (uint32_t)(row / (uint32_t)ix.W); t = (uint32_t)(row % (uint32_t)ix.W); }
+    else { id = ix.prow_id[row - full_rows]; t = ix.prow_t[row - full_rows]; }
+}
 
 }  // namespace bk

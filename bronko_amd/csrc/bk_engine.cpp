@@ -62,6 +62,54 @@ struct TimedSpan { hipEvent_t a, b; int kind; };
 
 namespace {
 
+// assign_buckets (lcb.rs:1-45) is the 1-based lexicographic rank of (V, position) where V is the k-mer with the
+// wildcard position set to A: ranks are ordered by V, then by position, and V contributes one rank per A it contains
+// (verified exhaustively for small k against the reference's known answers).  In exact arithmetic the rank of a k = 31
+// bucket reaches 31 * 4^30 ~ 1.94 * 2^64, and the reference keeps it modulo 2^64: two different (position, k-mer)
+// pairs whose ranks differ by 2^64 share a bucket.  rank128 / unrank128 are the exact map and its inverse.
+using u128 = unsigned __int128;
+
+u128 rank128(uint64_t v /* wildcard position already A */, int pos, int k) {
+    u128 cum = 0;   // sum of (number of A digits) over all k-digit strings < v
+    int a_pre = 0;
+    for (int i = 0; i < k; i++) {
+        const int d = (int)((v >> (2 * (k - 1 - i))) & 3);
+        const int rest = k - 1 - i;
+        const u128 pw = (u128)1 << (2 * rest);                  // 4^rest strings below each smaller digit
+        const u128 free_a = rest ? (u128)rest * (pw >> 2) : 0;  // A digits inside the free suffix, summed over them
+        for (int x = 0; x < d; x++) cum += (u128)(a_pre + (x == 0)) * pw + free_a;
+        a_pre += d == 0;
+    }
+    int before = 0;
+    for (int i = 0; i < pos; i++) before += ((v >> (2 * (k - 1 - i))) & 3) == 0;
+    return cum + (u128)before + 1;
+}
+
+bool unrank128(u128 r1, int k, uint64_t* v_out, int* pos_out) {
+    if (r1 == 0) return false;
+    u128 r = r1 - 1;
+    uint64_t v = 0;
+    int a_pre = 0;
+    for (int i = 0; i < k; i++) {
+        const int rest = k - 1 - i;
+        const u128 pw = (u128)1 << (2 * rest);
+        const u128 free_a = rest ? (u128)rest * (pw >> 2) : 0;
+        int x = 0;
+        for (; x < 4; x++) {
+            const u128 c = (u128)(a_pre + (x == 0)) * pw + free_a;
+            if (r < c) break;
+            r -= c;
+        }
+        if (x == 4) return false;   // rank beyond k * 4^(k-1)
+        v |= (uint64_t)x << (2 * rest);
+        a_pre += x == 0;
+    }
+    // r-th A position of v
+    for (int i = 0; i < k; i++)
+        if (((v >> (2 * (k - 1 - i))) & 3) == 0) { if (r == 0) { *v_out = v; *pos_out = i; return true; } r -= 1; }
+    return false;
+}
+
 // Perfect hash of distinct keys (bk_device.h phf_*): buckets of ~4 keys, largest first, smallest free pilot.
 // On success pos[i] is the position of keys[i] in a table of m >= n positions.
 bool build_phf(const std::vector<uint64_t>& keys, std::vector<uint16_t>& pilots, uint32_t& log2nb, uint32_t& m_out, std::vector<uint32_t>& pos) {
@@ -111,7 +159,10 @@ struct bk_engine {
     bk_params params{};
     int k = 0, wstart = 0, W = 0, n_files = 0;
     uint64_t total_cells = 0, n_slots = 0;
-    uint32_t log2s = 4, log2nb = 0, m = 1, n_u = 0, n_lds_bins = 0;
+    uint32_t log2s = 4, log2nb = 0, m = 1, n_u = 0, n_full = 0, n_lds_bins = 0;
+    uint64_t n_rows = 0;   // V rows (bk_device.h)
+    DevBuf<uint32_t> prow_id;
+    DevBuf<uint8_t> prow_t;
     bool ref_in_lds = false;
     int lo_bases = 0, n_cus = 256;
     int device = 0;
@@ -172,6 +223,7 @@ struct bk_engine {
         bk::IndexView v{};
         v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb;
         v.kmer_of = kmer_of.p; v.ref_words = ref_words.p; v.cell_flags = cell_flags.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
+        v.n_full = n_full; v.n_rows = n_rows; v.prow_id = prow_id.p; v.prow_t = prow_t.p;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb};
         v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
@@ -263,6 +315,12 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     std::vector<bk::DevEntry> h_ent;
     std::vector<uint64_t> per_t(e->W > 0 ? e->W : 1, 0);
     std::vector<uint64_t> h_u;   // canonical reference k-mers that own at least one window bucket (with repeats)
+    // k = 31 only: "pseudo" k-mers u*.  A read k-mer equal to u* except possibly at one window position can reach an
+    // index bucket through the u64 wrap of its bucket id (see rank128): u* stands for the alias key (j', V') of a
+    // real bucket (j, V) with the base of the real k-mer at j' filled in.  The wrap is structured (changing a few
+    // leading bases shifts every rank of a k-mer by exactly 2^64), so the W buckets of a reference k-mer usually
+    // share one pseudo k-mer.  Which window positions of u* really lead to a bucket is read back from the table.
+    std::vector<uint64_t> pseudo;
     uint64_t ids[32];
     for (uint64_t b = 0; b < ix->n_buckets && e->W > 0; b++) {
         const uint64_t lo = ix->bucket_off[b], hi = ix->bucket_off[b + 1];
@@ -270,6 +328,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         if (hi > ix->n_entries) return fail(BK_ERR_INVALID, "bucket_off out of range");
         // distinct (j, masked) keys present in this bucket: exactly one unless k = 31 ids wrapped onto each other
         std::vector<std::pair<int, uint64_t>> keys;
+        uint64_t first_kmer = 0;
         bool any_in_window = false;
         for (uint64_t i = lo; i < hi; i++) {
             const bk_bucket_info& bi = ix->entries[i];
@@ -283,11 +342,23 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             if (std::find(keys.begin(), keys.end(), std::make_pair(j, masked)) == keys.end()) {
                 bronko::assign_buckets(cn.kmer, k, ids);
                 if (ids[j] != ix->bucket_ids[b]) return fail(BK_ERR_INVALID, "bucket %llu: id does not match assign_buckets of its entries", (unsigned long long)ix->bucket_ids[b]);
+                if (keys.empty()) first_kmer = cn.kmer;
                 keys.emplace_back(j, masked);
             }
             if (j >= e->wstart && j < e->wstart + e->W) { any_in_window = true; h_u.push_back(cn.kmer); }
         }
-        if (!any_in_window) continue;
+        // the other exact rank that wraps onto this bucket's id, if the reference did not already put a k-mer there
+        int alias_j = -1;
+        uint64_t alias_masked = 0;
+        if (k == 31 && keys.size() == 1) {
+            const u128 own = rank128(keys[0].second, keys[0].first, k);
+            if ((uint64_t)own != ix->bucket_ids[b]) return fail(BK_ERR_INVALID, "internal: exact bucket rank disagrees with assign_buckets");
+            const u128 two64 = (u128)1 << 64;
+            const u128 other = own >= two64 ? own - two64 : own + two64;
+            uint64_t av; int aj;
+            if (unrank128(other, k, &av, &aj) && aj >= e->wstart && aj < e->wstart + e->W) { alias_j = aj; alias_masked = av; }
+        }
+        if (!any_in_window && alias_j < 0) continue;
         // every entry of the bucket is voted for by a probe of any of its keys (call.rs:1307-1309 iterates the
         // whole Vec<BucketInfo>), using each entry's own idx (call.rs:1329)
         const uint32_t off = (uint32_t)h_ent.size();
@@ -309,6 +380,14 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             h_len.push_back((uint32_t)(hi - lo));
             per_t[kv.first - e->wstart]++;
         }
+        if (alias_j >= 0) {
+            h_slot_key.push_back(alias_masked);
+            h_slot_t.push_back((uint8_t)(alias_j - e->wstart));
+            h_off.push_back(off);
+            h_len.push_back((uint32_t)(hi - lo));
+            per_t[alias_j - e->wstart]++;
+            pseudo.push_back(alias_masked | (first_kmer & (3ull << (2 * (k - 1 - alias_j)))));
+        }
         if (h_ent.size() >= (1ull << 32)) return fail(BK_ERR_UNSUPPORTED, "more than 2^32 index entries in the window");
     }
     e->n_slots = h_slot_key.size();
@@ -324,18 +403,49 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         bk::TableSlot* sub = h_table.data() + (size_t)h_slot_t[s] * S;
         uint32_t h = bk::hash_key(h_slot_key[s], e->log2s);
         while (sub[h].key != bk::kEmptyKey) {
-            if (sub[h].key == h_slot_key[s]) return fail(BK_ERR_INVALID, "duplicate window bucket in the index");
+            if (sub[h].key == h_slot_key[s]) {
+                if (k == 31) break;   // an alias key that coincides with a real key (same wrapped id, same bucket): keep the first
+                return fail(BK_ERR_INVALID, "duplicate window bucket in the index");
+            }
             h = (h + 1) & (uint32_t)(S - 1);
         }
-        sub[h].key = h_slot_key[s];
-        sub[h].slot = (uint32_t)s;
+        if (sub[h].key == bk::kEmptyKey) { sub[h].key = h_slot_key[s]; sub[h].slot = (uint32_t)s; }
     }
+    // a slot with no entries: "this k-mer has no bucket at that window position" (pseudo k-mers)
+    const uint32_t empty_slot = (uint32_t)h_off.size();
+    h_off.push_back(0);
+    h_len.push_back(0);
 
     // ---- reference k-mer set U ------------------------------------------------------------------------------
     // ids in order of first occurrence in reference order; perfect hash (membership + diagonal seeding);
     // half-key directories (neighbour search); the reference in reference order (diagonal walk); per-id tables.
     std::sort(h_u.begin(), h_u.end());
     h_u.erase(std::unique(h_u.begin(), h_u.end()), h_u.end());
+    // pseudo k-mers join U (so that the membership / neighbour machinery finds the read k-mers that alias), but they
+    // own only the window positions at which the table holds a key for them.  A pseudo value that is a real
+    // reference k-mer needs nothing: its alias key is that k-mer's own bucket key.
+    std::vector<uint64_t> extra;
+    std::sort(pseudo.begin(), pseudo.end());
+    pseudo.erase(std::unique(pseudo.begin(), pseudo.end()), pseudo.end());
+    for (uint64_t v : pseudo)
+        if (!std::binary_search(h_u.begin(), h_u.end(), v)) extra.push_back(v);
+    h_u.insert(h_u.end(), extra.begin(), extra.end());
+    std::sort(h_u.begin(), h_u.end());
+    // bucket (slot) of every k-mer of U at every window position, by table lookup; h_valid = positions with a bucket
+    std::vector<uint32_t> h_valid(h_u.size(), 0u);
+    std::vector<uint8_t> h_is_pseudo(h_u.size(), 0);
+    std::vector<uint32_t> slot_by_index((size_t)std::max<size_t>(h_u.size(), 1) * std::max(e->W, 1), empty_slot);
+    for (size_t i = 0; i < h_u.size(); i++) {
+        h_is_pseudo[i] = std::binary_search(extra.begin(), extra.end(), h_u[i]) ? 1 : 0;
+        for (int t = 0; t < e->W; t++) {
+            const uint64_t key = h_u[i] & ~(3ull << (2 * (k - 1 - (e->wstart + t))));
+            const bk::TableSlot* sub = h_table.data() + (size_t)t * S;
+            uint32_t h = bk::hash_key(key, e->log2s);
+            while (sub[h].key != key && sub[h].key != bk::kEmptyKey) h = (h + 1) & (uint32_t)(S - 1);
+            if (sub[h].key == key) { slot_by_index[i * e->W + t] = sub[h].slot; h_valid[i] |= 1u << t; }
+            else if (!h_is_pseudo[i]) return fail(BK_ERR_INVALID, "index lacks a window bucket of one of its own reference k-mers");
+        }
+    }
     e->lo_bases = k / 2;
     if (h_u.size() >= (1ull << 31)) return fail(BK_ERR_UNSUPPORTED, "too many distinct reference k-mers");
     e->n_u = (uint32_t)h_u.size();
@@ -376,7 +486,32 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             }
         }
         for (size_t i = 0; i < h_u.size(); i++)   // k-mers known only through index entries: ids after the others
+            if (id_of[i] == kNone && !h_is_pseudo[i]) id_of[i] = next_id++;
+        e->n_full = next_id;
+        for (size_t i = 0; i < h_u.size(); i++)   // pseudo k-mers last: they own V rows only where they own a bucket
             if (id_of[i] == kNone) id_of[i] = next_id++;
+        // V rows (bk_device.h): id*W + t for reference k-mers, then the pseudo k-mers' rows in id order
+        std::vector<uint32_t> row_base(h_u.size(), 0u);
+        {
+            std::vector<uint32_t> idx_by_id(h_u.size());
+            for (size_t i = 0; i < h_u.size(); i++) idx_by_id[id_of[i]] = (uint32_t)i;
+            uint64_t rows = (uint64_t)e->n_full * e->W;
+            std::vector<uint32_t> h_prow_id;
+            std::vector<uint8_t> h_prow_t;
+            for (size_t id = 0; id < h_u.size(); id++) {
+                const uint32_t i = idx_by_id[id];
+                if (id < e->n_full) { row_base[i] = (uint32_t)(id * e->W); continue; }
+                if (rows >= (1ull << 29)) return fail(BK_ERR_UNSUPPORTED, "index too large: variant counter plane exceeds 2^32 counters");
+                row_base[i] = (uint32_t)rows;
+                for (int t = 0; t < e->W; t++)
+                    if ((h_valid[i] >> t) & 1u) { h_prow_id.push_back((uint32_t)id); h_prow_t.push_back((uint8_t)t); rows++; }
+            }
+            if (rows >= (1ull << 29)) return fail(BK_ERR_UNSUPPORTED, "index too large: variant counter plane exceeds 2^32 counters");
+            e->n_rows = rows;
+            if (h_prow_id.empty()) { h_prow_id.push_back(0); h_prow_t.push_back(0); }
+            BK_HIP(e->prow_id.upload(h_prow_id));
+            BK_HIP(e->prow_t.upload(h_prow_t));
+        }
 
         // dirty flags (bk_device.h amb): another reference k-mer, on either strand, within Hamming distance 2, or
         // the k-mer within distance 2 of its own reverse complement.  Any two 2k-bit words at distance <= 2 agree
@@ -411,6 +546,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 }
             }
         }
+        for (size_t i = 0; i < h_u.size(); i++) if (h_is_pseudo[i]) h_amb[id_of[i]] = 1;
         std::vector<uint32_t> h_flags((cells + 7) / 8 + 1, 0u);   // bk_device.h cell_flags
         for (uint64_t c = 0; c < cells; c++) {
             if (h_id_at[c] == kNone) continue;
@@ -456,7 +592,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             std::vector<uint32_t> first, count;
             for (size_t i = 0; i < order.size(); i++) {
                 const uint64_t u = h_u[order[i]];
-                cand[i] = bk::NbEntry{u, id_of[order[i]], 0u};
+                cand[i] = bk::NbEntry{u, row_base[order[i]], h_valid[order[i]]};
                 if (halves.empty() || halves.back() != half_of(u)) { halves.push_back(half_of(u)); first.push_back((uint32_t)i); count.push_back(0); }
                 count.back()++;
             }
@@ -472,20 +608,11 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         }
 
         // slot_of[id*W + t]: the window bucket (wstart+t, u masked) of reference k-mer id -- every reference k-mer
-        // owns all of its buckets, so finalize needs no table probe for them.
-        std::vector<uint32_t> h_slot_of((size_t)std::max<size_t>(h_u.size(), 1) * std::max(e->W, 1), 0u);
-        for (size_t i = 0; i < h_u.size(); i++) {
-            for (int t = 0; t < e->W; t++) {
-                const uint64_t key = h_u[i] & ~(3ull << (2 * (k - 1 - (e->wstart + t))));
-                const bk::TableSlot* sub = h_table.data() + (size_t)t * S;
-                uint32_t h = bk::hash_key(key, e->log2s);
-                while (sub[h].key != key) {
-                    if (sub[h].key == bk::kEmptyKey) return fail(BK_ERR_INVALID, "index lacks a window bucket of one of its own reference k-mers");
-                    h = (h + 1) & (uint32_t)(S - 1);
-                }
-                h_slot_of[(size_t)id_of[i] * e->W + t] = sub[h].slot;
-            }
-        }
+        // owns all of its buckets, so finalize needs no table probe for them (pseudo k-mers: empty_slot where none).
+        std::vector<uint32_t> h_slot_of((size_t)std::max<size_t>(h_u.size(), 1) * std::max(e->W, 1), empty_slot);
+        for (size_t i = 0; i < h_u.size(); i++)
+            for (int t = 0; t < e->W; t++) h_slot_of[(size_t)id_of[i] * e->W + t] = slot_by_index[i * e->W + t];
+        std::vector<uint32_t>().swap(slot_by_index);
         BK_HIP(e->slot_of.upload(h_slot_of));
 
         // estat: per reference k-mer, its per-genome hit totals over its W window buckets (call.rs:1316-1318) and
@@ -532,8 +659,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     BK_HIP(e->ent_off.upload(h_off));
     BK_HIP(e->ent_len.upload(h_len));
     BK_HIP(e->entries.upload(h_ent));
-    if (bk::v_plane_len(e->n_u, e->W) >= (1ull << 32)) return fail(BK_ERR_UNSUPPORTED, "index too large: variant counter plane exceeds 2^32 counters");
-    for (int m = 0; m < 2; m++) BK_HIP(e->counters[m].alloc(bk::e_plane_len(e->n_u) + bk::v_plane_len(e->n_u, e->W)));
+    for (int m = 0; m < 2; m++) BK_HIP(e->counters[m].alloc(bk::e_plane_len(e->n_u) + bk::v_plane_len(e->n_rows)));
     if (prm->full_kmer_stats) {
         if (prm->kmer_table_log2 < 10 || prm->kmer_table_log2 > 31) return fail(BK_ERR_INVALID, "kmer_table_log2 out of range");
         BK_HIP(e->ktab_keys.alloc((size_t)1 << prm->kmer_table_log2));
@@ -541,7 +667,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     }
     BK_HIP(e->ktab_out.alloc(8));
     if (e->n_files <= 64) BK_HIP(e->fin_partials.alloc(bk::finalize_partial_rows() * ((size_t)e->n_files * 3 + 2)));
-    BK_HIP(e->deferred.alloc(bk::v_plane_len(e->n_u, e->W)));
+    BK_HIP(e->deferred.alloc(bk::v_plane_len(e->n_rows)));
     BK_HIP(e->n_deferred.alloc(1));
     if (e->n_lds_bins >= e->n_u) e->use_xcd_planes = false;   // every reference k-mer has an LDS bin
     if (e->use_xcd_planes) {
@@ -587,7 +713,7 @@ int bk_engine_set_stream(bk_engine* e, void* hip_stream) {
 uint64_t bk_total_cells(const bk_engine* e) { return e ? e->total_cells : 0; }
 int32_t bk_n_files(const bk_engine* e) { return e ? e->n_files : 0; }
 uint64_t bk_n_slots(const bk_engine* e) { return e ? e->n_slots : 0; }
-uint64_t bk_counter_len(const bk_engine* e) { return e ? bk::e_plane_len(e->n_u) + bk::v_plane_len(e->n_u, e->W) : 0; }
+uint64_t bk_counter_len(const bk_engine* e) { return e ? bk::e_plane_len(e->n_u) + bk::v_plane_len(e->n_rows) : 0; }
 
 int bk_sample_begin(bk_engine* e) {
     if (!e) return fail(BK_ERR_INVALID, "null engine");

@@ -72,12 +72,12 @@ __device__ __forceinline__ void for_each_neighbour(const IndexView& ix, uint64_t
     for (uint32_t i = 0; i < dl.cnt; ++i) {
         const uint4 e = *reinterpret_cast<const uint4*>(ix.lo.cand + dl.off + i);
         const int j = single_diff_pos((uint64_t)e.x | ((uint64_t)e.y << 32), c, k);
-        if (j >= wlo && j < whi) f(j, e.z);
+        if (j >= wlo && j < whi && ((e.w >> (j - wlo)) & 1u)) f(j, e.z);
     }
     for (uint32_t i = 0; i < dh.cnt; ++i) {
         const uint4 e = *reinterpret_cast<const uint4*>(ix.hi.cand + dh.off + i);
         const int j = single_diff_pos((uint64_t)e.x | ((uint64_t)e.y << 32), c, k);
-        if (j >= wlo && j < whi) f(j, e.z);
+        if (j >= wlo && j < whi && ((e.w >> (j - wlo)) & 1u)) f(j, e.z);
     }
 }
 
@@ -288,11 +288,11 @@ struct SlowPipe {
             stage = 3;
         } else if (stage == 3) {
             const int k = ix.k, wlo = ix.wstart, whi = ix.wstart + ix.W;
-            uint64_t best = ~0ull;   // (j << 32) | id, smallest wins
+            uint64_t best = ~0ull;   // (j << 32) | V row, smallest wins
             auto consider = [&](const uint4& e) {
                 const int j = single_diff_pos((uint64_t)e.x | ((uint64_t)e.y << 32), c, k);
-                if (j >= wlo && j < whi) {
-                    const uint64_t key = ((uint64_t)j << 32) | e.z;
+                if (j >= wlo && j < whi && ((e.w >> (j - wlo)) & 1u)) {   // the neighbour owns a bucket at j
+                    const uint64_t key = ((uint64_t)j << 32) | (e.z + (uint32_t)__popc(e.w & ((1u << (j - wlo)) - 1u)));
                     if (key < best) best = key;
                 }
             };
@@ -302,9 +302,9 @@ struct SlowPipe {
             for (uint32_t i = 1; i < cnt_hi; ++i) consider(*reinterpret_cast<const uint4*>(ix.hi.cand + d_hi.y + i));   // rare
             if (best != ~0ull) {
                 const int j = (int)(best >> 32);
-                const uint32_t p = (uint32_t)best;
+                const uint32_t row = (uint32_t)best;
                 const uint32_t b = (uint32_t)(c >> (2 * (k - 1 - j))) & 3u;
-                unsigned long long* ctr = v_counters + (((uint64_t)p * ix.W + (uint32_t)(j - ix.wstart)) * 4 + b) * 2 + isrc;
+                unsigned long long* ctr = v_counters + ((uint64_t)row * 4 + b) * 2 + isrc;
                 if (COUNT) atomicAdd(ctr, 1ull);
                 else if (best == 0x123456789ull) *ctr = 1;   // measurement aid: keep the lookup alive without the atomic
             } else if (have && kt.keys) {
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
 
     const int k = ix.k;
     const uint64_t n_e = e_plane_len(ix.n_u);
-    const uint64_t n_v = v_plane_len(ix.n_u, ix.W);
+    const uint64_t n_v = v_plane_len(ix.n_rows);
     const unsigned long long* __restrict__ vc = a.counters + n_e;
     unsigned int kept = 0, distinct = 0;
 
@@ -746,9 +746,8 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         const unsigned long long v = n > a.cs ? a.cs : n;       // kmc -cs: reported count saturates
         const uint32_t isrc = (uint32_t)vi & 1u;
         const uint32_t bb = (uint32_t)(vi >> 1) & 3u;
-        const uint64_t pt = vi >> 3;
-        const uint32_t t = (uint32_t)(pt % (uint32_t)ix.W);
-        const uint32_t p = (uint32_t)(pt / (uint32_t)ix.W);
+        uint32_t t, p;
+        row_owner(ix, vi >> 3, p, t);
         const int j = ix.wstart + (int)t;
         const int sh = 2 * (k - 1 - j);
         const uint64_t c = (ix.kmer_of[p] & ~(3ull << sh)) | ((uint64_t)bb << sh);
@@ -863,9 +862,10 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
                 const uint64_t vi = ci - n_e;
                 isrc = (uint32_t)vi & 1u;
                 const uint32_t bb = (uint32_t)(vi >> 1) & 3u;
-                const uint64_t pt = vi >> 3;
-                const int sh = 2 * (k - 1 - (ix.wstart + (int)(pt % (uint32_t)ix.W)));
-                c = (ix.kmer_of[pt / (uint32_t)ix.W] & ~(3ull << sh)) | ((uint64_t)bb << sh);
+                uint32_t t, p;
+                row_owner(ix, vi >> 3, p, t);
+                const int sh = 2 * (k - 1 - (ix.wstart + (int)t));
+                c = (ix.kmer_of[p] & ~(3ull << sh)) | ((uint64_t)bb << sh);
             }
 
             if (lane < ix.W) {
@@ -924,7 +924,7 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     FinalizeArgs a = a0;
     const size_t lds_stats = ((size_t)a.ix.n_files * 3 + 2) * sizeof(uint32_t);
     // K2a
-    const uint64_t n_v = v_plane_len(a.ix.n_u, a.ix.W);
+    const uint64_t n_v = v_plane_len(a.ix.n_rows);
     const unsigned b_var = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_v + 255) / 256, kFinVariantBlocks));
     hipLaunchKernelGGL(finalize_variant_kernel, dim3(b_var), dim3(256), lds_stats, stream, a);
     // K2e

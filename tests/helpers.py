@@ -62,3 +62,51 @@ def hpv_reads(n, seed, read_len=150, err=0.005, with_n=False, ragged=False):
             out.append(bytes(rd))
         reads = out
     return reads
+
+
+# ---- exact (unwrapped) LCB bucket ranks: test-side restatement used to construct k = 31 aliasing reads ----------
+def lcb_rank(v, pos, k):
+    """1-based lexicographic rank of (v, pos) among all (k-mer with an A at `pos`, position) pairs, ordered by k-mer
+    value then position; v must have A (0) at `pos`.  lcb.rs:1-45 computes this modulo 2^64 (checked on CPU in
+    tests/test_oracle_golden.py::test_exact_rank_matches_assign_buckets)."""
+    cum, a_pre = 0, 0
+    for i in range(k):
+        d = (v >> (2 * (k - 1 - i))) & 3
+        rest = k - 1 - i
+        pw = 4 ** rest
+        free_a = rest * (pw // 4) if rest else 0
+        for x in range(d):
+            cum += (a_pre + (x == 0)) * pw + free_a
+        a_pre += d == 0
+    before = sum(1 for i in range(pos) if ((v >> (2 * (k - 1 - i))) & 3) == 0)
+    return cum + before + 1
+
+
+def lcb_unrank(r1, k):
+    """Inverse of lcb_rank: (v, pos) or None when r1 is not a rank."""
+    if r1 <= 0:
+        return None
+    r, v, a_pre = r1 - 1, 0, 0
+    for i in range(k):
+        rest = k - 1 - i
+        pw = 4 ** rest
+        free_a = rest * (pw // 4) if rest else 0
+        for x in range(4):
+            c = (a_pre + (x == 0)) * pw + free_a
+            if r < c:
+                break
+            r -= c
+        else:
+            return None
+        v |= x << (2 * rest)
+        a_pre += x == 0
+    for i in range(k):
+        if ((v >> (2 * (k - 1 - i))) & 3) == 0:
+            if r == 0:
+                return v, i
+            r -= 1
+    return None
+
+
+def kmer_str(v, k):
+    return "".join("ACGT"[(v >> (2 * (k - 1 - i))) & 3] for i in range(k))

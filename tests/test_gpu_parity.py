@@ -280,3 +280,73 @@ def test_device_side_packing_and_async_ingest(oracle, hpv):
     # host packing and device packing produce the same number of records
     host = helpers.hip_sample(eng, [reads], 21)
     assert host.kmer_stats[0, 0] == res.kmer_stats[0, 0]
+
+
+def test_reference_walk_from_global_memory(oracle, golden_dir, monkeypatch):
+    """BK_REF_IN_LDS=0 forces the REF_LDS=false kernel (reference + flag nibbles read from global memory), the path
+    indexes too large for LDS take; combined with a tiny LDS histogram so that the XCD planes are used as well."""
+    ix = oracle.Index.load(os.path.join(golden_dir, "hpv.bkdb"))
+    reads = helpers.hpv_reads(8000, seed=21, with_n=True)
+    pile = oracle.sample_pileup(ix, [reads])
+    for env in ({"BK_REF_IN_LDS": "0"}, {"BK_REF_IN_LDS": "0", "BK_LDS_BINS": "100"}):
+        for kk, vv in env.items():
+            monkeypatch.setenv(kk, vv)
+        eng = helpers.engine_from_oracle_index(ix)
+        res = helpers.hip_sample(eng, [reads], 21)
+        helpers.assert_same_pileup(res, pile)
+        eng.close()
+        for kk in env:
+            monkeypatch.delenv(kk)
+    ix.close()
+
+
+def test_k31_reads_that_reach_buckets_through_the_u64_wrap_of_their_ids(oracle, sars_paths):
+    """k = 31 bucket ids exceed 2^64 and the reference keeps them modulo 2^64 (lcb.rs:1-45), so a read k-mer that has
+    nothing to do with the reference can still land in a reference bucket: the one whose exact rank differs by 2^64.
+    Build such k-mers on purpose (tests/helpers.lcb_rank / lcb_unrank), mix them with ordinary reads, and require
+    the same pileup and statistics as the oracle (whose assign_buckets wraps like the reference's)."""
+    ix = oracle.Index.build(31, [sars_paths[0]])
+    g = synth.read_fasta_bytes(sars_paths[0])
+    reads = []
+    n_alias = 0
+    for start in range(500, 29000, 700):
+        v, _ = oracle.canonical_kmer(g[start:start + 31].decode())
+        for j in range(2, 28):
+            masked = v & ~(3 << (2 * (30 - j)))
+            r = helpers.lcb_rank(masked, j, 31)
+            other = helpers.lcb_unrank(r - (1 << 64) if r >= (1 << 64) else r + (1 << 64), 31)
+            if other is None:
+                continue
+            av, aj = other
+            n_alias += 1
+            for b in ((0, 1, 2, 3) if n_alias % 5 == 0 else (n_alias & 3,)):
+                x = av | (b << (2 * (30 - aj)))
+                s = helpers.kmer_str(x, 31)
+                if n_alias & 1:
+                    s = s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+                reads += [s.encode()] * (3 + (n_alias % 3))
+    assert n_alias > 500
+    gm, isnv = synth.sample_genome(g, 9)
+    reads += synth.codes_to_ascii(synth.single_end_codes(gm, 20000, 150, 19, isnv=isnv))
+    pile = oracle.sample_pileup(ix, [reads])
+    only_alias = oracle.sample_pileup(ix, [reads[:-20000]])
+    assert int(only_alias.fwd_nk.sum() + only_alias.rev_nk.sum()) > 0   # the constructed k-mers do vote in the reference
+    eng = helpers.engine_from_oracle_index(ix)
+    res = helpers.hip_sample(eng, [reads], 31)
+    helpers.assert_same_pileup(res, pile)
+    eng.close()
+    ix.close()
+
+
+def test_k31_four_sarscov2_strains(oracle, sars_paths):
+    """The four golden SARS-CoV-2 genomes at k = 31 (the case that first exposed the wrap-around aliasing)."""
+    ix = oracle.Index.build(31, sars_paths)
+    gm, isnv = synth.sample_genome(synth.read_fasta_bytes(sars_paths[2]), 4)
+    reads = synth.codes_to_ascii(synth.single_end_codes(gm, 60000, 150, 44, isnv=isnv))
+    pile = oracle.sample_pileup(ix, [reads])
+    eng = helpers.engine_from_oracle_index(ix)
+    res = helpers.hip_sample(eng, [reads], 31)
+    helpers.assert_same_pileup(res, pile)
+    assert oracle.pick_best_genome(ix, res.stats[0], res.present[0]) == 2
+    eng.close()
+    ix.close()

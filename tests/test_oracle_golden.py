@@ -110,3 +110,28 @@ def test_clean_sample_id(oracle):  # util.rs:30-50
     assert oracle.clean_sample_id("a.fq.fq") == "a"          # trim_end_matches strips repeatedly
     assert oracle.clean_sample_id("a.fa.gz") == "a.fa"       # ".fa.gz" is not in the suffix list -> file_stem
     assert oracle.clean_sample_id("sample.txt") == "sample"
+
+
+def test_exact_rank_matches_assign_buckets(oracle):
+    """tests/helpers.lcb_rank (exact integers) reduces to the oracle's assign_buckets modulo 2^64 -- exhaustively for
+    k = 5, and for seeded k = 31 k-mers, where ranks exceed 2^64 and wrap; lcb_unrank inverts it."""
+    from bronko_amd import synth
+    from tests import helpers
+    for v in range(4 ** 5):
+        ids = oracle.assign_buckets(v, 5)
+        for j in range(5):
+            masked = v & ~(3 << (2 * (4 - j)))
+            r = helpers.lcb_rank(masked, j, 5)
+            assert r == int(ids[j])
+            assert helpers.lcb_unrank(r, 5) == (masked, j)
+    wrapped = 0
+    for v in synth.splitmix64(77, 300):
+        v = int(v) & ((1 << 62) - 1)
+        ids = oracle.assign_buckets(v, 31)
+        for j in range(31):
+            masked = v & ~(3 << (2 * (30 - j)))
+            r = helpers.lcb_rank(masked, j, 31)
+            assert r % (1 << 64) == int(ids[j])
+            assert helpers.lcb_unrank(r, 31) == (masked, j)
+            wrapped += r >= (1 << 64)
+    assert wrapped > 0

@@ -98,7 +98,10 @@ struct IndexView {
     const KmerPos*   kmer_pos; // [m] perfect-hash table of U (membership test, diagonal seeding)
     const uint64_t*  kmer_of;  // [n_u] id -> canonical k-mer
     // the reference in reference order, for the diagonal walk of scan_count (staged in LDS when it fits):
-    const uint32_t*  ref_words;   // 2-bit packed bases of all cells (nt_to_bits, 16 per word, LSB first), padded
+    const uint32_t*  ref_words;   // 2-bit packed bases of all cells (nt_to_bits, 16 per word, LSB first), padded in front
+                                  // (bk_kernels.h scan_ref_pad_words) and behind
+    const uint32_t*  cell_codes;  // 2 bits per cell, same layout and padding: 0 = no k-mer of U starts here, 1 = one does and
+                                  // it is canonical as written, 2 = it was reverse-complemented to become canonical
     const uint32_t*  cell_flags;  // 4 bits per cell q (8 cells per word): bit 0 = a k-mer starts at q, it is in U and it
                                   // is "clean" (see amb); bit 1 = it was reverse-complemented to become canonical;
                                   // bit 2 = id(q) == id(q-1) + 1; bit 3 = id(q+1) == id(q) + 1

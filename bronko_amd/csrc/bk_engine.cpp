@@ -170,7 +170,7 @@ struct bk_engine {
     DevBuf<bk::KmerPos> kmer_pos;
     DevBuf<bk::IndexView> d_view;   // device copy of view()
     DevBuf<uint64_t> kmer_of;
-    DevBuf<uint32_t> ref_words, cell_flags, id_at;
+    DevBuf<uint32_t> ref_words, cell_codes, cell_flags, id_at;
     struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0; } half_lo, half_hi;
     DevBuf<unsigned int> deferred, n_deferred;
     DevBuf<unsigned int> fin_partials;      // per-workgroup finalize tallies (small genome sets only)
@@ -222,7 +222,7 @@ struct bk_engine {
     bk::IndexView view() const {
         bk::IndexView v{};
         v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb;
-        v.kmer_of = kmer_of.p; v.ref_words = ref_words.p; v.cell_flags = cell_flags.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
+        v.kmer_of = kmer_of.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_flags = cell_flags.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
         v.n_full = n_full; v.n_rows = n_rows; v.prow_id = prow_id.p; v.prow_t = prow_t.p;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb};
@@ -459,7 +459,8 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         std::vector<uint8_t> first_rc(h_u.size(), 0);
         const uint64_t cells = e->total_cells;
         std::vector<uint32_t> h_id_at(std::max<uint64_t>(cells, 1), kNone);
-        std::vector<uint32_t> h_refw((cells + 15) / 16 + 4, 0u), h_brc((cells + 31) / 32 + 1, 0u);
+        const size_t pad_w = (size_t)bk::scan_ref_pad_words();   // front padding of the two 2-bit arrays
+        std::vector<uint32_t> h_refw(pad_w + (cells + 15) / 16 + 4, 0u), h_brc((cells + 31) / 32 + 1, 0u);
         uint32_t next_id = 0;
         size_t sq = 0;
         for (int f = 0; f < ix->n_files; f++) {
@@ -467,7 +468,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 const uint64_t len = ix->seq_lens[sq];
                 const uint8_t* seq = ix->seqs[sq];
                 const uint64_t c0 = cell_off[f][sidx];
-                for (uint64_t i = 0; i < len; i++) h_refw[(c0 + i) >> 4] |= (uint32_t)bronko::nt_to_bits(seq[i]) << (2 * ((c0 + i) & 15));
+                for (uint64_t i = 0; i < len; i++) h_refw[pad_w + ((c0 + i) >> 4)] |= (uint32_t)bronko::nt_to_bits(seq[i]) << (2 * ((c0 + i) & 15));
                 if (len < (uint64_t)k) continue;
                 const uint64_t mask = bronko::kmer_mask(k);
                 uint64_t fwd = 0;
@@ -548,8 +549,10 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         }
         for (size_t i = 0; i < h_u.size(); i++) if (h_is_pseudo[i]) h_amb[id_of[i]] = 1;
         std::vector<uint32_t> h_flags((cells + 7) / 8 + 1, 0u);   // bk_device.h cell_flags
+        std::vector<uint32_t> h_codes(h_refw.size(), 0u);           // bk_device.h cell_codes
         for (uint64_t c = 0; c < cells; c++) {
             if (h_id_at[c] == kNone) continue;
+            h_codes[pad_w + (c >> 4)] |= (((h_brc[c >> 5] >> (c & 31)) & 1u) ? 2u : 1u) << (2 * (c & 15));
             uint32_t fl = 0;
             if (!h_amb[h_id_at[c]]) fl |= 1u;
             if ((h_brc[c >> 5] >> (c & 31)) & 1u) fl |= 2u;
@@ -573,6 +576,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         BK_HIP(e->kmer_of.upload(h_kmer_of));
         BK_HIP(e->ref_words.upload(h_refw));
         BK_HIP(e->cell_flags.upload(h_flags));
+        BK_HIP(e->cell_codes.upload(h_codes));
         BK_HIP(e->id_at.upload(h_id_at));
         BK_HIP(e->amb.upload(h_amb));
 
@@ -645,9 +649,10 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         e->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         const size_t budget = bk::scan_lds_budget();
         const size_t ref_bytes = bk::scan_ref_lds_bytes((uint32_t)e->total_cells);
-        e->ref_in_lds = ref_bytes + std::min<size_t>((size_t)e->n_u * sizeof(unsigned int), budget / 2) <= budget;
+        e->ref_in_lds = ref_bytes + std::min<size_t>((size_t)e->total_cells * sizeof(unsigned int), budget / 2) <= budget;
         if (const char* rl = getenv("BK_REF_IN_LDS")) e->ref_in_lds = e->ref_in_lds && atoi(rl) != 0;
-        e->n_lds_bins = (uint32_t)std::min<size_t>(e->n_u, (budget - (e->ref_in_lds ? ref_bytes : 0)) / sizeof(unsigned int));
+        // bins are per cell: the first n_lds_bins cells (the first genome(s) of the index) are counted in LDS
+        e->n_lds_bins = (uint32_t)std::min<size_t>(e->total_cells, (budget - (e->ref_in_lds ? ref_bytes : 0)) / sizeof(unsigned int));
         if (const char* nl = getenv("BK_LDS_BINS")) e->n_lds_bins = std::min<uint32_t>(e->n_lds_bins, (uint32_t)atol(nl));
         BK_HIP(e->slabs.alloc((size_t)e->n_cus * std::max<uint32_t>(e->n_lds_bins, 1)));
     }
@@ -669,7 +674,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     if (e->n_files <= 64) BK_HIP(e->fin_partials.alloc(bk::finalize_partial_rows() * ((size_t)e->n_files * 3 + 2)));
     BK_HIP(e->deferred.alloc(bk::v_plane_len(e->n_rows)));
     BK_HIP(e->n_deferred.alloc(1));
-    if (e->n_lds_bins >= e->n_u) e->use_xcd_planes = false;   // every reference k-mer has an LDS bin
+    if (e->n_lds_bins >= e->total_cells) e->use_xcd_planes = false;   // every cell has an LDS bin
     if (e->use_xcd_planes) {
         BK_HIP(e->e_planes.alloc((size_t)bk::kXcdPlanes * bk::e_plane_len(e->n_u)));
         BK_HIP(hipMemset(e->e_planes.p, 0, e->e_planes.n * sizeof(unsigned int)));
@@ -741,7 +746,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.n_records_dev = n_records_dev;
     a.ixp = e->d_view.p;
     a.k = e->k; a.wstart = e->wstart; a.W = e->W; a.total_cells = (uint32_t)e->total_cells; a.n_u = e->n_u;
-    a.ref_words = e->ref_words.p; a.cell_flags = e->cell_flags.p; a.id_at = e->id_at.p;
+    a.ref_words = e->ref_words.p; a.cell_codes = e->cell_codes.p; a.cell_flags = e->cell_flags.p; a.id_at = e->id_at.p;
     a.words = d_words; a.lens = d_lens; a.n_records = n; a.stride_words = stride_words;
     a.counters = e->counters[mate].p;
     a.kmer_total = e->kstats.p + mate * 4 + 1;
@@ -752,18 +757,24 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.ref_in_lds = e->ref_in_lds ? 1 : 0;
     a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->params.kmer_table_log2;
     a.ktab_overflow = e->ktab_out.p + 4; a.mate = (uint32_t)mate;
-    const uint32_t grid = bk::scan_grid(n, e->n_cus);
-    {
-        bk_engine::Span sp(e, 0);
-        BK_HIP(bk::launch_scan_count(a, grid, e->stream));
-    }
-    if (e->W > 0 && e->ablate == 0) {
-        // histogram slabs (and the u32 overflow planes: a batch of < 2^32 k-mers cannot wrap them) -> u64 plane
-        bk::FoldArgs f{};
-        f.slabs = e->slabs.p; f.n_slabs = grid; f.n_lds_bins = e->n_lds_bins;
-        f.e_planes = a.e_planes; f.n_e = bk::e_plane_len(e->n_u); f.counters = e->counters[mate].p;
-        bk_engine::Span sp(e, 3);
-        bk::launch_fold(f, e->stream);
+    // a launch takes at most scan_max_records records (bound on what one workgroup's 16-bit LDS bins can receive)
+    for (uint64_t base = 0; base < n;) {
+        const uint32_t grid = bk::scan_grid(n - base, e->n_cus);
+        const uint64_t take = std::min<uint64_t>(n - base, bk::scan_max_records(grid));
+        a.rec_base = base; a.n_records = take;
+        {
+            bk_engine::Span sp(e, 0);
+            BK_HIP(bk::launch_scan_count(a, grid, e->stream));
+        }
+        if (e->W > 0) {
+            // per-cell bin slabs (and the u32 overflow planes: a batch of < 2^32 k-mers cannot wrap them) -> u64 plane
+            bk::FoldArgs f{};
+            f.slabs = e->slabs.p; f.n_slabs = grid; f.n_lds_bins = e->n_lds_bins; f.id_at = e->id_at.p;
+            f.e_planes = a.e_planes; f.n_e = bk::e_plane_len(e->n_u); f.counters = e->counters[mate].p;
+            bk_engine::Span sp(e, 3);
+            bk::launch_fold(f, e->stream);
+        }
+        base += take;
     }
     BK_HIP(hipGetLastError());
     if (!n_records_dev) e->pushed_records[mate] += n;

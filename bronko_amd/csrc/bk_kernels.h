@@ -11,19 +11,21 @@ struct ScanArgs {
     // what the hot path needs (kept in kernel-argument registers)
     int32_t k, wstart, W;
     uint32_t total_cells, n_u;
-    const uint32_t* ref_words;      // IndexView::ref_words / cell_flags / id_at
-    const uint32_t* cell_flags;
+    const uint32_t* ref_words;      // IndexView::ref_words / cell_codes (both with scan_ref_pad_words() words of front padding)
+    const uint32_t* cell_codes;
+    const uint32_t* cell_flags;     // IndexView::cell_flags / id_at
     const uint32_t* id_at;
     const uint32_t* words;          // [n_records][stride_words] 2-bit packed, 16 bases per word, LSB first
     const uint16_t* lens;           // [n_records] valid bases
+    uint64_t rec_base;              // this launch covers records [rec_base, rec_base + n_records)
     uint64_t n_records;             // upper bound when n_records_dev is set (sizes nothing but the tile loop)
     const unsigned long long* n_records_dev;   // optional: actual record count written by pack_reads_kernel
     uint32_t stride_words;
     unsigned long long* counters;   // u64 plane [E | V] (bk_device.h)
-    unsigned int* slabs;            // [grid][n_lds_bins] packed (rc<<16 | fwd) histogram of each workgroup
-    uint32_t n_lds_bins;            // reference k-mers at positions < n_lds_bins are counted in LDS
-    unsigned int* e_planes;         // [8 XCDs][E] u32 planes for positions >= n_lds_bins; null if none / disabled
-    int ref_in_lds;                 // stage the packed reference + flag bits in LDS (they fit next to the histogram)
+    unsigned int* slabs;            // [grid][n_lds_bins] packed (rc<<16 | fwd) per-cell bins of each workgroup
+    uint32_t n_lds_bins;            // exact hits at cells < n_lds_bins are counted in LDS
+    unsigned int* e_planes;         // [8 XCDs][E] u32 planes for hits at cells >= n_lds_bins; null if none / disabled
+    int ref_in_lds;                 // stage the packed reference + cell codes in LDS (they fit next to the bins)
     unsigned long long* kmer_total; // optional: += k-mer occurrences scanned
     // full_kmer_stats: k-mers that do not touch the index are counted in this open-addressing table (null = off)
     unsigned long long* ktab_keys;  // [1 << ktab_log2] canonical k-mer | orientation << 63 | mate << 62; ~0 = free
@@ -31,7 +33,7 @@ struct ScanArgs {
     uint32_t ktab_log2;
     unsigned long long* ktab_overflow;
     uint32_t mate;
-    int ablate;                     // measurement aid, 0 in production (see scan_count_kernel)
+    int ablate;                     // measurement aid, 0 in production: 1 = Level 1 only (see scan_count_kernel)
 };
 
 struct FinalizeArgs {
@@ -54,6 +56,7 @@ struct FoldArgs {
     const unsigned int* slabs;
     uint32_t n_slabs;               // = grid of the scan launch
     uint32_t n_lds_bins;
+    const uint32_t* id_at;          // cell -> id (bins are per cell)
     unsigned int* e_planes;         // may be null
     uint64_t n_e;                   // 2 * m
     unsigned long long* counters;
@@ -73,6 +76,8 @@ struct PackArgs {
 void launch_pack_reads(const PackArgs& a, hipStream_t stream);
 void launch_add_u64(unsigned long long* dst, const unsigned long long* src, hipStream_t stream);   // *dst += *src
 uint32_t scan_grid(uint64_t n_records, int n_cus);
+uint64_t scan_max_records(uint32_t grid);   // most records one launch_scan_count may be given
+int scan_ref_pad_words();
 size_t scan_lds_budget();   // bytes available for histogram bins (4 B each) + the staged reference
 size_t scan_ref_lds_bytes(uint32_t total_cells);
 size_t scan_lds_bytes(uint32_t n_lds_bins, bool ref_in_lds, uint32_t total_cells);

@@ -62,9 +62,11 @@ constexpr uint32_t kIdMask = 0x7fffffffu;
 // A reference k-mer in a neighbour list: 16 B so that one candidate is one global_load_dwordx4.
 struct alignas(16) NbEntry {
     uint64_t u;      // canonical reference k-mer
-    uint32_t p;      // first V row of the k-mer (bk_device.h "V rows"); unique per k-mer, so it also orders neighbours
-    uint32_t valid;  // bit t: the k-mer owns a bucket at window position wstart+t (all ones for a reference k-mer;
-                     // k = 31 "pseudo" k-mers own only the positions where a wrapped bucket id aliases, see bk_engine.cpp)
+    uint32_t p;      // reference k-mer: its id; pseudo k-mer: n_full + its first pseudo V row.  Unique per k-mer, so it also
+                     // orders neighbours
+    uint32_t valid;  // bit t (t < 31): the k-mer owns a bucket at window position wstart+t (all of them for a reference k-mer;
+                     // k = 31 "pseudo" k-mers own only the positions where a wrapped bucket id aliases, see bk_engine.cpp);
+                     // bit 31: the reference k-mer's first occurrence was reverse-complemented to become canonical
 };
 
 // Directory entry of a half-key: the reference k-mers sharing that half are cand[off .. off + cnt).
@@ -102,20 +104,23 @@ struct IndexView {
                                   // (bk_kernels.h scan_ref_pad_words) and behind
     const uint32_t*  cell_codes;  // 2 bits per cell, same layout and padding: 0 = no k-mer of U starts here, 1 = one does and
                                   // it is canonical as written, 2 = it was reverse-complemented to become canonical
-    const uint32_t*  cell_flags;  // 4 bits per cell q (8 cells per word): bit 0 = a k-mer starts at q, it is in U and it
-                                  // is "clean" (see amb); bit 1 = it was reverse-complemented to become canonical;
-                                  // bit 2 = id(q) == id(q-1) + 1; bit 3 = id(q+1) == id(q) + 1
+    const uint32_t*  cell_has;    // 1 bit per cell (32 per word, 2 words of front padding, 3 behind): a k-mer of U starts here
+    const uint32_t*  cell_clean;  // same layout: ... and it is "clean" (bit 0 of cell_yf)
+    const uint32_t*  cell_yf;     // 2 bits per cell q, same layout and padding, for a walk along the reference: bit 0 = the k-mer
+                                  // that starts at q is in U and "clean" (see amb); bit 1 = id(q) == id(q-1) + 1
+    const uint32_t*  cell_yr;     // ... for a walk against it: bit 0 the same; bit 1 = id(q) == id(q+1) - 1
     const uint32_t*  id_at;       // [total_cells] id of the k-mer starting at cell q (0xffffffff: none)
     uint32_t total_cells;
     uint32_t n_u;                 // |U| = number of ids
     uint32_t n_full;              // ids < n_full are reference k-mers (W V rows each); the rest are k = 31 pseudo k-mers
-    uint64_t n_rows;              // V rows in all (8 counters each)
-    const uint32_t*  prow_id;     // [n_rows - n_full*W] id of the pseudo k-mer that owns V row n_full*W + i
+    uint64_t n_prows;             // V rows of the pseudo k-mers (8 counters each)
+    const uint32_t*  prow_id;     // [n_prows] id of the pseudo k-mer that owns pseudo V row i
     const uint8_t*   prow_t;      //   ... and the window position t of that row
+    int32_t  v_omin, v_span;      // layout of the reference k-mers' V counters (see v_row_base)
     const uint16_t*  pilots;   // [1 << log2nb]
     HalfView         lo, hi;
     const uint32_t*  slot_of;  // [n_u][W] window bucket (slot) of reference k-mer id at window position t
-    const uint8_t*   amb;      // [n_u] 1 = "dirty": another reference k-mer (either strand) lies within Hamming
+    const uint8_t*   amb;      // [n_u] bit 1 = the k-mer's first occurrence was reverse-complemented to become canonical; bit 0 = "dirty": another reference k-mer (either strand) lies within Hamming
                                //       distance 2 of it, or it is within distance 2 of its own reverse complement
     const uint32_t*  estat_off;// [n_u + 1] per reference k-mer: its genomes, precomputed from the index alone
     const uint32_t*  estat;    //   (file << 1) | 1 if hits == W ("perfect"), | 0 otherwise ("variant")
@@ -134,24 +139,34 @@ struct IndexView {
     int32_t  n_files;
 };
 
-// Counter plane of one mate file, u64: [ E : 2 * n_u ][ V : n_rows * 8 ]
-//   E[2id + rc]                       occurrences of the reference k-mer u = kmer_of[id] read as-is (rc=0) / as
-//                                     its reverse complement (rc=1)
-//   V[(row(id,t)*4 + b)*2 + rc]       occurrences of the non-reference k-mer "u with base b at window position
-//                                     wstart+t".  A non-reference k-mer may neighbour several reference k-mers;
-//                                     it is always counted under the smallest (t, row) -- a function of the k-mer
-//                                     alone, so all its occurrences share one counter and it owns no other.
-// V rows: a reference k-mer (id < n_full) has rows id*W + t; a pseudo k-mer has one row per window position at which
-// it owns a bucket, numbered after those (NbEntry::p = its first row; row = p + popcount(valid below t)).
+// Counter plane of one mate file, u64 (all arithmetic wraps modulo 2^64, so planes of read shards simply add):
+//   [ E : 2 * n_u ][ V of the reference k-mers : v_real_len ][ V of the pseudo k-mers : n_prows * 8 ]
+//   E[2id + rc]      occurrences of the reference k-mer u = kmer_of[id] read as-is (rc=0) / as its reverse complement (rc=1)
+//   V                occurrences of the non-reference k-mers "u with another base at one position".  A non-reference k-mer may
+//                    neighbour several reference k-mers; it is always counted under the smallest (window position, NbEntry::p)
+//                    -- a function of the k-mer alone, so all its occurrences share one counter and it owns no other.
+//
+// V of the reference k-mers.  A sequencing error at one reference base turns the k reference k-mers that cover it --
+// consecutive ids along the reference -- into non-reference k-mers, each differing from "its" reference k-mer at a different
+// offset o from the k-mer's start along the reference (o = j for a k-mer that is canonical as written, k-1-j for one that
+// was reverse-complemented; j = position in the canonical k-mer).  id + o is the same for all of them.  So the plane is a set
+// of rows (q = id + o - omin, base b on the reference's forward strand, direction d of the read: 0 along / 1 against the
+// reference), each a DIFFERENCE ARRAY over o: the number of occurrences of "(q - o, o, b) read in direction d" is the prefix
+// sum row[0] + ... + row[o - omin].  A read with one error adds +1 at the first offset its k-mers cover and -1 after the last
+// -- two atomics for up to k k-mers; a single k-mer is +1 at o, -1 at o + 1.  finalize takes the prefix sums and derives each
+// k-mer (its canonical form and orientation included) from the row coordinates.
 BK_HD uint64_t e_plane_len(uint32_t n_u) { return 2ull * n_u; }
-BK_HD uint64_t v_plane_len(uint64_t n_rows) { return n_rows * 8ull; }
-// (id, t) of V row `row`
-BK_HD void row_owner(const struct IndexView& ix, uint64_t row, uint32_t& id, uint32_t& t);
-
-BK_HD void row_owner(const IndexView& ix, uint64_t row, uint32_t& id, uint32_t& t) {
-    const uint64_t full_rows = (uint64_t)ix.n_full * (uint32_t)ix.W;
-    if (row < full_rows) { id = (uint32_t)(row / (uint32_t)ix.W); t = (uint32_t)(row % (uint32_t)ix.W); }
-    else { id = ix.prow_id[row - full_rows]; t = ix.prow_t[row - full_rows]; }
+BK_HD int v_layout_omin(int k, int wstart, int W, bool all_offsets) { if (all_offsets) return 0; const int m = k - wstart - W; return wstart < m ? wstart : m; }
+BK_HD int v_layout_span(int k, int wstart, int W, bool all_offsets) {
+    if (W <= 0) return 0;
+    if (all_offsets) return k;
+    const int hi1 = wstart + W - 1, hi2 = k - 1 - wstart;
+    return (hi1 > hi2 ? hi1 : hi2) - v_layout_omin(k, wstart, W, false) + 1;
 }
+BK_HD uint64_t v_real_rows(uint32_t n_full, int span) { return span > 0 ? ((uint64_t)n_full + (uint32_t)span) * 8ull : 0ull; }
+BK_HD uint64_t v_real_len(uint32_t n_full, int span) { return v_real_rows(n_full, span) * (uint64_t)(span + 1); }
+// first counter of row (q, b, d); the row has span + 1 counters (the last only ever receives a -1)
+BK_HD uint64_t v_row_base(uint32_t q, uint32_t b, uint32_t d, int span) { return (((uint64_t)q * 4ull + b) * 2ull + d) * (uint64_t)(span + 1); }
+BK_HD uint64_t v_plane_len(uint32_t n_full, int span, uint64_t n_prows) { return v_real_len(n_full, span) + n_prows * 8ull; }
 
 }  // namespace bk

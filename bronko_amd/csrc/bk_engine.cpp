@@ -160,7 +160,8 @@ struct bk_engine {
     int k = 0, wstart = 0, W = 0, n_files = 0;
     uint64_t total_cells = 0, n_slots = 0;
     uint32_t log2s = 4, log2nb = 0, m = 1, n_u = 0, n_full = 0, n_lds_bins = 0;
-    uint64_t n_rows = 0;   // V rows (bk_device.h)
+    uint64_t n_prows = 0;  // V rows of the pseudo k-mers (bk_device.h)
+    int v_omin = 0, v_span = 0;
     DevBuf<uint32_t> prow_id;
     DevBuf<uint8_t> prow_t;
     bool ref_in_lds = false;
@@ -170,7 +171,7 @@ struct bk_engine {
     DevBuf<bk::KmerPos> kmer_pos;
     DevBuf<bk::IndexView> d_view;   // device copy of view()
     DevBuf<uint64_t> kmer_of;
-    DevBuf<uint32_t> ref_words, cell_codes, cell_flags, id_at;
+    DevBuf<uint32_t> ref_words, cell_codes, cell_has, cell_clean, cell_yf, cell_yr, id_at;
     struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0; } half_lo, half_hi;
     DevBuf<unsigned int> deferred, n_deferred;
     DevBuf<unsigned int> fin_partials;      // per-workgroup finalize tallies (small genome sets only)
@@ -222,8 +223,8 @@ struct bk_engine {
     bk::IndexView view() const {
         bk::IndexView v{};
         v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb;
-        v.kmer_of = kmer_of.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_flags = cell_flags.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
-        v.n_full = n_full; v.n_rows = n_rows; v.prow_id = prow_id.p; v.prow_t = prow_t.p;
+        v.kmer_of = kmer_of.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
+        v.n_full = n_full; v.n_prows = n_prows; v.prow_id = prow_id.p; v.prow_t = prow_t.p; v.v_omin = v_omin; v.v_span = v_span;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb};
         v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
@@ -460,7 +461,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         const uint64_t cells = e->total_cells;
         std::vector<uint32_t> h_id_at(std::max<uint64_t>(cells, 1), kNone);
         const size_t pad_w = (size_t)bk::scan_ref_pad_words();   // front padding of the two 2-bit arrays
-        std::vector<uint32_t> h_refw(pad_w + (cells + 15) / 16 + 4, 0u), h_brc((cells + 31) / 32 + 1, 0u);
+        std::vector<uint32_t> h_refw(pad_w + (cells + 15) / 16 + (size_t)bk::scan_ref_back_words(), 0u), h_brc((cells + 31) / 32 + 1, 0u);
         uint32_t next_id = 0;
         size_t sq = 0;
         for (int f = 0; f < ix->n_files; f++) {
@@ -491,24 +492,27 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         e->n_full = next_id;
         for (size_t i = 0; i < h_u.size(); i++)   // pseudo k-mers last: they own V rows only where they own a bucket
             if (id_of[i] == kNone) id_of[i] = next_id++;
-        // V rows (bk_device.h): id*W + t for reference k-mers, then the pseudo k-mers' rows in id order
+        // NbEntry::p (bk_device.h): the id of a reference k-mer; n_full + first pseudo V row of a pseudo k-mer (rows in id order)
         std::vector<uint32_t> row_base(h_u.size(), 0u);
+        // with full_kmer_stats the rows keep every offset, so that k-mers differing outside the window are not lost to the statistics
+        e->v_omin = bk::v_layout_omin(k, e->wstart, e->W, prm->full_kmer_stats != 0);
+        e->v_span = bk::v_layout_span(k, e->wstart, e->W, prm->full_kmer_stats != 0);
         {
             std::vector<uint32_t> idx_by_id(h_u.size());
             for (size_t i = 0; i < h_u.size(); i++) idx_by_id[id_of[i]] = (uint32_t)i;
-            uint64_t rows = (uint64_t)e->n_full * e->W;
+            uint64_t rows = 0;
             std::vector<uint32_t> h_prow_id;
             std::vector<uint8_t> h_prow_t;
             for (size_t id = 0; id < h_u.size(); id++) {
                 const uint32_t i = idx_by_id[id];
-                if (id < e->n_full) { row_base[i] = (uint32_t)(id * e->W); continue; }
-                if (rows >= (1ull << 29)) return fail(BK_ERR_UNSUPPORTED, "index too large: variant counter plane exceeds 2^32 counters");
-                row_base[i] = (uint32_t)rows;
+                if (id < e->n_full) { row_base[i] = (uint32_t)id; continue; }
+                row_base[i] = (uint32_t)(e->n_full + rows);
                 for (int t = 0; t < e->W; t++)
                     if ((h_valid[i] >> t) & 1u) { h_prow_id.push_back((uint32_t)id); h_prow_t.push_back((uint8_t)t); rows++; }
+                if (e->n_full + rows >= (1ull << 31)) return fail(BK_ERR_UNSUPPORTED, "index too large: too many pseudo k-mer buckets");
             }
-            if (rows >= (1ull << 29)) return fail(BK_ERR_UNSUPPORTED, "index too large: variant counter plane exceeds 2^32 counters");
-            e->n_rows = rows;
+            e->n_prows = rows;
+            if (bk::v_plane_len(e->n_full, e->v_span, rows) >= (1ull << 32)) return fail(BK_ERR_UNSUPPORTED, "index too large: variant counter plane exceeds 2^32 counters");
             if (h_prow_id.empty()) { h_prow_id.push_back(0); h_prow_t.push_back(0); }
             BK_HIP(e->prow_id.upload(h_prow_id));
             BK_HIP(e->prow_t.upload(h_prow_t));
@@ -548,17 +552,26 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             }
         }
         for (size_t i = 0; i < h_u.size(); i++) if (h_is_pseudo[i]) h_amb[id_of[i]] = 1;
-        std::vector<uint32_t> h_flags((cells + 7) / 8 + 1, 0u);   // bk_device.h cell_flags
-        std::vector<uint32_t> h_codes(h_refw.size(), 0u);           // bk_device.h cell_codes
+        std::vector<uint8_t> rc_of_id(h_u.size(), 0);   // the k-mer's first occurrence was reverse-complemented to become canonical
+        for (size_t i = 0; i < h_u.size(); i++) rc_of_id[id_of[i]] = first_rc[i];
+        std::vector<uint32_t> h_codes(h_refw.size(), 0u), h_yf(h_refw.size(), 0u), h_yr(h_refw.size(), 0u);   // bk_device.h
+        const size_t bpad_w = (size_t)bk::scan_bit_pad_words();
+        std::vector<uint32_t> h_has(bpad_w + (cells + 31) / 32 + (size_t)bk::scan_bit_back_words(), 0u), h_clean(h_has.size(), 0u);
         for (uint64_t c = 0; c < cells; c++) {
             if (h_id_at[c] == kNone) continue;
-            h_codes[pad_w + (c >> 4)] |= (((h_brc[c >> 5] >> (c & 31)) & 1u) ? 2u : 1u) << (2 * (c & 15));
-            uint32_t fl = 0;
-            if (!h_amb[h_id_at[c]]) fl |= 1u;
-            if ((h_brc[c >> 5] >> (c & 31)) & 1u) fl |= 2u;
-            if (c > 0 && h_id_at[c - 1] != kNone && h_id_at[c] == h_id_at[c - 1] + 1) fl |= 4u;
-            if (c + 1 < cells && h_id_at[c + 1] != kNone && h_id_at[c + 1] == h_id_at[c] + 1) fl |= 8u;
-            h_flags[c >> 3] |= fl << (4 * (c & 7));
+            const size_t wi = pad_w + (c >> 4);
+            const int sh = 2 * (int)(c & 15);
+            h_codes[wi] |= (((h_brc[c >> 5] >> (c & 31)) & 1u) ? 2u : 1u) << sh;
+            // clean also promises the orientation of the k-mer's first occurrence (the V layout is built on it): an
+            // occurrence on the other strand of a reverse-complement repeat is resolved by the general path
+            const uint32_t rc_here = (h_brc[c >> 5] >> (c & 31)) & 1u;
+            const uint32_t clean = (h_amb[h_id_at[c]] || rc_here != rc_of_id[h_id_at[c]]) ? 0u : 1u;
+            const bool from_prev = c > 0 && h_id_at[c - 1] != kNone && h_id_at[c] == h_id_at[c - 1] + 1;
+            const bool to_next = c + 1 < cells && h_id_at[c + 1] != kNone && h_id_at[c + 1] == h_id_at[c] + 1;
+            h_has[bpad_w + (c >> 5)] |= 1u << (c & 31);
+            if (clean) h_clean[bpad_w + (c >> 5)] |= 1u << (c & 31);
+            h_yf[wi] |= (clean | (from_prev ? 2u : 0u)) << sh;
+            h_yr[wi] |= (clean | (to_next ? 2u : 0u)) << sh;
         }
 
         // perfect hash over U
@@ -575,10 +588,17 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         BK_HIP(e->kmer_pos.upload(t_pos));
         BK_HIP(e->kmer_of.upload(h_kmer_of));
         BK_HIP(e->ref_words.upload(h_refw));
-        BK_HIP(e->cell_flags.upload(h_flags));
+        BK_HIP(e->cell_has.upload(h_has));
+        BK_HIP(e->cell_clean.upload(h_clean));
+        BK_HIP(e->cell_yf.upload(h_yf));
+        BK_HIP(e->cell_yr.upload(h_yr));
         BK_HIP(e->cell_codes.upload(h_codes));
         BK_HIP(e->id_at.upload(h_id_at));
-        BK_HIP(e->amb.upload(h_amb));
+        {
+            std::vector<uint8_t> h_amb2(h_amb);
+            for (size_t id = 0; id < h_amb2.size(); id++) h_amb2[id] = (h_amb[id] ? 1 : 0) | (rc_of_id[id] ? 2 : 0);
+            BK_HIP(e->amb.upload(h_amb2));
+        }
 
         // half-key directories (neighbour search)
         const int lo_bits = 2 * e->lo_bases;
@@ -596,7 +616,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             std::vector<uint32_t> first, count;
             for (size_t i = 0; i < order.size(); i++) {
                 const uint64_t u = h_u[order[i]];
-                cand[i] = bk::NbEntry{u, row_base[order[i]], h_valid[order[i]]};
+                cand[i] = bk::NbEntry{u, row_base[order[i]], (h_valid[order[i]] & 0x7fffffffu) | (first_rc[order[i]] ? 0x80000000u : 0u)};
                 if (halves.empty() || halves.back() != half_of(u)) { halves.push_back(half_of(u)); first.push_back((uint32_t)i); count.push_back(0); }
                 count.back()++;
             }
@@ -664,7 +684,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     BK_HIP(e->ent_off.upload(h_off));
     BK_HIP(e->ent_len.upload(h_len));
     BK_HIP(e->entries.upload(h_ent));
-    for (int m = 0; m < 2; m++) BK_HIP(e->counters[m].alloc(bk::e_plane_len(e->n_u) + bk::v_plane_len(e->n_rows)));
+    for (int m = 0; m < 2; m++) BK_HIP(e->counters[m].alloc(bk::e_plane_len(e->n_u) + bk::v_plane_len(e->n_full, e->v_span, e->n_prows)));
     if (prm->full_kmer_stats) {
         if (prm->kmer_table_log2 < 10 || prm->kmer_table_log2 > 31) return fail(BK_ERR_INVALID, "kmer_table_log2 out of range");
         BK_HIP(e->ktab_keys.alloc((size_t)1 << prm->kmer_table_log2));
@@ -672,7 +692,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     }
     BK_HIP(e->ktab_out.alloc(8));
     if (e->n_files <= 64) BK_HIP(e->fin_partials.alloc(bk::finalize_partial_rows() * ((size_t)e->n_files * 3 + 2)));
-    BK_HIP(e->deferred.alloc(bk::v_plane_len(e->n_rows)));
+    BK_HIP(e->deferred.alloc(bk::v_plane_len(e->n_full, e->v_span, e->n_prows)));
     BK_HIP(e->n_deferred.alloc(1));
     if (e->n_lds_bins >= e->total_cells) e->use_xcd_planes = false;   // every cell has an LDS bin
     if (e->use_xcd_planes) {
@@ -718,7 +738,7 @@ int bk_engine_set_stream(bk_engine* e, void* hip_stream) {
 uint64_t bk_total_cells(const bk_engine* e) { return e ? e->total_cells : 0; }
 int32_t bk_n_files(const bk_engine* e) { return e ? e->n_files : 0; }
 uint64_t bk_n_slots(const bk_engine* e) { return e ? e->n_slots : 0; }
-uint64_t bk_counter_len(const bk_engine* e) { return e ? bk::e_plane_len(e->n_u) + bk::v_plane_len(e->n_rows) : 0; }
+uint64_t bk_counter_len(const bk_engine* e) { return e ? bk::e_plane_len(e->n_u) + bk::v_plane_len(e->n_full, e->v_span, e->n_prows) : 0; }
 
 int bk_sample_begin(bk_engine* e) {
     if (!e) return fail(BK_ERR_INVALID, "null engine");
@@ -745,8 +765,8 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     bk::ScanArgs a{};
     a.n_records_dev = n_records_dev;
     a.ixp = e->d_view.p;
-    a.k = e->k; a.wstart = e->wstart; a.W = e->W; a.total_cells = (uint32_t)e->total_cells; a.n_u = e->n_u;
-    a.ref_words = e->ref_words.p; a.cell_codes = e->cell_codes.p; a.cell_flags = e->cell_flags.p; a.id_at = e->id_at.p;
+    a.k = e->k; a.wstart = e->wstart; a.W = e->W; a.v_omin = e->v_omin; a.v_span = e->v_span; a.total_cells = (uint32_t)e->total_cells; a.n_u = e->n_u;
+    a.ref_words = e->ref_words.p; a.cell_codes = e->cell_codes.p; a.cell_has = e->cell_has.p; a.cell_clean = e->cell_clean.p; a.cell_yf = e->cell_yf.p; a.cell_yr = e->cell_yr.p; a.id_at = e->id_at.p;
     a.words = d_words; a.lens = d_lens; a.n_records = n; a.stride_words = stride_words;
     a.counters = e->counters[mate].p;
     a.kmer_total = e->kstats.p + mate * 4 + 1;
@@ -769,7 +789,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
         if (e->W > 0) {
             // per-cell bin slabs (and the u32 overflow planes: a batch of < 2^32 k-mers cannot wrap them) -> u64 plane
             bk::FoldArgs f{};
-            f.slabs = e->slabs.p; f.n_slabs = grid; f.n_lds_bins = e->n_lds_bins; f.id_at = e->id_at.p;
+            f.slabs = e->slabs.p; f.n_slabs = grid; f.n_lds_bins = e->n_lds_bins; f.id_at = e->id_at.p; f.cell_codes = e->cell_codes.p + bk::scan_ref_pad_words();
             f.e_planes = a.e_planes; f.n_e = bk::e_plane_len(e->n_u); f.counters = e->counters[mate].p;
             bk_engine::Span sp(e, 3);
             bk::launch_fold(f, e->stream);
@@ -908,6 +928,8 @@ int bk_sample_finalize(bk_engine* e, int n_mates) {
         a.partials = e->fin_partials.p;
         a.deferred = e->deferred.p;
         a.n_deferred = e->n_deferred.p;
+        a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->params.kmer_table_log2;
+        a.ktab_overflow = e->ktab_out.p + 4; a.mate = (uint32_t)m;
         BK_HIP(hipMemsetAsync(e->n_deferred.p, 0, sizeof(unsigned int), e->stream));
         bk_engine::Span sp(e, 1);
         bk::launch_finalize(a, e->stream);

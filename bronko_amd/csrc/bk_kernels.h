@@ -9,11 +9,14 @@ namespace bk {
 struct ScanArgs {
     const IndexView* ixp;           // device copy of the index view: only the rare paths of scan_count read it
     // what the hot path needs (kept in kernel-argument registers)
-    int32_t k, wstart, W;
+    int32_t k, wstart, W, v_omin, v_span;   // v_*: IndexView::v_omin / v_span
     uint32_t total_cells, n_u;
     const uint32_t* ref_words;      // IndexView::ref_words / cell_codes (both with scan_ref_pad_words() words of front padding)
     const uint32_t* cell_codes;
-    const uint32_t* cell_flags;     // IndexView::cell_flags / id_at
+    const uint32_t* cell_has;       // IndexView::cell_has / cell_clean (scan_bit_pad_words() words of front padding)
+    const uint32_t* cell_clean;
+    const uint32_t* cell_yf;        // IndexView::cell_yf / cell_yr (same padding) / id_at
+    const uint32_t* cell_yr;
     const uint32_t* id_at;
     const uint32_t* words;          // [n_records][stride_words] 2-bit packed, 16 bases per word, LSB first
     const uint16_t* lens;           // [n_records] valid bases
@@ -33,7 +36,7 @@ struct ScanArgs {
     uint32_t ktab_log2;
     unsigned long long* ktab_overflow;
     uint32_t mate;
-    int ablate;                     // measurement aid, 0 in production: 1 = Level 1 only (see scan_count_kernel)
+    int ablate;                     // measurement aid, 0 in production: 1 = Level 1 only, 2 = no V atomics, 3 = no slow path
 };
 
 struct FinalizeArgs {
@@ -50,6 +53,12 @@ struct FinalizeArgs {
     int row_exact, row_general;     // first partials row of K2e / K2b (set by launch_finalize)
     unsigned int* deferred;         // [v_plane_len] V counter indices K2a hands to K2b
     unsigned int* n_deferred;       // [1], zeroed before each finalize
+    // full_kmer_stats: k-mers recorded in V rows that cannot touch the index join the statistics table (null = off)
+    unsigned long long* ktab_keys;
+    unsigned int* ktab_cnt;
+    uint32_t ktab_log2;
+    unsigned long long* ktab_overflow;
+    uint32_t mate;
 };
 
 struct FoldArgs {
@@ -57,6 +66,7 @@ struct FoldArgs {
     uint32_t n_slabs;               // = grid of the scan launch
     uint32_t n_lds_bins;
     const uint32_t* id_at;          // cell -> id (bins are per cell)
+    const uint32_t* cell_codes;     // IndexView::cell_codes + its front padding: symbol 0 = cell 0
     unsigned int* e_planes;         // may be null
     uint64_t n_e;                   // 2 * m
     unsigned long long* counters;
@@ -78,6 +88,9 @@ void launch_add_u64(unsigned long long* dst, const unsigned long long* src, hipS
 uint32_t scan_grid(uint64_t n_records, int n_cus);
 uint64_t scan_max_records(uint32_t grid);   // most records one launch_scan_count may be given
 int scan_ref_pad_words();
+int scan_ref_back_words();
+int scan_bit_pad_words();
+int scan_bit_back_words();
 size_t scan_lds_budget();   // bytes available for histogram bins (4 B each) + the staged reference
 size_t scan_ref_lds_bytes(uint32_t total_cells);
 size_t scan_lds_bytes(uint32_t n_lds_bins, bool ref_in_lds, uint32_t total_cells);

@@ -150,14 +150,14 @@ struct KmerTable {
     uint32_t mate;
 };
 
-__device__ __forceinline__ void ktab_insert(const KmerTable& t, uint64_t c, uint32_t isrc) {
+__device__ __forceinline__ void ktab_insert(const KmerTable& t, uint64_t c, uint32_t isrc, unsigned int n) {
     const unsigned long long key = c | ((unsigned long long)isrc << 63) | ((unsigned long long)t.mate << 62);
     const uint32_t mask = (1u << t.log2n) - 1u;   // log2n <= 32 handled by the host (<= 34 uses 64-bit below)
     uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> (64 - t.log2n);
     for (uint32_t probes = 0; probes < 4096; ++probes) {
         const unsigned long long old = atomicCAS(t.keys + h, ~0ull, key);
         if (old == ~0ull || old == key) {
-            if (t.cnt[h] < 0xfffffff0u) atomicAdd(t.cnt + h, 1u);   // saturates far above any -cx
+            if (t.cnt[h] < 0xf0000000u) atomicAdd(t.cnt + h, n);   // saturates far above any -cx
             return;
         }
         h = (h + 1) & (uint64_t)mask;
@@ -197,75 +197,70 @@ void launch_ktab_stats(const unsigned long long* keys, const unsigned int* cnt, 
 }
 
 // ------------------------------------------------------------------------------------------------ K1
-// Persistent workgroups of 16 waves (one per CU: the LDS histogram takes most of the CU's 160 KB); each wave
-// takes tiles of 64 records, one record per lane, and works in two levels.
+// Persistent workgroups of 16 waves (one per CU: the LDS arrays take most of the CU's 160 KB); each wave takes
+// tiles of 64 records, one record per lane.  Nothing is counted k-mer by k-mer unless it has to be.
 //
-// Level 1 -- word-parallel verification along a diagonal.  A read follows the reference, so a few seed k-mers
-// of the read (evenly spaced, looked up in the perfect hash of U) give its diagonal: read k-mer s <-> reference
-// cell a + s (same strand) or a - s (opposite strand).  Then, 16 bases at a time, the read word is XORed with the
-// reference word aligned to it (packed reference in LDS, one funnel shift; reversed and complemented for the
-// opposite strand) and folded to one mismatch flag per base.  The per-base loop only shifts that flag into a
-// k-bit window `dwin`:
-//   dwin == 0 and a reference k-mer starts at the cell (2-bit per-cell code, LDS)   the read k-mer IS that
-//        reference k-mer: one non-returning LDS add on the cell's bin (low half = read as canonical, high half =
-//        as reverse complement; the code says which).  Bins are per CELL, not per k-mer id -- the fast path needs
-//        no ids; fold adds bin c into E[id_at[c]].
-//   anything else                                                                   the k-mer belongs to a "range"
-//        of consecutive non-exact k-mers of this read; when the range ends, (lane, first k-mer, length) goes to
-//        the wave's range queue in LDS.
-// That is ~a dozen VALU instructions per base.  Reads without a usable diagonal (no seed hit, diagonal leaving
-// the reference, cells beyond the LDS bins) become one big range.
+// Level 1 -- word-parallel verification along a diagonal.  A few seed k-mers of the read (evenly spaced, looked
+// up in the perfect hash of U) give its diagonal: read k-mer s <-> reference cell dg + s (same strand) or dg - s
+// (opposite strand).  Then, 16 bases at a time, the read word is XORed with the reference word aligned to it
+// (packed reference in LDS, one funnel shift; reversed and complemented for the opposite strand) and folded to
+// one mismatch flag per base.  A k-step shift-and-or over the flag history says, for the 16 k-mers that end in
+// this word at once, whether their window holds no mismatch, exactly one, or more; with two per-cell bits from
+// LDS ("a reference k-mer starts here", "... and it is clean") every k-mer is
+//   E  exact      no mismatch, a reference k-mer starts at the cell: the read k-mer IS that reference k-mer;
+//   S  simple     one mismatch, the cell is clean: the read k-mer is "that reference k-mer with another base
+//                 at one offset" and (clean) cannot be anything else;
+//   G  general    everything else.
+// Consecutive k-mers of one kind form a run, and a run costs two atomics, whatever its length:
+//   E run   cells c0..c1 each seen once more in this read's direction: +1 at c0, -1 at c1 + 1 in a per-cell
+//           DIFFERENCE array in LDS (low half-word: reads along the reference, high half-word: against it).  The
+//           workgroup turns it into per-cell counts with one prefix sum at the end (epilogue) and writes them as a
+//           slab; fold adds slab cell c into E[id_at[c]] (orientation = the cell's, flipped for the high half).
+//   S run   the k-mers that cover one mismatch: one row of the V plane (bk_device.h), +1 at the first offset, -1
+//           after the last.  Needs the id of the run's first cell (global load), so runs are queued (lane, first
+//           k-mer, length) and done 64 at a time ("S batch", no per-k-mer loop).
+//   G run   queued in chunks of <= k k-mers for Level 2.
+// Reads without a usable diagonal (no seed hit, diagonal leaving the reference, cells beyond the LDS array)
+// become G runs as a whole.
 //
-// Level 2 -- whenever 64 ranges are pending (and at the end), they are processed one per lane with the exact
-// per-k-mer logic: rolling canonical k-mer + 2-bit mismatch mask against the diagonal,
-//   one base differs, cell "clean"  clean = no reference k-mer of either strand within Hamming distance 2 (host
-//                                   precomputed).  Then the read k-mer is provably not a reference k-mer and the
-//                                   reference k-mer here is its only possible neighbour: if both have the same
-//                                   canonical orientation and the differing base lies in the window, its V
-//                                   counter is known on the spot (one fire-and-forget global atomic); otherwise
-//                                   it touches nothing.
-//   anything else                   (no diagonal, several errors within one k-mer, strain-specific or repetitive
-//                                   neighbourhoods, sequence ends): perfect-hash membership test when the lane has
-//                                   no diagonal (a hit re-seeds it), else the asynchronous slow pipeline.
-// Level 2 only ever sees the k-mers Level 1 could not prove exact (~one in eight at 0.5 % error), densely packed:
-// every lane of the wave has work, which the per-base divergent branches of a one-level design cannot offer.
+// Level 2 ("G batch") -- one queued chunk per lane, the exact per-k-mer logic: rolling canonical k-mer + 2-bit
+// difference mask along the diagonal (both pre-aligned word-parallel, so a step is pure ALU).  A k-mer with one
+// difference at a clean cell of known id is a single-k-mer S run (+1 / -1 in its V row); everything else goes
+// to the slow path.
 //
-// Slow path -- k-mers not resolved on the diagonal are compacted (ballot + prefix popcount) into a per-wave LDS
-// queue; whenever 64 are pending they become a batch of the SlowPipe (one k-mer per lane), which looks up the
-// neighbours of each and adds to the V counter of the smallest (position, V row) while Level 2 keeps going.
+// Slow path -- compacted (ballot + prefix popcount) into a per-wave LDS queue; batches of the SlowPipe (one k-mer
+// per lane): perfect-hash membership test (a hit is an E count after all), then the neighbour search over the two
+// half-k-mer directories and a +1 / -1 in the V row of the smallest (position, NbEntry::p).
 //
-// LDS bins: one 32-bit word per cell, two 16-bit halves.  Level 1 adds without looking at the result; a launch
-// gives a workgroup at most kMaxRecordsPerGroup records and a record hits a (cell, half) at most once on its
-// diagonal, so Level 1 adds at most 0x4000 per launch to a half.  Every other add (Level 2, slow path) is a
-// returning add that moves 0x2000 to the u64 plane (compare-and-swap) whenever it sees the half at or above
-// 0x2000.  Hence a half stays below 0x2000 + 0x4000 + (adds in flight) < 0x8000 and can never carry into its
-// neighbour, whatever the input (millions of identical k-mers included).  At the end the bins are written as one
-// coalesced slab per workgroup; fold adds the slabs into the u64 plane.
+// LDS difference array: one 32-bit word per cell, value = (runs starting - runs ending) of reads along the
+// reference + 65536 * the same for reads against it, modulo 2^32.  The prefix sum S_c = F_c + 65536 R_c is exact
+// as long as both counts stay below 65536: a launch gives a workgroup at most kMaxRecordsPerGroup records, a
+// record covers a cell at most once on its diagonal, and the slow path's point updates are limited to
+// kSlowLdsQuota per wave (beyond that they go to the E plane directly).
 //
-// Cells beyond the LDS bins (large multi-genome indexes) are counted by Level 2 with workgroup-scope (non-sc1)
-// atomics in a u32 plane private to the XCD the workgroup runs on (HW_REG_XCC_ID, read at run time, so nothing
-// depends on how workgroups are placed); fold adds the planes up afterwards.  A reference too large for LDS is
-// read from global memory instead (REF_LDS = false).
+// Cells beyond the LDS array (large multi-genome indexes) are counted with workgroup-scope (non-sc1) atomics in
+// a u32 plane private to the XCD the workgroup runs on (HW_REG_XCC_ID, read at run time, so nothing depends on
+// how workgroups are placed); fold adds the planes up afterwards.  A reference too large for LDS is read from
+// global memory instead (REF_LDS = false).
 constexpr int kScanBlock = 1024;
 constexpr int kScanWaves = kScanBlock / 64;
-constexpr int kQueueCap = 128;
-constexpr int kRangeCap = 128;
-constexpr int kMaxRangeLen = 1023;          // 10 bits of a range entry
+constexpr int kQueueCap = 96;               // slow-path queue: a batch starts at 32 pending, a step adds <= 64
+constexpr int kRangeCap = 128;              // S and G queues: a batch starts at 64 pending, a round adds <= 64
 constexpr uint32_t kMaxRecordsPerGroup = 16384;
-constexpr uint32_t kSpillAt = 0x2000u;
+constexpr uint32_t kSlowLdsQuota = 2048;    // per wave and launch: slow-path E hits that may use the LDS array
 constexpr int kSeeds = 4;
-constexpr int kRefPadWords = 3;             // words of padding in front of ref_words / cell_codes (48 cells)
-constexpr size_t kQueueBytes = (size_t)kScanWaves * kQueueCap * (sizeof(unsigned long long) + 1);
+constexpr int kRefPadWords = 4;             // words of padding in front of the 2-bit per-cell arrays (64 cells)
+constexpr int kRefBackWords = 6;            // ... and behind them (96 cells)
+constexpr int kBitPadWords = 2;             // the same 64 cells for the 1-bit per-cell arrays
+constexpr int kBitBackWords = 3;
+constexpr size_t kQueueBytes = (size_t)kScanWaves * kQueueCap * sizeof(unsigned long long);
 constexpr size_t kRangeBytes = (size_t)kScanWaves * kRangeCap * sizeof(unsigned int);
-constexpr size_t kScanLdsFixed = kQueueBytes + kRangeBytes + 16;
-
-struct QueueView { unsigned long long* c; unsigned char* meta; };
+constexpr size_t kScanLdsFixed = kQueueBytes + 2 * kRangeBytes + 16 + 64;
 
 // number of set bits of a wave mask below this lane
 __device__ __forceinline__ uint32_t lane_prefix(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
-
 // reverse the order of the sixteen 2-bit groups of a word
 __device__ __forceinline__ uint32_t rev2_32(uint32_t x) {
     const uint32_t t = __builtin_bitreverse32(x);
@@ -273,6 +268,14 @@ __device__ __forceinline__ uint32_t rev2_32(uint32_t x) {
 }
 __device__ __forceinline__ uint64_t rev2_64(uint64_t x) {
     return ((uint64_t)rev2_32((uint32_t)x) << 32) | rev2_32((uint32_t)(x >> 32));
+}
+// the even bits of a word, packed
+__device__ __forceinline__ uint32_t even_bits(uint32_t x) {
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0f0f0f0fu;
+    x = (x | (x >> 4)) & 0x00ff00ffu;
+    return (x | (x >> 8)) & 0xffffu;
 }
 // 32 consecutive 2-bit symbols starting at symbol `pos` of a packed array (16 per word, LSB first); the caller
 // guarantees words [pos/16, pos/16 + 2] exist
@@ -291,13 +294,27 @@ __device__ __forceinline__ uint64_t read_symbols_at(const uint32_t* __restrict__
     const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
     return ((uint64_t)hi << 32) | lo;
 }
+// 16 bits of a 1-bit-per-cell array starting at cell `pos`
+__device__ __forceinline__ uint32_t bits16_at(const uint32_t* __restrict__ w, int32_t pos) {
+    return __builtin_amdgcn_alignbit(w[(pos >> 5) + 1], w[pos >> 5], (uint32_t)pos & 31u) & 0xffffu;
+}
+
+// +1 on "reference k-mer id with base b (forward strand of the reference) at offset o, read in direction d": a
+// single-k-mer run of its V row
+__device__ __forceinline__ void v_point(unsigned long long* __restrict__ v_counters, uint32_t id, uint32_t o, uint32_t b, uint32_t d,
+                                        int omin, int span) {
+    const uint32_t oo = o - (uint32_t)omin;
+    if (oo >= (uint32_t)span) return;   // offsets outside the layout touch no window bucket
+    unsigned long long* row = v_counters + v_row_base(id + oo, b, d, span) + oo;
+    atomicAdd(row, 1ull);
+    atomicAdd(row + 1, ~0ull);
+}
 
 // The slow path as a software pipeline.  A batch of up to 64 queued k-mers (one per lane) advances one stage per
 // k-mer step of Level 2: stage 1 has the three pilots in flight (reference k-mer set, low half, high half),
 // stage 2 the perfect-hash entry and the two directory entries, stage 3 the first candidate of each list (unless
 // the k-mer turned out to be a reference k-mer: then it is counted and done); stage 4 resolves the V counter
-// and issues the atomic.  Each stage only *issues* its loads; they are consumed one step later, so the
-// slow path's memory latency hides behind Level 2's work instead of stalling the wave.
+// and issues the atomics.  Each stage only *issues* its loads; they are consumed one step later.
 struct SlowPipe {
     int stage = 0;          // wave-uniform: 0 = empty
     bool have = false;      // this lane holds a k-mer of the batch
@@ -310,12 +327,13 @@ struct SlowPipe {
     //   after stage 3: b0 = first low candidate, b1 = first high candidate, b2 = {low off, low cnt, high off, high cnt}
     uint4 b0{}, b1{}, b2{};
 
-    __device__ __forceinline__ void start(const QueueView& q, uint32_t n, int lane, const IndexView& ix) {
+    // queue entry: canonical k-mer | orientation << 62 | stat_only << 63
+    __device__ __forceinline__ void start(const unsigned long long* q, uint32_t n, int lane, const IndexView& ix) {
         have = (uint32_t)lane < n;
-        c = have ? q.c[lane] : 0ull;
-        const uint32_t meta = have ? q.meta[lane] : 0u;
-        isrc = meta & 1u;
-        stat_only = (meta & 2u) != 0;
+        const unsigned long long e = have ? q[lane] : 0ull;
+        c = e & 0x3fffffffffffffffull;
+        isrc = (uint32_t)(e >> 62) & 1u;
+        stat_only = (e >> 63) != 0;
         const int lo_bits = 2 * ix.lo_bases;
         const uint64_t lo = c & ((1ull << lo_bits) - 1ull), hi = c >> lo_bits;
         b0.x = ix.pilots[phf_bucket(c, ix.log2nb)];
@@ -336,10 +354,9 @@ struct SlowPipe {
             b2 = *reinterpret_cast<const uint4*>(ix.hi.dir + phf_pos(hi, ph, ix.hi.m));
             stage = 2;
         } else if (stage == 2) {
-            if (have && !stat_only && ((uint64_t)b0.x | ((uint64_t)b0.y << 32)) == c) {   // a reference k-mer after all
-                count_exact(b0.z, b0.w & kIdMask, isrc);
-                have = false;
-            }
+            const bool member = have && !stat_only && ((uint64_t)b0.x | ((uint64_t)b0.y << 32)) == c;   // a reference k-mer after all
+            count_exact(member, b0.z, b0.w & kIdMask, isrc, b0.w >> 31);
+            if (member) have = false;
             const uint32_t cnt_lo = (have && !stat_only && b1.x == (uint32_t)lo) ? b1.z : 0u;
             const uint32_t cnt_hi = (have && !stat_only && b2.x == (uint32_t)hi) ? b2.z : 0u;
             const uint32_t off_lo = b1.y, off_hi = b2.y;
@@ -350,12 +367,13 @@ struct SlowPipe {
         } else if (stage == 3) {
             const int k = ix.k, wlo = ix.wstart, whi = ix.wstart + ix.W;
             const uint32_t off_lo = b2.x, cnt_lo = b2.y, off_hi = b2.z, cnt_hi = b2.w;
-            uint64_t best = ~0ull;   // (j << 32) | V row, smallest wins
+            uint64_t best = ~0ull;   // (j << 32) | NbEntry::p, smallest wins
+            uint32_t bvalid = 0;
             auto consider = [&](const uint4& e) {
                 const int j = single_diff_pos((uint64_t)e.x | ((uint64_t)e.y << 32), c, k);
                 if (j >= wlo && j < whi && ((e.w >> (j - wlo)) & 1u)) {   // the neighbour owns a bucket at j
-                    const uint64_t key = ((uint64_t)j << 32) | (e.z + (uint32_t)__popc(e.w & ((1u << (j - wlo)) - 1u)));
-                    if (key < best) best = key;
+                    const uint64_t key = ((uint64_t)j << 32) | e.z;
+                    if (key < best) { best = key; bvalid = e.w; }
                 }
             };
             if (cnt_lo) consider(b0);
@@ -364,11 +382,18 @@ struct SlowPipe {
             for (uint32_t i = 1; i < cnt_hi; ++i) consider(*reinterpret_cast<const uint4*>(ix.hi.cand + off_hi + i));   // rare
             if (best != ~0ull) {
                 const int j = (int)(best >> 32);
-                const uint32_t row = (uint32_t)best;
-                const uint32_t b = (uint32_t)(c >> (2 * (k - 1 - j))) & 3u;
-                atomicAdd(v_counters + ((uint64_t)row * 4 + b) * 2 + isrc, 1ull);
+                const uint32_t p = (uint32_t)best;
+                const uint32_t b = (uint32_t)(c >> (2 * (k - 1 - j))) & 3u;   // base of the canonical k-mer at j
+                if (p < ix.n_full) {
+                    // in reference coordinates: offset from the k-mer's start, base on the forward strand, read direction
+                    const uint32_t rcu = bvalid >> 31;
+                    v_point(v_counters, p, (uint32_t)(rcu ? k - 1 - j : j), rcu ? 3u - b : b, isrc ^ rcu, ix.v_omin, ix.v_span);
+                } else {
+                    const uint32_t row = p - ix.n_full + (uint32_t)__popc(bvalid & ((1u << (j - wlo)) - 1u));
+                    atomicAdd(v_counters + v_real_len(ix.n_full, ix.v_span) + ((uint64_t)row * 4 + b) * 2 + isrc, 1ull);
+                }
             } else if (have && kt.keys) {
-                ktab_insert(kt, c, isrc);   // touches no window bucket: only KMC's distinct / counted totals see it
+                ktab_insert(kt, c, isrc, 1u);   // touches no window bucket: only KMC's distinct / counted totals see it
             }
             stage = 0;
         }
@@ -385,74 +410,75 @@ template <bool REF_LDS, bool STATS>
 __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* queue_c = reinterpret_cast<unsigned long long*>(smem);
-    unsigned char* queue_m = smem + (size_t)kScanWaves * kQueueCap * sizeof(unsigned long long);
-    unsigned int* range_q = reinterpret_cast<unsigned int*>(smem + kQueueBytes);
-    unsigned int* block_kmers = reinterpret_cast<unsigned int*>(smem + kQueueBytes + kRangeBytes);   // 16 B reserved
-    unsigned int* bins = block_kmers + 4;
-    unsigned int* lds_ref = bins + a.n_lds_bins;   // REF_LDS: padded ref words, then the padded per-cell codes
+    unsigned int* range_s = reinterpret_cast<unsigned int*>(smem + kQueueBytes);
+    unsigned int* range_g = reinterpret_cast<unsigned int*>(smem + kQueueBytes + kRangeBytes);
+    unsigned int* block_kmers = reinterpret_cast<unsigned int*>(smem + kQueueBytes + 2 * kRangeBytes);   // 16 B reserved
+    unsigned int* scan_tmp = block_kmers + 4;       // 16 words: wave totals of the epilogue's prefix sum
+    unsigned int* bins = scan_tmp + 16;             // [n_lds_bins + 1] the per-cell difference array
+    unsigned int* lds_ref = bins + a.n_lds_bins + 1;   // REF_LDS: padded ref words, then the two padded bit arrays
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform by construction: tell the compiler
-    const QueueView q{queue_c + wave * kQueueCap, queue_m + wave * kQueueCap};
-    unsigned int* const rq = range_q + wave * kRangeCap;
+    unsigned long long* const q = queue_c + wave * kQueueCap;
+    unsigned int* const rqs = range_s + wave * kRangeCap;
+    unsigned int* const rqg = range_g + wave * kRangeCap;
 
     const uint32_t total = a.total_cells;
-    const uint32_t n_refw = kRefPadWords + (total + 15) / 16 + 4;   // both arrays: front pad, cells, >= k cells of back pad
-    for (uint32_t i = threadIdx.x; i < a.n_lds_bins; i += kScanBlock) bins[i] = 0u;
+    const uint32_t n_refw = kRefPadWords + (total + 15) / 16 + kRefBackWords;   // 2-bit arrays: front pad, cells, back pad
+    const uint32_t n_bitw = kBitPadWords + (total + 31) / 32 + kBitBackWords;   // 1-bit arrays
+    for (uint32_t i = threadIdx.x; i <= a.n_lds_bins; i += kScanBlock) bins[i] = 0u;
     if (REF_LDS) {
-        for (uint32_t i = threadIdx.x; i < n_refw; i += kScanBlock) { lds_ref[i] = a.ref_words[i]; lds_ref[n_refw + i] = a.cell_codes[i]; }
+        for (uint32_t i = threadIdx.x; i < n_refw; i += kScanBlock) lds_ref[i] = a.ref_words[i];
+        for (uint32_t i = threadIdx.x; i < n_bitw; i += kScanBlock) { lds_ref[n_refw + i] = a.cell_has[i]; lds_ref[n_refw + n_bitw + i] = a.cell_clean[i]; }
     }
     __syncthreads();
-    // symbol 0 of both arrays is cell 0; negative symbol positions down to -48 are readable padding
+    // symbol / bit 0 of the per-cell arrays is cell 0; negative positions down to -64 are readable padding
     const unsigned int* refw = (REF_LDS ? lds_ref : a.ref_words) + kRefPadWords;
-    const unsigned int* codew = (REF_LDS ? lds_ref + n_refw : a.cell_codes) + kRefPadWords;
-    const unsigned int* cflags = a.cell_flags;   // Level 2 only: 4 flag bits per cell, global memory (L1 / L2 cached)
+    const unsigned int* hasw = (REF_LDS ? lds_ref + n_refw : a.cell_has) + kBitPadWords;
+    const unsigned int* cleanw = (REF_LDS ? lds_ref + n_refw + n_bitw : a.cell_clean) + kBitPadWords;
+    const unsigned int* yfw = a.cell_yf + kRefPadWords;   // batches only (global memory, L1 / L2 cached)
+    const unsigned int* yrw = a.cell_yr + kRefPadWords;
 
     const int k = a.k;
-    const uint32_t W = (uint32_t)a.W;
-    const int wlo = a.wstart, whi = a.wstart + a.W;
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;  // k <= 31
     // 2k-bit values are kept as explicit 32-bit halves: 64-bit shifts and compares are slow-rate VALU ops
     const uint32_t kmask_lo = (uint32_t)kmask, kmask_hi = (uint32_t)(kmask >> 32);
-    const uint32_t kmask1 = (uint32_t)((1ull << k) - 1ull);   // one flag per base of a k-mer
     const int rcshift = 2 * (k - 1);
     const uint32_t rc_sh = (uint32_t)rcshift & 31u;
     const uint32_t rc_in_hi = rcshift >= 32 ? 0xffffffffu : 0u;   // which half receives the new complemented base
     const uint32_t km1 = (uint32_t)k - 1u;
+    const uint32_t chunk = (uint32_t)k;                             // most k-mers one Level-2 lane takes
+    const int omin = a.v_omin, span = a.v_span;
     const uint64_t n_e = e_plane_len(a.n_u);
     unsigned int* const e_local = a.e_planes ? a.e_planes + (size_t)xcc_id() * n_e : nullptr;
     unsigned long long* const v_counters = a.counters + n_e;
     const uint32_t last_word = a.stride_words - 1u;
+    uint32_t slow_lds = 0;   // wave-uniform: slow-path E hits this wave has put into the LDS array
 
-    // +1 on the E counter of reference k-mer `id` (first occurrence at `cell`) read in orientation `isrc`: Level 2 and
-    // the slow path (returning add + spill, see the header comment)
-    auto count_exact = [&](uint32_t cell, uint32_t id, uint32_t isrc) {
-        if (cell < a.n_lds_bins) {
-            const unsigned int old = atomicAdd(&bins[cell], isrc ? 0x10000u : 1u);
-            if (((isrc ? old >> 16 : old) & 0xffffu) >= kSpillAt) {
-                unsigned int cur = __hip_atomic_load(&bins[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                for (;;) {
-                    if (((isrc ? cur >> 16 : cur) & 0xffffu) < kSpillAt) break;   // somebody else moved it
-                    const unsigned int prev = atomicCAS(&bins[cell], cur, cur - (isrc ? (kSpillAt << 16) : kSpillAt));
-                    if (prev == cur) { atomicAdd(a.counters + 2 * (size_t)id + isrc, (unsigned long long)kSpillAt); break; }
-                    cur = prev;
-                }
-            }
+    // slow path: +1 on the E counter of reference k-mer `id` (first occurrence at `cell`, reverse-complemented there iff
+    // rc_first) read in orientation `isrc`.  Called by the whole wave (`hit` = this lane has one).
+    auto count_exact = [&](bool hit, uint32_t cell, uint32_t id, uint32_t isrc, uint32_t rc_first) {
+        const unsigned long long hm = __ballot(hit);
+        if (!hm) return;
+        const bool room = slow_lds + 64u <= kSlowLdsQuota;   // wave-uniform
+        if (room) slow_lds += (uint32_t)__popcll(hm);
+        if (!hit) return;
+        if (room && cell < a.n_lds_bins) {
+            // a single-cell run in the direction the read has relative to the reference there
+            const unsigned int inc = (isrc ^ rc_first) ? 0x10000u : 1u;
+            __hip_atomic_fetch_add(&bins[cell], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&bins[cell + 1], 0u - inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else if (e_local) {
             __hip_atomic_fetch_add(e_local + 2 * (size_t)id + isrc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
             atomicAdd(a.counters + 2 * (size_t)id + isrc, 1ull);
         }
     };
-    // +1 on the V counter of "reference k-mer id with base bb at canonical position j" (reference k-mers: V row = id*W + t)
-    auto count_variant = [&](uint32_t id, int j, uint32_t bb, uint32_t isrc) {
-        atomicAdd(v_counters + (((uint64_t)id * W + (uint32_t)(j - wlo)) * 4 + bb) * 2 + isrc, 1ull);   // fire and forget
-    };
 
     const KmerTable kt{STATS ? a.ktab_keys : nullptr, a.ktab_cnt, a.ktab_log2, a.ktab_overflow, a.mate};   // STATS = full_kmer_stats
     uint32_t nkm = 0;  // k-mer occurrences of this lane's records
     uint32_t qn = 0;   // wave-uniform fill of the slow-path queue
-    uint32_t qr = 0;   // wave-uniform fill of the range queue
+    uint32_t qs = 0, qg = 0;   // wave-uniform fill of the S and G run queues
     SlowPipe pipe;
     const IndexView& ix = *a.ixp;
 
@@ -464,22 +490,34 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     const uint32_t* const words0 = a.words + a.rec_base * a.stride_words;
     const uint16_t* const lens0 = a.lens + a.rec_base;
     const uint64_t n_tiles = (n_records + 63) / 64;
-    for (uint64_t tile = (uint64_t)blockIdx.x * kScanWaves + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * kScanWaves) {
+
+    // per-lane state of the current and of the previous tile (queued runs name their record by lane and tile parity)
+    uint32_t r32 = 0, pr32 = 0;         // record index within this launch (a launch has < 2^32 records)
+    int32_t dg = 0, pdg = 0;            // cell of the reference k-mer aligned with read k-mer 0: k-mer s <-> dg + s (fwd) / dg - s
+    uint32_t dfl = 0, pdfl = 0;         // bit 0: same strand as the reference; bit 1: the diagonal is known ("seeded")
+    uint32_t parity = 0;                // wave-uniform: parity of the current tile
+    uint32_t olds = 0, oldg = 0;        // wave-uniform: queued runs that belong to the previous tile (they are at the front)
+
+    for (uint64_t tile = (uint64_t)blockIdx.x * kScanWaves + wave;; tile += (uint64_t)gridDim.x * kScanWaves) {
+        const bool fin = tile >= n_tiles;   // one empty tile after the last: it flushes the queues
+        pr32 = r32; pdg = dg; pdfl = dfl;
+        parity ^= 1u;
+        olds = qs; oldg = qg;
         const uint64_t r = tile * 64 + lane;
-        const bool live = r < n_records;
-        uint32_t len = live ? (uint32_t)lens0[r] : 0u;
+        const bool live = !fin && r < n_records;
+        r32 = live ? (uint32_t)r : 0u;
+        uint32_t len = live ? (uint32_t)lens0[r32] : 0u;
         if (len < (uint32_t)k) len = 0u;   // no k-mer
         uint32_t maxlen = len;
 #pragma unroll
         for (int off = 32; off; off >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, off));
         maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxlen);
-        const uint32_t* __restrict__ w = words0 + (live ? r : 0) * a.stride_words;
+        const uint32_t* __restrict__ w = words0 + (uint64_t)r32 * a.stride_words;
         nkm += len ? len - km1 : 0u;
 
         // ---- seeds -> diagonal ----------------------------------------------------------------------------------
-        // dg: cell of the reference k-mer aligned with read k-mer 0; read k-mer s <-> cell dg + s (fwd) / dg - s
-        int32_t dg = 0;
-        bool fwd = true, seeded = false, l1ok = false;   // seeded: diagonal known; l1ok: ... and all its cells have LDS bins
+        bool fwd = true, seeded = false, l1ok = false;   // seeded: diagonal known; l1ok: ... and all its cells are in the LDS array
+        dg = 0;
         if (maxlen) {
             uint64_t sc[kSeeds];
             uint32_t sisrc[kSeeds], spil[kSeeds];
@@ -501,12 +539,12 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 const uint4 e = *reinterpret_cast<const uint4*>(ix.kmer_pos + phf_pos(sc[sq], spil[sq], ix.m));
                 if (len && ((uint64_t)e.x | ((uint64_t)e.y << 32)) == sc[sq] && e.z < best_cell) {
                     // several seeds may hit (usually all, on one diagonal); prefer the lowest cell: in a multi-genome
-                    // index that is the first genome, whose cells have the LDS bins
+                    // index that is the first genome, whose cells are the ones in LDS
                     const bool f = sisrc[sq] == (e.w >> 31);   // same strand as the reference?
                     const int64_t d0 = f ? (int64_t)e.z - (int64_t)s : (int64_t)e.z + (int64_t)s;
                     const int64_t lo_cell = f ? d0 : d0 - (int64_t)(len - (uint32_t)k);
                     const int64_t hi_cell = f ? d0 + (int64_t)(len - (uint32_t)k) : d0;
-                    // the whole read must lie on the reference (hi_cell + k <= total); Level 1 also needs its cells in the LDS bins
+                    // the whole read must lie on the reference (hi_cell + k <= total); Level 1 also needs its cells in LDS
                     if (lo_cell >= 0 && hi_cell + k <= (int64_t)total) {
                         best_cell = e.z; dg = (int32_t)d0; fwd = f; seeded = true;
                         l1ok = hi_cell < (int64_t)a.n_lds_bins;
@@ -514,289 +552,324 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 }
             }
         }
+        dfl = (fwd ? 1u : 0u) | (seeded ? 2u : 0u);
 
-        // ---- Level 1 / Level 2 state machine (all control flow wave-uniform) --------------------------------------
-        uint32_t i = 0;                 // base index of the next Level-1 step
-        uint32_t x = 0, Mw = 0, Zc = 0; // current read word (unused bases), its mismatch flags, the aligned cell codes
-        uint32_t dwin = 0xffffffffu;    // mismatch flags of the last k bases
-        uint32_t run_start = 0;         // first k-mer of the lane's open range
-        bool inrun = false;             // the lane has an open range
-        // LDS byte offset (within bins) of the cell of the k-mer that ends at base i: starts k-1 steps "before" cell dg
-        uint32_t bin_off = (uint32_t)((fwd ? dg - (int32_t)km1 : dg + (int32_t)km1) * 4);
-        const uint32_t bin_step = fwd ? 4u : (uint32_t)-4;
-        int phase = maxlen ? 0 : 2;     // 0 = stepping, 1 = close the open ranges, 2 = Level 1 done for this tile
+        // ---- Level 1 / batches: a state machine, all control flow wave-uniform --------------------------------------
+        uint32_t i0 = 0;                // first base of the next Level-1 word
+        uint32_t xn = len ? w[0] : 0u;  // the next read word (loaded a word ahead)
+        uint32_t h_lo = 0xffffffffu, h_hi = 0xffffffffu;   // mismatch flags of the last 64 bases, newest word in the top 16 bits
+        uint32_t run_start = 0;         // first k-mer of the lane's open run
+        uint32_t run_type = 0;          // its kind: 0 none, 1 E, 2 S, 3 G
+        uint32_t pe = 0, ps = 0, pg = 0;   // kind bits of the last k-mer of the previous word (bit 0)
+        uint32_t E16 = 0, S16 = 0, G16 = 0, Bd = 0;   // last word: kind of the k-mer of each step, steps where a new run starts
+        uint32_t tw_i0 = 0;             // wave-uniform: first base of that word
+        bool pend = false;              // wave-uniform: some lane still has run boundaries to process
+        bool words_done = maxlen == 0u;
         for (;;) {
-            if (qr >= 64u || (phase == 2 && qr)) {
-                // ================= Level 2: one queued range per lane ==============================================
-                const uint32_t nb2 = min(qr, 64u);
-                const uint32_t ent = (uint32_t)lane < nb2 ? rq[lane] : 0u;
+            const bool flush = !pend && words_done;
+            if (qg >= 64u || (flush && (fin ? qg != 0u : oldg != 0u))) {
+                // ================= Level 2 ("G batch"): one queued chunk (<= k k-mers) per lane ==================
+                const uint32_t nb2 = min(qg, 64u);
+                const uint32_t ent = (uint32_t)lane < nb2 ? rqg[lane] : 0u;
                 {   // move the rest of the queue down
-                    const uint32_t rest = qr - nb2;
-                    const uint32_t t = (uint32_t)lane < rest ? rq[64 + lane] : 0u;
+                    const uint32_t rest = qg - nb2;
+                    const uint32_t t = (uint32_t)lane < rest ? rqg[64 + lane] : 0u;
                     __builtin_amdgcn_wave_barrier();
-                    if ((uint32_t)lane < rest) rq[lane] = t;
+                    if ((uint32_t)lane < rest) rqg[lane] = t;
                     __builtin_amdgcn_wave_barrier();
-                    qr = rest;
+                    qg = rest;
+                    oldg = oldg > nb2 ? oldg - nb2 : 0u;
                 }
                 if (a.ablate == 1) continue;   // measurement aid: Level 1 alone (incomplete counts)
                 const int src = (int)(ent & 63u);
                 const uint32_t s_first = (ent >> 6) & 0xffffu;
-                const uint32_t n2 = (uint32_t)lane < nb2 ? ent >> 22 : 0u;
-                const int32_t dg2 = __shfl(dg, src);
-                const bool fwd2 = __shfl((int)fwd, src) != 0;
-                const bool seeded2 = __shfl((int)seeded, src) != 0 && n2;
-                const uint32_t r_lo = (uint32_t)__shfl((int)(uint32_t)r, src), r_hi = (uint32_t)__shfl((int)(uint32_t)(r >> 32), src);
-                const uint32_t* __restrict__ w2 = words0 + (n2 ? (((uint64_t)r_hi << 32) | r_lo) : 0ull) * a.stride_words;
+                const uint32_t n2 = (uint32_t)lane < nb2 ? (ent >> 22) & 63u : 0u;
+                const bool cur = ((ent >> 28) & 1u) == parity;
+                const int32_t dg_c = __shfl(dg, src), dg_p = __shfl(pdg, src);
+                const uint32_t fl_c = (uint32_t)__shfl((int)dfl, src), fl_p = (uint32_t)__shfl((int)pdfl, src);
+                const uint32_t r_c = (uint32_t)__shfl((int)r32, src), r_p = (uint32_t)__shfl((int)pr32, src);
+                const int32_t dg2 = cur ? dg_c : dg_p;
+                const uint32_t fl2 = cur ? fl_c : fl_p;
+                const bool fwd2 = fl2 & 1u;
+                const bool seeded2 = (fl2 & 2u) && n2;
+                const uint32_t* __restrict__ w2 = words0 + (uint64_t)(n2 ? (cur ? r_c : r_p) : 0u) * a.stride_words;
                 uint32_t nmax = n2;
 #pragma unroll
                 for (int off = 32; off; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off));
                 nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
 
-                // prime the rolling k-mers and the mismatch mask with the k-1 bases [s_first, s_first + k - 1)
+                // 64 read bases from s_first on (the chunk needs at most chunk + k - 1 <= 61 of them)
+                const uint64_t ga = read_symbols_at(w2, s_first, last_word), gb = read_symbols_at(w2, s_first + 32u, last_word);
+                // rolling k-mers primed with the k-1 bases [s_first, s_first + k - 1)
                 const int kp = k - 1;
                 const uint64_t pmask = (1ull << (2 * kp)) - 1ull;
-                const uint64_t g = read_symbols_at(w2, s_first, last_word) & pmask;
+                const uint64_t g = ga & pmask;
                 const uint64_t f0 = kp ? rev2_64(g) >> (64 - 2 * kp) : 0ull;
                 const uint64_t r0 = (~g & pmask) << 2;
                 uint32_t f_lo = (uint32_t)f0, f_hi = (uint32_t)(f0 >> 32), r_lo2 = (uint32_t)r0, r_hi2 = (uint32_t)(r0 >> 32);
-                uint32_t d_lo = 0, d_hi = 0;
-                const uint32_t ddir = fwd2 ? 1u : 0xffffffffu;
-                // cellc: cell of the reference k-mer the current read k-mer is aligned with (>= total: no diagonal)
-                uint32_t cellc = 0xffffffffu;
-                if (seeded2) {
-                    cellc = (uint32_t)(fwd2 ? dg2 + (int32_t)s_first : dg2 - (int32_t)s_first);
-                    // reference bases as the read sees them, aligned with read bases s_first .. s_first + k - 2
-                    uint64_t gref;
-                    if (fwd2) gref = symbols_at(refw, (int32_t)cellc);
-                    else gref = kp ? (~rev2_64(symbols_at(refw, (int32_t)cellc + 1))) >> (64 - 2 * kp) : 0ull;
-                    const uint64_t gx = (g ^ gref) & pmask;
-                    const uint64_t d0 = kp ? rev2_64(gx) >> (64 - 2 * kp) : 0ull;
-                    d_lo = (uint32_t)d0; d_hi = (uint32_t)(d0 >> 32);
-                }
-                uint32_t ddir2 = ddir, id = 0, bad = 0;
+                // along the diagonal: base differences with the reference as the read sees it, and the clean / follow bits of
+                // the <= 32 cells of the chunk, all in step order
+                uint64_t da = 0, db = 0, yc = 0;
+                uint32_t d_lo = 0, d_hi = 0, id = 0;
                 bool id_ok = false;
-                // base stream: xw = unused bases of the current word, xn = the next word (loaded a word ahead)
-                uint32_t bi = s_first + km1;
-                uint32_t xw = w2[min(bi >> 4, last_word)] >> (2u * (bi & 15u));
-                uint32_t xn = w2[min((bi >> 4) + 1u, last_word)];
+                const uint32_t ddir = fwd2 ? 1u : 0xffffffffu;
+                if (seeded2) {
+                    const int32_t c_first = fwd2 ? dg2 + (int32_t)s_first : dg2 - (int32_t)s_first;   // cell of the chunk's first k-mer
+                    uint64_t ra, rb;
+                    if (fwd2) {
+                        ra = symbols_at(refw, c_first); rb = symbols_at(refw, c_first + 32);
+                        yc = symbols_at(yfw, c_first);
+                    } else {
+                        // read base s_first + t <-> complement of reference base c_first + k - 1 - t
+                        ra = ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 31));
+                        rb = ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 63));
+                        yc = rev2_64(symbols_at(yrw, c_first - 31));
+                    }
+                    da = ga ^ ra; db = gb ^ rb;
+                    const uint64_t d0 = kp ? rev2_64(da & pmask) >> (64 - 2 * kp) : 0ull;
+                    d_lo = (uint32_t)d0; d_hi = (uint32_t)(d0 >> 32);
+                    id = a.id_at[c_first] - ddir;     // so that the first step's "previous id + direction" is this cell's id
+                    id_ok = id + ddir != 0xffffffffu;
+                    yc |= 2ull;                       // ... and that step needs no follow bit
+                }
+                const uint32_t g4[4] = {(uint32_t)ga, (uint32_t)(ga >> 32), (uint32_t)gb, (uint32_t)(gb >> 32)};
+                const uint32_t d4[4] = {(uint32_t)da, (uint32_t)(da >> 32), (uint32_t)db, (uint32_t)(db >> 32)};
+                const uint32_t y2[2] = {(uint32_t)yc, (uint32_t)(yc >> 32)};
                 for (uint32_t t = 0; t < nmax; ++t) {
-                    const uint32_t base = xw & 3u;
-                    xw >>= 2;
-                    ++bi;
-                    if ((bi & 15u) == 0u) { xw = xn; xn = w2[min((bi >> 4) + 1u, last_word)]; }
+                    const uint32_t bi = km1 + t;                 // base of the chunk that completes k-mer t
+                    const uint32_t gi = bi >> 4, sh = 2u * (bi & 15u), ci = t >> 4, csh = 2u * (t & 15u);
+                    const uint32_t gsel = gi == 0 ? g4[0] : gi == 1 ? g4[1] : gi == 2 ? g4[2] : g4[3];
+                    const uint32_t dsel = gi == 0 ? d4[0] : gi == 1 ? d4[1] : gi == 2 ? d4[2] : d4[3];
+                    const uint32_t base = (gsel >> sh) & 3u;
+                    const uint32_t dsym = (dsel >> sh) & 3u;
+                    const uint32_t y = ((ci ? y2[1] : y2[0]) >> csh) & 3u;
                     f_hi = ((f_hi << 2) | (f_lo >> 30)) & kmask_hi;
                     f_lo = ((f_lo << 2) | base) & kmask_lo;
                     const uint32_t cb = (3u - base) << rc_sh;
                     r_lo2 = ((r_lo2 >> 2) | (r_hi2 << 30)) | (cb & ~rc_in_hi);
                     r_hi2 = (r_hi2 >> 2) | (cb & rc_in_hi);
+                    d_hi = ((d_hi << 2) | (d_lo >> 30)) & kmask_hi;
+                    d_lo = ((d_lo << 2) | dsym) & kmask_lo;
                     const bool valid = t < n2;
-
-                    const bool fwd_dir = ddir2 == 1u;
-                    const bool ok = valid && cellc < total;
-                    const uint32_t nc = ok ? cellc : 0u;                         // clamped: the loads below are unconditional
-                    const uint32_t bpos = fwd_dir ? nc + km1 : nc;               // reference base aligned with the new read base
-                    const uint32_t rb = ((refw[bpos >> 4] >> (2 * (bpos & 15))) & 3u) ^ (fwd_dir ? 0u : 3u);
-                    const uint32_t nd_hi = ((d_hi << 2) | (d_lo >> 30)) & kmask_hi;
-                    const uint32_t nd_lo = ((d_lo << 2) | (base ^ rb)) & kmask_lo;
-                    d_hi = ok ? nd_hi : d_hi;
-                    d_lo = ok ? nd_lo : d_lo;
-                    const uint32_t fl = (cflags[nc >> 3] >> (4 * (nc & 7))) & 15u;   // this cell's clean / rc / follow bits
-                    const bool clean = ok && (fl & 1u);
-                    const bool follow = fl & (fwd_dir ? 4u : 8u);                   // id continues from the cell we came from
-                    const uint32_t ref_isrc = ((fl >> 1) & 1u) ^ (fwd_dir ? 0u : 1u); // orientation of the reference k-mer as the read sees it
-                    const bool id_known = ok && id_ok && follow;                 // previous id +-1 along an unbroken stretch
-                    id = id_known ? id + ddir2 : id;
+                    const bool ok = valid && seeded2;
+                    const bool clean = y & 1u;                                   // bk_device.h cell_yf / cell_yr
+                    const bool id_known = ok && id_ok && (y & 2u);               // previous id +-1 along an unbroken stretch
+                    id = id_known ? id + ddir : id;
                     id_ok = id_known;
                     const uint32_t dbits = (d_lo | (d_lo >> 1)) & 0x55555555u, dbits_hi = (d_hi | (d_hi >> 1)) & 0x55555555u;
                     const uint32_t n_diff = (uint32_t)__popc(dbits) + (uint32_t)__popc(dbits_hi);
-                    const bool exact = id_known && n_diff == 0;                  // follow => a k-mer starts here; diff == 0 => it is this one
-                    if (exact) { count_exact(nc, id, ref_isrc); bad = 0; }      // read orientation == the reference k-mer's
-                    // one base differs from a clean reference k-mer whose id is known (the sequencing-error case).
-                    // Provably not a reference k-mer, and that k-mer is its only possible neighbour (bk_device.h, amb):
-                    // name its V counter on the spot, or it touches nothing.
+                    // one base differs from a clean reference k-mer whose id is known: provably not a reference k-mer, and
+                    // that k-mer is its only possible neighbour (bk_device.h, amb) -- a single-k-mer S run
                     const bool simple = id_known && clean && n_diff == 1;
-                    bool stat_only = false;   // full_kmer_stats: a k-mer known to touch nothing still has to be counted somewhere
                     if (simple) {
-                        const bool lt = f_hi < r_hi2 || (f_hi == r_hi2 && f_lo < r_lo2);   // lcb.rs:90-94
-                        const uint32_t isrc = lt ? 0u : 1u;
                         const int from_right = dbits ? (__builtin_ctz(dbits) >> 1) : 16 + (__builtin_ctz(dbits_hi) >> 1);
-                        const int j = isrc ? from_right : k - 1 - from_right;    // differing position in canonical orientation
-                        if (ref_isrc == isrc && j >= wlo && j < whi) {
-                            const int sh = 2 * (k - 1 - j);                     // base of the canonical k-mer at j
-                            const uint32_t c_lo = lt ? f_lo : r_lo2, c_hi = lt ? f_hi : r_hi2;
-                            const uint32_t bb = (sh >= 32 ? c_hi >> (sh - 32) : c_lo >> sh) & 3u;
-                            count_variant(id, j, bb, isrc);
-                        } else {
-                            stat_only = STATS;
-                        }
+                        const int bsh = 2 * from_right;             // the differing base, as the read has it
+                        const uint32_t br = (bsh >= 32 ? f_hi >> (bsh - 32) : f_lo >> bsh) & 3u;
+                        if (a.ablate != 2)
+                            v_point(v_counters, id, fwd2 ? (uint32_t)(k - 1 - from_right) : (uint32_t)from_right, fwd2 ? br : 3u - br,
+                                    fwd2 ? 0u : 1u, omin, span);
                     }
-                    // everything else -- unknown id, several differences, dirty neighbourhoods, lanes without a
-                    // diagonal, the miss queue and the slow pipeline
-                    const bool slow = valid && !exact && !simple;
-                    if (__ballot(slow | stat_only) || qn >= 64 || pipe.stage) {
-                        bool lookup = false, miss = false;
-                        uint64_t c = 0;
-                        uint32_t isrc = 0;
-                        if (slow | stat_only) {
-                            const bool lt = f_hi < r_hi2 || (f_hi == r_hi2 && f_lo < r_lo2);
-                            isrc = lt ? 0u : 1u;
-                            c = lt ? (((uint64_t)f_hi << 32) | f_lo) : (((uint64_t)r_hi2 << 32) | r_lo2);
-                            miss = stat_only;
+                    // everything else (no diagonal, several differences, dirty neighbourhoods, unknown id, no reference
+                    // k-mer at the cell) is resolved by the slow pipeline
+                    const bool miss = valid && !simple && a.ablate != 3;
+                    const unsigned long long mm = __ballot(miss);
+                    if (mm) {
+                        if (miss) {
+                            const bool lt = f_hi < r_hi2 || (f_hi == r_hi2 && f_lo < r_lo2);   // lcb.rs:90-94
+                            const uint64_t cc = lt ? (((uint64_t)f_hi << 32) | f_lo) : (((uint64_t)r_hi2 << 32) | r_lo2);
+                            q[qn + lane_prefix(mm)] = cc | (lt ? 0ull : 1ull << 62);
                         }
-                        if (slow) {
-                            if (!ok) {
-                                lookup = true;                                   // no diagonal: perfect-hash lookup, may re-seed
-                            } else {
-                                bool done = false;
-                                if (n_diff == 0 || (n_diff == 1 && clean)) {
-                                    id = a.id_at[nc];                            // repeat, or first step on this stretch
-                                    id_ok = id != 0xffffffffu;
-                                    if (id_ok && n_diff == 0) {
-                                        count_exact(nc, id, ref_isrc);
-                                        bad = 0;
-                                        done = true;
-                                    } else if (id_ok) {
-                                        done = true;
-                                        const int from_right = dbits ? (__builtin_ctz(dbits) >> 1) : 16 + (__builtin_ctz(dbits_hi) >> 1);
-                                        const int j = isrc ? from_right : k - 1 - from_right;
-                                        if (ref_isrc == isrc && j >= wlo && j < whi)
-                                            count_variant(id, j, (uint32_t)(c >> (2 * (k - 1 - j))) & 3u, isrc);
-                                        else if (STATS) { miss = true; stat_only = true; }
-                                    }
-                                }
-                                if (!done) {
-                                    // several differences, a dirty neighbourhood or no k-mer at this cell: full search,
-                                    // asynchronously; the lane keeps walking its diagonal and gives it up only after more
-                                    // than a k-mer of such steps
-                                    miss = true;
-                                    bad += 1;
-                                    if (bad > (uint32_t)k + 4u) cellc = 0xffffffffu;
-                                }
-                            }
-                        }
-                        if (lookup) {
-                            // perfect-hash membership test; a hit (re-)seeds the diagonal
-                            const uint32_t pilot = ix.pilots[phf_bucket(c, ix.log2nb)];
-                            const uint4 e = *reinterpret_cast<const uint4*>(ix.kmer_pos + phf_pos(c, pilot, ix.m));
-                            if (((uint64_t)e.x | ((uint64_t)e.y << 32)) == c) {
-                                id = e.w & kIdMask;
-                                id_ok = true;
-                                count_exact(e.z, id, isrc);
-                                ddir2 = (isrc == (e.w >> 31)) ? 1u : 0xffffffffu;   // same strand as the reference?
-                                cellc = e.z;
-                                d_lo = d_hi = 0;
-                                bad = 0;
-                            } else {
-                                miss = true;
-                            }
-                        }
-                        const unsigned long long mm = __ballot(miss);
-                        if (mm) {
-                            const uint32_t pos = qn + lane_prefix(mm);
-                            if (miss) { q.c[pos] = c; q.meta[pos] = (unsigned char)(isrc | (stat_only ? 2u : 0u)); }
-                            qn += (uint32_t)__popcll(mm);
-                            __builtin_amdgcn_wave_barrier();
-                        }
-                        if (qn >= 64) {
-                            // a full batch is waiting: retire the batch in flight (its loads were issued steps ago), then
-                            // take 64 k-mers off the queue and issue the first loads of the new batch
-                            pipe.finish(ix, v_counters, count_exact, kt);
-                            pipe.start(q, 64, lane, ix);
-                            const uint32_t rest = qn - 64;
-                            const unsigned long long tc = ((uint32_t)lane < rest) ? q.c[64 + lane] : 0ull;
-                            const unsigned char tm = ((uint32_t)lane < rest) ? q.meta[64 + lane] : (unsigned char)0;
-                            __builtin_amdgcn_wave_barrier();
-                            if ((uint32_t)lane < rest) { q.c[lane] = tc; q.meta[lane] = tm; }
-                            __builtin_amdgcn_wave_barrier();
-                            qn = rest;
-                        } else if (pipe.stage) {
-                            pipe.advance(ix, v_counters, count_exact, kt);
-                        }
+                        qn += (uint32_t)__popcll(mm);
+                        __builtin_amdgcn_wave_barrier();
                     }
-                    cellc = cellc < total ? cellc + ddir2 : cellc;               // without a diagonal the lane stays without
+                    if (qn >= 32u) {
+                        // enough for a batch: retire the batch in flight (its loads were issued steps ago), then take up to
+                        // 64 k-mers off the queue and issue the first loads of the new batch
+                        pipe.finish(ix, v_counters, count_exact, kt);
+                        const uint32_t nb = min(qn, 64u);
+                        pipe.start(q, nb, lane, ix);
+                        const uint32_t rest = qn - nb;
+                        const unsigned long long tc = ((uint32_t)lane < rest) ? q[64 + lane] : 0ull;
+                        __builtin_amdgcn_wave_barrier();
+                        if ((uint32_t)lane < rest) q[lane] = tc;
+                        __builtin_amdgcn_wave_barrier();
+                        qn = rest;
+                    } else if (pipe.stage) {
+                        pipe.advance(ix, v_counters, count_exact, kt);
+                    }
                 }
                 continue;
             }
-            if (phase == 2) break;
-            if (phase == 1) {
-                // ---- close the ranges still open at the end of the longest read (qr < 64 here) ----
-                const unsigned long long om = __ballot(inrun);
-                if (om) {
-                    if (inrun) rq[qr + lane_prefix(om)] = (uint32_t)lane | (run_start << 6) | ((maxlen - km1 - run_start) << 22);
-                    qr += (uint32_t)__popcll(om);
+            if (qs >= 64u || (flush && (fin ? qs != 0u : olds != 0u))) {
+                // ================= S batch: one queued S run per lane, two atomics each (qg < 64 here) =============
+                const uint32_t nb2 = min(qs, 64u);
+                const uint32_t ent = (uint32_t)lane < nb2 ? rqs[lane] : 0u;
+                {   // move the rest of the queue down
+                    const uint32_t rest = qs - nb2;
+                    const uint32_t t = (uint32_t)lane < rest ? rqs[64 + lane] : 0u;
                     __builtin_amdgcn_wave_barrier();
-                    inrun = false;
+                    if ((uint32_t)lane < rest) rqs[lane] = t;
+                    __builtin_amdgcn_wave_barrier();
+                    qs = rest;
+                    olds = olds > nb2 ? olds - nb2 : 0u;
                 }
-                phase = 2;
+                if (a.ablate == 1) continue;
+                const bool have = (uint32_t)lane < nb2;
+                const int src = (int)(ent & 63u);
+                const uint32_t s_first = (ent >> 6) & 0xffffu;
+                const uint32_t n2 = (ent >> 22) & 63u;
+                const bool cur = ((ent >> 28) & 1u) == parity;
+                const int32_t dg_c = __shfl(dg, src), dg_p = __shfl(pdg, src);
+                const uint32_t fl_c = (uint32_t)__shfl((int)dfl, src), fl_p = (uint32_t)__shfl((int)pdfl, src);
+                const uint32_t r_c = (uint32_t)__shfl((int)r32, src), r_p = (uint32_t)__shfl((int)pr32, src);
+                const int32_t dg2 = cur ? dg_c : dg_p;
+                const bool fwd2 = (cur ? fl_c : fl_p) & 1u;
+                const uint32_t* __restrict__ w2 = words0 + (uint64_t)(have ? (cur ? r_c : r_p) : 0u) * a.stride_words;
+                // the run's first k-mer against the reference k-mer of its cell: where is the one difference, which base
+                const int32_t c_first = have ? (fwd2 ? dg2 + (int32_t)s_first : dg2 - (int32_t)s_first) : 0;
+                const uint64_t g = read_symbols_at(w2, s_first, last_word) & kmask;
+                const uint64_t gref = fwd2 ? symbols_at(refw, c_first) : ~rev2_64(symbols_at(refw, c_first + k - 32));
+                const uint64_t dx = (g ^ gref) & kmask;
+                const uint64_t dfl64 = (dx | (dx >> 1)) & 0x5555555555555555ull;
+                const uint32_t tpos = dfl64 ? (uint32_t)(__builtin_ctzll(dfl64) >> 1) : 0u;   // read offset of the differing base
+                const uint32_t br = (uint32_t)(g >> (2u * tpos)) & 3u;
+                const uint32_t id_first = a.id_at[c_first];
+                // the run's n2 - 1 further cells must continue the id sequence (follow bits of cell_yf / cell_yr)
+                const uint64_t ys = fwd2 ? symbols_at(yfw, c_first + 1) : symbols_at(yrw, c_first - (int32_t)(n2 ? n2 - 1u : 0u));
+                const uint64_t fmask = n2 > 1u ? (0xaaaaaaaaaaaaaaaaull >> (64u - 2u * (n2 - 1u))) : 0ull;
+                const bool good = have && __popcll(dfl64) == 1 && id_first != 0xffffffffu && (ys & fmask) == fmask && tpos + 1u >= n2;
+                if (good) {
+                    // offsets (along the reference, from each k-mer's start) the run's k-mers have the difference at
+                    const uint32_t o_first = fwd2 ? tpos : km1 - tpos;             // of the first k-mer
+                    const uint32_t o_lo = fwd2 ? tpos - (n2 - 1u) : o_first;       // fwd: later k-mers start later, the offset shrinks
+                    const uint32_t o_hi = fwd2 ? tpos : o_first + (n2 - 1u);
+                    const int lo2 = max((int)o_lo, omin), hi2 = min((int)o_hi, omin + span - 1);
+                    if (lo2 <= hi2 && a.ablate != 2) {
+                        unsigned long long* row = v_counters + v_row_base(id_first + o_first - (uint32_t)omin, fwd2 ? br : 3u - br, fwd2 ? 0u : 1u, span);
+                        atomicAdd(row + (lo2 - omin), 1ull);
+                        atomicAdd(row + (hi2 - omin + 1), ~0ull);
+                    }
+                }
+                // (cannot happen for a run Level 1 made on an intact index; kept so that nothing is ever dropped)
+                const unsigned long long bm = __ballot(have && !good);
+                if (bm) {
+                    if (have && !good) rqg[qg + lane_prefix(bm)] = ent;
+                    qg += (uint32_t)__popcll(bm);
+                    oldg += (uint32_t)__popcll(__ballot(have && !good && !cur));
+                    __builtin_amdgcn_wave_barrier();
+                }
                 continue;
             }
-            // ================= Level 1: one base =============================================================
-            const uint32_t b = i & 15u;
-            if (b == 0u) {
-                // next read word, the reference word aligned with it, the cell codes of the 16 k-mers that end in it
-                x = (i < len) ? w[i >> 4] : 0u;
-                const bool act = l1ok && i < len;
-                const int32_t p0 = act ? (fwd ? dg + (int32_t)i : dg + (int32_t)km1 - (int32_t)i - 15) : 0;
+            if (pend) {
+                // ---- the next run boundary of each lane: close the open run, open the next (qs, qg < 64 here) ----
+                const bool has = Bd != 0u;
+                const uint32_t b = has ? (uint32_t)__builtin_ctz(Bd) : 0u;
+                const uint32_t s = tw_i0 + b - km1;          // the k-mer that ends at that base: first of the new run
+                const uint32_t n = s - run_start;
+                const bool long_g = has && run_type == 3u && n > chunk;   // a long G run goes out chunk by chunk
+                const uint32_t take = long_g ? chunk : n;
+                if (has && run_type == 1u) {
+                    // E run over k-mers [run_start, s): cells dg + run_start .. dg + s - 1 (fwd) / dg - s + 1 .. dg - run_start
+                    const uint32_t c_lo = fwd ? (uint32_t)(dg + (int32_t)run_start) : (uint32_t)(dg - (int32_t)s + 1);
+                    const uint32_t inc = fwd ? 1u : 0x10000u;
+                    __hip_atomic_fetch_add(&bins[c_lo], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&bins[c_lo + n], 0u - inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                const uint32_t ent = (uint32_t)lane | (run_start << 6) | (take << 22) | (parity << 28);
+                const unsigned long long sm = __ballot(has && run_type == 2u);
+                if (sm) {
+                    if (has && run_type == 2u) rqs[qs + lane_prefix(sm)] = ent;
+                    qs += (uint32_t)__popcll(sm);
+                }
+                const unsigned long long gm = __ballot(has && run_type == 3u);
+                if (gm) {
+                    if (has && run_type == 3u) rqg[qg + lane_prefix(gm)] = ent;
+                    qg += (uint32_t)__popcll(gm);
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (long_g) {
+                    run_start += chunk;                      // the boundary stays: the rest goes out in the next rounds
+                } else if (has) {
+                    run_type = ((E16 >> b) & 1u) ? 1u : ((S16 >> b) & 1u) ? 2u : ((G16 >> b) & 1u) ? 3u : 0u;
+                    run_start = s;
+                    Bd &= Bd - 1u;
+                }
+                pend = __ballot(Bd != 0u) != 0ull;
+                continue;
+            }
+            if (words_done) break;
+            // ================= Level 1: one read word = 16 bases =================================================
+            {
+                const uint32_t x = xn;
+                xn = (i0 + 16u < len) ? w[(i0 >> 4) + 1u] : 0u;
+                const bool act = l1ok && i0 < len;
+                // mismatch flags of these 16 bases: read word vs the reference word aligned with it
+                const int32_t p0 = act ? (fwd ? dg + (int32_t)i0 : dg + (int32_t)km1 - (int32_t)i0 - 15) : 0;
                 const uint32_t sh = 2u * ((uint32_t)p0 & 15u);
                 const uint32_t yl = __builtin_amdgcn_alignbit(refw[(p0 >> 4) + 1], refw[p0 >> 4], sh);
-                const uint32_t y = fwd ? yl : ~rev2_32(yl);
-                const uint32_t dd = x ^ y;
-                Mw = act ? (dd | (dd >> 1)) & 0x55555555u : 0x55555555u;   // no usable diagonal: every base "differs"
-                const int32_t c0 = act ? (fwd ? dg + (int32_t)i - (int32_t)km1 : dg - (int32_t)i + (int32_t)km1 - 15) : 0;
-                const uint32_t zsh = 2u * ((uint32_t)c0 & 15u);
-                const uint32_t zl = __builtin_amdgcn_alignbit(codew[(c0 >> 4) + 1], codew[c0 >> 4], zsh);
-                Zc = fwd ? zl : __builtin_bitreverse32(zl);   // reversing the bits also swaps codes 1 <-> 2: the strand flips
-                // a range that has grown long is cut here, so that its length always fits the queue entry
-                if (i >= (uint32_t)kMaxRangeLen - 64u) {
-                    const uint32_t s_now = i - km1;   // an open range implies i >= k
-                    const bool cut = inrun && s_now - run_start >= (uint32_t)(kMaxRangeLen - 32);
-                    const unsigned long long cm = __ballot(cut);
-                    if (cm) {
-                        if (cut) { rq[qr + lane_prefix(cm)] = (uint32_t)lane | (run_start << 6) | ((s_now - run_start) << 22); run_start = s_now; }
-                        qr += (uint32_t)__popcll(cm);
-                        __builtin_amdgcn_wave_barrier();
-                        if (qr >= 64u) continue;   // (the word set-up is idempotent: i has not moved)
-                    }
+                const uint32_t dd = x ^ (fwd ? yl : ~rev2_32(yl));
+                const uint32_t M16 = act ? even_bits(dd | (dd >> 1)) : 0xffffu;   // no usable diagonal: every base "differs"
+                h_lo = __builtin_amdgcn_alignbit(h_hi, h_lo, 16);
+                h_hi = (h_hi >> 16) | (M16 << 16);
+                // per-cell bits of the 16 k-mers that end in this word, in step order
+                const int32_t c0 = act ? (fwd ? dg + (int32_t)i0 - (int32_t)km1 : dg - (int32_t)i0 + (int32_t)km1 - 15) : 0;
+                const uint32_t hl = bits16_at(hasw, c0), cl = bits16_at(cleanw, c0);
+                const uint32_t HAS16 = fwd ? hl : __builtin_bitreverse32(hl) >> 16;
+                const uint32_t CLEAN16 = fwd ? cl : __builtin_bitreverse32(cl) >> 16;
+                // steps of this word that end a k-mer of the read: i0 + b >= k - 1 and i0 + b < len
+                const uint32_t lo = i0 >= km1 ? 0u : min(km1 - i0, 16u);
+                const uint32_t hi = len > i0 ? min(len - i0, 16u) : 0u;
+                const uint32_t VAL16 = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                // A: some mismatch among the k bases that end at step b; B: at least two.  The flags of base i0 + b - t sit
+                // at bit 48 + b - t of (h_hi : h_lo)
+                uint32_t A = 0, B = 0;
+                for (int t = 0; t < k; ++t) {
+                    const uint32_t st = t <= 16 ? h_hi >> (16 - t) : __builtin_amdgcn_alignbit(h_hi, h_lo, (uint32_t)(48 - t));
+                    B |= A & st;
+                    A |= st;
                 }
-            }
-            {
-                const uint32_t mbit = (Mw >> (2u * b)) & 1u;
-                dwin = ((dwin << 1) | mbit) & kmask1;
-                const uint32_t z = (Zc >> (2u * b)) & 3u;
-                const bool valid = i < len && i >= km1;
-                const bool ex = valid && dwin == 0u && z != 0u;
-                if (ex) {
-                    // z = 1: the reference k-mer here is canonical as the read sees it (low half), 2: as its reverse complement
-                    __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(bins) + bin_off),
-                                           ((z << 15) | z) & 0x10001u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                bin_off += bin_step;
-                const bool ne = valid && !ex;
-                const bool end = inrun && !ne;
-                const uint32_t s = i - km1;   // the k-mer that ends at base i (meaningful when i >= k - 1)
-                run_start = (ne && !inrun) ? s : run_start;
-                inrun = ne;
-                const unsigned long long ends = __ballot(end);
-                if (ends) {
-                    if (end) rq[qr + lane_prefix(ends)] = (uint32_t)lane | (run_start << 6) | ((s - run_start) << 22);
-                    qr += (uint32_t)__popcll(ends);
-                    __builtin_amdgcn_wave_barrier();
-                }
-                ++i;
-                if (i == maxlen) phase = 1;
+                E16 = ~A & HAS16 & VAL16;
+                S16 = A & ~B & CLEAN16 & VAL16;
+                G16 = VAL16 & ~(E16 | S16);
+                // a new run starts where the kind changes, or where an S k-mer's one mismatch is the newest base (the
+                // mismatch the previous S k-mers had has just left the window)
+                Bd = (E16 ^ ((E16 << 1) | pe)) | (S16 ^ ((S16 << 1) | ps)) | (G16 ^ ((G16 << 1) | pg)) | (S16 & M16);
+                Bd &= 0xffffu;
+                pe = (E16 >> 15) & 1u; ps = (S16 >> 15) & 1u; pg = (G16 >> 15) & 1u;
+                tw_i0 = i0;
+                pend = __ballot(Bd != 0u) != 0ull;
+                i0 += 16u;
+                words_done = i0 > maxlen;   // one step past the longest read closes every open run
             }
         }
+        if (fin) break;
     }
     pipe.finish(ix, v_counters, count_exact, kt);
     if (qn) {
-        pipe.start(q, qn, lane, ix);
+        pipe.start(q, qn, lane, ix);   // qn < 64
         pipe.finish(ix, v_counters, count_exact, kt);
     }
 
-    // bins -> this workgroup's slab (coalesced); k-mer tally -> one atomic per workgroup
+    // ---- epilogue: difference array -> per-cell counts (prefix sum over the workgroup), written as this workgroup's slab ----
     if (threadIdx.x == 0) *block_kmers = 0;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < a.n_lds_bins; i += kScanBlock) a.slabs[(size_t)blockIdx.x * a.n_lds_bins + i] = bins[i];
+    {
+        const uint32_t nb = a.n_lds_bins;
+        const uint32_t per = (nb + kScanBlock - 1) / kScanBlock;
+        const uint32_t b0 = min(threadIdx.x * per, nb), b1 = min(b0 + per, nb);
+        uint32_t sum = 0;
+        for (uint32_t i = b0; i < b1; ++i) sum += bins[i];
+        uint32_t inc = sum;   // inclusive scan of the per-thread sums across the wave, then across waves
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, off); if (lane >= off) inc += t; }
+        if (lane == 63) scan_tmp[wave] = inc;
+        __syncthreads();
+        uint32_t run = inc - sum;
+        for (int wv = 0; wv < wave; ++wv) run += scan_tmp[wv];
+        for (uint32_t i = b0; i < b1; ++i) { run += bins[i]; bins[i] = run; }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nb; i += kScanBlock) a.slabs[(size_t)blockIdx.x * nb + i] = bins[i];
+    }
     uint32_t tot = nkm;
 #pragma unroll
     for (int off = 32; off; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off);
@@ -805,14 +878,18 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     if (threadIdx.x == 0 && *block_kmers && a.kmer_total) atomicAdd(a.kmer_total, (unsigned long long)*block_kmers);
 }
 
-size_t scan_lds_budget() { return 160u * 1024u - 64u - kScanLdsFixed; }
+size_t scan_lds_budget() { return 160u * 1024u - 64u - kScanLdsFixed - sizeof(unsigned int); }
 size_t scan_ref_lds_bytes(uint32_t total_cells) {
-    return 2 * (size_t)(kRefPadWords + (total_cells + 15) / 16 + 4) * sizeof(unsigned int);
+    return ((size_t)(kRefPadWords + (total_cells + 15) / 16 + kRefBackWords) + 2 * (size_t)(kBitPadWords + (total_cells + 31) / 32 + kBitBackWords)) *
+           sizeof(unsigned int);
 }
 size_t scan_lds_bytes(uint32_t n_lds_bins, bool ref_in_lds, uint32_t total_cells) {
-    return kScanLdsFixed + (size_t)n_lds_bins * sizeof(unsigned int) + (ref_in_lds ? scan_ref_lds_bytes(total_cells) : 0);
+    return kScanLdsFixed + ((size_t)n_lds_bins + 1) * sizeof(unsigned int) + (ref_in_lds ? scan_ref_lds_bytes(total_cells) : 0);
 }
 int scan_ref_pad_words() { return kRefPadWords; }
+int scan_ref_back_words() { return kRefBackWords; }
+int scan_bit_pad_words() { return kBitPadWords; }
+int scan_bit_back_words() { return kBitBackWords; }
 
 uint32_t scan_grid(uint64_t n_records, int n_cus) {
     const uint64_t want = (n_records + kScanBlock - 1) / kScanBlock;
@@ -835,13 +912,15 @@ hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t strea
 }
 
 // ------------------------------------------------------------------------------------------------ K1b
-// E[2 id_at[c] + h] += sum over workgroup slabs of half h of slab[b][c]   (c < n_lds_bins: bins are per cell), and
-// E[i]              += sum over the 8 XCD planes of e_planes[x][i]         (planes re-zeroed for the next batch).
+// slab[b][c] = (reads of workgroup b that contain the reference k-mer of cell c, along the reference) + 65536 * (against it)
+// E[2 id_at[c] + rc]     += sum over slabs of the low half   (rc = the cell's k-mer was reverse-complemented to become canonical:
+// E[2 id_at[c] + 1 - rc] += sum over slabs of the high half    a read along the reference has the k-mer as written), and
+// E[i]                   += sum over the 8 XCD planes of e_planes[x][i]   (planes re-zeroed for the next batch).
 __global__ __launch_bounds__(256) void fold_kernel(FoldArgs f) {
     const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * 256;
     // blockIdx.y splits the slabs into groups so that the 31 MB of slabs are streamed by the whole chip; each
-    // group adds its partial sums with one u64 atomic per non-zero bin half
+    // group adds its partial sums with one u64 atomic per non-zero half
     const uint32_t per = (f.n_slabs + gridDim.y - 1) / gridDim.y;
     const uint32_t b0 = blockIdx.y * per, b1 = min(f.n_slabs, b0 + per);
     for (uint64_t i = tid; i < f.n_lds_bins && b0 < b1; i += nthreads) {
@@ -853,8 +932,9 @@ __global__ __launch_bounds__(256) void fold_kernel(FoldArgs f) {
         }
         if (s0 | s1) {
             const uint32_t id = f.id_at[i];   // a counted cell always has a reference k-mer
-            if (s0) atomicAdd(f.counters + 2 * (size_t)id, s0);
-            if (s1) atomicAdd(f.counters + 2 * (size_t)id + 1, s1);
+            const uint32_t rc = ((f.cell_codes[i >> 4] >> (2 * (i & 15))) & 3u) == 2u ? 1u : 0u;
+            if (s0) atomicAdd(f.counters + 2 * (size_t)id + rc, s0);
+            if (s1) atomicAdd(f.counters + 2 * (size_t)id + (1u - rc), s1);
         }
     }
     if (f.e_planes && blockIdx.y == 0) {
@@ -944,11 +1024,55 @@ __global__ __launch_bounds__(256) void finalize_reduce_kernel(FinalizeArgs a, in
     else if (a.distinct_total) *a.distinct_total += s;
 }
 
-// K2a: one thread per V counter.  A kept non-reference k-mer almost always touches exactly one window bucket
-// (the one its name says); then the whole of map_kmers for it is: vote once per BucketInfo of that bucket,
-// and per genome file "variant" (or "perfect" if the file has exactly W entries there, which needs W == 1 or
-// repeats).  K-mers that touch several buckets need cross-bucket per-genome totals; they are appended (by
-// counter index) to `deferred` and mapped by K2b.
+// Reverse complement of a k-mer (first base on top, like every canonical k-mer here).
+__device__ __forceinline__ uint64_t revcomp_kmer(uint64_t c, int k) {
+    const uint64_t t = ~c;
+    const uint64_t r = ((uint64_t)rev2_32((uint32_t)t) << 32) | rev2_32((uint32_t)(t >> 32));
+    return r >> (64 - 2 * k);
+}
+
+// The k-mer a V counter stands for: canonical form c (in the orientation of its reference neighbour), orientation the reads
+// had it in, and its occurrence count n (reference k-mers: prefix sum of the row's difference array, bk_device.h).
+__device__ __forceinline__ void v_kmer_of_counter(const IndexView& ix, const unsigned long long* __restrict__ vc, uint64_t vi,
+                                                  uint32_t& p, uint32_t& t, uint64_t& c, uint32_t& isrc, unsigned long long& n) {
+    const int k = ix.k;
+    const uint64_t real_len = v_real_len(ix.n_full, ix.v_span);
+    uint32_t bb;
+    if (vi < real_len) {
+        const uint32_t rl = (uint32_t)ix.v_span + 1u;
+        const uint64_t row = vi / rl;
+        const uint32_t oo = (uint32_t)(vi % rl);
+        n = 0;
+        for (uint32_t x = 0; x <= oo; ++x) n += vc[row * rl + x];
+        p = (uint32_t)(row >> 3) - oo;
+        const uint32_t rcid = (ix.amb[p] >> 1) & 1u;
+        const int o = (int)oo + ix.v_omin;
+        const int j = rcid ? k - 1 - o : o;
+        const uint32_t bf = (uint32_t)(row >> 1) & 3u;
+        bb = rcid ? 3u - bf : bf;
+        isrc = ((uint32_t)row & 1u) ^ rcid;
+        t = (uint32_t)(j - ix.wstart);
+    } else {
+        const uint64_t x = vi - real_len;
+        isrc = (uint32_t)x & 1u;
+        bb = (uint32_t)(x >> 1) & 3u;
+        p = ix.prow_id[x >> 3];
+        t = ix.prow_t[x >> 3];
+        n = vc[vi];
+    }
+    const int sh = 2 * (k - 1 - (ix.wstart + (int)t));
+    c = (ix.kmer_of[p] & ~(3ull << sh)) | ((uint64_t)bb << sh);
+}
+
+// K2a: the V counters.  One thread per row of the reference k-mers' part (it walks the row's difference array, so each
+// k-mer's count is the running sum) and one per counter of the pseudo k-mers' part.  A kept non-reference k-mer almost
+// always touches exactly one window bucket (the one its name says); then the whole of map_kmers for it is: vote once per
+// BucketInfo of that bucket, and per genome file "variant" (or "perfect" if the file has exactly W entries there, which
+// needs W == 1 or repeats).  K-mers that touch several buckets need cross-bucket per-genome totals; they are appended
+// (by counter index) to `deferred` and mapped by K2b.
+// A row also holds k-mers that cannot touch the index: the difference outside the window, or a k-mer whose canonical form
+// lies on the other strand than its neighbour's (scan_count records what the reads contain, not what it means).  They are
+// skipped -- with full_kmer_stats they join the k-mer statistics table, like every other k-mer that touches nothing.
 __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const IndexView& ix = a.ix;
@@ -958,34 +1082,30 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
 
     const int k = ix.k;
     const uint64_t n_e = e_plane_len(ix.n_u);
-    const uint64_t n_v = v_plane_len(ix.n_rows);
+    const uint64_t n_rows = v_real_rows(ix.n_full, ix.v_span);
+    const uint64_t real_len = v_real_len(ix.n_full, ix.v_span);
+    const uint32_t rl = (uint32_t)ix.v_span + 1u;
+    const uint64_t n_work = n_rows + ix.n_prows * 8ull;
     const unsigned long long* __restrict__ vc = a.counters + n_e;
+    const KmerTable kt{a.ktab_keys, a.ktab_cnt, a.ktab_log2, a.ktab_overflow, a.mate};
     unsigned int kept = 0, distinct = 0;
 
-    for (uint64_t vi = (uint64_t)blockIdx.x * 256 + threadIdx.x; vi < n_v; vi += (uint64_t)gridDim.x * 256) {
-        const unsigned long long n = vc[vi];
-        distinct += n != 0;
-        if (n == 0 || n < a.ci || n > a.cx) continue;           // kmc -ci / -cx act on the true count
+    // one kept k-mer: c = reference k-mer p with base changed at window position t, read in orientation isrc, n times
+    auto map_one = [&](uint32_t p, uint32_t t, uint64_t c, uint32_t isrc, unsigned long long n, uint64_t vi) {
+        distinct += 1;
+        if (n < a.ci || n > a.cx) return;                        // kmc -ci / -cx act on the true count
         ++kept;
         const unsigned long long v = n > a.cs ? a.cs : n;       // kmc -cs: reported count saturates
-        const uint32_t isrc = (uint32_t)vi & 1u;
-        const uint32_t bb = (uint32_t)(vi >> 1) & 3u;
-        uint32_t t, p;
-        row_owner(ix, vi >> 3, p, t);
-        const int j = ix.wstart + (int)t;
-        const int sh = 2 * (k - 1 - j);
-        const uint64_t c = (ix.kmer_of[p] & ~(3ull << sh)) | ((uint64_t)bb << sh);
-
-        // c = u with one base changed at window position j.  It can touch a second window bucket only if another
-        // reference k-mer lies at Hamming distance 2 from u (amb[p], precomputed); otherwise its one bucket is
-        // u's own bucket at j.  Ambiguous u: enumerate the neighbours; several buckets -> general path (K2b).
-        if (ix.amb[p]) {
+        // It can touch a second window bucket only if another reference k-mer lies at Hamming distance 2 from u
+        // (amb[p], precomputed); otherwise its one bucket is u's own bucket at t.  Ambiguous u: enumerate the
+        // neighbours; several buckets -> general path (K2b).
+        if (ix.amb[p] & 1u) {
             uint32_t jmask = 0;   // window positions at which c has a neighbouring reference k-mer
             for_each_neighbour(ix, c, [&](int jj, uint32_t) { jmask |= 1u << (jj - ix.wstart); });
             if (jmask != (1u << t)) {
                 const unsigned int at = atomicAdd(a.n_deferred, 1u);
                 a.deferred[at] = (uint32_t)vi;
-                continue;
+                return;
             }
         }
         const uint32_t s = ix.slot_of[(size_t)p * ix.W + t];
@@ -1000,6 +1120,38 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
             else atomicAdd(&lstats[file * 3 + 1], 1u);
         }
         if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
+    };
+
+    for (uint64_t wk = (uint64_t)blockIdx.x * 256 + threadIdx.x; wk < n_work; wk += (uint64_t)gridDim.x * 256) {
+        if (wk >= n_rows) {   // a pseudo k-mer's counter
+            const uint64_t vi = real_len + (wk - n_rows);
+            if (vc[vi] == 0) continue;
+            uint32_t p, t, isrc; uint64_t c; unsigned long long n;
+            v_kmer_of_counter(ix, vc, vi, p, t, c, isrc, n);
+            map_one(p, t, c, isrc, n, vi);
+            continue;
+        }
+        const uint32_t d = (uint32_t)wk & 1u, bf = (uint32_t)(wk >> 1) & 3u, q = (uint32_t)(wk >> 3);
+        unsigned long long n = 0;
+        for (uint32_t oo = 0; oo < (uint32_t)ix.v_span; ++oo) {
+            n += vc[wk * rl + oo];
+            if (n == 0 || q < oo || q - oo >= ix.n_full) continue;
+            const uint32_t p = q - oo;
+            const uint32_t rcid = (ix.amb[p] >> 1) & 1u;
+            const int o = (int)oo + ix.v_omin;
+            const int j = rcid ? k - 1 - o : o;
+            const uint32_t bb = rcid ? 3u - bf : bf;
+            const uint32_t isrc = d ^ rcid;
+            const int sh = 2 * (k - 1 - j);
+            const uint64_t c = (ix.kmer_of[p] & ~(3ull << sh)) | ((uint64_t)bb << sh);
+            const uint64_t rc = revcomp_kmer(c, k);
+            const bool alive = j >= ix.wstart && j < ix.wstart + ix.W && c < rc;
+            if (!alive) {
+                if (kt.keys) ktab_insert(kt, c < rc ? c : rc, c < rc ? isrc : isrc ^ 1u, (unsigned int)(n > 0xf0000000ull ? 0xf0000000ull : n));
+                continue;
+            }
+            map_one(p, (uint32_t)(j - ix.wstart), c, isrc, n, wk * rl + oo);
+        }
     }
     __syncthreads();
     finalize_epilogue(a, lstats, kept, distinct, lstats + ix.n_files * 3, (int)blockIdx.x);
@@ -1074,23 +1226,12 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
     // thousand items spread over the whole grid
     for (uint64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         {
-            const uint64_t ci = n_e + a.deferred[item];
-            unsigned long long v = a.counters[ci];
-            v = v > a.cs ? a.cs : v;                              // kmc -cs: reported count saturates
+            const uint64_t ci = n_e + a.deferred[item];          // always a V counter: the E counters are mapped by K2e
+            unsigned long long v;
             uint64_t c;
-            uint32_t isrc;
-            if (ci < n_e) {                                       // E: a reference k-mer itself
-                c = ix.kmer_of[ci >> 1];
-                isrc = (uint32_t)ci & 1u;
-            } else {                                              // V: reference k-mer p with base bb at window position t
-                const uint64_t vi = ci - n_e;
-                isrc = (uint32_t)vi & 1u;
-                const uint32_t bb = (uint32_t)(vi >> 1) & 3u;
-                uint32_t t, p;
-                row_owner(ix, vi >> 3, p, t);
-                const int sh = 2 * (k - 1 - (ix.wstart + (int)t));
-                c = (ix.kmer_of[p] & ~(3ull << sh)) | ((uint64_t)bb << sh);
-            }
+            uint32_t isrc, p_, t_;
+            v_kmer_of_counter(ix, a.counters + n_e, ci - n_e, p_, t_, c, isrc, v);
+            v = v > a.cs ? a.cs : v;                              // kmc -cs: reported count saturates
 
             if (lane < ix.W) {
                 int s;
@@ -1148,7 +1289,7 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     FinalizeArgs a = a0;
     const size_t lds_stats = ((size_t)a.ix.n_files * 3 + 2) * sizeof(uint32_t);
     // K2a
-    const uint64_t n_v = v_plane_len(a.ix.n_rows);
+    const uint64_t n_v = v_real_rows(a.ix.n_full, a.ix.v_span) + a.ix.n_prows * 8ull;   // work items of K2a
     const unsigned b_var = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_v + 255) / 256, kFinVariantBlocks));
     hipLaunchKernelGGL(finalize_variant_kernel, dim3(b_var), dim3(256), lds_stats, stream, a);
     // K2e

@@ -31,6 +31,12 @@ struct alignas(8) DevEntry {
     uint8_t  canonical;
 };
 
+// Entry list of a window bucket + a copy of its first entry: 16 B, one global_load_dwordx4.
+struct alignas(16) SlotRec {
+    uint32_t off, len;   // entries[off .. off + len)
+    DevEntry first;
+};
+
 // Multiplicative hash into a table of 2^log2s positions.
 BK_HD uint32_t hash_key(uint64_t key, uint32_t log2s) {
     return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - log2s));
@@ -120,6 +126,8 @@ struct IndexView {
     const uint16_t*  pilots;   // [1 << log2nb]
     HalfView         lo, hi;
     const uint32_t*  slot_of;  // [n_u][W] window bucket (slot) of reference k-mer id at window position t
+    const SlotRec*   slot_rec; // [n_full][W] the same bucket's entry list, with its first BucketInfo inline (one load for the
+                               //             common single-entry bucket)
     const uint8_t*   amb;      // [n_u] bit 1 = the k-mer's first occurrence was reverse-complemented to become canonical; bit 0 = "dirty": another reference k-mer (either strand) lies within Hamming
                                //       distance 2 of it, or it is within distance 2 of its own reverse complement
     const uint32_t*  estat_off;// [n_u + 1] per reference k-mer: its genomes, precomputed from the index alone

@@ -179,6 +179,7 @@ struct bk_engine {
     DevBuf<unsigned int> ktab_cnt;
     DevBuf<unsigned long long> ktab_out;    // [2 mates][2] distinct, kept  + [4] overflow flag
     DevBuf<uint32_t> slot_of, estat_off, estat;
+    DevBuf<bk::SlotRec> slot_rec;
     DevBuf<uint8_t> amb;
     DevBuf<uint16_t> pilots;
     DevBuf<unsigned int> slabs;             // [n_cus][n_lds_bins] workgroup histograms of the last scan launch
@@ -227,7 +228,7 @@ struct bk_engine {
         v.n_full = n_full; v.n_prows = n_prows; v.prow_id = prow_id.p; v.prow_t = prow_t.p; v.v_omin = v_omin; v.v_span = v_span;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb};
-        v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
+        v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.slot_rec = slot_rec.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
         v.table = table.p; v.ent_off = ent_off.p; v.ent_len = ent_len.p;
         v.entries = entries.p; v.n_slots = n_slots; v.log2s = log2s; v.k = k; v.wstart = wstart; v.W = W; v.n_files = n_files;
         return v;
@@ -638,6 +639,18 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             for (int t = 0; t < e->W; t++) h_slot_of[(size_t)id_of[i] * e->W + t] = slot_by_index[i * e->W + t];
         std::vector<uint32_t>().swap(slot_by_index);
         BK_HIP(e->slot_of.upload(h_slot_of));
+        {
+            std::vector<bk::SlotRec> h_rec((size_t)std::max<size_t>(e->n_full, 1) * std::max(e->W, 1));
+            for (size_t id = 0; id < e->n_full; id++)
+                for (int t = 0; t < e->W; t++) {
+                    const uint32_t sl = h_slot_of[id * e->W + t];
+                    bk::SlotRec r{};
+                    r.off = h_off[sl]; r.len = h_len[sl];
+                    if (r.len) r.first = h_ent[r.off];
+                    h_rec[id * e->W + t] = r;
+                }
+            BK_HIP(e->slot_rec.upload(h_rec));
+        }
 
         // estat: per reference k-mer, its per-genome hit totals over its W window buckets (call.rs:1316-1318) and
         // hence perfect (== W) / variant -- a property of the index alone

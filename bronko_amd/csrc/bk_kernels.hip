@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "bk_device.h"
 #include "bk_kernels.h"
@@ -1064,8 +1065,8 @@ __device__ __forceinline__ void v_kmer_of_counter(const IndexView& ix, const uns
     c = (ix.kmer_of[p] & ~(3ull << sh)) | ((uint64_t)bb << sh);
 }
 
-// K2a: the V counters.  One thread per row of the reference k-mers' part (it walks the row's difference array, so each
-// k-mer's count is the running sum) and one per counter of the pseudo k-mers' part.  A kept non-reference k-mer almost
+// K2a: the V counters.  Half a wave per row of the reference k-mers' part (lane = offset; the running sums of the row's
+// difference array -- each k-mer's count -- by shuffles) and one thread per counter of the pseudo k-mers' part.  A kept non-reference k-mer almost
 // always touches exactly one window bucket (the one its name says); then the whole of map_kmers for it is: vote once per
 // BucketInfo of that bucket, and per genome file "variant" (or "perfect" if the file has exactly W entries there, which
 // needs W == 1 or repeats).  K-mers that touch several buckets need cross-bucket per-genome totals; they are appended
@@ -1085,10 +1086,33 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
     const uint64_t n_rows = v_real_rows(ix.n_full, ix.v_span);
     const uint64_t real_len = v_real_len(ix.n_full, ix.v_span);
     const uint32_t rl = (uint32_t)ix.v_span + 1u;
-    const uint64_t n_work = n_rows + ix.n_prows * 8ull;
     const unsigned long long* __restrict__ vc = a.counters + n_e;
     const KmerTable kt{a.ktab_keys, a.ktab_cnt, a.ktab_log2, a.ktab_overflow, a.mate};
     unsigned int kept = 0, distinct = 0;
+
+    // The k-mers of one row mostly vote for the same pileup cell (the reference position of the differing base): votes are
+    // gathered per (plane, cell) and written when the target changes -- #k-mers += votes, depth = max(depth, counts).
+    size_t acc_at[2] = {~(size_t)0, ~(size_t)0};
+    unsigned long long acc_n[2] = {0, 0}, acc_max[2] = {0, 0};
+    auto flush = [&](int f) {
+        if (acc_at[f] != ~(size_t)0) {
+            atomicAdd(a.pileup + (f ? 3 : 2) * a.plane + acc_at[f], acc_n[f]);   // #kmers
+            atomicMax(a.pileup + (f ? 1 : 0) * a.plane + acc_at[f], acc_max[f]); // depth
+        }
+        acc_at[f] = ~(size_t)0; acc_n[f] = 0; acc_max[f] = 0;
+    };
+    // the vote of call.rs:1327-1384 (see vote()), gathered
+    auto vote_acc = [&](const DevEntry& e, uint64_t c, uint32_t isrc, unsigned long long v) {
+        uint32_t bit_idx;
+        bool forward;
+        if (e.canonical) { bit_idx = ((uint32_t)(c >> (2 * e.idx)) & 3u) ^ 3u; forward = isrc != 0; }
+        else { bit_idx = (uint32_t)(c >> (2 * (k - 1 - e.idx))) & 3u; forward = isrc == 0; }
+        const size_t cell = (size_t)e.cell * 4 + bit_idx;
+        const int f = forward ? 0 : 1;
+        if (acc_at[f] != cell) { flush(f); acc_at[f] = cell; }
+        acc_n[f] += 1;
+        acc_max[f] = acc_max[f] > v ? acc_max[f] : v;
+    };
 
     // one kept k-mer: c = reference k-mer p with base changed at window position t, read in orientation isrc, n times
     auto map_one = [&](uint32_t p, uint32_t t, uint64_t c, uint32_t isrc, unsigned long long n, uint64_t vi) {
@@ -1108,50 +1132,149 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
                 return;
             }
         }
-        const uint32_t s = ix.slot_of[(size_t)p * ix.W + t];
-        const uint32_t off = ix.ent_off[s], cnt = ix.ent_len[s];
+        uint32_t off, cnt;
+        DevEntry first{};
+        if (p < ix.n_full) {
+            const uint4 r = *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)p * ix.W + t);
+            off = r.x; cnt = r.y;
+            first.cell = r.z; first.file = (uint16_t)(r.w & 0xffffu); first.idx = (uint8_t)(r.w >> 16); first.canonical = (uint8_t)(r.w >> 24);
+        } else {
+            const uint32_t s = ix.slot_of[(size_t)p * ix.W + t];
+            off = ix.ent_off[s]; cnt = ix.ent_len[s];
+            if (cnt) first = ix.entries[off];
+        }
         // entries of one bucket are grouped by file (index build appends file by file): run lengths = hits per file
         uint32_t n_perfect = 0, perfect_file = 0;
         for (uint32_t q = 0; q < cnt;) {
-            const uint32_t file = ix.entries[off + q].file;
+            DevEntry en = q ? ix.entries[off + q] : first;
+            const uint32_t file = en.file;
             uint32_t run = 0;
-            while (q < cnt && ix.entries[off + q].file == file) { vote(a, ix.entries[off + q], c, isrc, k, v); ++run; ++q; }
+            for (;;) {
+                vote_acc(en, c, isrc, v); ++run; ++q;
+                if (q >= cnt) break;
+                en = ix.entries[off + q];
+                if (en.file != file) break;
+            }
             if (run == (uint32_t)ix.W) { atomicAdd(&lstats[file * 3 + 0], 1u); ++n_perfect; perfect_file = file; }
             else atomicAdd(&lstats[file * 3 + 1], 1u);
         }
         if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
     };
 
-    for (uint64_t wk = (uint64_t)blockIdx.x * 256 + threadIdx.x; wk < n_work; wk += (uint64_t)gridDim.x * 256) {
-        if (wk >= n_rows) {   // a pseudo k-mer's counter
-            const uint64_t vi = real_len + (wk - n_rows);
-            if (vc[vi] == 0) continue;
-            uint32_t p, t, isrc; uint64_t c; unsigned long long n;
-            v_kmer_of_counter(ix, vc, vi, p, t, c, isrc, n);
-            map_one(p, t, c, isrc, n, vi);
-            continue;
+    // one half-wave (32 lanes) per row, lane oo = offset: the row's prefix sums by shuffles, then every lane maps its own
+    // k-mer.  The k-mers of a row mostly vote for the same pileup cell (the reference position of the differing base); when
+    // all single-entry votes of the row agree on (strand, cell) they are merged into one pair of atomics.
+    const uint32_t oo = threadIdx.x & 31u;
+    const int half = (threadIdx.x & 32u) ? 32 : 0;
+    for (uint64_t wk = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 5; wk < ((n_rows + 7) & ~7ull); wk += ((uint64_t)gridDim.x * 256) >> 5) {
+        const bool in_row = wk < n_rows && oo < rl;
+        unsigned long long n = in_row ? vc[wk * rl + oo] : 0ull;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            const unsigned long long t = __shfl_up(n, off, 32);
+            if (oo >= (uint32_t)off) n += t;
         }
         const uint32_t d = (uint32_t)wk & 1u, bf = (uint32_t)(wk >> 1) & 3u, q = (uint32_t)(wk >> 3);
-        unsigned long long n = 0;
-        for (uint32_t oo = 0; oo < (uint32_t)ix.v_span; ++oo) {
-            n += vc[wk * rl + oo];
-            if (n == 0 || q < oo || q - oo >= ix.n_full) continue;
-            const uint32_t p = q - oo;
-            const uint32_t rcid = (ix.amb[p] >> 1) & 1u;
-            const int o = (int)oo + ix.v_omin;
-            const int j = rcid ? k - 1 - o : o;
-            const uint32_t bb = rcid ? 3u - bf : bf;
-            const uint32_t isrc = d ^ rcid;
-            const int sh = 2 * (k - 1 - j);
-            const uint64_t c = (ix.kmer_of[p] & ~(3ull << sh)) | ((uint64_t)bb << sh);
-            const uint64_t rc = revcomp_kmer(c, k);
-            const bool alive = j >= ix.wstart && j < ix.wstart + ix.W && c < rc;
-            if (!alive) {
-                if (kt.keys) ktab_insert(kt, c < rc ? c : rc, c < rc ? isrc : isrc ^ 1u, (unsigned int)(n > 0xf0000000ull ? 0xf0000000ull : n));
-                continue;
-            }
-            map_one(p, (uint32_t)(j - ix.wstart), c, isrc, n, wk * rl + oo);
+        bool act = in_row && oo < (uint32_t)ix.v_span && n != 0 && q >= oo && q - oo < ix.n_full;
+        const uint32_t p = act ? q - oo : 0u;
+        const uint32_t rcid = (ix.amb[p] >> 1) & 1u;
+        const bool dirty = ix.amb[p] & 1u;
+        const int o = (int)oo + ix.v_omin;
+        const int j = rcid ? k - 1 - o : o;
+        const uint32_t bb = rcid ? 3u - bf : bf;
+        const uint32_t isrc = d ^ rcid;
+        const int sh = 2 * (k - 1 - (act ? j : 0));
+        const uint64_t c = (ix.kmer_of[p] & ~(3ull << sh)) | ((uint64_t)bb << sh);
+        const uint64_t rc = revcomp_kmer(c, k);
+        const bool alive = j >= ix.wstart && j < ix.wstart + ix.W && c < rc;
+        if (act && !alive) {
+            if (kt.keys) ktab_insert(kt, c < rc ? c : rc, c < rc ? isrc : isrc ^ 1u, (unsigned int)(n > 0xf0000000ull ? 0xf0000000ull : n));
+            act = false;
         }
+        if (act) { distinct += 1; if (n < a.ci || n > a.cx) act = false; else ++kept; }   // kmc -ci / -cx act on the true count
+        const unsigned long long v = n > a.cs ? a.cs : n;       // kmc -cs: reported count saturates
+        const uint32_t t = (uint32_t)(j - ix.wstart);
+        if (act && dirty) {
+            // u has another reference k-mer within Hamming distance 2: c may touch a second window bucket.  Enumerate its
+            // neighbours; several buckets -> general path (K2b)
+            uint32_t jmask = 0;
+            for_each_neighbour(ix, c, [&](int jj, uint32_t) { jmask |= 1u << (jj - ix.wstart); });
+            if (jmask != (1u << t)) {
+                const unsigned int at = atomicAdd(a.n_deferred, 1u);
+                a.deferred[at] = (uint32_t)(wk * rl + oo);
+                act = false;
+            }
+        }
+        const uint4 r = act ? *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)p * ix.W + t) : make_uint4(0, 0, 0, 0);
+        const uint32_t cnt = r.y;
+        DevEntry first;
+        first.cell = r.z; first.file = (uint16_t)(r.w & 0xffffu); first.idx = (uint8_t)(r.w >> 16); first.canonical = (uint8_t)(r.w >> 24);
+        // single-entry bucket: the vote of call.rs:1327-1384 (see vote()), merged across the row when possible
+        const bool single = act && cnt == 1u;
+        uint32_t bit_idx;
+        bool forward;
+        if (first.canonical) { bit_idx = ((uint32_t)(c >> (2 * first.idx)) & 3u) ^ 3u; forward = isrc != 0; }
+        else { bit_idx = (uint32_t)(c >> (2 * (k - 1 - first.idx))) & 3u; forward = isrc == 0; }
+        const unsigned long long key = single ? (((unsigned long long)first.cell * 4 + bit_idx) << 1) | (forward ? 0ull : 1ull) : ~0ull;
+        uint32_t rem = (uint32_t)(__ballot(single) >> half);   // single-entry votes of this row not yet cast (uniform within the half-wave)
+        const uint32_t me = 1u << oo;
+        if (rem) {
+            // per-genome tallies: one hit per k-mer in that genome ("variant" unless the window is a single bucket), merged
+            // over the lanes that share the first one's genome
+            const int lf = half + __builtin_ctz(rem);
+            const bool samef = single && first.file == (uint16_t)__shfl((int)first.file, lf);
+            const uint32_t nf = (uint32_t)__popc((uint32_t)(__ballot(samef) >> half));
+            const uint32_t add = samef ? ((int)(threadIdx.x & 63u) == lf ? nf : 0u) : (single ? 1u : 0u);
+            if (add) {
+                if (ix.W == 1) { atomicAdd(&lstats[first.file * 3 + 0], add); atomicAdd(&lstats[first.file * 3 + 2], add); }
+                else atomicAdd(&lstats[first.file * 3 + 1], add);
+            }
+        }
+        // k-mers that are canonical as written all vote for the reference position of the differing base; merge equal targets
+        // (two rounds catch that group whichever lane comes first), the rest vote one by one
+        for (int round = 0; round < 2 && rem; ++round) {
+            const int leader = half + __builtin_ctz(rem);
+            const unsigned long long lkey = __shfl(key, leader);
+            const bool same = (rem & me) && key == lkey;
+            unsigned long long vm = same ? v : 0ull;
+#pragma unroll
+            for (int off = 16; off; off >>= 1) { const unsigned long long o2 = __shfl_xor(vm, off, 32); vm = vm > o2 ? vm : o2; }
+            const uint32_t sm = (uint32_t)(__ballot(same) >> half);
+            if ((int)(threadIdx.x & 63u) == leader) {
+                const size_t cell = (size_t)(key >> 1);
+                atomicAdd(a.pileup + ((key & 1ull) ? 3 : 2) * a.plane + cell, (unsigned long long)__popc(sm));   // #kmers
+                atomicMax(a.pileup + ((key & 1ull) ? 1 : 0) * a.plane + cell, vm);                               // depth
+            }
+            rem &= ~sm;
+        }
+        if (rem & me) vote(a, first, c, isrc, k, v);
+        if (act && cnt > 1u) {
+            // entries of one bucket are grouped by file (index build appends file by file): run lengths = hits per file
+            uint32_t n_perfect = 0, perfect_file = 0;
+            for (uint32_t x = 0; x < cnt;) {
+                DevEntry en = x ? ix.entries[r.x + x] : first;
+                const uint32_t file = en.file;
+                uint32_t run = 0;
+                for (;;) {
+                    vote(a, en, c, isrc, k, v); ++run; ++x;
+                    if (x >= cnt) break;
+                    en = ix.entries[r.x + x];
+                    if (en.file != file) break;
+                }
+                if (run == (uint32_t)ix.W) { atomicAdd(&lstats[file * 3 + 0], 1u); ++n_perfect; perfect_file = file; }
+                else atomicAdd(&lstats[file * 3 + 1], 1u);
+            }
+            if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
+        }
+    }
+    // the pseudo k-mers' counters (k = 31 only), one thread each
+    for (uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x; x < ix.n_prows * 8ull; x += (uint64_t)gridDim.x * 256) {
+        const uint64_t vi = real_len + x;
+        if (vc[vi] == 0) continue;
+        uint32_t p, t, isrc; uint64_t c; unsigned long long n;
+        v_kmer_of_counter(ix, vc, vi, p, t, c, isrc, n);
+        map_one(p, t, c, isrc, n, vi);
+        flush(0); flush(1);
     }
     __syncthreads();
     finalize_epilogue(a, lstats, kept, distinct, lstats + ix.n_files * 3, (int)blockIdx.x);
@@ -1180,9 +1303,17 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
         const unsigned long long v = n > a.cs ? a.cs : n;       // kmc -cs: reported count saturates
         const uint32_t id = (uint32_t)(cidx >> 1), isrc = (uint32_t)cidx & 1u;
         const uint64_t c = ix.kmer_of[id];
-        const uint32_t s = ix.slot_of[(size_t)id * W + t];
-        const uint32_t off = ix.ent_off[s], cnt = ix.ent_len[s];
-        for (uint32_t q = 0; q < cnt; ++q) vote(a, ix.entries[off + q], c, isrc, k, v);
+        if (id < ix.n_full) {
+            const uint4 r = *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)id * W + t);
+            DevEntry first;
+            first.cell = r.z; first.file = (uint16_t)(r.w & 0xffffu); first.idx = (uint8_t)(r.w >> 16); first.canonical = (uint8_t)(r.w >> 24);
+            if (r.y) vote(a, first, c, isrc, k, v);
+            for (uint32_t q = 1; q < r.y; ++q) vote(a, ix.entries[r.x + q], c, isrc, k, v);
+        } else {
+            const uint32_t s = ix.slot_of[(size_t)id * W + t];
+            const uint32_t off = ix.ent_off[s], cnt = ix.ent_len[s];
+            for (uint32_t q = 0; q < cnt; ++q) vote(a, ix.entries[off + q], c, isrc, k, v);
+        }
         if (t == 0) {
             ++kept;
             uint32_t n_perfect = 0, perfect_file = 0;
@@ -1289,7 +1420,7 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     FinalizeArgs a = a0;
     const size_t lds_stats = ((size_t)a.ix.n_files * 3 + 2) * sizeof(uint32_t);
     // K2a
-    const uint64_t n_v = v_real_rows(a.ix.n_full, a.ix.v_span) + a.ix.n_prows * 8ull;   // work items of K2a
+    const uint64_t n_v = std::max<uint64_t>(v_real_rows(a.ix.n_full, a.ix.v_span) * 32ull, a.ix.n_prows * 8ull);   // threads K2a can use
     const unsigned b_var = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_v + 255) / 256, kFinVariantBlocks));
     hipLaunchKernelGGL(finalize_variant_kernel, dim3(b_var), dim3(256), lds_stats, stream, a);
     // K2e

@@ -407,7 +407,8 @@ struct SlowPipe {
     }
 };
 
-template <bool REF_LDS, bool STATS>
+// KT: k as a compile-time constant for the common sizes (the window loop of Level 1 unrolls), 0 = any k
+template <bool REF_LDS, bool STATS, int KT>
 __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* queue_c = reinterpret_cast<unsigned long long*>(smem);
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     const unsigned int* yfw = a.cell_yf + kRefPadWords;   // batches only (global memory, L1 / L2 cached)
     const unsigned int* yrw = a.cell_yr + kRefPadWords;
 
-    const int k = a.k;
+    const int k = KT ? KT : a.k;
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;  // k <= 31
     // 2k-bit values are kept as explicit 32-bit halves: 64-bit shifts and compares are slow-rate VALU ops
     const uint32_t kmask_lo = (uint32_t)kmask, kmask_hi = (uint32_t)(kmask >> 32);
@@ -497,6 +498,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     int32_t dg = 0, pdg = 0;            // cell of the reference k-mer aligned with read k-mer 0: k-mer s <-> dg + s (fwd) / dg - s
     uint32_t dfl = 0, pdfl = 0;         // bit 0: same strand as the reference; bit 1: the diagonal is known ("seeded")
     uint32_t parity = 0;                // wave-uniform: parity of the current tile
+    uint32_t pf_sink = 0;               // destination of the prefetch loads (never read)
     uint32_t olds = 0, oldg = 0;        // wave-uniform: queued runs that belong to the previous tile (they are at the front)
 
     for (uint64_t tile = (uint64_t)blockIdx.x * kScanWaves + wave;; tile += (uint64_t)gridDim.x * kScanWaves) {
@@ -515,6 +517,13 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
         maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxlen);
         const uint32_t* __restrict__ w = words0 + (uint64_t)r32 * a.stride_words;
         nkm += len ? len - km1 : 0u;
+        {   // touch the next tile's records (one lane per 128-byte line) so that its seed loads find them in cache
+            const uint64_t nt = tile + (uint64_t)gridDim.x * kScanWaves;
+            const uint64_t first = nt * 64ull * a.stride_words, words_tile = 64ull * a.stride_words;
+            const uint64_t at = first + (uint64_t)lane * 32ull;
+            if (nt < n_tiles && (uint64_t)lane * 32ull < words_tile && at < n_records * a.stride_words)
+                asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink) : "v"(words0 + at) : "memory");
+        }
 
         // ---- seeds -> diagonal ----------------------------------------------------------------------------------
         bool fwd = true, seeded = false, l1ok = false;   // seeded: diagonal known; l1ok: ... and all its cells are in the LDS array
@@ -824,10 +833,17 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 // A: some mismatch among the k bases that end at step b; B: at least two.  The flags of base i0 + b - t sit
                 // at bit 48 + b - t of (h_hi : h_lo)
                 uint32_t A = 0, B = 0;
-                for (int t = 0; t < k; ++t) {
-                    const uint32_t st = t <= 16 ? h_hi >> (16 - t) : __builtin_amdgcn_alignbit(h_hi, h_lo, (uint32_t)(48 - t));
-                    B |= A & st;
-                    A |= st;
+                if (KT) {
+#pragma unroll
+                    for (int t = 0; t < (KT ? KT : 1); ++t) {
+                        const uint32_t st = t <= 16 ? h_hi >> (16 - t) : __builtin_amdgcn_alignbit(h_hi, h_lo, (uint32_t)(48 - t));
+                        B |= A & st;
+                        A |= st;
+                    }
+                } else {
+                    const int k1 = min(k, 17);
+                    for (int t = 0; t < k1; ++t) { const uint32_t st = h_hi >> (16 - t); B |= A & st; A |= st; }
+                    for (int t = 17; t < k; ++t) { const uint32_t st = __builtin_amdgcn_alignbit(h_hi, h_lo, (uint32_t)(48 - t)); B |= A & st; A |= st; }
                 }
                 E16 = ~A & HAS16 & VAL16;
                 S16 = A & ~B & CLEAN16 & VAL16;
@@ -845,6 +861,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
         }
         if (fin) break;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(pf_sink) : "memory");   // the prefetch register stays reserved up to here
     pipe.finish(ix, v_counters, count_exact, kt);
     if (qn) {
         pipe.start(q, qn, lane, ix);   // qn < 64
@@ -904,8 +921,11 @@ hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t strea
     if (a.n_records > scan_max_records(grid)) return hipErrorInvalidValue;
     const size_t lds = scan_lds_bytes(a.n_lds_bins, a.ref_in_lds != 0, a.total_cells);
     const bool stats = a.ktab_keys != nullptr;
-    void (*kern)(ScanArgs) = a.ref_in_lds ? (stats ? scan_count_kernel<true, true> : scan_count_kernel<true, false>)
-                                          : (stats ? scan_count_kernel<false, true> : scan_count_kernel<false, false>);
+    void (*kern)(ScanArgs);
+#define BK_PICK(KT) (a.ref_in_lds ? (stats ? scan_count_kernel<true, true, KT> : scan_count_kernel<true, false, KT>) \
+                                  : (stats ? scan_count_kernel<false, true, KT> : scan_count_kernel<false, false, KT>))
+    kern = a.k == 21 ? BK_PICK(21) : a.k == 31 ? BK_PICK(31) : BK_PICK(0);
+#undef BK_PICK
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kScanBlock), lds, stream, a);

@@ -484,6 +484,17 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     SlowPipe pipe;
     const IndexView& ix = *a.ixp;
 
+    auto start_slow_batch = [&]() {
+        const uint32_t nb = min(qn, 64u);
+        pipe.start(q, nb, lane, ix);
+        const uint32_t rest = qn - nb;
+        const unsigned long long tc = ((uint32_t)lane < rest) ? q[64 + lane] : 0ull;
+        __builtin_amdgcn_wave_barrier();
+        if ((uint32_t)lane < rest) q[lane] = tc;
+        __builtin_amdgcn_wave_barrier();
+        qn = rest;
+    };
+
     uint64_t n_records = a.n_records;
     if (a.n_records_dev) {
         const uint64_t nd = *a.n_records_dev;
@@ -693,17 +704,10 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                         __builtin_amdgcn_wave_barrier();
                     }
                     if (qn >= 32u) {
-                        // enough for a batch: retire the batch in flight (its loads were issued steps ago), then take up to
-                        // 64 k-mers off the queue and issue the first loads of the new batch
+                        // enough for a batch: retire the batch in flight (it advanced with the steps / words since), then take
+                        // up to 64 k-mers off the queue and issue the first loads of the new batch
                         pipe.finish(ix, v_counters, count_exact, kt);
-                        const uint32_t nb = min(qn, 64u);
-                        pipe.start(q, nb, lane, ix);
-                        const uint32_t rest = qn - nb;
-                        const unsigned long long tc = ((uint32_t)lane < rest) ? q[64 + lane] : 0ull;
-                        __builtin_amdgcn_wave_barrier();
-                        if ((uint32_t)lane < rest) q[lane] = tc;
-                        __builtin_amdgcn_wave_barrier();
-                        qn = rest;
+                        start_slow_batch();
                     } else if (pipe.stage) {
                         pipe.advance(ix, v_counters, count_exact, kt);
                     }
@@ -809,6 +813,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
             }
             if (words_done) break;
             // ================= Level 1: one read word = 16 bases =================================================
+            if (pipe.stage) pipe.advance(ix, v_counters, count_exact, kt);   // the slow path's loads fly while Level 1 works
+            else if (qn >= 32u) start_slow_batch();
             {
                 const uint32_t x = xn;
                 xn = (i0 + 16u < len) ? w[(i0 >> 4) + 1u] : 0u;

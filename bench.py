@@ -125,10 +125,12 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure is the
     # one measured with rocprofv3 (separate --pmc passes) on this workload and committed under profiles/
     traffic = None
+    valu_insts = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if tj.get("workload_reads") == args.reads and tj.get("read_len") == args.read_len and not args.ref_len:
             traffic = tj["traffic_bytes_per_launch"]
+            valu_insts = tj.get("valu_wave_insts_per_launch")
     except (OSError, ValueError, KeyError):
         pass
 
@@ -157,7 +159,11 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "scan_count_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "avg_kernel_ms": scan_ms, "launches": kn[0],
-                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_READ * args.reads},
+                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_READ * args.reads,
+                     # the kernel is VALU-issue bound, not HBM bound: wave-instructions per launch from
+                     # the committed PMC pass; a wave64 VALU instruction occupies one of the chip's 1024 SIMDs for 4 cycles
+                     "valu_wave_insts_per_launch": valu_insts,
+                     "valu_busy_frac": (valu_insts * 4 / (1024 * 2.4e9) / (scan_ms * 1e-3)) if valu_insts and scan_ms > 0 else None},
         "kernels_ms": {"scan_count": scan_ms, "finalize": fin_ms, "memset_copy": kms[2] / max(kn[2], 1),
                        "fold": kms[3] / max(kn[3], 1)},
         "check": {"perfect_kmers": int(res.stats[0, 0, 0]), "variant_kmers": int(res.stats[0, 0, 1]),

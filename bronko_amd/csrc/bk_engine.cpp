@@ -217,6 +217,7 @@ struct bk_engine {
     uint64_t pushed_records[2] = {0, 0};
 
     int ablate = 0;   // BK_SCAN_ABLATE (measurement aid): see scan_count_kernel
+    uint64_t max_launch_records = 0;   // BK_MAX_LAUNCH_RECORDS (testing aid): split pushes into launches of at most this many records
     bool timing = false;
     std::vector<TimedSpan> spans;
     std::vector<hipEvent_t> free_events;
@@ -720,6 +721,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     BK_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
     if (const char* ab = getenv("BK_SCAN_ABLATE")) e->ablate = atoi(ab);
+    if (const char* ml = getenv("BK_MAX_LAUNCH_RECORDS")) e->max_launch_records = strtoull(ml, nullptr, 10);
     *out = e.release();
     return BK_OK;
 }
@@ -793,7 +795,8 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     // a launch takes at most scan_max_records records (bound on what one workgroup's 16-bit LDS bins can receive)
     for (uint64_t base = 0; base < n;) {
         const uint32_t grid = bk::scan_grid(n - base, e->n_cus);
-        const uint64_t take = std::min<uint64_t>(n - base, bk::scan_max_records(grid));
+        uint64_t take = std::min<uint64_t>(n - base, bk::scan_max_records(grid));
+        if (e->max_launch_records) take = std::min<uint64_t>(take, e->max_launch_records);
         a.rec_base = base; a.n_records = take;
         {
             bk_engine::Span sp(e, 0);

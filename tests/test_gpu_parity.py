@@ -350,3 +350,74 @@ def test_k31_four_sarscov2_strains(oracle, sars_paths):
     assert oracle.pick_best_genome(ix, res.stats[0], res.present[0]) == 2
     eng.close()
     ix.close()
+
+
+def test_counter_planes_of_read_shards_add_up(oracle, hpv):
+    """The multi-GPU identity on one device: two engines take the two halves of a sample, the
+    second engine's counter planes (difference arrays, wrapping u64) are added into the first's -- what the RCCL
+    all-reduce does across ranks -- and finalize of the sum equals the oracle on all reads, both mates."""
+    import torch
+    ix, _ = hpv
+
+    class _Dev:   # __cuda_array_interface__ view of a device pointer (as bench.py)
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+
+    gm, isnv = synth.sample_genome(synth.read_fasta_bytes(os.path.join(helpers.GOLDEN, "HPV16.fa")), 31)
+    c1, c2 = synth.paired_codes(gm, 6000, 150, 31, isnv=isnv)
+    mates = [synth.codes_to_ascii(c1), synth.codes_to_ascii(c2)]
+    pile = oracle.sample_pileup(ix, mates)
+    from bronko_amd import pack_reads
+    engs = [helpers.engine_from_oracle_index(ix) for _ in range(2)]
+    for e in engs:
+        e.sample_begin()
+    for m, reads in enumerate(mates):
+        half = len(reads) // 3   # uneven shards
+        for e, part in zip(engs, (reads[:half], reads[half:])):
+            w, l = pack_reads(part, 21)
+            e.push_reads(m, w, l)
+    torch.cuda.synchronize()
+    for m in range(2):
+        a = torch.as_tensor(_Dev(engs[0].counters_ptr(m), engs[0].counter_len), device="cuda:0")
+        b = torch.as_tensor(_Dev(engs[1].counters_ptr(m), engs[1].counter_len), device="cuda:0")
+        a += b
+    torch.cuda.synchronize()
+    res = engs[0].sample_finish(2)
+    helpers.assert_same_pileup(res, pile)
+    for e in engs:
+        e.close()
+
+
+def test_a_push_split_into_several_launches(oracle, hpv, monkeypatch):
+    """Large pushes are cut into launches of bounded size (the 16-bit halves of the LDS difference array bound the records
+    one workgroup may see); BK_MAX_LAUNCH_RECORDS forces the same splitting at test size, also for device-side packing
+    where the record count is only known on the device."""
+    ix, _ = hpv
+    reads = helpers.hpv_reads(5000, seed=77, with_n=True)
+    pile = oracle.sample_pileup(ix, [reads])
+    monkeypatch.setenv("BK_MAX_LAUNCH_RECORDS", "1100")
+    eng = helpers.engine_from_oracle_index(ix)
+    monkeypatch.delenv("BK_MAX_LAUNCH_RECORDS")
+    helpers.assert_same_pileup(helpers.hip_sample(eng, [reads], 21), pile)
+    helpers.assert_same_pileup(helpers.hip_sample(eng, [reads], 21, ascii_path=True), pile)
+    eng.close()
+
+
+def test_reverse_complement_repeats(oracle):
+    """A genome that contains the reverse complement of one of its own segments: the same canonical k-mers occur on both
+    strands, so cells of the second copy do not stand in the orientation of their k-mers' first occurrence (such cells are
+    not "clean": the V rows are laid out by the first occurrence) and exact hits on it land on ids seen before."""
+    r = synth.splitmix64(4242, 4000)
+    g = bytes(synth.BASES[int(x) & 3] for x in r)
+    seg = g[600:1100]
+    rc = seg[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+    genome = g[:2500] + rc + g[2500:]
+    files = [("inv", [("inv1", genome)])]
+    ix = oracle.Index.build_mem(21, files)
+    gm, isnv = synth.sample_genome(genome, 8)
+    reads = synth.codes_to_ascii(synth.single_end_codes(gm, 20000, 150, 18, isnv=isnv, err=0.01))
+    pile = oracle.sample_pileup(ix, [reads])
+    eng = helpers.engine_from_oracle_index(ix)
+    helpers.assert_same_pileup(helpers.hip_sample(eng, [reads], 21), pile)
+    eng.close()
+    ix.close()

@@ -45,7 +45,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1000000, help="reads per pass timed through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--cpu-passes", type=int, default=4, help="passes of the CPU oracle over the sample (about 10 s in total)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allreduce", action="store_true", help="N > 1: all-reduce the counter plane instead of reduce-scatter + sharded finalize")
     ap.add_argument("--ref-len", type=int, default=0, help="experiment: truncate the reference to its first N bases")
+    ap.add_argument("--backend", default="nccl", help="testing aid: 'gloo' lets several ranks share one GPU (rank r uses GPU r mod #GPUs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -53,16 +55,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
+    if args.backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from bronko_amd import Params, synth
-    from bronko_amd.dist import allreduce_counters
+    from bronko_amd.dist import allreduce_counters, sharded_finalize
     from bronko_amd.hostlib import HostIndex
 
     k = 21
@@ -88,9 +95,16 @@ def main():
     eng.set_stream(stream.cuda_stream)
     counters = torch.as_tensor(_DevArray(eng.counters_ptr(0), eng.counter_len, "<i8"), device=dev)
 
+    # N > 1: reduce-scatter of the counter plane + each rank maps its part + max / sum of the small pileups (the cheap form,
+    # include/bronko_hip.h); --allreduce selects the plain form (all-reduce the plane, every rank maps everything)
+    sharded = world > 1 and not args.allreduce and 64 % world == 0
+
     def step():
         eng.sample_begin()
         eng.push_reads_device(0, d_words.data_ptr(), stride, d_lens.data_ptr(), n_rec)
+        if sharded:
+            sharded_finalize(eng, 1, rank, world, dev)   # RCCL over xGMI: reduce-scatter(sum) + 3 small all-reduces
+            return
         if world > 1:
             allreduce_counters(counters)   # RCCL over xGMI: ONE all-reduce(sum) of the u64 k-mer occurrence counters
         eng.sample_finalize(1)
@@ -154,7 +168,9 @@ def main():
                                "%d synthetic %d bp single-end reads per GPU per step, 0.5%% substitution errors, seed 2"
                                % (args.reads, args.read_len),
                    "reads_per_gpu": args.reads, "read_len": args.read_len, "k": k,
-                   "parallelism": "reads sharded over %d GPU(s); RCCL all-reduce(sum) of k-mer counters" % world
+                   "parallelism": ("reads sharded over %d GPU(s); RCCL reduce-scatter(sum) of the k-mer counter plane, sharded finalize, "
+                                   "all-reduce(max / sum) of the pileups" if sharded else
+                                   "reads sharded over %d GPU(s); RCCL all-reduce(sum) of k-mer counters") % world
                    if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": "scan_count_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -27,6 +27,7 @@ class Params(C.Structure):
 SYMBOLS = ["bk_abi_version", "bk_last_error", "bk_params_default", "bk_engine_create", "bk_engine_destroy",
            "bk_engine_set_stream", "bk_total_cells", "bk_n_files", "bk_n_slots", "bk_counter_len", "bk_sample_begin",
            "bk_push_reads_packed", "bk_push_reads_packed_device", "bk_push_reads_ascii", "bk_counters_device_ptr", "bk_sample_finalize",
+           "bk_sample_finalize_shard", "bk_shard_sums_device_ptr", "bk_sample_merge_shards",
            "bk_pileup_device_ptr", "bk_sample_download", "bk_sample_finish", "bk_pack_reads", "bk_pack_reads_flat",
            "bk_timing_enable", "bk_timing_read"]
 
@@ -65,6 +66,12 @@ def load():
     L.bk_counters_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.bk_sample_finalize.restype = C.c_int
     L.bk_sample_finalize.argtypes = [vp, C.c_int]
+    L.bk_sample_finalize_shard.restype = C.c_int
+    L.bk_sample_finalize_shard.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.bk_shard_sums_device_ptr.restype = C.c_int
+    L.bk_shard_sums_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    L.bk_sample_merge_shards.restype = C.c_int
+    L.bk_sample_merge_shards.argtypes = [vp]
     L.bk_pileup_device_ptr.restype = C.c_int
     L.bk_pileup_device_ptr.argtypes = [vp, C.POINTER(vp)]
     L.bk_sample_download.restype = C.c_int

@@ -123,6 +123,7 @@ struct IndexView {
     const uint32_t*  prow_id;     // [n_prows] id of the pseudo k-mer that owns pseudo V row i
     const uint8_t*   prow_t;      //   ... and the window position t of that row
     int32_t  v_omin, v_span;      // layout of the reference k-mers' V counters (see v_row_base)
+    uint64_t v_off;               // element of the counter plane at which the V part starts (see counter_plane_layout)
     const uint16_t*  pilots;   // [1 << log2nb]
     HalfView         lo, hi;
     const uint32_t*  slot_of;  // [n_u][W] window bucket (slot) of reference k-mer id at window position t
@@ -176,5 +177,15 @@ BK_HD uint64_t v_real_len(uint32_t n_full, int span) { return v_real_rows(n_full
 // first counter of row (q, b, d); the row has span + 1 counters (the last only ever receives a -1)
 BK_HD uint64_t v_row_base(uint32_t q, uint32_t b, uint32_t d, int span) { return (((uint64_t)q * 4ull + b) * 2ull + d) * (uint64_t)(span + 1); }
 BK_HD uint64_t v_plane_len(uint32_t n_full, int span, uint64_t n_prows) { return v_real_len(n_full, span) + n_prows * 8ull; }
+// The whole plane: [ E | padding | V rows | pseudo counters | padding ].  The V part starts at a multiple of the row length
+// and the total is a multiple of kMaxShards row lengths, so that cutting the plane into n equal parts (n dividing kMaxShards:
+// what a reduce-scatter over n ranks leaves on each) never cuts a row.
+constexpr uint32_t kMaxShards = 64;
+BK_HD void counter_plane_layout(uint32_t n_u, uint32_t n_full, int span, uint64_t n_prows, uint64_t& v_off, uint64_t& total) {
+    const uint64_t rl = (uint64_t)(span > 0 ? span + 1 : 1);
+    v_off = (e_plane_len(n_u) + rl - 1) / rl * rl;
+    const uint64_t unit = rl * kMaxShards;
+    total = (v_off + v_plane_len(n_full, span, n_prows) + unit - 1) / unit * unit;
+}
 
 }  // namespace bk

@@ -162,6 +162,8 @@ struct bk_engine {
     uint32_t log2s = 4, log2nb = 0, m = 1, n_u = 0, n_full = 0, n_lds_bins = 0;
     uint64_t n_prows = 0;  // V rows of the pseudo k-mers (bk_device.h)
     int v_omin = 0, v_span = 0;
+    uint64_t v_off = 0, plane_len = 0;      // counter_plane_layout (bk_device.h)
+    DevBuf<unsigned long long> shard_sums;  // sharded finalize: [stats 2*n_files*3 | present 2*n_files | kstats 8]
     DevBuf<uint32_t> prow_id;
     DevBuf<uint8_t> prow_t;
     bool ref_in_lds = false;
@@ -226,7 +228,7 @@ struct bk_engine {
         bk::IndexView v{};
         v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb;
         v.kmer_of = kmer_of.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
-        v.n_full = n_full; v.n_prows = n_prows; v.prow_id = prow_id.p; v.prow_t = prow_t.p; v.v_omin = v_omin; v.v_span = v_span;
+        v.n_full = n_full; v.n_prows = n_prows; v.prow_id = prow_id.p; v.prow_t = prow_t.p; v.v_omin = v_omin; v.v_span = v_span; v.v_off = v_off;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb};
         v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.slot_rec = slot_rec.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
@@ -515,6 +517,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             }
             e->n_prows = rows;
             if (bk::v_plane_len(e->n_full, e->v_span, rows) >= (1ull << 32)) return fail(BK_ERR_UNSUPPORTED, "index too large: variant counter plane exceeds 2^32 counters");
+            bk::counter_plane_layout(e->n_u, e->n_full, e->v_span, rows, e->v_off, e->plane_len);
             if (h_prow_id.empty()) { h_prow_id.push_back(0); h_prow_t.push_back(0); }
             BK_HIP(e->prow_id.upload(h_prow_id));
             BK_HIP(e->prow_t.upload(h_prow_t));
@@ -698,7 +701,8 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     BK_HIP(e->ent_off.upload(h_off));
     BK_HIP(e->ent_len.upload(h_len));
     BK_HIP(e->entries.upload(h_ent));
-    for (int m = 0; m < 2; m++) BK_HIP(e->counters[m].alloc(bk::e_plane_len(e->n_u) + bk::v_plane_len(e->n_full, e->v_span, e->n_prows)));
+    for (int m = 0; m < 2; m++) BK_HIP(e->counters[m].alloc(e->plane_len));
+    BK_HIP(e->shard_sums.alloc((size_t)2 * e->n_files * 5 + 8));
     if (prm->full_kmer_stats) {
         if (prm->kmer_table_log2 < 10 || prm->kmer_table_log2 > 31) return fail(BK_ERR_INVALID, "kmer_table_log2 out of range");
         BK_HIP(e->ktab_keys.alloc((size_t)1 << prm->kmer_table_log2));
@@ -753,7 +757,7 @@ int bk_engine_set_stream(bk_engine* e, void* hip_stream) {
 uint64_t bk_total_cells(const bk_engine* e) { return e ? e->total_cells : 0; }
 int32_t bk_n_files(const bk_engine* e) { return e ? e->n_files : 0; }
 uint64_t bk_n_slots(const bk_engine* e) { return e ? e->n_slots : 0; }
-uint64_t bk_counter_len(const bk_engine* e) { return e ? bk::e_plane_len(e->n_u) + bk::v_plane_len(e->n_full, e->v_span, e->n_prows) : 0; }
+uint64_t bk_counter_len(const bk_engine* e) { return e ? e->plane_len : 0; }
 
 int bk_sample_begin(bk_engine* e) {
     if (!e) return fail(BK_ERR_INVALID, "null engine");
@@ -780,7 +784,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     bk::ScanArgs a{};
     a.n_records_dev = n_records_dev;
     a.ixp = e->d_view.p;
-    a.k = e->k; a.wstart = e->wstart; a.W = e->W; a.v_omin = e->v_omin; a.v_span = e->v_span; a.total_cells = (uint32_t)e->total_cells; a.n_u = e->n_u;
+    a.k = e->k; a.wstart = e->wstart; a.W = e->W; a.v_omin = e->v_omin; a.v_span = e->v_span; a.v_off = e->v_off; a.total_cells = (uint32_t)e->total_cells; a.n_u = e->n_u;
     a.ref_words = e->ref_words.p; a.cell_codes = e->cell_codes.p; a.cell_has = e->cell_has.p; a.cell_clean = e->cell_clean.p; a.cell_yf = e->cell_yf.p; a.cell_yr = e->cell_yr.p; a.id_at = e->id_at.p;
     a.words = d_words; a.lens = d_lens; a.n_records = n; a.stride_words = stride_words;
     a.counters = e->counters[mate].p;
@@ -925,8 +929,7 @@ int bk_pileup_device_ptr(bk_engine* e, void** d_ptr) {
     return BK_OK;
 }
 
-int bk_sample_finalize(bk_engine* e, int n_mates) {
-    if (!e) return fail(BK_ERR_INVALID, "null engine");
+static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t elem_hi) {
     if (!e->in_sample) return fail(BK_ERR_STATE, "bk_sample_finalize called before bk_sample_begin");
     if (n_mates < 1 || n_mates > 2) return fail(BK_ERR_INVALID, "n_mates must be 1 or 2");
     BK_HIP(hipSetDevice(e->device));
@@ -934,6 +937,7 @@ int bk_sample_finalize(bk_engine* e, int n_mates) {
         bk::FinalizeArgs a{};
         a.ix = e->view();
         a.counters = e->counters[m].p;
+        a.elem_lo = elem_lo; a.elem_hi = elem_hi;
         a.ci = e->params.ci; a.cs = e->params.cs; a.cx = e->params.cx;
         a.pileup = e->pileup.p;
         a.plane = (size_t)e->total_cells * 4;
@@ -956,6 +960,39 @@ int bk_sample_finalize(bk_engine* e, int n_mates) {
     }
     BK_HIP(hipGetLastError());
     e->in_sample = false;
+    return BK_OK;
+}
+
+int bk_sample_finalize(bk_engine* e, int n_mates) {
+    if (!e) return fail(BK_ERR_INVALID, "null engine");
+    return finalize_part(e, n_mates, 0, e->plane_len);
+}
+
+int bk_sample_finalize_shard(bk_engine* e, int n_mates, int shard, int n_shards) {
+    if (!e) return fail(BK_ERR_INVALID, "null engine");
+    if (n_shards < 1 || (int)bk::kMaxShards % n_shards != 0 || shard < 0 || shard >= n_shards)
+        return fail(BK_ERR_INVALID, "n_shards must divide %u and 0 <= shard < n_shards", bk::kMaxShards);
+    if (e->ktab_keys.p && n_shards > 1) return fail(BK_ERR_UNSUPPORTED, "full_kmer_stats is single-GPU only");
+    const uint64_t part = e->plane_len / (uint64_t)n_shards;
+    int rc = finalize_part(e, n_mates, part * shard, part * (shard + 1));
+    if (rc != BK_OK) return rc;
+    bk::launch_pack_sums(e->shard_sums.p, e->stats.p, e->present.p, e->kstats.p, e->n_files, e->stream);
+    BK_HIP(hipGetLastError());
+    return BK_OK;
+}
+
+int bk_shard_sums_device_ptr(bk_engine* e, void** d_ptr, uint64_t* len) {
+    if (!e || !d_ptr || !len) return fail(BK_ERR_INVALID, "null argument");
+    *d_ptr = e->shard_sums.p;
+    *len = (uint64_t)2 * e->n_files * 5 + 8;
+    return BK_OK;
+}
+
+int bk_sample_merge_shards(bk_engine* e) {
+    if (!e) return fail(BK_ERR_INVALID, "null engine");
+    BK_HIP(hipSetDevice(e->device));
+    bk::launch_unpack_sums(e->shard_sums.p, e->stats.p, e->present.p, e->kstats.p, e->n_files, e->stream);
+    BK_HIP(hipGetLastError());
     return BK_OK;
 }
 

@@ -9,7 +9,8 @@ namespace bk {
 struct ScanArgs {
     const IndexView* ixp;           // device copy of the index view: only the rare paths of scan_count read it
     // what the hot path needs (kept in kernel-argument registers)
-    int32_t k, wstart, W, v_omin, v_span;   // v_*: IndexView::v_omin / v_span
+    int32_t k, wstart, W, v_omin, v_span;   // v_*: IndexView::v_omin / v_span / v_off
+    uint64_t v_off;
     uint32_t total_cells, n_u;
     const uint32_t* ref_words;      // IndexView::ref_words / cell_codes (both with scan_ref_pad_words() words of front padding)
     const uint32_t* cell_codes;
@@ -42,6 +43,7 @@ struct ScanArgs {
 struct FinalizeArgs {
     IndexView ix;
     const unsigned long long* counters;
+    uint64_t elem_lo, elem_hi;      // finalize the counters [elem_lo, elem_hi) of the plane only (a whole number of V rows)
     unsigned long long ci, cs, cx;
     unsigned long long* pileup;     // 4 planes of `plane` u64: fwd depth, rev depth, fwd #kmers, rev #kmers
     size_t plane;                   // total_cells * 4
@@ -99,6 +101,11 @@ void launch_fold(const FoldArgs& f, hipStream_t stream);
 void launch_ktab_stats(const unsigned long long* keys, const unsigned int* cnt, uint32_t log2n, unsigned long long ci,
                        unsigned long long cx, unsigned long long* out, hipStream_t stream);
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
+// shard_sums <-> {stats, present, kstats}: the small additive results of a sharded finalize as one u64 vector
+void launch_pack_sums(unsigned long long* sums, const unsigned long long* stats, const unsigned char* present, const unsigned long long* kstats,
+                      int n_files, hipStream_t stream);
+void launch_unpack_sums(const unsigned long long* sums, unsigned long long* stats, unsigned char* present, unsigned long long* kstats,
+                        int n_files, hipStream_t stream);
 size_t finalize_lds_bytes(int n_files);
 size_t finalize_partial_rows();
 

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     const int omin = a.v_omin, span = a.v_span;
     const uint64_t n_e = e_plane_len(a.n_u);
     unsigned int* const e_local = a.e_planes ? a.e_planes + (size_t)xcc_id() * n_e : nullptr;
-    unsigned long long* const v_counters = a.counters + n_e;
+    unsigned long long* const v_counters = a.counters + a.v_off;
     const uint32_t last_word = a.stride_words - 1u;
     uint32_t slow_lds = 0;   // wave-uniform: slow-path E hits this wave has put into the LDS array
 
@@ -1108,13 +1108,16 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
     __syncthreads();
 
     const int k = ix.k;
-    const uint64_t n_e = e_plane_len(ix.n_u);
     const uint64_t n_rows = v_real_rows(ix.n_full, ix.v_span);
     const uint64_t real_len = v_real_len(ix.n_full, ix.v_span);
     const uint32_t rl = (uint32_t)ix.v_span + 1u;
-    const unsigned long long* __restrict__ vc = a.counters + n_e;
+    const unsigned long long* __restrict__ vc = a.counters + ix.v_off;
     const KmerTable kt{a.ktab_keys, a.ktab_cnt, a.ktab_log2, a.ktab_overflow, a.mate};
     unsigned int kept = 0, distinct = 0;
+    // this shard's rows and pseudo counters (elem_lo / elem_hi are multiples of the row length, like v_off)
+    const uint64_t vlo = a.elem_lo > ix.v_off ? a.elem_lo - ix.v_off : 0ull, vhi = a.elem_hi > ix.v_off ? a.elem_hi - ix.v_off : 0ull;
+    const uint64_t row_lo = min(vlo / rl, n_rows), row_hi = min(vhi / rl, n_rows);
+    const uint64_t px_lo = min(vlo > real_len ? vlo - real_len : 0ull, ix.n_prows * 8ull), px_hi = min(vhi > real_len ? vhi - real_len : 0ull, ix.n_prows * 8ull);
 
     // The k-mers of one row mostly vote for the same pileup cell (the reference position of the differing base): votes are
     // gathered per (plane, cell) and written when the target changes -- #k-mers += votes, depth = max(depth, counts).
@@ -1192,8 +1195,9 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
     // all single-entry votes of the row agree on (strand, cell) they are merged into one pair of atomics.
     const uint32_t oo = threadIdx.x & 31u;
     const int half = (threadIdx.x & 32u) ? 32 : 0;
-    for (uint64_t wk = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 5; wk < ((n_rows + 7) & ~7ull); wk += ((uint64_t)gridDim.x * 256) >> 5) {
-        const bool in_row = wk < n_rows && oo < rl;
+    for (uint64_t wk = row_lo + (((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 5); wk < row_lo + ((row_hi - row_lo + 7) & ~7ull);
+         wk += ((uint64_t)gridDim.x * 256) >> 5) {
+        const bool in_row = wk < row_hi && oo < rl;
         unsigned long long n = in_row ? vc[wk * rl + oo] : 0ull;
 #pragma unroll
         for (int off = 1; off < 32; off <<= 1) {
@@ -1294,7 +1298,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         }
     }
     // the pseudo k-mers' counters (k = 31 only), one thread each
-    for (uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x; x < ix.n_prows * 8ull; x += (uint64_t)gridDim.x * 256) {
+    for (uint64_t x = px_lo + (uint64_t)blockIdx.x * 256 + threadIdx.x; x < px_hi; x += (uint64_t)gridDim.x * 256) {
         const uint64_t vi = real_len + x;
         if (vc[vi] == 0) continue;
         uint32_t p, t, isrc; uint64_t c; unsigned long long n;
@@ -1318,9 +1322,10 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     __syncthreads();
     const int k = ix.k;
     const uint32_t W = (uint32_t)ix.W;
-    const uint64_t n_work = e_plane_len(ix.n_u) * W;
+    const uint64_t c_lo = min(a.elem_lo, e_plane_len(ix.n_u)), c_hi = min(a.elem_hi, e_plane_len(ix.n_u));   // this shard's E counters
+    const uint64_t n_work = c_hi * W;
     unsigned int kept = 0, distinct = 0;
-    for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < n_work; g += (uint64_t)gridDim.x * 256) {
+    for (uint64_t g = c_lo * W + (uint64_t)blockIdx.x * 256 + threadIdx.x; g < n_work; g += (uint64_t)gridDim.x * 256) {
         const uint64_t cidx = g / W;
         const uint32_t t = (uint32_t)(g % W);
         const unsigned long long n = a.counters[cidx];
@@ -1383,11 +1388,11 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
     // thousand items spread over the whole grid
     for (uint64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         {
-            const uint64_t ci = n_e + a.deferred[item];          // always a V counter: the E counters are mapped by K2e
+            const uint64_t ci = n_e + a.deferred[item];          // always a V counter: the E counters are mapped by K2e (n_e: unused offset)
             unsigned long long v;
             uint64_t c;
             uint32_t isrc, p_, t_;
-            v_kmer_of_counter(ix, a.counters + n_e, ci - n_e, p_, t_, c, isrc, v);
+            v_kmer_of_counter(ix, a.counters + ix.v_off, ci - n_e, p_, t_, c, isrc, v);
             v = v > a.cs ? a.cs : v;                              // kmc -cs: reported count saturates
 
             if (lane < ix.W) {
@@ -1463,6 +1468,31 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
         const int cols = a.ix.n_files * 3 + 2;
         hipLaunchKernelGGL(finalize_reduce_kernel, dim3((unsigned)cols), dim3(256), 0, stream, a, (int)(b_var + b_ex + b_gen));
     }
+}
+
+// ---- sharded finalize: the small additive results as one u64 vector [stats 2*n_files*3 | present 2*n_files | kstats 8]
+__global__ void pack_sums_kernel(unsigned long long* sums, const unsigned long long* stats, const unsigned char* present,
+                                 const unsigned long long* kstats, int n_files) {
+    const int n_s = 2 * n_files * 3, n_p = 2 * n_files;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_s + n_p + 8; i += gridDim.x * blockDim.x)
+        sums[i] = i < n_s ? stats[i] : i < n_s + n_p ? (unsigned long long)present[i - n_s] : kstats[i - n_s - n_p];
+}
+__global__ void unpack_sums_kernel(const unsigned long long* sums, unsigned long long* stats, unsigned char* present,
+                                   unsigned long long* kstats, int n_files) {
+    const int n_s = 2 * n_files * 3, n_p = 2 * n_files;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_s + n_p + 8; i += gridDim.x * blockDim.x) {
+        if (i < n_s) stats[i] = sums[i];
+        else if (i < n_s + n_p) present[i - n_s] = sums[i] ? 1 : 0;
+        else kstats[i - n_s - n_p] = sums[i];
+    }
+}
+void launch_pack_sums(unsigned long long* sums, const unsigned long long* stats, const unsigned char* present, const unsigned long long* kstats,
+                      int n_files, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_sums_kernel, dim3(8), dim3(256), 0, stream, sums, stats, present, kstats, n_files);
+}
+void launch_unpack_sums(const unsigned long long* sums, unsigned long long* stats, unsigned char* present, unsigned long long* kstats,
+                        int n_files, hipStream_t stream) {
+    hipLaunchKernelGGL(unpack_sums_kernel, dim3(8), dim3(256), 0, stream, sums, stats, present, kstats, n_files);
 }
 
 }  // namespace bk

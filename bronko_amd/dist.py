@@ -16,10 +16,68 @@ def shard_bounds(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _all_reduce(t, op):
+    """dist.all_reduce in place; with the gloo backend (CPU tests, or several test ranks sharing one GPU) device tensors
+    are staged through host memory explicitly."""
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+
+
 def allreduce_counters(counters):
     """In-place sum of a counter plane across ranks.  `counters`: int64 view of the engine's u64 plane
     (two's-complement addition is the same operation); a no-op outside a process group."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         assert counters.dtype == torch.int64
-        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
+        _all_reduce(counters, dist.ReduceOp.SUM)
     return counters
+
+
+def reduce_scatter_plane(plane, rank, world):
+    """Sum `plane` (1-D int64, length divisible by world) across ranks, leaving only this rank's part -- elements
+    [rank * n / world, (rank + 1) * n / world) -- summed, in place; the other parts are left as they were.
+    RCCL reduce-scatter on GPUs; gloo (CPU tests) has no reduce-scatter, there it is an all-reduce."""
+    if not (dist.is_available() and dist.is_initialized()) or world == 1:
+        return plane
+    assert plane.dtype == torch.int64 and plane.numel() % world == 0
+    part = plane.numel() // world
+    if dist.get_backend() == "gloo":
+        _all_reduce(plane, dist.ReduceOp.SUM)
+        return plane
+    out = torch.empty(part, dtype=torch.int64, device=plane.device)
+    dist.reduce_scatter_tensor(out, plane, op=dist.ReduceOp.SUM)
+    plane[rank * part:(rank + 1) * part].copy_(out)
+    return plane
+
+
+def combine_shard_results(depth, nk, sums):
+    """After every rank mapped its part of the planes: depth = max over ranks, #k-mers and the small statistics add."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        _all_reduce(depth, dist.ReduceOp.MAX)
+        _all_reduce(nk, dist.ReduceOp.SUM)
+        _all_reduce(sums, dist.ReduceOp.SUM)
+
+
+class DeviceVector:
+    """__cuda_array_interface__ view of n little-endian 64-bit integers at a device pointer (for torch.as_tensor)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+
+
+def sharded_finalize(eng, n_mates, rank, world, device):
+    """The cheap multi-GPU form (include/bronko_hip.h): reduce-scatter the counter planes, map this rank's part, combine the
+    pileups (max / sum) and the statistics.  Afterwards eng.sample_download() returns the full result on every rank."""
+    for m in range(n_mates):
+        plane = torch.as_tensor(DeviceVector(eng.counters_ptr(m), eng.counter_len), device=device)
+        reduce_scatter_plane(plane, rank, world)
+    eng.sample_finalize_shard(n_mates, rank, world)
+    cells4 = eng.total_cells * 4
+    pile = torch.as_tensor(DeviceVector(eng.pileup_ptr(), 4 * cells4), device=device)
+    sp, sn = eng.shard_sums()
+    sums = torch.as_tensor(DeviceVector(sp, sn), device=device)
+    combine_shard_results(pile[:2 * cells4], pile[2 * cells4:], sums)
+    eng.sample_merge_shards()

@@ -164,6 +164,19 @@ class Engine:
     def sample_finalize(self, n_mates=1):
         _check(self._L.bk_sample_finalize(self.h, n_mates))
 
+    def sample_finalize_shard(self, n_mates, shard, n_shards):
+        """Map only the shard-th of n_shards equal parts of each counter plane (include/bronko_hip.h)."""
+        _check(self._L.bk_sample_finalize_shard(self.h, n_mates, shard, n_shards))
+
+    def shard_sums(self):
+        """(device pointer, u64 length) of the small additive results of sample_finalize_shard."""
+        p, n = C.c_void_p(), C.c_uint64()
+        _check(self._L.bk_shard_sums_device_ptr(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def sample_merge_shards(self):
+        _check(self._L.bk_sample_merge_shards(self.h))
+
     def sample_download(self, n_mates=1, arrays=True):
         r = SampleResult(n_mates, self.n_files, self.total_cells)
         a = [x.ctypes.data if arrays else None for x in (r.fwd_depth, r.rev_depth, r.fwd_nk, r.rev_nk)]

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BK_ABI_VERSION 2
+#define BK_ABI_VERSION 3
 
 typedef enum {
     BK_OK = 0,
@@ -139,6 +139,20 @@ int bk_counters_device_ptr(bk_engine* e, int mate, void** d_ptr);
 
 /* Runs the threshold + map_kmers kernels for mates [0, n_mates) on the device (asynchronous). */
 int bk_sample_finalize(bk_engine* e, int n_mates);
+
+/* Multi-GPU, cheaper form: instead of all-reducing the planes and finalizing everything on every rank, REDUCE-SCATTER each
+ * plane over the n ranks (n divides 64; bk_counter_len() is a multiple of 64 and a part never cuts a counter row), then
+ *   bk_sample_finalize_shard(e, n_mates, rank, n)   maps only the rank-th of n equal parts of each plane -- the part the
+ *                                                   reduce-scatter left summed in place on this rank -- into this rank's
+ *                                                   pileup arrays and statistics;
+ *   all-reduce MAX the two depth planes and SUM the two #k-mer planes (bk_pileup_device_ptr: 4 planes of total_cells * 4
+ *   u64, depth fwd, depth rev, #k-mers fwd, #k-mers rev), and SUM the bk_shard_sums_device_ptr vector;
+ *   bk_sample_merge_shards(e)                       installs the summed statistics; bk_sample_download then returns the
+ *                                                   same results as the all-reduce form on every rank.
+ * (map_kmers' votes are max / += per k-mer, so maps of disjoint sets of k-mers combine by max / sum.) */
+int bk_sample_finalize_shard(bk_engine* e, int n_mates, int shard, int n_shards);
+int bk_shard_sums_device_ptr(bk_engine* e, void** d_ptr, uint64_t* len);
+int bk_sample_merge_shards(bk_engine* e);
 /* Device pointers of the finalized arrays: 4 planes (fwd depth, rev depth, fwd #kmers, rev #kmers) of
  * total_cells*4 u64 each, contiguous, in (file, seq, pos, base) order. */
 int bk_pileup_device_ptr(bk_engine* e, void** d_ptr);

@@ -76,3 +76,39 @@ def test_counter_allreduce_then_finalize_equals_single_process(oracle, tmp_path)
     # summing per-shard pileups is NOT the pileup of the sample
     assert (got["wrong"] != want.fwd_depth).sum() > 100
     ix.close()
+
+
+def _worker_shards(rank, world, port, out_dir):
+    from bronko_amd.dist import combine_shard_results, reduce_scatter_plane
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        plane = torch.randint(-5, 50, (64 * 19,), generator=g, dtype=torch.int64)
+        mine = plane.clone()
+        reduce_scatter_plane(mine, rank, world)
+        depth = torch.randint(0, 1000, (40,), generator=g, dtype=torch.int64)
+        nk = torch.randint(0, 1000, (40,), generator=g, dtype=torch.int64)
+        sums = torch.randint(0, 1000, (14,), generator=g, dtype=torch.int64)
+        d2, n2, s2 = depth.clone(), nk.clone(), sums.clone()
+        combine_shard_results(d2, n2, s2)
+        torch.save({"plane": plane, "mine": mine, "depth": depth, "nk": nk, "sums": sums, "d2": d2, "n2": n2, "s2": s2},
+                   os.path.join(out_dir, "s%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reduce_scatter_and_combine_helpers(tmp_path):
+    """bronko_amd.dist.reduce_scatter_plane leaves each rank's own part summed; combine_shard_results is max / sum / sum."""
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker_shards, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(os.path.join(str(tmp_path), "s%d.pt" % r)) for r in range(world)]
+    total = got[0]["plane"] + got[1]["plane"]
+    part = total.numel() // world
+    for r in range(world):
+        assert torch.equal(got[r]["mine"][r * part:(r + 1) * part], total[r * part:(r + 1) * part])
+        assert torch.equal(got[r]["d2"], torch.maximum(got[0]["depth"], got[1]["depth"]))
+        assert torch.equal(got[r]["n2"], got[0]["nk"] + got[1]["nk"])
+        assert torch.equal(got[r]["s2"], got[0]["sums"] + got[1]["sums"])

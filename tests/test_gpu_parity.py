@@ -421,3 +421,62 @@ def test_reverse_complement_repeats(oracle):
     helpers.assert_same_pileup(helpers.hip_sample(eng, [reads], 21), pile)
     eng.close()
     ix.close()
+
+
+def test_sharded_finalize_on_one_device(oracle, sars_paths):
+    """The cheap multi-GPU form (reduce-scatter + bk_sample_finalize_shard + max / sum of the pileups) simulated on one
+    device with four engines standing for four ranks: every "rank" scans its reads; the planes are summed (what the
+    reduce-scatter computes) and each rank keeps ONLY its quarter of the sum -- the rest of its plane is overwritten with
+    garbage, which a correct shard never reads; the four partial pileups are combined by max / sum, the statistics by
+    sum.  Result must equal the oracle on all reads (4 strains: several genomes, dirty neighbourhoods, deferred k-mers)."""
+    import torch
+    from bronko_amd import pack_reads
+    from bronko_amd.dist import DeviceVector
+    world = 4
+    ix = oracle.Index.build(21, sars_paths)
+    gm, isnv = synth.sample_genome(synth.read_fasta_bytes(sars_paths[1]), 13)
+    c1, c2 = synth.paired_codes(gm, 20000, 150, 13, isnv=isnv)
+    mates = [synth.codes_to_ascii(c1), synth.codes_to_ascii(c2)]
+    pile = oracle.sample_pileup(ix, mates)
+    engs = [helpers.engine_from_oracle_index(ix) for _ in range(world)]
+    assert engs[0].counter_len % 64 == 0
+    for r, e in enumerate(engs):
+        e.sample_begin()
+        for m, reads in enumerate(mates):
+            lo, hi = len(reads) * r // world, len(reads) * (r + 1) // world
+            w, l = pack_reads(reads[lo:hi], 21)
+            e.push_reads(m, w, l)
+    torch.cuda.synchronize()
+    n = engs[0].counter_len
+    part = n // world
+    for m in range(2):
+        planes = [torch.as_tensor(DeviceVector(e.counters_ptr(m), n), device="cuda:0") for e in engs]
+        total = planes[0].clone()
+        for p in planes[1:]:
+            total += p
+        for r, p in enumerate(planes):
+            p.fill_(0x5a5a5a5a5a5a5a5)
+            p[r * part:(r + 1) * part] = total[r * part:(r + 1) * part]
+    torch.cuda.synchronize()
+    cells4 = engs[0].total_cells * 4
+    piles, sums = [], []
+    for r, e in enumerate(engs):
+        e.sample_finalize_shard(2, r, world)
+        piles.append(torch.as_tensor(DeviceVector(e.pileup_ptr(), 4 * cells4), device="cuda:0"))
+        sp, sn = e.shard_sums()
+        sums.append(torch.as_tensor(DeviceVector(sp, sn), device="cuda:0"))
+    torch.cuda.synchronize()
+    depth = torch.stack([p[:2 * cells4] for p in piles]).max(dim=0).values
+    nk = torch.stack([p[2 * cells4:] for p in piles]).sum(dim=0)
+    ssum = torch.stack(sums).sum(dim=0)
+    piles[0][:2 * cells4] = depth
+    piles[0][2 * cells4:] = nk
+    sums[0].copy_(ssum)
+    torch.cuda.synchronize()
+    engs[0].sample_merge_shards()
+    res = engs[0].sample_download(2)
+    helpers.assert_same_pileup(res, pile)
+    assert oracle.pick_best_genome(ix, res.stats.sum(axis=0), res.present.max(axis=0)) == 1
+    for e in engs:
+        e.close()
+    ix.close()

@@ -69,7 +69,7 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from bronko_amd import Params, synth
-    from bronko_amd.dist import allreduce_counters, sharded_finalize
+    from bronko_amd.dist import ShardedFinalize, allreduce_counters
     from bronko_amd.hostlib import HostIndex
 
     k = 21
@@ -98,12 +98,13 @@ def main():
     # N > 1: reduce-scatter of the counter plane + each rank maps its part + max / sum of the small pileups (the cheap form,
     # include/bronko_hip.h); --allreduce selects the plain form (all-reduce the plane, every rank maps everything)
     sharded = world > 1 and not args.allreduce and 64 % world == 0
+    shard_fin = ShardedFinalize(eng, 1, rank, world, dev) if sharded else None
 
     def step():
         eng.sample_begin()
         eng.push_reads_device(0, d_words.data_ptr(), stride, d_lens.data_ptr(), n_rec)
         if sharded:
-            sharded_finalize(eng, 1, rank, world, dev)   # RCCL over xGMI: reduce-scatter(sum) + 3 small all-reduces
+            shard_fin()   # RCCL over xGMI: reduce-scatter(sum) + 3 small all-reduces
             return
         if world > 1:
             allreduce_counters(counters)   # RCCL over xGMI: ONE all-reduce(sum) of the u64 k-mer occurrence counters

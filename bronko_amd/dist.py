@@ -36,7 +36,7 @@ def allreduce_counters(counters):
     return counters
 
 
-def reduce_scatter_plane(plane, rank, world):
+def reduce_scatter_plane(plane, rank, world, out=None):
     """Sum `plane` (1-D int64, length divisible by world) across ranks, leaving only this rank's part -- elements
     [rank * n / world, (rank + 1) * n / world) -- summed, in place; the other parts are left as they were.
     RCCL reduce-scatter on GPUs; gloo (CPU tests) has no reduce-scatter, there it is an all-reduce."""
@@ -47,7 +47,8 @@ def reduce_scatter_plane(plane, rank, world):
     if dist.get_backend() == "gloo":
         _all_reduce(plane, dist.ReduceOp.SUM)
         return plane
-    out = torch.empty(part, dtype=torch.int64, device=plane.device)
+    if out is None:
+        out = torch.empty(part, dtype=torch.int64, device=plane.device)
     dist.reduce_scatter_tensor(out, plane, op=dist.ReduceOp.SUM)
     plane[rank * part:(rank + 1) * part].copy_(out)
     return plane
@@ -68,16 +69,30 @@ class DeviceVector:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
 
 
-def sharded_finalize(eng, n_mates, rank, world, device):
+class ShardedFinalize:
     """The cheap multi-GPU form (include/bronko_hip.h): reduce-scatter the counter planes, map this rank's part, combine the
-    pileups (max / sum) and the statistics.  Afterwards eng.sample_download() returns the full result on every rank."""
-    for m in range(n_mates):
-        plane = torch.as_tensor(DeviceVector(eng.counters_ptr(m), eng.counter_len), device=device)
-        reduce_scatter_plane(plane, rank, world)
-    eng.sample_finalize_shard(n_mates, rank, world)
-    cells4 = eng.total_cells * 4
-    pile = torch.as_tensor(DeviceVector(eng.pileup_ptr(), 4 * cells4), device=device)
-    sp, sn = eng.shard_sums()
-    sums = torch.as_tensor(DeviceVector(sp, sn), device=device)
-    combine_shard_results(pile[:2 * cells4], pile[2 * cells4:], sums)
-    eng.sample_merge_shards()
+    pileups (max / sum) and the statistics.  After __call__ eng.sample_download() returns the full result on every rank.
+    The tensor views of the engine's device buffers are made once."""
+
+    def __init__(self, eng, n_mates, rank, world, device):
+        self.eng, self.n_mates, self.rank, self.world = eng, n_mates, rank, world
+        self.planes = [torch.as_tensor(DeviceVector(eng.counters_ptr(m), eng.counter_len), device=device) for m in range(n_mates)]
+        cells4 = eng.total_cells * 4
+        pile = torch.as_tensor(DeviceVector(eng.pileup_ptr(), 4 * cells4), device=device)
+        self.depth, self.nk = pile[:2 * cells4], pile[2 * cells4:]
+        sp, sn = eng.shard_sums()
+        self.sums = torch.as_tensor(DeviceVector(sp, sn), device=device)
+        part = eng.counter_len // world
+        self.out = torch.empty(part, dtype=torch.int64, device=device) if world > 1 else None
+
+    def __call__(self):
+        for plane in self.planes:
+            reduce_scatter_plane(plane, self.rank, self.world, self.out)
+        self.eng.sample_finalize_shard(self.n_mates, self.rank, self.world)
+        combine_shard_results(self.depth, self.nk, self.sums)
+        self.eng.sample_merge_shards()
+
+
+def sharded_finalize(eng, n_mates, rank, world, device):
+    """One-shot convenience wrapper of ShardedFinalize."""
+    ShardedFinalize(eng, n_mates, rank, world, device)()

@@ -107,6 +107,7 @@ def main():
             shard_fin()   # RCCL over xGMI: reduce-scatter(sum) + 3 small all-reduces
             return
         if world > 1:
+            eng.counters_ptr(0)            # (same pointer every step; a plane nothing was pushed to is zeroed by this call)
             allreduce_counters(counters)   # RCCL over xGMI: ONE all-reduce(sum) of the u64 k-mer occurrence counters
         eng.sample_finalize(1)
 

@@ -217,6 +217,7 @@ struct bk_engine {
     hipStream_t own_stream = nullptr, stream = nullptr;
     bool in_sample = false;
     uint64_t pushed_records[2] = {0, 0};
+    bool plane_stale[2] = {true, true};   // the mate's counter plane still holds an earlier sample (zeroed at its first push / at finalize)
 
     int ablate = 0;   // BK_SCAN_ABLATE (measurement aid): see scan_count_kernel
     uint64_t max_launch_records = 0;   // BK_MAX_LAUNCH_RECORDS (testing aid): split pushes into launches of at most this many records
@@ -711,7 +712,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     BK_HIP(e->ktab_out.alloc(8));
     if (e->n_files <= 64) BK_HIP(e->fin_partials.alloc(bk::finalize_partial_rows() * ((size_t)e->n_files * 3 + 2)));
     BK_HIP(e->deferred.alloc(bk::v_plane_len(e->n_full, e->v_span, e->n_prows)));
-    BK_HIP(e->n_deferred.alloc(1));
+    BK_HIP(e->n_deferred.alloc(2));   // one per mate file
     if (e->n_lds_bins >= e->total_cells) e->use_xcd_planes = false;   // every cell has an LDS bin
     if (e->use_xcd_planes) {
         BK_HIP(e->e_planes.alloc((size_t)bk::kXcdPlanes * bk::e_plane_len(e->n_u)));
@@ -763,13 +764,10 @@ int bk_sample_begin(bk_engine* e) {
     if (!e) return fail(BK_ERR_INVALID, "null engine");
     BK_HIP(hipSetDevice(e->device));
     bk_engine::Span sp(e, 2);
-    for (int m = 0; m < 2; m++)
-        BK_HIP(hipMemsetAsync(e->counters[m].p, 0, std::max<size_t>(e->counters[m].n, 1) * sizeof(unsigned long long), e->stream));
+    e->plane_stale[0] = e->plane_stale[1] = true;   // a plane is zeroed when its mate file is first pushed (or finalized unpushed)
     BK_HIP(hipMemsetAsync(e->pileup.p, 0, std::max<size_t>(e->pileup.n, 1) * sizeof(unsigned long long), e->stream));
-    BK_HIP(hipMemsetAsync(e->stats.p, 0, e->stats.n * sizeof(unsigned long long), e->stream));
-    BK_HIP(hipMemsetAsync(e->present.p, 0, e->present.n, e->stream));
-    BK_HIP(hipMemsetAsync(e->kstats.p, 0, e->kstats.n * sizeof(unsigned long long), e->stream));
-    BK_HIP(hipMemsetAsync(e->ktab_out.p, 0, e->ktab_out.n * sizeof(unsigned long long), e->stream));
+    bk::launch_zero_small(e->stats.p, e->stats.n, e->kstats.p, e->kstats.n, e->ktab_out.p, e->ktab_out.n, e->present.p, e->present.n,
+                          e->n_deferred.p, e->n_deferred.n, e->stream);
     if (e->ktab_keys.p) {
         BK_HIP(hipMemsetAsync(e->ktab_keys.p, 0xff, e->ktab_keys.n * sizeof(unsigned long long), e->stream));
         BK_HIP(hipMemsetAsync(e->ktab_cnt.p, 0, e->ktab_cnt.n * sizeof(unsigned int), e->stream));
@@ -779,8 +777,18 @@ int bk_sample_begin(bk_engine* e) {
     return BK_OK;
 }
 
+static int zero_plane_if_stale(bk_engine* e, int mate) {
+    if (e->plane_stale[mate]) {
+        bk_engine::Span sp(e, 2);
+        BK_HIP(hipMemsetAsync(e->counters[mate].p, 0, std::max<size_t>(e->counters[mate].n, 1) * sizeof(unsigned long long), e->stream));
+        e->plane_stale[mate] = false;
+    }
+    return BK_OK;
+}
+
 static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t stride_words, const uint16_t* d_lens, uint64_t n,
                        const unsigned long long* n_records_dev = nullptr) {
+    if (int rc = zero_plane_if_stale(e, mate)) return rc;
     bk::ScanArgs a{};
     a.n_records_dev = n_records_dev;
     a.ixp = e->d_view.p;
@@ -919,6 +927,10 @@ int bk_push_reads_packed(bk_engine* e, int mate, const uint32_t* words, uint32_t
 
 int bk_counters_device_ptr(bk_engine* e, int mate, void** d_ptr) {
     if (!e || !d_ptr || mate < 0 || mate > 1) return fail(BK_ERR_INVALID, "bad argument");
+    if (e->in_sample) {   // a mate file nothing was pushed for yet: its plane is zeroed lazily -- now, before the caller reduces it
+        BK_HIP(hipSetDevice(e->device));
+        if (int rc = zero_plane_if_stale(e, mate)) return rc;
+    }
     *d_ptr = e->counters[mate].p;
     return BK_OK;
 }
@@ -947,10 +959,10 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
         a.distinct_total = e->kstats.p + m * 4 + 2;
         a.partials = e->fin_partials.p;
         a.deferred = e->deferred.p;
-        a.n_deferred = e->n_deferred.p;
+        a.n_deferred = e->n_deferred.p + m;
         a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->params.kmer_table_log2;
         a.ktab_overflow = e->ktab_out.p + 4; a.mate = (uint32_t)m;
-        BK_HIP(hipMemsetAsync(e->n_deferred.p, 0, sizeof(unsigned int), e->stream));
+        if (int rc = zero_plane_if_stale(e, m)) return rc;
         bk_engine::Span sp(e, 1);
         bk::launch_finalize(a, e->stream);
     }

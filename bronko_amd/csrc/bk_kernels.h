@@ -101,6 +101,9 @@ void launch_fold(const FoldArgs& f, hipStream_t stream);
 void launch_ktab_stats(const unsigned long long* keys, const unsigned int* cnt, uint32_t log2n, unsigned long long ci,
                        unsigned long long cx, unsigned long long* out, hipStream_t stream);
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
+// one launch zeroes the engine's small per-sample buffers
+void launch_zero_small(unsigned long long* a, size_t na, unsigned long long* b, size_t nb, unsigned long long* c, size_t nc,
+                       unsigned char* d, size_t nd, unsigned int* e, size_t ne, hipStream_t stream);
 // shard_sums <-> {stats, present, kstats}: the small additive results of a sharded finalize as one u64 vector
 void launch_pack_sums(unsigned long long* sums, const unsigned long long* stats, const unsigned char* present, const unsigned long long* kstats,
                       int n_files, hipStream_t stream);

@@ -1470,6 +1470,20 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     }
 }
 
+__global__ void zero_small_kernel(unsigned long long* a, size_t na, unsigned long long* b, size_t nb, unsigned long long* c, size_t nc,
+                                  unsigned char* d, size_t nd, unsigned int* e, size_t ne) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = t; i < na; i += n) a[i] = 0;
+    for (size_t i = t; i < nb; i += n) b[i] = 0;
+    for (size_t i = t; i < nc; i += n) c[i] = 0;
+    for (size_t i = t; i < nd; i += n) d[i] = 0;
+    for (size_t i = t; i < ne; i += n) e[i] = 0;
+}
+void launch_zero_small(unsigned long long* a, size_t na, unsigned long long* b, size_t nb, unsigned long long* c, size_t nc,
+                       unsigned char* d, size_t nd, unsigned int* e, size_t ne, hipStream_t stream) {
+    hipLaunchKernelGGL(zero_small_kernel, dim3(16), dim3(256), 0, stream, a, na, b, nb, c, nc, d, nd, e, ne);
+}
+
 // ---- sharded finalize: the small additive results as one u64 vector [stats 2*n_files*3 | present 2*n_files | kstats 8]
 __global__ void pack_sums_kernel(unsigned long long* sums, const unsigned long long* stats, const unsigned char* present,
                                  const unsigned long long* kstats, int n_files) {

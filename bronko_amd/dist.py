@@ -86,7 +86,8 @@ class ShardedFinalize:
         self.out = torch.empty(part, dtype=torch.int64, device=device) if world > 1 else None
 
     def __call__(self):
-        for plane in self.planes:
+        for m, plane in enumerate(self.planes):
+            self.eng.counters_ptr(m)   # (a plane this rank pushed nothing to is zeroed by this call)
             reduce_scatter_plane(plane, self.rank, self.world, self.out)
         self.eng.sample_finalize_shard(self.n_mates, self.rank, self.world)
         combine_shard_results(self.depth, self.nk, self.sums)

@@ -134,7 +134,8 @@ int bk_push_reads_ascii(bk_engine* e, int mate, const uint8_t* buf, const uint64
 /* Multi-GPU hook: the only additive quantity is the per-k-mer occurrence counter plane.
  * (Its u64 elements are difference arrays and counters whose sums wrap modulo 2^64 -- opaque to the host, linear.)
  * A host that shards one sample's reads over several GPUs all-reduces (sum, u64) each plane in place between
- * the last push and bk_sample_finish.  The pointer is device memory of bk_counter_len() u64. */
+ * the last push and bk_sample_finish.  The pointer is device memory of bk_counter_len() u64; call this after the
+ * sample's bk_sample_begin (a plane nothing was pushed to yet is zeroed here, not at begin). */
 int bk_counters_device_ptr(bk_engine* e, int mate, void** d_ptr);
 
 /* Runs the threshold + map_kmers kernels for mates [0, n_mates) on the device (asynchronous). */

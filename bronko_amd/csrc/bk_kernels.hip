@@ -295,9 +295,9 @@ __device__ __forceinline__ uint64_t read_symbols_at(const uint32_t* __restrict__
     const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
     return ((uint64_t)hi << 32) | lo;
 }
-// 16 bits of a 1-bit-per-cell array starting at cell `pos`
-__device__ __forceinline__ uint32_t bits16_at(const uint32_t* __restrict__ w, int32_t pos) {
-    return __builtin_amdgcn_alignbit(w[(pos >> 5) + 1], w[pos >> 5], (uint32_t)pos & 31u) & 0xffffu;
+// 32 bits of a 1-bit-per-cell array starting at cell `pos`
+__device__ __forceinline__ uint32_t bits32_at(const uint32_t* __restrict__ w, int32_t pos) {
+    return __builtin_amdgcn_alignbit(w[(pos >> 5) + 1], w[pos >> 5], (uint32_t)pos & 31u);
 }
 
 // +1 on "reference k-mer id with base b (forward strand of the reference) at offset o, read in direction d": a
@@ -576,9 +576,9 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
         dfl = (fwd ? 1u : 0u) | (seeded ? 2u : 0u);
 
         // ---- Level 1 / batches: a state machine, all control flow wave-uniform --------------------------------------
-        uint32_t i0 = 0;                // first base of the next Level-1 word
-        uint32_t xn = len ? w[0] : 0u;  // the next read word (loaded a word ahead)
-        uint32_t h_lo = 0xffffffffu, h_hi = 0xffffffffu;   // mismatch flags of the last 64 bases, newest word in the top 16 bits
+        uint32_t i0 = 0;                // first base of the next Level-1 step (32 bases)
+        uint32_t xn0 = len ? w[0] : 0u, xn1 = len > 16u ? w[1] : 0u;   // the next two read words (loaded a step ahead)
+        uint32_t h_lo = 0xffffffffu, h_hi = 0xffffffffu;   // mismatch flags of the last 64 bases, newest 32 in h_hi
         uint32_t run_start = 0;         // first k-mer of the lane's open run
         uint32_t run_type = 0;          // its kind: 0 none, 1 E, 2 S, 3 G
         uint32_t pe = 0, ps = 0, pg = 0;   // kind bits of the last k-mer of the previous word (bit 0)
@@ -812,56 +812,56 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 continue;
             }
             if (words_done) break;
-            // ================= Level 1: one read word = 16 bases =================================================
+            // ================= Level 1: two read words = 32 bases ================================================
             if (pipe.stage) pipe.advance(ix, v_counters, count_exact, kt);   // the slow path's loads fly while Level 1 works
             else if (qn >= 32u) start_slow_batch();
             {
-                const uint32_t x = xn;
-                xn = (i0 + 16u < len) ? w[(i0 >> 4) + 1u] : 0u;
+                const uint32_t x0 = xn0, x1 = xn1;
+                xn0 = (i0 + 32u < len) ? w[(i0 >> 4) + 2u] : 0u;
+                xn1 = (i0 + 48u < len) ? w[(i0 >> 4) + 3u] : 0u;
                 const bool act = l1ok && i0 < len;
-                // mismatch flags of these 16 bases: read word vs the reference word aligned with it
-                const int32_t p0 = act ? (fwd ? dg + (int32_t)i0 : dg + (int32_t)km1 - (int32_t)i0 - 15) : 0;
+                // mismatch flags of these 32 bases: read words vs the reference words aligned with them
+                const int32_t p0 = act ? (fwd ? dg + (int32_t)i0 : dg + (int32_t)km1 - (int32_t)i0 - 31) : 0;
                 const uint32_t sh = 2u * ((uint32_t)p0 & 15u);
-                const uint32_t yl = __builtin_amdgcn_alignbit(refw[(p0 >> 4) + 1], refw[p0 >> 4], sh);
-                const uint32_t dd = x ^ (fwd ? yl : ~rev2_32(yl));
-                const uint32_t M16 = act ? even_bits(dd | (dd >> 1)) : 0xffffu;   // no usable diagonal: every base "differs"
-                h_lo = __builtin_amdgcn_alignbit(h_hi, h_lo, 16);
-                h_hi = (h_hi >> 16) | (M16 << 16);
-                // per-cell bits of the 16 k-mers that end in this word, in step order
-                const int32_t c0 = act ? (fwd ? dg + (int32_t)i0 - (int32_t)km1 : dg - (int32_t)i0 + (int32_t)km1 - 15) : 0;
-                const uint32_t hl = bits16_at(hasw, c0), cl = bits16_at(cleanw, c0);
-                const uint32_t HAS16 = fwd ? hl : __builtin_bitreverse32(hl) >> 16;
-                const uint32_t CLEAN16 = fwd ? cl : __builtin_bitreverse32(cl) >> 16;
-                // steps of this word that end a k-mer of the read: i0 + b >= k - 1 and i0 + b < len
-                const uint32_t lo = i0 >= km1 ? 0u : min(km1 - i0, 16u);
-                const uint32_t hi = len > i0 ? min(len - i0, 16u) : 0u;
-                const uint32_t VAL16 = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-                // A: some mismatch among the k bases that end at step b; B: at least two.  The flags of base i0 + b - t sit
-                // at bit 48 + b - t of (h_hi : h_lo)
-                uint32_t A = 0, B = 0;
+                const uint32_t r0 = refw[p0 >> 4], r1 = refw[(p0 >> 4) + 1], r2 = refw[(p0 >> 4) + 2];
+                const uint32_t ya = __builtin_amdgcn_alignbit(r1, r0, sh), yb = __builtin_amdgcn_alignbit(r2, r1, sh);   // 32 reference bases, rising
+                // against the reference: read base i0 + t <-> complement of reference base p0 + 31 - t
+                const uint32_t d0 = x0 ^ (fwd ? ya : ~rev2_32(yb)), d1 = x1 ^ (fwd ? yb : ~rev2_32(ya));
+                const uint32_t M32 = act ? even_bits(d0 | (d0 >> 1)) | (even_bits(d1 | (d1 >> 1)) << 16) : 0xffffffffu;   // no usable diagonal: every base "differs"
+                h_lo = h_hi;
+                h_hi = M32;
+                // per-cell bits of the 32 k-mers that end in these words, in step order
+                const int32_t c0 = act ? (fwd ? dg + (int32_t)i0 - (int32_t)km1 : dg - (int32_t)i0 + (int32_t)km1 - 31) : 0;
+                const uint32_t hl = bits32_at(hasw, c0), cl = bits32_at(cleanw, c0);
+                const uint32_t HAS32 = fwd ? hl : __builtin_bitreverse32(hl);
+                const uint32_t CLEAN32 = fwd ? cl : __builtin_bitreverse32(cl);
+                // steps that end a k-mer of the read: i0 + b >= k - 1 and i0 + b < len
+                const uint32_t lo = i0 >= km1 ? 0u : min(km1 - i0, 32u);
+                const uint32_t hi = len > i0 ? min(len - i0, 32u) : 0u;
+                const uint32_t VAL32 = (hi >= 32u ? 0xffffffffu : (1u << hi) - 1u) & (lo >= 32u ? 0u : ~((1u << lo) - 1u));
+                // A: some mismatch among the k bases that end at step b; B: at least two.  The flag of base i0 + b - t sits
+                // at bit 32 + b - t of (h_hi : h_lo)
+                uint32_t A = h_hi, B = 0;
                 if (KT) {
 #pragma unroll
-                    for (int t = 0; t < (KT ? KT : 1); ++t) {
-                        const uint32_t st = t <= 16 ? h_hi >> (16 - t) : __builtin_amdgcn_alignbit(h_hi, h_lo, (uint32_t)(48 - t));
+                    for (int t = 1; t < (KT ? KT : 2); ++t) {
+                        const uint32_t st = __builtin_amdgcn_alignbit(h_hi, h_lo, (uint32_t)(32 - t));
                         B |= A & st;
                         A |= st;
                     }
                 } else {
-                    const int k1 = min(k, 17);
-                    for (int t = 0; t < k1; ++t) { const uint32_t st = h_hi >> (16 - t); B |= A & st; A |= st; }
-                    for (int t = 17; t < k; ++t) { const uint32_t st = __builtin_amdgcn_alignbit(h_hi, h_lo, (uint32_t)(48 - t)); B |= A & st; A |= st; }
+                    for (int t = 1; t < k; ++t) { const uint32_t st = __builtin_amdgcn_alignbit(h_hi, h_lo, (uint32_t)(32 - t)); B |= A & st; A |= st; }
                 }
-                E16 = ~A & HAS16 & VAL16;
-                S16 = A & ~B & CLEAN16 & VAL16;
-                G16 = VAL16 & ~(E16 | S16);
+                E16 = ~A & HAS32 & VAL32;
+                S16 = A & ~B & CLEAN32 & VAL32;
+                G16 = VAL32 & ~(E16 | S16);
                 // a new run starts where the kind changes, or where an S k-mer's one mismatch is the newest base (the
                 // mismatch the previous S k-mers had has just left the window)
-                Bd = (E16 ^ ((E16 << 1) | pe)) | (S16 ^ ((S16 << 1) | ps)) | (G16 ^ ((G16 << 1) | pg)) | (S16 & M16);
-                Bd &= 0xffffu;
-                pe = (E16 >> 15) & 1u; ps = (S16 >> 15) & 1u; pg = (G16 >> 15) & 1u;
+                Bd = (E16 ^ ((E16 << 1) | pe)) | (S16 ^ ((S16 << 1) | ps)) | (G16 ^ ((G16 << 1) | pg)) | (S16 & M32);
+                pe = E16 >> 31; ps = S16 >> 31; pg = G16 >> 31;
                 tw_i0 = i0;
                 pend = __ballot(Bd != 0u) != 0ull;
-                i0 += 16u;
+                i0 += 32u;
                 words_done = i0 > maxlen;   // one step past the longest read closes every open run
             }
         }

@@ -112,6 +112,8 @@ struct IndexView {
                                   // it is canonical as written, 2 = it was reverse-complemented to become canonical
     const uint32_t*  cell_has;    // 1 bit per cell (32 per word, 2 words of front padding, 3 behind): a k-mer of U starts here
     const uint32_t*  cell_clean;  // same layout: ... and it is "clean" (bit 0 of cell_yf)
+    const uint32_t*  cell_clean3; // same layout: ... and no other reference k-mer, on either strand, lies within Hamming distance 3
+                                  // of it, nor its own reverse complement (all zero when the index is too large to work that out)
     const uint32_t*  cell_yf;     // 2 bits per cell q, same layout and padding, for a walk along the reference: bit 0 = the k-mer
                                   // that starts at q is in U and "clean" (see amb); bit 1 = id(q) == id(q-1) + 1
     const uint32_t*  cell_yr;     // ... for a walk against it: bit 0 the same; bit 1 = id(q) == id(q+1) - 1

@@ -173,7 +173,7 @@ struct bk_engine {
     DevBuf<bk::KmerPos> kmer_pos;
     DevBuf<bk::IndexView> d_view;   // device copy of view()
     DevBuf<uint64_t> kmer_of;
-    DevBuf<uint32_t> ref_words, cell_codes, cell_has, cell_clean, cell_yf, cell_yr, id_at;
+    DevBuf<uint32_t> ref_words, cell_codes, cell_has, cell_clean, cell_clean3, cell_yf, cell_yr, id_at;
     struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0; } half_lo, half_hi;
     DevBuf<unsigned int> deferred, n_deferred;
     DevBuf<unsigned int> fin_partials;      // per-workgroup finalize tallies (small genome sets only)
@@ -229,7 +229,7 @@ struct bk_engine {
     bk::IndexView view() const {
         bk::IndexView v{};
         v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb;
-        v.kmer_of = kmer_of.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
+        v.kmer_of = kmer_of.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_clean3 = cell_clean3.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
         v.n_full = n_full; v.n_prows = n_prows; v.prow_id = prow_id.p; v.prow_t = prow_t.p; v.v_omin = v_omin; v.v_span = v_span; v.v_off = v_off;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb};
@@ -529,6 +529,10 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         // the k-mer within distance 2 of its own reverse complement.  Any two 2k-bit words at distance <= 2 agree
         // on at least one of three parts, so group all forms (u and rc(u)) by each part and compare inside groups.
         std::vector<uint8_t> h_amb(h_u.size(), 0);   // by id
+        // amb3: the same with distance 3 (four parts); lets Level 2 discard k-mers with two differences on the spot.  The
+        // groups grow with |U| (a quarter of a k-mer distinguishes little): above kAmb3MaxKmers everything is flagged.
+        std::vector<uint8_t> h_amb3(h_u.size(), 0);
+        constexpr size_t kAmb3MaxKmers = 300000;
         {
             struct Form { uint64_t w; uint32_t id; };
             std::vector<Form> forms;
@@ -537,33 +541,40 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 forms.push_back(Form{h_u[i], id_of[i]});
                 forms.push_back(Form{bronko::reverse_complement_u64(h_u[i], k), id_of[i]});
             }
-            const int cut[4] = {0, k / 3, (2 * k) / 3, k};
-            for (int part = 0; part < 3; part++) {
-                const uint64_t mask = (((1ull << (2 * (cut[part + 1] - cut[part]))) - 1ull) << (2 * cut[part]));
-                std::sort(forms.begin(), forms.end(), [&](const Form& x, const Form& y) { return (x.w & mask) < (y.w & mask); });
-                for (size_t a0 = 0; a0 < forms.size();) {
-                    size_t a1 = a0 + 1;
-                    while (a1 < forms.size() && (forms[a1].w & mask) == (forms[a0].w & mask)) a1++;
-                    if (a1 - a0 > 4096) {   // pathological low-complexity group: flag all, skip the quadratic pass
-                        for (size_t x = a0; x < a1; x++) h_amb[forms[x].id] = 1;
-                    } else {
-                        for (size_t x = a0; x < a1; x++)
-                            for (size_t y = x + 1; y < a1; y++) {
-                                const uint64_t d = forms[x].w ^ forms[y].w;
-                                if (__builtin_popcountll((d | (d >> 1)) & 0x5555555555555555ull) <= 2)
-                                    h_amb[forms[x].id] = h_amb[forms[y].id] = 1;   // also catches u vs rc(u) (same id)
-                            }
+            auto flag_within = [&](int dist, std::vector<uint8_t>& out) {
+                const int parts = dist + 1;   // words at distance <= dist agree on at least one of dist + 1 parts
+                for (int part = 0; part < parts; part++) {
+                    const int c0 = (part * k) / parts, c1 = ((part + 1) * k) / parts;
+                    const uint64_t mask = (((1ull << (2 * (c1 - c0))) - 1ull) << (2 * c0));
+                    std::sort(forms.begin(), forms.end(), [&](const Form& x, const Form& y) { return (x.w & mask) < (y.w & mask); });
+                    for (size_t a0 = 0; a0 < forms.size();) {
+                        size_t a1 = a0 + 1;
+                        while (a1 < forms.size() && (forms[a1].w & mask) == (forms[a0].w & mask)) a1++;
+                        if (a1 - a0 > 4096) {   // pathological low-complexity group: flag all, skip the quadratic pass
+                            for (size_t x = a0; x < a1; x++) out[forms[x].id] = 1;
+                        } else {
+                            for (size_t x = a0; x < a1; x++)
+                                for (size_t y = x + 1; y < a1; y++) {
+                                    const uint64_t d = forms[x].w ^ forms[y].w;
+                                    if (__builtin_popcountll((d | (d >> 1)) & 0x5555555555555555ull) <= dist)
+                                        out[forms[x].id] = out[forms[y].id] = 1;   // also catches u vs rc(u) (same id)
+                                }
+                        }
+                        a0 = a1;
                     }
-                    a0 = a1;
                 }
-            }
+            };
+            flag_within(2, h_amb);
+            if (h_u.size() <= kAmb3MaxKmers) flag_within(3, h_amb3);
+            else std::fill(h_amb3.begin(), h_amb3.end(), (uint8_t)1);
         }
+        for (size_t i = 0; i < h_u.size(); i++) if (h_is_pseudo[i]) h_amb3[id_of[i]] = 1;
         for (size_t i = 0; i < h_u.size(); i++) if (h_is_pseudo[i]) h_amb[id_of[i]] = 1;
         std::vector<uint8_t> rc_of_id(h_u.size(), 0);   // the k-mer's first occurrence was reverse-complemented to become canonical
         for (size_t i = 0; i < h_u.size(); i++) rc_of_id[id_of[i]] = first_rc[i];
         std::vector<uint32_t> h_codes(h_refw.size(), 0u), h_yf(h_refw.size(), 0u), h_yr(h_refw.size(), 0u);   // bk_device.h
         const size_t bpad_w = (size_t)bk::scan_bit_pad_words();
-        std::vector<uint32_t> h_has(bpad_w + (cells + 31) / 32 + (size_t)bk::scan_bit_back_words(), 0u), h_clean(h_has.size(), 0u);
+        std::vector<uint32_t> h_has(bpad_w + (cells + 31) / 32 + (size_t)bk::scan_bit_back_words(), 0u), h_clean(h_has.size(), 0u), h_clean3(h_has.size(), 0u);
         for (uint64_t c = 0; c < cells; c++) {
             if (h_id_at[c] == kNone) continue;
             const size_t wi = pad_w + (c >> 4);
@@ -577,6 +588,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             const bool to_next = c + 1 < cells && h_id_at[c + 1] != kNone && h_id_at[c + 1] == h_id_at[c] + 1;
             h_has[bpad_w + (c >> 5)] |= 1u << (c & 31);
             if (clean) h_clean[bpad_w + (c >> 5)] |= 1u << (c & 31);
+            if (!h_amb3[h_id_at[c]]) h_clean3[bpad_w + (c >> 5)] |= 1u << (c & 31);
             h_yf[wi] |= (clean | (from_prev ? 2u : 0u)) << sh;
             h_yr[wi] |= (clean | (to_next ? 2u : 0u)) << sh;
         }
@@ -597,6 +609,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         BK_HIP(e->ref_words.upload(h_refw));
         BK_HIP(e->cell_has.upload(h_has));
         BK_HIP(e->cell_clean.upload(h_clean));
+        BK_HIP(e->cell_clean3.upload(h_clean3));
         BK_HIP(e->cell_yf.upload(h_yf));
         BK_HIP(e->cell_yr.upload(h_yr));
         BK_HIP(e->cell_codes.upload(h_codes));
@@ -794,7 +807,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.n_records_dev = n_records_dev;
     a.ixp = e->d_view.p;
     a.k = e->k; a.wstart = e->wstart; a.W = e->W; a.v_omin = e->v_omin; a.v_span = e->v_span; a.v_off = e->v_off; a.total_cells = (uint32_t)e->total_cells; a.n_u = e->n_u;
-    a.ref_words = e->ref_words.p; a.cell_codes = e->cell_codes.p; a.cell_has = e->cell_has.p; a.cell_clean = e->cell_clean.p; a.cell_yf = e->cell_yf.p; a.cell_yr = e->cell_yr.p; a.id_at = e->id_at.p;
+    a.ref_words = e->ref_words.p; a.cell_codes = e->cell_codes.p; a.cell_has = e->cell_has.p; a.cell_clean = e->cell_clean.p; a.cell_clean3 = e->cell_clean3.p; a.cell_yf = e->cell_yf.p; a.cell_yr = e->cell_yr.p; a.id_at = e->id_at.p;
     a.words = d_words; a.lens = d_lens; a.n_records = n; a.stride_words = stride_words;
     a.counters = e->counters[mate].p;
     a.kmer_total = e->kstats.p + mate * 4 + 1;

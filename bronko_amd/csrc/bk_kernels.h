@@ -16,6 +16,7 @@ struct ScanArgs {
     const uint32_t* cell_codes;
     const uint32_t* cell_has;       // IndexView::cell_has / cell_clean (scan_bit_pad_words() words of front padding)
     const uint32_t* cell_clean;
+    const uint32_t* cell_clean3;    // IndexView::cell_clean3 (same padding)
     const uint32_t* cell_yf;        // IndexView::cell_yf / cell_yr (same padding) / id_at
     const uint32_t* cell_yr;
     const uint32_t* id_at;

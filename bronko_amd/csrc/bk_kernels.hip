@@ -308,7 +308,7 @@ __device__ __forceinline__ void v_point(unsigned long long* __restrict__ v_count
     if (oo >= (uint32_t)span) return;   // offsets outside the layout touch no window bucket
     unsigned long long* row = v_counters + v_row_base(id + oo, b, d, span) + oo;
     atomicAdd(row, 1ull);
-    atomicAdd(row + 1, ~0ull);
+    if (oo + 1u < (uint32_t)span) atomicAdd(row + 1, ~0ull);   // (slot `span` is never read)
 }
 
 // The slow path as a software pipeline.  A batch of up to 64 queued k-mers (one per lane) advances one stage per
@@ -440,6 +440,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     const unsigned int* cleanw = (REF_LDS ? lds_ref + n_refw + n_bitw : a.cell_clean) + kBitPadWords;
     const unsigned int* yfw = a.cell_yf + kRefPadWords;   // batches only (global memory, L1 / L2 cached)
     const unsigned int* yrw = a.cell_yr + kRefPadWords;
+    const unsigned int* c3w = a.cell_clean3 + kBitPadWords;
 
     const int k = KT ? KT : a.k;
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;  // k <= 31
@@ -631,6 +632,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 // along the diagonal: base differences with the reference as the read sees it, and the clean / follow bits of
                 // the <= 32 cells of the chunk, all in step order
                 uint64_t da = 0, db = 0, yc = 0;
+                uint32_t c3 = 0;   // per cell of the chunk: no other reference k-mer form within Hamming distance 3 (bk_device.h cell_clean3)
                 uint32_t d_lo = 0, d_hi = 0, id = 0;
                 bool id_ok = false;
                 const uint32_t ddir = fwd2 ? 1u : 0xffffffffu;
@@ -640,11 +642,13 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                     if (fwd2) {
                         ra = symbols_at(refw, c_first); rb = symbols_at(refw, c_first + 32);
                         yc = symbols_at(yfw, c_first);
+                        c3 = bits32_at(c3w, c_first);
                     } else {
                         // read base s_first + t <-> complement of reference base c_first + k - 1 - t
                         ra = ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 31));
                         rb = ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 63));
                         yc = rev2_64(symbols_at(yrw, c_first - 31));
+                        c3 = __builtin_bitreverse32(bits32_at(c3w, c_first - 31));
                     }
                     da = ga ^ ra; db = gb ^ rb;
                     const uint64_t d0 = kp ? rev2_64(da & pmask) >> (64 - 2 * kp) : 0ull;
@@ -692,13 +696,17 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                     }
                     // everything else (no diagonal, several differences, dirty neighbourhoods, unknown id, no reference
                     // k-mer at the cell) is resolved by the slow pipeline
-                    const bool miss = valid && !simple && a.ablate != 3;
+                    // ... except two differences from a reference k-mer that has no other reference k-mer form within distance 3:
+                    // such a k-mer is neither a reference k-mer nor one base away from one (triangle inequality) -- it touches
+                    // nothing (full_kmer_stats: only the statistics table wants it)
+                    const bool dead = ok && n_diff == 2u && ((c3 >> t) & 1u);
+                    const bool miss = valid && !simple && !(dead && !STATS) && a.ablate != 3;
                     const unsigned long long mm = __ballot(miss);
                     if (mm) {
                         if (miss) {
                             const bool lt = f_hi < r_hi2 || (f_hi == r_hi2 && f_lo < r_lo2);   // lcb.rs:90-94
                             const uint64_t cc = lt ? (((uint64_t)f_hi << 32) | f_lo) : (((uint64_t)r_hi2 << 32) | r_lo2);
-                            q[qn + lane_prefix(mm)] = cc | (lt ? 0ull : 1ull << 62);
+                            q[qn + lane_prefix(mm)] = cc | (lt ? 0ull : 1ull << 62) | (dead ? 1ull << 63 : 0ull);
                         }
                         qn += (uint32_t)__popcll(mm);
                         __builtin_amdgcn_wave_barrier();
@@ -761,7 +769,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                     if (lo2 <= hi2 && a.ablate != 2) {
                         unsigned long long* row = v_counters + v_row_base(id_first + o_first - (uint32_t)omin, fwd2 ? br : 3u - br, fwd2 ? 0u : 1u, span);
                         atomicAdd(row + (lo2 - omin), 1ull);
-                        atomicAdd(row + (hi2 - omin + 1), ~0ull);
+                        if (hi2 - omin + 1 < span) atomicAdd(row + (hi2 - omin + 1), ~0ull);   // (slot `span` is never read)
                     }
                 }
                 // (cannot happen for a run Level 1 made on an intact index; kept so that nothing is ever dropped)

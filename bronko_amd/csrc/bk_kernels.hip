@@ -1059,6 +1059,56 @@ __global__ __launch_bounds__(256) void finalize_reduce_kernel(FinalizeArgs a, in
     else if (a.distinct_total) *a.distinct_total += s;
 }
 
+// Votes of one workgroup gathered in LDS before they go to the pileup: many k-mers vote for the same cell (the k-mers that
+// cover one reference position), and scattered 64-bit global atomics are what bounds finalize.  A small open-addressing
+// table keyed by (strand, cell, base): #k-mers add up, depth takes the max; vt_flush writes every used slot with one pair of
+// global atomics.  A vote that finds its neighbourhood of the table full goes to the pileup directly.
+constexpr int kVoteSlots = 512;
+constexpr size_t kVoteLdsBytes = (size_t)kVoteSlots * (8 + 8 + 4);
+struct VoteTable {
+    unsigned long long* keys;   // [kVoteSlots], ~0 = free
+    unsigned long long* mx;     // [kVoteSlots]
+    unsigned int* cnt;          // [kVoteSlots]
+};
+__device__ __forceinline__ VoteTable vt_make(unsigned char* lds) {
+    VoteTable vt;
+    vt.keys = reinterpret_cast<unsigned long long*>(lds);
+    vt.mx = vt.keys + kVoteSlots;
+    vt.cnt = reinterpret_cast<unsigned int*>(vt.mx + kVoteSlots);
+    return vt;
+}
+__device__ __forceinline__ void vt_clear(const VoteTable& vt) {   // whole workgroup; caller synchronises
+    for (int i = threadIdx.x; i < kVoteSlots; i += blockDim.x) { vt.keys[i] = ~0ull; vt.mx[i] = 0ull; vt.cnt[i] = 0u; }
+}
+// the vote of call.rs:1327-1384 (see vote()), into the table
+__device__ __forceinline__ void vt_vote(const VoteTable& vt, const FinalizeArgs& a, const DevEntry& e, uint64_t c, uint32_t isrc, int k,
+                                        unsigned long long v) {
+    uint32_t bit_idx;
+    bool forward;
+    if (e.canonical) { bit_idx = ((uint32_t)(c >> (2 * e.idx)) & 3u) ^ 3u; forward = isrc != 0; }
+    else { bit_idx = (uint32_t)(c >> (2 * (k - 1 - e.idx))) & 3u; forward = isrc == 0; }
+    const unsigned long long key = (((unsigned long long)e.cell * 4 + bit_idx) << 1) | (forward ? 0ull : 1ull);
+    uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 55) & (kVoteSlots - 1);
+    for (int probe = 0; probe < 8; ++probe) {
+        const unsigned long long old = atomicCAS(&vt.keys[h], ~0ull, key);
+        if (old == ~0ull || old == key) { atomicAdd(&vt.cnt[h], 1u); atomicMax(&vt.mx[h], v); return; }
+        h = (h + 1) & (kVoteSlots - 1);
+    }
+    vote(a, e, c, isrc, k, v);
+}
+__device__ __forceinline__ void vt_flush(const VoteTable& vt, const FinalizeArgs& a) {   // whole workgroup, between two barriers
+    __syncthreads();
+    for (int i = threadIdx.x; i < kVoteSlots; i += blockDim.x) {
+        const unsigned long long key = vt.keys[i];
+        if (key == ~0ull) continue;
+        const size_t cell = (size_t)(key >> 1);
+        atomicAdd(a.pileup + ((key & 1ull) ? 3 : 2) * a.plane + cell, (unsigned long long)vt.cnt[i]);   // #kmers
+        atomicMax(a.pileup + ((key & 1ull) ? 1 : 0) * a.plane + cell, vt.mx[i]);                        // depth
+        vt.keys[i] = ~0ull; vt.mx[i] = 0ull; vt.cnt[i] = 0u;
+    }
+    __syncthreads();
+}
+
 // Reverse complement of a k-mer (first base on top, like every canonical k-mer here).
 __device__ __forceinline__ uint64_t revcomp_kmer(uint64_t c, int k) {
     const uint64_t t = ~c;
@@ -1112,7 +1162,9 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const IndexView& ix = a.ix;
     uint32_t* lstats = reinterpret_cast<uint32_t*>(smem);   // [n_files][3] block-local tallies + 2 scratch words
+    const VoteTable vt = vt_make(smem + (((size_t)ix.n_files * 3 + 2) * sizeof(uint32_t) + 15) / 16 * 16);
     for (int g = threadIdx.x; g < ix.n_files * 3 + 2; g += 256) lstats[g] = 0;
+    vt_clear(vt);
     __syncthreads();
 
     const int k = ix.k;
@@ -1198,14 +1250,19 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
     };
 
-    // one half-wave (32 lanes) per row, lane oo = offset: the row's prefix sums by shuffles, then every lane maps its own
-    // k-mer.  The k-mers of a row mostly vote for the same pileup cell (the reference position of the differing base); when
-    // all single-entry votes of the row agree on (strand, cell) they are merged into one pair of atomics.
+    // One half-wave (32 lanes) per row, lane oo = offset: the row's prefix sums by shuffles, then every lane maps its own
+    // k-mer.  A workgroup takes 8 rows with the same base and direction and q, q + 2, ..., q + 14: the k-mers of a row that
+    // are canonical as written all vote for one pileup cell (the reference position the row stands for), and those that
+    // were reverse-complemented vote for cells that rows q and q + 2 share (their vote mirrors the offset, call.rs:1331-1357)
+    // -- the workgroup's vote table (LDS) merges both kinds before anything goes to the pileup.
     const uint32_t oo = threadIdx.x & 31u;
-    const int half = (threadIdx.x & 32u) ? 32 : 0;
-    for (uint64_t wk = row_lo + (((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 5); wk < row_lo + ((row_hi - row_lo + 7) & ~7ull);
-         wk += ((uint64_t)gridDim.x * 256) >> 5) {
-        const bool in_row = wk < row_hi && oo < rl;
+    const uint32_t hw = threadIdx.x >> 5;                       // half-wave of the workgroup: 0..7
+    const uint64_t nq = (uint64_t)ix.n_full + (uint32_t)ix.v_span;
+    const uint64_t n_units = ((nq + 15) / 16) * 16;            // unit u: q block u / 16, parity (u / 8) & 1, (base, direction) u & 7
+    for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const uint64_t qrow = (u >> 4) * 16 + ((u >> 3) & 1ull) + 2ull * hw;
+        const uint64_t wk = qrow * 8 + (u & 7ull);
+        const bool in_row = qrow < nq && wk >= row_lo && wk < row_hi && oo < rl;
         unsigned long long n = in_row ? vc[wk * rl + oo] : 0ull;
 #pragma unroll
         for (int off = 1; off < 32; off <<= 1) {
@@ -1249,43 +1306,12 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         first.cell = r.z; first.file = (uint16_t)(r.w & 0xffffu); first.idx = (uint8_t)(r.w >> 16); first.canonical = (uint8_t)(r.w >> 24);
         // single-entry bucket: the vote of call.rs:1327-1384 (see vote()), merged across the row when possible
         const bool single = act && cnt == 1u;
-        uint32_t bit_idx;
-        bool forward;
-        if (first.canonical) { bit_idx = ((uint32_t)(c >> (2 * first.idx)) & 3u) ^ 3u; forward = isrc != 0; }
-        else { bit_idx = (uint32_t)(c >> (2 * (k - 1 - first.idx))) & 3u; forward = isrc == 0; }
-        const unsigned long long key = single ? (((unsigned long long)first.cell * 4 + bit_idx) << 1) | (forward ? 0ull : 1ull) : ~0ull;
-        uint32_t rem = (uint32_t)(__ballot(single) >> half);   // single-entry votes of this row not yet cast (uniform within the half-wave)
-        const uint32_t me = 1u << oo;
-        if (rem) {
-            // per-genome tallies: one hit per k-mer in that genome ("variant" unless the window is a single bucket), merged
-            // over the lanes that share the first one's genome
-            const int lf = half + __builtin_ctz(rem);
-            const bool samef = single && first.file == (uint16_t)__shfl((int)first.file, lf);
-            const uint32_t nf = (uint32_t)__popc((uint32_t)(__ballot(samef) >> half));
-            const uint32_t add = samef ? ((int)(threadIdx.x & 63u) == lf ? nf : 0u) : (single ? 1u : 0u);
-            if (add) {
-                if (ix.W == 1) { atomicAdd(&lstats[first.file * 3 + 0], add); atomicAdd(&lstats[first.file * 3 + 2], add); }
-                else atomicAdd(&lstats[first.file * 3 + 1], add);
-            }
+        if (single) {
+            vt_vote(vt, a, first, c, isrc, k, v);
+            // one hit in that genome: "variant" unless the window is a single bucket
+            if (ix.W == 1) { atomicAdd(&lstats[first.file * 3 + 0], 1u); atomicAdd(&lstats[first.file * 3 + 2], 1u); }
+            else atomicAdd(&lstats[first.file * 3 + 1], 1u);
         }
-        // k-mers that are canonical as written all vote for the reference position of the differing base; merge equal targets
-        // (two rounds catch that group whichever lane comes first), the rest vote one by one
-        for (int round = 0; round < 2 && rem; ++round) {
-            const int leader = half + __builtin_ctz(rem);
-            const unsigned long long lkey = __shfl(key, leader);
-            const bool same = (rem & me) && key == lkey;
-            unsigned long long vm = same ? v : 0ull;
-#pragma unroll
-            for (int off = 16; off; off >>= 1) { const unsigned long long o2 = __shfl_xor(vm, off, 32); vm = vm > o2 ? vm : o2; }
-            const uint32_t sm = (uint32_t)(__ballot(same) >> half);
-            if ((int)(threadIdx.x & 63u) == leader) {
-                const size_t cell = (size_t)(key >> 1);
-                atomicAdd(a.pileup + ((key & 1ull) ? 3 : 2) * a.plane + cell, (unsigned long long)__popc(sm));   // #kmers
-                atomicMax(a.pileup + ((key & 1ull) ? 1 : 0) * a.plane + cell, vm);                               // depth
-            }
-            rem &= ~sm;
-        }
-        if (rem & me) vote(a, first, c, isrc, k, v);
         if (act && cnt > 1u) {
             // entries of one bucket are grouped by file (index build appends file by file): run lengths = hits per file
             uint32_t n_perfect = 0, perfect_file = 0;
@@ -1294,7 +1320,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
                 const uint32_t file = en.file;
                 uint32_t run = 0;
                 for (;;) {
-                    vote(a, en, c, isrc, k, v); ++run; ++x;
+                    vt_vote(vt, a, en, c, isrc, k, v); ++run; ++x;
                     if (x >= cnt) break;
                     en = ix.entries[r.x + x];
                     if (en.file != file) break;
@@ -1304,6 +1330,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
             }
             if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
         }
+        vt_flush(vt, a);
     }
     // the pseudo k-mers' counters (k = 31 only), one thread each
     for (uint64_t x = px_lo + (uint64_t)blockIdx.x * 256 + threadIdx.x; x < px_hi; x += (uint64_t)gridDim.x * 256) {
@@ -1326,19 +1353,25 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const IndexView& ix = a.ix;
     uint32_t* lstats = reinterpret_cast<uint32_t*>(smem);   // [n_files][3] block-local tallies + 2 scratch words
+    const VoteTable vt = vt_make(smem + (((size_t)ix.n_files * 3 + 2) * sizeof(uint32_t) + 15) / 16 * 16);
     for (int g = threadIdx.x; g < ix.n_files * 3 + 2; g += 256) lstats[g] = 0;
+    vt_clear(vt);
     __syncthreads();
     const int k = ix.k;
     const uint32_t W = (uint32_t)ix.W;
     const uint64_t c_lo = min(a.elem_lo, e_plane_len(ix.n_u)), c_hi = min(a.elem_hi, e_plane_len(ix.n_u));   // this shard's E counters
     const uint64_t n_work = c_hi * W;
     unsigned int kept = 0, distinct = 0;
-    for (uint64_t g = c_lo * W + (uint64_t)blockIdx.x * 256 + threadIdx.x; g < n_work; g += (uint64_t)gridDim.x * 256) {
+    // 256 consecutive (counter, bucket) pairs per workgroup and round: ~8 consecutive reference k-mers, whose votes fall on
+    // ~25 pileup cells -- gathered in the workgroup's vote table (LDS) before they go to the pileup
+    for (uint64_t g0 = c_lo * W + (uint64_t)blockIdx.x * 256; g0 < n_work; g0 += (uint64_t)gridDim.x * 256) {
+      const uint64_t g = g0 + threadIdx.x;
+      if (g < n_work) do {
         const uint64_t cidx = g / W;
         const uint32_t t = (uint32_t)(g % W);
         const unsigned long long n = a.counters[cidx];
         distinct += (n != 0 && t == 0);
-        if (n == 0 || n < a.ci || n > a.cx) continue;           // kmc -ci / -cx act on the true count
+        if (n == 0 || n < a.ci || n > a.cx) break;              // kmc -ci / -cx act on the true count
         const unsigned long long v = n > a.cs ? a.cs : n;       // kmc -cs: reported count saturates
         const uint32_t id = (uint32_t)(cidx >> 1), isrc = (uint32_t)cidx & 1u;
         const uint64_t c = ix.kmer_of[id];
@@ -1346,12 +1379,12 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
             const uint4 r = *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)id * W + t);
             DevEntry first;
             first.cell = r.z; first.file = (uint16_t)(r.w & 0xffffu); first.idx = (uint8_t)(r.w >> 16); first.canonical = (uint8_t)(r.w >> 24);
-            if (r.y) vote(a, first, c, isrc, k, v);
-            for (uint32_t q = 1; q < r.y; ++q) vote(a, ix.entries[r.x + q], c, isrc, k, v);
+            if (r.y) vt_vote(vt, a, first, c, isrc, k, v);
+            for (uint32_t q = 1; q < r.y; ++q) vt_vote(vt, a, ix.entries[r.x + q], c, isrc, k, v);
         } else {
             const uint32_t s = ix.slot_of[(size_t)id * W + t];
             const uint32_t off = ix.ent_off[s], cnt = ix.ent_len[s];
-            for (uint32_t q = 0; q < cnt; ++q) vote(a, ix.entries[off + q], c, isrc, k, v);
+            for (uint32_t q = 0; q < cnt; ++q) vt_vote(vt, a, ix.entries[off + q], c, isrc, k, v);
         }
         if (t == 0) {
             ++kept;
@@ -1363,6 +1396,8 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
             }
             if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
         }
+      } while (false);
+      vt_flush(vt, a);
     }
     __syncthreads();
     finalize_epilogue(a, lstats, kept, distinct, lstats + ix.n_files * 3, a.row_exact + (int)blockIdx.x);
@@ -1461,12 +1496,13 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     // K2a
     const uint64_t n_v = std::max<uint64_t>(v_real_rows(a.ix.n_full, a.ix.v_span) * 32ull, a.ix.n_prows * 8ull);   // threads K2a can use
     const unsigned b_var = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_v + 255) / 256, kFinVariantBlocks));
-    hipLaunchKernelGGL(finalize_variant_kernel, dim3(b_var), dim3(256), lds_stats, stream, a);
+    const size_t lds_votes = (lds_stats + 15) / 16 * 16 + kVoteLdsBytes;
+    hipLaunchKernelGGL(finalize_variant_kernel, dim3(b_var), dim3(256), lds_votes, stream, a);
     // K2e
     const uint64_t n_work = e_plane_len(a.ix.n_u) * (uint64_t)a.ix.W;
     const unsigned b_ex = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_work + 255) / 256, kFinExactBlocks));
     a.row_exact = (int)b_var;
-    hipLaunchKernelGGL(finalize_exact_kernel, dim3(b_ex), dim3(256), lds_stats, stream, a);
+    hipLaunchKernelGGL(finalize_exact_kernel, dim3(b_ex), dim3(256), lds_votes, stream, a);
     // K2b (deferred k-mers only; the kernel reads their number on the device)
     const size_t lds = finalize_lds_bytes(a.ix.n_files);
     unsigned b_gen = (unsigned)std::min<size_t>(kFinGeneralBlocks, 256 * std::max<size_t>(1, (160u * 1024u) / lds));

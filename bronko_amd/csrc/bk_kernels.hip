@@ -1064,25 +1064,30 @@ __global__ __launch_bounds__(256) void finalize_reduce_kernel(FinalizeArgs a, in
 // table keyed by (strand, cell, base): #k-mers add up, depth takes the max; vt_flush writes every used slot with one pair of
 // global atomics.  A vote that finds its neighbourhood of the table full goes to the pileup directly.
 constexpr int kVoteSlots = 512;
-constexpr size_t kVoteLdsBytes = (size_t)kVoteSlots * (8 + 8 + 4);
+constexpr size_t kVoteLdsBytes = (size_t)kVoteSlots * (8 + 8 + 4 + 2) + 16;
 struct VoteTable {
     unsigned long long* keys;   // [kVoteSlots], ~0 = free
     unsigned long long* mx;     // [kVoteSlots]
     unsigned int* cnt;          // [kVoteSlots]
+    unsigned int* n_used;       // [2] slots taken since the last flush, alternating with the round's parity
+    unsigned short* used;       // [kVoteSlots] ... and which
 };
 __device__ __forceinline__ VoteTable vt_make(unsigned char* lds) {
     VoteTable vt;
     vt.keys = reinterpret_cast<unsigned long long*>(lds);
     vt.mx = vt.keys + kVoteSlots;
     vt.cnt = reinterpret_cast<unsigned int*>(vt.mx + kVoteSlots);
+    vt.n_used = vt.cnt + kVoteSlots;
+    vt.used = reinterpret_cast<unsigned short*>(vt.n_used + 4);
     return vt;
 }
 __device__ __forceinline__ void vt_clear(const VoteTable& vt) {   // whole workgroup; caller synchronises
     for (int i = threadIdx.x; i < kVoteSlots; i += blockDim.x) { vt.keys[i] = ~0ull; vt.mx[i] = 0ull; vt.cnt[i] = 0u; }
+    if (threadIdx.x == 0) { vt.n_used[0] = 0u; vt.n_used[1] = 0u; }
 }
 // the vote of call.rs:1327-1384 (see vote()), into the table
-__device__ __forceinline__ void vt_vote(const VoteTable& vt, const FinalizeArgs& a, const DevEntry& e, uint64_t c, uint32_t isrc, int k,
-                                        unsigned long long v) {
+__device__ __forceinline__ void vt_vote(const VoteTable& vt, uint32_t par, const FinalizeArgs& a, const DevEntry& e, uint64_t c, uint32_t isrc,
+                                        int k, unsigned long long v) {
     uint32_t bit_idx;
     bool forward;
     if (e.canonical) { bit_idx = ((uint32_t)(c >> (2 * e.idx)) & 3u) ^ 3u; forward = isrc != 0; }
@@ -1091,22 +1096,27 @@ __device__ __forceinline__ void vt_vote(const VoteTable& vt, const FinalizeArgs&
     uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 55) & (kVoteSlots - 1);
     for (int probe = 0; probe < 8; ++probe) {
         const unsigned long long old = atomicCAS(&vt.keys[h], ~0ull, key);
+        if (old == ~0ull) vt.used[atomicAdd(vt.n_used + par, 1u)] = (unsigned short)h;
         if (old == ~0ull || old == key) { atomicAdd(&vt.cnt[h], 1u); atomicMax(&vt.mx[h], v); return; }
         h = (h + 1) & (kVoteSlots - 1);
     }
     vote(a, e, c, isrc, k, v);
 }
-__device__ __forceinline__ void vt_flush(const VoteTable& vt, const FinalizeArgs& a) {   // whole workgroup, between two barriers
+// whole workgroup, between two barriers; par = parity of the round that just voted (the next round uses the other counter)
+__device__ __forceinline__ void vt_flush(const VoteTable& vt, uint32_t par, const FinalizeArgs& a) {
     __syncthreads();
-    for (int i = threadIdx.x; i < kVoteSlots; i += blockDim.x) {
+    const unsigned int nu = vt.n_used[par];
+    if (threadIdx.x == 0) vt.n_used[par ^ 1u] = 0u;
+    for (unsigned int u = threadIdx.x; u < nu; u += blockDim.x) {
+        const int i = vt.used[u];
         const unsigned long long key = vt.keys[i];
-        if (key == ~0ull) continue;
         const size_t cell = (size_t)(key >> 1);
         atomicAdd(a.pileup + ((key & 1ull) ? 3 : 2) * a.plane + cell, (unsigned long long)vt.cnt[i]);   // #kmers
         atomicMax(a.pileup + ((key & 1ull) ? 1 : 0) * a.plane + cell, vt.mx[i]);                        // depth
         vt.keys[i] = ~0ull; vt.mx[i] = 0ull; vt.cnt[i] = 0u;
     }
     __syncthreads();
+    if (threadIdx.x == 0) { vt.n_used[0] = 0u; vt.n_used[1] = 0u; }
 }
 
 // Reverse complement of a k-mer (first base on top, like every canonical k-mer here).
@@ -1259,6 +1269,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
     const uint32_t hw = threadIdx.x >> 5;                       // half-wave of the workgroup: 0..7
     const uint64_t nq = (uint64_t)ix.n_full + (uint32_t)ix.v_span;
     const uint64_t n_units = ((nq + 15) / 16) * 16;            // unit u: q block u / 16, parity (u / 8) & 1, (base, direction) u & 7
+    uint32_t par = 0;
     for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         const uint64_t qrow = (u >> 4) * 16 + ((u >> 3) & 1ull) + 2ull * hw;
         const uint64_t wk = qrow * 8 + (u & 7ull);
@@ -1307,7 +1318,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         // single-entry bucket: the vote of call.rs:1327-1384 (see vote()), merged across the row when possible
         const bool single = act && cnt == 1u;
         if (single) {
-            vt_vote(vt, a, first, c, isrc, k, v);
+            vt_vote(vt, par, a, first, c, isrc, k, v);
             // one hit in that genome: "variant" unless the window is a single bucket
             if (ix.W == 1) { atomicAdd(&lstats[first.file * 3 + 0], 1u); atomicAdd(&lstats[first.file * 3 + 2], 1u); }
             else atomicAdd(&lstats[first.file * 3 + 1], 1u);
@@ -1320,7 +1331,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
                 const uint32_t file = en.file;
                 uint32_t run = 0;
                 for (;;) {
-                    vt_vote(vt, a, en, c, isrc, k, v); ++run; ++x;
+                    vote(a, en, c, isrc, k, v); ++run; ++x;   // (several genomes: as many cells -- not worth the table)
                     if (x >= cnt) break;
                     en = ix.entries[r.x + x];
                     if (en.file != file) break;
@@ -1330,7 +1341,8 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
             }
             if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
         }
-        vt_flush(vt, a);
+        vt_flush(vt, par, a);
+        par ^= 1u;
     }
     // the pseudo k-mers' counters (k = 31 only), one thread each
     for (uint64_t x = px_lo + (uint64_t)blockIdx.x * 256 + threadIdx.x; x < px_hi; x += (uint64_t)gridDim.x * 256) {
@@ -1360,8 +1372,10 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     const int k = ix.k;
     const uint32_t W = (uint32_t)ix.W;
     const uint64_t c_lo = min(a.elem_lo, e_plane_len(ix.n_u)), c_hi = min(a.elem_hi, e_plane_len(ix.n_u));   // this shard's E counters
-    const uint64_t n_work = c_hi * W;
+    const uint64_t r_hi = min(c_hi, 2ull * ix.n_full);          // E counters of reference k-mers proper end here
+    const uint64_t n_work = r_hi * W;
     unsigned int kept = 0, distinct = 0;
+    uint32_t par = 0;
     // 256 consecutive (counter, bucket) pairs per workgroup and round: ~8 consecutive reference k-mers, whose votes fall on
     // ~25 pileup cells -- gathered in the workgroup's vote table (LDS) before they go to the pileup
     for (uint64_t g0 = c_lo * W + (uint64_t)blockIdx.x * 256; g0 < n_work; g0 += (uint64_t)gridDim.x * 256) {
@@ -1375,16 +1389,13 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
         const unsigned long long v = n > a.cs ? a.cs : n;       // kmc -cs: reported count saturates
         const uint32_t id = (uint32_t)(cidx >> 1), isrc = (uint32_t)cidx & 1u;
         const uint64_t c = ix.kmer_of[id];
-        if (id < ix.n_full) {
+        {
             const uint4 r = *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)id * W + t);
             DevEntry first;
             first.cell = r.z; first.file = (uint16_t)(r.w & 0xffffu); first.idx = (uint8_t)(r.w >> 16); first.canonical = (uint8_t)(r.w >> 24);
-            if (r.y) vt_vote(vt, a, first, c, isrc, k, v);
-            for (uint32_t q = 1; q < r.y; ++q) vt_vote(vt, a, ix.entries[r.x + q], c, isrc, k, v);
-        } else {
-            const uint32_t s = ix.slot_of[(size_t)id * W + t];
-            const uint32_t off = ix.ent_off[s], cnt = ix.ent_len[s];
-            for (uint32_t q = 0; q < cnt; ++q) vt_vote(vt, a, ix.entries[off + q], c, isrc, k, v);
+            if (r.y == 1u) vt_vote(vt, par, a, first, c, isrc, k, v);
+            else if (r.y) vote(a, first, c, isrc, k, v);       // (several genomes: as many cells -- not worth the table)
+            for (uint32_t q = 1; q < r.y; ++q) vote(a, ix.entries[r.x + q], c, isrc, k, v);
         }
         if (t == 0) {
             ++kept;
@@ -1397,7 +1408,31 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
             if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
         }
       } while (false);
-      vt_flush(vt, a);
+      vt_flush(vt, par, a);
+      par ^= 1u;
+    }
+    // pseudo k-mers (k = 31): nearly all of their counters are zero -- one thread per counter, the buckets in a loop
+    for (uint64_t cidx = max(c_lo, 2ull * ix.n_full) + (uint64_t)blockIdx.x * 256 + threadIdx.x; cidx < c_hi; cidx += (uint64_t)gridDim.x * 256) {
+        const unsigned long long n = a.counters[cidx];
+        if (n == 0) continue;
+        distinct += 1;
+        if (n < a.ci || n > a.cx) continue;
+        ++kept;
+        const unsigned long long v = n > a.cs ? a.cs : n;
+        const uint32_t id = (uint32_t)(cidx >> 1), isrc = (uint32_t)cidx & 1u;
+        const uint64_t c = ix.kmer_of[id];
+        for (uint32_t t = 0; t < W; ++t) {
+            const uint32_t s = ix.slot_of[(size_t)id * W + t];
+            const uint32_t off = ix.ent_off[s], cnt = ix.ent_len[s];
+            for (uint32_t q = 0; q < cnt; ++q) vote(a, ix.entries[off + q], c, isrc, k, v);
+        }
+        uint32_t n_perfect = 0, perfect_file = 0;
+        for (uint32_t q = ix.estat_off[id]; q < ix.estat_off[id + 1]; ++q) {   // (file << 1) | perfect
+            const uint32_t e = ix.estat[q];
+            atomicAdd(&lstats[(e >> 1) * 3 + ((e & 1u) ? 0 : 1)], 1u);
+            if (e & 1u) { ++n_perfect; perfect_file = e >> 1; }
+        }
+        if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
     }
     __syncthreads();
     finalize_epilogue(a, lstats, kept, distinct, lstats + ix.n_files * 3, a.row_exact + (int)blockIdx.x);

@@ -480,3 +480,37 @@ def test_sharded_finalize_on_one_device(oracle, sars_paths):
     for e in engs:
         e.close()
     ix.close()
+
+
+def test_long_reads_with_indels_and_chimeras(oracle, sars_paths):
+    """Reads that leave their seed diagonal: 1000 bp reads (63-word records) with deletions, insertions and chimeric joins of
+    both strands.  Level 1 proves what lies on the diagonal of the chosen seed; everything behind an indel / breakpoint is
+    far from it and must come out of the general path with the same counts (the oracle does not care how reads look)."""
+    ix = oracle.Index.build(21, [sars_paths[0]])
+    g = synth.read_fasta_bytes(sars_paths[0])
+    r = synth.splitmix64(909, 6 * 3000)
+    tr = bytes.maketrans(b"ACGT", b"TGCA")
+    reads = []
+    for i in range(3000):
+        a = int(r[6 * i] % np.uint64(len(g) - 1100))
+        s = bytearray(g[a:a + 1000])
+        kind = int(r[6 * i + 1] % np.uint64(4))
+        p = 100 + int(r[6 * i + 2] % np.uint64(800))
+        if kind == 0:
+            del s[p:p + 1 + int(r[6 * i + 3] % np.uint64(5))]                      # deletion
+        elif kind == 1:
+            s[p:p] = bytes(synth.BASES[int(x) & 3] for x in r[6 * i + 3:6 * i + 5])  # 2-base insertion
+        elif kind == 2:
+            b = int(r[6 * i + 3] % np.uint64(len(g) - 600))
+            s = s[:p] + bytearray(g[b:b + 500][::-1].translate(tr))                 # chimera: other locus, other strand
+        for e in range(4):                                                           # a few substitutions
+            q = int(r[6 * i + 4] >> np.uint64(8 * e)) % len(s)
+            s[q] = synth.BASES[(synth.CODE[s[q]] + 1 + e % 3) & 3]
+        s = bytes(s)
+        reads.append(s[::-1].translate(tr) if r[6 * i + 5] & np.uint64(1) else s)
+    pile = oracle.sample_pileup(ix, [reads])
+    eng = helpers.engine_from_oracle_index(ix)
+    helpers.assert_same_pileup(helpers.hip_sample(eng, [reads], 21), pile)
+    helpers.assert_same_pileup(helpers.hip_sample(eng, [reads], 21, stride_words=20), pile)   # cut into overlapping 320-base records
+    eng.close()
+    ix.close()

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--allreduce", action="store_true", help="N > 1: all-reduce the counter plane instead of reduce-scatter + sharded finalize")
     ap.add_argument("--ref-len", type=int, default=0, help="experiment: truncate the reference to its first N bases")
+    ap.add_argument("--wide", action="store_true", help="N > 1: move the counter plane as 64-bit integers even when 32 bits would do")
     ap.add_argument("--backend", default="nccl", help="testing aid: 'gloo' lets several ranks share one GPU (rank r uses GPU r mod #GPUs)")
     args = ap.parse_args()
 
@@ -91,14 +92,20 @@ def main():
     d_lens = torch.from_numpy(lens.view(np.int16)).to(dev)
     n_rec = len(lens)
 
-    stream = torch.cuda.current_stream()
+    # one explicit (non-default) stream for the engine AND for every torch / torch.distributed operation on its buffers: the
+    # collectives are ordered against the kernels by the stream.  (The default stream's handle is 0, which
+    # bk_engine_set_stream reads as "use your own stream" -- that would leave the collectives unordered.)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     eng.set_stream(stream.cuda_stream)
     counters = torch.as_tensor(_DevArray(eng.counters_ptr(0), eng.counter_len, "<i8"), device=dev)
 
     # N > 1: reduce-scatter of the counter plane + each rank maps its part + max / sum of the small pileups (the cheap form,
     # include/bronko_hip.h); --allreduce selects the plain form (all-reduce the plane, every rank maps everything)
     sharded = world > 1 and not args.allreduce and 64 % world == 0
-    shard_fin = ShardedFinalize(eng, 1, rank, world, dev) if sharded else None
+    # (the plane travels as 32-bit integers when no k-mer of the whole sample can occur 2^31 times)
+    narrow = world * args.reads * max(args.read_len - k + 1, 1) < 2 ** 31 and not args.wide
+    shard_fin = ShardedFinalize(eng, 1, rank, world, dev, narrow=narrow) if sharded else None
 
     def step():
         eng.sample_begin()
@@ -179,7 +186,7 @@ def main():
                                "%d synthetic %d bp single-end reads per GPU per step, 0.5%% substitution errors, seed 2"
                                % (args.reads, args.read_len),
                    "reads_per_gpu": args.reads, "read_len": args.read_len, "k": k,
-                   "parallelism": ("reads sharded over %d GPU(s); RCCL reduce-scatter(sum) of the k-mer counter plane, sharded finalize, "
+                   "parallelism": ("reads sharded over %d GPU(s); RCCL reduce-scatter(sum) of the k-mer counter plane" + (" as int32" if narrow else "") + ", sharded finalize, "
                                    "all-reduce(max / sum) of the pileups" if sharded else
                                    "reads sharded over %d GPU(s); RCCL all-reduce(sum) of k-mer counters") % world
                    if world > 1 else "single GPU"},

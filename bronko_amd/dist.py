@@ -36,21 +36,27 @@ def allreduce_counters(counters):
     return counters
 
 
-def reduce_scatter_plane(plane, rank, world, out=None):
+def reduce_scatter_plane(plane, rank, world, out=None, narrow=False):
     """Sum `plane` (1-D int64, length divisible by world) across ranks, leaving only this rank's part -- elements
     [rank * n / world, (rank + 1) * n / world) -- summed, in place; the other parts are left as they were.
-    RCCL reduce-scatter on GPUs; gloo (CPU tests) has no reduce-scatter, there it is an all-reduce."""
+    RCCL reduce-scatter on GPUs; gloo (CPU tests) has no reduce-scatter, there it is an all-reduce.
+    narrow: move the plane as 32-bit integers (half the bytes over xGMI).  The plane's elements are counts and differences of
+    counts that wrap modulo 2^64; truncated to 32 bits, summed modulo 2^32 and sign-extended they are the same numbers as long
+    as every true sum lies in [-2^31, 2^31) -- the caller vouches for that (no k-mer of the sample occurs 2^31 times)."""
     if not (dist.is_available() and dist.is_initialized()) or world == 1:
         return plane
     assert plane.dtype == torch.int64 and plane.numel() % world == 0
     part = plane.numel() // world
+    src = plane.to(torch.int32) if narrow else plane
     if dist.get_backend() == "gloo":
-        _all_reduce(plane, dist.ReduceOp.SUM)
+        _all_reduce(src, dist.ReduceOp.SUM)
+        if narrow:
+            plane.copy_(src)   # int32 -> int64 sign-extends
         return plane
-    if out is None:
-        out = torch.empty(part, dtype=torch.int64, device=plane.device)
-    dist.reduce_scatter_tensor(out, plane, op=dist.ReduceOp.SUM)
-    plane[rank * part:(rank + 1) * part].copy_(out)
+    if out is None or out.dtype != src.dtype:
+        out = torch.empty(part, dtype=src.dtype, device=plane.device)
+    dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM)
+    plane[rank * part:(rank + 1) * part].copy_(out)   # (int32 -> int64 sign-extends)
     return plane
 
 
@@ -72,10 +78,13 @@ class DeviceVector:
 class ShardedFinalize:
     """The cheap multi-GPU form (include/bronko_hip.h): reduce-scatter the counter planes, map this rank's part, combine the
     pileups (max / sum) and the statistics.  After __call__ eng.sample_download() returns the full result on every rank.
-    The tensor views of the engine's device buffers are made once."""
+    The tensor views of the engine's device buffers are made once.
+    The engine must run on torch's current stream (eng.set_stream(torch.cuda.current_stream().cuda_stream) with a stream that
+    is NOT the default one, whose handle 0 means "the engine's own stream"): the collectives are ordered against the engine's
+    kernels by that stream only."""
 
-    def __init__(self, eng, n_mates, rank, world, device):
-        self.eng, self.n_mates, self.rank, self.world = eng, n_mates, rank, world
+    def __init__(self, eng, n_mates, rank, world, device, narrow=False):
+        self.eng, self.n_mates, self.rank, self.world, self.narrow = eng, n_mates, rank, world, narrow
         self.planes = [torch.as_tensor(DeviceVector(eng.counters_ptr(m), eng.counter_len), device=device) for m in range(n_mates)]
         cells4 = eng.total_cells * 4
         pile = torch.as_tensor(DeviceVector(eng.pileup_ptr(), 4 * cells4), device=device)
@@ -83,12 +92,12 @@ class ShardedFinalize:
         sp, sn = eng.shard_sums()
         self.sums = torch.as_tensor(DeviceVector(sp, sn), device=device)
         part = eng.counter_len // world
-        self.out = torch.empty(part, dtype=torch.int64, device=device) if world > 1 else None
+        self.out = torch.empty(part, dtype=torch.int32 if narrow else torch.int64, device=device) if world > 1 else None
 
     def __call__(self):
         for m, plane in enumerate(self.planes):
             self.eng.counters_ptr(m)   # (a plane this rank pushed nothing to is zeroed by this call)
-            reduce_scatter_plane(plane, self.rank, self.world, self.out)
+            reduce_scatter_plane(plane, self.rank, self.world, self.out, self.narrow)
         self.eng.sample_finalize_shard(self.n_mates, self.rank, self.world)
         combine_shard_results(self.depth, self.nk, self.sums)
         self.eng.sample_merge_shards()

@@ -88,12 +88,14 @@ def _worker_shards(rank, world, port, out_dir):
         plane = torch.randint(-5, 50, (64 * 19,), generator=g, dtype=torch.int64)
         mine = plane.clone()
         reduce_scatter_plane(mine, rank, world)
+        mine32 = plane.clone()
+        reduce_scatter_plane(mine32, rank, world, narrow=True)   # 32-bit transport: same numbers (negative differences included)
         depth = torch.randint(0, 1000, (40,), generator=g, dtype=torch.int64)
         nk = torch.randint(0, 1000, (40,), generator=g, dtype=torch.int64)
         sums = torch.randint(0, 1000, (14,), generator=g, dtype=torch.int64)
         d2, n2, s2 = depth.clone(), nk.clone(), sums.clone()
         combine_shard_results(d2, n2, s2)
-        torch.save({"plane": plane, "mine": mine, "depth": depth, "nk": nk, "sums": sums, "d2": d2, "n2": n2, "s2": s2},
+        torch.save({"plane": plane, "mine": mine, "mine32": mine32, "depth": depth, "nk": nk, "sums": sums, "d2": d2, "n2": n2, "s2": s2},
                    os.path.join(out_dir, "s%d.pt" % rank))
     finally:
         dist.destroy_process_group()
@@ -109,6 +111,7 @@ def test_reduce_scatter_and_combine_helpers(tmp_path):
     part = total.numel() // world
     for r in range(world):
         assert torch.equal(got[r]["mine"][r * part:(r + 1) * part], total[r * part:(r + 1) * part])
+        assert torch.equal(got[r]["mine32"][r * part:(r + 1) * part], total[r * part:(r + 1) * part])
         assert torch.equal(got[r]["d2"], torch.maximum(got[0]["depth"], got[1]["depth"]))
         assert torch.equal(got[r]["n2"], got[0]["nk"] + got[1]["nk"])
         assert torch.equal(got[r]["s2"], got[0]["sums"] + got[1]["sums"])

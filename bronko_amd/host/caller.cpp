@@ -4,7 +4,10 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <map>
+#include <cerrno>
 #include <cstdio>
+#include <cstring>
 #include <stdexcept>
 
 #include "lcb.hpp"
@@ -267,6 +270,53 @@ void write_overview_tsv(const std::string& out_path, const std::vector<OverviewR
         fprintf(f.fp, "%s\t%s\t%llu\t%llu\t%s\t%s\t%llu\t%llu\t%llu\n", r.filename.c_str(), r.selected_genome.c_str(),
                 (unsigned long long)r.n_major, (unsigned long long)r.n_minor, fixed(r.breadth, 4).c_str(), fixed(r.depth, 4).c_str(),
                 (unsigned long long)r.n_perfect, (unsigned long long)r.n_variant, (unsigned long long)r.n_unmapped);
+}
+
+void write_alignments(const std::string& out_dir, const Index& ix, const std::vector<SampleCalls>& samples,
+                      void (*note)(const std::string&)) {
+    for (size_t g = 0; g < ix.files.size(); g++) {
+        const FileMeta& fm = ix.files[g];
+        std::vector<const SampleCalls*> group;
+        for (const SampleCalls& sc : samples) {
+            if (sc.selected_genome != fm.name) continue;
+            if (sc.breadth < 0.90) {                                                    // call.rs:520-523
+                if (note) note("Skipping " + sc.filename + " (breadth of coverage = " + std::to_string(sc.breadth) + ")");
+                continue;
+            }
+            group.push_back(&sc);
+        }
+        if (group.empty()) continue;
+        if (group.size() < 3) {                                                         // call.rs:540-543
+            if (note) note("Skipping " + fm.name + " (only " + std::to_string(group.size()) + " samples)");
+            continue;
+        }
+        if (note) note("Building alignment for genome " + fm.name + " with " + std::to_string(group.size()) + " samples");
+        // every (sequence name, position) with a major variant in some sample -> its reference base (call.rs:570-582)
+        std::map<std::pair<std::string, uint64_t>, uint8_t> columns;
+        std::vector<std::map<std::pair<std::string, uint64_t>, uint8_t>> own(group.size());
+        for (size_t i = 0; i < group.size(); i++)
+            for (const VcfRecord& r : group[i]->records) {
+                if (!(r.af >= 0.5)) continue;
+                const std::pair<std::string, uint64_t> key(fm.sequences[(size_t)r.seq_id].name, r.pos);
+                columns[key] = r.ref_base;
+                own[i][key] = r.alt_base;
+            }
+        const std::string path = out_dir + "/" + fm.name + ".mfa";
+        FILE* f = fopen(path.c_str(), "wb");
+        if (!f) throw std::runtime_error(std::string(strerror(errno)) + " | Failed to create mfa alignment file");
+        std::string row;
+        for (const auto& kv : columns) row.push_back(base_char(kv.second));            // std::map iterates in (name, position) order
+        fprintf(f, ">%s\n%s\n", fm.name.c_str(), row.c_str());
+        for (size_t i = 0; i < group.size(); i++) {
+            row.clear();
+            for (const auto& kv : columns) {
+                const auto it = own[i].find(kv.first);
+                row.push_back(base_char(it != own[i].end() ? it->second : kv.second));
+            }
+            fprintf(f, ">%s\n%s\n", clean_sample_id(group[i]->filename).c_str(), row.c_str());
+        }
+        fclose(f);
+    }
 }
 
 }  // namespace bronko

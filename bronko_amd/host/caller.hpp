@@ -69,4 +69,17 @@ struct OverviewRow {                 // call.rs:138-149
 };
 void write_overview_tsv(const std::string& out_path, const std::vector<OverviewRow>& rows);  // call.rs:698-732
 
+// --alignment (call.rs:504-628): per selected genome with at least three samples of breadth >= 0.90, OUT/<genome>.mfa =
+// the columns of all positions at which some sample has a major variant (AF >= 0.5), reference row first, then one row per
+// sample (its alternative base where it has a major variant, the reference base elsewhere).  Columns are ordered by
+// (sequence name, position).  Upstream emits genomes and samples in hash-map order; here: index order, input order.
+// `note` receives the "Skipping ..." / "Building ..." log lines of call.rs:521,541,551.
+struct SampleCalls {
+    std::string filename, selected_genome;
+    double breadth;
+    std::vector<VcfRecord> records;
+};
+void write_alignments(const std::string& out_dir, const Index& ix, const std::vector<SampleCalls>& samples,
+                      void (*note)(const std::string&));
+
 }  // namespace bronko

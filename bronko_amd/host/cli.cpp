@@ -332,6 +332,7 @@ int run_call(const Args& a) {
     const size_t n_files = ix.files.size();
     const uint64_t cells4 = ix.total_cells() * 4;
     std::vector<OverviewRow> overview;
+    std::vector<SampleCalls> all_calls;   // --alignment
 
     // one sample = one -r file (call.rs:213-293) or one R1/R2 pair (call.rs:298-386); outputs are named after R1
     auto process = [&](const std::vector<std::string>& mates) {
@@ -382,6 +383,7 @@ int run_call(const Args& a) {
             write_vcf(a.output + "/" + stem + ".vcf", mates[0], ix, best, cs.records);
         } catch (const std::exception& e) { die(T, e.what()); }
         overview.push_back(OverviewRow{mates[0], gname, cs.n_major, cs.n_minor, cs.breadth, cs.depth, n_perfect, n_variant, n_unmapped});
+        if (a.alignment) all_calls.push_back(SampleCalls{mates[0], gname, cs.breadth, cs.records});
     };
 
     for (const auto& r : a.reads) { LOG_INFO(T, "Processing " + r); process({r}); }
@@ -393,7 +395,11 @@ int run_call(const Args& a) {
     try { write_overview_tsv(a.output + "/bronko_overview.tsv", overview); }
     catch (const std::exception& e) { die(T, e.what()); }
     LOG_INFO(T, "All samples processed successfully");
-    if (a.alignment) LOG_WARN(T, "--alignment (.mfa output, call.rs:504-628) is not implemented in this build");
+    if (a.alignment) {                                                                  // call.rs:394-397
+        LOG_INFO(T, "Building alignment(s)");
+        try { write_alignments(a.output, ix, all_calls, [](const std::string& m) { LOG_INFO("bronko::call", m); }); }
+        catch (const std::exception& e) { die(T, e.what()); }
+    }
     LOG_INFO(T, "");
     LOG_INFO(T, "bronko complete!");
     return 0;

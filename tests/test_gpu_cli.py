@@ -106,3 +106,48 @@ def test_cli_error_conventions(golden_dir, tmp_path):
         res = subprocess.run([BRONKO] + c + ["-o", str(tmp_path / "e")], capture_output=True, text=True)
         assert res.returncode == 1, (c, res.stdout, res.stderr)
         assert "ERROR" in res.stdout
+
+
+def test_call_alignment_mfa(oracle, golden_dir, tmp_path):
+    """--alignment (call.rs:504-628): four HPV16 samples with different fixed SNPs (one of them covering too little of the
+    genome: breadth < 0.90, left out) -> OUT/HPV16.mfa = the columns of all major-variant positions, reference row first, then
+    one row per kept sample.  The expected rows are rebuilt here from the oracle's variant calls for each sample."""
+    g = synth.read_fasta_bytes(os.path.join(golden_dir, "HPV16.fa"))
+    ix = oracle.Index.load(os.path.join(golden_dir, "hpv.bkdb"))
+    paths, samples = [], []
+    for i in range(4):
+        gm, isnv = synth.sample_genome(g, 40 + i, n_snp=4 + i, n_isnv=2)
+        if i == 3:
+            gm = gm[:3000]                                   # a sample that covers less than 90 % of the genome
+        reads = synth.codes_to_ascii(synth.single_end_codes(gm, 6000, 150, 140 + i, isnv=isnv if i < 3 else ()))
+        p = str(tmp_path / ("smp%d.fastq.gz" % i))
+        write_fastq_gz(p, reads, "s%d" % i)
+        paths.append(p)
+        samples.append(reads)
+    out = str(tmp_path / "out")
+    res = subprocess.run([BRONKO, "call", "-d", os.path.join(golden_dir, "hpv.bkdb"), "-r"] + paths + ["--alignment", "-o", out],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "Skipping %s (breadth of coverage" % paths[3] in res.stdout
+    # expected: from the oracle's calls
+    cols, own = {}, []
+    for i in range(4):
+        pile = oracle.sample_pileup(ix, [samples[i]])
+        recs, ptr, n, nmaj, nmin, br, dc = oracle.call_variants(ix, 0, pile, oracle.default_call_params(21))
+        if br < 0.90:
+            assert i == 3
+            continue
+        mine = {}
+        for r in recs:
+            if r["af"] >= 0.5:
+                cols[int(r["pos"])] = "ACGT"[r["ref_base"]]
+                mine[int(r["pos"])] = "ACGT"[r["alt_base"]]
+        own.append((oracle.clean_sample_id(paths[i]), mine))
+    assert len(own) == 3 and len(cols) >= 4
+    order = sorted(cols)
+    want = [">HPV16", "".join(cols[p] for p in order)]
+    for name, mine in own:
+        want += [">" + name, "".join(mine.get(p, cols[p]) for p in order)]
+    got = open(os.path.join(out, "HPV16.mfa")).read().splitlines()
+    assert got == want
+    ix.close()

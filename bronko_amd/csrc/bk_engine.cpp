@@ -5,12 +5,15 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
+#include <atomic>
 #include <unordered_map>
 #include <vector>
 
@@ -57,6 +60,32 @@ struct DevBuf {
 };
 
 struct TimedSpan { hipEvent_t a, b; int kind; };
+
+// fn(begin, end) over [0, n) on up to hardware_concurrency() threads (capped at 32): host-side table construction only
+template <typename F>
+void parallel_for(size_t n, F&& fn) {
+    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    if (n < (size_t)nt * 1024) { fn((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + nt - 1) / nt;
+    for (unsigned i = 0; i < nt; i++) {
+        const size_t b = std::min(n, i * per), en = std::min(n, b + per);
+        if (b < en) th.emplace_back([&fn, b, en] { fn(b, en); });
+    }
+    for (auto& t : th) t.join();
+}
+
+// BK_CREATE_TIMING=1: wall-clock of the phases of bk_engine_create on stderr (host-side table construction)
+struct PhaseClock {
+    bool on = getenv("BK_CREATE_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[bk_engine_create] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
 
 }  // namespace
 
@@ -312,6 +341,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     if (cells >= (1ull << 32)) return fail(BK_ERR_UNSUPPORTED, "more than 2^32 reference positions");
     e->total_cells = cells;
 
+    PhaseClock pc;
     // ---- window buckets -> device slots ------------------------------------------------------------------
     // Device key of a bucket = (wildcard position j, canonical reference k-mer with position j zeroed).  It is
     // recomputed from the metadata sequence at (file, seq, location) and checked against the stored bucket id
@@ -397,6 +427,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         }
         if (h_ent.size() >= (1ull << 32)) return fail(BK_ERR_UNSUPPORTED, "more than 2^32 index entries in the window");
     }
+    pc.lap("buckets -> slots (+aliases)");
     e->n_slots = h_slot_key.size();
     if (e->n_slots >= (1ull << 31)) return fail(BK_ERR_UNSUPPORTED, "too many window buckets");
 
@@ -418,6 +449,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         }
         if (sub[h].key == bk::kEmptyKey) { sub[h].key = h_slot_key[s]; sub[h].slot = (uint32_t)s; }
     }
+    pc.lap("window tables");
     // a slot with no entries: "this k-mer has no bucket at that window position" (pseudo k-mers)
     const uint32_t empty_slot = (uint32_t)h_off.size();
     h_off.push_back(0);
@@ -442,25 +474,27 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     std::vector<uint32_t> h_valid(h_u.size(), 0u);
     std::vector<uint8_t> h_is_pseudo(h_u.size(), 0);
     std::vector<uint32_t> slot_by_index((size_t)std::max<size_t>(h_u.size(), 1) * std::max(e->W, 1), empty_slot);
-    for (size_t i = 0; i < h_u.size(); i++) {
-        h_is_pseudo[i] = std::binary_search(extra.begin(), extra.end(), h_u[i]) ? 1 : 0;
-        for (int t = 0; t < e->W; t++) {
-            const uint64_t key = h_u[i] & ~(3ull << (2 * (k - 1 - (e->wstart + t))));
-            const bk::TableSlot* sub = h_table.data() + (size_t)t * S;
-            uint32_t h = bk::hash_key(key, e->log2s);
-            while (sub[h].key != key && sub[h].key != bk::kEmptyKey) h = (h + 1) & (uint32_t)(S - 1);
-            if (sub[h].key == key) { slot_by_index[i * e->W + t] = sub[h].slot; h_valid[i] |= 1u << t; }
-            else if (!h_is_pseudo[i]) return fail(BK_ERR_INVALID, "index lacks a window bucket of one of its own reference k-mers");
+    std::atomic<bool> lacks{false};
+    parallel_for(h_u.size(), [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++) {
+            h_is_pseudo[i] = std::binary_search(extra.begin(), extra.end(), h_u[i]) ? 1 : 0;
+            for (int t = 0; t < e->W; t++) {
+                const uint64_t key = h_u[i] & ~(3ull << (2 * (k - 1 - (e->wstart + t))));
+                const bk::TableSlot* sub = h_table.data() + (size_t)t * S;
+                uint32_t h = bk::hash_key(key, e->log2s);
+                while (sub[h].key != key && sub[h].key != bk::kEmptyKey) h = (h + 1) & (uint32_t)(S - 1);
+                if (sub[h].key == key) { slot_by_index[i * e->W + t] = sub[h].slot; h_valid[i] |= 1u << t; }
+                else if (!h_is_pseudo[i]) lacks = true;
+            }
         }
-    }
+    });
+    if (lacks) return fail(BK_ERR_INVALID, "index lacks a window bucket of one of its own reference k-mers");
+    pc.lap("U + slot lookup");
     e->lo_bases = k / 2;
     if (h_u.size() >= (1ull << 31)) return fail(BK_ERR_UNSUPPORTED, "too many distinct reference k-mers");
     e->n_u = (uint32_t)h_u.size();
     {
         // walk the metadata sequences: ids, first occurrences, packed bases and the per-cell flag bits
-        std::unordered_map<uint64_t, uint32_t> idx_of;   // k-mer -> index into h_u
-        idx_of.reserve(h_u.size() * 2);
-        for (size_t i = 0; i < h_u.size(); i++) idx_of.emplace(h_u[i], (uint32_t)i);
         const uint32_t kNone = 0xffffffffu;
         std::vector<uint32_t> id_of(h_u.size(), kNone), first_cell(h_u.size(), kNone);
         std::vector<uint8_t> first_rc(h_u.size(), 0);
@@ -483,9 +517,9 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 for (uint64_t i = 0; i + k <= len; i++) {
                     fwd = ((fwd << 2) | bronko::nt_to_bits(seq[i + k - 1])) & mask;
                     const bronko::Canon cn = bronko::canonical_u64(fwd, k);
-                    const auto it = idx_of.find(cn.kmer);
-                    if (it == idx_of.end()) continue;   // not in the index: never predicted, never counted
-                    const uint32_t ui = it->second;
+                    const auto it = std::lower_bound(h_u.begin(), h_u.end(), cn.kmer);   // h_u is sorted
+                    if (it == h_u.end() || *it != cn.kmer) continue;   // not in the index: never predicted, never counted
+                    const uint32_t ui = (uint32_t)(it - h_u.begin());
                     const uint64_t cell = c0 + i;
                     if (id_of[ui] == kNone) { id_of[ui] = next_id++; first_cell[ui] = (uint32_t)cell; first_rc[ui] = cn.rc ? 1 : 0; }
                     h_id_at[cell] = id_of[ui];
@@ -525,6 +559,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             BK_HIP(e->prow_t.upload(h_prow_t));
         }
 
+        pc.lap("reference walk + ids");
         // dirty flags (bk_device.h amb): another reference k-mer, on either strand, within Hamming distance 2, or
         // the k-mer within distance 2 of its own reverse complement.  Any two 2k-bit words at distance <= 2 agree
         // on at least one of three parts, so group all forms (u and rc(u)) by each part and compare inside groups.
@@ -543,26 +578,29 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             }
             auto flag_within = [&](int dist, std::vector<uint8_t>& out) {
                 const int parts = dist + 1;   // words at distance <= dist agree on at least one of dist + 1 parts
-                for (int part = 0; part < parts; part++) {
+                std::vector<std::thread> th;
+                for (int part = 0; part < parts; part++) th.emplace_back([&, part] {   // (flags are only ever set to 1: benign races)
+                    std::vector<Form> fs(forms);
                     const int c0 = (part * k) / parts, c1 = ((part + 1) * k) / parts;
                     const uint64_t mask = (((1ull << (2 * (c1 - c0))) - 1ull) << (2 * c0));
-                    std::sort(forms.begin(), forms.end(), [&](const Form& x, const Form& y) { return (x.w & mask) < (y.w & mask); });
-                    for (size_t a0 = 0; a0 < forms.size();) {
+                    std::sort(fs.begin(), fs.end(), [&](const Form& x, const Form& y) { return (x.w & mask) < (y.w & mask); });
+                    for (size_t a0 = 0; a0 < fs.size();) {
                         size_t a1 = a0 + 1;
-                        while (a1 < forms.size() && (forms[a1].w & mask) == (forms[a0].w & mask)) a1++;
+                        while (a1 < fs.size() && (fs[a1].w & mask) == (fs[a0].w & mask)) a1++;
                         if (a1 - a0 > 4096) {   // pathological low-complexity group: flag all, skip the quadratic pass
-                            for (size_t x = a0; x < a1; x++) out[forms[x].id] = 1;
+                            for (size_t x = a0; x < a1; x++) out[fs[x].id] = 1;
                         } else {
                             for (size_t x = a0; x < a1; x++)
                                 for (size_t y = x + 1; y < a1; y++) {
-                                    const uint64_t d = forms[x].w ^ forms[y].w;
+                                    const uint64_t d = fs[x].w ^ fs[y].w;
                                     if (__builtin_popcountll((d | (d >> 1)) & 0x5555555555555555ull) <= dist)
-                                        out[forms[x].id] = out[forms[y].id] = 1;   // also catches u vs rc(u) (same id)
+                                        out[fs[x].id] = out[fs[y].id] = 1;   // also catches u vs rc(u) (same id)
                                 }
                         }
                         a0 = a1;
                     }
-                }
+                });
+                for (auto& t : th) t.join();
             };
             flag_within(2, h_amb);
             if (h_u.size() <= kAmb3MaxKmers) flag_within(3, h_amb3);
@@ -570,6 +608,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         }
         for (size_t i = 0; i < h_u.size(); i++) if (h_is_pseudo[i]) h_amb3[id_of[i]] = 1;
         for (size_t i = 0; i < h_u.size(); i++) if (h_is_pseudo[i]) h_amb[id_of[i]] = 1;
+        pc.lap("dirty flags (dist 2, 3)");
         std::vector<uint8_t> rc_of_id(h_u.size(), 0);   // the k-mer's first occurrence was reverse-complemented to become canonical
         for (size_t i = 0; i < h_u.size(); i++) rc_of_id[id_of[i]] = first_rc[i];
         std::vector<uint32_t> h_codes(h_refw.size(), 0u), h_yf(h_refw.size(), 0u), h_yr(h_refw.size(), 0u);   // bk_device.h
@@ -593,6 +632,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             h_yr[wi] |= (clean | (to_next ? 2u : 0u)) << sh;
         }
 
+        pc.lap("per-cell arrays");
         // perfect hash over U
         std::vector<uint16_t> h_pilots;
         std::vector<uint32_t> u_pos;
@@ -620,37 +660,52 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             BK_HIP(e->amb.upload(h_amb2));
         }
 
+        pc.lap("perfect hash of U + uploads");
         // half-key directories (neighbour search)
         const int lo_bits = 2 * e->lo_bases;
         const uint64_t lo_mask = (1ull << lo_bits) - 1ull;
-        for (int which = 0; which < 2; which++) {
-            auto half_of = [&](uint64_t u) { return which == 0 ? (u & lo_mask) : (u >> lo_bits); };
-            std::vector<uint32_t> order(h_u.size());
-            for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
-            std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-                const uint64_t hx = half_of(h_u[x]), hy = half_of(h_u[y]);
-                return hx != hy ? hx < hy : h_u[x] < h_u[y];
-            });
-            std::vector<bk::NbEntry> cand(order.size());
-            std::vector<uint64_t> halves;
-            std::vector<uint32_t> first, count;
-            for (size_t i = 0; i < order.size(); i++) {
-                const uint64_t u = h_u[order[i]];
-                cand[i] = bk::NbEntry{u, row_base[order[i]], (h_valid[order[i]] & 0x7fffffffu) | (first_rc[order[i]] ? 0x80000000u : 0u)};
-                if (halves.empty() || halves.back() != half_of(u)) { halves.push_back(half_of(u)); first.push_back((uint32_t)i); count.push_back(0); }
-                count.back()++;
+        {
+            // both halves at once (host threads); the low half needs a sort of its own, the high half is h_u's order
+            struct HalfHost { std::vector<uint16_t> hp; std::vector<bk::HalfDir> dir; std::vector<bk::NbEntry> cand; bool ok = true; };
+            HalfHost hh[2];
+            auto build_half = [&](int which) {
+                auto half_of = [&](uint64_t u) { return which == 0 ? (u & lo_mask) : (u >> lo_bits); };
+                std::vector<uint32_t> order(h_u.size());
+                for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+                if (which == 0)
+                    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+                        const uint64_t hx = half_of(h_u[x]), hy = half_of(h_u[y]);
+                        return hx != hy ? hx < hy : h_u[x] < h_u[y];
+                    });   // (which == 1: h_u is sorted by value, hence by its high half, then by value)
+                std::vector<bk::NbEntry>& cand = hh[which].cand;
+                cand.resize(order.size());
+                std::vector<uint64_t> halves;
+                std::vector<uint32_t> first, count;
+                for (size_t i = 0; i < order.size(); i++) {
+                    const uint64_t u = h_u[order[i]];
+                    cand[i] = bk::NbEntry{u, row_base[order[i]], (h_valid[order[i]] & 0x7fffffffu) | (first_rc[order[i]] ? 0x80000000u : 0u)};
+                    if (halves.empty() || halves.back() != half_of(u)) { halves.push_back(half_of(u)); first.push_back((uint32_t)i); count.push_back(0); }
+                    count.back()++;
+                }
+                bk_engine::HalfBufs& hb = which == 0 ? e->half_lo : e->half_hi;
+                std::vector<uint32_t> hpos;
+                if (!build_phf(halves, hh[which].hp, hb.log2nb, hb.m, hpos)) { hh[which].ok = false; return; }
+                hh[which].dir.assign(hb.m, bk::HalfDir{0u, 0u, 0u, 0u});
+                for (size_t i = 0; i < halves.size(); i++) hh[which].dir[hpos[i]] = bk::HalfDir{(uint32_t)halves[i], first[i], count[i], 0u};
+            };
+            std::thread t0(build_half, 0);
+            build_half(1);
+            t0.join();
+            for (int which = 0; which < 2; which++) {
+                if (!hh[which].ok) return fail(BK_ERR_UNSUPPORTED, "perfect hash construction failed");
+                bk_engine::HalfBufs& hb = which == 0 ? e->half_lo : e->half_hi;
+                BK_HIP(hb.pilots.upload(hh[which].hp));
+                BK_HIP(hb.dir.upload(hh[which].dir));
+                BK_HIP(hb.cand.upload(hh[which].cand));
             }
-            bk_engine::HalfBufs& hb = which == 0 ? e->half_lo : e->half_hi;
-            std::vector<uint16_t> hp;
-            std::vector<uint32_t> hpos;
-            if (!build_phf(halves, hp, hb.log2nb, hb.m, hpos)) return fail(BK_ERR_UNSUPPORTED, "perfect hash construction failed");
-            std::vector<bk::HalfDir> dir(hb.m, bk::HalfDir{0u, 0u, 0u, 0u});
-            for (size_t i = 0; i < halves.size(); i++) dir[hpos[i]] = bk::HalfDir{(uint32_t)halves[i], first[i], count[i], 0u};
-            BK_HIP(hb.pilots.upload(hp));
-            BK_HIP(hb.dir.upload(dir));
-            BK_HIP(hb.cand.upload(cand));
         }
 
+        pc.lap("half-key directories");
         // slot_of[id*W + t]: the window bucket (wstart+t, u masked) of reference k-mer id -- every reference k-mer
         // owns all of its buckets, so finalize needs no table probe for them (pseudo k-mers: empty_slot where none).
         std::vector<uint32_t> h_slot_of((size_t)std::max<size_t>(h_u.size(), 1) * std::max(e->W, 1), empty_slot);
@@ -671,6 +726,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             BK_HIP(e->slot_rec.upload(h_rec));
         }
 
+        pc.lap("slot_of + slot_rec");
         // estat: per reference k-mer, its per-genome hit totals over its W window buckets (call.rs:1316-1318) and
         // hence perfect (== W) / variant -- a property of the index alone
         std::vector<uint32_t> h_estat_off(h_u.size() + 1, 0u), h_estat;
@@ -708,6 +764,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         if (const char* nl = getenv("BK_LDS_BINS")) e->n_lds_bins = std::min<uint32_t>(e->n_lds_bins, (uint32_t)atol(nl));
         BK_HIP(e->slabs.alloc((size_t)e->n_cus * std::max<uint32_t>(e->n_lds_bins, 1)));
     }
+    pc.lap("estat + LDS policy");
     if (const char* nx = getenv("BK_NO_XCD_PLANES")) e->use_xcd_planes = atoi(nx) == 0;
 
     if (bk::finalize_lds_bytes(e->n_files) > 160 * 1024) return fail(BK_ERR_UNSUPPORTED, "more than ~8000 genome files are not supported by the finalize kernel");
@@ -741,6 +798,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     e->stream = e->own_stream;
     if (const char* ab = getenv("BK_SCAN_ABLATE")) e->ablate = atoi(ab);
     if (const char* ml = getenv("BK_MAX_LAUNCH_RECORDS")) e->max_launch_records = strtoull(ml, nullptr, 10);
+    pc.lap("uploads + buffers");
     *out = e.release();
     return BK_OK;
 }

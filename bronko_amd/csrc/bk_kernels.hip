@@ -540,12 +540,20 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
         // ---- seeds -> diagonal ----------------------------------------------------------------------------------
         bool fwd = true, seeded = false, l1ok = false;   // seeded: diagonal known; l1ok: ... and all its cells are in the LDS array
         dg = 0;
-        if (maxlen) {
+        // round 0: kSeeds k-mers evenly spaced from the first to the last; round 1, only when some lane found nothing (an
+        // error in every seed: one read in 10^4 at 0.5 % errors): the midpoints between them.  A read without a diagonal costs
+        // ~100 slow-path searches, so the rare second round pays.
+        for (int round = 0; round < 2 && maxlen; ++round) {
+            if (round == 1 && !__ballot(len != 0u && !seeded)) break;
+            const bool had = seeded;   // round 1 is for the lanes round 0 left without a diagonal
             uint64_t sc[kSeeds];
-            uint32_t sisrc[kSeeds], spil[kSeeds];
+            uint32_t sisrc[kSeeds], spil[kSeeds], spos[kSeeds];
 #pragma unroll
             for (int sq = 0; sq < kSeeds; ++sq) {
-                const uint32_t s = len ? ((len - (uint32_t)k) * (uint32_t)sq) / (uint32_t)(kSeeds - 1) : 0u;
+                const uint32_t span_k = len ? len - (uint32_t)k : 0u;
+                const uint32_t s = round == 0 ? (span_k * (uint32_t)sq) / (uint32_t)(kSeeds - 1)
+                                              : (span_k * (uint32_t)(2 * sq + 1)) / (uint32_t)(2 * kSeeds);
+                spos[sq] = s;
                 const uint64_t g = read_symbols_at(w, s, last_word) & kmask;       // base t of the k-mer at bits 2t
                 const uint64_t rr = ~g & kmask;                                      // its reverse complement, first base on top
                 const uint64_t ff = rev2_64(g) >> (64 - 2 * k);                      // the k-mer, first base on top
@@ -557,9 +565,9 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
             uint32_t best_cell = 0xffffffffu;
 #pragma unroll
             for (int sq = 0; sq < kSeeds; ++sq) {
-                const uint32_t s = len ? ((len - (uint32_t)k) * (uint32_t)sq) / (uint32_t)(kSeeds - 1) : 0u;
+                const uint32_t s = spos[sq];
                 const uint4 e = *reinterpret_cast<const uint4*>(ix.kmer_pos + phf_pos(sc[sq], spil[sq], ix.m));
-                if (len && ((uint64_t)e.x | ((uint64_t)e.y << 32)) == sc[sq] && e.z < best_cell) {
+                if (len && !had && ((uint64_t)e.x | ((uint64_t)e.y << 32)) == sc[sq] && e.z < best_cell) {
                     // several seeds may hit (usually all, on one diagonal); prefer the lowest cell: in a multi-genome
                     // index that is the first genome, whose cells are the ones in LDS
                     const bool f = sisrc[sq] == (e.w >> 31);   // same strand as the reference?

@@ -756,11 +756,16 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         BK_HIP(hipGetDeviceProperties(&prop, prm->device));
         e->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         const size_t budget = bk::scan_lds_budget();
-        const size_t ref_bytes = bk::scan_ref_lds_bytes((uint32_t)e->total_cells);
-        e->ref_in_lds = ref_bytes + std::min<size_t>((size_t)e->total_cells * sizeof(unsigned int), budget / 2) <= budget;
-        if (const char* rl = getenv("BK_REF_IN_LDS")) e->ref_in_lds = e->ref_in_lds && atoi(rl) != 0;
-        // bins are per cell: the first n_lds_bins cells (the first genome(s) of the index) are counted in LDS
-        e->n_lds_bins = (uint32_t)std::min<size_t>(e->total_cells, (budget - (e->ref_in_lds ? ref_bytes : 0)) / sizeof(unsigned int));
+        // LDS holds, for the first n_lds_bins cells (the first genome(s) of the index): the difference array (4 B per cell) and
+        // Level 1's copies of the per-cell arrays (2 + 1 + 1 bits per cell).  As many cells as fit.
+        e->ref_in_lds = true;
+        if (const char* rl = getenv("BK_REF_IN_LDS")) e->ref_in_lds = atoi(rl) != 0;
+        uint64_t nb = std::min<uint64_t>(e->total_cells, budget / sizeof(unsigned int));
+        if (e->ref_in_lds) {
+            nb = std::min<uint64_t>(e->total_cells, budget * 2 / 9);   // 4.5 bytes per cell ...
+            while (nb > 0 && nb * sizeof(unsigned int) + bk::scan_ref_lds_bytes((uint32_t)nb) > budget) nb -= std::min<uint64_t>(nb, 64);   // ... and the paddings
+        }
+        e->n_lds_bins = (uint32_t)nb;
         if (const char* nl = getenv("BK_LDS_BINS")) e->n_lds_bins = std::min<uint32_t>(e->n_lds_bins, (uint32_t)atol(nl));
         BK_HIP(e->slabs.alloc((size_t)e->n_cus * std::max<uint32_t>(e->n_lds_bins, 1)));
     }

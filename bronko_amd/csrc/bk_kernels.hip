@@ -426,8 +426,11 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     unsigned int* const rqg = range_g + wave * kRangeCap;
 
     const uint32_t total = a.total_cells;
-    const uint32_t n_refw = kRefPadWords + (total + 15) / 16 + kRefBackWords;   // 2-bit arrays: front pad, cells, back pad
-    const uint32_t n_bitw = kBitPadWords + (total + 31) / 32 + kBitBackWords;   // 1-bit arrays
+    // Level 1 only ever looks at cells below n_lds_bins (a read whose diagonal leaves them goes to Level 2 as a whole), so
+    // that is all the LDS copies of the per-cell arrays hold: front pad, the first n_lds_bins cells, back pad
+    const uint32_t lds_cells = min(total, a.n_lds_bins);
+    const uint32_t n_refw = kRefPadWords + (lds_cells + 15) / 16 + kRefBackWords;
+    const uint32_t n_bitw = kBitPadWords + (lds_cells + 31) / 32 + kBitBackWords;
     for (uint32_t i = threadIdx.x; i <= a.n_lds_bins; i += kScanBlock) bins[i] = 0u;
     if (REF_LDS) {
         for (uint32_t i = threadIdx.x; i < n_refw; i += kScanBlock) lds_ref[i] = a.ref_words[i];
@@ -435,7 +438,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     }
     __syncthreads();
     // symbol / bit 0 of the per-cell arrays is cell 0; negative positions down to -64 are readable padding
-    const unsigned int* refw = (REF_LDS ? lds_ref : a.ref_words) + kRefPadWords;
+    const unsigned int* refw1 = (REF_LDS ? lds_ref : a.ref_words) + kRefPadWords;   // Level 1
+    const unsigned int* refw = a.ref_words + kRefPadWords;                            // the batches: any cell (global, cached)
     const unsigned int* hasw = (REF_LDS ? lds_ref + n_refw : a.cell_has) + kBitPadWords;
     const unsigned int* cleanw = (REF_LDS ? lds_ref + n_refw + n_bitw : a.cell_clean) + kBitPadWords;
     const unsigned int* yfw = a.cell_yf + kRefPadWords;   // batches only (global memory, L1 / L2 cached)
@@ -839,7 +843,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 // mismatch flags of these 32 bases: read words vs the reference words aligned with them
                 const int32_t p0 = act ? (fwd ? dg + (int32_t)i0 : dg + (int32_t)km1 - (int32_t)i0 - 31) : 0;
                 const uint32_t sh = 2u * ((uint32_t)p0 & 15u);
-                const uint32_t r0 = refw[p0 >> 4], r1 = refw[(p0 >> 4) + 1], r2 = refw[(p0 >> 4) + 2];
+                const uint32_t r0 = refw1[p0 >> 4], r1 = refw1[(p0 >> 4) + 1], r2 = refw1[(p0 >> 4) + 2];
                 const uint32_t ya = __builtin_amdgcn_alignbit(r1, r0, sh), yb = __builtin_amdgcn_alignbit(r2, r1, sh);   // 32 reference bases, rising
                 // against the reference: read base i0 + t <-> complement of reference base p0 + 31 - t
                 const uint32_t d0 = x0 ^ (fwd ? ya : ~rev2_32(yb)), d1 = x1 ^ (fwd ? yb : ~rev2_32(ya));
@@ -919,12 +923,14 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
 }
 
 size_t scan_lds_budget() { return 160u * 1024u - 64u - kScanLdsFixed - sizeof(unsigned int); }
-size_t scan_ref_lds_bytes(uint32_t total_cells) {
-    return ((size_t)(kRefPadWords + (total_cells + 15) / 16 + kRefBackWords) + 2 * (size_t)(kBitPadWords + (total_cells + 31) / 32 + kBitBackWords)) *
+// LDS bytes of the per-cell arrays Level 1 stages for `cells` cells (reference 2 bits, two 1-bit arrays, paddings)
+size_t scan_ref_lds_bytes(uint32_t cells) {
+    return ((size_t)(kRefPadWords + (cells + 15) / 16 + kRefBackWords) + 2 * (size_t)(kBitPadWords + (cells + 31) / 32 + kBitBackWords)) *
            sizeof(unsigned int);
 }
 size_t scan_lds_bytes(uint32_t n_lds_bins, bool ref_in_lds, uint32_t total_cells) {
-    return kScanLdsFixed + ((size_t)n_lds_bins + 1) * sizeof(unsigned int) + (ref_in_lds ? scan_ref_lds_bytes(total_cells) : 0);
+    return kScanLdsFixed + ((size_t)n_lds_bins + 1) * sizeof(unsigned int) +
+           (ref_in_lds ? scan_ref_lds_bytes(std::min(n_lds_bins, total_cells)) : 0);
 }
 int scan_ref_pad_words() { return kRefPadWords; }
 int scan_ref_back_words() { return kRefBackWords; }

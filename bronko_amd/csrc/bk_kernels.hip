@@ -1078,6 +1078,7 @@ __global__ __launch_bounds__(256) void finalize_reduce_kernel(FinalizeArgs a, in
 // table keyed by (strand, cell, base): #k-mers add up, depth takes the max; vt_flush writes every used slot with one pair of
 // global atomics.  A vote that finds its neighbourhood of the table full goes to the pileup directly.
 constexpr int kVoteSlots = 512;
+constexpr uint32_t kVoteMaxEntries = 4;   // buckets with more BucketInfos than this vote directly
 constexpr size_t kVoteLdsBytes = (size_t)kVoteSlots * (8 + 8 + 4 + 2) + 16;
 struct VoteTable {
     unsigned long long* keys;   // [kVoteSlots], ~0 = free
@@ -1345,7 +1346,9 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
                 const uint32_t file = en.file;
                 uint32_t run = 0;
                 for (;;) {
-                    vote(a, en, c, isrc, k, v); ++run; ++x;   // (several genomes: as many cells -- not worth the table)
+                    if (cnt <= kVoteMaxEntries) vt_vote(vt, par, a, en, c, isrc, k, v);   // a few genomes: still worth the table
+                    else vote(a, en, c, isrc, k, v);                                        // many: as many cells, it would overflow
+                    ++run; ++x;
                     if (x >= cnt) break;
                     en = ix.entries[r.x + x];
                     if (en.file != file) break;
@@ -1407,9 +1410,13 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
             const uint4 r = *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)id * W + t);
             DevEntry first;
             first.cell = r.z; first.file = (uint16_t)(r.w & 0xffffu); first.idx = (uint8_t)(r.w >> 16); first.canonical = (uint8_t)(r.w >> 24);
-            if (r.y == 1u) vt_vote(vt, par, a, first, c, isrc, k, v);
-            else if (r.y) vote(a, first, c, isrc, k, v);       // (several genomes: as many cells -- not worth the table)
-            for (uint32_t q = 1; q < r.y; ++q) vote(a, ix.entries[r.x + q], c, isrc, k, v);
+            if (r.y && r.y <= kVoteMaxEntries) {               // a few genomes: still worth the table
+                vt_vote(vt, par, a, first, c, isrc, k, v);
+                for (uint32_t q = 1; q < r.y; ++q) vt_vote(vt, par, a, ix.entries[r.x + q], c, isrc, k, v);
+            } else if (r.y) {                                  // many: as many cells, it would overflow
+                vote(a, first, c, isrc, k, v);
+                for (uint32_t q = 1; q < r.y; ++q) vote(a, ix.entries[r.x + q], c, isrc, k, v);
+            }
         }
         if (t == 0) {
             ++kept;

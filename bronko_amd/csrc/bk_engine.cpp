@@ -246,6 +246,13 @@ struct bk_engine {
     hipStream_t own_stream = nullptr, stream = nullptr;
     bool in_sample = false;
     uint64_t pushed_records[2] = {0, 0};
+    // multi-genome indexes: the LDS window (difference array + Level 1's arrays) sits on the genome the sample looks like
+    DevBuf<uint32_t> occ;                   // [n_full][n_files] first occurrence of each reference k-mer in each genome file
+    DevBuf<unsigned int> win_votes;         // [n_files]
+    std::vector<uint32_t> file_cell_lo;     // first cell of each genome file
+    uint32_t win_lo = 0;
+    int win_file = 0;
+    bool win_chosen = false;                // for the current sample
     bool plane_stale[2] = {true, true};   // the mate's counter plane still holds an earlier sample (zeroed at its first push / at finalize)
 
     int ablate = 0;   // BK_SCAN_ABLATE (measurement aid): see scan_count_kernel
@@ -654,6 +661,22 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         BK_HIP(e->cell_yr.upload(h_yr));
         BK_HIP(e->cell_codes.upload(h_codes));
         BK_HIP(e->id_at.upload(h_id_at));
+        e->file_cell_lo.assign((size_t)ix->n_files, 0u);
+        for (int f = 0; f < ix->n_files; f++) e->file_cell_lo[f] = ix->n_seqs[f] ? (uint32_t)cell_off[f][0] : (uint32_t)cells;
+        if (ix->n_files > 1 && (uint64_t)e->n_full * (uint64_t)ix->n_files <= (1ull << 28)) {
+            std::vector<uint32_t> h_occ((size_t)e->n_full * ix->n_files, 0xffffffffu);
+            for (int f = 0; f < ix->n_files; f++) {
+                const uint64_t c_lo = e->file_cell_lo[f], c_hi = f + 1 < ix->n_files ? e->file_cell_lo[f + 1] : cells;
+                for (uint64_t c = c_lo; c < c_hi; c++) {
+                    const uint32_t id = h_id_at[c];
+                    if (id == kNone || id >= e->n_full) continue;
+                    uint32_t& o = h_occ[(size_t)id * ix->n_files + f];
+                    if (o == 0xffffffffu) o = (uint32_t)c | (((h_brc[c >> 5] >> (c & 31)) & 1u) << 31);
+                }
+            }
+            BK_HIP(e->occ.upload(h_occ));
+            BK_HIP(e->win_votes.alloc((size_t)ix->n_files));
+        }
         {
             std::vector<uint8_t> h_amb2(h_amb);
             for (size_t id = 0; id < h_amb2.size(); id++) h_amb2[id] = (h_amb[id] ? 1 : 0) | (rc_of_id[id] ? 2 : 0);
@@ -842,6 +865,7 @@ int bk_sample_begin(bk_engine* e) {
     BK_HIP(hipSetDevice(e->device));
     bk_engine::Span sp(e, 2);
     e->plane_stale[0] = e->plane_stale[1] = true;   // a plane is zeroed when its mate file is first pushed (or finalized unpushed)
+    e->win_chosen = false;
     BK_HIP(hipMemsetAsync(e->pileup.p, 0, std::max<size_t>(e->pileup.n, 1) * sizeof(unsigned long long), e->stream));
     bk::launch_zero_small(e->stats.p, e->stats.n, e->kstats.p, e->kstats.n, e->ktab_out.p, e->ktab_out.n, e->present.p, e->present.n,
                           e->n_deferred.p, e->n_deferred.n, e->stream);
@@ -881,6 +905,24 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.ref_in_lds = e->ref_in_lds ? 1 : 0;
     a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->params.kmer_table_log2;
     a.ktab_overflow = e->ktab_out.p + 4; a.mate = (uint32_t)mate;
+    a.occ = e->occ.p; a.n_files = e->n_files;
+    if (e->occ.p && !e->win_chosen && n > 0) {
+        // first records of the sample vote for the genome they look like (one synchronisation per sample); the LDS window
+        // goes on that genome and stays there for the sample.  Any choice gives the same counts -- this is about speed.
+        a.win_file = 0; a.win_lo = 0;
+        BK_HIP(hipMemsetAsync(e->win_votes.p, 0, e->win_votes.n * sizeof(unsigned int), e->stream));
+        bk::launch_pick_window(a, 16384, e->win_votes.p, e->stream);
+        std::vector<unsigned int> votes(e->win_votes.n);
+        BK_HIP(hipMemcpyAsync(votes.data(), e->win_votes.p, votes.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));
+        BK_HIP(hipStreamSynchronize(e->stream));
+        int best = 0;
+        for (int f = 1; f < e->n_files; f++) if (votes[f] > votes[best]) best = f;
+        if (const char* wf = getenv("BK_WINDOW_FILE")) best = std::max(0, std::min(e->n_files - 1, atoi(wf)));   // testing aid
+        e->win_file = best;
+        e->win_lo = e->file_cell_lo[best] & ~31u;
+        e->win_chosen = true;
+    }
+    a.win_file = e->win_file; a.win_lo = e->occ.p ? e->win_lo : 0u;
     // a launch takes at most scan_max_records records (bound on what one workgroup's 16-bit LDS bins can receive)
     for (uint64_t base = 0; base < n;) {
         const uint32_t grid = bk::scan_grid(n - base, e->n_cus);
@@ -894,7 +936,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
         if (e->W > 0) {
             // per-cell bin slabs (and the u32 overflow planes: a batch of < 2^32 k-mers cannot wrap them) -> u64 plane
             bk::FoldArgs f{};
-            f.slabs = e->slabs.p; f.n_slabs = grid; f.n_lds_bins = e->n_lds_bins; f.id_at = e->id_at.p; f.cell_codes = e->cell_codes.p + bk::scan_ref_pad_words();
+            f.slabs = e->slabs.p; f.n_slabs = grid; f.n_lds_bins = e->n_lds_bins; f.id_at = e->id_at.p; f.cell_codes = e->cell_codes.p + bk::scan_ref_pad_words(); f.win_lo = a.win_lo;
             f.e_planes = a.e_planes; f.n_e = bk::e_plane_len(e->n_u); f.counters = e->counters[mate].p;
             bk_engine::Span sp(e, 3);
             bk::launch_fold(f, e->stream);

@@ -28,7 +28,11 @@ struct ScanArgs {
     uint32_t stride_words;
     unsigned long long* counters;   // u64 plane [E | V] (bk_device.h)
     unsigned int* slabs;            // [grid][n_lds_bins] packed (rc<<16 | fwd) per-cell bins of each workgroup
-    uint32_t n_lds_bins;            // exact hits at cells < n_lds_bins are counted in LDS
+    uint32_t n_lds_bins;            // exact hits at cells [win_lo, win_lo + n_lds_bins) are counted in LDS
+    uint32_t win_lo;                // first cell of that window (a multiple of 32): the genome the sample looks like
+    const uint32_t* occ;            // [n_full][n_files] cell | rc << 31 of the k-mer's first occurrence in each genome file
+                                    // (0xffffffff: none), or null; with win_file, seeds land on that genome's copy of a k-mer
+    int32_t win_file, n_files;
     unsigned int* e_planes;         // [8 XCDs][E] u32 planes for hits at cells >= n_lds_bins; null if none / disabled
     int ref_in_lds;                 // stage the packed reference + cell codes in LDS (they fit next to the bins)
     unsigned long long* kmer_total; // optional: += k-mer occurrences scanned
@@ -69,6 +73,7 @@ struct FoldArgs {
     uint32_t n_slabs;               // = grid of the scan launch
     uint32_t n_lds_bins;
     const uint32_t* id_at;          // cell -> id (bins are per cell)
+    uint32_t win_lo;                // slab cell i is cell win_lo + i
     const uint32_t* cell_codes;     // IndexView::cell_codes + its front padding: symbol 0 = cell 0
     unsigned int* e_planes;         // may be null
     uint64_t n_e;                   // 2 * m
@@ -87,6 +92,8 @@ struct PackArgs {
     unsigned long long* n_records;  // out (device): number of records written; zeroed by the launcher
 };
 void launch_pack_reads(const PackArgs& a, hipStream_t stream);
+// votes[f] += number of the first records' middle k-mers that occur in genome file f (which genome does the sample look like?)
+void launch_pick_window(const ScanArgs& a, uint64_t n_probe, unsigned int* votes, hipStream_t stream);
 void launch_add_u64(unsigned long long* dst, const unsigned long long* src, hipStream_t stream);   // *dst += *src
 uint32_t scan_grid(uint64_t n_records, int n_cus);
 uint64_t scan_max_records(uint32_t grid);   // most records one launch_scan_count may be given

@@ -428,20 +428,24 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     const uint32_t total = a.total_cells;
     // Level 1 only ever looks at cells below n_lds_bins (a read whose diagonal leaves them goes to Level 2 as a whole), so
     // that is all the LDS copies of the per-cell arrays hold: front pad, the first n_lds_bins cells, back pad
-    const uint32_t lds_cells = min(total, a.n_lds_bins);
+    const uint32_t win_lo = a.win_lo;
+    const uint32_t lds_cells = min(total - win_lo, a.n_lds_bins);
     const uint32_t n_refw = kRefPadWords + (lds_cells + 15) / 16 + kRefBackWords;
     const uint32_t n_bitw = kBitPadWords + (lds_cells + 31) / 32 + kBitBackWords;
     for (uint32_t i = threadIdx.x; i <= a.n_lds_bins; i += kScanBlock) bins[i] = 0u;
     if (REF_LDS) {
-        for (uint32_t i = threadIdx.x; i < n_refw; i += kScanBlock) lds_ref[i] = a.ref_words[i];
-        for (uint32_t i = threadIdx.x; i < n_bitw; i += kScanBlock) { lds_ref[n_refw + i] = a.cell_has[i]; lds_ref[n_refw + n_bitw + i] = a.cell_clean[i]; }
+        for (uint32_t i = threadIdx.x; i < n_refw; i += kScanBlock) lds_ref[i] = a.ref_words[(win_lo >> 4) + i];
+        for (uint32_t i = threadIdx.x; i < n_bitw; i += kScanBlock) {
+            lds_ref[n_refw + i] = a.cell_has[(win_lo >> 5) + i];
+            lds_ref[n_refw + n_bitw + i] = a.cell_clean[(win_lo >> 5) + i];
+        }
     }
     __syncthreads();
-    // symbol / bit 0 of the per-cell arrays is cell 0; negative positions down to -64 are readable padding
-    const unsigned int* refw1 = (REF_LDS ? lds_ref : a.ref_words) + kRefPadWords;   // Level 1
-    const unsigned int* refw = a.ref_words + kRefPadWords;                            // the batches: any cell (global, cached)
-    const unsigned int* hasw = (REF_LDS ? lds_ref + n_refw : a.cell_has) + kBitPadWords;
-    const unsigned int* cleanw = (REF_LDS ? lds_ref + n_refw + n_bitw : a.cell_clean) + kBitPadWords;
+    // Level 1's arrays: symbol / bit 0 is cell win_lo; negative positions down to -64 are readable (padding or earlier cells)
+    const unsigned int* refw1 = (REF_LDS ? lds_ref : a.ref_words + (win_lo >> 4)) + kRefPadWords;
+    const unsigned int* hasw = (REF_LDS ? lds_ref + n_refw : a.cell_has + (win_lo >> 5)) + kBitPadWords;
+    const unsigned int* cleanw = (REF_LDS ? lds_ref + n_refw + n_bitw : a.cell_clean + (win_lo >> 5)) + kBitPadWords;
+    const unsigned int* refw = a.ref_words + kRefPadWords;   // the batches: any cell, symbol 0 = cell 0 (global, cached)
     const unsigned int* yfw = a.cell_yf + kRefPadWords;   // batches only (global memory, L1 / L2 cached)
     const unsigned int* yrw = a.cell_yr + kRefPadWords;
     const unsigned int* c3w = a.cell_clean3 + kBitPadWords;
@@ -470,11 +474,11 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
         const bool room = slow_lds + 64u <= kSlowLdsQuota;   // wave-uniform
         if (room) slow_lds += (uint32_t)__popcll(hm);
         if (!hit) return;
-        if (room && cell < a.n_lds_bins) {
+        if (room && cell - win_lo < a.n_lds_bins) {
             // a single-cell run in the direction the read has relative to the reference there
             const unsigned int inc = (isrc ^ rc_first) ? 0x10000u : 1u;
-            __hip_atomic_fetch_add(&bins[cell], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&bins[cell + 1], 0u - inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&bins[cell - win_lo], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&bins[cell - win_lo + 1], 0u - inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else if (e_local) {
             __hip_atomic_fetch_add(e_local + 2 * (size_t)id + isrc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
@@ -571,17 +575,23 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
             for (int sq = 0; sq < kSeeds; ++sq) {
                 const uint32_t s = spos[sq];
                 const uint4 e = *reinterpret_cast<const uint4*>(ix.kmer_pos + phf_pos(sc[sq], spil[sq], ix.m));
-                if (len && !had && ((uint64_t)e.x | ((uint64_t)e.y << 32)) == sc[sq] && e.z < best_cell) {
-                    // several seeds may hit (usually all, on one diagonal); prefer the lowest cell: in a multi-genome
-                    // index that is the first genome, whose cells are the ones in LDS
-                    const bool f = sisrc[sq] == (e.w >> 31);   // same strand as the reference?
-                    const int64_t d0 = f ? (int64_t)e.z - (int64_t)s : (int64_t)e.z + (int64_t)s;
+                uint32_t scell = e.z, src_rc = e.w >> 31;   // where the seed sits: the k-mer's first occurrence ...
+                const bool hit = len && !had && ((uint64_t)e.x | ((uint64_t)e.y << 32)) == sc[sq];
+                if (a.occ && hit && (e.w & kIdMask) < ix.n_full) {
+                    // ... or, in a multi-genome index, its occurrence in the genome the LDS window covers
+                    const uint32_t oc = a.occ[(size_t)(e.w & kIdMask) * (uint32_t)a.n_files + (uint32_t)a.win_file];
+                    if (oc != 0xffffffffu) { scell = oc & 0x7fffffffu; src_rc = oc >> 31; }
+                }
+                if (hit && scell < best_cell) {
+                    // several seeds may hit (usually all, on one diagonal); prefer the lowest cell
+                    const bool f = sisrc[sq] == src_rc;        // same strand as the reference?
+                    const int64_t d0 = f ? (int64_t)scell - (int64_t)s : (int64_t)scell + (int64_t)s;
                     const int64_t lo_cell = f ? d0 : d0 - (int64_t)(len - (uint32_t)k);
                     const int64_t hi_cell = f ? d0 + (int64_t)(len - (uint32_t)k) : d0;
                     // the whole read must lie on the reference (hi_cell + k <= total); Level 1 also needs its cells in LDS
                     if (lo_cell >= 0 && hi_cell + k <= (int64_t)total) {
-                        best_cell = e.z; dg = (int32_t)d0; fwd = f; seeded = true;
-                        l1ok = hi_cell < (int64_t)a.n_lds_bins;
+                        best_cell = scell; dg = (int32_t)d0; fwd = f; seeded = true;
+                        l1ok = lo_cell >= (int64_t)win_lo && hi_cell < (int64_t)win_lo + (int64_t)a.n_lds_bins;
                     }
                 }
             }
@@ -804,7 +814,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 const uint32_t take = long_g ? chunk : n;
                 if (has && run_type == 1u) {
                     // E run over k-mers [run_start, s): cells dg + run_start .. dg + s - 1 (fwd) / dg - s + 1 .. dg - run_start
-                    const uint32_t c_lo = fwd ? (uint32_t)(dg + (int32_t)run_start) : (uint32_t)(dg - (int32_t)s + 1);
+                    const uint32_t c_lo = (fwd ? (uint32_t)(dg + (int32_t)run_start) : (uint32_t)(dg - (int32_t)s + 1)) - win_lo;
                     const uint32_t inc = fwd ? 1u : 0x10000u;
                     __hip_atomic_fetch_add(&bins[c_lo], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(&bins[c_lo + n], 0u - inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -841,7 +851,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 xn1 = (i0 + 48u < len) ? w[(i0 >> 4) + 3u] : 0u;
                 const bool act = l1ok && i0 < len;
                 // mismatch flags of these 32 bases: read words vs the reference words aligned with them
-                const int32_t p0 = act ? (fwd ? dg + (int32_t)i0 : dg + (int32_t)km1 - (int32_t)i0 - 31) : 0;
+                const int32_t dgw = dg - (int32_t)win_lo;   // the diagonal in window coordinates
+                const int32_t p0 = act ? (fwd ? dgw + (int32_t)i0 : dgw + (int32_t)km1 - (int32_t)i0 - 31) : 0;
                 const uint32_t sh = 2u * ((uint32_t)p0 & 15u);
                 const uint32_t r0 = refw1[p0 >> 4], r1 = refw1[(p0 >> 4) + 1], r2 = refw1[(p0 >> 4) + 2];
                 const uint32_t ya = __builtin_amdgcn_alignbit(r1, r0, sh), yb = __builtin_amdgcn_alignbit(r2, r1, sh);   // 32 reference bases, rising
@@ -851,7 +862,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 h_lo = h_hi;
                 h_hi = M32;
                 // per-cell bits of the 32 k-mers that end in these words, in step order
-                const int32_t c0 = act ? (fwd ? dg + (int32_t)i0 - (int32_t)km1 : dg - (int32_t)i0 + (int32_t)km1 - 31) : 0;
+                const int32_t c0 = act ? (fwd ? dgw + (int32_t)i0 - (int32_t)km1 : dgw - (int32_t)i0 + (int32_t)km1 - 31) : 0;
                 const uint32_t hl = bits32_at(hasw, c0), cl = bits32_at(cleanw, c0);
                 const uint32_t HAS32 = fwd ? hl : __builtin_bitreverse32(hl);
                 const uint32_t CLEAN32 = fwd ? cl : __builtin_bitreverse32(cl);
@@ -922,6 +933,31 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     if (threadIdx.x == 0 && *block_kmers && a.kmer_total) atomicAdd(a.kmer_total, (unsigned long long)*block_kmers);
 }
 
+// Which genome does the sample look like?  One k-mer (the middle one) of each of the first records: votes[f] += 1 for every
+// genome file the k-mer occurs in.  The engine puts the LDS window on the genome with the most votes.
+__global__ __launch_bounds__(256) void pick_window_kernel(ScanArgs a, uint64_t n_probe, unsigned int* votes) {
+    const IndexView& ix = *a.ixp;
+    uint64_t n_records = a.n_records;
+    if (a.n_records_dev) n_records = min((uint64_t)*a.n_records_dev, a.n_records);
+    n_records = min(n_records, n_probe);
+    const int k = a.k;
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull;
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n_records; r += (uint64_t)gridDim.x * 256) {
+        const uint32_t len = a.lens[r];
+        if (len < (uint32_t)k) continue;
+        const uint64_t g = read_symbols_at(a.words + r * a.stride_words, (len - (uint32_t)k) / 2u, a.stride_words - 1u) & kmask;
+        const uint64_t rr = ~g & kmask, ff = rev2_64(g) >> (64 - 2 * k);
+        const uint64_t c = ff < rr ? ff : rr;
+        const uint4 e = *reinterpret_cast<const uint4*>(ix.kmer_pos + phf_pos(c, ix.pilots[phf_bucket(c, ix.log2nb)], ix.m));
+        if (((uint64_t)e.x | ((uint64_t)e.y << 32)) != c || (e.w & kIdMask) >= ix.n_full) continue;
+        const uint32_t* oc = a.occ + (size_t)(e.w & kIdMask) * (uint32_t)a.n_files;
+        for (int f = 0; f < a.n_files; ++f) if (oc[f] != 0xffffffffu) atomicAdd(votes + f, 1u);
+    }
+}
+void launch_pick_window(const ScanArgs& a, uint64_t n_probe, unsigned int* votes, hipStream_t stream) {
+    hipLaunchKernelGGL(pick_window_kernel, dim3(64), dim3(256), 0, stream, a, n_probe, votes);
+}
+
 size_t scan_lds_budget() { return 160u * 1024u - 64u - kScanLdsFixed - sizeof(unsigned int); }
 // LDS bytes of the per-cell arrays Level 1 stages for `cells` cells (reference 2 bits, two 1-bit arrays, paddings)
 size_t scan_ref_lds_bytes(uint32_t cells) {
@@ -980,8 +1016,9 @@ __global__ __launch_bounds__(256) void fold_kernel(FoldArgs f) {
             s1 += v >> 16;
         }
         if (s0 | s1) {
-            const uint32_t id = f.id_at[i];   // a counted cell always has a reference k-mer
-            const uint32_t rc = ((f.cell_codes[i >> 4] >> (2 * (i & 15))) & 3u) == 2u ? 1u : 0u;
+            const uint64_t cell = f.win_lo + i;
+            const uint32_t id = f.id_at[cell];   // a counted cell always has a reference k-mer
+            const uint32_t rc = ((f.cell_codes[cell >> 4] >> (2 * (cell & 15))) & 3u) == 2u ? 1u : 0u;
             if (s0) atomicAdd(f.counters + 2 * (size_t)id + rc, s0);
             if (s1) atomicAdd(f.counters + 2 * (size_t)id + (1u - rc), s1);
         }

@@ -14,6 +14,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_gpu_first():
+    """Some GPU tests view engine buffers as torch tensors.  torch must initialise its HIP context before the engine library
+    has spun up its own streams and threads in the process (initialising it afterwards has failed with "No HIP GPUs are
+    available" depending on test order), so do it once at session start; a no-op on a box without a GPU."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.zeros(1, device="cuda:0")
+    except Exception:   # noqa: BLE001 -- CPU-only runs do not care
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -514,3 +514,22 @@ def test_long_reads_with_indels_and_chimeras(oracle, sars_paths):
     helpers.assert_same_pileup(helpers.hip_sample(eng, [reads], 21, stride_words=20), pile)   # cut into overlapping 320-base records
     eng.close()
     ix.close()
+
+
+def test_lds_window_on_any_genome_gives_the_same_counts(oracle, sars_paths, monkeypatch):
+    """Multi-genome indexes: the LDS window (difference array + Level 1's arrays) is put on the genome the first reads vote
+    for; BK_WINDOW_FILE forces it elsewhere.  Whatever genome it sits on, the counts are the same -- it is about speed."""
+    ix = oracle.Index.build(21, sars_paths)
+    gm, isnv = synth.sample_genome(synth.read_fasta_bytes(sars_paths[3]), 23)
+    c1, c2 = synth.paired_codes(gm, 15000, 150, 23, isnv=isnv)
+    mates = [synth.codes_to_ascii(c1), synth.codes_to_ascii(c2)]
+    pile = oracle.sample_pileup(ix, mates)
+    eng = helpers.engine_from_oracle_index(ix)
+    helpers.assert_same_pileup(helpers.hip_sample(eng, mates, 21), pile)          # the vote (genome 3, presumably)
+    for wf in ("0", "1", "2", "3"):
+        monkeypatch.setenv("BK_WINDOW_FILE", wf)
+        helpers.assert_same_pileup(helpers.hip_sample(eng, mates, 21), pile)
+    monkeypatch.delenv("BK_WINDOW_FILE")
+    assert oracle.pick_best_genome(ix, pile.stats.sum(axis=0), pile.present.max(axis=0)) == 3
+    eng.close()
+    ix.close()

@@ -1,22 +1,22 @@
 // bk_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the k-mer -> pileup engine.
 //
-// K1  scan_count       : packed 2-bit read records -> for every k-mer, canonical form (lcb.rs:87-95) -> which distinct
-//                        index-touching k-mer is it? -> +1 on that k-mer's occurrence counter.  Replaces the external
-//                        KMC3 run of call.rs:1166-1211 for every k-mer that can touch the index.  Two levels: a
-//                        word-parallel comparison of the read with the reference along its diagonal proves most
-//                        k-mers exact; the rest go through the rolling k-mer / neighbour-search machinery.
-// K1b fold             : adds the workgroup histogram slabs (and the per-XCD overflow planes) into the u64 plane.
-// K2a finalize_variant : V counters -> KMC thresholds -> map_kmers vote, one thread per non-reference k-mer.
+// K0  pack_reads       : ASCII sequence lines -> 2-bit fixed-stride records (KMC's read handling: split at non-ACGT, ...).
+// K1  scan_count       : records -> for every k-mer, which distinct index-touching k-mer is it? -> its occurrence counter.
+//                        Replaces the external KMC3 run of call.rs:1166-1211 for every k-mer that can touch the index.
+//                        Counts are recorded per RUN of consecutive k-mers (difference arrays, see K1's comment): a
+//                        word-parallel comparison of the read with the reference along its diagonal finds the runs, a
+//                        per-k-mer path (rolling canonical k-mer, neighbour search) takes what is left.
+// K1b fold             : per-workgroup per-cell counts (slabs) and the per-XCD overflow planes -> E counters of the u64 plane.
+// K2a finalize_variant : V rows -> per-k-mer counts (prefix sums) -> KMC thresholds -> map_kmers vote.
 // K2e finalize_exact   : E counters -> thresholds -> map_kmers vote, one thread per (reference k-mer, bucket).
-// K2b finalize_general : the k-mers K2a defers -> map_kmers vote, one wave per k-mer.
+// K2b finalize_general : the k-mers K2a defers (several buckets) -> map_kmers vote, one wave per k-mer.
 //                        K2a/K2e/K2b together are call.rs:1286-1418 applied to KMC's kept k-mers (-ci/-cs/-cx).
 //
-// Counter naming (bk_device.h): a read k-mer equal to a reference k-mer u owns E[2*pos(u) + rc]; a read k-mer
-// at Hamming distance 1 from reference k-mers, differing at a window position, owns the V counter of the
-// smallest (position, pos(u)).  Both are functions of the k-mer alone, so every occurrence of a k-mer lands on
-// the same counter and no k-mer owns two; a k-mer that touches no window bucket is not counted at all
-// (map_kmers would ignore it: call.rs:1307).  finalize re-derives the k-mer from the counter's coordinates and
-// replays map_kmers on it with its exact count.
+// Counter naming (bk_device.h): a read k-mer equal to a reference k-mer u owns E[2*id(u) + rc]; a read k-mer at Hamming
+// distance 1 from reference k-mers, differing at a window position, owns the V counter of the smallest (position,
+// neighbour).  Both are functions of the k-mer alone, so every occurrence of a k-mer lands on the same counter and no k-mer
+// owns two; a k-mer that touches no window bucket is not counted at all (map_kmers would ignore it: call.rs:1307).
+// finalize re-derives the k-mer from the counter's coordinates and replays map_kmers on it with its exact count.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -202,11 +202,12 @@ void launch_ktab_stats(const unsigned long long* keys, const unsigned int* cnt, 
 // tiles of 64 records, one record per lane.  Nothing is counted k-mer by k-mer unless it has to be.
 //
 // Level 1 -- word-parallel verification along a diagonal.  A few seed k-mers of the read (evenly spaced, looked
-// up in the perfect hash of U) give its diagonal: read k-mer s <-> reference cell dg + s (same strand) or dg - s
-// (opposite strand).  Then, 16 bases at a time, the read word is XORed with the reference word aligned to it
-// (packed reference in LDS, one funnel shift; reversed and complemented for the opposite strand) and folded to
-// one mismatch flag per base.  A k-step shift-and-or over the flag history says, for the 16 k-mers that end in
-// this word at once, whether their window holds no mismatch, exactly one, or more; with two per-cell bits from
+// up in the perfect hash of U; a second round at the midpoints for the rare read whose seeds all carry an error)
+// give its diagonal: read k-mer s <-> reference cell dg + s (same strand) or dg - s (opposite strand).  Then, 32
+// bases at a time, the read words are XORed with the reference words aligned to them (packed reference in LDS,
+// funnel shifts; reversed and complemented for the opposite strand) and folded to one mismatch flag per base.  A
+// k-step shift-and-or over the flag history says, for the 32 k-mers that end in these words at once, whether their
+// window holds no mismatch, exactly one, or more; with two per-cell bits from
 // LDS ("a reference k-mer starts here", "... and it is clean") every k-mer is
 //   E  exact      no mismatch, a reference k-mer starts at the cell: the read k-mer IS that reference k-mer;
 //   S  simple     one mismatch, the cell is clean: the read k-mer is "that reference k-mer with another base
@@ -226,8 +227,9 @@ void launch_ktab_stats(const unsigned long long* keys, const unsigned int* cnt, 
 //
 // Level 2 ("G batch") -- one queued chunk per lane, the exact per-k-mer logic: rolling canonical k-mer + 2-bit
 // difference mask along the diagonal (both pre-aligned word-parallel, so a step is pure ALU).  A k-mer with one
-// difference at a clean cell of known id is a single-k-mer S run (+1 / -1 in its V row); everything else goes
-// to the slow path.
+// difference at a clean cell of known id is a single-k-mer S run (+1 / -1 in its V row); one with two differences
+// at a cell whose k-mer is isolated up to Hamming distance 3 (cell_clean3) touches nothing and is dropped; everything
+// else goes to the slow path.
 //
 // Slow path -- compacted (ballot + prefix popcount) into a per-wave LDS queue; batches of the SlowPipe (one k-mer
 // per lane): perfect-hash membership test (a hit is an E count after all), then the neighbour search over the two
@@ -239,8 +241,10 @@ void launch_ktab_stats(const unsigned long long* keys, const unsigned int* cnt, 
 // record covers a cell at most once on its diagonal, and the slow path's point updates are limited to
 // kSlowLdsQuota per wave (beyond that they go to the E plane directly).
 //
-// Cells beyond the LDS array (large multi-genome indexes) are counted with workgroup-scope (non-sc1) atomics in
-// a u32 plane private to the XCD the workgroup runs on (HW_REG_XCC_ID, read at run time, so nothing depends on
+// The LDS arrays cover a window of cells [win_lo, win_lo + n_lds_bins): everything for one genome of SARS-CoV-2 size;
+// for a multi-genome index the engine puts it on the genome the sample looks like (pick_window_kernel) and the seeds
+// land on that genome's copy of a k-mer (occ).  Exact hits outside the window (other genomes' copies, found by the
+// slow path) are counted with workgroup-scope (non-sc1) atomics in a u32 plane private to the XCD the workgroup runs on (HW_REG_XCC_ID, read at run time, so nothing depends on
 // how workgroups are placed); fold adds the planes up afterwards.  A reference too large for LDS is read from
 // global memory instead (REF_LDS = false).
 constexpr int kScanBlock = 1024;

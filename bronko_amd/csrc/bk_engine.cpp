@@ -365,74 +365,122 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     // leading bases shifts every rank of a k-mer by exactly 2^64), so the W buckets of a reference k-mer usually
     // share one pseudo k-mer.  Which window positions of u* really lead to a bucket is read back from the table.
     std::vector<uint64_t> pseudo;
-    uint64_t ids[32];
-    for (uint64_t b = 0; b < ix->n_buckets && e->W > 0; b++) {
-        const uint64_t lo = ix->bucket_off[b], hi = ix->bucket_off[b + 1];
-        if (hi <= lo) continue;
-        if (hi > ix->n_entries) return fail(BK_ERR_INVALID, "bucket_off out of range");
-        // distinct (j, masked) keys present in this bucket: exactly one unless k = 31 ids wrapped onto each other
-        std::vector<std::pair<int, uint64_t>> keys;
-        uint64_t first_kmer = 0;
-        bool any_in_window = false;
-        for (uint64_t i = lo; i < hi; i++) {
-            const bk_bucket_info& bi = ix->entries[i];
-            if (bi.file_id >= ix->n_files || bi.seq_id >= ix->n_seqs[bi.file_id]) return fail(BK_ERR_INVALID, "entry %llu references a missing sequence", (unsigned long long)i);
-            const size_t sq = seq_base[bi.file_id] + bi.seq_id;
-            if ((uint64_t)bi.location + k > ix->seq_lens[sq] || bi.idx >= k) return fail(BK_ERR_INVALID, "entry %llu lies outside its sequence", (unsigned long long)i);
-            const bronko::Canon cn = bronko::canonical_kmer(ix->seqs[sq] + bi.location, k);
-            if (cn.rc != (bi.canonical != 0)) return fail(BK_ERR_INVALID, "entry %llu: canonical flag disagrees with the metadata sequence", (unsigned long long)i);
-            const int j = bi.idx;
-            const uint64_t masked = cn.kmer & ~(3ull << (2 * (k - 1 - j)));
-            if (std::find(keys.begin(), keys.end(), std::make_pair(j, masked)) == keys.end()) {
-                bronko::assign_buckets(cn.kmer, k, ids);
-                if (ids[j] != ix->bucket_ids[b]) return fail(BK_ERR_INVALID, "bucket %llu: id does not match assign_buckets of its entries", (unsigned long long)ix->bucket_ids[b]);
-                if (keys.empty()) first_kmer = cn.kmer;
-                keys.emplace_back(j, masked);
+    // The buckets are taken in contiguous chunks by host threads, each filling its own output; the chunks are then joined in
+    // order, so the result is the one a single pass over all buckets gives.
+    struct ChunkOut {
+        std::vector<uint64_t> h_slot_key, h_u, pseudo, per_t;
+        std::vector<uint8_t> h_slot_t;
+        std::vector<uint32_t> h_off, h_len;   // h_off: relative to this chunk's h_ent
+        std::vector<bk::DevEntry> h_ent;
+        int code = BK_OK;
+        std::string err;
+        bool fail(int c, const char* fmt, ...) {
+            char buf[512];
+            va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+            code = c; err = buf;
+            return false;
+        }
+    };
+    auto process_buckets = [&](uint64_t b0, uint64_t b1, ChunkOut& o) -> bool {
+        uint64_t ids[32];
+        o.per_t.assign(e->W > 0 ? e->W : 1, 0);
+        for (uint64_t b = b0; b < b1; b++) {
+            const uint64_t lo = ix->bucket_off[b], hi = ix->bucket_off[b + 1];
+            if (hi <= lo) continue;
+            if (hi > ix->n_entries) return o.fail(BK_ERR_INVALID, "bucket_off out of range");
+            // distinct (j, masked) keys present in this bucket: exactly one unless k = 31 ids wrapped onto each other
+            std::vector<std::pair<int, uint64_t>> keys;
+            uint64_t first_kmer = 0;
+            bool any_in_window = false;
+            for (uint64_t i = lo; i < hi; i++) {
+                const bk_bucket_info& bi = ix->entries[i];
+                if (bi.file_id >= ix->n_files || bi.seq_id >= ix->n_seqs[bi.file_id]) return o.fail(BK_ERR_INVALID, "entry %llu references a missing sequence", (unsigned long long)i);
+                const size_t sq = seq_base[bi.file_id] + bi.seq_id;
+                if ((uint64_t)bi.location + k > ix->seq_lens[sq] || bi.idx >= k) return o.fail(BK_ERR_INVALID, "entry %llu lies outside its sequence", (unsigned long long)i);
+                const bronko::Canon cn = bronko::canonical_kmer(ix->seqs[sq] + bi.location, k);
+                if (cn.rc != (bi.canonical != 0)) return o.fail(BK_ERR_INVALID, "entry %llu: canonical flag disagrees with the metadata sequence", (unsigned long long)i);
+                const int j = bi.idx;
+                const uint64_t masked = cn.kmer & ~(3ull << (2 * (k - 1 - j)));
+                if (std::find(keys.begin(), keys.end(), std::make_pair(j, masked)) == keys.end()) {
+                    bronko::assign_buckets(cn.kmer, k, ids);
+                    if (ids[j] != ix->bucket_ids[b]) return o.fail(BK_ERR_INVALID, "bucket %llu: id does not match assign_buckets of its entries", (unsigned long long)ix->bucket_ids[b]);
+                    if (keys.empty()) first_kmer = cn.kmer;
+                    keys.emplace_back(j, masked);
+                }
+                if (j >= e->wstart && j < e->wstart + e->W) { any_in_window = true; o.h_u.push_back(cn.kmer); }
             }
-            if (j >= e->wstart && j < e->wstart + e->W) { any_in_window = true; h_u.push_back(cn.kmer); }
+            // the other exact rank that wraps onto this bucket's id, if the reference did not already put a k-mer there
+            int alias_j = -1;
+            uint64_t alias_masked = 0;
+            if (k == 31 && keys.size() == 1) {
+                const u128 own = rank128(keys[0].second, keys[0].first, k);
+                if ((uint64_t)own != ix->bucket_ids[b]) return o.fail(BK_ERR_INVALID, "internal: exact bucket rank disagrees with assign_buckets");
+                const u128 two64 = (u128)1 << 64;
+                const u128 other = own >= two64 ? own - two64 : own + two64;
+                uint64_t av; int aj;
+                if (unrank128(other, k, &av, &aj) && aj >= e->wstart && aj < e->wstart + e->W) { alias_j = aj; alias_masked = av; }
+            }
+            if (!any_in_window && alias_j < 0) continue;
+            // every entry of the bucket is voted for by a probe of any of its keys (call.rs:1307-1309 iterates the
+            // whole Vec<BucketInfo>), using each entry's own idx (call.rs:1329)
+            const uint32_t off = (uint32_t)o.h_ent.size();
+            for (uint64_t i = lo; i < hi; i++) {
+                const bk_bucket_info& bi = ix->entries[i];
+                bk::DevEntry de;
+                de.cell = (uint32_t)(cell_off[bi.file_id][bi.seq_id] + bi.location + bi.idx);
+                de.file = bi.file_id; de.idx = bi.idx; de.canonical = bi.canonical ? 1 : 0;
+                o.h_ent.push_back(de);
+            }
+            // finalize_variant counts hits per file as run lengths: keep each bucket grouped by file (build_indexes
+            // already appends file by file, build.rs:223-228; votes are order-independent)
+            std::stable_sort(o.h_ent.begin() + off, o.h_ent.end(), [](const bk::DevEntry& x, const bk::DevEntry& y) { return x.file < y.file; });
+            for (auto& kv : keys) {
+                if (kv.first < e->wstart || kv.first >= e->wstart + e->W) continue;
+                o.h_slot_key.push_back(kv.second);
+                o.h_slot_t.push_back((uint8_t)(kv.first - e->wstart));
+                o.h_off.push_back(off);
+                o.h_len.push_back((uint32_t)(hi - lo));
+                o.per_t[kv.first - e->wstart]++;
+            }
+            if (alias_j >= 0) {
+                o.h_slot_key.push_back(alias_masked);
+                o.h_slot_t.push_back((uint8_t)(alias_j - e->wstart));
+                o.h_off.push_back(off);
+                o.h_len.push_back((uint32_t)(hi - lo));
+                o.per_t[alias_j - e->wstart]++;
+                o.pseudo.push_back(alias_masked | (first_kmer & (3ull << (2 * (k - 1 - alias_j)))));
+            }
+            if (o.h_ent.size() >= (1ull << 32)) return o.fail(BK_ERR_UNSUPPORTED, "more than 2^32 index entries in the window");
         }
-        // the other exact rank that wraps onto this bucket's id, if the reference did not already put a k-mer there
-        int alias_j = -1;
-        uint64_t alias_masked = 0;
-        if (k == 31 && keys.size() == 1) {
-            const u128 own = rank128(keys[0].second, keys[0].first, k);
-            if ((uint64_t)own != ix->bucket_ids[b]) return fail(BK_ERR_INVALID, "internal: exact bucket rank disagrees with assign_buckets");
-            const u128 two64 = (u128)1 << 64;
-            const u128 other = own >= two64 ? own - two64 : own + two64;
-            uint64_t av; int aj;
-            if (unrank128(other, k, &av, &aj) && aj >= e->wstart && aj < e->wstart + e->W) { alias_j = aj; alias_masked = av; }
+        return true;
+    };
+    {
+        const uint64_t nbk = e->W > 0 ? ix->n_buckets : 0;
+        const unsigned nt = nbk < 65536 ? 1u : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+        std::vector<ChunkOut> outs(nt);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) {
+            const uint64_t b0 = nbk * t / nt, b1 = nbk * (t + 1) / nt;
+            if (nt == 1) process_buckets(b0, b1, outs[0]);
+            else th.emplace_back([&, t, b0, b1] { process_buckets(b0, b1, outs[t]); });
         }
-        if (!any_in_window && alias_j < 0) continue;
-        // every entry of the bucket is voted for by a probe of any of its keys (call.rs:1307-1309 iterates the
-        // whole Vec<BucketInfo>), using each entry's own idx (call.rs:1329)
-        const uint32_t off = (uint32_t)h_ent.size();
-        for (uint64_t i = lo; i < hi; i++) {
-            const bk_bucket_info& bi = ix->entries[i];
-            bk::DevEntry de;
-            de.cell = (uint32_t)(cell_off[bi.file_id][bi.seq_id] + bi.location + bi.idx);
-            de.file = bi.file_id; de.idx = bi.idx; de.canonical = bi.canonical ? 1 : 0;
-            h_ent.push_back(de);
+        for (auto& t : th) t.join();
+        for (auto& o : outs) if (o.code != BK_OK) return fail(o.code, "%s", o.err.c_str());
+        uint64_t n_ent = 0;
+        for (auto& o : outs) n_ent += o.h_ent.size();
+        if (n_ent >= (1ull << 32)) return fail(BK_ERR_UNSUPPORTED, "more than 2^32 index entries in the window");
+        for (auto& o : outs) {
+            const uint32_t base = (uint32_t)h_ent.size();
+            h_ent.insert(h_ent.end(), o.h_ent.begin(), o.h_ent.end());
+            h_slot_key.insert(h_slot_key.end(), o.h_slot_key.begin(), o.h_slot_key.end());
+            h_slot_t.insert(h_slot_t.end(), o.h_slot_t.begin(), o.h_slot_t.end());
+            h_len.insert(h_len.end(), o.h_len.begin(), o.h_len.end());
+            for (uint32_t off : o.h_off) h_off.push_back(base + off);
+            h_u.insert(h_u.end(), o.h_u.begin(), o.h_u.end());
+            pseudo.insert(pseudo.end(), o.pseudo.begin(), o.pseudo.end());
+            for (size_t t = 0; t < per_t.size() && t < o.per_t.size(); t++) per_t[t] += o.per_t[t];
+            o = ChunkOut();   // free
         }
-        // finalize_variant counts hits per file as run lengths: keep each bucket grouped by file (build_indexes
-        // already appends file by file, build.rs:223-228; votes are order-independent)
-        std::stable_sort(h_ent.begin() + off, h_ent.end(), [](const bk::DevEntry& x, const bk::DevEntry& y) { return x.file < y.file; });
-        for (auto& kv : keys) {
-            if (kv.first < e->wstart || kv.first >= e->wstart + e->W) continue;
-            h_slot_key.push_back(kv.second);
-            h_slot_t.push_back((uint8_t)(kv.first - e->wstart));
-            h_off.push_back(off);
-            h_len.push_back((uint32_t)(hi - lo));
-            per_t[kv.first - e->wstart]++;
-        }
-        if (alias_j >= 0) {
-            h_slot_key.push_back(alias_masked);
-            h_slot_t.push_back((uint8_t)(alias_j - e->wstart));
-            h_off.push_back(off);
-            h_len.push_back((uint32_t)(hi - lo));
-            per_t[alias_j - e->wstart]++;
-            pseudo.push_back(alias_masked | (first_kmer & (3ull << (2 * (k - 1 - alias_j)))));
-        }
-        if (h_ent.size() >= (1ull << 32)) return fail(BK_ERR_UNSUPPORTED, "more than 2^32 index entries in the window");
     }
     pc.lap("buckets -> slots (+aliases)");
     e->n_slots = h_slot_key.size();

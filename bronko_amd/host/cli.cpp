@@ -9,6 +9,10 @@
 
 #include <cerrno>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -248,26 +252,73 @@ void hip_check(int rc, const char* what) {
     if (rc != 0) die("bronko::call", std::string(what) + ": " + bk_last_error());
 }
 
-// One mate file: FASTQ(.gz) -> batches of sequence lines -> bk_push_reads_ascii (packed on the GPU, asynchronous: the
-// next batch is parsed while the previous ones are copied, packed and scanned).  Returns reads seen.
-uint64_t push_fastq(bk_engine* e, int mate, const std::string& path) {
-    constexpr uint64_t kBatchReads = 1u << 18;
-    GzLineReader in(path);
-    std::string line, buf;
-    std::vector<uint64_t> off{0};
-    uint64_t n_reads = 0, ln = 0;
-    auto flush = [&]() {
-        if (off.size() <= 1) return;
-        hip_check(bk_push_reads_ascii(e, mate, reinterpret_cast<const uint8_t*>(buf.data()), off.data(), off.size() - 1), "bk_push_reads_ascii");
-        buf.clear(); off.assign(1, 0);
-    };
-    while (in.next(line)) {
-        if ((ln++ & 3) != 1) continue;           // 4-line FASTQ records: @id / sequence / + / quality
-        buf += line;
-        off.push_back(buf.size());
-        if (++n_reads % kBatchReads == 0) flush();
+// The mate files of one sample: FASTQ(.gz) -> batches of sequence lines -> bk_push_reads_ascii (packed on the GPU,
+// asynchronous: the next batch is parsed while the previous ones are copied, packed and scanned).  Every mate file is
+// inflated and parsed by its own host thread (upstream runs the two KMC processes of a pair concurrently too,
+// call.rs:301-307); the engine is only ever called from this thread.  Returns reads seen.
+struct FastqBatch { std::string buf; std::vector<uint64_t> off{0}; bool last = false; std::string error; };
+struct BatchQueue {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<FastqBatch> q;
+    static constexpr size_t kDepth = 3;
+    void put(FastqBatch&& b) {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return q.size() < kDepth; });
+        q.push_back(std::move(b));
+        cv.notify_all();
     }
-    flush();
+    FastqBatch take() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return !q.empty(); });
+        FastqBatch b = std::move(q.front());
+        q.pop_front();
+        cv.notify_all();
+        return b;
+    }
+};
+void parse_fastq(const std::string& path, BatchQueue& out) {
+    constexpr uint64_t kBatchReads = 1u << 18;
+    FastqBatch cur;
+    try {
+        GzLineReader in(path);
+        std::string line;
+        uint64_t ln = 0, n = 0;
+        while (in.next(line)) {
+            if ((ln++ & 3) != 1) continue;           // 4-line FASTQ records: @id / sequence / + / quality
+            cur.buf += line;
+            cur.off.push_back(cur.buf.size());
+            if (++n % kBatchReads == 0) { out.put(std::move(cur)); cur = FastqBatch(); }
+        }
+    } catch (const std::exception& e) {
+        cur = FastqBatch();
+        cur.error = e.what();
+    }
+    cur.last = true;
+    out.put(std::move(cur));
+}
+uint64_t push_fastqs(bk_engine* e, const std::vector<std::string>& mates) {
+    const size_t nm = mates.size();
+    std::vector<BatchQueue> queues(nm);
+    std::vector<std::thread> readers;
+    for (size_t m = 0; m < nm; m++) readers.emplace_back(parse_fastq, std::cref(mates[m]), std::ref(queues[m]));
+    uint64_t n_reads = 0;
+    std::string error;
+    std::vector<bool> done(nm, false);
+    for (size_t left = nm; left;) {
+        for (size_t m = 0; m < nm; m++) {
+            if (done[m]) continue;
+            FastqBatch b = queues[m].take();
+            if (!b.error.empty() && error.empty()) error = b.error;
+            if (error.empty() && b.off.size() > 1) {
+                hip_check(bk_push_reads_ascii(e, (int)m, reinterpret_cast<const uint8_t*>(b.buf.data()), b.off.data(), b.off.size() - 1), "bk_push_reads_ascii");
+                n_reads += b.off.size() - 1;
+            }
+            if (b.last) { done[m] = true; left--; }
+        }
+    }
+    for (auto& t : readers) t.join();
+    if (!error.empty()) throw std::runtime_error(error);
     return n_reads;
 }
 
@@ -339,10 +390,8 @@ int run_call(const Args& a) {
         const int n_mates = (int)mates.size();
         hip_check(bk_sample_begin(eng.e), "bk_sample_begin");
         uint64_t total_reads = 0;
-        for (int m = 0; m < n_mates; m++) {
-            try { total_reads += push_fastq(eng.e, m, mates[m]); }
-            catch (const std::exception& e) { die(T, e.what()); }
-        }
+        try { total_reads = push_fastqs(eng.e, mates); }
+        catch (const std::exception& e) { die(T, e.what()); }
         LOG_INFO(T, std::to_string(total_reads) + " reads counted from " + mates[0]);
         Pileup p;
         p.fwd_depth.resize(cells4); p.rev_depth.resize(cells4); p.fwd_nk.resize(cells4); p.rev_nk.resize(cells4);

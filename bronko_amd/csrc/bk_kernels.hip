@@ -1373,11 +1373,21 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         first.cell = r.z; first.file = (uint16_t)(r.w & 0xffffu); first.idx = (uint8_t)(r.w >> 16); first.canonical = (uint8_t)(r.w >> 24);
         // single-entry bucket: the vote of call.rs:1327-1384 (see vote()), merged across the row when possible
         const bool single = act && cnt == 1u;
-        if (single) {
-            vt_vote(vt, par, a, first, c, isrc, k, v);
-            // one hit in that genome: "variant" unless the window is a single bucket
-            if (ix.W == 1) { atomicAdd(&lstats[first.file * 3 + 0], 1u); atomicAdd(&lstats[first.file * 3 + 2], 1u); }
-            else atomicAdd(&lstats[first.file * 3 + 1], 1u);
+        if (single) vt_vote(vt, par, a, first, c, isrc, k, v);
+        {
+            // one hit in that genome: "variant" unless the window is a single bucket.  Tallied once per wave for the genome of
+            // the wave's first voter (64 lanes adding 1 to the same LDS word would serialise), one by one for the others
+            const unsigned long long sm = __ballot(single);
+            if (sm) {
+                const int lf = __builtin_ctzll(sm);
+                const bool same = single && first.file == (uint16_t)__shfl((int)first.file, lf);
+                const uint32_t n_same = (uint32_t)__popcll(__ballot(same));
+                const uint32_t add = same ? ((int)(threadIdx.x & 63u) == lf ? n_same : 0u) : (single ? 1u : 0u);
+                if (add) {
+                    if (ix.W == 1) { atomicAdd(&lstats[first.file * 3 + 0], add); atomicAdd(&lstats[first.file * 3 + 2], add); }
+                    else atomicAdd(&lstats[first.file * 3 + 1], add);
+                }
+            }
         }
         if (act && cnt > 1u) {
             // entries of one bucket are grouped by file (index build appends file by file): run lengths = hits per file

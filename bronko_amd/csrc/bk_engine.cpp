@@ -214,6 +214,7 @@ struct bk_engine {
     DevBuf<uint8_t> amb;
     DevBuf<uint16_t> pilots;
     DevBuf<unsigned int> slabs;             // [n_cus][n_lds_bins] workgroup histograms of the last scan launch
+    DevBuf<uint4> gring;                    // scan scratch: per-wave rings of Level-2 chunks (bk_kernels.h ScanArgs::gq)
     DevBuf<unsigned int> e_planes;          // [8][E] u32, XCD-private planes for positions >= n_lds_bins
     bool use_xcd_planes = true;
     uint64_t kmers_since_fold = 0;
@@ -828,17 +829,18 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         e->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         const size_t budget = bk::scan_lds_budget();
         // LDS holds, for the first n_lds_bins cells (the first genome(s) of the index): the difference array (4 B per cell) and
-        // Level 1's copies of the per-cell arrays (2 + 1 + 1 bits per cell).  As many cells as fit.
+        // Level 1's copies of the per-cell arrays (2 + 1 bits per cell).  As many cells as fit.
         e->ref_in_lds = true;
         if (const char* rl = getenv("BK_REF_IN_LDS")) e->ref_in_lds = atoi(rl) != 0;
         uint64_t nb = std::min<uint64_t>(e->total_cells, budget / sizeof(unsigned int));
         if (e->ref_in_lds) {
-            nb = std::min<uint64_t>(e->total_cells, budget * 2 / 9);   // 4.5 bytes per cell ...
+            nb = std::min<uint64_t>(e->total_cells, budget * 8 / 35);   // 4.375 bytes per cell ...
             while (nb > 0 && nb * sizeof(unsigned int) + bk::scan_ref_lds_bytes((uint32_t)nb) > budget) nb -= std::min<uint64_t>(nb, 64);   // ... and the paddings
         }
         e->n_lds_bins = (uint32_t)nb;
         if (const char* nl = getenv("BK_LDS_BINS")) e->n_lds_bins = std::min<uint32_t>(e->n_lds_bins, (uint32_t)atol(nl));
         BK_HIP(e->slabs.alloc((size_t)e->n_cus * std::max<uint32_t>(e->n_lds_bins, 1)));
+        BK_HIP(e->gring.alloc(bk::scan_gring_entries((uint32_t)e->n_cus)));
     }
     pc.lap("estat + LDS policy");
     if (const char* nx = getenv("BK_NO_XCD_PLANES")) e->use_xcd_planes = atoi(nx) == 0;
@@ -949,6 +951,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.ablate = e->ablate;
     a.e_planes = e->use_xcd_planes ? e->e_planes.p : nullptr;
     a.slabs = e->slabs.p;
+    a.gq = e->gring.p;
     a.n_lds_bins = e->n_lds_bins;
     a.ref_in_lds = e->ref_in_lds ? 1 : 0;
     a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->params.kmer_table_log2;

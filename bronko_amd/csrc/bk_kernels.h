@@ -28,6 +28,7 @@ struct ScanArgs {
     uint32_t stride_words;
     unsigned long long* counters;   // u64 plane [E | V] (bk_device.h)
     unsigned int* slabs;            // [grid][n_lds_bins] packed (rc<<16 | fwd) per-cell bins of each workgroup
+    uint4* gq;                      // [scan_gring_entries(grid)] scratch: the waves' rings of Level-2 chunks
     uint32_t n_lds_bins;            // exact hits at cells [win_lo, win_lo + n_lds_bins) are counted in LDS
     uint32_t win_lo;                // first cell of that window (a multiple of 32): the genome the sample looks like
     const uint32_t* occ;            // [n_full][n_files] cell | rc << 31 of the k-mer's first occurrence in each genome file
@@ -42,7 +43,7 @@ struct ScanArgs {
     uint32_t ktab_log2;
     unsigned long long* ktab_overflow;
     uint32_t mate;
-    int ablate;                     // measurement aid, 0 in production: 1 = Level 1 only, 2 = no V atomics, 3 = no slow path
+    int ablate;                     // measurement aid, 0 in production: 1 = Level 1 only, 2 = no V atomics, 3 = no slow path, 4 = no Level 2
 };
 
 struct FinalizeArgs {
@@ -96,6 +97,7 @@ void launch_pack_reads(const PackArgs& a, hipStream_t stream);
 void launch_pick_window(const ScanArgs& a, uint64_t n_probe, unsigned int* votes, hipStream_t stream);
 void launch_add_u64(unsigned long long* dst, const unsigned long long* src, hipStream_t stream);   // *dst += *src
 uint32_t scan_grid(uint64_t n_records, int n_cus);
+size_t scan_gring_entries(uint32_t grid);    // uint4 entries ScanArgs::gq must hold for a launch of `grid` workgroups
 uint64_t scan_max_records(uint32_t grid);   // most records one launch_scan_count may be given
 int scan_ref_pad_words();
 int scan_ref_back_words();

@@ -250,7 +250,8 @@ void launch_ktab_stats(const unsigned long long* keys, const unsigned int* cnt, 
 constexpr int kScanBlock = 1024;
 constexpr int kScanWaves = kScanBlock / 64;
 constexpr int kQueueCap = 96;               // slow-path queue: a batch starts at 32 pending, a step adds <= 64
-constexpr int kRangeCap = 128;              // S and G queues: a batch starts at 64 pending, a round adds <= 64
+constexpr int kRangeCap = 128;              // N queue: a batch starts at 64 pending, a round adds <= 64
+constexpr uint32_t kGRing = 128;            // Level-2 ring (global memory, per wave): a batch starts at 64 pending, an N batch adds <= 64
 constexpr uint32_t kMaxRecordsPerGroup = 16384;
 constexpr uint32_t kSlowLdsQuota = 2048;    // per wave and launch: slow-path E hits that may use the LDS array
 constexpr int kSeeds = 4;
@@ -260,7 +261,7 @@ constexpr int kBitPadWords = 2;             // the same 64 cells for the 1-bit p
 constexpr int kBitBackWords = 3;
 constexpr size_t kQueueBytes = (size_t)kScanWaves * kQueueCap * sizeof(unsigned long long);
 constexpr size_t kRangeBytes = (size_t)kScanWaves * kRangeCap * sizeof(unsigned int);
-constexpr size_t kScanLdsFixed = kQueueBytes + 2 * kRangeBytes + 16 + 64;
+constexpr size_t kScanLdsFixed = kQueueBytes + kRangeBytes + 16 + 64;
 
 // number of set bits of a wave mask below this lane
 __device__ __forceinline__ uint32_t lane_prefix(unsigned long long m) {
@@ -417,17 +418,16 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* queue_c = reinterpret_cast<unsigned long long*>(smem);
     unsigned int* range_s = reinterpret_cast<unsigned int*>(smem + kQueueBytes);
-    unsigned int* range_g = reinterpret_cast<unsigned int*>(smem + kQueueBytes + kRangeBytes);
-    unsigned int* block_kmers = reinterpret_cast<unsigned int*>(smem + kQueueBytes + 2 * kRangeBytes);   // 16 B reserved
+    unsigned int* block_kmers = reinterpret_cast<unsigned int*>(smem + kQueueBytes + kRangeBytes);   // 16 B reserved
     unsigned int* scan_tmp = block_kmers + 4;       // 16 words: wave totals of the epilogue's prefix sum
     unsigned int* bins = scan_tmp + 16;             // [n_lds_bins + 1] the per-cell difference array
-    unsigned int* lds_ref = bins + a.n_lds_bins + 1;   // REF_LDS: padded ref words, then the two padded bit arrays
+    unsigned int* lds_ref = bins + a.n_lds_bins + 1;   // REF_LDS: padded ref words, then the padded bit array
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform by construction: tell the compiler
     unsigned long long* const q = queue_c + wave * kQueueCap;
     unsigned int* const rqs = range_s + wave * kRangeCap;
-    unsigned int* const rqg = range_g + wave * kRangeCap;
+    uint4* const gq = a.gq + ((size_t)blockIdx.x * kScanWaves + wave) * kGRing;   // this wave's ring of Level-2 chunks (global memory)
 
     const uint32_t total = a.total_cells;
     // Level 1 only ever looks at cells below n_lds_bins (a read whose diagonal leaves them goes to Level 2 as a whole), so
@@ -439,16 +439,12 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     for (uint32_t i = threadIdx.x; i <= a.n_lds_bins; i += kScanBlock) bins[i] = 0u;
     if (REF_LDS) {
         for (uint32_t i = threadIdx.x; i < n_refw; i += kScanBlock) lds_ref[i] = a.ref_words[(win_lo >> 4) + i];
-        for (uint32_t i = threadIdx.x; i < n_bitw; i += kScanBlock) {
-            lds_ref[n_refw + i] = a.cell_has[(win_lo >> 5) + i];
-            lds_ref[n_refw + n_bitw + i] = a.cell_clean[(win_lo >> 5) + i];
-        }
+        for (uint32_t i = threadIdx.x; i < n_bitw; i += kScanBlock) lds_ref[n_refw + i] = a.cell_has[(win_lo >> 5) + i];
     }
     __syncthreads();
     // Level 1's arrays: symbol / bit 0 is cell win_lo; negative positions down to -64 are readable (padding or earlier cells)
     const unsigned int* refw1 = (REF_LDS ? lds_ref : a.ref_words + (win_lo >> 4)) + kRefPadWords;
     const unsigned int* hasw = (REF_LDS ? lds_ref + n_refw : a.cell_has + (win_lo >> 5)) + kBitPadWords;
-    const unsigned int* cleanw = (REF_LDS ? lds_ref + n_refw + n_bitw : a.cell_clean + (win_lo >> 5)) + kBitPadWords;
     const unsigned int* refw = a.ref_words + kRefPadWords;   // the batches: any cell, symbol 0 = cell 0 (global, cached)
     const unsigned int* yfw = a.cell_yf + kRefPadWords;   // batches only (global memory, L1 / L2 cached)
     const unsigned int* yrw = a.cell_yr + kRefPadWords;
@@ -463,6 +459,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     const uint32_t rc_in_hi = rcshift >= 32 ? 0xffffffffu : 0u;   // which half receives the new complemented base
     const uint32_t km1 = (uint32_t)k - 1u;
     const uint32_t chunk = (uint32_t)k;                             // most k-mers one Level-2 lane takes
+    const uint32_t piece = 65u - (uint32_t)k;                       // most k-mers of an N run the N batch looks at together (64 bases)
     const int omin = a.v_omin, span = a.v_span;
     const uint64_t n_e = e_plane_len(a.n_u);
     unsigned int* const e_local = a.e_planes ? a.e_planes + (size_t)xcc_id() * n_e : nullptr;
@@ -493,7 +490,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     const KmerTable kt{STATS ? a.ktab_keys : nullptr, a.ktab_cnt, a.ktab_log2, a.ktab_overflow, a.mate};   // STATS = full_kmer_stats
     uint32_t nkm = 0;  // k-mer occurrences of this lane's records
     uint32_t qn = 0;   // wave-uniform fill of the slow-path queue
-    uint32_t qs = 0, qg = 0;   // wave-uniform fill of the S and G run queues
+    uint32_t qs = 0, qg = 0, gh = 0;   // wave-uniform: fill of the N queue, fill and head of the Level-2 ring
     SlowPipe pipe;
     const IndexView& ix = *a.ixp;
 
@@ -523,13 +520,13 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     uint32_t dfl = 0, pdfl = 0;         // bit 0: same strand as the reference; bit 1: the diagonal is known ("seeded")
     uint32_t parity = 0;                // wave-uniform: parity of the current tile
     uint32_t pf_sink = 0;               // destination of the prefetch loads (never read)
-    uint32_t olds = 0, oldg = 0;        // wave-uniform: queued runs that belong to the previous tile (they are at the front)
+    uint32_t olds = 0;                  // wave-uniform: queued N pieces that belong to the previous tile
 
     for (uint64_t tile = (uint64_t)blockIdx.x * kScanWaves + wave;; tile += (uint64_t)gridDim.x * kScanWaves) {
         const bool fin = tile >= n_tiles;   // one empty tile after the last: it flushes the queues
         pr32 = r32; pdg = dg; pdfl = dfl;
         parity ^= 1u;
-        olds = qs; oldg = qg;
+        olds = qs;
         const uint64_t r = tile * 64 + lane;
         const bool live = !fin && r < n_records;
         r32 = live ? (uint32_t)r : 0u;
@@ -607,40 +604,36 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
         uint32_t xn0 = len ? w[0] : 0u, xn1 = len > 16u ? w[1] : 0u;   // the next two read words (loaded a step ahead)
         uint32_t h_lo = 0xffffffffu, h_hi = 0xffffffffu;   // mismatch flags of the last 64 bases, newest 32 in h_hi
         uint32_t run_start = 0;         // first k-mer of the lane's open run
-        uint32_t run_type = 0;          // its kind: 0 none, 1 E, 2 S, 3 G
-        uint32_t pe = 0, ps = 0, pg = 0;   // kind bits of the last k-mer of the previous word (bit 0)
-        uint32_t E16 = 0, S16 = 0, G16 = 0, Bd = 0;   // last word: kind of the k-mer of each step, steps where a new run starts
+        uint32_t run_type = 0;          // its kind: 0 none, 1 E, 2 N
+        uint32_t pe = 0, pn = 0;        // kind bits of the last k-mer of the previous word (bit 0)
+        uint32_t E32 = 0, N32 = 0, Bd = 0;   // last word: kind of the k-mer of each step, steps where a new run starts
         uint32_t tw_i0 = 0;             // wave-uniform: first base of that word
         bool pend = false;              // wave-uniform: some lane still has run boundaries to process
         bool words_done = maxlen == 0u;
         for (;;) {
             const bool flush = !pend && words_done;
-            if (qg >= 64u || (flush && (fin ? qg != 0u : oldg != 0u))) {
+            // (at the very end the N batches go first: what they send to Level 2 joins the same G batch)
+            if (qg >= 64u || (flush && fin && qg != 0u && qs == 0u)) {
                 // ================= Level 2 ("G batch"): one queued chunk (<= k k-mers) per lane ==================
+                // The last batch of a wave is rarely full: its chunks are cut into 2^ps parts, one per lane, so that the batch
+                // takes as many steps as the longest part and not as the longest chunk.
                 const uint32_t nb2 = min(qg, 64u);
-                const uint32_t ent = (uint32_t)lane < nb2 ? rqg[lane] : 0u;
-                {   // move the rest of the queue down
-                    const uint32_t rest = qg - nb2;
-                    const uint32_t t = (uint32_t)lane < rest ? rqg[64 + lane] : 0u;
-                    __builtin_amdgcn_wave_barrier();
-                    if ((uint32_t)lane < rest) rqg[lane] = t;
-                    __builtin_amdgcn_wave_barrier();
-                    qg = rest;
-                    oldg = oldg > nb2 ? oldg - nb2 : 0u;
-                }
-                if (a.ablate == 1) continue;   // measurement aid: Level 1 alone (incomplete counts)
-                const int src = (int)(ent & 63u);
-                const uint32_t s_first = (ent >> 6) & 0xffffu;
-                const uint32_t n2 = (uint32_t)lane < nb2 ? (ent >> 22) & 63u : 0u;
-                const bool cur = ((ent >> 28) & 1u) == parity;
-                const int32_t dg_c = __shfl(dg, src), dg_p = __shfl(pdg, src);
-                const uint32_t fl_c = (uint32_t)__shfl((int)dfl, src), fl_p = (uint32_t)__shfl((int)pdfl, src);
-                const uint32_t r_c = (uint32_t)__shfl((int)r32, src), r_p = (uint32_t)__shfl((int)pr32, src);
-                const int32_t dg2 = cur ? dg_c : dg_p;
-                const uint32_t fl2 = cur ? fl_c : fl_p;
+                const uint32_t ps = 31u - (uint32_t)__builtin_clz(64u / nb2);     // wave-uniform
+                const uint32_t sub = (chunk + (1u << ps) - 1u) >> ps;             // k-mers per part
+                const uint32_t ei = (uint32_t)lane >> ps, part = (uint32_t)lane & ((1u << ps) - 1u);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint4 ge = ei < nb2 ? gq[(gh + ei) & (kGRing - 1u)] : make_uint4(0u, 0u, 0u, 0u);
+                gh = (gh + nb2) & (kGRing - 1u);
+                qg -= nb2;
+                if (a.ablate == 1 || a.ablate == 4) continue;   // measurement aids: Level 1 alone / without Level 2 (incomplete counts)
+                const uint32_t n_e = (ge.z >> 16) & 0xffu;     // 0 for a lane without an entry
+                const uint32_t s_first = (ge.z & 0xffffu) + part * sub;
+                const uint32_t n2 = n_e > part * sub ? min(sub, n_e - part * sub) : 0u;
+                const int32_t dg2 = (int32_t)ge.y;
+                const uint32_t fl2 = ge.z >> 24;
                 const bool fwd2 = fl2 & 1u;
                 const bool seeded2 = (fl2 & 2u) && n2;
-                const uint32_t* __restrict__ w2 = words0 + (uint64_t)(n2 ? (cur ? r_c : r_p) : 0u) * a.stride_words;
+                const uint32_t* __restrict__ w2 = words0 + (uint64_t)ge.x * a.stride_words;
                 uint32_t nmax = n2;
 #pragma unroll
                 for (int off = 32; off; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off));
@@ -749,7 +742,10 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 continue;
             }
             if (qs >= 64u || (flush && (fin ? qs != 0u : olds != 0u))) {
-                // ================= S batch: one queued S run per lane, two atomics each (qg < 64 here) =============
+                // ================= N batch: one queued piece of an N run per lane (qg < 64 here) ====================
+                // The piece's n <= 65 - k k-mers lie in 64 read bases.  With one mismatch in them the piece is one S run; with
+                // two (t1 < t2) it is the k-mers that hold only t1 (an S run), both (a G chunk), only t2 (an S run).  An S run
+                // needs clean cells with consecutive ids.  Anything else goes to Level 2 chunk by chunk.
                 const uint32_t nb2 = min(qs, 64u);
                 const uint32_t ent = (uint32_t)lane < nb2 ? rqs[lane] : 0u;
                 {   // move the rest of the queue down
@@ -759,63 +755,122 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                     if ((uint32_t)lane < rest) rqs[lane] = t;
                     __builtin_amdgcn_wave_barrier();
                     qs = rest;
-                    olds = olds > nb2 ? olds - nb2 : 0u;
                 }
-                if (a.ablate == 1) continue;
                 const bool have = (uint32_t)lane < nb2;
+                const bool cur = (ent >> 31) == parity;
+                olds -= (uint32_t)__popcll(__ballot(have && !cur));
+                if (a.ablate == 1) continue;
                 const int src = (int)(ent & 63u);
                 const uint32_t s_first = (ent >> 6) & 0xffffu;
-                const uint32_t n2 = (ent >> 22) & 63u;
-                const bool cur = ((ent >> 28) & 1u) == parity;
+                const uint32_t n2 = (ent >> 22) & 0xffu;
                 const int32_t dg_c = __shfl(dg, src), dg_p = __shfl(pdg, src);
                 const uint32_t fl_c = (uint32_t)__shfl((int)dfl, src), fl_p = (uint32_t)__shfl((int)pdfl, src);
                 const uint32_t r_c = (uint32_t)__shfl((int)r32, src), r_p = (uint32_t)__shfl((int)pr32, src);
                 const int32_t dg2 = cur ? dg_c : dg_p;
-                const bool fwd2 = (cur ? fl_c : fl_p) & 1u;
+                const uint32_t fl2 = cur ? fl_c : fl_p;
+                const bool fwd2 = fl2 & 1u;
+                const bool an = have && (fl2 & 2u) && n2 + km1 <= 64u;   // analysable: a diagonal, and 64 bases hold it
                 const uint32_t* __restrict__ w2 = words0 + (uint64_t)(have ? (cur ? r_c : r_p) : 0u) * a.stride_words;
-                // the run's first k-mer against the reference k-mer of its cell: where is the one difference, which base
-                const int32_t c_first = have ? (fwd2 ? dg2 + (int32_t)s_first : dg2 - (int32_t)s_first) : 0;
-                const uint64_t g = read_symbols_at(w2, s_first, last_word) & kmask;
-                const uint64_t gref = fwd2 ? symbols_at(refw, c_first) : ~rev2_64(symbols_at(refw, c_first + k - 32));
-                const uint64_t dx = (g ^ gref) & kmask;
-                const uint64_t dfl64 = (dx | (dx >> 1)) & 0x5555555555555555ull;
-                const uint32_t tpos = dfl64 ? (uint32_t)(__builtin_ctzll(dfl64) >> 1) : 0u;   // read offset of the differing base
-                const uint32_t br = (uint32_t)(g >> (2u * tpos)) & 3u;
-                const uint32_t id_first = a.id_at[c_first];
-                // the run's n2 - 1 further cells must continue the id sequence (follow bits of cell_yf / cell_yr)
-                const uint64_t ys = fwd2 ? symbols_at(yfw, c_first + 1) : symbols_at(yrw, c_first - (int32_t)(n2 ? n2 - 1u : 0u));
-                const uint64_t fmask = n2 > 1u ? (0xaaaaaaaaaaaaaaaaull >> (64u - 2u * (n2 - 1u))) : 0ull;
-                const bool good = have && __popcll(dfl64) == 1 && id_first != 0xffffffffu && (ys & fmask) == fmask && tpos + 1u >= n2;
-                if (good) {
+                const int32_t c_first = an ? (fwd2 ? dg2 + (int32_t)s_first : dg2 - (int32_t)s_first) : 0;
+                const uint64_t ga = read_symbols_at(w2, s_first, last_word), gb = read_symbols_at(w2, s_first + 32u, last_word);
+                uint64_t fa, fb;   // mismatch flags of read bases s_first + [0, 32) and + [32, 64), at the even bits
+                {
+                    // read base s_first + t <-> reference base c_first + t (fwd) / complement of base c_first + k - 1 - t
+                    const uint64_t ra = fwd2 ? symbols_at(refw, c_first) : ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 31));
+                    const uint64_t rb = fwd2 ? symbols_at(refw, c_first + 32) : ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 63));
+                    const uint64_t da = ga ^ ra, db = gb ^ rb;
+                    const uint32_t L = an ? n2 + km1 : 0u;   // bases the piece covers
+                    const uint64_t ma = L >= 32u ? ~0ull : (1ull << (2u * L)) - 1ull;
+                    const uint64_t mb = L >= 64u ? ~0ull : L > 32u ? (1ull << (2u * (L - 32u))) - 1ull : 0ull;
+                    fa = (da | (da >> 1)) & 0x5555555555555555ull & ma;
+                    fb = (db | (db >> 1)) & 0x5555555555555555ull & mb;
+                }
+                const int m = __popcll(fa) + __popcll(fb);
+                const int t1 = fa ? (__builtin_ctzll(fa) >> 1) : fb ? 32 + (__builtin_ctzll(fb) >> 1) : 0;
+                const uint64_t fa2 = fa & (fa - 1ull), fb2 = fa ? fb : fb & (fb - 1ull);
+                const int t2 = fa2 ? (__builtin_ctzll(fa2) >> 1) : fb2 ? 32 + (__builtin_ctzll(fb2) >> 1) : 0;
+                // k-mer j of the piece holds base t iff t - (k-1) <= j <= t
+                const int kk = (int)km1, nn = (int)n2;
+                int jA = max(0, t1 - kk), a_hi = min(t1, nn - 1);
+                int jB = 0, nB = 0, jC = 0, nC = 0;
+                if (m == 2) {
+                    a_hi = min(a_hi, t2 - k);
+                    jB = max(0, t2 - kk); nB = max(0, min(t1, nn - 1) - jB + 1);
+                    jC = max(t1 + 1, t2 - kk); nC = max(0, min(t2, nn - 1) - jC + 1);
+                }
+                const int nA = max(0, a_hi - jA + 1);
+                const bool shaped = an && (m == 1 || m == 2) && nA + nB + nC == nn;   // no k-mer of the piece is left over
+                // an S run of nS k-mers from k-mer j0 of the piece on: its cells must be clean and continue one id sequence
+                auto check = [&](int j0, int nS, uint32_t& idS) -> bool {
+                    const bool on = shaped && nS > 0;
+                    const int32_t cS = on ? (fwd2 ? c_first + j0 : c_first - j0) : 0;
+                    const uint32_t nm1 = on ? (uint32_t)nS - 1u : 0u;
+                    idS = a.id_at[cS];
+                    const uint64_t ys = fwd2 ? symbols_at(yfw, cS) : symbols_at(yrw, cS - (int32_t)nm1);   // cells in rising order
+                    const uint64_t cm = 0x5555555555555555ull >> (62u - 2u * nm1);
+                    const uint64_t f0 = nm1 ? 0xaaaaaaaaaaaaaaaaull >> (64u - 2u * nm1) : 0ull;
+                    const uint64_t need = cm | (fwd2 ? f0 << 2 : f0);   // follow bits: of every cell but the run's first
+                    return on && idS != 0xffffffffu && (ys & need) == need;
+                };
+                auto emit = [&](int j0, int nS, int t, uint32_t idS) {
+                    const uint32_t tpos = (uint32_t)(t - j0);    // offset of the differing base in the run's first k-mer
+                    const uint32_t br = (uint32_t)((t < 32 ? ga : gb) >> (2u * ((uint32_t)t & 31u))) & 3u;
+                    const uint32_t nm1 = (uint32_t)nS - 1u;
                     // offsets (along the reference, from each k-mer's start) the run's k-mers have the difference at
-                    const uint32_t o_first = fwd2 ? tpos : km1 - tpos;             // of the first k-mer
-                    const uint32_t o_lo = fwd2 ? tpos - (n2 - 1u) : o_first;       // fwd: later k-mers start later, the offset shrinks
-                    const uint32_t o_hi = fwd2 ? tpos : o_first + (n2 - 1u);
+                    const uint32_t o_first = fwd2 ? tpos : km1 - tpos;
+                    const uint32_t o_lo = fwd2 ? tpos - nm1 : o_first;       // fwd: later k-mers start later, the offset shrinks
+                    const uint32_t o_hi = fwd2 ? tpos : o_first + nm1;
                     const int lo2 = max((int)o_lo, omin), hi2 = min((int)o_hi, omin + span - 1);
                     if (lo2 <= hi2 && a.ablate != 2) {
-                        unsigned long long* row = v_counters + v_row_base(id_first + o_first - (uint32_t)omin, fwd2 ? br : 3u - br, fwd2 ? 0u : 1u, span);
+                        unsigned long long* row = v_counters + v_row_base(idS + o_first - (uint32_t)omin, fwd2 ? br : 3u - br, fwd2 ? 0u : 1u, span);
                         atomicAdd(row + (lo2 - omin), 1ull);
                         if (hi2 - omin + 1 < span) atomicAdd(row + (hi2 - omin + 1), ~0ull);   // (slot `span` is never read)
                     }
+                };
+                uint32_t idA, idC;
+                const bool okA = check(jA, nA, idA), okC = check(jC, nC, idC);
+                const bool good = shaped && (nA == 0 || okA) && (nC == 0 || okC);
+                if (good && nA) emit(jA, nA, t1, idA);
+                if (good && nC) emit(jC, nC, t2, idC);
+                // to Level 2: the k-mers that hold both mismatches -- unless every one of their cells has no other reference k-mer
+                // form within Hamming distance 3: then they are neither reference k-mers nor one base away from one and touch
+                // nothing (full_kmer_stats: the statistics table still wants them); of a piece that is not of this shape, the first
+                // chunk (the rest comes back here)
+                bool b_dead = false;
+                if (!STATS) {
+                    const int32_t cB = good && nB ? (fwd2 ? c_first + jB : c_first - jB - (nB - 1)) : 0;
+                    const uint32_t need = nB ? 0xffffffffu >> (32 - nB) : 0u;
+                    b_dead = (bits32_at(c3w, cB) & need) == need;
                 }
-                // (cannot happen for a run Level 1 made on an intact index; kept so that nothing is ever dropped)
-                const unsigned long long bm = __ballot(have && !good);
+                const uint32_t take = min(n2, chunk);
+                const bool pushg = have && (good ? nB != 0 && !b_dead : true);
+                const bool requeue = have && !good && n2 > take;
+                const unsigned long long bm = __ballot(pushg);
                 if (bm) {
-                    if (have && !good) rqg[qg + lane_prefix(bm)] = ent;
+                    if (pushg) {
+                        const uint32_t sf = good ? s_first + (uint32_t)jB : s_first, ng = good ? (uint32_t)nB : take;
+                        gq[(gh + qg + lane_prefix(bm)) & (kGRing - 1u)] = make_uint4(cur ? r_c : r_p, (uint32_t)dg2, sf | (ng << 16) | (fl2 << 24), 0u);
+                    }
                     qg += (uint32_t)__popcll(bm);
-                    oldg += (uint32_t)__popcll(__ballot(have && !good && !cur));
-                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 }
+                const unsigned long long rm = __ballot(requeue);
+                if (rm) {
+                    if (requeue) rqs[qs + lane_prefix(rm)] = (uint32_t)src | (ent & 0x80000000u) | ((s_first + take) << 6) | ((n2 - take) << 22);
+                    qs += (uint32_t)__popcll(rm);
+                    olds += (uint32_t)__popcll(__ballot(requeue && !cur));
+                }
+                __builtin_amdgcn_wave_barrier();
                 continue;
             }
             if (pend) {
-                // ---- the next run boundary of each lane: close the open run, open the next (qs, qg < 64 here) ----
+                // ---- the next run boundary of each lane: close the open run, open the next (qs < 64 here) ----
                 const bool has = Bd != 0u;
                 const uint32_t b = has ? (uint32_t)__builtin_ctz(Bd) : 0u;
                 const uint32_t s = tw_i0 + b - km1;          // the k-mer that ends at that base: first of the new run
                 const uint32_t n = s - run_start;
-                const bool long_g = has && run_type == 3u && n > chunk;   // a long G run goes out chunk by chunk
-                const uint32_t take = long_g ? chunk : n;
+                const bool long_n = has && run_type == 2u && n > piece;   // a long N run goes out piece by piece
+                const uint32_t take = long_n ? piece : n;
                 if (has && run_type == 1u) {
                     // E run over k-mers [run_start, s): cells dg + run_start .. dg + s - 1 (fwd) / dg - s + 1 .. dg - run_start
                     const uint32_t c_lo = (fwd ? (uint32_t)(dg + (int32_t)run_start) : (uint32_t)(dg - (int32_t)s + 1)) - win_lo;
@@ -823,22 +878,16 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                     __hip_atomic_fetch_add(&bins[c_lo], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(&bins[c_lo + n], 0u - inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                const uint32_t ent = (uint32_t)lane | (run_start << 6) | (take << 22) | (parity << 28);
                 const unsigned long long sm = __ballot(has && run_type == 2u);
                 if (sm) {
-                    if (has && run_type == 2u) rqs[qs + lane_prefix(sm)] = ent;
+                    if (has && run_type == 2u) rqs[qs + lane_prefix(sm)] = (uint32_t)lane | (run_start << 6) | (take << 22) | (parity << 31);
                     qs += (uint32_t)__popcll(sm);
+                    __builtin_amdgcn_wave_barrier();
                 }
-                const unsigned long long gm = __ballot(has && run_type == 3u);
-                if (gm) {
-                    if (has && run_type == 3u) rqg[qg + lane_prefix(gm)] = ent;
-                    qg += (uint32_t)__popcll(gm);
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (long_g) {
-                    run_start += chunk;                      // the boundary stays: the rest goes out in the next rounds
+                if (long_n) {
+                    run_start += piece;                      // the boundary stays: the rest goes out in the next rounds
                 } else if (has) {
-                    run_type = ((E16 >> b) & 1u) ? 1u : ((S16 >> b) & 1u) ? 2u : ((G16 >> b) & 1u) ? 3u : 0u;
+                    run_type = ((E32 >> b) & 1u) ? 1u : ((N32 >> b) & 1u) ? 2u : 0u;
                     run_start = s;
                     Bd &= Bd - 1u;
                 }
@@ -867,33 +916,25 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 h_hi = M32;
                 // per-cell bits of the 32 k-mers that end in these words, in step order
                 const int32_t c0 = act ? (fwd ? dgw + (int32_t)i0 - (int32_t)km1 : dgw - (int32_t)i0 + (int32_t)km1 - 31) : 0;
-                const uint32_t hl = bits32_at(hasw, c0), cl = bits32_at(cleanw, c0);
+                const uint32_t hl = bits32_at(hasw, c0);
                 const uint32_t HAS32 = fwd ? hl : __builtin_bitreverse32(hl);
-                const uint32_t CLEAN32 = fwd ? cl : __builtin_bitreverse32(cl);
                 // steps that end a k-mer of the read: i0 + b >= k - 1 and i0 + b < len
                 const uint32_t lo = i0 >= km1 ? 0u : min(km1 - i0, 32u);
                 const uint32_t hi = len > i0 ? min(len - i0, 32u) : 0u;
                 const uint32_t VAL32 = (hi >= 32u ? 0xffffffffu : (1u << hi) - 1u) & (lo >= 32u ? 0u : ~((1u << lo) - 1u));
-                // A: some mismatch among the k bases that end at step b; B: at least two.  The flag of base i0 + b - t sits
-                // at bit 32 + b - t of (h_hi : h_lo)
-                uint32_t A = h_hi, B = 0;
+                // A: some mismatch among the k bases that end at step b.  The flag of base i0 + b - t sits at bit 32 + b - t of
+                // (h_hi : h_lo)
+                uint32_t A = h_hi;
                 if (KT) {
 #pragma unroll
-                    for (int t = 1; t < (KT ? KT : 2); ++t) {
-                        const uint32_t st = __builtin_amdgcn_alignbit(h_hi, h_lo, (uint32_t)(32 - t));
-                        B |= A & st;
-                        A |= st;
-                    }
+                    for (int t = 1; t < (KT ? KT : 2); ++t) A |= __builtin_amdgcn_alignbit(h_hi, h_lo, (uint32_t)(32 - t));
                 } else {
-                    for (int t = 1; t < k; ++t) { const uint32_t st = __builtin_amdgcn_alignbit(h_hi, h_lo, (uint32_t)(32 - t)); B |= A & st; A |= st; }
+                    for (int t = 1; t < k; ++t) A |= __builtin_amdgcn_alignbit(h_hi, h_lo, (uint32_t)(32 - t));
                 }
-                E16 = ~A & HAS32 & VAL32;
-                S16 = A & ~B & CLEAN32 & VAL32;
-                G16 = VAL32 & ~(E16 | S16);
-                // a new run starts where the kind changes, or where an S k-mer's one mismatch is the newest base (the
-                // mismatch the previous S k-mers had has just left the window)
-                Bd = (E16 ^ ((E16 << 1) | pe)) | (S16 ^ ((S16 << 1) | ps)) | (G16 ^ ((G16 << 1) | pg)) | (S16 & M32);
-                pe = E16 >> 31; ps = S16 >> 31; pg = G16 >> 31;
+                E32 = ~A & HAS32 & VAL32;
+                N32 = VAL32 & ~E32;
+                Bd = (E32 ^ ((E32 << 1) | pe)) | (N32 ^ ((N32 << 1) | pn));   // a new run starts where the kind changes
+                pe = E32 >> 31; pn = N32 >> 31;
                 tw_i0 = i0;
                 pend = __ballot(Bd != 0u) != 0ull;
                 i0 += 32u;
@@ -963,9 +1004,9 @@ void launch_pick_window(const ScanArgs& a, uint64_t n_probe, unsigned int* votes
 }
 
 size_t scan_lds_budget() { return 160u * 1024u - 64u - kScanLdsFixed - sizeof(unsigned int); }
-// LDS bytes of the per-cell arrays Level 1 stages for `cells` cells (reference 2 bits, two 1-bit arrays, paddings)
+// LDS bytes of the per-cell arrays Level 1 stages for `cells` cells (reference 2 bits, one 1-bit array, paddings)
 size_t scan_ref_lds_bytes(uint32_t cells) {
-    return ((size_t)(kRefPadWords + (cells + 15) / 16 + kRefBackWords) + 2 * (size_t)(kBitPadWords + (cells + 31) / 32 + kBitBackWords)) *
+    return ((size_t)(kRefPadWords + (cells + 15) / 16 + kRefBackWords) + (size_t)(kBitPadWords + (cells + 31) / 32 + kBitBackWords)) *
            sizeof(unsigned int);
 }
 size_t scan_lds_bytes(uint32_t n_lds_bins, bool ref_in_lds, uint32_t total_cells) {
@@ -982,6 +1023,7 @@ uint32_t scan_grid(uint64_t n_records, int n_cus) {
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)n_cus));
 }
 // records one launch may take so that no workgroup sees more than kMaxRecordsPerGroup of them
+size_t scan_gring_entries(uint32_t grid) { return (size_t)grid * kScanWaves * kGRing; }   // uint4 each
 uint64_t scan_max_records(uint32_t grid) { return (uint64_t)grid * (kMaxRecordsPerGroup - kScanBlock - 64); }
 
 hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t stream) {

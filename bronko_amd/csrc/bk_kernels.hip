@@ -251,7 +251,8 @@ constexpr int kScanBlock = 1024;
 constexpr int kScanWaves = kScanBlock / 64;
 constexpr int kQueueCap = 96;               // slow-path queue: a batch starts at 32 pending, a step adds <= 64
 constexpr int kRangeCap = 128;              // N queue: a batch starts at 64 pending, a round adds <= 64
-constexpr uint32_t kGRing = 128;            // Level-2 ring (global memory, per wave): a batch starts at 64 pending, an N batch adds <= 64
+constexpr int kNIters = 8;                  // mismatches of a piece the N batch resolves in one pass
+constexpr uint32_t kGRing = 1024;           // Level-2 ring (global memory, per wave): a batch starts at 64 pending, an N batch adds <= 64 * (kNIters + 1)
 constexpr uint32_t kMaxRecordsPerGroup = 16384;
 constexpr uint32_t kSlowLdsQuota = 2048;    // per wave and launch: slow-path E hits that may use the LDS array
 constexpr int kSeeds = 4;
@@ -743,9 +744,13 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
             }
             if (qs >= 64u || (flush && (fin ? qs != 0u : olds != 0u))) {
                 // ================= N batch: one queued piece of an N run per lane (qg < 64 here) ====================
-                // The piece's n <= 65 - k k-mers lie in 64 read bases.  With one mismatch in them the piece is one S run; with
-                // two (t1 < t2) it is the k-mers that hold only t1 (an S run), both (a G chunk), only t2 (an S run).  An S run
-                // needs clean cells with consecutive ids.  Anything else goes to Level 2 chunk by chunk.
+                // The piece's n <= 65 - k k-mers lie in 64 read bases.  Its leading k-mers whose cells are clean and continue one
+                // id sequence are resolved here, mismatch by mismatch (t_1 < t_2 < ...): the k-mers that hold only t_i are an S
+                // run (two atomics); those that hold t_i and t_i+1 go to Level 2 as a chunk -- unless they hold exactly these two
+                // and every one of their cells has no other reference k-mer form within Hamming distance 3: then they are
+                // neither reference k-mers nor one base away from one and touch nothing (full_kmer_stats: the statistics table
+                // still wants them).  K-mers without a mismatch (a read off the LDS window), at dirty cells or without a diagonal
+                // go to Level 2 as a chunk; what is left of the piece comes back here.
                 const uint32_t nb2 = min(qs, 64u);
                 const uint32_t ent = (uint32_t)lane < nb2 ? rqs[lane] : 0u;
                 {   // move the rest of the queue down
@@ -768,95 +773,118 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 const uint32_t r_c = (uint32_t)__shfl((int)r32, src), r_p = (uint32_t)__shfl((int)pr32, src);
                 const int32_t dg2 = cur ? dg_c : dg_p;
                 const uint32_t fl2 = cur ? fl_c : fl_p;
+                const uint32_t rec2 = cur ? r_c : r_p;
                 const bool fwd2 = fl2 & 1u;
                 const bool an = have && (fl2 & 2u) && n2 + km1 <= 64u;   // analysable: a diagonal, and 64 bases hold it
-                const uint32_t* __restrict__ w2 = words0 + (uint64_t)(have ? (cur ? r_c : r_p) : 0u) * a.stride_words;
+                const uint32_t* __restrict__ w2 = words0 + (uint64_t)(have ? rec2 : 0u) * a.stride_words;
                 const int32_t c_first = an ? (fwd2 ? dg2 + (int32_t)s_first : dg2 - (int32_t)s_first) : 0;
+                const uint32_t ddir = fwd2 ? 1u : 0xffffffffu;
                 const uint64_t ga = read_symbols_at(w2, s_first, last_word), gb = read_symbols_at(w2, s_first + 32u, last_word);
-                uint64_t fa, fb;   // mismatch flags of read bases s_first + [0, 32) and + [32, 64), at the even bits
+                const uint32_t id_first = a.id_at[c_first];
+                // how many leading k-mers sit at clean cells that continue one id sequence (the first needs no follow bit)
+                int n1;          // ... that many; 0: the first cell is dirty
+                int head = 0;    // leading k-mers that go to Level 2 as one chunk
+                {
+                    const uint64_t y_lo = fwd2 ? symbols_at(yfw, c_first) : rev2_64(symbols_at(yrw, c_first - 31));      // symbol j: cell of k-mer j
+                    const uint64_t y_hi = fwd2 ? symbols_at(yfw, c_first + 32) : rev2_64(symbols_at(yrw, c_first - 63));
+                    const uint64_t e5 = 0x5555555555555555ull;
+                    const uint64_t bad_lo = ~(y_lo & ((y_lo >> 1) | 1ull)) & e5, bad_hi = ~(y_hi & (y_hi >> 1)) & e5;
+                    const int good_len = bad_lo ? (__builtin_ctzll(bad_lo) >> 1) : 32 + (bad_hi ? (__builtin_ctzll(bad_hi) >> 1) : 32);
+                    const uint64_t cl_lo = y_lo & e5, cl_hi = y_hi & e5;
+                    const int dirty_len = cl_lo ? (__builtin_ctzll(cl_lo) >> 1) : 32 + (cl_hi ? (__builtin_ctzll(cl_hi) >> 1) : 32);
+                    n1 = an ? min(good_len, (int)n2) : 0;
+                    if (n1 == 0) head = an ? min(dirty_len, (int)n2) : (int)n2;
+                }
+                uint64_t F;   // mismatch flags of the read bases s_first + [0, 64) the first n1 k-mers cover
                 {
                     // read base s_first + t <-> reference base c_first + t (fwd) / complement of base c_first + k - 1 - t
                     const uint64_t ra = fwd2 ? symbols_at(refw, c_first) : ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 31));
                     const uint64_t rb = fwd2 ? symbols_at(refw, c_first + 32) : ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 63));
                     const uint64_t da = ga ^ ra, db = gb ^ rb;
-                    const uint32_t L = an ? n2 + km1 : 0u;   // bases the piece covers
-                    const uint64_t ma = L >= 32u ? ~0ull : (1ull << (2u * L)) - 1ull;
-                    const uint64_t mb = L >= 64u ? ~0ull : L > 32u ? (1ull << (2u * (L - 32u))) - 1ull : 0ull;
-                    fa = (da | (da >> 1)) & 0x5555555555555555ull & ma;
-                    fb = (db | (db >> 1)) & 0x5555555555555555ull & mb;
+                    const uint32_t f_lo = even_bits((uint32_t)(da | (da >> 1))) | (even_bits((uint32_t)((da | (da >> 1)) >> 32)) << 16);
+                    const uint32_t f_hi = even_bits((uint32_t)(db | (db >> 1))) | (even_bits((uint32_t)((db | (db >> 1)) >> 32)) << 16);
+                    const uint32_t L = n1 ? (uint32_t)n1 + km1 : 0u;   // bases they cover
+                    F = (((uint64_t)f_hi << 32) | f_lo) & (L >= 64u ? ~0ull : (1ull << L) - 1ull);
                 }
-                const int m = __popcll(fa) + __popcll(fb);
-                const int t1 = fa ? (__builtin_ctzll(fa) >> 1) : fb ? 32 + (__builtin_ctzll(fb) >> 1) : 0;
-                const uint64_t fa2 = fa & (fa - 1ull), fb2 = fa ? fb : fb & (fb - 1ull);
-                const int t2 = fa2 ? (__builtin_ctzll(fa2) >> 1) : fb2 ? 32 + (__builtin_ctzll(fb2) >> 1) : 0;
-                // k-mer j of the piece holds base t iff t - (k-1) <= j <= t
-                const int kk = (int)km1, nn = (int)n2;
-                int jA = max(0, t1 - kk), a_hi = min(t1, nn - 1);
-                int jB = 0, nB = 0, jC = 0, nC = 0;
-                if (m == 2) {
-                    a_hi = min(a_hi, t2 - k);
-                    jB = max(0, t2 - kk); nB = max(0, min(t1, nn - 1) - jB + 1);
-                    jC = max(t1 + 1, t2 - kk); nC = max(0, min(t2, nn - 1) - jC + 1);
+                const int kk = (int)km1;
+                int cutn = n1;   // k-mers [0, cutn) of the piece are resolved in this pass
+                uint64_t c3 = 0;   // bit j: the cell of k-mer j has no other reference k-mer form within Hamming distance 3
+                if (!STATS) c3 = fwd2 ? ((uint64_t)bits32_at(c3w, c_first + 32) << 32) | bits32_at(c3w, c_first)
+                                      : ((uint64_t)__builtin_bitreverse32(bits32_at(c3w, c_first - 63)) << 32) | __builtin_bitreverse32(bits32_at(c3w, c_first - 31));
+                if (n1) {
+                    const int t1 = F ? __builtin_ctzll(F) : 1000;
+                    if (t1 > kk) { head = min(t1 - kk, n1); cutn = 0; F = 0ull; }   // leading k-mers without a mismatch
                 }
-                const int nA = max(0, a_hi - jA + 1);
-                const bool shaped = an && (m == 1 || m == 2) && nA + nB + nC == nn;   // no k-mer of the piece is left over
-                // an S run of nS k-mers from k-mer j0 of the piece on: its cells must be clean and continue one id sequence
-                auto check = [&](int j0, int nS, uint32_t& idS) -> bool {
-                    const bool on = shaped && nS > 0;
-                    const int32_t cS = on ? (fwd2 ? c_first + j0 : c_first - j0) : 0;
-                    const uint32_t nm1 = on ? (uint32_t)nS - 1u : 0u;
-                    idS = a.id_at[cS];
-                    const uint64_t ys = fwd2 ? symbols_at(yfw, cS) : symbols_at(yrw, cS - (int32_t)nm1);   // cells in rising order
-                    const uint64_t cm = 0x5555555555555555ull >> (62u - 2u * nm1);
-                    const uint64_t f0 = nm1 ? 0xaaaaaaaaaaaaaaaaull >> (64u - 2u * nm1) : 0ull;
-                    const uint64_t need = cm | (fwd2 ? f0 << 2 : f0);   // follow bits: of every cell but the run's first
-                    return on && idS != 0xffffffffu && (ys & need) == need;
-                };
-                auto emit = [&](int j0, int nS, int t, uint32_t idS) {
-                    const uint32_t tpos = (uint32_t)(t - j0);    // offset of the differing base in the run's first k-mer
-                    const uint32_t br = (uint32_t)((t < 32 ? ga : gb) >> (2u * ((uint32_t)t & 31u))) & 3u;
-                    const uint32_t nm1 = (uint32_t)nS - 1u;
-                    // offsets (along the reference, from each k-mer's start) the run's k-mers have the difference at
-                    const uint32_t o_first = fwd2 ? tpos : km1 - tpos;
-                    const uint32_t o_lo = fwd2 ? tpos - nm1 : o_first;       // fwd: later k-mers start later, the offset shrinks
-                    const uint32_t o_hi = fwd2 ? tpos : o_first + nm1;
-                    const int lo2 = max((int)o_lo, omin), hi2 = min((int)o_hi, omin + span - 1);
-                    if (lo2 <= hi2 && a.ablate != 2) {
-                        unsigned long long* row = v_counters + v_row_base(idS + o_first - (uint32_t)omin, fwd2 ? br : 3u - br, fwd2 ? 0u : 1u, span);
-                        atomicAdd(row + (lo2 - omin), 1ull);
-                        if (hi2 - omin + 1 < span) atomicAdd(row + (hi2 - omin + 1), ~0ull);   // (slot `span` is never read)
+                head = min(head, (int)chunk);
+                // ---- the head chunk ----
+                {
+                    const bool pushg = have && head > 0;
+                    const unsigned long long bm = __ballot(pushg);
+                    if (bm) {
+                        if (pushg) gq[(gh + qg + lane_prefix(bm)) & (kGRing - 1u)] = make_uint4(rec2, (uint32_t)dg2, s_first | ((uint32_t)head << 16) | (fl2 << 24), 0u);
+                        qg += (uint32_t)__popcll(bm);
                     }
-                };
-                uint32_t idA, idC;
-                const bool okA = check(jA, nA, idA), okC = check(jC, nC, idC);
-                const bool good = shaped && (nA == 0 || okA) && (nC == 0 || okC);
-                if (good && nA) emit(jA, nA, t1, idA);
-                if (good && nC) emit(jC, nC, t2, idC);
-                // to Level 2: the k-mers that hold both mismatches -- unless every one of their cells has no other reference k-mer
-                // form within Hamming distance 3: then they are neither reference k-mers nor one base away from one and touch
-                // nothing (full_kmer_stats: the statistics table still wants them); of a piece that is not of this shape, the first
-                // chunk (the rest comes back here)
-                bool b_dead = false;
-                if (!STATS) {
-                    const int32_t cB = good && nB ? (fwd2 ? c_first + jB : c_first - jB - (nB - 1)) : 0;
-                    const uint32_t need = nB ? 0xffffffffu >> (32 - nB) : 0u;
-                    b_dead = (bits32_at(c3w, cB) & need) == need;
+                    if (pushg) cutn = head;
                 }
-                const uint32_t take = min(n2, chunk);
-                const bool pushg = have && (good ? nB != 0 && !b_dead : true);
-                const bool requeue = have && !good && n2 > take;
-                const unsigned long long bm = __ballot(pushg);
-                if (bm) {
-                    if (pushg) {
-                        const uint32_t sf = good ? s_first + (uint32_t)jB : s_first, ng = good ? (uint32_t)nB : take;
-                        gq[(gh + qg + lane_prefix(bm)) & (kGRing - 1u)] = make_uint4(cur ? r_c : r_p, (uint32_t)dg2, sf | (ng << 16) | (fl2 << 24), 0u);
+                // ---- mismatch by mismatch ----
+                int tprev = -1000, gprev = -1;   // the previous mismatch; the last k-mer already sent to Level 2
+                for (int it = 0; it < kNIters; ++it) {
+                    const bool act = F != 0ull;
+                    if (!__ballot(act)) break;
+                    const int ti = act ? __builtin_ctzll(F) : 0;
+                    F &= F - 1ull;
+                    int tn = F ? __builtin_ctzll(F) : 1000;
+                    const uint64_t F2 = F & (F - 1ull);
+                    const int tn2 = F2 ? __builtin_ctzll(F2) : 1000;
+                    if (act && (tn - ti > k || it == kNIters - 1)) {
+                        // k-mers without a mismatch follow (or the piece has more mismatches than passes): the piece is cut
+                        // after the last k-mer that holds t_i
+                        cutn = min(cutn, ti + 1);
+                        F = 0ull;
+                        if (tn - ti > k) tn = 1000;
                     }
-                    qg += (uint32_t)__popcll(bm);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    // S run: the k-mers that hold t_i and nothing else
+                    const int s_lo = max(max(ti - kk, tprev + 1), 0), s_hi = min(min(ti, tn - k), cutn - 1);
+                    if (act && s_hi >= s_lo) {
+                        const uint32_t tpos = (uint32_t)(ti - s_lo);    // offset of the differing base in the run's first k-mer
+                        const uint32_t br = (uint32_t)((ti < 32 ? ga : gb) >> (2u * ((uint32_t)ti & 31u))) & 3u;
+                        const uint32_t nm1 = (uint32_t)(s_hi - s_lo);
+                        // offsets (along the reference, from each k-mer's start) the run's k-mers have the difference at
+                        const uint32_t o_first = fwd2 ? tpos : km1 - tpos;
+                        const uint32_t o_lo = fwd2 ? tpos - nm1 : o_first;       // fwd: later k-mers start later, the offset shrinks
+                        const uint32_t o_hi = fwd2 ? tpos : o_first + nm1;
+                        const int lo2 = max((int)o_lo, omin), hi2 = min((int)o_hi, omin + span - 1);
+                        if (lo2 <= hi2 && a.ablate != 2) {
+                            const uint32_t idS = id_first + ddir * (uint32_t)s_lo;
+                            unsigned long long* row = v_counters + v_row_base(idS + o_first - (uint32_t)omin, fwd2 ? br : 3u - br, fwd2 ? 0u : 1u, span);
+                            atomicAdd(row + (lo2 - omin), 1ull);
+                            if (hi2 - omin + 1 < span) atomicAdd(row + (hi2 - omin + 1), ~0ull);   // (slot `span` is never read)
+                        }
+                    }
+                    // the k-mers that hold t_i and t_i+1 (those that also hold t_i-1 went with the previous pair)
+                    const int g_lo = max(max(tn - kk, gprev + 1), 0), g_hi = min(ti, cutn - 1);
+                    const bool pair = act && tn - ti <= kk && g_hi >= g_lo;
+                    bool dead = false;
+                    if (!STATS) {
+                        const uint32_t need = pair ? 0xffffffffu >> (31 - (g_hi - g_lo)) : 0u;
+                        dead = tn2 - kk > g_hi && ((uint32_t)(c3 >> (pair ? g_lo : 0)) & need) == need;   // none of them reaches t_i+2
+                    }
+                    const bool pushg = pair && !dead;
+                    const unsigned long long bm = __ballot(pushg);
+                    if (bm) {
+                        if (pushg) gq[(gh + qg + lane_prefix(bm)) & (kGRing - 1u)] =
+                            make_uint4(rec2, (uint32_t)dg2, (s_first + (uint32_t)g_lo) | ((uint32_t)(g_hi - g_lo + 1) << 16) | (fl2 << 24), 0u);
+                        qg += (uint32_t)__popcll(bm);
+                    }
+                    if (pair) gprev = g_hi;
+                    tprev = ti;
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                // ---- what is left of the piece comes back ----
+                const bool requeue = have && (uint32_t)cutn < n2;
                 const unsigned long long rm = __ballot(requeue);
                 if (rm) {
-                    if (requeue) rqs[qs + lane_prefix(rm)] = (uint32_t)src | (ent & 0x80000000u) | ((s_first + take) << 6) | ((n2 - take) << 22);
+                    if (requeue) rqs[qs + lane_prefix(rm)] = (uint32_t)src | (ent & 0x80000000u) | ((s_first + (uint32_t)cutn) << 6) | ((n2 - (uint32_t)cutn) << 22);
                     qs += (uint32_t)__popcll(rm);
                     olds += (uint32_t)__popcll(__ballot(requeue && !cur));
                 }

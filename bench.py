@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--allreduce", action="store_true", help="N > 1: all-reduce the counter plane instead of reduce-scatter + sharded finalize")
     ap.add_argument("--ref-len", type=int, default=0, help="experiment: truncate the reference to its first N bases")
     ap.add_argument("--wide", action="store_true", help="N > 1: move the counter plane as 64-bit integers even when 32 bits would do")
+    ap.add_argument("--in-flight", type=int, default=2, help="samples in flight per GPU: steps alternate over this many engines "
+                    "(bk_engine_fork: shared index tables, own counter planes / outputs / stream), so that a sample's scan overlaps "
+                    "the previous sample's finalize; 1 = strictly one sample after the other")
     ap.add_argument("--backend", default="nccl", help="testing aid: 'gloo' lets several ranks share one GPU (rank r uses GPU r mod #GPUs)")
     args = ap.parse_args()
 
@@ -92,31 +95,37 @@ def main():
     d_lens = torch.from_numpy(lens.view(np.int16)).to(dev)
     n_rec = len(lens)
 
-    # one explicit (non-default) stream for the engine AND for every torch / torch.distributed operation on its buffers: the
-    # collectives are ordered against the kernels by the stream.  (The default stream's handle is 0, which
-    # bk_engine_set_stream reads as "use your own stream" -- that would leave the collectives unordered.)
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    eng.set_stream(stream.cuda_stream)
-    counters = torch.as_tensor(_DevArray(eng.counters_ptr(0), eng.counter_len, "<i8"), device=dev)
+    # Samples are independent (call.rs:212 handles them one after the other), so `--in-flight` engines take the steps in turn.
+    # Each engine launches on its own HIP stream (created with the engine); torch sees it as an ExternalStream and every
+    # torch / torch.distributed operation on the engine's buffers is enqueued on it: the collectives are ordered against the
+    # kernels by the stream.  (torch's pool streams are not used: on this ROCm two of them may share a hardware queue, and then
+    # nothing overlaps.)
+    n_fly = max(1, args.in_flight)
+    engs = [eng] + [eng.fork() for _ in range(n_fly - 1)]
+    streams = [torch.cuda.ExternalStream(e.stream_ptr(), device=dev) for e in engs]
+    torch.cuda.set_stream(streams[0])
+    counters = [torch.as_tensor(_DevArray(e.counters_ptr(0), e.counter_len, "<i8"), device=dev) for e in engs]
 
     # N > 1: reduce-scatter of the counter plane + each rank maps its part + max / sum of the small pileups (the cheap form,
     # include/bronko_hip.h); --allreduce selects the plain form (all-reduce the plane, every rank maps everything)
     sharded = world > 1 and not args.allreduce and 64 % world == 0
     # (the plane travels as 32-bit integers when no k-mer of the whole sample can occur 2^31 times)
     narrow = world * args.reads * max(args.read_len - k + 1, 1) < 2 ** 31 and not args.wide
-    shard_fin = ShardedFinalize(eng, 1, rank, world, dev, narrow=narrow) if sharded else None
+    shard_fin = [ShardedFinalize(e, 1, rank, world, dev, narrow=narrow) for e in engs] if sharded else None
 
-    def step():
-        eng.sample_begin()
-        eng.push_reads_device(0, d_words.data_ptr(), stride, d_lens.data_ptr(), n_rec)
-        if sharded:
-            shard_fin()   # RCCL over xGMI: reduce-scatter(sum) + 3 small all-reduces
-            return
-        if world > 1:
-            eng.counters_ptr(0)            # (same pointer every step; a plane nothing was pushed to is zeroed by this call)
-            allreduce_counters(counters)   # RCCL over xGMI: ONE all-reduce(sum) of the u64 k-mer occurrence counters
-        eng.sample_finalize(1)
+    def step(i):
+        j = i % len(engs)
+        e = engs[j]
+        with torch.cuda.stream(streams[j]):
+            e.sample_begin()
+            e.push_reads_device(0, d_words.data_ptr(), stride, d_lens.data_ptr(), n_rec)
+            if sharded:
+                shard_fin[j]()   # RCCL over xGMI: reduce-scatter(sum) + 3 small all-reduces
+                return
+            if world > 1:
+                e.counters_ptr(0)                 # (same pointer every step; a plane nothing was pushed to is zeroed by this call)
+                allreduce_counters(counters[j])   # RCCL over xGMI: ONE all-reduce(sum) of the u64 k-mer occurrence counters
+            e.sample_finalize(1)
 
     def fence():
         torch.cuda.synchronize()
@@ -124,33 +133,57 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    def timing(kind):
+        for e in engs:
+            e.timing_enable(kind)
+
+    def timing_read():
+        tot_ms, tot_n = None, None
+        for e in engs:
+            ms, n = e.timing_read(reset=True)
+            tot_ms = list(ms) if tot_ms is None else [a + b for a, b in zip(tot_ms, ms)]
+            tot_n = list(n) if tot_n is None else [a + b for a, b in zip(tot_n, n)]
+        return tot_ms, tot_n
+
+    for i in range(args.warmup):
+        step(i)
     fence()
     # timed region: only the dominant kernel is bracketed by HIP events (on its launch stream) -- bracketing every launch
     # costs ~10 event records per sample; the other kernels' averages come from a short extra pass after the timed region
-    eng.timing_enable(2)
-    eng.timing_read(reset=True)
+    timing(2)
+    timing_read()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
     fence()
     dt = time.perf_counter() - t0
-    kms, kn = eng.timing_read(reset=True)
-    eng.timing_enable(1)
-    for _ in range(max(2, min(5, args.steps))):
-        step()
+    kms, kn = timing_read()
+    timing(1)
+    for i in range(max(2, min(6, args.steps))):
+        step(i)
     fence()
-    kms_all, kn_all = eng.timing_read(reset=True)
-    eng.timing_enable(0)
+    kms_all, kn_all = timing_read()
+    timing(0)
     kms = [kms[0]] + list(kms_all[1:])
     kn = [kn[0]] + list(kn_all[1:])
+    # for reference: the same steps strictly one after the other on one engine (what a single sample's turnaround looks like)
+    n_serial = max(2, min(10, args.steps))
+    saved = engs
+    engs = engs[:1]
+    step(0)
+    fence()
+    ts0 = time.perf_counter()
+    for i in range(n_serial):
+        step(i)
+    fence()
+    serial_ms = (time.perf_counter() - ts0) / n_serial * 1e3
+    engs = saved
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    res = eng.sample_download(1, arrays=False)   # sanity only: the step really produced a pileup
+    res = engs[(args.steps - 1) % len(engs)].sample_download(1, arrays=False)   # sanity only: the last timed step really produced a pileup
     total_reads = args.reads * world * args.steps
     value = total_reads / dt
 
@@ -177,6 +210,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
+        "serial_ms_per_step": serial_ms,   # one sample at a time on one engine (not the headline: see config.samples_in_flight)
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -185,7 +219,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: SARS-CoV-2 single ref (wuhan_ref, 29903 bp), k=21, n_fixed=2, "
                                "%d synthetic %d bp single-end reads per GPU per step, 0.5%% substitution errors, seed 2"
                                % (args.reads, args.read_len),
-                   "reads_per_gpu": args.reads, "read_len": args.read_len, "k": k,
+                   "reads_per_gpu": args.reads, "read_len": args.read_len, "k": k, "samples_in_flight": len(engs),
                    "parallelism": ("reads sharded over %d GPU(s); RCCL reduce-scatter(sum) of the k-mer counter plane" + (" as int32" if narrow else "") + ", sharded finalize, "
                                    "all-reduce(max / sum) of the pileups" if sharded else
                                    "reads sharded over %d GPU(s); RCCL all-reduce(sum) of k-mer counters") % world
@@ -227,7 +261,8 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
-    eng.close()
+    for e in reversed(engs):
+        e.close()
 
 
 if __name__ == "__main__":

@@ -24,7 +24,7 @@ class Params(C.Structure):
 
 
 # every symbol include/bronko_hip.h declares (checked by tests/test_abi.py)
-SYMBOLS = ["bk_abi_version", "bk_last_error", "bk_params_default", "bk_engine_create", "bk_engine_destroy",
+SYMBOLS = ["bk_abi_version", "bk_last_error", "bk_params_default", "bk_engine_create", "bk_engine_destroy", "bk_engine_fork", "bk_engine_get_stream",
            "bk_engine_set_stream", "bk_total_cells", "bk_n_files", "bk_n_slots", "bk_counter_len", "bk_sample_begin",
            "bk_push_reads_packed", "bk_push_reads_packed_device", "bk_push_reads_ascii", "bk_counters_device_ptr", "bk_sample_finalize",
            "bk_sample_finalize_shard", "bk_shard_sums_device_ptr", "bk_sample_merge_shards",
@@ -49,6 +49,10 @@ def load():
     L.bk_engine_create.restype = C.c_int
     L.bk_engine_create.argtypes = [C.POINTER(IndexDesc), C.POINTER(Params), C.POINTER(vp)]
     L.bk_engine_destroy.argtypes = [vp]
+    L.bk_engine_get_stream.restype = vp
+    L.bk_engine_get_stream.argtypes = [vp]
+    L.bk_engine_fork.restype = C.c_int
+    L.bk_engine_fork.argtypes = [vp, C.POINTER(vp)]
     L.bk_engine_set_stream.restype = C.c_int
     L.bk_engine_set_stream.argtypes = [vp, vp]
     for n, rt in (("bk_total_cells", u64), ("bk_n_files", i32), ("bk_n_slots", u64), ("bk_counter_len", u64)):

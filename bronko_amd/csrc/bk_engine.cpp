@@ -46,9 +46,12 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool owned = true;
+    ~DevBuf() { if (p && owned) (void)hipFree(p); }
+    void alias(const DevBuf& o) { if (p && owned) (void)hipFree(p); p = o.p; n = o.n; owned = false; }   // a view of another engine's table
     hipError_t alloc(size_t count) {
-        if (p) { (void)hipFree(p); p = nullptr; }
+        if (p && owned) (void)hipFree(p);
+        p = nullptr; owned = true;
         n = count;
         return hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
     }
@@ -292,6 +295,37 @@ struct bk_engine {
         }
     };
 };
+
+// everything a sample writes (counter planes, scan scratch, outputs) and the engine's stream: per engine, never shared by forks
+static int alloc_sample_state(bk_engine* e) {
+    const bk_params* prm = &e->params;
+    for (int m = 0; m < 2; m++) BK_HIP(e->counters[m].alloc(e->plane_len));
+    BK_HIP(e->shard_sums.alloc((size_t)2 * e->n_files * 5 + 8));
+    if (prm->full_kmer_stats) {
+        if (prm->kmer_table_log2 < 10 || prm->kmer_table_log2 > 31) return fail(BK_ERR_INVALID, "kmer_table_log2 out of range");
+        BK_HIP(e->ktab_keys.alloc((size_t)1 << prm->kmer_table_log2));
+        BK_HIP(e->ktab_cnt.alloc((size_t)1 << prm->kmer_table_log2));
+    }
+    BK_HIP(e->ktab_out.alloc(8));
+    if (e->n_files <= 64) BK_HIP(e->fin_partials.alloc(bk::finalize_partial_rows() * ((size_t)e->n_files * 3 + 2)));
+    BK_HIP(e->deferred.alloc(bk::v_plane_len(e->n_full, e->v_span, e->n_prows)));
+    BK_HIP(e->n_deferred.alloc(2));   // one per mate file
+    if (e->n_lds_bins >= e->total_cells) e->use_xcd_planes = false;   // every cell has an LDS bin
+    if (e->use_xcd_planes) {
+        BK_HIP(e->e_planes.alloc((size_t)bk::kXcdPlanes * bk::e_plane_len(e->n_u)));
+        BK_HIP(hipMemset(e->e_planes.p, 0, e->e_planes.n * sizeof(unsigned int)));
+    }
+    BK_HIP(e->pileup.alloc(e->total_cells * 4 * 4));
+    BK_HIP(e->stats.alloc((size_t)2 * e->n_files * 3));
+    BK_HIP(e->present.alloc((size_t)2 * e->n_files));
+    BK_HIP(e->kstats.alloc(8));
+    BK_HIP(e->slabs.alloc((size_t)e->n_cus * std::max<uint32_t>(e->n_lds_bins, 1)));
+    BK_HIP(e->gring.alloc(bk::scan_gring_entries((uint32_t)e->n_cus)));
+    if (e->n_files > 1) BK_HIP(e->win_votes.alloc((size_t)e->n_files));
+    BK_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    e->stream = e->own_stream;
+    return BK_OK;
+}
 
 extern "C" {
 
@@ -724,7 +758,6 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 }
             }
             BK_HIP(e->occ.upload(h_occ));
-            BK_HIP(e->win_votes.alloc((size_t)ix->n_files));
         }
         {
             std::vector<uint8_t> h_amb2(h_amb);
@@ -839,8 +872,6 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         }
         e->n_lds_bins = (uint32_t)nb;
         if (const char* nl = getenv("BK_LDS_BINS")) e->n_lds_bins = std::min<uint32_t>(e->n_lds_bins, (uint32_t)atol(nl));
-        BK_HIP(e->slabs.alloc((size_t)e->n_cus * std::max<uint32_t>(e->n_lds_bins, 1)));
-        BK_HIP(e->gring.alloc(bk::scan_gring_entries((uint32_t)e->n_cus)));
     }
     pc.lap("estat + LDS policy");
     if (const char* nx = getenv("BK_NO_XCD_PLANES")) e->use_xcd_planes = atoi(nx) == 0;
@@ -851,32 +882,37 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     BK_HIP(e->ent_off.upload(h_off));
     BK_HIP(e->ent_len.upload(h_len));
     BK_HIP(e->entries.upload(h_ent));
-    for (int m = 0; m < 2; m++) BK_HIP(e->counters[m].alloc(e->plane_len));
-    BK_HIP(e->shard_sums.alloc((size_t)2 * e->n_files * 5 + 8));
-    if (prm->full_kmer_stats) {
-        if (prm->kmer_table_log2 < 10 || prm->kmer_table_log2 > 31) return fail(BK_ERR_INVALID, "kmer_table_log2 out of range");
-        BK_HIP(e->ktab_keys.alloc((size_t)1 << prm->kmer_table_log2));
-        BK_HIP(e->ktab_cnt.alloc((size_t)1 << prm->kmer_table_log2));
-    }
-    BK_HIP(e->ktab_out.alloc(8));
-    if (e->n_files <= 64) BK_HIP(e->fin_partials.alloc(bk::finalize_partial_rows() * ((size_t)e->n_files * 3 + 2)));
-    BK_HIP(e->deferred.alloc(bk::v_plane_len(e->n_full, e->v_span, e->n_prows)));
-    BK_HIP(e->n_deferred.alloc(2));   // one per mate file
-    if (e->n_lds_bins >= e->total_cells) e->use_xcd_planes = false;   // every cell has an LDS bin
-    if (e->use_xcd_planes) {
-        BK_HIP(e->e_planes.alloc((size_t)bk::kXcdPlanes * bk::e_plane_len(e->n_u)));
-        BK_HIP(hipMemset(e->e_planes.p, 0, e->e_planes.n * sizeof(unsigned int)));
-    }
-    BK_HIP(e->pileup.alloc(e->total_cells * 4 * 4));
-    BK_HIP(e->stats.alloc((size_t)2 * e->n_files * 3));
-    BK_HIP(e->present.alloc((size_t)2 * e->n_files));
-    BK_HIP(e->kstats.alloc(8));
+    if (int rc = alloc_sample_state(e.get())) return rc;
     BK_HIP(e->d_view.upload(std::vector<bk::IndexView>(1, e->view())));
-    BK_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
-    e->stream = e->own_stream;
     if (const char* ab = getenv("BK_SCAN_ABLATE")) e->ablate = atoi(ab);
     if (const char* ml = getenv("BK_MAX_LAUNCH_RECORDS")) e->max_launch_records = strtoull(ml, nullptr, 10);
     pc.lap("uploads + buffers");
+    *out = e.release();
+    return BK_OK;
+}
+
+int bk_engine_fork(const bk_engine* parent, bk_engine** out) {
+    if (!parent || !out) return fail(BK_ERR_INVALID, "null argument");
+    BK_HIP(hipSetDevice(parent->device));
+    std::unique_ptr<bk_engine> e(new bk_engine());
+    const bk_engine* p = parent;
+    e->params = p->params; e->k = p->k; e->wstart = p->wstart; e->W = p->W; e->n_files = p->n_files;
+    e->total_cells = p->total_cells; e->n_slots = p->n_slots; e->log2s = p->log2s; e->log2nb = p->log2nb; e->m = p->m;
+    e->n_u = p->n_u; e->n_full = p->n_full; e->n_lds_bins = p->n_lds_bins; e->n_prows = p->n_prows;
+    e->v_omin = p->v_omin; e->v_span = p->v_span; e->v_off = p->v_off; e->plane_len = p->plane_len;
+    e->ref_in_lds = p->ref_in_lds; e->lo_bases = p->lo_bases; e->n_cus = p->n_cus; e->device = p->device;
+    e->use_xcd_planes = p->use_xcd_planes; e->file_cell_lo = p->file_cell_lo; e->ablate = p->ablate; e->max_launch_records = p->max_launch_records;
+    e->half_lo.m = p->half_lo.m; e->half_lo.log2nb = p->half_lo.log2nb; e->half_hi.m = p->half_hi.m; e->half_hi.log2nb = p->half_hi.log2nb;
+    // the index tables are immutable after bk_engine_create: the fork reads the parent's
+    e->prow_id.alias(p->prow_id); e->prow_t.alias(p->prow_t); e->kmer_pos.alias(p->kmer_pos); e->d_view.alias(p->d_view); e->kmer_of.alias(p->kmer_of);
+    e->ref_words.alias(p->ref_words); e->cell_codes.alias(p->cell_codes); e->cell_has.alias(p->cell_has); e->cell_clean.alias(p->cell_clean);
+    e->cell_clean3.alias(p->cell_clean3); e->cell_yf.alias(p->cell_yf); e->cell_yr.alias(p->cell_yr); e->id_at.alias(p->id_at);
+    e->half_lo.pilots.alias(p->half_lo.pilots); e->half_lo.dir.alias(p->half_lo.dir); e->half_lo.cand.alias(p->half_lo.cand);
+    e->half_hi.pilots.alias(p->half_hi.pilots); e->half_hi.dir.alias(p->half_hi.dir); e->half_hi.cand.alias(p->half_hi.cand);
+    e->slot_of.alias(p->slot_of); e->estat_off.alias(p->estat_off); e->estat.alias(p->estat); e->slot_rec.alias(p->slot_rec); e->amb.alias(p->amb);
+    e->pilots.alias(p->pilots); e->table.alias(p->table); e->ent_off.alias(p->ent_off); e->ent_len.alias(p->ent_len); e->entries.alias(p->entries);
+    e->occ.alias(p->occ);
+    if (int rc = alloc_sample_state(e.get())) return rc;
     *out = e.release();
     return BK_OK;
 }
@@ -904,6 +940,8 @@ int bk_engine_set_stream(bk_engine* e, void* hip_stream) {
     e->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : e->own_stream;
     return BK_OK;
 }
+
+void* bk_engine_get_stream(const bk_engine* e) { return e ? reinterpret_cast<void*>(e->stream) : nullptr; }
 
 uint64_t bk_total_cells(const bk_engine* e) { return e ? e->total_cells : 0; }
 int32_t bk_n_files(const bk_engine* e) { return e ? e->n_files : 0; }

@@ -111,6 +111,17 @@ class Engine:
         self.n_slots = L.bk_n_slots(h)
         self.counter_len = L.bk_counter_len(h)
 
+    def fork(self):
+        """A second engine on the same device tables with its own counter planes, outputs and stream (bk_engine_fork):
+        alternate independent samples over the two so that one's scan overlaps the other's finalize."""
+        h = C.c_void_p()
+        _check(self._L.bk_engine_fork(self.h, C.byref(h)))
+        e = object.__new__(Engine)
+        e._L, e.h, e.k, e.params = self._L, h, self.k, self.params
+        e.n_files, e.total_cells, e.n_slots, e.counter_len = self.n_files, self.total_cells, self.n_slots, self.counter_len
+        e._parent = self   # the parent's tables must outlive the fork
+        return e
+
     def close(self):
         if self.h:
             self._L.bk_engine_destroy(self.h)
@@ -124,6 +135,10 @@ class Engine:
 
     def set_stream(self, stream_ptr):
         _check(self._L.bk_engine_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def stream_ptr(self):
+        """hipStream_t (as int) the engine launches on -- wrap it (torch.cuda.ExternalStream) to order other work with it."""
+        return int(self._L.bk_engine_get_stream(self.h) or 0)
 
     def sample_begin(self):
         _check(self._L.bk_sample_begin(self.h))

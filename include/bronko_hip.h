@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BK_ABI_VERSION 3
+#define BK_ABI_VERSION 4
 
 typedef enum {
     BK_OK = 0,
@@ -95,10 +95,21 @@ void        bk_params_default(bk_params* p);
 int  bk_engine_create(const bk_index_desc* index, const bk_params* params, bk_engine** out);
 void bk_engine_destroy(bk_engine* e);
 
+/* A second engine on the same index: it reads the parent's device-resident tables (immutable after
+ * bk_engine_create) and owns everything a sample writes -- counter planes, scan scratch, pileup / statistics
+ * outputs, stream.  Samples are independent (call.rs:212 / :390 handle them one after the other), so a host
+ * with many samples alternates them over two engines: sample i+1's scan overlaps sample i's finalize on the
+ * device.  Same parameters as the parent.  Destroy the forks before the parent. */
+int  bk_engine_fork(const bk_engine* parent, bk_engine** out);
+
 /* Launch all work of this engine on an existing HIP stream (hipStream_t passed as void*); NULL restores the
  * engine's own stream.  Lets a host that already owns a stream (e.g. PyTorch's current stream) order and
  * time the engine's kernels. */
 int bk_engine_set_stream(bk_engine* e, void* hip_stream);
+/* The stream the engine launches on (hipStream_t as void*): its own, created with the engine, unless
+ * bk_engine_set_stream replaced it.  A host orders its own work on the engine's buffers (e.g. RCCL collectives on
+ * the counter plane) by enqueueing it on this stream. */
+void* bk_engine_get_stream(const bk_engine* e);
 
 /* Geometry of the outputs */
 uint64_t bk_total_cells(const bk_engine* e);     /* sum of all sequence lengths = rows of each pileup array */

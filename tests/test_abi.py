@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     L = _ffi.load()
     for s in declared:
         assert hasattr(L, s), s
-    assert L.bk_abi_version() == 3
+    assert L.bk_abi_version() == 4
 
 
 def test_bucket_info_layout_matches_repr_c():

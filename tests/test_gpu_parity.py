@@ -533,3 +533,34 @@ def test_lds_window_on_any_genome_gives_the_same_counts(oracle, sars_paths, monk
     assert oracle.pick_best_genome(ix, pile.stats.sum(axis=0), pile.present.max(axis=0)) == 3
     eng.close()
     ix.close()
+
+
+def test_forked_engines_take_samples_in_turn(oracle, hpv):
+    """bk_engine_fork: a second engine on the parent's device tables with its own counter planes, outputs and stream.  Three
+    different samples alternate over parent and fork without any host synchronisation in between (every call is
+    asynchronous on the engine's own stream: sample i+1's scan overlaps sample i's finalize); each result is downloaded at
+    the end and must equal the oracle's for that sample -- twice over, so that every engine is also reused."""
+    from bronko_amd import pack_reads
+    ix, eng = hpv
+    fork = eng.fork()
+    try:
+        samples = [helpers.hpv_reads(9000 + 1500 * i, seed=60 + i, err=0.004 * (i + 1)) for i in range(3)]
+        packed = [pack_reads(s, 21, None) for s in samples]
+        want = [oracle.sample_pileup(ix, [s]) for s in samples]
+        for order in ([0, 1, 2], [2, 0, 1]):
+            engines = [eng, fork]
+            done = {}
+            for turn, si in enumerate(order):
+                e = engines[turn % 2]
+                if turn >= 2:                       # the engine is about to be reused: take its previous sample's result first
+                    done[order[turn - 2]] = e.sample_download(1)
+                e.sample_begin()
+                e.push_reads(0, *packed[si])
+                e.sample_finalize(1)
+            for turn in range(max(0, len(order) - 2), len(order)):
+                done[order[turn]] = engines[turn % 2].sample_download(1)
+            for si in order:
+                helpers.assert_same_pileup(done[si], want[si])
+                assert done[si].kmer_stats[0, 1] == want[si].kmc_stats[0, 1]
+    finally:
+        fork.close()

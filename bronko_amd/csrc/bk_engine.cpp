@@ -217,9 +217,9 @@ struct bk_engine {
     DevBuf<uint8_t> amb;
     DevBuf<uint16_t> pilots;
     DevBuf<unsigned int> slabs;             // [n_cus][n_lds_bins] workgroup histograms of the last scan launch
-    DevBuf<uint4> gring;                    // scan scratch: per-wave rings of Level-2 chunks (bk_kernels.h ScanArgs::gq)
-    DevBuf<unsigned int> e_planes;          // [8][E] u32, XCD-private planes for positions >= n_lds_bins
-    bool use_xcd_planes = true;
+    DevBuf<unsigned int> l2_bits;           // scan -> Level 2: one bit per k-mer of each record of a launch (bk_kernels.h ScanArgs), all zero between launches
+    DevBuf<unsigned int> l2_any;            // ... one bit per record: its row has bits
+    DevBuf<uint2> l2_diag;                  // ... and each record's diagonal
     uint64_t kmers_since_fold = 0;
     DevBuf<bk::TableSlot> table;
     DevBuf<uint32_t> ent_off, ent_len;
@@ -310,17 +310,11 @@ static int alloc_sample_state(bk_engine* e) {
     if (e->n_files <= 64) BK_HIP(e->fin_partials.alloc(bk::finalize_partial_rows() * ((size_t)e->n_files * 3 + 2)));
     BK_HIP(e->deferred.alloc(bk::v_plane_len(e->n_full, e->v_span, e->n_prows)));
     BK_HIP(e->n_deferred.alloc(2));   // one per mate file
-    if (e->n_lds_bins >= e->total_cells) e->use_xcd_planes = false;   // every cell has an LDS bin
-    if (e->use_xcd_planes) {
-        BK_HIP(e->e_planes.alloc((size_t)bk::kXcdPlanes * bk::e_plane_len(e->n_u)));
-        BK_HIP(hipMemset(e->e_planes.p, 0, e->e_planes.n * sizeof(unsigned int)));
-    }
     BK_HIP(e->pileup.alloc(e->total_cells * 4 * 4));
     BK_HIP(e->stats.alloc((size_t)2 * e->n_files * 3));
     BK_HIP(e->present.alloc((size_t)2 * e->n_files));
     BK_HIP(e->kstats.alloc(8));
     BK_HIP(e->slabs.alloc((size_t)e->n_cus * std::max<uint32_t>(e->n_lds_bins, 1)));
-    BK_HIP(e->gring.alloc(bk::scan_gring_entries((uint32_t)e->n_cus)));
     if (e->n_files > 1) BK_HIP(e->win_votes.alloc((size_t)e->n_files));
     BK_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
@@ -874,7 +868,6 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         if (const char* nl = getenv("BK_LDS_BINS")) e->n_lds_bins = std::min<uint32_t>(e->n_lds_bins, (uint32_t)atol(nl));
     }
     pc.lap("estat + LDS policy");
-    if (const char* nx = getenv("BK_NO_XCD_PLANES")) e->use_xcd_planes = atoi(nx) == 0;
 
     if (bk::finalize_lds_bytes(e->n_files) > 160 * 1024) return fail(BK_ERR_UNSUPPORTED, "more than ~8000 genome files are not supported by the finalize kernel");
 
@@ -901,7 +894,7 @@ int bk_engine_fork(const bk_engine* parent, bk_engine** out) {
     e->n_u = p->n_u; e->n_full = p->n_full; e->n_lds_bins = p->n_lds_bins; e->n_prows = p->n_prows;
     e->v_omin = p->v_omin; e->v_span = p->v_span; e->v_off = p->v_off; e->plane_len = p->plane_len;
     e->ref_in_lds = p->ref_in_lds; e->lo_bases = p->lo_bases; e->n_cus = p->n_cus; e->device = p->device;
-    e->use_xcd_planes = p->use_xcd_planes; e->file_cell_lo = p->file_cell_lo; e->ablate = p->ablate; e->max_launch_records = p->max_launch_records;
+    e->file_cell_lo = p->file_cell_lo; e->ablate = p->ablate; e->max_launch_records = p->max_launch_records;
     e->half_lo.m = p->half_lo.m; e->half_lo.log2nb = p->half_lo.log2nb; e->half_hi.m = p->half_hi.m; e->half_hi.log2nb = p->half_hi.log2nb;
     // the index tables are immutable after bk_engine_create: the fork reads the parent's
     e->prow_id.alias(p->prow_id); e->prow_t.alias(p->prow_t); e->kmer_pos.alias(p->kmer_pos); e->d_view.alias(p->d_view); e->kmer_of.alias(p->kmer_of);
@@ -987,9 +980,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.counters = e->counters[mate].p;
     a.kmer_total = e->kstats.p + mate * 4 + 1;
     a.ablate = e->ablate;
-    a.e_planes = e->use_xcd_planes ? e->e_planes.p : nullptr;
     a.slabs = e->slabs.p;
-    a.gq = e->gring.p;
     a.n_lds_bins = e->n_lds_bins;
     a.ref_in_lds = e->ref_in_lds ? 1 : 0;
     a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->params.kmer_table_log2;
@@ -1012,22 +1003,41 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
         e->win_chosen = true;
     }
     a.win_file = e->win_file; a.win_lo = e->occ.p ? e->win_lo : 0u;
-    // a launch takes at most scan_max_records records (bound on what one workgroup's 16-bit LDS bins can receive)
+    // a launch takes at most scan_max_records records (bound on what one workgroup's 16-bit LDS bins can receive), and no
+    // more than keeps Level 2's bitmap below 1 GiB
+    a.l2_words = bk::scan_l2_words(stride_words, e->k);
+    const uint64_t l2_cap = std::max<uint64_t>(64, ((1ull << 30) / sizeof(unsigned int)) / a.l2_words);
     for (uint64_t base = 0; base < n;) {
         const uint32_t grid = bk::scan_grid(n - base, e->n_cus);
-        uint64_t take = std::min<uint64_t>(n - base, bk::scan_max_records(grid));
+        uint64_t take = std::min<uint64_t>(std::min<uint64_t>(n - base, bk::scan_max_records(grid)), l2_cap);
         if (e->max_launch_records) take = std::min<uint64_t>(take, e->max_launch_records);
+        if (e->l2_bits.n < take * a.l2_words || e->l2_diag.n < take) {
+            BK_HIP(hipStreamSynchronize(e->stream));
+            const uint64_t recs = std::min<uint64_t>(std::max<uint64_t>(take + take / 4, 1 << 16), l2_cap);
+            BK_HIP(e->l2_bits.alloc((size_t)recs * a.l2_words));
+            BK_HIP(e->l2_diag.alloc((size_t)recs));
+            BK_HIP(e->l2_any.alloc((size_t)(recs + 31) / 32));
+            BK_HIP(hipMemsetAsync(e->l2_bits.p, 0, e->l2_bits.n * sizeof(unsigned int), e->stream));
+            BK_HIP(hipMemsetAsync(e->l2_any.p, 0, e->l2_any.n * sizeof(unsigned int), e->stream));
+        }
+        a.l2_bits = e->l2_bits.p; a.l2_diag = e->l2_diag.p; a.l2_any = e->l2_any.p;
         a.rec_base = base; a.n_records = take;
         {
             bk_engine::Span sp(e, 0);
             BK_HIP(bk::launch_scan_count(a, grid, e->stream));
         }
         if (e->W > 0) {
-            // per-cell bin slabs (and the u32 overflow planes: a batch of < 2^32 k-mers cannot wrap them) -> u64 plane
+            bk_engine::Span sp(e, 3);
+            // the k-mers the scan left marked (it clears the marks it takes)
+            if (e->ablate == 1 || e->ablate == 4) {   // measurement aids: without Level 2
+                BK_HIP(hipMemsetAsync(e->l2_bits.p, 0, (size_t)take * a.l2_words * sizeof(unsigned int), e->stream));
+                BK_HIP(hipMemsetAsync(e->l2_any.p, 0, e->l2_any.n * sizeof(unsigned int), e->stream));
+            }
+            else BK_HIP(bk::launch_level2(a, e->n_cus, e->stream));
+            // per-cell bin slabs -> u64 plane
             bk::FoldArgs f{};
             f.slabs = e->slabs.p; f.n_slabs = grid; f.n_lds_bins = e->n_lds_bins; f.id_at = e->id_at.p; f.cell_codes = e->cell_codes.p + bk::scan_ref_pad_words(); f.win_lo = a.win_lo;
-            f.e_planes = a.e_planes; f.n_e = bk::e_plane_len(e->n_u); f.counters = e->counters[mate].p;
-            bk_engine::Span sp(e, 3);
+            f.e_planes = nullptr; f.n_e = bk::e_plane_len(e->n_u); f.counters = e->counters[mate].p;
             bk::launch_fold(f, e->stream);
         }
         base += take;

@@ -28,13 +28,17 @@ struct ScanArgs {
     uint32_t stride_words;
     unsigned long long* counters;   // u64 plane [E | V] (bk_device.h)
     unsigned int* slabs;            // [grid][n_lds_bins] packed (rc<<16 | fwd) per-cell bins of each workgroup
-    uint4* gq;                      // [scan_gring_entries(grid)] scratch: the waves' rings of Level-2 chunks
+    // Level 2's work list, per launch: one bit per k-mer of each record (set by the scan, taken and cleared by
+    // launch_level2) and each record's diagonal
+    unsigned int* l2_bits;          // [n_records][l2_words], all zero between launches
+    unsigned int* l2_any;           // [ceil(n_records / 32)] bit per record: some bit of its row is set; all zero between launches
+    uint2* l2_diag;                 // [n_records] {cell of the reference k-mer aligned with read k-mer 0, bit 0 same strand | bit 1 known}
+    uint32_t l2_words;              // = scan_l2_words(stride_words, k)
     uint32_t n_lds_bins;            // exact hits at cells [win_lo, win_lo + n_lds_bins) are counted in LDS
     uint32_t win_lo;                // first cell of that window (a multiple of 32): the genome the sample looks like
     const uint32_t* occ;            // [n_full][n_files] cell | rc << 31 of the k-mer's first occurrence in each genome file
                                     // (0xffffffff: none), or null; with win_file, seeds land on that genome's copy of a k-mer
     int32_t win_file, n_files;
-    unsigned int* e_planes;         // [8 XCDs][E] u32 planes for hits at cells >= n_lds_bins; null if none / disabled
     int ref_in_lds;                 // stage the packed reference + cell codes in LDS (they fit next to the bins)
     unsigned long long* kmer_total; // optional: += k-mer occurrences scanned
     // full_kmer_stats: k-mers that do not touch the index are counted in this open-addressing table (null = off)
@@ -43,7 +47,7 @@ struct ScanArgs {
     uint32_t ktab_log2;
     unsigned long long* ktab_overflow;
     uint32_t mate;
-    int ablate;                     // measurement aid, 0 in production: 1 = Level 1 only, 2 = no V atomics, 3 = no slow path, 4 = no Level 2
+    int ablate;                     // measurement aid, 0 in production: 1 = Level 1 only, 2 = no V atomics, 3 = no slow path
 };
 
 struct FinalizeArgs {
@@ -97,7 +101,7 @@ void launch_pack_reads(const PackArgs& a, hipStream_t stream);
 void launch_pick_window(const ScanArgs& a, uint64_t n_probe, unsigned int* votes, hipStream_t stream);
 void launch_add_u64(unsigned long long* dst, const unsigned long long* src, hipStream_t stream);   // *dst += *src
 uint32_t scan_grid(uint64_t n_records, int n_cus);
-size_t scan_gring_entries(uint32_t grid);    // uint4 entries ScanArgs::gq must hold for a launch of `grid` workgroups
+uint32_t scan_l2_words(uint32_t stride_words, int k);   // bitmap words per record (ScanArgs::l2_words)
 uint64_t scan_max_records(uint32_t grid);   // most records one launch_scan_count may be given
 int scan_ref_pad_words();
 int scan_ref_back_words();
@@ -106,6 +110,7 @@ int scan_bit_back_words();
 size_t scan_lds_budget();   // bytes available for histogram bins (4 B each) + the staged reference
 size_t scan_ref_lds_bytes(uint32_t total_cells);
 size_t scan_lds_bytes(uint32_t n_lds_bins, bool ref_in_lds, uint32_t total_cells);
+hipError_t launch_level2(const ScanArgs& a, int n_cus, hipStream_t stream);   // after launch_scan_count, same arguments
 hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t stream);
 void launch_fold(const FoldArgs& f, hipStream_t stream);
 void launch_ktab_stats(const unsigned long long* keys, const unsigned int* cnt, uint32_t log2n, unsigned long long ci,

@@ -252,17 +252,14 @@ constexpr int kScanWaves = kScanBlock / 64;
 constexpr int kQueueCap = 96;               // slow-path queue: a batch starts at 32 pending, a step adds <= 64
 constexpr int kRangeCap = 128;              // N queue: a batch starts at 64 pending, a round adds <= 64
 constexpr int kNIters = 8;                  // mismatches of a piece the N batch resolves in one pass
-constexpr uint32_t kGRing = 1024;           // Level-2 ring (global memory, per wave): a batch starts at 64 pending, an N batch adds <= 64 * (kNIters + 1)
 constexpr uint32_t kMaxRecordsPerGroup = 16384;
-constexpr uint32_t kSlowLdsQuota = 2048;    // per wave and launch: slow-path E hits that may use the LDS array
 constexpr int kSeeds = 4;
 constexpr int kRefPadWords = 4;             // words of padding in front of the 2-bit per-cell arrays (64 cells)
 constexpr int kRefBackWords = 6;            // ... and behind them (96 cells)
 constexpr int kBitPadWords = 2;             // the same 64 cells for the 1-bit per-cell arrays
 constexpr int kBitBackWords = 3;
-constexpr size_t kQueueBytes = (size_t)kScanWaves * kQueueCap * sizeof(unsigned long long);
 constexpr size_t kRangeBytes = (size_t)kScanWaves * kRangeCap * sizeof(unsigned int);
-constexpr size_t kScanLdsFixed = kQueueBytes + kRangeBytes + 16 + 64;
+constexpr size_t kScanLdsFixed = kRangeBytes + 16 + 64;
 
 // number of set bits of a wave mask below this lane
 __device__ __forceinline__ uint32_t lane_prefix(unsigned long long m) {
@@ -417,18 +414,15 @@ struct SlowPipe {
 template <bool REF_LDS, bool STATS, int KT>
 __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* queue_c = reinterpret_cast<unsigned long long*>(smem);
-    unsigned int* range_s = reinterpret_cast<unsigned int*>(smem + kQueueBytes);
-    unsigned int* block_kmers = reinterpret_cast<unsigned int*>(smem + kQueueBytes + kRangeBytes);   // 16 B reserved
+    unsigned int* range_s = reinterpret_cast<unsigned int*>(smem);
+    unsigned int* block_kmers = reinterpret_cast<unsigned int*>(smem + kRangeBytes);   // 16 B reserved
     unsigned int* scan_tmp = block_kmers + 4;       // 16 words: wave totals of the epilogue's prefix sum
     unsigned int* bins = scan_tmp + 16;             // [n_lds_bins + 1] the per-cell difference array
     unsigned int* lds_ref = bins + a.n_lds_bins + 1;   // REF_LDS: padded ref words, then the padded bit array
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform by construction: tell the compiler
-    unsigned long long* const q = queue_c + wave * kQueueCap;
     unsigned int* const rqs = range_s + wave * kRangeCap;
-    uint4* const gq = a.gq + ((size_t)blockIdx.x * kScanWaves + wave) * kGRing;   // this wave's ring of Level-2 chunks (global memory)
 
     const uint32_t total = a.total_cells;
     // Level 1 only ever looks at cells below n_lds_bins (a read whose diagonal leaves them goes to Level 2 as a whole), so
@@ -453,57 +447,26 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
 
     const int k = KT ? KT : a.k;
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;  // k <= 31
-    // 2k-bit values are kept as explicit 32-bit halves: 64-bit shifts and compares are slow-rate VALU ops
-    const uint32_t kmask_lo = (uint32_t)kmask, kmask_hi = (uint32_t)(kmask >> 32);
-    const int rcshift = 2 * (k - 1);
-    const uint32_t rc_sh = (uint32_t)rcshift & 31u;
-    const uint32_t rc_in_hi = rcshift >= 32 ? 0xffffffffu : 0u;   // which half receives the new complemented base
     const uint32_t km1 = (uint32_t)k - 1u;
-    const uint32_t chunk = (uint32_t)k;                             // most k-mers one Level-2 lane takes
     const uint32_t piece = 65u - (uint32_t)k;                       // most k-mers of an N run the N batch looks at together (64 bases)
     const int omin = a.v_omin, span = a.v_span;
-    const uint64_t n_e = e_plane_len(a.n_u);
-    unsigned int* const e_local = a.e_planes ? a.e_planes + (size_t)xcc_id() * n_e : nullptr;
     unsigned long long* const v_counters = a.counters + a.v_off;
     const uint32_t last_word = a.stride_words - 1u;
-    uint32_t slow_lds = 0;   // wave-uniform: slow-path E hits this wave has put into the LDS array
 
-    // slow path: +1 on the E counter of reference k-mer `id` (first occurrence at `cell`, reverse-complemented there iff
-    // rc_first) read in orientation `isrc`.  Called by the whole wave (`hit` = this lane has one).
-    auto count_exact = [&](bool hit, uint32_t cell, uint32_t id, uint32_t isrc, uint32_t rc_first) {
-        const unsigned long long hm = __ballot(hit);
-        if (!hm) return;
-        const bool room = slow_lds + 64u <= kSlowLdsQuota;   // wave-uniform
-        if (room) slow_lds += (uint32_t)__popcll(hm);
-        if (!hit) return;
-        if (room && cell - win_lo < a.n_lds_bins) {
-            // a single-cell run in the direction the read has relative to the reference there
-            const unsigned int inc = (isrc ^ rc_first) ? 0x10000u : 1u;
-            __hip_atomic_fetch_add(&bins[cell - win_lo], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&bins[cell - win_lo + 1], 0u - inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else if (e_local) {
-            __hip_atomic_fetch_add(e_local + 2 * (size_t)id + isrc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-            atomicAdd(a.counters + 2 * (size_t)id + isrc, 1ull);
-        }
-    };
-
-    const KmerTable kt{STATS ? a.ktab_keys : nullptr, a.ktab_cnt, a.ktab_log2, a.ktab_overflow, a.mate};   // STATS = full_kmer_stats
     uint32_t nkm = 0;  // k-mer occurrences of this lane's records
-    uint32_t qn = 0;   // wave-uniform fill of the slow-path queue
-    uint32_t qs = 0, qg = 0, gh = 0;   // wave-uniform: fill of the N queue, fill and head of the Level-2 ring
-    SlowPipe pipe;
+    uint32_t qs = 0;   // wave-uniform: fill of the N queue
     const IndexView& ix = *a.ixp;
-
-    auto start_slow_batch = [&]() {
-        const uint32_t nb = min(qn, 64u);
-        pipe.start(q, nb, lane, ix);
-        const uint32_t rest = qn - nb;
-        const unsigned long long tc = ((uint32_t)lane < rest) ? q[64 + lane] : 0ull;
-        __builtin_amdgcn_wave_barrier();
-        if ((uint32_t)lane < rest) q[lane] = tc;
-        __builtin_amdgcn_wave_barrier();
-        qn = rest;
+    // k-mers [s, s + n) of record `rec` (index within this launch) are left to Level 2: set their bits
+    auto l2_mark = [&](bool on, uint32_t rec, uint32_t sk, uint32_t n) {
+        if (!on) return;
+        unsigned int* row = a.l2_bits + (size_t)rec * a.l2_words;
+        atomicOr(a.l2_any + (rec >> 5), 1u << (rec & 31u));
+        uint32_t w = sk >> 5, bit = sk & 31u, left = n;
+        while (left) {
+            const uint32_t take = min(left, 32u - bit);
+            atomicOr(row + w, (take == 32u ? 0xffffffffu : (1u << take) - 1u) << bit);
+            left -= take; ++w; bit = 0u;
+        }
     };
 
     uint64_t n_records = a.n_records;
@@ -599,6 +562,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
             }
         }
         dfl = (fwd ? 1u : 0u) | (seeded ? 2u : 0u);
+        if (live) a.l2_diag[r32] = make_uint2((uint32_t)dg, dfl);   // Level 2 finds the record's diagonal here
 
         // ---- Level 1 / batches: a state machine, all control flow wave-uniform --------------------------------------
         uint32_t i0 = 0;                // first base of the next Level-1 step (32 bases)
@@ -613,135 +577,6 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
         bool words_done = maxlen == 0u;
         for (;;) {
             const bool flush = !pend && words_done;
-            // (at the very end the N batches go first: what they send to Level 2 joins the same G batch)
-            if (qg >= 64u || (flush && fin && qg != 0u && qs == 0u)) {
-                // ================= Level 2 ("G batch"): one queued chunk (<= k k-mers) per lane ==================
-                // The last batch of a wave is rarely full: its chunks are cut into 2^ps parts, one per lane, so that the batch
-                // takes as many steps as the longest part and not as the longest chunk.
-                const uint32_t nb2 = min(qg, 64u);
-                const uint32_t ps = 31u - (uint32_t)__builtin_clz(64u / nb2);     // wave-uniform
-                const uint32_t sub = (chunk + (1u << ps) - 1u) >> ps;             // k-mers per part
-                const uint32_t ei = (uint32_t)lane >> ps, part = (uint32_t)lane & ((1u << ps) - 1u);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint4 ge = ei < nb2 ? gq[(gh + ei) & (kGRing - 1u)] : make_uint4(0u, 0u, 0u, 0u);
-                gh = (gh + nb2) & (kGRing - 1u);
-                qg -= nb2;
-                if (a.ablate == 1 || a.ablate == 4) continue;   // measurement aids: Level 1 alone / without Level 2 (incomplete counts)
-                const uint32_t n_e = (ge.z >> 16) & 0xffu;     // 0 for a lane without an entry
-                const uint32_t s_first = (ge.z & 0xffffu) + part * sub;
-                const uint32_t n2 = n_e > part * sub ? min(sub, n_e - part * sub) : 0u;
-                const int32_t dg2 = (int32_t)ge.y;
-                const uint32_t fl2 = ge.z >> 24;
-                const bool fwd2 = fl2 & 1u;
-                const bool seeded2 = (fl2 & 2u) && n2;
-                const uint32_t* __restrict__ w2 = words0 + (uint64_t)ge.x * a.stride_words;
-                uint32_t nmax = n2;
-#pragma unroll
-                for (int off = 32; off; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off));
-                nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
-
-                // 64 read bases from s_first on (the chunk needs at most chunk + k - 1 <= 61 of them)
-                const uint64_t ga = read_symbols_at(w2, s_first, last_word), gb = read_symbols_at(w2, s_first + 32u, last_word);
-                // rolling k-mers primed with the k-1 bases [s_first, s_first + k - 1)
-                const int kp = k - 1;
-                const uint64_t pmask = (1ull << (2 * kp)) - 1ull;
-                const uint64_t g = ga & pmask;
-                const uint64_t f0 = kp ? rev2_64(g) >> (64 - 2 * kp) : 0ull;
-                const uint64_t r0 = (~g & pmask) << 2;
-                uint32_t f_lo = (uint32_t)f0, f_hi = (uint32_t)(f0 >> 32), r_lo2 = (uint32_t)r0, r_hi2 = (uint32_t)(r0 >> 32);
-                // along the diagonal: base differences with the reference as the read sees it, and the clean / follow bits of
-                // the <= 32 cells of the chunk, all in step order
-                uint64_t da = 0, db = 0, yc = 0;
-                uint32_t c3 = 0;   // per cell of the chunk: no other reference k-mer form within Hamming distance 3 (bk_device.h cell_clean3)
-                uint32_t d_lo = 0, d_hi = 0, id = 0;
-                bool id_ok = false;
-                const uint32_t ddir = fwd2 ? 1u : 0xffffffffu;
-                if (seeded2) {
-                    const int32_t c_first = fwd2 ? dg2 + (int32_t)s_first : dg2 - (int32_t)s_first;   // cell of the chunk's first k-mer
-                    uint64_t ra, rb;
-                    if (fwd2) {
-                        ra = symbols_at(refw, c_first); rb = symbols_at(refw, c_first + 32);
-                        yc = symbols_at(yfw, c_first);
-                        c3 = bits32_at(c3w, c_first);
-                    } else {
-                        // read base s_first + t <-> complement of reference base c_first + k - 1 - t
-                        ra = ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 31));
-                        rb = ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 63));
-                        yc = rev2_64(symbols_at(yrw, c_first - 31));
-                        c3 = __builtin_bitreverse32(bits32_at(c3w, c_first - 31));
-                    }
-                    da = ga ^ ra; db = gb ^ rb;
-                    const uint64_t d0 = kp ? rev2_64(da & pmask) >> (64 - 2 * kp) : 0ull;
-                    d_lo = (uint32_t)d0; d_hi = (uint32_t)(d0 >> 32);
-                    id = a.id_at[c_first] - ddir;     // so that the first step's "previous id + direction" is this cell's id
-                    id_ok = id + ddir != 0xffffffffu;
-                    yc |= 2ull;                       // ... and that step needs no follow bit
-                }
-                const uint32_t g4[4] = {(uint32_t)ga, (uint32_t)(ga >> 32), (uint32_t)gb, (uint32_t)(gb >> 32)};
-                const uint32_t d4[4] = {(uint32_t)da, (uint32_t)(da >> 32), (uint32_t)db, (uint32_t)(db >> 32)};
-                const uint32_t y2[2] = {(uint32_t)yc, (uint32_t)(yc >> 32)};
-                for (uint32_t t = 0; t < nmax; ++t) {
-                    const uint32_t bi = km1 + t;                 // base of the chunk that completes k-mer t
-                    const uint32_t gi = bi >> 4, sh = 2u * (bi & 15u), ci = t >> 4, csh = 2u * (t & 15u);
-                    const uint32_t gsel = gi == 0 ? g4[0] : gi == 1 ? g4[1] : gi == 2 ? g4[2] : g4[3];
-                    const uint32_t dsel = gi == 0 ? d4[0] : gi == 1 ? d4[1] : gi == 2 ? d4[2] : d4[3];
-                    const uint32_t base = (gsel >> sh) & 3u;
-                    const uint32_t dsym = (dsel >> sh) & 3u;
-                    const uint32_t y = ((ci ? y2[1] : y2[0]) >> csh) & 3u;
-                    f_hi = ((f_hi << 2) | (f_lo >> 30)) & kmask_hi;
-                    f_lo = ((f_lo << 2) | base) & kmask_lo;
-                    const uint32_t cb = (3u - base) << rc_sh;
-                    r_lo2 = ((r_lo2 >> 2) | (r_hi2 << 30)) | (cb & ~rc_in_hi);
-                    r_hi2 = (r_hi2 >> 2) | (cb & rc_in_hi);
-                    d_hi = ((d_hi << 2) | (d_lo >> 30)) & kmask_hi;
-                    d_lo = ((d_lo << 2) | dsym) & kmask_lo;
-                    const bool valid = t < n2;
-                    const bool ok = valid && seeded2;
-                    const bool clean = y & 1u;                                   // bk_device.h cell_yf / cell_yr
-                    const bool id_known = ok && id_ok && (y & 2u);               // previous id +-1 along an unbroken stretch
-                    id = id_known ? id + ddir : id;
-                    id_ok = id_known;
-                    const uint32_t dbits = (d_lo | (d_lo >> 1)) & 0x55555555u, dbits_hi = (d_hi | (d_hi >> 1)) & 0x55555555u;
-                    const uint32_t n_diff = (uint32_t)__popc(dbits) + (uint32_t)__popc(dbits_hi);
-                    // one base differs from a clean reference k-mer whose id is known: provably not a reference k-mer, and
-                    // that k-mer is its only possible neighbour (bk_device.h, amb) -- a single-k-mer S run
-                    const bool simple = id_known && clean && n_diff == 1;
-                    if (simple) {
-                        const int from_right = dbits ? (__builtin_ctz(dbits) >> 1) : 16 + (__builtin_ctz(dbits_hi) >> 1);
-                        const int bsh = 2 * from_right;             // the differing base, as the read has it
-                        const uint32_t br = (bsh >= 32 ? f_hi >> (bsh - 32) : f_lo >> bsh) & 3u;
-                        if (a.ablate != 2)
-                            v_point(v_counters, id, fwd2 ? (uint32_t)(k - 1 - from_right) : (uint32_t)from_right, fwd2 ? br : 3u - br,
-                                    fwd2 ? 0u : 1u, omin, span);
-                    }
-                    // everything else (no diagonal, several differences, dirty neighbourhoods, unknown id, no reference
-                    // k-mer at the cell) is resolved by the slow pipeline
-                    // ... except two differences from a reference k-mer that has no other reference k-mer form within distance 3:
-                    // such a k-mer is neither a reference k-mer nor one base away from one (triangle inequality) -- it touches
-                    // nothing (full_kmer_stats: only the statistics table wants it)
-                    const bool dead = ok && n_diff == 2u && ((c3 >> t) & 1u);
-                    const bool miss = valid && !simple && !(dead && !STATS) && a.ablate != 3;
-                    const unsigned long long mm = __ballot(miss);
-                    if (mm) {
-                        if (miss) {
-                            const bool lt = f_hi < r_hi2 || (f_hi == r_hi2 && f_lo < r_lo2);   // lcb.rs:90-94
-                            const uint64_t cc = lt ? (((uint64_t)f_hi << 32) | f_lo) : (((uint64_t)r_hi2 << 32) | r_lo2);
-                            q[qn + lane_prefix(mm)] = cc | (lt ? 0ull : 1ull << 62) | (dead ? 1ull << 63 : 0ull);
-                        }
-                        qn += (uint32_t)__popcll(mm);
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                    if (qn >= 32u) {
-                        // enough for a batch: retire the batch in flight (it advanced with the steps / words since), then take
-                        // up to 64 k-mers off the queue and issue the first loads of the new batch
-                        pipe.finish(ix, v_counters, count_exact, kt);
-                        start_slow_batch();
-                    } else if (pipe.stage) {
-                        pipe.advance(ix, v_counters, count_exact, kt);
-                    }
-                }
-                continue;
-            }
             if (qs >= 64u || (flush && (fin ? qs != 0u : olds != 0u))) {
                 // ================= N batch: one queued piece of an N run per lane (qg < 64 here) ====================
                 // The piece's n <= 65 - k k-mers lie in 64 read bases.  Its leading k-mers whose cells are clean and continue one
@@ -815,17 +650,9 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                     const int t1 = F ? __builtin_ctzll(F) : 1000;
                     if (t1 > kk) { head = min(t1 - kk, n1); cutn = 0; F = 0ull; }   // leading k-mers without a mismatch
                 }
-                head = min(head, (int)chunk);
-                // ---- the head chunk ----
-                {
-                    const bool pushg = have && head > 0;
-                    const unsigned long long bm = __ballot(pushg);
-                    if (bm) {
-                        if (pushg) gq[(gh + qg + lane_prefix(bm)) & (kGRing - 1u)] = make_uint4(rec2, (uint32_t)dg2, s_first | ((uint32_t)head << 16) | (fl2 << 24), 0u);
-                        qg += (uint32_t)__popcll(bm);
-                    }
-                    if (pushg) cutn = head;
-                }
+                // ---- the head ----
+                l2_mark(have && head > 0, rec2, s_first, (uint32_t)head);
+                if (have && head > 0) cutn = head;
                 // ---- mismatch by mismatch ----
                 int tprev = -1000, gprev = -1;   // the previous mismatch; the last k-mer already sent to Level 2
                 for (int it = 0; it < kNIters; ++it) {
@@ -869,17 +696,10 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                         const uint32_t need = pair ? 0xffffffffu >> (31 - (g_hi - g_lo)) : 0u;
                         dead = tn2 - kk > g_hi && ((uint32_t)(c3 >> (pair ? g_lo : 0)) & need) == need;   // none of them reaches t_i+2
                     }
-                    const bool pushg = pair && !dead;
-                    const unsigned long long bm = __ballot(pushg);
-                    if (bm) {
-                        if (pushg) gq[(gh + qg + lane_prefix(bm)) & (kGRing - 1u)] =
-                            make_uint4(rec2, (uint32_t)dg2, (s_first + (uint32_t)g_lo) | ((uint32_t)(g_hi - g_lo + 1) << 16) | (fl2 << 24), 0u);
-                        qg += (uint32_t)__popcll(bm);
-                    }
+                    l2_mark(pair && !dead, rec2, s_first + (uint32_t)(pair ? g_lo : 0), (uint32_t)(g_hi - g_lo + 1));
                     if (pair) gprev = g_hi;
                     tprev = ti;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 // ---- what is left of the piece comes back ----
                 const bool requeue = have && (uint32_t)cutn < n2;
                 const unsigned long long rm = __ballot(requeue);
@@ -924,8 +744,6 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
             }
             if (words_done) break;
             // ================= Level 1: two read words = 32 bases ================================================
-            if (pipe.stage) pipe.advance(ix, v_counters, count_exact, kt);   // the slow path's loads fly while Level 1 works
-            else if (qn >= 32u) start_slow_batch();
             {
                 const uint32_t x0 = xn0, x1 = xn1;
                 xn0 = (i0 + 32u < len) ? w[(i0 >> 4) + 2u] : 0u;
@@ -972,11 +790,6 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
         if (fin) break;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::"v"(pf_sink) : "memory");   // the prefetch register stays reserved up to here
-    pipe.finish(ix, v_counters, count_exact, kt);
-    if (qn) {
-        pipe.start(q, qn, lane, ix);   // qn < 64
-        pipe.finish(ix, v_counters, count_exact, kt);
-    }
 
     // ---- epilogue: difference array -> per-cell counts (prefix sum over the workgroup), written as this workgroup's slab ----
     if (threadIdx.x == 0) *block_kmers = 0;
@@ -1006,6 +819,306 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     if (threadIdx.x == 0 && *block_kmers && a.kmer_total) atomicAdd(a.kmer_total, (unsigned long long)*block_kmers);
 }
 
+// ------------------------------------------------------------------------------------------------ K1b
+// Level 2: the k-mers the scan left marked (ScanArgs::l2_bits, one bit per k-mer of each record) -- k-mers without a
+// usable diagonal, at dirty cells, with several differences that the N batch could not settle, exact k-mers of reads off
+// the LDS window.  Few (about one k-mer in a thousand on the benchmark), so this kernel mostly reads the bitmap and finds
+// it empty; it clears the bits it takes.  Marked runs are cut into chunks of <= k k-mers, queued per wave in LDS, and
+// done 64 at a time ("G batch"), one chunk per lane, the exact per-k-mer logic: rolling canonical k-mer + 2-bit
+// difference mask along the diagonal (both pre-aligned word-parallel, so a step is pure ALU).  A k-mer with one
+// difference at a clean cell of known id is a single-k-mer S run (+1 / -1 in its V row); one with two differences at a
+// cell whose k-mer is isolated up to Hamming distance 3 (cell_clean3) touches nothing and is dropped; everything else
+// goes to the slow path: compacted (ballot + prefix popcount) into a per-wave LDS queue, batches of the SlowPipe (one
+// k-mer per lane): perfect-hash membership test (a hit is a +1 on the k-mer's E counter), then the neighbour search over
+// the two half-k-mer directories and a +1 / -1 in the V row of the smallest (position, NbEntry::p).
+constexpr int kL2Block = 256;
+constexpr int kL2Waves = kL2Block / 64;
+constexpr int kChunkCap = 128;              // chunk queue: a batch starts at 64 pending, a step adds <= 64
+constexpr int kAnyWords = 8;                // words of l2_any a wave takes at a time (256 records): many short waves, the kernel is a chain of dependent loads
+template <bool STATS, int KT>
+__global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
+    __shared__ unsigned long long queue_c[kL2Waves * kQueueCap];
+    __shared__ uint2 chunk_q[kL2Waves * kChunkCap];
+    __shared__ unsigned int rec_q[kL2Waves * kChunkCap];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned long long* const q = queue_c + wave * kQueueCap;
+    uint2* const cq = chunk_q + wave * kChunkCap;
+    unsigned int* const rq = rec_q + wave * kChunkCap;
+
+    const unsigned int* refw = a.ref_words + kRefPadWords;
+    const unsigned int* yfw = a.cell_yf + kRefPadWords;
+    const unsigned int* yrw = a.cell_yr + kRefPadWords;
+    const unsigned int* c3w = a.cell_clean3 + kBitPadWords;
+    const int k = KT ? KT : a.k;
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull;  // k <= 31
+    const uint32_t kmask_lo = (uint32_t)kmask, kmask_hi = (uint32_t)(kmask >> 32);
+    const int rcshift = 2 * (k - 1);
+    const uint32_t rc_sh = (uint32_t)rcshift & 31u;
+    const uint32_t rc_in_hi = rcshift >= 32 ? 0xffffffffu : 0u;   // which half receives the new complemented base
+    const uint32_t km1 = (uint32_t)k - 1u;
+    const uint32_t chunk = (uint32_t)k;                             // most k-mers one lane takes
+    const int omin = a.v_omin, span = a.v_span;
+    unsigned long long* const v_counters = a.counters + a.v_off;
+    const uint32_t last_word = a.stride_words - 1u;
+    const IndexView& ix = *a.ixp;
+    const KmerTable kt{STATS ? a.ktab_keys : nullptr, a.ktab_cnt, a.ktab_log2, a.ktab_overflow, a.mate};   // STATS = full_kmer_stats
+
+    // slow path: +1 on the E counter of reference k-mer `id` read in orientation `isrc`
+    auto count_exact = [&](bool hit, uint32_t /*cell*/, uint32_t id, uint32_t isrc, uint32_t /*rc_first*/) {
+        if (hit) atomicAdd(a.counters + 2 * (size_t)id + isrc, 1ull);
+    };
+    uint32_t qn = 0;   // wave-uniform fill of the slow-path queue
+    uint32_t qc = 0;   // wave-uniform fill of the chunk queue
+    SlowPipe pipe;
+    auto start_slow_batch = [&]() {
+        const uint32_t nb = min(qn, 64u);
+        pipe.start(q, nb, lane, ix);
+        const uint32_t rest = qn - nb;
+        const unsigned long long tc = ((uint32_t)lane < rest) ? q[64 + lane] : 0ull;
+        __builtin_amdgcn_wave_barrier();
+        if ((uint32_t)lane < rest) q[lane] = tc;
+        __builtin_amdgcn_wave_barrier();
+        qn = rest;
+    };
+
+    uint64_t n_records = a.n_records;
+    if (a.n_records_dev) {
+        const uint64_t nd = *a.n_records_dev;
+        n_records = nd > a.rec_base ? min(nd - a.rec_base, a.n_records) : 0ull;
+    }
+    const uint32_t* const words0 = a.words + a.rec_base * a.stride_words;
+    const uint32_t nw = a.l2_words;
+
+    // Work discovery, three levels down: l2_any has one bit per record ("some k-mer of it is marked"); this wave reads kAnyWords of
+    // its words at a time, compacts the marked records into an LDS queue, takes 64 of them (one per lane) and
+    // loads 8 words of their bitmap rows at a time; the marked runs become chunks.
+    const uint64_t n_any = (n_records + 31) / 32;                    // words of l2_any
+    const uint64_t n_blk = (n_any + kAnyWords - 1) / kAnyWords;
+    uint64_t blk = (uint64_t)blockIdx.x * kL2Waves + wave;           // kAnyWords words of l2_any
+    uint32_t anyw = 0;                                               // this lane's word of them: records still to queue
+    if (blk < n_blk) {
+        const uint64_t i = blk * kAnyWords + lane;
+        anyw = (lane < kAnyWords && i < n_any) ? a.l2_any[i] : 0u;
+        if (anyw) a.l2_any[i] = 0u;     // taken: l2_any and l2_bits are all zero again when this kernel ends
+    }
+    bool any_done = blk >= n_blk;       // no more words of l2_any for this wave
+    uint32_t qr = 0;                    // wave-uniform fill of the record queue
+    bool have_recs = false;             // a batch of records is loaded:
+    uint32_t rec = 0xffffffffu;         //   this lane's record (index within the launch), or none
+    uint32_t wg = 0, wi = 0;            //   first word of the group of 8 bitmap words in registers, current word of the group
+    uint32_t bw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool need_load = false;
+    bool done = false;
+    for (;;) {
+        if (qc >= 64u || (done && qc != 0u)) {
+            // ================= G batch: one queued chunk (<= k k-mers) per lane ==================
+            // The last batch of a wave is rarely full: its chunks are cut into 2^ps parts, one per lane, so that the batch
+            // takes as many steps as the longest part and not as the longest chunk.
+            const uint32_t nb2 = min(qc, 64u);
+            const uint32_t ps = 31u - (uint32_t)__builtin_clz(64u / nb2);     // wave-uniform
+            const uint32_t sub = (chunk + (1u << ps) - 1u) >> ps;             // k-mers per part
+            const uint32_t ei = (uint32_t)lane >> ps, part = (uint32_t)lane & ((1u << ps) - 1u);
+            const uint2 ce = ei < nb2 ? cq[ei] : make_uint2(0u, 0u);
+            {   // move the rest of the queue down
+                const uint32_t rest = qc - nb2;
+                const uint2 t = (uint32_t)lane < rest ? cq[64 + lane] : make_uint2(0u, 0u);
+                __builtin_amdgcn_wave_barrier();
+                if ((uint32_t)lane < rest) cq[lane] = t;
+                __builtin_amdgcn_wave_barrier();
+                qc = rest;
+            }
+            const uint32_t n_e = ce.y >> 16;     // 0 for a lane without an entry
+            const uint32_t s_first = (ce.y & 0xffffu) + part * sub;
+            const uint32_t n2 = n_e > part * sub ? min(sub, n_e - part * sub) : 0u;
+            const uint2 dgf = a.l2_diag[ce.x];
+            const int32_t dg2 = (int32_t)dgf.x;
+            const bool fwd2 = dgf.y & 1u;
+            const bool seeded2 = (dgf.y & 2u) && n2;
+            const uint32_t* __restrict__ w2 = words0 + (uint64_t)ce.x * a.stride_words;
+            uint32_t nmax = n2;
+#pragma unroll
+            for (int off = 32; off; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off));
+            nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+
+            // 64 read bases from s_first on (the chunk needs at most chunk + k - 1 <= 61 of them)
+            const uint64_t ga = read_symbols_at(w2, s_first, last_word), gb = read_symbols_at(w2, s_first + 32u, last_word);
+            // rolling k-mers primed with the k-1 bases [s_first, s_first + k - 1)
+            const int kp = k - 1;
+            const uint64_t pmask = (1ull << (2 * kp)) - 1ull;
+            const uint64_t g = ga & pmask;
+            const uint64_t f0 = kp ? rev2_64(g) >> (64 - 2 * kp) : 0ull;
+            const uint64_t r0 = (~g & pmask) << 2;
+            uint32_t f_lo = (uint32_t)f0, f_hi = (uint32_t)(f0 >> 32), r_lo2 = (uint32_t)r0, r_hi2 = (uint32_t)(r0 >> 32);
+            // along the diagonal: base differences with the reference as the read sees it, and the clean / follow bits of
+            // the <= 32 cells of the chunk, all in step order
+            uint64_t da = 0, db = 0, yc = 0;
+            uint32_t c3 = 0;   // per cell of the chunk: no other reference k-mer form within Hamming distance 3 (bk_device.h cell_clean3)
+            uint32_t d_lo = 0, d_hi = 0, id = 0;
+            bool id_ok = false;
+            const uint32_t ddir = fwd2 ? 1u : 0xffffffffu;
+            if (seeded2) {
+                const int32_t c_first = fwd2 ? dg2 + (int32_t)s_first : dg2 - (int32_t)s_first;   // cell of the chunk's first k-mer
+                uint64_t ra, rb;
+                if (fwd2) {
+                    ra = symbols_at(refw, c_first); rb = symbols_at(refw, c_first + 32);
+                    yc = symbols_at(yfw, c_first);
+                    c3 = bits32_at(c3w, c_first);
+                } else {
+                    // read base s_first + t <-> complement of reference base c_first + k - 1 - t
+                    ra = ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 31));
+                    rb = ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 63));
+                    yc = rev2_64(symbols_at(yrw, c_first - 31));
+                    c3 = __builtin_bitreverse32(bits32_at(c3w, c_first - 31));
+                }
+                da = ga ^ ra; db = gb ^ rb;
+                const uint64_t d0 = kp ? rev2_64(da & pmask) >> (64 - 2 * kp) : 0ull;
+                d_lo = (uint32_t)d0; d_hi = (uint32_t)(d0 >> 32);
+                id = a.id_at[c_first] - ddir;     // so that the first step's "previous id + direction" is this cell's id
+                id_ok = id + ddir != 0xffffffffu;
+                yc |= 2ull;                       // ... and that step needs no follow bit
+            }
+            const uint32_t g4[4] = {(uint32_t)ga, (uint32_t)(ga >> 32), (uint32_t)gb, (uint32_t)(gb >> 32)};
+            const uint32_t d4[4] = {(uint32_t)da, (uint32_t)(da >> 32), (uint32_t)db, (uint32_t)(db >> 32)};
+            const uint32_t y2[2] = {(uint32_t)yc, (uint32_t)(yc >> 32)};
+            for (uint32_t t = 0; t < nmax; ++t) {
+                const uint32_t bi = km1 + t;                 // base of the chunk that completes k-mer t
+                const uint32_t gi = bi >> 4, sh = 2u * (bi & 15u), ci = t >> 4, csh = 2u * (t & 15u);
+                const uint32_t gsel = gi == 0 ? g4[0] : gi == 1 ? g4[1] : gi == 2 ? g4[2] : g4[3];
+                const uint32_t dsel = gi == 0 ? d4[0] : gi == 1 ? d4[1] : gi == 2 ? d4[2] : d4[3];
+                const uint32_t base = (gsel >> sh) & 3u;
+                const uint32_t dsym = (dsel >> sh) & 3u;
+                const uint32_t y = ((ci ? y2[1] : y2[0]) >> csh) & 3u;
+                f_hi = ((f_hi << 2) | (f_lo >> 30)) & kmask_hi;
+                f_lo = ((f_lo << 2) | base) & kmask_lo;
+                const uint32_t cb = (3u - base) << rc_sh;
+                r_lo2 = ((r_lo2 >> 2) | (r_hi2 << 30)) | (cb & ~rc_in_hi);
+                r_hi2 = (r_hi2 >> 2) | (cb & rc_in_hi);
+                d_hi = ((d_hi << 2) | (d_lo >> 30)) & kmask_hi;
+                d_lo = ((d_lo << 2) | dsym) & kmask_lo;
+                const bool valid = t < n2;
+                const bool ok = valid && seeded2;
+                const bool clean = y & 1u;                                   // bk_device.h cell_yf / cell_yr
+                const bool id_known = ok && id_ok && (y & 2u);               // previous id +-1 along an unbroken stretch
+                id = id_known ? id + ddir : id;
+                id_ok = id_known;
+                const uint32_t dbits = (d_lo | (d_lo >> 1)) & 0x55555555u, dbits_hi = (d_hi | (d_hi >> 1)) & 0x55555555u;
+                const uint32_t n_diff = (uint32_t)__popc(dbits) + (uint32_t)__popc(dbits_hi);
+                // one base differs from a clean reference k-mer whose id is known: provably not a reference k-mer, and
+                // that k-mer is its only possible neighbour (bk_device.h, amb) -- a single-k-mer S run
+                const bool simple = id_known && clean && n_diff == 1;
+                if (simple) {
+                    const int from_right = dbits ? (__builtin_ctz(dbits) >> 1) : 16 + (__builtin_ctz(dbits_hi) >> 1);
+                    const int bsh = 2 * from_right;             // the differing base, as the read has it
+                    const uint32_t br = (bsh >= 32 ? f_hi >> (bsh - 32) : f_lo >> bsh) & 3u;
+                    if (a.ablate != 2)
+                        v_point(v_counters, id, fwd2 ? (uint32_t)(k - 1 - from_right) : (uint32_t)from_right, fwd2 ? br : 3u - br,
+                                fwd2 ? 0u : 1u, omin, span);
+                }
+                // everything else (no diagonal, several differences, dirty neighbourhoods, unknown id, no reference
+                // k-mer at the cell) is resolved by the slow pipeline
+                // ... except two differences from a reference k-mer that has no other reference k-mer form within distance 3:
+                // such a k-mer is neither a reference k-mer nor one base away from one (triangle inequality) -- it touches
+                // nothing (full_kmer_stats: only the statistics table wants it)
+                const bool dead = ok && n_diff == 2u && ((c3 >> t) & 1u);
+                const bool miss = valid && !simple && !(dead && !STATS) && a.ablate != 3;
+                const unsigned long long mm = __ballot(miss);
+                if (mm) {
+                    if (miss) {
+                        const bool lt = f_hi < r_hi2 || (f_hi == r_hi2 && f_lo < r_lo2);   // lcb.rs:90-94
+                        const uint64_t cc = lt ? (((uint64_t)f_hi << 32) | f_lo) : (((uint64_t)r_hi2 << 32) | r_lo2);
+                        q[qn + lane_prefix(mm)] = cc | (lt ? 0ull : 1ull << 62) | (dead ? 1ull << 63 : 0ull);
+                    }
+                    qn += (uint32_t)__popcll(mm);
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (qn >= 32u) {
+                    // enough for a batch: retire the batch in flight (it advanced with the steps / words since), then take
+                    // up to 64 k-mers off the queue and issue the first loads of the new batch
+                    pipe.finish(ix, v_counters, count_exact, kt);
+                    start_slow_batch();
+                } else if (pipe.stage) {
+                    pipe.advance(ix, v_counters, count_exact, kt);
+                }
+            }
+            continue;
+        }
+        if (done) break;
+        if (have_recs) {
+            if (need_load) {
+                unsigned int* row = a.l2_bits + (size_t)(rec == 0xffffffffu ? 0u : rec) * nw;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    bw[j] = (rec != 0xffffffffu && wg + j < nw) ? row[wg + j] : 0u;
+                    if (bw[j]) row[wg + j] = 0u;
+                }
+                wi = 0;
+                need_load = false;
+            }
+            uint32_t bits = bw[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) bits = wi == (uint32_t)j ? bw[j] : bits;
+            if (!__ballot(bits != 0u)) {
+                if (++wi == 8u || wg + wi >= nw) {
+                    wg += 8u;
+                    if (wg >= nw) have_recs = false; else need_load = true;
+                }
+                continue;
+            }
+            // the next marked run of each lane's word, at most `chunk` k-mers of it
+            const bool has = bits != 0u;
+            const uint32_t s0 = has ? (uint32_t)__builtin_ctz(bits) : 0u;
+            const uint32_t rest = ~(bits >> s0);
+            const uint32_t run = min(rest ? (uint32_t)__builtin_ctz(rest) : 32u, chunk);
+            if (has) bits &= ~((run == 32u ? 0xffffffffu : (1u << run) - 1u) << s0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bw[j] = wi == (uint32_t)j ? bits : bw[j];
+            const unsigned long long hm = __ballot(has);
+            if (has) cq[qc + lane_prefix(hm)] = make_uint2(rec, ((wg + wi) * 32u + s0) | (run << 16));
+            qc += (uint32_t)__popcll(hm);
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+        if (qr >= 64u || (any_done && qr != 0u)) {
+            // the next 64 marked records, one per lane
+            const uint32_t nb = min(qr, 64u);
+            rec = (uint32_t)lane < nb ? rq[lane] : 0xffffffffu;
+            const uint32_t rest = qr - nb;
+            const uint32_t t = (uint32_t)lane < rest ? rq[64 + lane] : 0u;
+            __builtin_amdgcn_wave_barrier();
+            if ((uint32_t)lane < rest) rq[lane] = t;
+            __builtin_amdgcn_wave_barrier();
+            qr = rest;
+            have_recs = true; wg = 0; need_load = true;
+            continue;
+        }
+        if (any_done) { done = true; continue; }
+        if (__ballot(anyw != 0u)) {
+            // one marked record of each lane's word into the record queue (qr < 64 here)
+            const bool has = anyw != 0u;
+            const uint32_t b = has ? (uint32_t)__builtin_ctz(anyw) : 0u;
+            anyw &= anyw - 1u;
+            const unsigned long long hm = __ballot(has);
+            if (has) rq[qr + lane_prefix(hm)] = (uint32_t)((blk * kAnyWords + lane) * 32 + b);
+            qr += (uint32_t)__popcll(hm);
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+        blk += (uint64_t)gridDim.x * kL2Waves;
+        if (blk >= n_blk) { any_done = true; continue; }
+        {
+            const uint64_t i = blk * kAnyWords + lane;
+            anyw = (lane < kAnyWords && i < n_any) ? a.l2_any[i] : 0u;
+            if (anyw) a.l2_any[i] = 0u;
+        }
+    }
+    pipe.finish(ix, v_counters, count_exact, kt);
+    if (qn) {
+        pipe.start(q, qn, lane, ix);   // qn < 64
+        pipe.finish(ix, v_counters, count_exact, kt);
+    }
+}
+
 // Which genome does the sample look like?  One k-mer (the middle one) of each of the first records: votes[f] += 1 for every
 // genome file the k-mer occurs in.  The engine puts the LDS window on the genome with the most votes.
 __global__ __launch_bounds__(256) void pick_window_kernel(ScanArgs a, uint64_t n_probe, unsigned int* votes) {
@@ -1031,7 +1144,8 @@ void launch_pick_window(const ScanArgs& a, uint64_t n_probe, unsigned int* votes
     hipLaunchKernelGGL(pick_window_kernel, dim3(64), dim3(256), 0, stream, a, n_probe, votes);
 }
 
-size_t scan_lds_budget() { return 160u * 1024u - 64u - kScanLdsFixed - sizeof(unsigned int); }
+// (12 KB of the CU's 160 KB are left free: a workgroup of another stream's finalize kernels fits next to the scan's)
+size_t scan_lds_budget() { return 148u * 1024u - 64u - kScanLdsFixed - sizeof(unsigned int); }
 // LDS bytes of the per-cell arrays Level 1 stages for `cells` cells (reference 2 bits, one 1-bit array, paddings)
 size_t scan_ref_lds_bytes(uint32_t cells) {
     return ((size_t)(kRefPadWords + (cells + 15) / 16 + kRefBackWords) + (size_t)(kBitPadWords + (cells + 31) / 32 + kBitBackWords)) *
@@ -1051,7 +1165,7 @@ uint32_t scan_grid(uint64_t n_records, int n_cus) {
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)n_cus));
 }
 // records one launch may take so that no workgroup sees more than kMaxRecordsPerGroup of them
-size_t scan_gring_entries(uint32_t grid) { return (size_t)grid * kScanWaves * kGRing; }   // uint4 each
+uint32_t scan_l2_words(uint32_t stride_words, int k) { const uint32_t b = stride_words * 16u; return b >= (uint32_t)k ? (b - (uint32_t)k + 1u + 31u) / 32u : 1u; }
 uint64_t scan_max_records(uint32_t grid) { return (uint64_t)grid * (kMaxRecordsPerGroup - kScanBlock - 64); }
 
 hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t stream) {
@@ -1070,7 +1184,20 @@ hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t strea
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------ K1b
+hipError_t launch_level2(const ScanArgs& a, int n_cus, hipStream_t stream) {
+    if (a.n_records == 0 || a.W <= 0) return hipSuccess;
+    const bool stats = a.ktab_keys != nullptr;
+    void (*kern)(ScanArgs);
+#define BK_PICK(KT) (stats ? level2_kernel<true, KT> : level2_kernel<false, KT>)
+    kern = a.k == 21 ? BK_PICK(21) : a.k == 31 ? BK_PICK(31) : BK_PICK(0);
+#undef BK_PICK
+    const uint64_t blks = (a.n_records + 32 * kAnyWords - 1) / (32 * kAnyWords);     // a wave takes kAnyWords words of l2_any at a time
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((blks + kL2Waves - 1) / kL2Waves, (uint64_t)n_cus * 8));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kL2Block), 0, stream, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ K1c
 // slab[b][c] = (reads of workgroup b that contain the reference k-mer of cell c, along the reference) + 65536 * (against it)
 // E[2 id_at[c] + rc]     += sum over slabs of the low half   (rc = the cell's k-mer was reverse-complemented to become canonical:
 // E[2 id_at[c] + 1 - rc] += sum over slabs of the high half    a read along the reference has the k-mer as written), and

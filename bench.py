@@ -2,14 +2,18 @@
 """bench.py -- reads/sec through the k-mer -> pileup hot path on MI355X (BASELINE.json metric).
 
 One "step" = one pass of the hot path over one batch of synthetic reads that is already resident in HBM:
-    bk_sample_begin (zero counters + pileups)  ->  bk_push_reads_packed_device (scan_count kernel)
-    [-> RCCL all-reduce(sum) of the k-mer counter plane when world_size > 1]  ->  bk_sample_finalize (thresholds
-    + map_kmers kernel).  Outputs stay in HBM.
+    bk_sample_begin (zero counters + pileups)  ->  bk_push_reads_packed_device (scan_count + level2 + fold kernels)
+    [-> RCCL reduce-scatter(sum) of the k-mer counter plane when world_size > 1]  ->  bk_sample_finalize (thresholds
+    + map_kmers kernels).  Outputs stay in HBM.
+Steps are independent samples (call.rs:212 handles a run's samples one after the other): `--in-flight` engines on the same
+device tables (bk_engine_fork) take them in turn, each on its own stream, so that a sample's scan runs next to the previous
+samples' finalize kernels.  value = reads of all K steps / wall time of the K steps; serial_ms_per_step reports the same
+steps with one sample at a time.
 Workload at N=1: BASELINE.json configs[1] -- SARS-CoV-2 single reference (wuhan_ref.fasta, k=21), 1,000,000
 synthetic 150 bp single-end reads (seed 2).  N>1: every rank scans its own 1M-read shard of one sample (weak
-scaling), counters are all-reduced once per step, every rank finalizes.
+scaling), the counter plane is reduce-scattered once per step, every rank maps its part.
 
-Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--cpu-sample S | --no-cpu-baseline]
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--in-flight E] [--cpu-sample S | --no-cpu-baseline]
 """
 import argparse
 import json
@@ -48,7 +52,7 @@ def main():
     ap.add_argument("--allreduce", action="store_true", help="N > 1: all-reduce the counter plane instead of reduce-scatter + sharded finalize")
     ap.add_argument("--ref-len", type=int, default=0, help="experiment: truncate the reference to its first N bases")
     ap.add_argument("--wide", action="store_true", help="N > 1: move the counter plane as 64-bit integers even when 32 bits would do")
-    ap.add_argument("--in-flight", type=int, default=2, help="samples in flight per GPU: steps alternate over this many engines "
+    ap.add_argument("--in-flight", type=int, default=3, help="samples in flight per GPU: steps alternate over this many engines "
                     "(bk_engine_fork: shared index tables, own counter planes / outputs / stream), so that a sample's scan overlaps "
                     "the previous sample's finalize; 1 = strictly one sample after the other")
     ap.add_argument("--backend", default="nccl", help="testing aid: 'gloo' lets several ranks share one GPU (rank r uses GPU r mod #GPUs)")
@@ -166,17 +170,23 @@ def main():
     timing(0)
     kms = [kms[0]] + list(kms_all[1:])
     kn = [kn[0]] + list(kn_all[1:])
-    # for reference: the same steps strictly one after the other on one engine (what a single sample's turnaround looks like)
+    # The same steps strictly one after the other on one engine: a single sample's turnaround, and the dominant kernel's own
+    # duration (HIP events on its launch stream) with nothing running next to it -- the figure the roofline object is about;
+    # in the timed region above a scan shares the CUs with the other samples' finalize kernels.
     n_serial = max(2, min(10, args.steps))
     saved = engs
     engs = engs[:1]
     step(0)
     fence()
+    timing(2)
+    timing_read()
     ts0 = time.perf_counter()
     for i in range(n_serial):
         step(i)
     fence()
     serial_ms = (time.perf_counter() - ts0) / n_serial * 1e3
+    kms_solo, kn_solo = timing_read()
+    timing(0)
     engs = saved
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -199,7 +209,8 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
 
-    scan_ms = kms[0] / max(kn[0], 1)
+    scan_ms_fly = kms[0] / max(kn[0], 1)
+    scan_ms = kms_solo[0] / max(kn_solo[0], 1)
     fin_ms = kms[1] / max(kn[1], 1)
     achieved = (ALGO_BYTES_PER_READ * args.reads) / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     out = {
@@ -226,7 +237,9 @@ def main():
                    if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": "scan_count_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "avg_kernel_ms": scan_ms, "launches": kn[0],
+                     "avg_kernel_ms": scan_ms, "launches": kn_solo[0],
+                     "measured": "HIP events around the kernel, steps run one sample at a time after the timed region",
+                     "avg_kernel_ms_in_flight": scan_ms_fly, "launches_in_flight": kn[0],   # timed region: sharing the CUs with other samples' kernels
                      "algorithmic_bytes_per_launch": ALGO_BYTES_PER_READ * args.reads,
                      # the kernel is VALU-issue bound, not HBM bound: wave-instructions per launch from
                      # the committed PMC pass; a wave64 VALU instruction occupies one of the chip's 1024 SIMDs for 4 cycles

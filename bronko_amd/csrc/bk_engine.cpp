@@ -1029,6 +1029,17 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
         if (e->W > 0) {
             bk_engine::Span sp(e, 3);
             // the k-mers the scan left marked (it clears the marks it takes)
+            if (getenv("BK_L2_COUNT")) {   // debugging aid: how much is left to Level 2
+                std::vector<unsigned int> hb((size_t)take * a.l2_words), ha((size_t)(take + 31) / 32);
+                BK_HIP(hipMemcpyAsync(hb.data(), e->l2_bits.p, hb.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));
+                BK_HIP(hipMemcpyAsync(ha.data(), e->l2_any.p, ha.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));
+                BK_HIP(hipStreamSynchronize(e->stream));
+                uint64_t nk = 0, nr = 0, runs = 0;
+                for (size_t i = 0; i < hb.size(); i++) { nk += (uint64_t)__builtin_popcount(hb[i]); runs += (uint64_t)__builtin_popcount(hb[i] & ~(hb[i] << 1)); }
+                for (unsigned int w : ha) nr += (uint64_t)__builtin_popcount(w);
+                fprintf(stderr, "[bk] level 2: %llu of %llu records marked, %llu k-mers in %llu runs (per 32-bit word)\n", (unsigned long long)nr,
+                        (unsigned long long)take, (unsigned long long)nk, (unsigned long long)runs);
+            }
             if (e->ablate == 1 || e->ablate == 4) {   // measurement aids: without Level 2
                 BK_HIP(hipMemsetAsync(e->l2_bits.p, 0, (size_t)take * a.l2_words * sizeof(unsigned int), e->stream));
                 BK_HIP(hipMemsetAsync(e->l2_any.p, 0, e->l2_any.n * sizeof(unsigned int), e->stream));

@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
 """From a rocprofv3 --kernel-trace CSV: per kernel, average duration and how much of it ran while a kernel of another
-stream (queue) was running too; wall time per bench step.  Usage: trace_overlap.py kernel_trace.csv [steps]"""
+stream (queue) was running too; wall time per bench step.  Usage: trace_overlap.py kernel_trace.csv [steps [warmup]]"""
 import csv, sys
 from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void bk::", "").replace("bk::", ""), r.get("Queue_Id", "0")) for r in rows]
 ev.sort()
-# keep the last 60 % of the trace (steady state)
-t_lo = ev[0][0] + (ev[-1][1] - ev[0][0]) * 4 // 10
-ev = [e for e in ev if e[0] >= t_lo]
+# bench.py's timed region: the scan launches after the warm-up ones, `steps` of them (default: 3 warm-up, 20 timed)
+warm = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+scans = [e for e in ev if e[2].startswith("scan_count")]
+t_lo = scans[warm][0]
+t_hi = scans[warm + steps][0] if len(scans) > warm + steps else ev[-1][1]
+ev = [e for e in ev if t_lo <= e[0] < t_hi]
 tot = defaultdict(int); cnt = defaultdict(int); ovl = defaultdict(int)
 for i, (s, e, n, q) in enumerate(ev):
     tot[n] += e - s; cnt[n] += 1

@@ -13,7 +13,6 @@ namespace bk {
 constexpr uint64_t kEmptyKey = ~0ull;
 constexpr int kMaxK = 31;            // consts.rs:4 MAX_KMER_SIZE
 constexpr int kCountersPerSlot = 8;  // 4 bases x 2 read orientations
-constexpr int kXcdPlanes = 8;        // MI355X: 8 XCDs, each with a private L2
 
 // One position of a window sub-table (open addressing, linear probing).  16 B so that a probe is one
 // global_load_dwordx4.  key = canonical k-mer with the sub-table's wildcard position zeroed.

@@ -1044,12 +1044,11 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
                 BK_HIP(hipMemsetAsync(e->l2_bits.p, 0, (size_t)take * a.l2_words * sizeof(unsigned int), e->stream));
                 BK_HIP(hipMemsetAsync(e->l2_any.p, 0, e->l2_any.n * sizeof(unsigned int), e->stream));
             }
-            else BK_HIP(bk::launch_level2(a, e->n_cus, e->stream));
-            // per-cell bin slabs -> u64 plane
+            // ... and, in the same launch, the per-cell bin slabs -> u64 plane
             bk::FoldArgs f{};
             f.slabs = e->slabs.p; f.n_slabs = grid; f.n_lds_bins = e->n_lds_bins; f.id_at = e->id_at.p; f.cell_codes = e->cell_codes.p + bk::scan_ref_pad_words(); f.win_lo = a.win_lo;
-            f.e_planes = nullptr; f.n_e = bk::e_plane_len(e->n_u); f.counters = e->counters[mate].p;
-            bk::launch_fold(f, e->stream);
+            f.counters = e->counters[mate].p;
+            BK_HIP(bk::launch_level2_fold(a, f, e->n_cus, e->stream));
         }
         base += take;
     }

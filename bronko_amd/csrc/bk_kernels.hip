@@ -47,11 +47,6 @@ __device__ __forceinline__ int single_diff_pos(uint64_t a, uint64_t b, int k) {
     return k - 1 - (__builtin_ctzll(y) >> 1);
 }
 
-__device__ __forceinline__ uint32_t xcc_id() {
-    uint32_t v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-    return v & (kXcdPlanes - 1);
-}
 
 __device__ __forceinline__ HalfDir half_lookup(const HalfView& hv, uint64_t half) {
     const uint32_t pilot = hv.pilots[phf_bucket(half, hv.log2nb)];
@@ -819,6 +814,35 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     if (threadIdx.x == 0 && *block_kmers && a.kmer_total) atomicAdd(a.kmer_total, (unsigned long long)*block_kmers);
 }
 
+// ------------------------------------------------------------------------------------------------ K1c (fold)
+// slab[b][c] = (reads of workgroup b that contain the reference k-mer of cell c, along the reference) + 65536 * (against it)
+// E[2 id_at[c] + rc]     += sum over slabs of the low half   (rc = the cell's k-mer was reverse-complemented to become canonical:
+// E[2 id_at[c] + 1 - rc] += sum over slabs of the high half    a read along the reference has the k-mer as written).
+// Runs as the first blocks of the Level-2 launch (the two are independent; one link less in the stream's chain): block
+// (bx of nbx, by of nby); by splits the slabs into groups so that the 31 MB of slabs are streamed by many CUs, each group
+// adds its partial sums with one u64 atomic per non-zero half.
+__device__ __forceinline__ void fold_block(const FoldArgs& f, uint32_t bx, uint32_t nbx, uint32_t by, uint32_t nby) {
+    const uint64_t tid = (uint64_t)bx * blockDim.x + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)nbx * blockDim.x;
+    const uint32_t per = (f.n_slabs + nby - 1) / nby;
+    const uint32_t b0 = by * per, b1 = min(f.n_slabs, b0 + per);
+    for (uint64_t i = tid; i < f.n_lds_bins && b0 < b1; i += nthreads) {
+        unsigned long long s0 = 0, s1 = 0;
+        for (uint32_t b = b0; b < b1; ++b) {
+            const unsigned int v = f.slabs[(size_t)b * f.n_lds_bins + i];
+            s0 += v & 0xffffu;
+            s1 += v >> 16;
+        }
+        if (s0 | s1) {
+            const uint64_t cell = f.win_lo + i;
+            const uint32_t id = f.id_at[cell];   // a counted cell always has a reference k-mer
+            const uint32_t rc = ((f.cell_codes[cell >> 4] >> (2 * (cell & 15))) & 3u) == 2u ? 1u : 0u;
+            if (s0) atomicAdd(f.counters + 2 * (size_t)id + rc, s0);
+            if (s1) atomicAdd(f.counters + 2 * (size_t)id + (1u - rc), s1);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K1b
 // Level 2: the k-mers the scan left marked (ScanArgs::l2_bits, one bit per k-mer of each record) -- k-mers without a
 // usable diagonal, at dirty cells, with several differences that the N batch could not settle, exact k-mers of reads off
@@ -836,7 +860,12 @@ constexpr int kL2Waves = kL2Block / 64;
 constexpr int kChunkCap = 128;              // chunk queue: a batch starts at 64 pending, a step adds <= 64
 constexpr int kAnyWords = 8;                // words of l2_any a wave takes at a time (256 records): many short waves, the kernel is a chain of dependent loads
 template <bool STATS, int KT>
-__global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
+__global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a, FoldArgs f, uint32_t fold_bx, uint32_t fold_by) {
+    // the first fold_bx * fold_by blocks fold the scan's slabs, the others are Level 2
+    const uint32_t n_fold = fold_bx * fold_by;
+    if (blockIdx.x < n_fold) { fold_block(f, blockIdx.x % fold_bx, fold_bx, blockIdx.x / fold_bx, fold_by); return; }
+    const uint32_t l2_block = blockIdx.x - n_fold, l2_grid = gridDim.x - n_fold;
+    if (a.ablate == 1 || a.ablate == 4) return;   // measurement aids: without Level 2 (the engine clears the marks)
     __shared__ unsigned long long queue_c[kL2Waves * kQueueCap];
     __shared__ uint2 chunk_q[kL2Waves * kChunkCap];
     __shared__ unsigned int rec_q[kL2Waves * kChunkCap];
@@ -895,7 +924,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
     // loads 8 words of their bitmap rows at a time; the marked runs become chunks.
     const uint64_t n_any = (n_records + 31) / 32;                    // words of l2_any
     const uint64_t n_blk = (n_any + kAnyWords - 1) / kAnyWords;
-    uint64_t blk = (uint64_t)blockIdx.x * kL2Waves + wave;           // kAnyWords words of l2_any
+    uint64_t blk = (uint64_t)l2_block * kL2Waves + wave;             // kAnyWords words of l2_any
     uint32_t anyw = 0;                                               // this lane's word of them: records still to queue
     if (blk < n_blk) {
         const uint64_t i = blk * kAnyWords + lane;
@@ -1104,7 +1133,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
             __builtin_amdgcn_wave_barrier();
             continue;
         }
-        blk += (uint64_t)gridDim.x * kL2Waves;
+        blk += (uint64_t)l2_grid * kL2Waves;
         if (blk >= n_blk) { any_done = true; continue; }
         {
             const uint64_t i = blk * kAnyWords + lane;
@@ -1184,66 +1213,19 @@ hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t strea
     return hipGetLastError();
 }
 
-hipError_t launch_level2(const ScanArgs& a, int n_cus, hipStream_t stream) {
+hipError_t launch_level2_fold(const ScanArgs& a, const FoldArgs& f, int n_cus, hipStream_t stream) {
     if (a.n_records == 0 || a.W <= 0) return hipSuccess;
     const bool stats = a.ktab_keys != nullptr;
-    void (*kern)(ScanArgs);
+    void (*kern)(ScanArgs, FoldArgs, uint32_t, uint32_t);
 #define BK_PICK(KT) (stats ? level2_kernel<true, KT> : level2_kernel<false, KT>)
     kern = a.k == 21 ? BK_PICK(21) : a.k == 31 ? BK_PICK(31) : BK_PICK(0);
 #undef BK_PICK
+    const uint32_t fold_bx = (uint32_t)std::min<uint64_t>(1024, ((uint64_t)f.n_lds_bins + kL2Block - 1) / kL2Block);
+    const uint32_t fold_by = f.n_lds_bins ? std::max(1u, std::min(16u, f.n_slabs / 8)) : 0u;
     const uint64_t blks = (a.n_records + 32 * kAnyWords - 1) / (32 * kAnyWords);     // a wave takes kAnyWords words of l2_any at a time
-    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((blks + kL2Waves - 1) / kL2Waves, (uint64_t)n_cus * 8));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kL2Block), 0, stream, a);
+    const unsigned l2_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((blks + kL2Waves - 1) / kL2Waves, (uint64_t)n_cus * 8));
+    hipLaunchKernelGGL(kern, dim3(fold_bx * fold_by + l2_grid), dim3(kL2Block), 0, stream, a, f, fold_bx, fold_by);
     return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------ K1c
-// slab[b][c] = (reads of workgroup b that contain the reference k-mer of cell c, along the reference) + 65536 * (against it)
-// E[2 id_at[c] + rc]     += sum over slabs of the low half   (rc = the cell's k-mer was reverse-complemented to become canonical:
-// E[2 id_at[c] + 1 - rc] += sum over slabs of the high half    a read along the reference has the k-mer as written), and
-// E[i]                   += sum over the 8 XCD planes of e_planes[x][i]   (planes re-zeroed for the next batch).
-__global__ __launch_bounds__(256) void fold_kernel(FoldArgs f) {
-    const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t nthreads = (uint64_t)gridDim.x * 256;
-    // blockIdx.y splits the slabs into groups so that the 31 MB of slabs are streamed by the whole chip; each
-    // group adds its partial sums with one u64 atomic per non-zero half
-    const uint32_t per = (f.n_slabs + gridDim.y - 1) / gridDim.y;
-    const uint32_t b0 = blockIdx.y * per, b1 = min(f.n_slabs, b0 + per);
-    for (uint64_t i = tid; i < f.n_lds_bins && b0 < b1; i += nthreads) {
-        unsigned long long s0 = 0, s1 = 0;
-        for (uint32_t b = b0; b < b1; ++b) {
-            const unsigned int v = f.slabs[(size_t)b * f.n_lds_bins + i];
-            s0 += v & 0xffffu;
-            s1 += v >> 16;
-        }
-        if (s0 | s1) {
-            const uint64_t cell = f.win_lo + i;
-            const uint32_t id = f.id_at[cell];   // a counted cell always has a reference k-mer
-            const uint32_t rc = ((f.cell_codes[cell >> 4] >> (2 * (cell & 15))) & 3u) == 2u ? 1u : 0u;
-            if (s0) atomicAdd(f.counters + 2 * (size_t)id + rc, s0);
-            if (s1) atomicAdd(f.counters + 2 * (size_t)id + (1u - rc), s1);
-        }
-    }
-    if (f.e_planes && blockIdx.y == 0) {
-        for (uint64_t i = tid; i < f.n_e; i += nthreads) {
-            unsigned long long s = 0;
-#pragma unroll
-            for (int x = 0; x < kXcdPlanes; ++x) {
-                const unsigned int v = f.e_planes[(size_t)x * f.n_e + i];
-                if (v) { s += v; f.e_planes[(size_t)x * f.n_e + i] = 0u; }
-            }
-            if (s) atomicAdd(f.counters + i, s);
-        }
-    }
-}
-
-void launch_fold(const FoldArgs& f, hipStream_t stream) {
-    const uint64_t work = std::max<uint64_t>(f.n_lds_bins, f.e_planes ? f.n_e : 0);
-    if (work == 0) return;
-    uint64_t blocks = (work + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    const unsigned groups = std::max(1u, std::min(16u, f.n_slabs / 8));
-    hipLaunchKernelGGL(fold_kernel, dim3((unsigned)blocks, groups), dim3(256), 0, stream, f);
 }
 
 // ------------------------------------------------------------------------------------------------ K2

@@ -1044,11 +1044,12 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
                 BK_HIP(hipMemsetAsync(e->l2_bits.p, 0, (size_t)take * a.l2_words * sizeof(unsigned int), e->stream));
                 BK_HIP(hipMemsetAsync(e->l2_any.p, 0, e->l2_any.n * sizeof(unsigned int), e->stream));
             }
-            // ... and, in the same launch, the per-cell bin slabs -> u64 plane
+            else BK_HIP(bk::launch_level2(a, e->n_cus, e->stream));
+            // per-cell bin slabs -> u64 plane
             bk::FoldArgs f{};
             f.slabs = e->slabs.p; f.n_slabs = grid; f.n_lds_bins = e->n_lds_bins; f.id_at = e->id_at.p; f.cell_codes = e->cell_codes.p + bk::scan_ref_pad_words(); f.win_lo = a.win_lo;
             f.counters = e->counters[mate].p;
-            BK_HIP(bk::launch_level2_fold(a, f, e->n_cus, e->stream));
+            bk::launch_fold(f, e->stream);
         }
         base += take;
     }

@@ -108,8 +108,9 @@ int scan_bit_back_words();
 size_t scan_lds_budget();   // bytes available for histogram bins (4 B each) + the staged reference
 size_t scan_ref_lds_bytes(uint32_t total_cells);
 size_t scan_lds_bytes(uint32_t n_lds_bins, bool ref_in_lds, uint32_t total_cells);
-hipError_t launch_level2_fold(const ScanArgs& a, const FoldArgs& f, int n_cus, hipStream_t stream);   // after launch_scan_count, same ScanArgs: Level 2 + fold of the slabs
+hipError_t launch_level2(const ScanArgs& a, int n_cus, hipStream_t stream);   // after launch_scan_count, same arguments
 hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t stream);
+void launch_fold(const FoldArgs& f, hipStream_t stream);
 void launch_ktab_stats(const unsigned long long* keys, const unsigned int* cnt, uint32_t log2n, unsigned long long ci,
                        unsigned long long cx, unsigned long long* out, hipStream_t stream);
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);

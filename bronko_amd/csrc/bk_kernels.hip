@@ -4,9 +4,10 @@
 // K1  scan_count       : records -> for every k-mer, which distinct index-touching k-mer is it? -> its occurrence counter.
 //                        Replaces the external KMC3 run of call.rs:1166-1211 for every k-mer that can touch the index.
 //                        Counts are recorded per RUN of consecutive k-mers (difference arrays, see K1's comment): a
-//                        word-parallel comparison of the read with the reference along its diagonal finds the runs, a
-//                        per-k-mer path (rolling canonical k-mer, neighbour search) takes what is left.
-// K1b fold             : per-workgroup per-cell counts (slabs) and the per-XCD overflow planes -> E counters of the u64 plane.
+//                        word-parallel comparison of the read with the reference along its diagonal finds the runs; what
+//                        it cannot settle is marked in a per-record bitmap.
+// K1b level2           : the marked k-mers, one by one (rolling canonical k-mer, membership test, neighbour search).
+// K1c fold             : per-workgroup per-cell counts (slabs) -> E counters of the u64 plane.
 // K2a finalize_variant : V rows -> per-k-mer counts (prefix sums) -> KMC thresholds -> map_kmers vote.
 // K2e finalize_exact   : E counters -> thresholds -> map_kmers vote, one thread per (reference k-mer, bucket).
 // K2b finalize_general : the k-mers K2a defers (several buckets) -> map_kmers vote, one wave per k-mer.
@@ -202,45 +203,31 @@ void launch_ktab_stats(const unsigned long long* keys, const unsigned int* cnt, 
 // bases at a time, the read words are XORed with the reference words aligned to them (packed reference in LDS,
 // funnel shifts; reversed and complemented for the opposite strand) and folded to one mismatch flag per base.  A
 // k-step shift-and-or over the flag history says, for the 32 k-mers that end in these words at once, whether their
-// window holds no mismatch, exactly one, or more; with two per-cell bits from
-// LDS ("a reference k-mer starts here", "... and it is clean") every k-mer is
+// window holds a mismatch; with one per-cell bit from LDS ("a reference k-mer starts here") every k-mer is
 //   E  exact      no mismatch, a reference k-mer starts at the cell: the read k-mer IS that reference k-mer;
-//   S  simple     one mismatch, the cell is clean: the read k-mer is "that reference k-mer with another base
-//                 at one offset" and (clean) cannot be anything else;
-//   G  general    everything else.
-// Consecutive k-mers of one kind form a run, and a run costs two atomics, whatever its length:
+//   N  not        everything else.
+// Consecutive k-mers of one kind form a run.
 //   E run   cells c0..c1 each seen once more in this read's direction: +1 at c0, -1 at c1 + 1 in a per-cell
 //           DIFFERENCE array in LDS (low half-word: reads along the reference, high half-word: against it).  The
 //           workgroup turns it into per-cell counts with one prefix sum at the end (epilogue) and writes them as a
 //           slab; fold adds slab cell c into E[id_at[c]] (orientation = the cell's, flipped for the high half).
-//   S run   the k-mers that cover one mismatch: one row of the V plane (bk_device.h), +1 at the first offset, -1
-//           after the last.  Needs the id of the run's first cell (global load), so runs are queued (lane, first
-//           k-mer, length) and done 64 at a time ("S batch", no per-k-mer loop).
-//   G run   queued in chunks of <= k k-mers for Level 2.
-// Reads without a usable diagonal (no seed hit, diagonal leaving the reference, cells beyond the LDS array)
-// become G runs as a whole.
-//
-// Level 2 ("G batch") -- one queued chunk per lane, the exact per-k-mer logic: rolling canonical k-mer + 2-bit
-// difference mask along the diagonal (both pre-aligned word-parallel, so a step is pure ALU).  A k-mer with one
-// difference at a clean cell of known id is a single-k-mer S run (+1 / -1 in its V row); one with two differences
-// at a cell whose k-mer is isolated up to Hamming distance 3 (cell_clean3) touches nothing and is dropped; everything
-// else goes to the slow path.
-//
-// Slow path -- compacted (ballot + prefix popcount) into a per-wave LDS queue; batches of the SlowPipe (one k-mer
-// per lane): perfect-hash membership test (a hit is an E count after all), then the neighbour search over the two
-// half-k-mer directories and a +1 / -1 in the V row of the smallest (position, NbEntry::p).
+//   N run   queued (lane, first k-mer, length) in pieces of <= 65 - k k-mers -- a piece lies in 64 read bases -- and done
+//           64 pieces at a time, one per lane ("N batch", see there): the k-mers that cover one mismatch and nothing
+//           else are an S run -- one row of the V plane (bk_device.h), +1 at the first offset, -1 after the last,
+//           whatever the length; what the N batch cannot settle is marked for Level 2 (level2_kernel): one bit per
+//           k-mer in l2_bits[record], one bit per record in l2_any.
+// Reads without a usable diagonal (no seed hit, diagonal leaving the reference, cells beyond the LDS array) are N
+// runs as a whole.
 //
 // LDS difference array: one 32-bit word per cell, value = (runs starting - runs ending) of reads along the
 // reference + 65536 * the same for reads against it, modulo 2^32.  The prefix sum S_c = F_c + 65536 R_c is exact
-// as long as both counts stay below 65536: a launch gives a workgroup at most kMaxRecordsPerGroup records, a
-// record covers a cell at most once on its diagonal, and the slow path's point updates are limited to
-// kSlowLdsQuota per wave (beyond that they go to the E plane directly).
+// as long as both counts stay below 65536: a launch gives a workgroup at most kMaxRecordsPerGroup records and a
+// record covers a cell at most once on its diagonal.
 //
 // The LDS arrays cover a window of cells [win_lo, win_lo + n_lds_bins): everything for one genome of SARS-CoV-2 size;
 // for a multi-genome index the engine puts it on the genome the sample looks like (pick_window_kernel) and the seeds
-// land on that genome's copy of a k-mer (occ).  Exact hits outside the window (other genomes' copies, found by the
-// slow path) are counted with workgroup-scope (non-sc1) atomics in a u32 plane private to the XCD the workgroup runs on (HW_REG_XCC_ID, read at run time, so nothing depends on
-// how workgroups are placed); fold adds the planes up afterwards.  A reference too large for LDS is read from
+// land on that genome's copy of a k-mer (occ).  Exact hits outside the window (other genomes' copies) are found by
+// Level 2's membership test and counted in the u64 plane directly.  A reference too large for LDS is read from
 // global memory instead (REF_LDS = false).
 constexpr int kScanBlock = 1024;
 constexpr int kScanWaves = kScanBlock / 64;
@@ -814,35 +801,6 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     if (threadIdx.x == 0 && *block_kmers && a.kmer_total) atomicAdd(a.kmer_total, (unsigned long long)*block_kmers);
 }
 
-// ------------------------------------------------------------------------------------------------ K1c (fold)
-// slab[b][c] = (reads of workgroup b that contain the reference k-mer of cell c, along the reference) + 65536 * (against it)
-// E[2 id_at[c] + rc]     += sum over slabs of the low half   (rc = the cell's k-mer was reverse-complemented to become canonical:
-// E[2 id_at[c] + 1 - rc] += sum over slabs of the high half    a read along the reference has the k-mer as written).
-// Runs as the first blocks of the Level-2 launch (the two are independent; one link less in the stream's chain): block
-// (bx of nbx, by of nby); by splits the slabs into groups so that the 31 MB of slabs are streamed by many CUs, each group
-// adds its partial sums with one u64 atomic per non-zero half.
-__device__ __forceinline__ void fold_block(const FoldArgs& f, uint32_t bx, uint32_t nbx, uint32_t by, uint32_t nby) {
-    const uint64_t tid = (uint64_t)bx * blockDim.x + threadIdx.x;
-    const uint64_t nthreads = (uint64_t)nbx * blockDim.x;
-    const uint32_t per = (f.n_slabs + nby - 1) / nby;
-    const uint32_t b0 = by * per, b1 = min(f.n_slabs, b0 + per);
-    for (uint64_t i = tid; i < f.n_lds_bins && b0 < b1; i += nthreads) {
-        unsigned long long s0 = 0, s1 = 0;
-        for (uint32_t b = b0; b < b1; ++b) {
-            const unsigned int v = f.slabs[(size_t)b * f.n_lds_bins + i];
-            s0 += v & 0xffffu;
-            s1 += v >> 16;
-        }
-        if (s0 | s1) {
-            const uint64_t cell = f.win_lo + i;
-            const uint32_t id = f.id_at[cell];   // a counted cell always has a reference k-mer
-            const uint32_t rc = ((f.cell_codes[cell >> 4] >> (2 * (cell & 15))) & 3u) == 2u ? 1u : 0u;
-            if (s0) atomicAdd(f.counters + 2 * (size_t)id + rc, s0);
-            if (s1) atomicAdd(f.counters + 2 * (size_t)id + (1u - rc), s1);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ K1b
 // Level 2: the k-mers the scan left marked (ScanArgs::l2_bits, one bit per k-mer of each record) -- k-mers without a
 // usable diagonal, at dirty cells, with several differences that the N batch could not settle, exact k-mers of reads off
@@ -860,12 +818,7 @@ constexpr int kL2Waves = kL2Block / 64;
 constexpr int kChunkCap = 128;              // chunk queue: a batch starts at 64 pending, a step adds <= 64
 constexpr int kAnyWords = 8;                // words of l2_any a wave takes at a time (256 records): many short waves, the kernel is a chain of dependent loads
 template <bool STATS, int KT>
-__global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a, FoldArgs f, uint32_t fold_bx, uint32_t fold_by) {
-    // the first fold_bx * fold_by blocks fold the scan's slabs, the others are Level 2
-    const uint32_t n_fold = fold_bx * fold_by;
-    if (blockIdx.x < n_fold) { fold_block(f, blockIdx.x % fold_bx, fold_bx, blockIdx.x / fold_bx, fold_by); return; }
-    const uint32_t l2_block = blockIdx.x - n_fold, l2_grid = gridDim.x - n_fold;
-    if (a.ablate == 1 || a.ablate == 4) return;   // measurement aids: without Level 2 (the engine clears the marks)
+__global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
     __shared__ unsigned long long queue_c[kL2Waves * kQueueCap];
     __shared__ uint2 chunk_q[kL2Waves * kChunkCap];
     __shared__ unsigned int rec_q[kL2Waves * kChunkCap];
@@ -924,7 +877,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a, FoldArgs f
     // loads 8 words of their bitmap rows at a time; the marked runs become chunks.
     const uint64_t n_any = (n_records + 31) / 32;                    // words of l2_any
     const uint64_t n_blk = (n_any + kAnyWords - 1) / kAnyWords;
-    uint64_t blk = (uint64_t)l2_block * kL2Waves + wave;             // kAnyWords words of l2_any
+    uint64_t blk = (uint64_t)blockIdx.x * kL2Waves + wave;           // kAnyWords words of l2_any
     uint32_t anyw = 0;                                               // this lane's word of them: records still to queue
     if (blk < n_blk) {
         const uint64_t i = blk * kAnyWords + lane;
@@ -1133,7 +1086,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a, FoldArgs f
             __builtin_amdgcn_wave_barrier();
             continue;
         }
-        blk += (uint64_t)l2_grid * kL2Waves;
+        blk += (uint64_t)gridDim.x * kL2Waves;
         if (blk >= n_blk) { any_done = true; continue; }
         {
             const uint64_t i = blk * kAnyWords + lane;
@@ -1213,19 +1166,54 @@ hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t strea
     return hipGetLastError();
 }
 
-hipError_t launch_level2_fold(const ScanArgs& a, const FoldArgs& f, int n_cus, hipStream_t stream) {
+hipError_t launch_level2(const ScanArgs& a, int n_cus, hipStream_t stream) {
     if (a.n_records == 0 || a.W <= 0) return hipSuccess;
     const bool stats = a.ktab_keys != nullptr;
-    void (*kern)(ScanArgs, FoldArgs, uint32_t, uint32_t);
+    void (*kern)(ScanArgs);
 #define BK_PICK(KT) (stats ? level2_kernel<true, KT> : level2_kernel<false, KT>)
     kern = a.k == 21 ? BK_PICK(21) : a.k == 31 ? BK_PICK(31) : BK_PICK(0);
 #undef BK_PICK
-    const uint32_t fold_bx = (uint32_t)std::min<uint64_t>(1024, ((uint64_t)f.n_lds_bins + kL2Block - 1) / kL2Block);
-    const uint32_t fold_by = f.n_lds_bins ? std::max(1u, std::min(16u, f.n_slabs / 8)) : 0u;
     const uint64_t blks = (a.n_records + 32 * kAnyWords - 1) / (32 * kAnyWords);     // a wave takes kAnyWords words of l2_any at a time
-    const unsigned l2_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((blks + kL2Waves - 1) / kL2Waves, (uint64_t)n_cus * 8));
-    hipLaunchKernelGGL(kern, dim3(fold_bx * fold_by + l2_grid), dim3(kL2Block), 0, stream, a, f, fold_bx, fold_by);
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((blks + kL2Waves - 1) / kL2Waves, (uint64_t)n_cus * 8));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kL2Block), 0, stream, a);
     return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ K1c
+// slab[b][c] = (reads of workgroup b that contain the reference k-mer of cell c, along the reference) + 65536 * (against it)
+// E[2 id_at[c] + rc]     += sum over slabs of the low half   (rc = the cell's k-mer was reverse-complemented to become canonical:
+// E[2 id_at[c] + 1 - rc] += sum over slabs of the high half    a read along the reference has the k-mer as written), and
+__global__ __launch_bounds__(256) void fold_kernel(FoldArgs f) {
+    const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * 256;
+    // blockIdx.y splits the slabs into groups so that the 31 MB of slabs are streamed by the whole chip; each
+    // group adds its partial sums with one u64 atomic per non-zero half
+    const uint32_t per = (f.n_slabs + gridDim.y - 1) / gridDim.y;
+    const uint32_t b0 = blockIdx.y * per, b1 = min(f.n_slabs, b0 + per);
+    for (uint64_t i = tid; i < f.n_lds_bins && b0 < b1; i += nthreads) {
+        unsigned long long s0 = 0, s1 = 0;
+        for (uint32_t b = b0; b < b1; ++b) {
+            const unsigned int v = f.slabs[(size_t)b * f.n_lds_bins + i];
+            s0 += v & 0xffffu;
+            s1 += v >> 16;
+        }
+        if (s0 | s1) {
+            const uint64_t cell = f.win_lo + i;
+            const uint32_t id = f.id_at[cell];   // a counted cell always has a reference k-mer
+            const uint32_t rc = ((f.cell_codes[cell >> 4] >> (2 * (cell & 15))) & 3u) == 2u ? 1u : 0u;
+            if (s0) atomicAdd(f.counters + 2 * (size_t)id + rc, s0);
+            if (s1) atomicAdd(f.counters + 2 * (size_t)id + (1u - rc), s1);
+        }
+    }
+}
+
+void launch_fold(const FoldArgs& f, hipStream_t stream) {
+    const uint64_t work = f.n_lds_bins;
+    if (work == 0) return;
+    uint64_t blocks = (work + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    const unsigned groups = std::max(1u, std::min(16u, f.n_slabs / 8));
+    hipLaunchKernelGGL(fold_kernel, dim3((unsigned)blocks, groups), dim3(256), 0, stream, f);
 }
 
 // ------------------------------------------------------------------------------------------------ K2

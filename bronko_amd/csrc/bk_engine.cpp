@@ -986,6 +986,13 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->params.kmer_table_log2;
     a.ktab_overflow = e->ktab_out.p + 4; a.mate = (uint32_t)mate;
     a.occ = e->occ.p; a.n_files = e->n_files;
+    if (e->W <= 0) {
+        // empty window: nothing can touch the index (map_kmers finds no bucket, call.rs:1291-1307); KMC's total k-mer count is all
+        bk::launch_count_kmers(a, e->stream);
+        BK_HIP(hipGetLastError());
+        if (!n_records_dev) e->pushed_records[mate] += n;
+        return BK_OK;
+    }
     if (e->occ.p && !e->win_chosen && n > 0) {
         // first records of the sample vote for the genome they look like (one synchronisation per sample); the LDS window
         // goes on that genome and stays there for the sample.  Any choice gives the same counts -- this is about speed.

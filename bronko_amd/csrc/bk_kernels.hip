@@ -1126,6 +1126,24 @@ void launch_pick_window(const ScanArgs& a, uint64_t n_probe, unsigned int* votes
     hipLaunchKernelGGL(pick_window_kernel, dim3(64), dim3(256), 0, stream, a, n_probe, votes);
 }
 
+// Empty window (n_fixed * 2 + 1 >= k, call.rs:1291-1300): no k-mer can touch the index, only KMC's total is wanted.
+__global__ __launch_bounds__(256) void count_kmers_kernel(ScanArgs a) {
+    uint64_t n_records = a.n_records;
+    if (a.n_records_dev) n_records = min((uint64_t)*a.n_records_dev, a.n_records);
+    unsigned long long sum = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n_records; r += (uint64_t)gridDim.x * 256) {
+        const uint32_t len = a.lens[r];
+        if (len >= (uint32_t)a.k) sum += len - (uint32_t)a.k + 1u;
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((threadIdx.x & 63) == 0 && sum && a.kmer_total) atomicAdd(a.kmer_total, sum);
+}
+void launch_count_kmers(const ScanArgs& a, hipStream_t stream) {
+    if (a.n_records == 0) return;
+    hipLaunchKernelGGL(count_kmers_kernel, dim3((unsigned)std::min<uint64_t>(1024, (a.n_records + 255) / 256)), dim3(256), 0, stream, a);
+}
+
 // (12 KB of the CU's 160 KB are left free: a workgroup of another stream's finalize kernels fits next to the scan's)
 size_t scan_lds_budget() { return 148u * 1024u - 64u - kScanLdsFixed - sizeof(unsigned int); }
 // LDS bytes of the per-cell arrays Level 1 stages for `cells` cells (reference 2 bits, one 1-bit array, paddings)

@@ -564,3 +564,31 @@ def test_forked_engines_take_samples_in_turn(oracle, hpv):
                 assert done[si].kmer_stats[0, 1] == want[si].kmc_stats[0, 1]
     finally:
         fork.close()
+
+
+def test_empty_window_counts_kmers_and_touches_nothing(oracle):
+    """n_fixed * 2 + 1 >= k (call.rs:1291-1300): the window slice is empty, nothing maps, KMC's k-mer total is still reported;
+    a multi-file index at k = 11 (this combination once sent the window vote through tables that do not exist)."""
+    from bronko_amd import Params
+    base = synth.read_fasta_bytes(os.path.join(helpers.GOLDEN, "HPV16.fa"))[:2500]
+    files = [("f%d" % i, [("s%d" % i, base[i * 300:i * 300 + 1500])]) for i in range(3)]
+    ix = oracle.Index.build_mem(11, files)
+    eng = helpers.engine_from_oracle_index(ix, Params(n_fixed=5, ci=1))
+    reads = [base[i:i + 150] for i in range(0, 2300, 7)] + [b"ACGTACGTAC", b"", b"N" * 40]
+    res = helpers.hip_sample(eng, [reads], 11)
+    pile = oracle.sample_pileup(ix, [reads], n_fixed=5, ci=1)
+    helpers.assert_same_pileup(res, pile)
+    assert res.kmer_stats[0, 1] == pile.kmc_stats[0, 1] > 0 and int(res.fwd_nk.sum()) == 0
+    eng.close()
+    ix.close()
+
+
+def test_randomised_indexes_and_reads():
+    """tools/fuzz_parity.py: random small indexes (repeats, reverse-complement repeats, homopolymers, several sequences /
+    files, k = 11..31, window variants incl. empty and full) x random read sets (20..400 bp, up to 12 % substitutions, indels,
+    chimeras, foreign reads, N), ci = 1, HIP path vs oracle bit for bit.  A short run here; 2000 iterations were clean."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "60", "11"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]

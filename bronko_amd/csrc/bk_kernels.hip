@@ -1126,14 +1126,29 @@ void launch_pick_window(const ScanArgs& a, uint64_t n_probe, unsigned int* votes
     hipLaunchKernelGGL(pick_window_kernel, dim3(64), dim3(256), 0, stream, a, n_probe, votes);
 }
 
-// Empty window (n_fixed * 2 + 1 >= k, call.rs:1291-1300): no k-mer can touch the index, only KMC's total is wanted.
+// Empty window (n_fixed * 2 + 1 >= k, call.rs:1291-1300): no k-mer can touch the index.  KMC's total is still wanted, and with
+// full_kmer_stats its distinct / kept k-mer counts: every k-mer of every record goes into the statistics table (one thread per
+// record, rolling canonical k-mer -- this configuration maps nothing, speed is not a concern).
 __global__ __launch_bounds__(256) void count_kmers_kernel(ScanArgs a) {
     uint64_t n_records = a.n_records;
     if (a.n_records_dev) n_records = min((uint64_t)*a.n_records_dev, a.n_records);
+    const KmerTable kt{a.ktab_keys, a.ktab_cnt, a.ktab_log2, a.ktab_overflow, a.mate};
+    const int k = a.k;
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull;
     unsigned long long sum = 0;
     for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n_records; r += (uint64_t)gridDim.x * 256) {
         const uint32_t len = a.lens[r];
-        if (len >= (uint32_t)a.k) sum += len - (uint32_t)a.k + 1u;
+        if (len < (uint32_t)k) continue;
+        sum += len - (uint32_t)k + 1u;
+        if (!kt.keys) continue;
+        const uint32_t* w = a.words + r * a.stride_words;
+        uint64_t f = 0, rc = 0;
+        for (uint32_t i = 0; i < len; ++i) {
+            const uint64_t b = (w[i >> 4] >> (2u * (i & 15u))) & 3u;
+            f = ((f << 2) | b) & kmask;
+            rc = (rc >> 2) | ((3ull - b) << (2 * (k - 1)));
+            if (i + 1u >= (uint32_t)k) ktab_insert(kt, f < rc ? f : rc, f < rc ? 0u : 1u, 1u);   // lcb.rs:90-94
+        }
     }
 #pragma unroll
     for (int off = 32; off; off >>= 1) sum += __shfl_xor(sum, off);

@@ -56,7 +56,15 @@ for it in range(first, first + iters):
         continue
     n_fixed = int(rng.choice([2, 2, 0, 1, 5]))
     full = bool(rng.random() < 0.15)
-    prm = Params(ci=1, n_fixed=n_fixed, use_full_kmer=int(full))
+    # how the engine is driven: exact k-mer statistics table, a small LDS window (cells outside it go through Level 2), the
+    # reference read from global memory, pushes split into several launches
+    stats = bool(rng.random() < 0.25)
+    prm = Params(ci=int(rng.choice([1, 1, 1, 2, 3])), n_fixed=n_fixed, use_full_kmer=int(full), full_kmer_stats=stats, kmer_table_log2=21)
+    for var in ("BK_LDS_BINS", "BK_REF_IN_LDS", "BK_MAX_LAUNCH_RECORDS"):
+        os.environ.pop(var, None)
+    if rng.random() < 0.2: os.environ["BK_LDS_BINS"] = str(int(rng.integers(64, 2000)))
+    if rng.random() < 0.1: os.environ["BK_REF_IN_LDS"] = "0"
+    if rng.random() < 0.2: os.environ["BK_MAX_LAUNCH_RECORDS"] = str(int(rng.integers(1, 700)))
     eng = helpers.engine_from_oracle_index(ix, prm)
     src = mutate(rng, base, int(rng.integers(0, 12)))
     reads = []
@@ -79,14 +87,24 @@ for it in range(first, first + iters):
         if rng.random() < 0.5: r = r.translate(COMP)[::-1]
         reads.append(r)
     if os.environ.get("FUZZ_VERBOSE"): print("it=%d k=%d n_fixed=%d full=%d files=%d cells=%d reads=%d err=%.3f maxlen=%d" % (it, k, n_fixed, full, len(files), sum(len(s[1]) for f in files for s in f[1]), len(reads), err, max(len(r) for r in reads)), flush=True)
-    res = helpers.hip_sample(eng, [reads], k)
-    pile = orc.sample_pileup(ix, [reads], n_fixed=n_fixed, use_full_kmer=full, ci=1)
+    mates = [reads]
+    if rng.random() < 0.3 and len(reads) > 1:                                           # paired: two mate files
+        h = len(reads) // 2
+        mates = [reads[:h], reads[h:]]
+    batch = int(rng.integers(1, 500)) if rng.random() < 0.3 else None
+    ascii_path = bool(rng.random() < 0.3)
+    res = helpers.hip_sample(eng, mates, k, batch=batch, ascii_path=ascii_path)
+    pile = orc.sample_pileup(ix, mates, n_fixed=n_fixed, use_full_kmer=full, ci=int(prm.ci))
     try:
         helpers.assert_same_pileup(res, pile)
-        assert res.kmer_stats[0, 1] == pile.kmc_stats[0, 1]
+        assert res.kmer_stats[:, 1].tolist() == pile.kmc_stats[:, 1].tolist(), ("total k-mers", res.kmer_stats[:, 1], pile.kmc_stats[:, 1])
+        if stats:
+            assert res.kmer_stats[:, 2:4].tolist() == pile.kmc_stats[:, 2:4].tolist(), ("kmc stats", res.kmer_stats, pile.kmc_stats)
     except AssertionError as e:
         bad += 1
-        print("MISMATCH it=%d seed=%d k=%d n_fixed=%d full=%d files=%d reads=%d err=%.3f: %s" % (it, seed0, k, n_fixed, full, len(files), len(reads), err, str(e)[:200]), flush=True)
+        print("MISMATCH it=%d seed=%d k=%d n_fixed=%d full=%d files=%d reads=%d err=%.3f mates=%d batch=%s ascii=%d stats=%d env=%s: %s" %
+              (it, seed0, k, n_fixed, full, len(files), len(reads), err, len(mates), batch, ascii_path, stats,
+               {v: os.environ[v] for v in ("BK_LDS_BINS", "BK_REF_IN_LDS", "BK_MAX_LAUNCH_RECORDS") if v in os.environ}, str(e)[:300]), flush=True)
     eng.close(); ix.close()
 print("%d iterations, %d mismatches, %.0f s" % (iters, bad, time.time() - t0))
 sys.exit(1 if bad else 0)

@@ -45,7 +45,7 @@ for it in range(first, first + iters):
     k = int(rng.choice([11, 15, 19, 21, 21, 21, 25, 31, 31]))
     base = make_genome(rng, int(rng.integers(300, 6000)))
     files = []
-    for f in range(int(rng.integers(1, 4))):
+    for f in range(int(rng.choice([1, 1, 2, 2, 3, 3, 5, 8]))):
         g = base if f == 0 else mutate(rng, base, int(rng.integers(0, 30)))
         cuts = sorted(set([0, len(g)] + [int(x) for x in rng.integers(0, len(g), int(rng.integers(0, 3)))]))
         seqs = [("s%d_%d" % (f, i), g[a:b]) for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])) if b - a >= 1]

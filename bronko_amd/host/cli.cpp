@@ -385,20 +385,27 @@ int run_call(const Args& a) {
     std::vector<OverviewRow> overview;
     std::vector<SampleCalls> all_calls;   // --alignment
 
-    // one sample = one -r file (call.rs:213-293) or one R1/R2 pair (call.rs:298-386); outputs are named after R1
-    auto process = [&](const std::vector<std::string>& mates) {
-        const int n_mates = (int)mates.size();
-        hip_check(bk_sample_begin(eng.e), "bk_sample_begin");
+    // one sample = one -r file (call.rs:213-293) or one R1/R2 pair (call.rs:298-386); outputs are named after R1.
+    // A sample has two halves: ingest (parse the FASTQ files, push the reads: host-bound, the scan runs behind it) and
+    // complete (finalize on the GPU, download, pick the genome, call variants, write the files).  With several samples the two
+    // halves of consecutive samples overlap: sample i+1 is ingested into a second engine on the same device tables
+    // (bk_engine_fork) while a worker thread completes sample i.  Results are reported in input order.
+    auto ingest = [&](bk_engine* e, const std::vector<std::string>& mates) -> uint64_t {
+        hip_check(bk_sample_begin(e), "bk_sample_begin");
         uint64_t total_reads = 0;
-        try { total_reads = push_fastqs(eng.e, mates); }
-        catch (const std::exception& e) { die(T, e.what()); }
+        try { total_reads = push_fastqs(e, mates); }
+        catch (const std::exception& ex) { die(T, ex.what()); }
         LOG_INFO(T, std::to_string(total_reads) + " reads counted from " + mates[0]);
+        return total_reads;
+    };
+    auto complete = [&](bk_engine* e, const std::vector<std::string>& mates) {
+        const int n_mates = (int)mates.size();
         Pileup p;
         p.fwd_depth.resize(cells4); p.rev_depth.resize(cells4); p.fwd_nk.resize(cells4); p.rev_nk.resize(cells4);
         std::vector<uint64_t> stats((size_t)n_mates * n_files * 3), kstats((size_t)n_mates * 4);
         std::vector<uint8_t> present((size_t)n_mates * n_files);
-        LOG_INFO(T, "Mapping kmers to all genomes");
-        hip_check(bk_sample_finish(eng.e, n_mates, p.fwd_depth.data(), p.rev_depth.data(), p.fwd_nk.data(), p.rev_nk.data(),
+        LOG_INFO(T, "Mapping kmers to all genomes (" + mates[0] + ")");
+        hip_check(bk_sample_finish(e, n_mates, p.fwd_depth.data(), p.rev_depth.data(), p.fwd_nk.data(), p.rev_nk.data(),
                                    stats.data(), present.data(), kstats.data()), "bk_sample_finish");
         p.stats.assign(n_files * 3, 0);
         p.present.assign(n_files, 0);
@@ -430,16 +437,27 @@ int run_call(const Args& a) {
             if (a.pileup) { LOG_INFO(T, "Writing output to pileup"); write_pileup_tsv(a.output + "/" + stem + ".tsv", ix, best, p); }
             LOG_INFO(T, "Writing output to VCF");
             write_vcf(a.output + "/" + stem + ".vcf", mates[0], ix, best, cs.records);
-        } catch (const std::exception& e) { die(T, e.what()); }
+        } catch (const std::exception& ex) { die(T, ex.what()); }
         overview.push_back(OverviewRow{mates[0], gname, cs.n_major, cs.n_minor, cs.breadth, cs.depth, n_perfect, n_variant, n_unmapped});
         if (a.alignment) all_calls.push_back(SampleCalls{mates[0], gname, cs.breadth, cs.records});
     };
 
-    for (const auto& r : a.reads) { LOG_INFO(T, "Processing " + r); process({r}); }
-    for (size_t i = 0; i < a.first_pairs.size(); i++) {
-        LOG_INFO(T, "Processing paired reads " + a.first_pairs[i] + ", " + a.second_pairs[i]);
-        process({a.first_pairs[i], a.second_pairs[i]});
+    std::vector<std::vector<std::string>> samples;
+    for (const auto& r : a.reads) samples.push_back({r});
+    for (size_t i = 0; i < a.first_pairs.size(); i++) samples.push_back({a.first_pairs[i], a.second_pairs[i]});
+    Engine fork;
+    if (samples.size() > 1) hip_check(bk_engine_fork(eng.e, &fork.e), "bk_engine_fork");
+    std::thread worker;     // completes the previous sample
+    for (size_t i = 0; i < samples.size(); i++) {
+        const auto& mates = samples[i];
+        LOG_INFO(T, mates.size() == 1 ? "Processing " + mates[0] : "Processing paired reads " + mates[0] + ", " + mates[1]);
+        bk_engine* e = (i & 1) ? fork.e : eng.e;     // (its previous sample, i - 2, was completed before sample i - 1's worker started)
+        ingest(e, mates);
+        if (worker.joinable()) worker.join();
+        worker = std::thread([&complete, e, &mates] { complete(e, mates); });
     }
+    if (worker.joinable()) worker.join();
+    if (fork.e) { bk_engine_destroy(fork.e); fork.e = nullptr; }   // (the fork goes before its parent)
     LOG_INFO(T, "Printing overview");
     try { write_overview_tsv(a.output + "/bronko_overview.tsv", overview); }
     catch (const std::exception& e) { die(T, e.what()); }

@@ -151,3 +151,33 @@ def test_call_alignment_mfa(oracle, golden_dir, tmp_path):
     got = open(os.path.join(out, "HPV16.mfa")).read().splitlines()
     assert got == want
     ix.close()
+
+
+def test_call_three_samples_overlapped(oracle, golden_dir, tmp_path):
+    """Several samples in one run: sample i+1 is ingested into a forked engine while a worker thread completes sample i
+    (cli.cpp).  Every sample's VCF and pileup TSV must equal the oracle's, and bronko_overview.tsv keeps the input order."""
+    g = synth.read_fasta_bytes(os.path.join(golden_dir, "HPV16.fa"))
+    ix = oracle.Index.load(os.path.join(golden_dir, "hpv.bkdb"))
+    paths, samples = [], []
+    for i in range(3):
+        gm, isnv = synth.sample_genome(g, 70 + i, n_snp=3 + 2 * i, n_isnv=3)
+        reads = synth.codes_to_ascii(synth.single_end_codes(gm, 7000 + 2500 * i, 150, 170 + i, isnv=isnv))
+        p = str(tmp_path / ("multi%d.fastq.gz" % i))
+        write_fastq_gz(p, reads, "m%d" % i)
+        paths.append(p)
+        samples.append(reads)
+    out = str(tmp_path / "out")
+    res = subprocess.run([BRONKO, "call", "-d", os.path.join(golden_dir, "hpv.bkdb"), "-r"] + paths + ["--pileup", "-o", out],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    odir = str(tmp_path / "oracle")
+    os.makedirs(odir)
+    ov = open(os.path.join(out, "bronko_overview.tsv")).read().splitlines()
+    assert [line.split("\t")[0] for line in ov[1:]] == paths
+    for i in range(3):
+        stem, best, n, ov_want = oracle_outputs(oracle, ix, [samples[i]], odir, paths[i])
+        for ext in (".vcf", ".tsv"):
+            assert open(os.path.join(out, stem + ext), "rb").read() == open(os.path.join(odir, stem + ext), "rb").read(), (i, ext)
+        perfect, variant, unmapped, nmaj, nmin, br, dc = ov_want
+        assert ov[1 + i].split("\t")[2:] == [str(nmaj), str(nmin), "%.4f" % br, "%.4f" % dc, str(perfect), str(variant), str(unmapped)]
+    ix.close()

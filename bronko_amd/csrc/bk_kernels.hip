@@ -1531,22 +1531,32 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         const uint64_t wk = qrow * 8 + (u & 7ull);
         const bool in_row = qrow < nq && wk >= row_lo && wk < row_hi && oo < rl;
         unsigned long long n = in_row ? vc[wk * rl + oo] : 0ull;
+        // Everything else this lane may need depends on the row's coordinates only, not on its counts: the loads are issued
+        // together with the row's (one round trip instead of three dependent ones) -- the reference k-mer, its flags, and
+        // the bucket record at both window positions the offset can stand for (the k-mer as written / reverse-complemented)
+        const uint32_t d = (uint32_t)wk & 1u, bf = (uint32_t)(wk >> 1) & 3u, q = (uint32_t)(wk >> 3);
+        const bool inq = in_row && oo < (uint32_t)ix.v_span && q >= oo && q - oo < ix.n_full;
+        const uint32_t p = inq ? q - oo : 0u;
+        const uint32_t ambp = ix.amb[p];
+        const uint64_t kmer_p = ix.kmer_of[p];
+        const int o = (int)oo + ix.v_omin;
+        const int t_fw = o - ix.wstart, t_rc = k - 1 - o - ix.wstart;
+        const bool in_fw = inq && t_fw >= 0 && t_fw < ix.W, in_rc = inq && t_rc >= 0 && t_rc < ix.W;
+        const uint4 r_fw = in_fw ? *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)p * ix.W + t_fw) : make_uint4(0, 0, 0, 0);
+        const uint4 r_rc = in_rc ? *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)p * ix.W + t_rc) : make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int off = 1; off < 32; off <<= 1) {
             const unsigned long long t = __shfl_up(n, off, 32);
             if (oo >= (uint32_t)off) n += t;
         }
-        const uint32_t d = (uint32_t)wk & 1u, bf = (uint32_t)(wk >> 1) & 3u, q = (uint32_t)(wk >> 3);
-        bool act = in_row && oo < (uint32_t)ix.v_span && n != 0 && q >= oo && q - oo < ix.n_full;
-        const uint32_t p = act ? q - oo : 0u;
-        const uint32_t rcid = (ix.amb[p] >> 1) & 1u;
-        const bool dirty = ix.amb[p] & 1u;
-        const int o = (int)oo + ix.v_omin;
+        bool act = inq && n != 0;
+        const uint32_t rcid = (ambp >> 1) & 1u;
+        const bool dirty = ambp & 1u;
         const int j = rcid ? k - 1 - o : o;
         const uint32_t bb = rcid ? 3u - bf : bf;
         const uint32_t isrc = d ^ rcid;
         const int sh = 2 * (k - 1 - (act ? j : 0));
-        const uint64_t c = (ix.kmer_of[p] & ~(3ull << sh)) | ((uint64_t)bb << sh);
+        const uint64_t c = (kmer_p & ~(3ull << sh)) | ((uint64_t)bb << sh);
         const uint64_t rc = revcomp_kmer(c, k);
         const bool alive = j >= ix.wstart && j < ix.wstart + ix.W && c < rc;
         if (act && !alive) {
@@ -1567,7 +1577,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
                 act = false;
             }
         }
-        const uint4 r = act ? *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)p * ix.W + t) : make_uint4(0, 0, 0, 0);
+        const uint4 r = act ? (rcid ? r_rc : r_fw) : make_uint4(0, 0, 0, 0);
         const uint32_t cnt = r.y;
         DevEntry first;
         first.cell = r.z; first.file = (uint16_t)(r.w & 0xffffu); first.idx = (uint8_t)(r.w >> 16); first.canonical = (uint8_t)(r.w >> 24);

@@ -48,7 +48,8 @@ BK_HD uint32_t hash_key(uint64_t key, uint32_t log2s) {
 // another lane's collisions.
 BK_HD uint32_t phf_bucket(uint64_t x, uint32_t log2nb) { return hash_key(x, log2nb); }
 BK_HD uint32_t phf_pos(uint64_t x, uint32_t pilot, uint32_t m) {
-    uint32_t h = (uint32_t)((x * 0xD6E8FEB86659FD93ull) >> 32) ^ (pilot * 0x9E3779B1u);
+    // (the pilot enters before the multiplication: two keys whose products agree in the upper half for one pilot part for another)
+    uint32_t h = (uint32_t)(((x ^ ((uint64_t)pilot * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull) >> 32);
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return (uint32_t)(((uint64_t)h * m) >> 32);
 }

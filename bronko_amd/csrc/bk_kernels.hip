@@ -1415,7 +1415,7 @@ __device__ __forceinline__ void v_kmer_of_counter(const IndexView& ix, const uns
     c = (ix.kmer_of[p] & ~(3ull << sh)) | ((uint64_t)bb << sh);
 }
 
-// K2a: the V counters.  Half a wave (a quarter when a row holds <= 16 counts) per row of the reference k-mers' part (lane = offset; the running sums of the row's
+// K2a: the V counters.  v_span lanes per row of the reference k-mers' part (lane = offset; the running sums of the row's
 // difference array -- each k-mer's count -- by shuffles) and one thread per counter of the pseudo k-mers' part.  A kept non-reference k-mer almost
 // always touches exactly one window bucket (the one its name says); then the whole of map_kmers for it is: vote once per
 // BucketInfo of that bucket, and per genome file "variant" (or "perfect" if the file has exactly W entries there, which
@@ -1424,7 +1424,6 @@ __device__ __forceinline__ void v_kmer_of_counter(const IndexView& ix, const uns
 // A row also holds k-mers that cannot touch the index: the difference outside the window, or a k-mer whose canonical form
 // lies on the other strand than its neighbour's (scan_count records what the reads contain, not what it means).  They are
 // skipped -- with full_kmer_stats they join the k-mer statistics table, like every other k-mer that touches nothing.
-template <int LPR>   // lanes per row: 16 when the rows hold <= 16 counts (the slot behind them is never read), else 32
 __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const IndexView& ix = a.ix;
@@ -1517,21 +1516,28 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
     };
 
-    // LPR lanes per row, lane oo = offset: the row's prefix sums by shuffles, then every lane maps its own
+    // v_span lanes per row, lane oo = offset: the row's prefix sums by shuffles, then every lane maps its own
     // k-mer.  A workgroup takes 8 rows with the same base and direction and q, q + 2, ..., q + 14: the k-mers of a row that
     // are canonical as written all vote for one pileup cell (the reference position the row stands for), and those that
     // were reverse-complemented vote for cells that rows q and q + 2 share (their vote mirrors the offset, call.rs:1331-1357)
     // -- the workgroup's vote table (LDS) merges both kinds before anything goes to the pileup.
-    const uint32_t oo = threadIdx.x & (uint32_t)(LPR - 1);
-    const uint32_t hw = threadIdx.x / (uint32_t)LPR;             // part of the workgroup that takes one row: 0..RPW-1
-    constexpr uint32_t RPW = 256 / LPR;                          // rows per workgroup and unit
+    // A row holds v_span counts (the slot behind them is never read): as many rows share a wave as fit, lanes [g * v_span,
+    // (g + 1) * v_span) take row g (17 counts: three rows per wave, one lane idle).
+    const uint32_t lpr = (uint32_t)ix.v_span;                    // lanes per row (<= 32: k <= 31)
+    const uint32_t gpw = 64u / lpr;                              // rows per wave
+    const uint32_t lane64 = threadIdx.x & 63u;
+    const uint32_t grp = lane64 / lpr;
+    const uint32_t oo = lane64 - grp * lpr;
+    const bool lane_on = grp < gpw;
+    const uint32_t hw = (threadIdx.x >> 6) * gpw + grp;          // which of the workgroup's rows
+    const uint32_t RPW = 4u * gpw;                               // rows per workgroup and unit
     const uint64_t nq = (uint64_t)ix.n_full + (uint32_t)ix.v_span;
     const uint64_t n_units = ((nq + 2 * RPW - 1) / (2 * RPW)) * 16;   // unit u: q block u / 16 (2 RPW values of q), parity (u / 8) & 1, (base, direction) u & 7
     uint32_t par = 0;
     for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         const uint64_t qrow = (u >> 4) * (2 * RPW) + ((u >> 3) & 1ull) + 2ull * hw;
         const uint64_t wk = qrow * 8 + (u & 7ull);
-        const bool in_row = qrow < nq && wk >= row_lo && wk < row_hi && oo < rl;
+        const bool in_row = lane_on && qrow < nq && wk >= row_lo && wk < row_hi;
         unsigned long long n = in_row ? vc[wk * rl + oo] : 0ull;
         // Everything else this lane may need depends on the row's coordinates only, not on its counts: the loads are issued
         // together with the row's (one round trip instead of three dependent ones) -- the reference k-mer, its flags, and
@@ -1547,8 +1553,8 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         const uint4 r_fw = in_fw ? *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)p * ix.W + t_fw) : make_uint4(0, 0, 0, 0);
         const uint4 r_rc = in_rc ? *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)p * ix.W + t_rc) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int off = 1; off < LPR; off <<= 1) {
-            const unsigned long long t = __shfl_up(n, off, LPR);
+        for (int off = 1; off < 32; off <<= 1) {
+            const unsigned long long t = __shfl_up(n, off, 64);   // (lane - off is in the same row whenever oo >= off)
             if (oo >= (uint32_t)off) n += t;
         }
         bool act = inq && n != 0;
@@ -1813,12 +1819,11 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     FinalizeArgs a = a0;
     const size_t lds_stats = ((size_t)a.ix.n_files * 3 + 2) * sizeof(uint32_t);
     // K2a
-    const bool narrow = a.ix.v_span <= 16;   // 16 lanes per row
-    const uint64_t n_v = std::max<uint64_t>(v_real_rows(a.ix.n_full, a.ix.v_span) * (narrow ? 16ull : 32ull), a.ix.n_prows * 8ull);   // threads K2a can use
+    const uint64_t rows_per_group = 4ull * (64ull / (uint64_t)std::max(a.ix.v_span, 1));   // rows a workgroup takes at a time
+    const uint64_t n_v = std::max<uint64_t>((v_real_rows(a.ix.n_full, a.ix.v_span) + rows_per_group - 1) / rows_per_group * 256ull, a.ix.n_prows * 8ull);   // threads K2a can use
     const unsigned b_var = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_v + 255) / 256, kFinVariantBlocks));
     const size_t lds_votes = (lds_stats + 15) / 16 * 16 + kVoteLdsBytes;
-    if (narrow) hipLaunchKernelGGL(finalize_variant_kernel<16>, dim3(b_var), dim3(256), lds_votes, stream, a);
-    else hipLaunchKernelGGL(finalize_variant_kernel<32>, dim3(b_var), dim3(256), lds_votes, stream, a);
+    hipLaunchKernelGGL(finalize_variant_kernel, dim3(b_var), dim3(256), lds_votes, stream, a);
     // K2e
     const uint64_t n_work = e_plane_len(a.ix.n_u) * (uint64_t)a.ix.W;
     const unsigned b_ex = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_work + 255) / 256, kFinExactBlocks));

@@ -196,7 +196,7 @@ uint64_t bk_pack_reads_flat(const uint8_t* buf, const uint64_t* offsets, uint64_
 /* ---- measurement ------------------------------------------------------------------------------------------
  * When enabled, every kernel launch is bracketed by HIP events on the launch stream.  bk_timing_read
  * synchronises and returns accumulated milliseconds and launch counts since the last reset:
- *   [0] scan_count kernel, [1] finalize kernel, [2] memsets + H2D/D2H copies, [3] fold kernel.
+ *   [0] scan_count kernel, [1] finalize kernels, [2] memsets + H2D/D2H copies, [3] level2 + fold kernels.
  * on = 1 brackets all four kinds; on = 2 << kind (or-able) only the selected ones, e.g. 2 = the scan kernel alone
  * (two event records per launch instead of ten per sample). */
 int bk_timing_enable(bk_engine* e, int on);

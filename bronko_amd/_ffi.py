@@ -4,6 +4,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbronko_hip.so")
+# the -DBK_TESTING build of the same sources: BK_* environment variables that force a code path exist only there
+TESTING_LIB_PATH = os.path.join(_HERE, "libbronko_hip_testing.so")
 
 
 class BucketInfo(C.Structure):  # include/bronko_hip.h bk_bucket_info == build.rs:52-60
@@ -31,17 +33,26 @@ SYMBOLS = ["bk_abi_version", "bk_last_error", "bk_params_default", "bk_engine_cr
            "bk_pileup_device_ptr", "bk_sample_download", "bk_sample_finish", "bk_pack_reads", "bk_pack_reads_flat",
            "bk_timing_enable", "bk_timing_read"]
 
-_lib = None
+_libs = {}
+_testing = False
 
 
-def load():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def use_testing_library(flag=True):
+    """Engines created from now on bind libbronko_hip_testing.so (tests that force a path through a BK_* variable, profiling
+    tools); the product and bench.py never call this."""
+    global _testing
+    _testing = bool(flag)
+
+
+def load(testing=None):
+    testing = _testing if testing is None else bool(testing)
+    if testing in _libs:
+        return _libs[testing]
+    path = TESTING_LIB_PATH if testing else LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError("bronko_amd: %s is missing -- build it with `make -C bronko_amd/csrc` "
-                           "(or python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+                           "(or python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % path)
+    L = C.CDLL(path)
     vp, u64, i32, u32 = C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32
     L.bk_abi_version.restype = C.c_int
     L.bk_last_error.restype = C.c_char_p
@@ -90,5 +101,5 @@ def load():
     L.bk_timing_enable.argtypes = [vp, C.c_int]
     L.bk_timing_read.restype = C.c_int
     L.bk_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), C.c_int]
-    _lib = L
+    _libs[testing] = L
     return L

@@ -78,9 +78,17 @@ void parallel_for(size_t n, F&& fn) {
     for (auto& t : th) t.join();
 }
 
-// BK_CREATE_TIMING=1: wall-clock of the phases of bk_engine_create on stderr (host-side table construction)
+// Testing / measurement aids exist only in the -DBK_TESTING build (libbronko_hip_testing.so, loaded by the tests that force a
+// path and by the profiling tools); the release library reads no environment variable.
+#ifdef BK_TESTING
+const char* test_env(const char* name) { return getenv(name); }
+#else
+const char* test_env(const char*) { return nullptr; }
+#endif
+
+// BK_CREATE_TIMING=1 (testing build): wall-clock of the phases of bk_engine_create on stderr (host-side table construction)
 struct PhaseClock {
-    bool on = getenv("BK_CREATE_TIMING") != nullptr;
+    bool on = test_env("BK_CREATE_TIMING") != nullptr;
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     void lap(const char* what) {
         if (!on) return;
@@ -146,41 +154,48 @@ bool unrank128(u128 r1, int k, uint64_t* v_out, int* pos_out) {
 // On success pos[i] is the position of keys[i] in a table of m >= n positions.
 bool build_phf(const std::vector<uint64_t>& keys, std::vector<uint16_t>& pilots, uint32_t& log2nb, uint32_t& m_out, std::vector<uint32_t>& pos) {
     const size_t n = keys.size();
-    log2nb = 0;
-    while ((4ull << log2nb) < n) log2nb++;
-    const size_t nb = (size_t)1 << log2nb;
-    std::vector<std::vector<uint32_t>> bucket(nb);
-    for (size_t i = 0; i < n; i++) bucket[bk::phf_bucket(keys[i], log2nb)].push_back((uint32_t)i);
-    std::vector<uint32_t> order(nb);
-    for (size_t i = 0; i < nb; i++) order[i] = (uint32_t)i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return bucket[a].size() > bucket[b].size(); });
-    uint64_t m = std::max<uint64_t>(64, (uint64_t)((double)n / 0.97) + 1);
+    uint32_t log2nb0 = 0;
+    while ((4ull << log2nb0) < n) log2nb0++;
     pos.assign(n, 0);
     std::vector<uint8_t> used;
     std::vector<uint32_t> trial;
-    for (int attempt = 0; attempt <= 20 && m < (1ull << 31); attempt++, m += m / 16 + 1) {
-        used.assign(m, 0);
-        pilots.assign(nb, 0);
-        bool ok = true;
-        for (uint32_t b : order) {
-            const auto& members = bucket[b];
-            if (members.empty()) break;
-            uint32_t pilot = 0;
-            for (; pilot < 65536; pilot++) {
-                trial.clear();
-                bool good = true;
-                for (uint32_t i : members) {
-                    const uint32_t p = bk::phf_pos(keys[i], pilot, (uint32_t)m);
-                    if (used[p] || std::find(trial.begin(), trial.end(), p) != trial.end()) { good = false; break; }
-                    trial.push_back(p);
+    // A construction can fail only when a bucket finds no pilot among 65536: first the table grows (m), then the buckets
+    // shrink (twice as many, half the keys each) -- the device reads both sizes from the view, so any outcome is a valid
+    // table; an index is never refused because of its hash.
+    for (uint32_t extra = 0; extra <= 6; extra++) {
+        log2nb = log2nb0 + extra;
+        if (log2nb > 30) break;
+        const size_t nb = (size_t)1 << log2nb;
+        std::vector<std::vector<uint32_t>> bucket(nb);
+        for (size_t i = 0; i < n; i++) bucket[bk::phf_bucket(keys[i], log2nb)].push_back((uint32_t)i);
+        std::vector<uint32_t> order(nb);
+        for (size_t i = 0; i < nb; i++) order[i] = (uint32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return bucket[a].size() > bucket[b].size(); });
+        uint64_t m = std::max<uint64_t>(64, (uint64_t)((double)n / 0.97) + 1);
+        for (int attempt = 0; attempt <= 8 && m < (1ull << 31); attempt++, m += m / 8 + 1) {
+            used.assign(m, 0);
+            pilots.assign(nb, 0);
+            bool ok = true;
+            for (uint32_t b : order) {
+                const auto& members = bucket[b];
+                if (members.empty()) break;
+                uint32_t pilot = 0;
+                for (; pilot < 65536; pilot++) {
+                    trial.clear();
+                    bool good = true;
+                    for (uint32_t i : members) {
+                        const uint32_t p = bk::phf_pos(keys[i], pilot, (uint32_t)m);
+                        if (used[p] || std::find(trial.begin(), trial.end(), p) != trial.end()) { good = false; break; }
+                        trial.push_back(p);
+                    }
+                    if (good) break;
                 }
-                if (good) break;
+                if (pilot == 65536) { ok = false; break; }
+                pilots[b] = (uint16_t)pilot;
+                for (size_t q = 0; q < members.size(); q++) { pos[members[q]] = trial[q]; used[trial[q]] = 1; }
             }
-            if (pilot == 65536) { ok = false; break; }
-            pilots[b] = (uint16_t)pilot;
-            for (size_t q = 0; q < members.size(); q++) { pos[members[q]] = trial[q]; used[trial[q]] = 1; }
+            if (ok) { m_out = (uint32_t)m; return true; }
         }
-        if (ok) { m_out = (uint32_t)m; return true; }
     }
     return false;
 }
@@ -352,6 +367,12 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(BK_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
     if (prm->device < 0 || prm->device >= ndev) return fail(BK_ERR_NO_DEVICE, "device %d not present (%d visible)", prm->device, ndev);
     BK_HIP(hipSetDevice(prm->device));
+    {
+        hipDeviceProp_t prop;
+        BK_HIP(hipGetDeviceProperties(&prop, prm->device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)   // the kernels are built for gfx950 only
+            return fail(BK_ERR_NO_DEVICE, "device %d is %s, not gfx950 (MI355X); this library has no other code path", prm->device, prop.gcnArchName);
+    }
 
     std::unique_ptr<bk_engine> e(new bk_engine());
     e->params = *prm;
@@ -720,7 +741,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         // perfect hash over U
         std::vector<uint16_t> h_pilots;
         std::vector<uint32_t> u_pos;
-        if (!build_phf(h_u, h_pilots, e->log2nb, e->m, u_pos)) return fail(BK_ERR_UNSUPPORTED, "perfect hash construction failed");
+        if (!build_phf(h_u, h_pilots, e->log2nb, e->m, u_pos)) return fail(BK_ERR_HIP, "internal error: perfect hash construction failed after every fallback");
         std::vector<bk::KmerPos> t_pos(e->m, bk::KmerPos{bk::kEmptyKey, kNone, 0u});
         std::vector<uint64_t> h_kmer_of(std::max<size_t>(h_u.size(), 1), bk::kEmptyKey);
         for (size_t i = 0; i < h_u.size(); i++) {
@@ -796,7 +817,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             build_half(1);
             t0.join();
             for (int which = 0; which < 2; which++) {
-                if (!hh[which].ok) return fail(BK_ERR_UNSUPPORTED, "perfect hash construction failed");
+                if (!hh[which].ok) return fail(BK_ERR_HIP, "internal error: perfect hash construction failed after every fallback");
                 bk_engine::HalfBufs& hb = which == 0 ? e->half_lo : e->half_hi;
                 BK_HIP(hb.pilots.upload(hh[which].hp));
                 BK_HIP(hb.dir.upload(hh[which].dir));
@@ -858,14 +879,14 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         // LDS holds, for the first n_lds_bins cells (the first genome(s) of the index): the difference array (4 B per cell) and
         // Level 1's copies of the per-cell arrays (2 + 1 bits per cell).  As many cells as fit.
         e->ref_in_lds = true;
-        if (const char* rl = getenv("BK_REF_IN_LDS")) e->ref_in_lds = atoi(rl) != 0;
+        if (const char* rl = test_env("BK_REF_IN_LDS")) e->ref_in_lds = atoi(rl) != 0;
         uint64_t nb = std::min<uint64_t>(e->total_cells, budget / sizeof(unsigned int));
         if (e->ref_in_lds) {
             nb = std::min<uint64_t>(e->total_cells, budget * 8 / 35);   // 4.375 bytes per cell ...
             while (nb > 0 && nb * sizeof(unsigned int) + bk::scan_ref_lds_bytes((uint32_t)nb) > budget) nb -= std::min<uint64_t>(nb, 64);   // ... and the paddings
         }
         e->n_lds_bins = (uint32_t)nb;
-        if (const char* nl = getenv("BK_LDS_BINS")) e->n_lds_bins = std::min<uint32_t>(e->n_lds_bins, (uint32_t)atol(nl));
+        if (const char* nl = test_env("BK_LDS_BINS")) e->n_lds_bins = std::min<uint32_t>(e->n_lds_bins, (uint32_t)atol(nl));
     }
     pc.lap("estat + LDS policy");
 
@@ -877,8 +898,8 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     BK_HIP(e->entries.upload(h_ent));
     if (int rc = alloc_sample_state(e.get())) return rc;
     BK_HIP(e->d_view.upload(std::vector<bk::IndexView>(1, e->view())));
-    if (const char* ab = getenv("BK_SCAN_ABLATE")) e->ablate = atoi(ab);
-    if (const char* ml = getenv("BK_MAX_LAUNCH_RECORDS")) e->max_launch_records = strtoull(ml, nullptr, 10);
+    if (const char* ab = test_env("BK_SCAN_ABLATE")) e->ablate = atoi(ab);
+    if (const char* ml = test_env("BK_MAX_LAUNCH_RECORDS")) e->max_launch_records = strtoull(ml, nullptr, 10);
     pc.lap("uploads + buffers");
     *out = e.release();
     return BK_OK;
@@ -1004,7 +1025,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
         BK_HIP(hipStreamSynchronize(e->stream));
         int best = 0;
         for (int f = 1; f < e->n_files; f++) if (votes[f] > votes[best]) best = f;
-        if (const char* wf = getenv("BK_WINDOW_FILE")) best = std::max(0, std::min(e->n_files - 1, atoi(wf)));   // testing aid
+        if (const char* wf = test_env("BK_WINDOW_FILE")) best = std::max(0, std::min(e->n_files - 1, atoi(wf)));   // testing aid
         e->win_file = best;
         e->win_lo = e->file_cell_lo[best] & ~31u;
         e->win_chosen = true;
@@ -1036,7 +1057,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
         if (e->W > 0) {
             bk_engine::Span sp(e, 3);
             // the k-mers the scan left marked (it clears the marks it takes)
-            if (getenv("BK_L2_COUNT")) {   // debugging aid: how much is left to Level 2
+            if (test_env("BK_L2_COUNT")) {   // debugging aid: how much is left to Level 2
                 std::vector<unsigned int> hb((size_t)take * a.l2_words), ha((size_t)(take + 31) / 32);
                 BK_HIP(hipMemcpyAsync(hb.data(), e->l2_bits.p, hb.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));
                 BK_HIP(hipMemcpyAsync(ha.data(), e->l2_any.p, ha.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));

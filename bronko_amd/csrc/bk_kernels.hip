@@ -28,6 +28,13 @@
 
 namespace bk {
 
+// Measurement aids (ScanArgs::ablate) exist in the -DBK_TESTING build only; in the release library the tests fold away.
+#ifdef BK_TESTING
+#define BK_ABLATE(a, x) ((a).ablate == (x))
+#else
+#define BK_ABLATE(a, x) false
+#endif
+
 __device__ __forceinline__ int probe_table(const TableSlot* __restrict__ sub, uint32_t log2s, uint64_t key) {
     const uint32_t smask = (1u << log2s) - 1u;
     uint32_t h = hash_key(key, log2s);
@@ -581,7 +588,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 const bool have = (uint32_t)lane < nb2;
                 const bool cur = (ent >> 31) == parity;
                 olds -= (uint32_t)__popcll(__ballot(have && !cur));
-                if (a.ablate == 1) continue;
+                if (BK_ABLATE(a, 1)) continue;
                 const int src = (int)(ent & 63u);
                 const uint32_t s_first = (ent >> 6) & 0xffffu;
                 const uint32_t n2 = (ent >> 22) & 0xffu;
@@ -663,7 +670,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                         const uint32_t o_lo = fwd2 ? tpos - nm1 : o_first;       // fwd: later k-mers start later, the offset shrinks
                         const uint32_t o_hi = fwd2 ? tpos : o_first + nm1;
                         const int lo2 = max((int)o_lo, omin), hi2 = min((int)o_hi, omin + span - 1);
-                        if (lo2 <= hi2 && a.ablate != 2) {
+                        if (lo2 <= hi2 && !BK_ABLATE(a, 2)) {
                             const uint32_t idS = id_first + ddir * (uint32_t)s_lo;
                             unsigned long long* row = v_counters + v_row_base(idS + o_first - (uint32_t)omin, fwd2 ? br : 3u - br, fwd2 ? 0u : 1u, span);
                             atomicAdd(row + (lo2 - omin), 1ull);
@@ -993,7 +1000,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
                     const int from_right = dbits ? (__builtin_ctz(dbits) >> 1) : 16 + (__builtin_ctz(dbits_hi) >> 1);
                     const int bsh = 2 * from_right;             // the differing base, as the read has it
                     const uint32_t br = (bsh >= 32 ? f_hi >> (bsh - 32) : f_lo >> bsh) & 3u;
-                    if (a.ablate != 2)
+                    if (!BK_ABLATE(a, 2))
                         v_point(v_counters, id, fwd2 ? (uint32_t)(k - 1 - from_right) : (uint32_t)from_right, fwd2 ? br : 3u - br,
                                 fwd2 ? 0u : 1u, omin, span);
                 }
@@ -1003,7 +1010,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
                 // such a k-mer is neither a reference k-mer nor one base away from one (triangle inequality) -- it touches
                 // nothing (full_kmer_stats: only the statistics table wants it)
                 const bool dead = ok && n_diff == 2u && ((c3 >> t) & 1u);
-                const bool miss = valid && !simple && !(dead && !STATS) && a.ablate != 3;
+                const bool miss = valid && !simple && !(dead && !STATS) && !BK_ABLATE(a, 3);
                 const unsigned long long mm = __ballot(miss);
                 if (mm) {
                     if (miss) {
@@ -1823,6 +1830,12 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     const uint64_t n_v = std::max<uint64_t>((v_real_rows(a.ix.n_full, a.ix.v_span) + rows_per_group - 1) / rows_per_group * 256ull, a.ix.n_prows * 8ull);   // threads K2a can use
     const unsigned b_var = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_v + 255) / 256, kFinVariantBlocks));
     const size_t lds_votes = (lds_stats + 15) / 16 * 16 + kVoteLdsBytes;
+    const size_t lds = finalize_lds_bytes(a.ix.n_files);
+    if (lds_votes > 64 * 1024 || lds > 64 * 1024) {   // thousands of genome files: beyond the default dynamic LDS limit
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_variant_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_votes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_votes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     hipLaunchKernelGGL(finalize_variant_kernel, dim3(b_var), dim3(256), lds_votes, stream, a);
     // K2e
     const uint64_t n_work = e_plane_len(a.ix.n_u) * (uint64_t)a.ix.W;
@@ -1830,7 +1843,6 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     a.row_exact = (int)b_var;
     hipLaunchKernelGGL(finalize_exact_kernel, dim3(b_ex), dim3(256), lds_votes, stream, a);
     // K2b (deferred k-mers only; the kernel reads their number on the device)
-    const size_t lds = finalize_lds_bytes(a.ix.n_files);
     unsigned b_gen = (unsigned)std::min<size_t>(kFinGeneralBlocks, 256 * std::max<size_t>(1, (160u * 1024u) / lds));
     a.row_general = (int)(b_var + b_ex);
     hipLaunchKernelGGL(finalize_general_kernel, dim3(b_gen), dim3(64), lds, stream, a);

@@ -29,9 +29,9 @@ def lib_path():
     return _ffi.LIB_PATH
 
 
-def _check(rc):
+def _check(rc, L=None):
     if rc != 0:
-        raise BronkoError(rc, _ffi.load().bk_last_error().decode(errors="replace"))
+        raise BronkoError(rc, (L or _ffi.load()).bk_last_error().decode(errors="replace"))
 
 
 def Params(n_fixed=2, use_full_kmer=False, ci=3, cs=1000000, cx=1000000000, device=0, full_kmer_stats=False,
@@ -102,7 +102,7 @@ class Engine:
         d = _ffi.IndexDesc(k, len(ids), ids.ctypes.data, off.ctypes.data, ent.ctypes.data, len(ent), len(files),
                            n_seqs.ctypes.data, seq_lens.ctypes.data, C.addressof(ptrs))
         h = C.c_void_p()
-        _check(L.bk_engine_create(C.byref(d), C.byref(params), C.byref(h)))
+        _check(L.bk_engine_create(C.byref(d), C.byref(params), C.byref(h)), L)
         self.h = h
         self.k = k
         self.params = params
@@ -115,7 +115,7 @@ class Engine:
         """A second engine on the same device tables with its own counter planes, outputs and stream (bk_engine_fork):
         alternate independent samples over the two so that one's scan overlaps the other's finalize."""
         h = C.c_void_p()
-        _check(self._L.bk_engine_fork(self.h, C.byref(h)))
+        _check(self._L.bk_engine_fork(self.h, C.byref(h)), self._L)
         e = object.__new__(Engine)
         e._L, e.h, e.k, e.params = self._L, h, self.k, self.params
         e.n_files, e.total_cells, e.n_slots, e.counter_len = self.n_files, self.total_cells, self.n_slots, self.counter_len
@@ -134,14 +134,14 @@ class Engine:
             pass
 
     def set_stream(self, stream_ptr):
-        _check(self._L.bk_engine_set_stream(self.h, C.c_void_p(stream_ptr)))
+        _check(self._L.bk_engine_set_stream(self.h, C.c_void_p(stream_ptr)), self._L)
 
     def stream_ptr(self):
         """hipStream_t (as int) the engine launches on -- wrap it (torch.cuda.ExternalStream) to order other work with it."""
         return int(self._L.bk_engine_get_stream(self.h) or 0)
 
     def sample_begin(self):
-        _check(self._L.bk_sample_begin(self.h))
+        _check(self._L.bk_sample_begin(self.h), self._L)
 
     def push_reads(self, mate, words, lens):
         words = np.ascontiguousarray(words, np.uint32)
@@ -149,7 +149,7 @@ class Engine:
         if len(lens) == 0:
             return
         assert words.ndim == 2 and words.shape[0] == len(lens)
-        _check(self._L.bk_push_reads_packed(self.h, mate, words.ctypes.data, words.shape[1], lens.ctypes.data, len(lens)))
+        _check(self._L.bk_push_reads_packed(self.h, mate, words.ctypes.data, words.shape[1], lens.ctypes.data, len(lens)), self._L)
 
     def push_reads_ascii(self, mate, reads):
         """bk_push_reads_ascii: list of ASCII reads, packed on the GPU, asynchronous."""
@@ -160,43 +160,43 @@ class Engine:
         flat = np.ascontiguousarray(flat) if len(flat) else np.zeros(1, np.uint8)
         off = np.zeros(len(reads) + 1, np.uint64)
         off[1:] = np.cumsum([len(r) for r in reads])
-        _check(self._L.bk_push_reads_ascii(self.h, mate, flat.ctypes.data, off.ctypes.data, len(reads)))
+        _check(self._L.bk_push_reads_ascii(self.h, mate, flat.ctypes.data, off.ctypes.data, len(reads)), self._L)
 
     def push_reads_device(self, mate, d_words_ptr, stride_words, d_lens_ptr, n_records):
         _check(self._L.bk_push_reads_packed_device(self.h, mate, C.c_void_p(d_words_ptr), stride_words,
-                                                   C.c_void_p(d_lens_ptr), n_records))
+                                                   C.c_void_p(d_lens_ptr), n_records), self._L)
 
     def counters_ptr(self, mate):
         p = C.c_void_p()
-        _check(self._L.bk_counters_device_ptr(self.h, mate, C.byref(p)))
+        _check(self._L.bk_counters_device_ptr(self.h, mate, C.byref(p)), self._L)
         return p.value
 
     def pileup_ptr(self):
         p = C.c_void_p()
-        _check(self._L.bk_pileup_device_ptr(self.h, C.byref(p)))
+        _check(self._L.bk_pileup_device_ptr(self.h, C.byref(p)), self._L)
         return p.value
 
     def sample_finalize(self, n_mates=1):
-        _check(self._L.bk_sample_finalize(self.h, n_mates))
+        _check(self._L.bk_sample_finalize(self.h, n_mates), self._L)
 
     def sample_finalize_shard(self, n_mates, shard, n_shards):
         """Map only the shard-th of n_shards equal parts of each counter plane (include/bronko_hip.h)."""
-        _check(self._L.bk_sample_finalize_shard(self.h, n_mates, shard, n_shards))
+        _check(self._L.bk_sample_finalize_shard(self.h, n_mates, shard, n_shards), self._L)
 
     def shard_sums(self):
         """(device pointer, u64 length) of the small additive results of sample_finalize_shard."""
         p, n = C.c_void_p(), C.c_uint64()
-        _check(self._L.bk_shard_sums_device_ptr(self.h, C.byref(p), C.byref(n)))
+        _check(self._L.bk_shard_sums_device_ptr(self.h, C.byref(p), C.byref(n)), self._L)
         return p.value, n.value
 
     def sample_merge_shards(self):
-        _check(self._L.bk_sample_merge_shards(self.h))
+        _check(self._L.bk_sample_merge_shards(self.h), self._L)
 
     def sample_download(self, n_mates=1, arrays=True):
         r = SampleResult(n_mates, self.n_files, self.total_cells)
         a = [x.ctypes.data if arrays else None for x in (r.fwd_depth, r.rev_depth, r.fwd_nk, r.rev_nk)]
         _check(self._L.bk_sample_download(self.h, n_mates, a[0], a[1], a[2], a[3], r.stats.ctypes.data,
-                                          r.present.ctypes.data, r.kmer_stats.ctypes.data))
+                                          r.present.ctypes.data, r.kmer_stats.ctypes.data), self._L)
         return r
 
     def sample_finish(self, n_mates=1):
@@ -204,10 +204,10 @@ class Engine:
         return self.sample_download(n_mates)
 
     def timing_enable(self, on=True):
-        _check(self._L.bk_timing_enable(self.h, int(on)))
+        _check(self._L.bk_timing_enable(self.h, int(on)), self._L)
 
     def timing_read(self, reset=True):
         ms = (C.c_double * 4)()
         n = (C.c_uint64 * 4)()
-        _check(self._L.bk_timing_read(self.h, ms, n, int(reset)))
+        _check(self._L.bk_timing_read(self.h, ms, n, int(reset)), self._L)
         return list(ms), list(n)

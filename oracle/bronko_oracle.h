@@ -170,6 +170,15 @@ void orc_sample_pileup(const orc_index* ix, const orc_map_params* mp, int n_mate
                        uint64_t* fwd_depth, uint64_t* rev_depth, uint64_t* fwd_nk, uint64_t* rev_nk,
                        uint64_t* stats, uint8_t* present, uint64_t* kmc_stats);
 
+/* The same result computed on n_threads host threads the way the reference uses its cores (bronko_oracle_mt.c): stage 1 =
+ * sharded exact counting (kmc -t, call.rs:1166-1181), stage 2 = map_kmers over chunks in parallel (call.rs:1279-1281).
+ * Reads are given back to back: read r = bases[offsets[r] .. offsets[r+1]).  stage_seconds (optional) receives the
+ * wall-clock of the two stages, summed over the mate files. */
+void orc_sample_pileup_mt(const orc_index* ix, const orc_map_params* mp, int n_mates, const uint8_t* bases,
+                          const uint64_t* offsets, const uint64_t* mate_off, int n_threads,
+                          uint64_t* fwd_depth, uint64_t* rev_depth, uint64_t* fwd_nk, uint64_t* rev_nk,
+                          uint64_t* stats, uint8_t* present, uint64_t* kmc_stats, double* stage_seconds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("bronko_oracle.c", "bronko_oracle.h", "tcrit_table.inc")]
+    src = [os.path.join(_HERE, f) for f in ("bronko_oracle.c", "bronko_oracle_mt.c", "bronko_oracle.h", "tcrit_table.inc")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
         return _LIB_PATH
@@ -134,6 +134,9 @@ def lib():
     L.orc_write_vcf.argtypes = [C.c_char_p, C.c_char_p, vp, C.c_int, C.POINTER(VcfRecord), C.c_uint64]
     L.orc_write_pileup.restype = C.c_int
     L.orc_write_pileup.argtypes = [C.c_char_p, vp, C.c_int, vp, vp]
+    L.orc_sample_pileup_mt.restype = None
+    L.orc_sample_pileup_mt.argtypes = [vp, C.POINTER(MapParams), C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp,
+                                       vp, C.POINTER(C.c_double)]
     L.orc_sample_pileup.restype = None
     L.orc_sample_pileup.argtypes = [vp, C.POINTER(MapParams), C.c_int, C.POINTER(C.c_char_p), u64p, u64p,
                                     vp, vp, vp, vp, vp, vp, vp]
@@ -324,6 +327,31 @@ def sample_pileup(ix, mates, n_fixed=2, use_full_kmer=False, ci=3, cs=1000000, c
                             _ptr(pile.fwd_nk), _ptr(pile.rev_nk), _ptr(pile.stats), _ptr(pile.present),
                             _ptr(pile.kmc_stats))
     return pile
+
+
+def sample_pileup_mt(ix, mates, n_threads, n_fixed=2, use_full_kmer=False, ci=3, cs=1000000, cx=1000000000):
+    """Same result as sample_pileup on n_threads host threads (bronko_oracle_mt.c).  mates: list of either lists of ASCII reads
+    or 2-D uint8 arrays [n][len] of ASCII symbols.  Returns (Pileup, (stage-1 seconds, stage-2 seconds))."""
+    pile = Pileup(ix, len(mates))
+    mp = MapParams(n_fixed, int(use_full_kmer), ci, cs, cx)
+    flats, lens = [], []
+    for m in mates:
+        if isinstance(m, np.ndarray) and m.ndim == 2:
+            flats.append(np.ascontiguousarray(m, np.uint8).reshape(-1))
+            lens.append(np.full(m.shape[0], m.shape[1], np.uint64))
+        else:
+            flats.append(np.frombuffer(b"".join(bytes(r) for r in m), np.uint8))
+            lens.append(np.array([len(r) for r in m], np.uint64))
+    flat = np.concatenate(flats + [np.zeros(1, np.uint8)])
+    offs = np.zeros(sum(len(x) for x in lens) + 1, np.uint64)
+    offs[1:] = np.cumsum(np.concatenate(lens)) if len(offs) > 1 else 0
+    moff = np.zeros(len(mates) + 1, np.uint64)
+    moff[1:] = np.cumsum([len(x) for x in lens])
+    secs = (C.c_double * 2)()
+    lib().orc_sample_pileup_mt(ix.h, C.byref(mp), len(mates), flat.ctypes.data, offs.ctypes.data, moff.ctypes.data, int(n_threads),
+                               _ptr(pile.fwd_depth), _ptr(pile.rev_depth), _ptr(pile.fwd_nk), _ptr(pile.rev_nk),
+                               _ptr(pile.stats), _ptr(pile.present), _ptr(pile.kmc_stats), secs)
+    return pile, (secs[0], secs[1])
 
 
 def pick_best_genome(ix, stats, present):

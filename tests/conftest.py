@@ -12,6 +12,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # built artefacts are not tracked: a fresh checkout builds them (make is incremental, a no-op when they are current)
+    built = [os.path.join(ROOT, "bronko_amd", f) for f in ("libbronko_hip.so", "libbronko_hip_testing.so", "libbronko_host.so",
+                                                           os.path.join("bin", "bronko"))] + [os.path.join(ROOT, "oracle", "liboracle.so")]
+    if not all(os.path.exists(b) for b in built):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session", autouse=True)
@@ -27,6 +33,16 @@ def _torch_gpu_first():
     except Exception:   # noqa: BLE001 -- CPU-only runs do not care
         pass
     yield
+
+
+@pytest.fixture
+def testing_lib():
+    """Engines created inside the test bind libbronko_hip_testing.so, the -DBK_TESTING build of the same sources: the BK_*
+    environment variables that force a code path (a small LDS window, launch splitting, ...) exist only there."""
+    from bronko_amd import _ffi
+    _ffi.use_testing_library(True)
+    yield
+    _ffi.use_testing_library(False)
 
 
 @pytest.fixture(scope="session")

@@ -17,10 +17,20 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "bronko_hip.h")).read()
     declared = set(re.findall(r"\b(bk_[a-z_0-9]+)\s*\(", hdr))
     assert declared == set(_ffi.SYMBOLS)
-    L = _ffi.load()
-    for s in declared:
-        assert hasattr(L, s), s
-    assert L.bk_abi_version() == 4
+    for testing in (False, True):   # the release library and its -DBK_TESTING twin
+        L = _ffi.load(testing=testing)
+        for s in declared:
+            assert hasattr(L, s), s
+        assert L.bk_abi_version() == 4
+
+
+def test_release_library_reads_no_environment_variable():
+    """The BK_* testing / measurement aids are compiled into libbronko_hip_testing.so only."""
+    rel = open(_ffi.LIB_PATH, "rb").read()
+    tst = open(_ffi.TESTING_LIB_PATH, "rb").read()
+    for name in (b"BK_SCAN_ABLATE", b"BK_LDS_BINS", b"BK_REF_IN_LDS", b"BK_WINDOW_FILE", b"BK_MAX_LAUNCH_RECORDS", b"BK_L2_COUNT"):
+        assert name not in rel, name
+        assert name in tst, name
 
 
 def test_bucket_info_layout_matches_repr_c():

@@ -139,13 +139,14 @@ def test_degenerate_identical_reads_spill_the_lds_histogram(oracle, hpv):
     assert int(res.fwd_depth.max()) == 200000 and int(res.rev_depth.max()) == 100000
 
 
-def test_overflow_planes_when_lds_histogram_is_smaller_than_the_reference(oracle, golden_dir, monkeypatch):
-    """BK_LDS_BINS caps the LDS histogram so that most reference k-mers take the XCD-private plane path (the
-    path large multi-genome indexes use); BK_NO_XCD_PLANES=1 then forces plain agent-scope atomics."""
+def test_lds_window_smaller_than_the_reference(oracle, golden_dir, monkeypatch, testing_lib):
+    """BK_LDS_BINS (testing build) caps the LDS window: reads whose diagonal leaves it are N runs as a whole and their exact
+    k-mers are counted by Level 2's membership test -- the path every genome but one of a multi-genome index takes.
+    0 = no window at all: everything through Level 2."""
     ix = oracle.Index.load(os.path.join(golden_dir, "hpv.bkdb"))
     reads = helpers.hpv_reads(6000, seed=8)
     pile = oracle.sample_pileup(ix, [reads])
-    for env in ({"BK_LDS_BINS": "1000"}, {"BK_LDS_BINS": "0"}, {"BK_LDS_BINS": "500", "BK_NO_XCD_PLANES": "1"}):
+    for env in ({"BK_LDS_BINS": "1000"}, {"BK_LDS_BINS": "0"}, {"BK_LDS_BINS": "500"}):
         for kk, vv in env.items():
             monkeypatch.setenv(kk, vv)
         eng = helpers.engine_from_oracle_index(ix)
@@ -282,9 +283,9 @@ def test_device_side_packing_and_async_ingest(oracle, hpv):
     assert host.kmer_stats[0, 0] == res.kmer_stats[0, 0]
 
 
-def test_reference_walk_from_global_memory(oracle, golden_dir, monkeypatch):
+def test_reference_walk_from_global_memory(oracle, golden_dir, monkeypatch, testing_lib):
     """BK_REF_IN_LDS=0 forces the REF_LDS=false kernel (reference + flag nibbles read from global memory), the path
-    indexes too large for LDS take; combined with a tiny LDS histogram so that the XCD planes are used as well."""
+    indexes too large for LDS take; also combined with a tiny LDS window."""
     ix = oracle.Index.load(os.path.join(golden_dir, "hpv.bkdb"))
     reads = helpers.hpv_reads(8000, seed=21, with_n=True)
     pile = oracle.sample_pileup(ix, [reads])
@@ -388,7 +389,7 @@ def test_counter_planes_of_read_shards_add_up(oracle, hpv):
         e.close()
 
 
-def test_a_push_split_into_several_launches(oracle, hpv, monkeypatch):
+def test_a_push_split_into_several_launches(oracle, hpv, monkeypatch, testing_lib):
     """Large pushes are cut into launches of bounded size (the 16-bit halves of the LDS difference array bound the records
     one workgroup may see); BK_MAX_LAUNCH_RECORDS forces the same splitting at test size, also for device-side packing
     where the record count is only known on the device."""
@@ -516,7 +517,7 @@ def test_long_reads_with_indels_and_chimeras(oracle, sars_paths):
     ix.close()
 
 
-def test_lds_window_on_any_genome_gives_the_same_counts(oracle, sars_paths, monkeypatch):
+def test_lds_window_on_any_genome_gives_the_same_counts(oracle, sars_paths, monkeypatch, testing_lib):
     """Multi-genome indexes: the LDS window (difference array + Level 1's arrays) is put on the genome the first reads vote
     for; BK_WINDOW_FILE forces it elsewhere.  Whatever genome it sits on, the counts are the same -- it is about speed."""
     ix = oracle.Index.build(21, sars_paths)

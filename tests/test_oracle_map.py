@@ -121,3 +121,27 @@ def test_kmc_contract_counting(oracle):
     assert d == {u("ACGTA"): 3, u("CGTAC"): 3} and st[3] == 2      # -ci3 drops, -cs3 saturates
     km, ct, st = oracle.count_kmers(5, reads, ci=1, cx=3)
     assert u("ACGTA") not in set(int(x) for x in km)               # -cx excludes on the true count
+
+
+def test_multithreaded_orchestration_equals_the_single_threaded_one(oracle, sars_paths):
+    """bronko_oracle_mt.c (bench.py's cpu_baseline: sharded counting + map_kmers over chunks in parallel, call.rs:1279-1281)
+    gives the literal single-threaded result bit for bit, single-end and paired, any thread count."""
+    from bronko_amd import synth
+    ix = oracle.Index.build(21, sars_paths)
+    gm, isnv = synth.sample_genome(synth.read_fasta_bytes(sars_paths[2]), 9)
+    c1, c2 = synth.paired_codes(gm, 6000, 150, 9, isnv=isnv)
+    c1[5, 40] = 0
+    mates = [synth.codes_to_ascii(c1), synth.codes_to_ascii(c2)]
+    mates[0][7] = mates[0][7][:60] + b"N" + mates[0][7][61:]     # a read split by N
+    mates[1][3] = b"ACGT"                                          # shorter than k
+    ref = oracle.sample_pileup(ix, mates, ci=2)
+    for threads in (1, 3, 8):
+        got, secs = oracle.sample_pileup_mt(ix, mates, threads, ci=2)
+        for name in ("fwd_depth", "rev_depth", "fwd_nk", "rev_nk", "stats", "present", "kmc_stats"):
+            assert np.array_equal(getattr(ref, name), getattr(got, name)), (threads, name)
+        assert secs[0] >= 0 and secs[1] >= 0
+    # 2-D symbol arrays are accepted as well (what bench.py hands over)
+    got, _ = oracle.sample_pileup_mt(ix, [synth.BASES[c1], synth.BASES[c2]], 4, ci=2)
+    ref2 = oracle.sample_pileup(ix, [synth.codes_to_ascii(c1), synth.codes_to_ascii(c2)], ci=2)
+    assert np.array_equal(ref2.fwd_depth, got.fwd_depth) and np.array_equal(ref2.stats, got.stats)
+    ix.close()

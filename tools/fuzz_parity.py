@@ -6,7 +6,8 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bronko_amd import Params, pack_reads
+from bronko_amd import Params, pack_reads, _ffi
+_ffi.use_testing_library(True)   # BK_LDS_BINS / BK_REF_IN_LDS / BK_MAX_LAUNCH_RECORDS exist in the -DBK_TESTING build only
 from tests import helpers
 from oracle import oracle as orc
 

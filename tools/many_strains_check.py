@@ -17,15 +17,7 @@ n_strains = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
 use_oracle = "--no-oracle" not in sys.argv
 base = synth.read_fasta_bytes(os.path.join(ROOT, "tests", "golden", "4_sarscov2", "wuhan_ref.fasta"))
-files = []
-for s in range(n_strains):
-    g = np.frombuffer(base, np.uint8).copy()
-    r = synth.splitmix64(5000 + s, 600)
-    pos = (r[0::2] % np.uint64(len(g))).astype(np.int64)
-    sh = (r[1::2] % np.uint64(3)).astype(np.int64) + 1
-    for p, d in zip(pos, sh):
-        g[p] = synth.BASES[(int(synth.CODE[g[p]]) + int(d)) & 3]
-    files.append(("strain%03d" % s, [("seq%03d" % s, g.tobytes())]))
+files = synth.strain_files(base, n_strains)
 t0 = time.time()
 ix = HostIndex.build_mem(31, files, threads=8)
 t1 = time.time()

@@ -36,6 +36,17 @@ struct alignas(16) SlotRec {
     DevEntry first;
 };
 
+// Per reference k-mer (id), everything finalize needs to replay map_kmers on a k-mer named by that id, in one 16-byte load.
+// "simple": every one of its W window buckets holds exactly one BucketInfo -- its own single occurrence -- so the bucket at
+// canonical position j is {cell = cell + j, file, idx = j, canonical = rc} and no table is read at all (every k-mer of a
+// single genome without repeats).
+struct alignas(16) IdRec {
+    uint64_t kmer;     // canonical reference k-mer (= kmer_of[id])
+    uint32_t cell;     // cell at which its first occurrence starts
+    uint32_t flags;    // bit 0 dirty, bit 1 first occurrence reverse-complemented (= amb[id]); bit 2 simple; bits 16..31 file (simple only)
+};
+constexpr uint32_t kIdDirty = 1u, kIdRc = 2u, kIdSimple = 4u;
+
 // Multiplicative hash into a table of 2^log2s positions.
 BK_HD uint32_t hash_key(uint64_t key, uint32_t log2s) {
     return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - log2s));
@@ -105,6 +116,7 @@ struct HalfView {
 struct IndexView {
     const KmerPos*   kmer_pos; // [m] perfect-hash table of U (membership test, diagonal seeding)
     const uint64_t*  kmer_of;  // [n_u] id -> canonical k-mer
+    const IdRec*     id_rec;   // [n_u] id -> k-mer, first cell, flags (see IdRec)
     // the reference in reference order, for the diagonal walk of scan_count (staged in LDS when it fits):
     const uint32_t*  ref_words;   // 2-bit packed bases of all cells (nt_to_bits, 16 per word, LSB first), padded in front
                                   // (bk_kernels.h scan_ref_pad_words) and behind

@@ -220,6 +220,7 @@ struct bk_engine {
     DevBuf<bk::KmerPos> kmer_pos;
     DevBuf<bk::IndexView> d_view;   // device copy of view()
     DevBuf<uint64_t> kmer_of;
+    DevBuf<bk::IdRec> id_rec;
     DevBuf<uint32_t> ref_words, cell_codes, cell_has, cell_clean, cell_clean3, cell_yf, cell_yr, id_at;
     struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0; } half_lo, half_hi;
     DevBuf<unsigned int> deferred, n_deferred;
@@ -274,6 +275,7 @@ struct bk_engine {
     bool win_chosen = false;                // for the current sample
     bool plane_stale[2] = {true, true};   // the mate's counter plane still holds an earlier sample (zeroed at its first push / at finalize)
 
+    DevBuf<unsigned long long> dbg;   // BK_L2_STATS (testing build): tallies of what the scan leaves to Level 2
     int ablate = 0;   // BK_SCAN_ABLATE (measurement aid): see scan_count_kernel
     uint64_t max_launch_records = 0;   // BK_MAX_LAUNCH_RECORDS (testing aid): split pushes into launches of at most this many records
     bool timing = false;
@@ -284,7 +286,7 @@ struct bk_engine {
     bk::IndexView view() const {
         bk::IndexView v{};
         v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb;
-        v.kmer_of = kmer_of.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_clean3 = cell_clean3.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
+        v.kmer_of = kmer_of.p; v.id_rec = id_rec.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_clean3 = cell_clean3.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
         v.n_full = n_full; v.n_prows = n_prows; v.prow_id = prow_id.p; v.prow_t = prow_t.p; v.v_omin = v_omin; v.v_span = v_span; v.v_off = v_off;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb};
@@ -844,6 +846,23 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     h_rec[id * e->W + t] = r;
                 }
             BK_HIP(e->slot_rec.upload(h_rec));
+            // IdRec: k-mer, first cell, flags; "simple" = each of the W buckets holds the k-mer's own single occurrence and nothing else
+            std::vector<bk::IdRec> h_idrec(std::max<size_t>(h_u.size(), 1), bk::IdRec{bk::kEmptyKey, 0u, 0u});
+            for (size_t i = 0; i < h_u.size(); i++) {
+                const uint32_t id = id_of[i];
+                bk::IdRec r{h_u[i], first_cell[i] == kNone ? 0u : first_cell[i], (h_amb[id] ? bk::kIdDirty : 0u) | (first_rc[i] ? bk::kIdRc : 0u)};
+                if (id < e->n_full && first_cell[i] != kNone && e->W > 0) {
+                    bool simple = true;
+                    for (int t = 0; t < e->W && simple; t++) {
+                        const bk::SlotRec& sr = h_rec[(size_t)id * e->W + t];
+                        simple = sr.len == 1 && sr.first.cell == first_cell[i] + (uint32_t)(e->wstart + t) && sr.first.idx == (uint8_t)(e->wstart + t) &&
+                                 sr.first.canonical == (first_rc[i] ? 1 : 0);
+                    }
+                    if (simple) r.flags |= bk::kIdSimple | ((uint32_t)h_rec[(size_t)id * e->W].first.file << 16);
+                }
+                h_idrec[id] = r;
+            }
+            BK_HIP(e->id_rec.upload(h_idrec));
         }
 
         pc.lap("slot_of + slot_rec");
@@ -918,7 +937,7 @@ int bk_engine_fork(const bk_engine* parent, bk_engine** out) {
     e->file_cell_lo = p->file_cell_lo; e->ablate = p->ablate; e->max_launch_records = p->max_launch_records;
     e->half_lo.m = p->half_lo.m; e->half_lo.log2nb = p->half_lo.log2nb; e->half_hi.m = p->half_hi.m; e->half_hi.log2nb = p->half_hi.log2nb;
     // the index tables are immutable after bk_engine_create: the fork reads the parent's
-    e->prow_id.alias(p->prow_id); e->prow_t.alias(p->prow_t); e->kmer_pos.alias(p->kmer_pos); e->d_view.alias(p->d_view); e->kmer_of.alias(p->kmer_of);
+    e->prow_id.alias(p->prow_id); e->prow_t.alias(p->prow_t); e->kmer_pos.alias(p->kmer_pos); e->d_view.alias(p->d_view); e->kmer_of.alias(p->kmer_of); e->id_rec.alias(p->id_rec);
     e->ref_words.alias(p->ref_words); e->cell_codes.alias(p->cell_codes); e->cell_has.alias(p->cell_has); e->cell_clean.alias(p->cell_clean);
     e->cell_clean3.alias(p->cell_clean3); e->cell_yf.alias(p->cell_yf); e->cell_yr.alias(p->cell_yr); e->id_at.alias(p->id_at);
     e->half_lo.pilots.alias(p->half_lo.pilots); e->half_lo.dir.alias(p->half_lo.dir); e->half_lo.cand.alias(p->half_lo.cand);
@@ -1007,6 +1026,8 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->params.kmer_table_log2;
     a.ktab_overflow = e->ktab_out.p + 4; a.mate = (uint32_t)mate;
     a.occ = e->occ.p; a.n_files = e->n_files;
+    if (test_env("BK_L2_STATS") && !e->dbg.p) { BK_HIP(e->dbg.alloc(16)); BK_HIP(hipMemsetAsync(e->dbg.p, 0, 16 * sizeof(unsigned long long), e->stream)); }
+    a.dbg = e->dbg.p;
     if (e->W <= 0) {
         // empty window: nothing can touch the index (map_kmers finds no bucket, call.rs:1291-1307); KMC's total k-mer count is all
         bk::launch_count_kmers(a, e->stream);
@@ -1229,6 +1250,15 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
     }
     BK_HIP(hipGetLastError());
     e->in_sample = false;
+    if (e->dbg.p) {   // BK_L2_STATS (testing build)
+        unsigned long long h[16];
+        BK_HIP(hipMemcpyAsync(h, e->dbg.p, sizeof h, hipMemcpyDeviceToHost, e->stream));
+        BK_HIP(hipMemsetAsync(e->dbg.p, 0, sizeof h, e->stream));
+        BK_HIP(hipStreamSynchronize(e->stream));
+        fprintf(stderr, "[bk] scan marked: no-diagonal %llu, dirty-head %llu, clean-head %llu, pairs %llu | level 2: k-mers %llu in %llu chunks, simple %llu, dead %llu, "
+                "slow %llu (diffs 0/1/2/3+ with a diagonal: %llu/%llu/%llu/%llu) -> member %llu, neighbour %llu, nothing %llu\n",
+                h[0], h[1], h[2], h[3], h[4], h[11], h[5], h[6], h[7], h[12], h[13], h[14], h[15], h[8], h[9], h[10]);
+    }
     return BK_OK;
 }
 

@@ -31,8 +31,13 @@ namespace bk {
 // Measurement aids (ScanArgs::ablate) exist in the -DBK_TESTING build only; in the release library the tests fold away.
 #ifdef BK_TESTING
 #define BK_ABLATE(a, x) ((a).ablate == (x))
+// BK_L2_STATS tallies (ScanArgs::dbg): k-mers marked by the scan [0] without a diagonal, [1] at a dirty / id-breaking head,
+// [2] mismatch-free head, [3] close pairs; Level 2: [4] k-mers looked at, [5] single-k-mer S runs, [6] dropped as dead,
+// [7] queued for the slow pipeline, [8] ... reference k-mers after all, [9] ... a neighbour found, [10] ... nothing; [11] chunks
+#define BK_DBG(a, idx, pred, cnt) do { if ((a).dbg && (pred)) atomicAdd((a).dbg + (idx), (unsigned long long)(cnt)); } while (0)
 #else
 #define BK_ABLATE(a, x) false
+#define BK_DBG(a, idx, pred, cnt) do { } while (0)
 #endif
 
 __device__ __forceinline__ int probe_table(const TableSlot* __restrict__ sub, uint32_t log2s, uint64_t key) {
@@ -319,6 +324,9 @@ struct SlowPipe {
     //   after stage 2: b0 = entry of U, b1 = low directory entry, b2 = high directory entry
     //   after stage 3: b0 = first low candidate, b1 = first high candidate, b2 = {low off, low cnt, high off, high cnt}
     uint4 b0{}, b1{}, b2{};
+#ifdef BK_TESTING
+    unsigned long long* dbg = nullptr;   // BK_L2_STATS tallies
+#endif
 
     // queue entry: canonical k-mer | orientation << 62 | stat_only << 63
     __device__ __forceinline__ void start(const unsigned long long* q, uint32_t n, int lane, const IndexView& ix) {
@@ -388,6 +396,9 @@ struct SlowPipe {
             } else if (have && kt.keys) {
                 ktab_insert(kt, c, isrc, 1u);   // touches no window bucket: only KMC's distinct / counted totals see it
             }
+#ifdef BK_TESTING
+            if (dbg && have && !stat_only) atomicAdd(dbg + (best != ~0ull ? 9 : 10), 1ull);
+#endif
             stage = 0;
         }
     }
@@ -446,10 +457,13 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     uint32_t qs = 0;   // wave-uniform: fill of the N queue
     const IndexView& ix = *a.ixp;
     // k-mers [s, s + n) of record `rec` (index within this launch) are left to Level 2: set their bits
-    auto l2_mark = [&](bool on, uint32_t rec, uint32_t sk, uint32_t n) {
+    // (the record's diagonal goes with the mark: Level 2 reads l2_diag only for marked records, so nothing is written for
+    // the others -- about one record in eight on the benchmark has a mark)
+    auto l2_mark = [&](bool on, uint32_t rec, uint32_t sk, uint32_t n, int32_t dgm, uint32_t flm) {
         if (!on) return;
         unsigned int* row = a.l2_bits + (size_t)rec * a.l2_words;
         atomicOr(a.l2_any + (rec >> 5), 1u << (rec & 31u));
+        a.l2_diag[rec] = make_uint2((uint32_t)dgm, flm);
         uint32_t w = sk >> 5, bit = sk & 31u, left = n;
         while (left) {
             const uint32_t take = min(left, 32u - bit);
@@ -551,7 +565,6 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
             }
         }
         dfl = (fwd ? 1u : 0u) | (seeded ? 2u : 0u);
-        if (live) a.l2_diag[r32] = make_uint2((uint32_t)dg, dfl);   // Level 2 finds the record's diagonal here
 
         // ---- Level 1 / batches: a state machine, all control flow wave-uniform --------------------------------------
         uint32_t i0 = 0;                // first base of the next Level-1 step (32 bases)
@@ -640,7 +653,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                     if (t1 > kk) { head = min(t1 - kk, n1); cutn = 0; F = 0ull; }   // leading k-mers without a mismatch
                 }
                 // ---- the head ----
-                l2_mark(have && head > 0, rec2, s_first, (uint32_t)head);
+                BK_DBG(a, !(have && (fl2 & 2u) && n2 + km1 <= 64u) ? 0 : n1 == 0 ? 1 : 2, have && head > 0, head);
+                l2_mark(have && head > 0, rec2, s_first, (uint32_t)head, dg2, fl2);
                 if (have && head > 0) cutn = head;
                 // ---- mismatch by mismatch ----
                 int tprev = -1000, gprev = -1;   // the previous mismatch; the last k-mer already sent to Level 2
@@ -685,7 +699,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                         const uint32_t need = pair ? 0xffffffffu >> (31 - (g_hi - g_lo)) : 0u;
                         dead = tn2 - kk > g_hi && ((uint32_t)(c3 >> (pair ? g_lo : 0)) & need) == need;   // none of them reaches t_i+2
                     }
-                    l2_mark(pair && !dead, rec2, s_first + (uint32_t)(pair ? g_lo : 0), (uint32_t)(g_hi - g_lo + 1));
+                    BK_DBG(a, 3, pair && !dead, g_hi - g_lo + 1);
+                    l2_mark(pair && !dead, rec2, s_first + (uint32_t)(pair ? g_lo : 0), (uint32_t)(g_hi - g_lo + 1), dg2, fl2);
                     if (pair) gprev = g_hi;
                     tprev = ti;
                 }
@@ -856,10 +871,14 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
     // slow path: +1 on the E counter of reference k-mer `id` read in orientation `isrc`
     auto count_exact = [&](bool hit, uint32_t /*cell*/, uint32_t id, uint32_t isrc, uint32_t /*rc_first*/) {
         if (hit) atomicAdd(a.counters + 2 * (size_t)id + isrc, 1ull);
+        BK_DBG(a, 8, hit, 1);
     };
     uint32_t qn = 0;   // wave-uniform fill of the slow-path queue
     uint32_t qc = 0;   // wave-uniform fill of the chunk queue
     SlowPipe pipe;
+#ifdef BK_TESTING
+    pipe.dbg = a.dbg;
+#endif
     auto start_slow_batch = [&]() {
         const uint32_t nb = min(qn, 64u);
         pipe.start(q, nb, lane, ix);
@@ -918,6 +937,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
                 qc = rest;
             }
             const uint32_t n_e = ce.y >> 16;     // 0 for a lane without an entry
+            BK_DBG(a, 11, n_e != 0u && part == 0u, 1);
             const uint32_t s_first = (ce.y & 0xffffu) + part * sub;
             const uint32_t n2 = n_e > part * sub ? min(sub, n_e - part * sub) : 0u;
             const uint2 dgf = a.l2_diag[ce.x];
@@ -1011,6 +1031,8 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
                 // nothing (full_kmer_stats: only the statistics table wants it)
                 const bool dead = ok && n_diff == 2u && ((c3 >> t) & 1u);
                 const bool miss = valid && !simple && !(dead && !STATS) && !BK_ABLATE(a, 3);
+                BK_DBG(a, 4, valid, 1); BK_DBG(a, 5, simple, 1); BK_DBG(a, 6, valid && !simple && dead, 1); BK_DBG(a, 7, miss, 1);
+                BK_DBG(a, 12 + (n_diff > 3u ? 3u : n_diff), miss && ok, 1);
                 const unsigned long long mm = __ballot(miss);
                 if (mm) {
                     if (miss) {
@@ -1546,19 +1568,15 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         const uint64_t wk = qrow * 8 + (u & 7ull);
         const bool in_row = lane_on && qrow < nq && wk >= row_lo && wk < row_hi;
         unsigned long long n = in_row ? vc[wk * rl + oo] : 0ull;
-        // Everything else this lane may need depends on the row's coordinates only, not on its counts: the loads are issued
-        // together with the row's (one round trip instead of three dependent ones) -- the reference k-mer, its flags, and
-        // the bucket record at both window positions the offset can stand for (the k-mer as written / reverse-complemented)
+        // What this lane needs besides its count depends on the row's coordinates only: the reference k-mer's record (k-mer,
+        // first cell, flags -- one 16-byte load, consecutive ids across the lanes) goes out together with the row's load.
         const uint32_t d = (uint32_t)wk & 1u, bf = (uint32_t)(wk >> 1) & 3u, q = (uint32_t)(wk >> 3);
         const bool inq = in_row && oo < (uint32_t)ix.v_span && q >= oo && q - oo < ix.n_full;
         const uint32_t p = inq ? q - oo : 0u;
-        const uint32_t ambp = ix.amb[p];
-        const uint64_t kmer_p = ix.kmer_of[p];
+        const uint4 idr = *reinterpret_cast<const uint4*>(ix.id_rec + p);
+        const uint64_t kmer_p = (uint64_t)idr.x | ((uint64_t)idr.y << 32);
+        const uint32_t ambp = idr.w;
         const int o = (int)oo + ix.v_omin;
-        const int t_fw = o - ix.wstart, t_rc = k - 1 - o - ix.wstart;
-        const bool in_fw = inq && t_fw >= 0 && t_fw < ix.W, in_rc = inq && t_rc >= 0 && t_rc < ix.W;
-        const uint4 r_fw = in_fw ? *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)p * ix.W + t_fw) : make_uint4(0, 0, 0, 0);
-        const uint4 r_rc = in_rc ? *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)p * ix.W + t_rc) : make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int off = 1; off < 32; off <<= 1) {
             const unsigned long long t = __shfl_up(n, off, 64);   // (lane - off is in the same row whenever oo >= off)
@@ -1592,7 +1610,12 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
                 act = false;
             }
         }
-        const uint4 r = act ? (rcid ? r_rc : r_fw) : make_uint4(0, 0, 0, 0);
+        // the bucket (p, t): a "simple" k-mer's is its own single occurrence, known from the record; otherwise the table says
+        uint4 r = make_uint4(0u, 0u, 0u, 0u);
+        if (act) {
+            if (ambp & kIdSimple) r = make_uint4(0u, 1u, idr.z + (uint32_t)j, (ambp >> 16) | ((uint32_t)j << 16) | (rcid << 24));
+            else r = *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)p * ix.W + t);
+        }
         const uint32_t cnt = r.y;
         DevEntry first;
         first.cell = r.z; first.file = (uint16_t)(r.w & 0xffffu); first.idx = (uint8_t)(r.w >> 16); first.canonical = (uint8_t)(r.w >> 24);
@@ -1681,9 +1704,12 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
         if (n == 0 || n < a.ci || n > a.cx) break;              // kmc -ci / -cx act on the true count
         const unsigned long long v = n > a.cs ? a.cs : n;       // kmc -cs: reported count saturates
         const uint32_t id = (uint32_t)(cidx >> 1), isrc = (uint32_t)cidx & 1u;
-        const uint64_t c = ix.kmer_of[id];
+        const uint4 idr = *reinterpret_cast<const uint4*>(ix.id_rec + id);
+        const uint64_t c = (uint64_t)idr.x | ((uint64_t)idr.y << 32);
         {
-            const uint4 r = *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)id * W + t);
+            const uint32_t j = (uint32_t)ix.wstart + t;
+            const uint4 r = (idr.w & kIdSimple) ? make_uint4(0u, 1u, idr.z + j, (idr.w >> 16) | (j << 16) | (((idr.w >> 1) & 1u) << 24))
+                                                : *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)id * W + t);
             DevEntry first;
             first.cell = r.z; first.file = (uint16_t)(r.w & 0xffffu); first.idx = (uint8_t)(r.w >> 16); first.canonical = (uint8_t)(r.w >> 24);
             if (r.y && r.y <= kVoteMaxEntries) {               // a few genomes: still worth the table

@@ -47,6 +47,19 @@ struct alignas(16) IdRec {
 };
 constexpr uint32_t kIdDirty = 1u, kIdRc = 2u, kIdSimple = 4u;
 
+// Precomputed outcome of "reference k-mer `id` with base bb at position j (both in the orientation of the canonical k-mer)"
+// for reference k-mers that are not clean (another reference k-mer form within Hamming distance 2, or occurrences in both
+// orientations): is it another reference k-mer, a neighbour of which one (smallest (window position, NbEntry::p), the rule
+// of the neighbour search), or nothing.  A function of the index alone, so Level 2 settles a read k-mer that differs from
+// the reference in one base at such a cell with two loads (dirty_ix[id], then the answer) instead of a hash-table search.
+// The read's orientation enters at run time: isrc = the canonical form is the reverse complement of the k-mer as read.
+struct alignas(8) DirtyAns {
+    uint32_t idx;    // kind 1: E counter 2 * id' (+ isrc); kind 2: V counter of direction 0 relative to the V part (+ row length
+                     // when isrc ^ rcu); kind 3: pseudo k-mer counter relative to the V part (+ isrc)
+    uint32_t meta;   // bits 0-1 kind (0 = touches nothing); bit 2 rcu (kind 2); bit 3 (kind 2): -1 on the next counter as well
+};
+constexpr uint32_t kNoDirtyIx = 0xffffffffu;
+
 // Multiplicative hash into a table of 2^log2s positions.
 BK_HD uint32_t hash_key(uint64_t key, uint32_t log2s) {
     return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - log2s));
@@ -117,6 +130,8 @@ struct IndexView {
     const KmerPos*   kmer_pos; // [m] perfect-hash table of U (membership test, diagonal seeding)
     const uint64_t*  kmer_of;  // [n_u] id -> canonical k-mer
     const IdRec*     id_rec;   // [n_u] id -> k-mer, first cell, flags (see IdRec)
+    const uint32_t*  dirty_ix; // [n_u] id -> row of dirty_ans (kNoDirtyIx: none), or null when the tables were not built
+    const DirtyAns*  dirty_ans;// [n_dirty][k][4] (see DirtyAns), indexed (row * k + j) * 4 + bb
     // the reference in reference order, for the diagonal walk of scan_count (staged in LDS when it fits):
     const uint32_t*  ref_words;   // 2-bit packed bases of all cells (nt_to_bits, 16 per word, LSB first), padded in front
                                   // (bk_kernels.h scan_ref_pad_words) and behind

@@ -221,6 +221,8 @@ struct bk_engine {
     DevBuf<bk::IndexView> d_view;   // device copy of view()
     DevBuf<uint64_t> kmer_of;
     DevBuf<bk::IdRec> id_rec;
+    DevBuf<uint32_t> dirty_ix;
+    DevBuf<bk::DirtyAns> dirty_ans;
     DevBuf<uint32_t> ref_words, cell_codes, cell_has, cell_clean, cell_clean3, cell_yf, cell_yr, id_at;
     struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0; } half_lo, half_hi;
     DevBuf<unsigned int> deferred, n_deferred;
@@ -286,7 +288,7 @@ struct bk_engine {
     bk::IndexView view() const {
         bk::IndexView v{};
         v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb;
-        v.kmer_of = kmer_of.p; v.id_rec = id_rec.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_clean3 = cell_clean3.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
+        v.kmer_of = kmer_of.p; v.id_rec = id_rec.p; v.dirty_ix = dirty_ans.p ? dirty_ix.p : nullptr; v.dirty_ans = dirty_ans.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_clean3 = cell_clean3.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
         v.n_full = n_full; v.n_prows = n_prows; v.prow_id = prow_id.p; v.prow_t = prow_t.p; v.v_omin = v_omin; v.v_span = v_span; v.v_off = v_off;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb};
@@ -675,19 +677,24 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         // groups grow with |U| (a quarter of a k-mer distinguishes little): above kAmb3MaxKmers everything is flagged.
         std::vector<uint8_t> h_amb3(h_u.size(), 0);
         constexpr size_t kAmb3MaxKmers = 300000;
+        std::vector<uint64_t> h_near;                     // (canonical form's index << 32 | near form), sorted: the near lists
+        std::vector<uint8_t> h_no_list(h_u.size(), 0);    // by index: in a group too large to enumerate -- no near list
         {
-            struct Form { uint64_t w; uint32_t id; };
+            struct Form { uint64_t w; uint32_t id; uint32_t fi; };   // fi = 2 * (index into h_u) + (1: the reverse complement)
             std::vector<Form> forms;
             forms.reserve(h_u.size() * 2);
             for (size_t i = 0; i < h_u.size(); i++) {
-                forms.push_back(Form{h_u[i], id_of[i]});
-                forms.push_back(Form{bronko::reverse_complement_u64(h_u[i], k), id_of[i]});
+                forms.push_back(Form{h_u[i], id_of[i], (uint32_t)(2 * i)});
+                forms.push_back(Form{bronko::reverse_complement_u64(h_u[i], k), id_of[i], (uint32_t)(2 * i + 1)});
             }
-            auto flag_within = [&](int dist, std::vector<uint8_t>& out) {
+            // collect: for every canonical form, the forms within `dist` of it (the near lists the dirty answers are worked out from)
+            auto flag_within = [&](int dist, std::vector<uint8_t>& out, std::vector<std::vector<uint64_t>>* collect) {
                 const int parts = dist + 1;   // words at distance <= dist agree on at least one of dist + 1 parts
+                if (collect) collect->assign(parts, {});
                 std::vector<std::thread> th;
                 for (int part = 0; part < parts; part++) th.emplace_back([&, part] {   // (flags are only ever set to 1: benign races)
                     std::vector<Form> fs(forms);
+                    std::vector<uint64_t>* near = collect ? &(*collect)[part] : nullptr;
                     const int c0 = (part * k) / parts, c1 = ((part + 1) * k) / parts;
                     const uint64_t mask = (((1ull << (2 * (c1 - c0))) - 1ull) << (2 * c0));
                     std::sort(fs.begin(), fs.end(), [&](const Form& x, const Form& y) { return (x.w & mask) < (y.w & mask); });
@@ -695,13 +702,18 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                         size_t a1 = a0 + 1;
                         while (a1 < fs.size() && (fs[a1].w & mask) == (fs[a0].w & mask)) a1++;
                         if (a1 - a0 > 4096) {   // pathological low-complexity group: flag all, skip the quadratic pass
-                            for (size_t x = a0; x < a1; x++) out[fs[x].id] = 1;
+                            for (size_t x = a0; x < a1; x++) { out[fs[x].id] = 1; if (near) h_no_list[fs[x].fi >> 1] = 1; }
                         } else {
                             for (size_t x = a0; x < a1; x++)
                                 for (size_t y = x + 1; y < a1; y++) {
                                     const uint64_t d = fs[x].w ^ fs[y].w;
-                                    if (__builtin_popcountll((d | (d >> 1)) & 0x5555555555555555ull) <= dist)
+                                    if (__builtin_popcountll((d | (d >> 1)) & 0x5555555555555555ull) <= dist) {
                                         out[fs[x].id] = out[fs[y].id] = 1;   // also catches u vs rc(u) (same id)
+                                        if (near) {   // (owner canonical form << 32) | the other form
+                                            if (!(fs[x].fi & 1u)) near->push_back(((uint64_t)(fs[x].fi >> 1) << 32) | fs[y].fi);
+                                            if (!(fs[y].fi & 1u)) near->push_back(((uint64_t)(fs[y].fi >> 1) << 32) | fs[x].fi);
+                                        }
+                                    }
                                 }
                         }
                         a0 = a1;
@@ -709,9 +721,16 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 });
                 for (auto& t : th) t.join();
             };
-            flag_within(2, h_amb);
-            if (h_u.size() <= kAmb3MaxKmers) flag_within(3, h_amb3);
+            std::vector<std::vector<uint64_t>> near_parts;
+            flag_within(2, h_amb, &near_parts);
+            if (h_u.size() <= kAmb3MaxKmers) flag_within(3, h_amb3, nullptr);
             else std::fill(h_amb3.begin(), h_amb3.end(), (uint8_t)1);
+            size_t tot = 0;
+            for (auto& v : near_parts) tot += v.size();
+            h_near.reserve(tot);
+            for (auto& v : near_parts) { h_near.insert(h_near.end(), v.begin(), v.end()); std::vector<uint64_t>().swap(v); }
+            std::sort(h_near.begin(), h_near.end());
+            h_near.erase(std::unique(h_near.begin(), h_near.end()), h_near.end());
         }
         for (size_t i = 0; i < h_u.size(); i++) if (h_is_pseudo[i]) h_amb3[id_of[i]] = 1;
         for (size_t i = 0; i < h_u.size(); i++) if (h_is_pseudo[i]) h_amb[id_of[i]] = 1;
@@ -719,6 +738,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         std::vector<uint8_t> rc_of_id(h_u.size(), 0);   // the k-mer's first occurrence was reverse-complemented to become canonical
         for (size_t i = 0; i < h_u.size(); i++) rc_of_id[id_of[i]] = first_rc[i];
         std::vector<uint32_t> h_codes(h_refw.size(), 0u), h_yf(h_refw.size(), 0u), h_yr(h_refw.size(), 0u);   // bk_device.h
+        std::vector<uint8_t> h_needs_ans(h_u.size(), 0);   // by id: some cell of this reference k-mer is not clean
         const size_t bpad_w = (size_t)bk::scan_bit_pad_words();
         std::vector<uint32_t> h_has(bpad_w + (cells + 31) / 32 + (size_t)bk::scan_bit_back_words(), 0u), h_clean(h_has.size(), 0u), h_clean3(h_has.size(), 0u);
         for (uint64_t c = 0; c < cells; c++) {
@@ -734,12 +754,146 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             const bool to_next = c + 1 < cells && h_id_at[c + 1] != kNone && h_id_at[c + 1] == h_id_at[c] + 1;
             h_has[bpad_w + (c >> 5)] |= 1u << (c & 31);
             if (clean) h_clean[bpad_w + (c >> 5)] |= 1u << (c & 31);
+            else h_needs_ans[h_id_at[c]] = 1;
             if (!h_amb3[h_id_at[c]]) h_clean3[bpad_w + (c >> 5)] |= 1u << (c & 31);
             h_yf[wi] |= (clean | (from_prev ? 2u : 0u)) << sh;
             h_yr[wi] |= (clean | (to_next ? 2u : 0u)) << sh;
         }
 
         pc.lap("per-cell arrays");
+        // ---- dirty answers (bk_device.h DirtyAns): for every reference k-mer with a cell that is not clean, what "this k-mer with
+        // base bb at position j" is -- worked out from its near list (every reference k-mer form within Hamming distance 2: a
+        // k-mer one base away from u can only equal, or neighbour, forms within distance 2 of u).  Same rule as the neighbour
+        // search of Level 2's slow pipeline: a reference k-mer if it equals one, else the smallest (window position, NbEntry::p)
+        // among the reference k-mers one base away in the window that own a bucket there, else nothing.
+        {
+            std::vector<uint32_t> idx_by_id(h_u.size());
+            for (size_t i = 0; i < h_u.size(); i++) idx_by_id[id_of[i]] = (uint32_t)i;
+            std::vector<uint32_t> h_dix(std::max<size_t>(h_u.size(), 1), bk::kNoDirtyIx);
+            std::vector<uint32_t> owners;   // index into h_u of each row
+            for (size_t id = 0; id < e->n_full; id++)
+                if (h_needs_ans[id] && !h_no_list[idx_by_id[id]]) { h_dix[id] = (uint32_t)owners.size(); owners.push_back(idx_by_id[id]); }
+            const size_t per = (size_t)k * 4;
+            const bool build = e->W > 0 && owners.size() * per * sizeof(bk::DirtyAns) <= ((size_t)8 << 30);
+            if (build && !owners.empty()) {
+                std::vector<bk::DirtyAns> h_ans(owners.size() * per, bk::DirtyAns{0u, 0u});
+                const uint64_t vreal = bk::v_real_len(e->n_full, e->v_span);
+                auto diff1 = [&](uint64_t a, uint64_t b) -> int {   // position (from the left) of the single differing base, or -1
+                    const uint64_t x = a ^ b, y = (x | (x >> 1)) & 0x5555555555555555ull;
+                    if (y == 0 || (y & (y - 1)) != 0) return -1;
+                    return k - 1 - (__builtin_ctzll(y) >> 1);
+                };
+                parallel_for(owners.size(), [&](size_t r0, size_t r1) {
+                    std::vector<std::pair<uint64_t, uint32_t>> fl;   // (form word, form index) of u itself and its near forms
+                    for (size_t r = r0; r < r1; r++) {
+                        const uint32_t i = owners[r];
+                        const uint64_t u = h_u[i];
+                        fl.clear();
+                        fl.emplace_back(u, (uint32_t)(2 * i));
+                        for (auto it = std::lower_bound(h_near.begin(), h_near.end(), (uint64_t)i << 32); it != h_near.end() && (*it >> 32) == i; ++it) {
+                            const uint32_t fi = (uint32_t)*it;
+                            fl.emplace_back((fi & 1u) ? bronko::reverse_complement_u64(h_u[fi >> 1], k) : h_u[fi >> 1], fi);
+                        }
+                        for (int j = 0; j < k; j++) {
+                            const int sh = 2 * (k - 1 - j);
+                            for (uint32_t bb = 0; bb < 4; bb++) {
+                                if (((u >> sh) & 3ull) == bb) continue;
+                                bk::DirtyAns& A = h_ans[(r * (size_t)k + j) * 4 + bb];
+                                const uint64_t z = (u & ~(3ull << sh)) | ((uint64_t)bb << sh);
+                                const uint64_t zr = bronko::reverse_complement_u64(z, k);
+                                const bool flip = zr < z;              // the canonical form of z is its reverse complement
+                                const uint64_t c = flip ? zr : z;
+                                bool member = false;
+                                uint64_t best = ~0ull; uint32_t best_fi = 0;
+                                for (auto& f : fl) {
+                                    // a form says something about c (the canonical form of z) only in c's orientation: c vs u' is z vs u', or
+                                    // rc(z) vs u' = z vs rc(u').  (k = 31 pseudo k-mers are not canonical values: the other pairing does occur.)
+                                    if (((f.second & 1u) != 0) != flip) continue;
+                                    if (f.first == z) { A.idx = 2u * id_of[f.second >> 1]; A.meta = 1u; member = true; break; }
+                                    const int pp = diff1(f.first, z);
+                                    if (pp < 0) continue;
+                                    const int jn = flip ? k - 1 - pp : pp;            // position in c (= in the neighbour's canonical form)
+                                    if (jn < e->wstart || jn >= e->wstart + e->W || !((h_valid[f.second >> 1] >> (jn - e->wstart)) & 1u)) continue;
+                                    const uint64_t key = ((uint64_t)jn << 32) | row_base[f.second >> 1];
+                                    if (key < best) { best = key; best_fi = f.second; }
+                                }
+                                if (member || best == ~0ull) continue;
+                                const int jn = (int)(best >> 32);
+                                const uint32_t pnb = (uint32_t)best, ni = best_fi >> 1;
+                                const uint32_t bc = (uint32_t)(c >> (2 * (k - 1 - jn))) & 3u;
+                                if (pnb < e->n_full) {
+                                    const uint32_t rcu = first_rc[ni] ? 1u : 0u;
+                                    const int oo = (rcu ? k - 1 - jn : jn) - e->v_omin;
+                                    if (oo < 0 || oo >= e->v_span) continue;            // (v_point's guard)
+                                    A.idx = (uint32_t)(bk::v_row_base(pnb + (uint32_t)oo, rcu ? 3u - bc : bc, 0u, e->v_span) + (uint32_t)oo);
+                                    A.meta = 2u | (rcu << 2) | ((oo + 1 < e->v_span) ? 8u : 0u);
+                                } else {
+                                    const uint32_t row = pnb - e->n_full + (uint32_t)__builtin_popcount(h_valid[ni] & ((1u << (jn - e->wstart)) - 1u));
+                                    A.idx = (uint32_t)(vreal + ((uint64_t)row * 4 + bc) * 2);
+                                    A.meta = 3u;
+                                }
+                            }
+                        }
+                    }
+                });
+                if (test_env("BK_VERIFY_ANSWERS")) {
+                    // testing build: every answer against the definition -- membership in U and the neighbour search spelled out
+                    // (all 3 W substitutions inside the window), no near lists involved
+                    std::atomic<uint64_t> bad{0};
+                    parallel_for(owners.size(), [&](size_t r0, size_t r1) {
+                        for (size_t r = r0; r < r1; r++) {
+                            const uint64_t u = h_u[owners[r]];
+                            for (int j = 0; j < k; j++) for (uint32_t bb = 0; bb < 4; bb++) {
+                                const int sh = 2 * (k - 1 - j);
+                                if (((u >> sh) & 3ull) == bb) continue;
+                                const uint64_t z = (u & ~(3ull << sh)) | ((uint64_t)bb << sh), zr = bronko::reverse_complement_u64(z, k), c = zr < z ? zr : z;
+                                bk::DirtyAns want{0u, 0u};
+                                const auto it = std::lower_bound(h_u.begin(), h_u.end(), c);
+                                if (it != h_u.end() && *it == c) { want.idx = 2u * id_of[it - h_u.begin()]; want.meta = 1u; }
+                                else {
+                                    uint64_t best = ~0ull; size_t bi = 0;
+                                    for (int jn = e->wstart; jn < e->wstart + e->W; jn++) for (uint64_t alt = 0; alt < 4; alt++) {
+                                        const int s2 = 2 * (k - 1 - jn);
+                                        if (((c >> s2) & 3ull) == alt) continue;
+                                        const uint64_t cand = (c & ~(3ull << s2)) | (alt << s2);
+                                        const auto ct = std::lower_bound(h_u.begin(), h_u.end(), cand);
+                                        if (ct == h_u.end() || *ct != cand) continue;
+                                        const size_t ci = ct - h_u.begin();
+                                        if (!((h_valid[ci] >> (jn - e->wstart)) & 1u)) continue;
+                                        const uint64_t key = ((uint64_t)jn << 32) | row_base[ci];
+                                        if (key < best) { best = key; bi = ci; }
+                                    }
+                                    if (best != ~0ull) {
+                                        const int jn = (int)(best >> 32);
+                                        const uint32_t pnb = (uint32_t)best, bc = (uint32_t)(c >> (2 * (k - 1 - jn))) & 3u;
+                                        if (pnb < e->n_full) {
+                                            const uint32_t rcu = first_rc[bi] ? 1u : 0u;
+                                            const int oo = (rcu ? k - 1 - jn : jn) - e->v_omin;
+                                            if (oo >= 0 && oo < e->v_span) {
+                                                want.idx = (uint32_t)(bk::v_row_base(pnb + (uint32_t)oo, rcu ? 3u - bc : bc, 0u, e->v_span) + (uint32_t)oo);
+                                                want.meta = 2u | (rcu << 2) | ((oo + 1 < e->v_span) ? 8u : 0u);
+                                            }
+                                        } else {
+                                            want.idx = (uint32_t)(vreal + ((uint64_t)(pnb - e->n_full + (uint32_t)__builtin_popcount(h_valid[bi] & ((1u << (jn - e->wstart)) - 1u))) * 4 + bc) * 2);
+                                            want.meta = 3u;
+                                        }
+                                    }
+                                }
+                                const bk::DirtyAns& got = h_ans[(r * (size_t)k + j) * 4 + bb];
+                                if (got.idx != want.idx || got.meta != want.meta) {
+                                    if (bad++ < 5) fprintf(stderr, "[bk] dirty answer differs: id %u j %d bb %u: table (%u, %u) definition (%u, %u)\n", id_of[owners[r]], j, bb, got.idx, got.meta, want.idx, want.meta);
+                                }
+                            }
+                        }
+                    });
+                    if (bad) return fail(BK_ERR_INVALID, "internal: %llu dirty answers disagree with their definition", (unsigned long long)bad.load());
+                }
+                BK_HIP(e->dirty_ix.upload(h_dix));
+                BK_HIP(e->dirty_ans.upload(h_ans));
+            }
+            std::vector<uint64_t>().swap(h_near);
+        }
+        pc.lap("dirty answers");
         // perfect hash over U
         std::vector<uint16_t> h_pilots;
         std::vector<uint32_t> u_pos;
@@ -937,7 +1091,7 @@ int bk_engine_fork(const bk_engine* parent, bk_engine** out) {
     e->file_cell_lo = p->file_cell_lo; e->ablate = p->ablate; e->max_launch_records = p->max_launch_records;
     e->half_lo.m = p->half_lo.m; e->half_lo.log2nb = p->half_lo.log2nb; e->half_hi.m = p->half_hi.m; e->half_hi.log2nb = p->half_hi.log2nb;
     // the index tables are immutable after bk_engine_create: the fork reads the parent's
-    e->prow_id.alias(p->prow_id); e->prow_t.alias(p->prow_t); e->kmer_pos.alias(p->kmer_pos); e->d_view.alias(p->d_view); e->kmer_of.alias(p->kmer_of); e->id_rec.alias(p->id_rec);
+    e->prow_id.alias(p->prow_id); e->prow_t.alias(p->prow_t); e->kmer_pos.alias(p->kmer_pos); e->d_view.alias(p->d_view); e->kmer_of.alias(p->kmer_of); e->id_rec.alias(p->id_rec); e->dirty_ix.alias(p->dirty_ix); e->dirty_ans.alias(p->dirty_ans);
     e->ref_words.alias(p->ref_words); e->cell_codes.alias(p->cell_codes); e->cell_has.alias(p->cell_has); e->cell_clean.alias(p->cell_clean);
     e->cell_clean3.alias(p->cell_clean3); e->cell_yf.alias(p->cell_yf); e->cell_yr.alias(p->cell_yr); e->id_at.alias(p->id_at);
     e->half_lo.pilots.alias(p->half_lo.pilots); e->half_lo.dir.alias(p->half_lo.dir); e->half_lo.cand.alias(p->half_lo.cand);
@@ -1026,7 +1180,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->params.kmer_table_log2;
     a.ktab_overflow = e->ktab_out.p + 4; a.mate = (uint32_t)mate;
     a.occ = e->occ.p; a.n_files = e->n_files;
-    if (test_env("BK_L2_STATS") && !e->dbg.p) { BK_HIP(e->dbg.alloc(16)); BK_HIP(hipMemsetAsync(e->dbg.p, 0, 16 * sizeof(unsigned long long), e->stream)); }
+    if (test_env("BK_L2_STATS") && !e->dbg.p) { BK_HIP(e->dbg.alloc(32)); BK_HIP(hipMemsetAsync(e->dbg.p, 0, 32 * sizeof(unsigned long long), e->stream)); }
     a.dbg = e->dbg.p;
     if (e->W <= 0) {
         // empty window: nothing can touch the index (map_kmers finds no bucket, call.rs:1291-1307); KMC's total k-mer count is all
@@ -1251,13 +1405,13 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
     BK_HIP(hipGetLastError());
     e->in_sample = false;
     if (e->dbg.p) {   // BK_L2_STATS (testing build)
-        unsigned long long h[16];
+        unsigned long long h[32];
         BK_HIP(hipMemcpyAsync(h, e->dbg.p, sizeof h, hipMemcpyDeviceToHost, e->stream));
         BK_HIP(hipMemsetAsync(e->dbg.p, 0, sizeof h, e->stream));
         BK_HIP(hipStreamSynchronize(e->stream));
         fprintf(stderr, "[bk] scan marked: no-diagonal %llu, dirty-head %llu, clean-head %llu, pairs %llu | level 2: k-mers %llu in %llu chunks, simple %llu, dead %llu, "
-                "slow %llu (diffs 0/1/2/3+ with a diagonal: %llu/%llu/%llu/%llu) -> member %llu, neighbour %llu, nothing %llu\n",
-                h[0], h[1], h[2], h[3], h[4], h[11], h[5], h[6], h[7], h[12], h[13], h[14], h[15], h[8], h[9], h[10]);
+                "dirty answers %llu (one difference but id unknown: %llu), slow %llu (diffs 0/1/2/3+ with a diagonal: %llu/%llu/%llu/%llu) -> member %llu, neighbour %llu, nothing %llu\n",
+                h[0], h[1], h[2], h[3], h[4], h[11], h[5], h[6], h[16], h[17], h[7], h[12], h[13], h[14], h[15], h[8], h[9], h[10]);
     }
     return BK_OK;
 }

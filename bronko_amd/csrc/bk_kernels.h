@@ -48,7 +48,7 @@ struct ScanArgs {
     unsigned long long* ktab_overflow;
     uint32_t mate;
     int ablate;                     // measurement aid (-DBK_TESTING build only): 1 = Level 1 only, 2 = no V atomics, 3 = no slow path
-    unsigned long long* dbg;        // -DBK_TESTING build, BK_L2_STATS=1: [16] tallies of what is left to Level 2 and why; null otherwise
+    unsigned long long* dbg;        // -DBK_TESTING build, BK_L2_STATS=1: [32] tallies of what is left to Level 2 and why; null otherwise
 };
 
 struct FinalizeArgs {

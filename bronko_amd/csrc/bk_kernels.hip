@@ -70,7 +70,7 @@ __device__ __forceinline__ HalfDir half_lookup(const HalfView& hv, uint64_t half
 }
 
 // Reference k-mers at Hamming distance exactly 1 from c whose differing position lies in the window.
-// Calls f(j, p) for each (pigeonhole: such a k-mer shares c's low half or c's high half).
+// Calls f(j, p, valid) for each (pigeonhole: such a k-mer shares c's low half or c's high half).
 template <typename F>
 __device__ __forceinline__ void for_each_neighbour(const IndexView& ix, uint64_t c, F&& f) {
     const int k = ix.k;
@@ -82,12 +82,12 @@ __device__ __forceinline__ void for_each_neighbour(const IndexView& ix, uint64_t
     for (uint32_t i = 0; i < dl.cnt; ++i) {
         const uint4 e = *reinterpret_cast<const uint4*>(ix.lo.cand + dl.off + i);
         const int j = single_diff_pos((uint64_t)e.x | ((uint64_t)e.y << 32), c, k);
-        if (j >= wlo && j < whi && ((e.w >> (j - wlo)) & 1u)) f(j, e.z);
+        if (j >= wlo && j < whi && ((e.w >> (j - wlo)) & 1u)) f(j, e.z, e.w);
     }
     for (uint32_t i = 0; i < dh.cnt; ++i) {
         const uint4 e = *reinterpret_cast<const uint4*>(ix.hi.cand + dh.off + i);
         const int j = single_diff_pos((uint64_t)e.x | ((uint64_t)e.y << 32), c, k);
-        if (j >= wlo && j < whi && ((e.w >> (j - wlo)) & 1u)) f(j, e.z);
+        if (j >= wlo && j < whi && ((e.w >> (j - wlo)) & 1u)) f(j, e.z, e.w);
     }
 }
 
@@ -407,6 +407,60 @@ struct SlowPipe {
     __device__ __forceinline__ void finish(const IndexView& ix, unsigned long long* __restrict__ v_counters, CountExact&& count_exact,
                                            const KmerTable& kt) {
         while (stage) advance(ix, v_counters, count_exact, kt);
+    }
+};
+
+// A read k-mer that differs from the reference along its diagonal in exactly one base, at a cell whose reference k-mer is known
+// but not clean: what it is was worked out when the engine was created (bk_device.h DirtyAns).  Two loads -- the k-mer's row of
+// the answer table, then the answer -- one stage per k-mer step of Level 2, like the SlowPipe.
+struct DirtyPipe {
+    int stage = 0;          // wave-uniform: 0 = empty
+    bool have = false;
+    uint32_t id = 0, meta = 0;   // meta: position j in the canonical reference k-mer | base there << 5 | isrc << 7
+    uint32_t dix = 0;
+    uint2 ans{};
+    bool spill = false;               // after the last stage: this lane's k-mer has no answer row ...
+    unsigned long long spill_e = 0;   // ... and is this slow-queue entry
+
+    __device__ __forceinline__ void start(const uint2* q, uint32_t n, int lane, const IndexView& ix) {
+        have = (uint32_t)lane < n;
+        const uint2 e = have ? q[lane] : make_uint2(0u, 0u);
+        id = e.x; meta = e.y;
+        dix = have ? ix.dirty_ix[id] : kNoDirtyIx;
+        stage = 1;
+    }
+    __device__ __forceinline__ void advance(const IndexView& ix, unsigned long long* __restrict__ counters, unsigned long long* __restrict__ v_counters,
+                                            const KmerTable& kt) {
+        const int k = ix.k;
+        const uint32_t j = meta & 31u, bb = (meta >> 5) & 3u, isrc = (meta >> 7) & 1u;
+        if (stage == 1) {
+            if (have && dix != kNoDirtyIx) ans = *reinterpret_cast<const uint2*>(ix.dirty_ans + ((size_t)dix * (uint32_t)k + j) * 4u + bb);
+            stage = 2;
+            return;
+        }
+        if (have && dix != kNoDirtyIx) {
+            const uint32_t kind = ans.y & 3u;
+            if (kind == 1u) atomicAdd(counters + ans.x + isrc, 1ull);
+            else if (kind == 2u) {
+                unsigned long long* row = v_counters + ans.x + (((isrc ^ (ans.y >> 2)) & 1u) ? (uint32_t)ix.v_span + 1u : 0u);
+                atomicAdd(row, 1ull);
+                if (ans.y & 8u) atomicAdd(row + 1, ~0ull);
+            } else if (kind == 3u) atomicAdd(v_counters + ans.x + isrc, 1ull);
+        }
+        spill = false;
+        if (have && (dix == kNoDirtyIx || ((ans.y & 3u) == 0u && kt.keys))) {
+            // no precomputed answer (a k-mer of a low-complexity group too large to enumerate), or one that touches nothing while
+            // the statistics table wants it: rebuild the canonical k-mer (rare)
+            const uint64_t u = ix.kmer_of[id];
+            const int sh = 2 * (k - 1 - (int)j);
+            const uint64_t z = (u & ~(3ull << sh)) | ((uint64_t)bb << sh);
+            const uint64_t t = ~z;
+            const uint64_t zr = (((uint64_t)rev2_32((uint32_t)t) << 32) | rev2_32((uint32_t)(t >> 32))) >> (64 - 2 * k);
+            const uint64_t c = zr < z ? zr : z;
+            if (dix != kNoDirtyIx) ktab_insert(kt, c, isrc, 1u);
+            else { spill = true; spill_e = c | ((unsigned long long)isrc << 62); }   // the caller hands it to the slow pipeline
+        }
+        stage = 0;
     }
 };
 
@@ -842,11 +896,13 @@ constexpr int kAnyWords = 8;                // words of l2_any a wave takes at a
 template <bool STATS, int KT>
 __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
     __shared__ unsigned long long queue_c[kL2Waves * kQueueCap];
+    __shared__ uint2 queue_d[kL2Waves * kQueueCap];
     __shared__ uint2 chunk_q[kL2Waves * kChunkCap];
     __shared__ unsigned int rec_q[kL2Waves * kChunkCap];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     unsigned long long* const q = queue_c + wave * kQueueCap;
+    uint2* const qdq = queue_d + wave * kQueueCap;
     uint2* const cq = chunk_q + wave * kChunkCap;
     unsigned int* const rq = rec_q + wave * kChunkCap;
 
@@ -854,6 +910,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
     const unsigned int* yfw = a.cell_yf + kRefPadWords;
     const unsigned int* yrw = a.cell_yr + kRefPadWords;
     const unsigned int* c3w = a.cell_clean3 + kBitPadWords;
+    const unsigned int* codesw = a.cell_codes + kRefPadWords;
     const int k = KT ? KT : a.k;
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;  // k <= 31
     const uint32_t kmask_lo = (uint32_t)kmask, kmask_hi = (uint32_t)(kmask >> 32);
@@ -879,6 +936,10 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
 #ifdef BK_TESTING
     pipe.dbg = a.dbg;
 #endif
+    // the dirty-cell pipeline (DirtyPipe): same scheme, its own queue
+    uint32_t qd = 0;   // wave-uniform fill
+    DirtyPipe dpipe;
+    const bool have_ans = ix.dirty_ix != nullptr;
     auto start_slow_batch = [&]() {
         const uint32_t nb = min(qn, 64u);
         pipe.start(q, nb, lane, ix);
@@ -888,6 +949,28 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
         if ((uint32_t)lane < rest) q[lane] = tc;
         __builtin_amdgcn_wave_barrier();
         qn = rest;
+    };
+    // one stage of the DirtyPipe; k-mers it cannot answer go to the slow queue (which has room: it is pumped below 32 entries)
+    auto dirty_advance = [&]() {
+        dpipe.advance(ix, a.counters, v_counters, kt);
+        const unsigned long long sm = __ballot(dpipe.spill);
+        if (sm) {
+            if (dpipe.spill) q[qn + lane_prefix(sm)] = dpipe.spill_e;
+            dpipe.spill = false;
+            qn += (uint32_t)__popcll(sm);
+            __builtin_amdgcn_wave_barrier();
+            if (qn >= 32u) { pipe.finish(ix, v_counters, count_exact, kt); start_slow_batch(); }
+        }
+    };
+    auto start_dirty_batch = [&]() {
+        const uint32_t nb = min(qd, 64u);
+        dpipe.start(qdq, nb, lane, ix);
+        const uint32_t rest = qd - nb;
+        const uint2 tc = ((uint32_t)lane < rest) ? qdq[64 + lane] : make_uint2(0u, 0u);
+        __builtin_amdgcn_wave_barrier();
+        if ((uint32_t)lane < rest) qdq[lane] = tc;
+        __builtin_amdgcn_wave_barrier();
+        qd = rest;
     };
 
     uint64_t n_records = a.n_records;
@@ -961,7 +1044,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
             uint32_t f_lo = (uint32_t)f0, f_hi = (uint32_t)(f0 >> 32), r_lo2 = (uint32_t)r0, r_hi2 = (uint32_t)(r0 >> 32);
             // along the diagonal: base differences with the reference as the read sees it, and the clean / follow bits of
             // the <= 32 cells of the chunk, all in step order
-            uint64_t da = 0, db = 0, yc = 0;
+            uint64_t da = 0, db = 0, yc = 0, cc = 0;   // cc: cell_codes of the chunk's cells (0 none, 1 canonical as written, 2 reverse-complemented)
             uint32_t c3 = 0;   // per cell of the chunk: no other reference k-mer form within Hamming distance 3 (bk_device.h cell_clean3)
             uint32_t d_lo = 0, d_hi = 0, id = 0;
             bool id_ok = false;
@@ -972,12 +1055,14 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
                 if (fwd2) {
                     ra = symbols_at(refw, c_first); rb = symbols_at(refw, c_first + 32);
                     yc = symbols_at(yfw, c_first);
+                    cc = symbols_at(codesw, c_first);
                     c3 = bits32_at(c3w, c_first);
                 } else {
                     // read base s_first + t <-> complement of reference base c_first + k - 1 - t
                     ra = ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 31));
                     rb = ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 63));
                     yc = rev2_64(symbols_at(yrw, c_first - 31));
+                    cc = rev2_64(symbols_at(codesw, c_first - 31));
                     c3 = __builtin_bitreverse32(bits32_at(c3w, c_first - 31));
                 }
                 da = ga ^ ra; db = gb ^ rb;
@@ -990,6 +1075,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
             const uint32_t g4[4] = {(uint32_t)ga, (uint32_t)(ga >> 32), (uint32_t)gb, (uint32_t)(gb >> 32)};
             const uint32_t d4[4] = {(uint32_t)da, (uint32_t)(da >> 32), (uint32_t)db, (uint32_t)(db >> 32)};
             const uint32_t y2[2] = {(uint32_t)yc, (uint32_t)(yc >> 32)};
+            const uint32_t c2[2] = {(uint32_t)cc, (uint32_t)(cc >> 32)};
             for (uint32_t t = 0; t < nmax; ++t) {
                 const uint32_t bi = km1 + t;                 // base of the chunk that completes k-mer t
                 const uint32_t gi = bi >> 4, sh = 2u * (bi & 15u), ci = t >> 4, csh = 2u * (t & 15u);
@@ -1029,8 +1115,38 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
                 // ... except two differences from a reference k-mer that has no other reference k-mer form within distance 3:
                 // such a k-mer is neither a reference k-mer nor one base away from one (triangle inequality) -- it touches
                 // nothing (full_kmer_stats: only the statistics table wants it)
+                // one base differs at a cell whose reference k-mer is known but not clean (other reference k-mers nearby, or the
+                // other orientation of a repeat): the answer was worked out at create (DirtyAns) -- queue (id, position and base in
+                // the orientation of the canonical reference k-mer, read orientation) for the DirtyPipe
+                const uint32_t code = ((ci ? c2[1] : c2[0]) >> csh) & 3u;
+                const bool dfast = have_ans && id_known && !clean && n_diff == 1 && code != 0u;
+                {
+                    const unsigned long long dm = __ballot(dfast);
+                    if (dm) {
+                        if (dfast) {
+                            const int from_right = dbits ? (__builtin_ctz(dbits) >> 1) : 16 + (__builtin_ctz(dbits_hi) >> 1);
+                            const int bsh = 2 * from_right;
+                            const uint32_t br = (bsh >= 32 ? f_hi >> (bsh - 32) : f_lo >> bsh) & 3u;             // the differing base as read
+                            const uint32_t o = fwd2 ? (uint32_t)(k - 1 - from_right) : (uint32_t)from_right;      // offset along the reference
+                            const uint32_t bfw = fwd2 ? br : 3u - br;                                             // base on its forward strand
+                            const bool rcq = code == 2u;                                                          // the cell's k-mer was reverse-complemented
+                            const uint32_t jq = rcq ? km1 - o : o, bq = rcq ? 3u - bfw : bfw;
+                            const bool lt = f_hi < r_hi2 || (f_hi == r_hi2 && f_lo < r_lo2);                      // lcb.rs:90-94
+                            qdq[qd + lane_prefix(dm)] = make_uint2(id, jq | (bq << 5) | (lt ? 0u : 1u << 7));
+                        }
+                        qd += (uint32_t)__popcll(dm);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    if (qd >= 32u) {
+                        while (dpipe.stage) dirty_advance();
+                        start_dirty_batch();
+                    } else if (dpipe.stage) {
+                        dirty_advance();
+                    }
+                }
                 const bool dead = ok && n_diff == 2u && ((c3 >> t) & 1u);
-                const bool miss = valid && !simple && !(dead && !STATS) && !BK_ABLATE(a, 3);
+                const bool miss = valid && !simple && !dfast && !(dead && !STATS) && !BK_ABLATE(a, 3);
+                BK_DBG(a, 16, dfast, 1); BK_DBG(a, 17, ok && !id_known && n_diff == 1 && code != 0u, 1);
                 BK_DBG(a, 4, valid, 1); BK_DBG(a, 5, simple, 1); BK_DBG(a, 6, valid && !simple && dead, 1); BK_DBG(a, 7, miss, 1);
                 BK_DBG(a, 12 + (n_diff > 3u ? 3u : n_diff), miss && ok, 1);
                 const unsigned long long mm = __ballot(miss);
@@ -1122,6 +1238,11 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
             anyw = (lane < kAnyWords && i < n_any) ? a.l2_any[i] : 0u;
             if (anyw) a.l2_any[i] = 0u;
         }
+    }
+    while (dpipe.stage) dirty_advance();
+    if (qd) {
+        start_dirty_batch();   // qd < 64
+        while (dpipe.stage) dirty_advance();
     }
     pipe.finish(ix, v_counters, count_exact, kt);
     if (qn) {
@@ -1509,7 +1630,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         // neighbours; several buckets -> general path (K2b).
         if (ix.amb[p] & 1u) {
             uint32_t jmask = 0;   // window positions at which c has a neighbouring reference k-mer
-            for_each_neighbour(ix, c, [&](int jj, uint32_t) { jmask |= 1u << (jj - ix.wstart); });
+            for_each_neighbour(ix, c, [&](int jj, uint32_t, uint32_t) { jmask |= 1u << (jj - ix.wstart); });
             if (jmask != (1u << t)) {
                 const unsigned int at = atomicAdd(a.n_deferred, 1u);
                 a.deferred[at] = (uint32_t)vi;
@@ -1603,7 +1724,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
             // u has another reference k-mer within Hamming distance 2: c may touch a second window bucket.  Enumerate its
             // neighbours; several buckets -> general path (K2b)
             uint32_t jmask = 0;
-            for_each_neighbour(ix, c, [&](int jj, uint32_t) { jmask |= 1u << (jj - ix.wstart); });
+            for_each_neighbour(ix, c, [&](int jj, uint32_t, uint32_t) { jmask |= 1u << (jj - ix.wstart); });
             if (jmask != (1u << t)) {
                 const unsigned int at = atomicAdd(a.n_deferred, 1u);
                 a.deferred[at] = (uint32_t)(wk * rl + oo);

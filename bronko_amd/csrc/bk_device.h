@@ -56,9 +56,13 @@ constexpr uint32_t kIdDirty = 1u, kIdRc = 2u, kIdSimple = 4u;
 struct alignas(8) DirtyAns {
     uint32_t idx;    // kind 1: E counter 2 * id' (+ isrc); kind 2: V counter of direction 0 relative to the V part (+ row length
                      // when isrc ^ rcu); kind 3: pseudo k-mer counter relative to the V part (+ isrc)
-    uint32_t meta;   // bits 0-1 kind (0 = touches nothing); bit 2 rcu (kind 2); bit 3 (kind 2): -1 on the next counter as well
+    uint32_t meta;   // bits 0-1 kind (0 = touches nothing); bit 2 rcu (kind 2); bit 3 (kind 2): -1 on the next counter as well;
+                     // bit 4: no answer was worked out for this reference k-mer (search instead)
 };
-constexpr uint32_t kNoDirtyIx = 0xffffffffu;
+constexpr uint32_t kAnsNone = 16u;
+// per-cell flags byte (Level 2): bits 0-1 = cell_codes symbol (0 no k-mer of U starts here, 1 canonical as written, 2 reverse-
+// complemented), bit 2 = clean (cell_yf bit 0), bit 3 = cell_clean3
+constexpr uint32_t kCellClean = 4u, kCellClean3 = 8u;
 
 // Multiplicative hash into a table of 2^log2s positions.
 BK_HD uint32_t hash_key(uint64_t key, uint32_t log2s) {
@@ -130,8 +134,9 @@ struct IndexView {
     const KmerPos*   kmer_pos; // [m] perfect-hash table of U (membership test, diagonal seeding)
     const uint64_t*  kmer_of;  // [n_u] id -> canonical k-mer
     const IdRec*     id_rec;   // [n_u] id -> k-mer, first cell, flags (see IdRec)
-    const uint32_t*  dirty_ix; // [n_u] id -> row of dirty_ans (kNoDirtyIx: none), or null when the tables were not built
-    const DirtyAns*  dirty_ans;// [n_dirty][k][4] (see DirtyAns), indexed (row * k + j) * 4 + bb
+    const DirtyAns*  dirty_ans;// [n_full][k][4] (see DirtyAns), indexed (id * k + j) * 4 + bb; rows of k-mers all of whose cells are
+                               // clean are never read; null when the table was not built (index too large)
+    const uint8_t*   cell_flags;// [total_cells] per-cell flags byte (see kCellClean)
     // the reference in reference order, for the diagonal walk of scan_count (staged in LDS when it fits):
     const uint32_t*  ref_words;   // 2-bit packed bases of all cells (nt_to_bits, 16 per word, LSB first), padded in front
                                   // (bk_kernels.h scan_ref_pad_words) and behind

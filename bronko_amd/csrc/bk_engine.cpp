@@ -221,8 +221,8 @@ struct bk_engine {
     DevBuf<bk::IndexView> d_view;   // device copy of view()
     DevBuf<uint64_t> kmer_of;
     DevBuf<bk::IdRec> id_rec;
-    DevBuf<uint32_t> dirty_ix;
     DevBuf<bk::DirtyAns> dirty_ans;
+    DevBuf<uint8_t> cell_flags;
     DevBuf<uint32_t> ref_words, cell_codes, cell_has, cell_clean, cell_clean3, cell_yf, cell_yr, id_at;
     struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0; } half_lo, half_hi;
     DevBuf<unsigned int> deferred, n_deferred;
@@ -288,7 +288,7 @@ struct bk_engine {
     bk::IndexView view() const {
         bk::IndexView v{};
         v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb;
-        v.kmer_of = kmer_of.p; v.id_rec = id_rec.p; v.dirty_ix = dirty_ans.p ? dirty_ix.p : nullptr; v.dirty_ans = dirty_ans.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_clean3 = cell_clean3.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
+        v.kmer_of = kmer_of.p; v.id_rec = id_rec.p; v.dirty_ans = dirty_ans.p; v.cell_flags = cell_flags.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_clean3 = cell_clean3.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
         v.n_full = n_full; v.n_prows = n_prows; v.prow_id = prow_id.p; v.prow_t = prow_t.p; v.v_omin = v_omin; v.v_span = v_span; v.v_off = v_off;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb};
@@ -739,6 +739,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         for (size_t i = 0; i < h_u.size(); i++) rc_of_id[id_of[i]] = first_rc[i];
         std::vector<uint32_t> h_codes(h_refw.size(), 0u), h_yf(h_refw.size(), 0u), h_yr(h_refw.size(), 0u);   // bk_device.h
         std::vector<uint8_t> h_needs_ans(h_u.size(), 0);   // by id: some cell of this reference k-mer is not clean
+        std::vector<uint8_t> h_cflags(std::max<uint64_t>(cells, 1), 0);   // bk_device.h kCellClean
         const size_t bpad_w = (size_t)bk::scan_bit_pad_words();
         std::vector<uint32_t> h_has(bpad_w + (cells + 31) / 32 + (size_t)bk::scan_bit_back_words(), 0u), h_clean(h_has.size(), 0u), h_clean3(h_has.size(), 0u);
         for (uint64_t c = 0; c < cells; c++) {
@@ -755,6 +756,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             h_has[bpad_w + (c >> 5)] |= 1u << (c & 31);
             if (clean) h_clean[bpad_w + (c >> 5)] |= 1u << (c & 31);
             else h_needs_ans[h_id_at[c]] = 1;
+            h_cflags[c] = (uint8_t)((rc_here ? 2u : 1u) | (clean ? bk::kCellClean : 0u) | (h_amb3[h_id_at[c]] ? 0u : bk::kCellClean3));
             if (!h_amb3[h_id_at[c]]) h_clean3[bpad_w + (c >> 5)] |= 1u << (c & 31);
             h_yf[wi] |= (clean | (from_prev ? 2u : 0u)) << sh;
             h_yr[wi] |= (clean | (to_next ? 2u : 0u)) << sh;
@@ -769,14 +771,15 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         {
             std::vector<uint32_t> idx_by_id(h_u.size());
             for (size_t i = 0; i < h_u.size(); i++) idx_by_id[id_of[i]] = (uint32_t)i;
-            std::vector<uint32_t> h_dix(std::max<size_t>(h_u.size(), 1), bk::kNoDirtyIx);
-            std::vector<uint32_t> owners;   // index into h_u of each row
+            // rows are indexed by id (no indirection: Level 2 reads an answer with one load); only the rows of k-mers with a
+            // cell that is not clean are filled in -- the others are never read
+            std::vector<uint32_t> owners;   // index into h_u of each filled row
             for (size_t id = 0; id < e->n_full; id++)
-                if (h_needs_ans[id] && !h_no_list[idx_by_id[id]]) { h_dix[id] = (uint32_t)owners.size(); owners.push_back(idx_by_id[id]); }
+                if (h_needs_ans[id]) owners.push_back(idx_by_id[id]);
             const size_t per = (size_t)k * 4;
-            const bool build = e->W > 0 && owners.size() * per * sizeof(bk::DirtyAns) <= ((size_t)8 << 30);
+            const bool build = e->W > 0 && (size_t)e->n_full * per * sizeof(bk::DirtyAns) <= ((size_t)16 << 30);
             if (build && !owners.empty()) {
-                std::vector<bk::DirtyAns> h_ans(owners.size() * per, bk::DirtyAns{0u, 0u});
+                std::vector<bk::DirtyAns> h_ans((size_t)e->n_full * per, bk::DirtyAns{0u, 0u});
                 const uint64_t vreal = bk::v_real_len(e->n_full, e->v_span);
                 auto diff1 = [&](uint64_t a, uint64_t b) -> int {   // position (from the left) of the single differing base, or -1
                     const uint64_t x = a ^ b, y = (x | (x >> 1)) & 0x5555555555555555ull;
@@ -788,6 +791,11 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     for (size_t r = r0; r < r1; r++) {
                         const uint32_t i = owners[r];
                         const uint64_t u = h_u[i];
+                        const size_t row = id_of[i];
+                        if (h_no_list[i]) {   // a low-complexity group too large to enumerate: no near list, no answers
+                            for (size_t x = 0; x < per; x++) h_ans[row * per + x] = bk::DirtyAns{0u, bk::kAnsNone};
+                            continue;
+                        }
                         fl.clear();
                         fl.emplace_back(u, (uint32_t)(2 * i));
                         for (auto it = std::lower_bound(h_near.begin(), h_near.end(), (uint64_t)i << 32); it != h_near.end() && (*it >> 32) == i; ++it) {
@@ -798,7 +806,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                             const int sh = 2 * (k - 1 - j);
                             for (uint32_t bb = 0; bb < 4; bb++) {
                                 if (((u >> sh) & 3ull) == bb) continue;
-                                bk::DirtyAns& A = h_ans[(r * (size_t)k + j) * 4 + bb];
+                                bk::DirtyAns& A = h_ans[(row * (size_t)k + j) * 4 + bb];
                                 const uint64_t z = (u & ~(3ull << sh)) | ((uint64_t)bb << sh);
                                 const uint64_t zr = bronko::reverse_complement_u64(z, k);
                                 const bool flip = zr < z;              // the canonical form of z is its reverse complement
@@ -843,6 +851,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     parallel_for(owners.size(), [&](size_t r0, size_t r1) {
                         for (size_t r = r0; r < r1; r++) {
                             const uint64_t u = h_u[owners[r]];
+                            if (h_no_list[owners[r]]) continue;
                             for (int j = 0; j < k; j++) for (uint32_t bb = 0; bb < 4; bb++) {
                                 const int sh = 2 * (k - 1 - j);
                                 if (((u >> sh) & 3ull) == bb) continue;
@@ -879,7 +888,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                                         }
                                     }
                                 }
-                                const bk::DirtyAns& got = h_ans[(r * (size_t)k + j) * 4 + bb];
+                                const bk::DirtyAns& got = h_ans[((size_t)id_of[owners[r]] * (size_t)k + j) * 4 + bb];
                                 if (got.idx != want.idx || got.meta != want.meta) {
                                     if (bad++ < 5) fprintf(stderr, "[bk] dirty answer differs: id %u j %d bb %u: table (%u, %u) definition (%u, %u)\n", id_of[owners[r]], j, bb, got.idx, got.meta, want.idx, want.meta);
                                 }
@@ -888,7 +897,6 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     });
                     if (bad) return fail(BK_ERR_INVALID, "internal: %llu dirty answers disagree with their definition", (unsigned long long)bad.load());
                 }
-                BK_HIP(e->dirty_ix.upload(h_dix));
                 BK_HIP(e->dirty_ans.upload(h_ans));
             }
             std::vector<uint64_t>().swap(h_near);
@@ -914,6 +922,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         BK_HIP(e->cell_yf.upload(h_yf));
         BK_HIP(e->cell_yr.upload(h_yr));
         BK_HIP(e->cell_codes.upload(h_codes));
+        BK_HIP(e->cell_flags.upload(h_cflags));
         BK_HIP(e->id_at.upload(h_id_at));
         e->file_cell_lo.assign((size_t)ix->n_files, 0u);
         for (int f = 0; f < ix->n_files; f++) e->file_cell_lo[f] = ix->n_seqs[f] ? (uint32_t)cell_off[f][0] : (uint32_t)cells;
@@ -1091,7 +1100,7 @@ int bk_engine_fork(const bk_engine* parent, bk_engine** out) {
     e->file_cell_lo = p->file_cell_lo; e->ablate = p->ablate; e->max_launch_records = p->max_launch_records;
     e->half_lo.m = p->half_lo.m; e->half_lo.log2nb = p->half_lo.log2nb; e->half_hi.m = p->half_hi.m; e->half_hi.log2nb = p->half_hi.log2nb;
     // the index tables are immutable after bk_engine_create: the fork reads the parent's
-    e->prow_id.alias(p->prow_id); e->prow_t.alias(p->prow_t); e->kmer_pos.alias(p->kmer_pos); e->d_view.alias(p->d_view); e->kmer_of.alias(p->kmer_of); e->id_rec.alias(p->id_rec); e->dirty_ix.alias(p->dirty_ix); e->dirty_ans.alias(p->dirty_ans);
+    e->prow_id.alias(p->prow_id); e->prow_t.alias(p->prow_t); e->kmer_pos.alias(p->kmer_pos); e->d_view.alias(p->d_view); e->kmer_of.alias(p->kmer_of); e->id_rec.alias(p->id_rec); e->dirty_ans.alias(p->dirty_ans); e->cell_flags.alias(p->cell_flags);
     e->ref_words.alias(p->ref_words); e->cell_codes.alias(p->cell_codes); e->cell_has.alias(p->cell_has); e->cell_clean.alias(p->cell_clean);
     e->cell_clean3.alias(p->cell_clean3); e->cell_yf.alias(p->cell_yf); e->cell_yr.alias(p->cell_yr); e->id_at.alias(p->id_at);
     e->half_lo.pilots.alias(p->half_lo.pilots); e->half_lo.dir.alias(p->half_lo.dir); e->half_lo.cand.alias(p->half_lo.cand);

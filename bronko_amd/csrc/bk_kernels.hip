@@ -243,7 +243,6 @@ void launch_ktab_stats(const unsigned long long* keys, const unsigned int* cnt, 
 // global memory instead (REF_LDS = false).
 constexpr int kScanBlock = 1024;
 constexpr int kScanWaves = kScanBlock / 64;
-constexpr int kQueueCap = 96;               // slow-path queue: a batch starts at 32 pending, a step adds <= 64
 constexpr int kRangeCap = 128;              // N queue: a batch starts at 64 pending, a round adds <= 64
 constexpr int kNIters = 8;                  // mismatches of a piece the N batch resolves in one pass
 constexpr uint32_t kMaxRecordsPerGroup = 16384;
@@ -407,60 +406,6 @@ struct SlowPipe {
     __device__ __forceinline__ void finish(const IndexView& ix, unsigned long long* __restrict__ v_counters, CountExact&& count_exact,
                                            const KmerTable& kt) {
         while (stage) advance(ix, v_counters, count_exact, kt);
-    }
-};
-
-// A read k-mer that differs from the reference along its diagonal in exactly one base, at a cell whose reference k-mer is known
-// but not clean: what it is was worked out when the engine was created (bk_device.h DirtyAns).  Two loads -- the k-mer's row of
-// the answer table, then the answer -- one stage per k-mer step of Level 2, like the SlowPipe.
-struct DirtyPipe {
-    int stage = 0;          // wave-uniform: 0 = empty
-    bool have = false;
-    uint32_t id = 0, meta = 0;   // meta: position j in the canonical reference k-mer | base there << 5 | isrc << 7
-    uint32_t dix = 0;
-    uint2 ans{};
-    bool spill = false;               // after the last stage: this lane's k-mer has no answer row ...
-    unsigned long long spill_e = 0;   // ... and is this slow-queue entry
-
-    __device__ __forceinline__ void start(const uint2* q, uint32_t n, int lane, const IndexView& ix) {
-        have = (uint32_t)lane < n;
-        const uint2 e = have ? q[lane] : make_uint2(0u, 0u);
-        id = e.x; meta = e.y;
-        dix = have ? ix.dirty_ix[id] : kNoDirtyIx;
-        stage = 1;
-    }
-    __device__ __forceinline__ void advance(const IndexView& ix, unsigned long long* __restrict__ counters, unsigned long long* __restrict__ v_counters,
-                                            const KmerTable& kt) {
-        const int k = ix.k;
-        const uint32_t j = meta & 31u, bb = (meta >> 5) & 3u, isrc = (meta >> 7) & 1u;
-        if (stage == 1) {
-            if (have && dix != kNoDirtyIx) ans = *reinterpret_cast<const uint2*>(ix.dirty_ans + ((size_t)dix * (uint32_t)k + j) * 4u + bb);
-            stage = 2;
-            return;
-        }
-        if (have && dix != kNoDirtyIx) {
-            const uint32_t kind = ans.y & 3u;
-            if (kind == 1u) atomicAdd(counters + ans.x + isrc, 1ull);
-            else if (kind == 2u) {
-                unsigned long long* row = v_counters + ans.x + (((isrc ^ (ans.y >> 2)) & 1u) ? (uint32_t)ix.v_span + 1u : 0u);
-                atomicAdd(row, 1ull);
-                if (ans.y & 8u) atomicAdd(row + 1, ~0ull);
-            } else if (kind == 3u) atomicAdd(v_counters + ans.x + isrc, 1ull);
-        }
-        spill = false;
-        if (have && (dix == kNoDirtyIx || ((ans.y & 3u) == 0u && kt.keys))) {
-            // no precomputed answer (a k-mer of a low-complexity group too large to enumerate), or one that touches nothing while
-            // the statistics table wants it: rebuild the canonical k-mer (rare)
-            const uint64_t u = ix.kmer_of[id];
-            const int sh = 2 * (k - 1 - (int)j);
-            const uint64_t z = (u & ~(3ull << sh)) | ((uint64_t)bb << sh);
-            const uint64_t t = ~z;
-            const uint64_t zr = (((uint64_t)rev2_32((uint32_t)t) << 32) | rev2_32((uint32_t)(t >> 32))) >> (64 - 2 * k);
-            const uint64_t c = zr < z ? zr : z;
-            if (dix != kNoDirtyIx) ktab_insert(kt, c, isrc, 1u);
-            else { spill = true; spill_e = c | ((unsigned long long)isrc << 62); }   // the caller hands it to the slow pipeline
-        }
-        stage = 0;
     }
 };
 
@@ -878,52 +823,53 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ K1b
-// Level 2: the k-mers the scan left marked (ScanArgs::l2_bits, one bit per k-mer of each record) -- k-mers without a
-// usable diagonal, at dirty cells, with several differences that the N batch could not settle, exact k-mers of reads off
-// the LDS window.  Few (about one k-mer in a thousand on the benchmark), so this kernel mostly reads the bitmap and finds
-// it empty; it clears the bits it takes.  Marked runs are cut into chunks of <= k k-mers, queued per wave in LDS, and
-// done 64 at a time ("G batch"), one chunk per lane, the exact per-k-mer logic: rolling canonical k-mer + 2-bit
-// difference mask along the diagonal (both pre-aligned word-parallel, so a step is pure ALU).  A k-mer with one
-// difference at a clean cell of known id is a single-k-mer S run (+1 / -1 in its V row); one with two differences at a
-// cell whose k-mer is isolated up to Hamming distance 3 (cell_clean3) touches nothing and is dropped; everything else
-// goes to the slow path: compacted (ballot + prefix popcount) into a per-wave LDS queue, batches of the SlowPipe (one
-// k-mer per lane): perfect-hash membership test (a hit is a +1 on the k-mer's E counter), then the neighbour search over
-// the two half-k-mer directories and a +1 / -1 in the V row of the smallest (position, NbEntry::p).
+// Level 2: the k-mers the scan left marked (ScanArgs::l2_bits, one bit per k-mer of each record) -- k-mers at cells that are
+// not clean, with several differences that the N batch could not settle, without a usable diagonal, exact k-mers of reads off
+// the LDS window.  One k-mer per lane, nothing rolls: every lane extracts its k-mer and the reference along the record's
+// diagonal straight from the packed words, so the 64 k-mers of a batch are independent and all their loads are in flight
+// together (this kernel is latency, not arithmetic: about one k-mer in a thousand on the benchmark, one in forty with four
+// strains).
+//   discovery   l2_any (a bit per record) -> marked records (LDS queue) -> their bitmap words -> the marked k-mers, listed
+//               (record, k-mer index) in an LDS queue in record order: the k-mers of a marked run sit in neighbouring lanes.
+//               Every bit taken is cleared: the bitmaps are all zero again when the kernel ends.
+//   per k-mer   differences with the reference at its cell along the diagonal, the cell's id and flags (bk_device.h):
+//               0 differences, a reference k-mer starts there     -> it IS that k-mer: +1 on its E counter
+//               1 difference, clean cell                          -> a single-k-mer S run in the V row of (id, offset, base)
+//               1 difference, cell not clean                      -> the precomputed answer (DirtyAns): one load
+//               2 differences, isolated up to distance 3          -> touches nothing (full_kmer_stats: statistics table)
+//               everything else (no diagonal, no k-mer at the cell, more differences) -> the slow path: compacted into a
+//               per-wave LDS queue, batches of the SlowPipe (perfect-hash membership, then the neighbour search over the two
+//               half-k-mer directories, smallest (position, NbEntry::p) wins).
+//   V atomics   a single-k-mer S run is +1 at its counter, -1 at the next.  The k-mers that cover one sequencing error are
+//               consecutive and land in one row at consecutive offsets, so the -1 of one is the +1 of its neighbour: lanes
+//               compare with their neighbours (shuffles) and only the ends of a run reach memory.
 constexpr int kL2Block = 256;
 constexpr int kL2Waves = kL2Block / 64;
-constexpr int kChunkCap = 128;              // chunk queue: a batch starts at 64 pending, a step adds <= 64
-constexpr int kAnyWords = 8;                // words of l2_any a wave takes at a time (256 records): many short waves, the kernel is a chain of dependent loads
+constexpr int kL2QueueCap = 128;            // record / slow queues: a batch is taken at 64 pending, a round adds <= 64
+constexpr int kL2KmerCap = 256;             // k-mer queue
+constexpr int kAnyWords = 8;                // words of l2_any a wave takes at a time (256 records)
 template <bool STATS, int KT>
 __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
-    __shared__ unsigned long long queue_c[kL2Waves * kQueueCap];
-    __shared__ uint2 queue_d[kL2Waves * kQueueCap];
-    __shared__ uint2 chunk_q[kL2Waves * kChunkCap];
-    __shared__ unsigned int rec_q[kL2Waves * kChunkCap];
+    __shared__ unsigned long long queue_c[kL2Waves * kL2QueueCap];   // slow-path queue: canonical k-mer | orientation << 62 | stat_only << 63
+    __shared__ unsigned int rec_q[kL2Waves * kL2QueueCap];
+    __shared__ unsigned long long kmer_q[kL2Waves * kL2KmerCap];     // record << 16 | k-mer index in the record
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    unsigned long long* const q = queue_c + wave * kQueueCap;
-    uint2* const qdq = queue_d + wave * kQueueCap;
-    uint2* const cq = chunk_q + wave * kChunkCap;
-    unsigned int* const rq = rec_q + wave * kChunkCap;
+    unsigned long long* const q = queue_c + wave * kL2QueueCap;
+    unsigned int* const rq = rec_q + wave * kL2QueueCap;
+    unsigned long long* const kq = kmer_q + wave * kL2KmerCap;
 
     const unsigned int* refw = a.ref_words + kRefPadWords;
-    const unsigned int* yfw = a.cell_yf + kRefPadWords;
-    const unsigned int* yrw = a.cell_yr + kRefPadWords;
-    const unsigned int* c3w = a.cell_clean3 + kBitPadWords;
-    const unsigned int* codesw = a.cell_codes + kRefPadWords;
     const int k = KT ? KT : a.k;
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;  // k <= 31
-    const uint32_t kmask_lo = (uint32_t)kmask, kmask_hi = (uint32_t)(kmask >> 32);
-    const int rcshift = 2 * (k - 1);
-    const uint32_t rc_sh = (uint32_t)rcshift & 31u;
-    const uint32_t rc_in_hi = rcshift >= 32 ? 0xffffffffu : 0u;   // which half receives the new complemented base
     const uint32_t km1 = (uint32_t)k - 1u;
-    const uint32_t chunk = (uint32_t)k;                             // most k-mers one lane takes
     const int omin = a.v_omin, span = a.v_span;
     unsigned long long* const v_counters = a.counters + a.v_off;
     const uint32_t last_word = a.stride_words - 1u;
     const IndexView& ix = *a.ixp;
     const KmerTable kt{STATS ? a.ktab_keys : nullptr, a.ktab_cnt, a.ktab_log2, a.ktab_overflow, a.mate};   // STATS = full_kmer_stats
+    const DirtyAns* const answers = ix.dirty_ans;
+    const uint8_t* const cflags = ix.cell_flags;
 
     // slow path: +1 on the E counter of reference k-mer `id` read in orientation `isrc`
     auto count_exact = [&](bool hit, uint32_t /*cell*/, uint32_t id, uint32_t isrc, uint32_t /*rc_first*/) {
@@ -931,16 +877,12 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
         BK_DBG(a, 8, hit, 1);
     };
     uint32_t qn = 0;   // wave-uniform fill of the slow-path queue
-    uint32_t qc = 0;   // wave-uniform fill of the chunk queue
     SlowPipe pipe;
 #ifdef BK_TESTING
     pipe.dbg = a.dbg;
 #endif
-    // the dirty-cell pipeline (DirtyPipe): same scheme, its own queue
-    uint32_t qd = 0;   // wave-uniform fill
-    DirtyPipe dpipe;
-    const bool have_ans = ix.dirty_ix != nullptr;
-    auto start_slow_batch = [&]() {
+    // resolve up to 64 queued k-mers: every stage's loads of the whole batch are issued together
+    auto slow_batch = [&]() {
         const uint32_t nb = min(qn, 64u);
         pipe.start(q, nb, lane, ix);
         const uint32_t rest = qn - nb;
@@ -949,28 +891,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
         if ((uint32_t)lane < rest) q[lane] = tc;
         __builtin_amdgcn_wave_barrier();
         qn = rest;
-    };
-    // one stage of the DirtyPipe; k-mers it cannot answer go to the slow queue (which has room: it is pumped below 32 entries)
-    auto dirty_advance = [&]() {
-        dpipe.advance(ix, a.counters, v_counters, kt);
-        const unsigned long long sm = __ballot(dpipe.spill);
-        if (sm) {
-            if (dpipe.spill) q[qn + lane_prefix(sm)] = dpipe.spill_e;
-            dpipe.spill = false;
-            qn += (uint32_t)__popcll(sm);
-            __builtin_amdgcn_wave_barrier();
-            if (qn >= 32u) { pipe.finish(ix, v_counters, count_exact, kt); start_slow_batch(); }
-        }
-    };
-    auto start_dirty_batch = [&]() {
-        const uint32_t nb = min(qd, 64u);
-        dpipe.start(qdq, nb, lane, ix);
-        const uint32_t rest = qd - nb;
-        const uint2 tc = ((uint32_t)lane < rest) ? qdq[64 + lane] : make_uint2(0u, 0u);
-        __builtin_amdgcn_wave_barrier();
-        if ((uint32_t)lane < rest) qdq[lane] = tc;
-        __builtin_amdgcn_wave_barrier();
-        qd = rest;
+        pipe.finish(ix, v_counters, count_exact, kt);
     };
 
     uint64_t n_records = a.n_records;
@@ -981,274 +902,191 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
     const uint32_t* const words0 = a.words + a.rec_base * a.stride_words;
     const uint32_t nw = a.l2_words;
 
-    // Work discovery, three levels down: l2_any has one bit per record ("some k-mer of it is marked"); this wave reads kAnyWords of
-    // its words at a time, compacts the marked records into an LDS queue, takes 64 of them (one per lane) and
-    // loads 8 words of their bitmap rows at a time; the marked runs become chunks.
-    const uint64_t n_any = (n_records + 31) / 32;                    // words of l2_any
-    const uint64_t n_blk = (n_any + kAnyWords - 1) / kAnyWords;
-    uint64_t blk = (uint64_t)blockIdx.x * kL2Waves + wave;           // kAnyWords words of l2_any
-    uint32_t anyw = 0;                                               // this lane's word of them: records still to queue
-    if (blk < n_blk) {
-        const uint64_t i = blk * kAnyWords + lane;
-        anyw = (lane < kAnyWords && i < n_any) ? a.l2_any[i] : 0u;
-        if (anyw) a.l2_any[i] = 0u;     // taken: l2_any and l2_bits are all zero again when this kernel ends
-    }
-    bool any_done = blk >= n_blk;       // no more words of l2_any for this wave
-    uint32_t qr = 0;                    // wave-uniform fill of the record queue
-    bool have_recs = false;             // a batch of records is loaded:
-    uint32_t rec = 0xffffffffu;         //   this lane's record (index within the launch), or none
-    uint32_t wg = 0, wi = 0;            //   first word of the group of 8 bitmap words in registers, current word of the group
-    uint32_t bw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool need_load = false;
-    bool done = false;
-    for (;;) {
-        if (qc >= 64u || (done && qc != 0u)) {
-            // ================= G batch: one queued chunk (<= k k-mers) per lane ==================
-            // The last batch of a wave is rarely full: its chunks are cut into 2^ps parts, one per lane, so that the batch
-            // takes as many steps as the longest part and not as the longest chunk.
-            const uint32_t nb2 = min(qc, 64u);
-            const uint32_t ps = 31u - (uint32_t)__builtin_clz(64u / nb2);     // wave-uniform
-            const uint32_t sub = (chunk + (1u << ps) - 1u) >> ps;             // k-mers per part
-            const uint32_t ei = (uint32_t)lane >> ps, part = (uint32_t)lane & ((1u << ps) - 1u);
-            const uint2 ce = ei < nb2 ? cq[ei] : make_uint2(0u, 0u);
-            {   // move the rest of the queue down
-                const uint32_t rest = qc - nb2;
-                const uint2 t = (uint32_t)lane < rest ? cq[64 + lane] : make_uint2(0u, 0u);
-                __builtin_amdgcn_wave_barrier();
-                if ((uint32_t)lane < rest) cq[lane] = t;
-                __builtin_amdgcn_wave_barrier();
-                qc = rest;
-            }
-            const uint32_t n_e = ce.y >> 16;     // 0 for a lane without an entry
-            BK_DBG(a, 11, n_e != 0u && part == 0u, 1);
-            const uint32_t s_first = (ce.y & 0xffffu) + part * sub;
-            const uint32_t n2 = n_e > part * sub ? min(sub, n_e - part * sub) : 0u;
-            const uint2 dgf = a.l2_diag[ce.x];
-            const int32_t dg2 = (int32_t)dgf.x;
-            const bool fwd2 = dgf.y & 1u;
-            const bool seeded2 = (dgf.y & 2u) && n2;
-            const uint32_t* __restrict__ w2 = words0 + (uint64_t)ce.x * a.stride_words;
-            uint32_t nmax = n2;
-#pragma unroll
-            for (int off = 32; off; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off));
-            nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
-
-            // 64 read bases from s_first on (the chunk needs at most chunk + k - 1 <= 61 of them)
-            const uint64_t ga = read_symbols_at(w2, s_first, last_word), gb = read_symbols_at(w2, s_first + 32u, last_word);
-            // rolling k-mers primed with the k-1 bases [s_first, s_first + k - 1)
-            const int kp = k - 1;
-            const uint64_t pmask = (1ull << (2 * kp)) - 1ull;
-            const uint64_t g = ga & pmask;
-            const uint64_t f0 = kp ? rev2_64(g) >> (64 - 2 * kp) : 0ull;
-            const uint64_t r0 = (~g & pmask) << 2;
-            uint32_t f_lo = (uint32_t)f0, f_hi = (uint32_t)(f0 >> 32), r_lo2 = (uint32_t)r0, r_hi2 = (uint32_t)(r0 >> 32);
-            // along the diagonal: base differences with the reference as the read sees it, and the clean / follow bits of
-            // the <= 32 cells of the chunk, all in step order
-            uint64_t da = 0, db = 0, yc = 0, cc = 0;   // cc: cell_codes of the chunk's cells (0 none, 1 canonical as written, 2 reverse-complemented)
-            uint32_t c3 = 0;   // per cell of the chunk: no other reference k-mer form within Hamming distance 3 (bk_device.h cell_clean3)
-            uint32_t d_lo = 0, d_hi = 0, id = 0;
-            bool id_ok = false;
-            const uint32_t ddir = fwd2 ? 1u : 0xffffffffu;
-            if (seeded2) {
-                const int32_t c_first = fwd2 ? dg2 + (int32_t)s_first : dg2 - (int32_t)s_first;   // cell of the chunk's first k-mer
-                uint64_t ra, rb;
-                if (fwd2) {
-                    ra = symbols_at(refw, c_first); rb = symbols_at(refw, c_first + 32);
-                    yc = symbols_at(yfw, c_first);
-                    cc = symbols_at(codesw, c_first);
-                    c3 = bits32_at(c3w, c_first);
-                } else {
-                    // read base s_first + t <-> complement of reference base c_first + k - 1 - t
-                    ra = ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 31));
-                    rb = ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 63));
-                    yc = rev2_64(symbols_at(yrw, c_first - 31));
-                    cc = rev2_64(symbols_at(codesw, c_first - 31));
-                    c3 = __builtin_bitreverse32(bits32_at(c3w, c_first - 31));
+    // the first n (<= 64) k-mers of the queue, one per lane
+    auto process_kmers = [&](uint32_t n) {
+        const bool on = (uint32_t)lane < n;
+        const unsigned long long e = on ? kq[lane] : 0ull;
+        const uint32_t rec = (uint32_t)(e >> 16), s = (uint32_t)e & 0xffffu;
+        const uint2 dgf = on ? a.l2_diag[rec] : make_uint2(0u, 0u);
+        const int32_t dg = (int32_t)dgf.x;
+        const bool fwd = dgf.y & 1u, ok = on && (dgf.y & 2u) != 0u;
+        const uint32_t* __restrict__ w = words0 + (uint64_t)rec * a.stride_words;
+        const uint64_t g = read_symbols_at(w, s, last_word) & kmask;             // base t of the k-mer at bits 2t
+        const uint64_t rr = ~g & kmask;                                          // its reverse complement, first base on top
+        const uint64_t ff = rev2_64(g) >> (64 - 2 * k);                          // the k-mer, first base on top
+        const bool lt = ff < rr;                                                 // lcb.rs:90-94
+        const uint64_t c = lt ? ff : rr;
+        const uint32_t isrc = lt ? 0u : 1u;
+        // along the diagonal: the reference as the read sees it at the k-mer's cell, the cell's id and flags
+        const int32_t cell = ok ? (fwd ? dg + (int32_t)s : dg - (int32_t)s) : 0;
+        const uint64_t ra = fwd ? symbols_at(refw, cell) : ~rev2_64(symbols_at(refw, cell + (int32_t)km1 - 31));
+        const uint32_t id = a.id_at[cell];
+        const uint32_t fl = ok ? (uint32_t)cflags[cell] : 0u;
+        const uint64_t da = (g ^ ra) & kmask;
+        const uint64_t dbits = (da | (da >> 1)) & 0x5555555555555555ull;
+        const uint32_t n_diff = ok ? (uint32_t)__popcll(dbits) : 99u;
+        const bool has = (fl & 3u) != 0u;                                        // a reference k-mer starts at the cell (id valid)
+        BK_DBG(a, 4, on, 1);
+        bool slow = on;
+        bool stat_only = false;
+        // a V counter of the reference k-mers' part: +1 at vp, -1 at vm (0xffffffff: none)
+        uint32_t vp = 0xffffffffu, vm = 0xffffffffu;
+        if (has && n_diff == 0u) {
+            atomicAdd(a.counters + 2 * (size_t)id + isrc, 1ull);                // the read k-mer IS the cell's reference k-mer
+            slow = false;
+            BK_DBG(a, 8, true, 1);
+        } else if (has && n_diff == 1u) {
+            const uint32_t t = (uint32_t)__builtin_ctzll(dbits) >> 1;           // position of the difference in the read k-mer
+            const uint32_t br = (uint32_t)(g >> (2u * t)) & 3u;                 // ... and the read's base there
+            const uint32_t o = fwd ? t : km1 - t;                               // offset along the reference from the cell
+            const uint32_t bfw = fwd ? br : 3u - br;                            // base on the reference's forward strand
+            if (fl & kCellClean) {
+                // a clean reference k-mer of known id: provably not a reference k-mer, and that k-mer is its only possible
+                // neighbour (bk_device.h, amb) -- a single-k-mer S run (v_point)
+                const uint32_t oo = o - (uint32_t)omin;
+                if (oo < (uint32_t)span && !BK_ABLATE(a, 2)) {                  // offsets outside the layout touch no window bucket
+                    vp = (uint32_t)(v_row_base(id + oo, bfw, fwd ? 0u : 1u, span) + oo);
+                    if (oo + 1u < (uint32_t)span) vm = vp + 1u;                 // (slot `span` is never read)
                 }
-                da = ga ^ ra; db = gb ^ rb;
-                const uint64_t d0 = kp ? rev2_64(da & pmask) >> (64 - 2 * kp) : 0ull;
-                d_lo = (uint32_t)d0; d_hi = (uint32_t)(d0 >> 32);
-                id = a.id_at[c_first] - ddir;     // so that the first step's "previous id + direction" is this cell's id
-                id_ok = id + ddir != 0xffffffffu;
-                yc |= 2ull;                       // ... and that step needs no follow bit
-            }
-            const uint32_t g4[4] = {(uint32_t)ga, (uint32_t)(ga >> 32), (uint32_t)gb, (uint32_t)(gb >> 32)};
-            const uint32_t d4[4] = {(uint32_t)da, (uint32_t)(da >> 32), (uint32_t)db, (uint32_t)(db >> 32)};
-            const uint32_t y2[2] = {(uint32_t)yc, (uint32_t)(yc >> 32)};
-            const uint32_t c2[2] = {(uint32_t)cc, (uint32_t)(cc >> 32)};
-            for (uint32_t t = 0; t < nmax; ++t) {
-                const uint32_t bi = km1 + t;                 // base of the chunk that completes k-mer t
-                const uint32_t gi = bi >> 4, sh = 2u * (bi & 15u), ci = t >> 4, csh = 2u * (t & 15u);
-                const uint32_t gsel = gi == 0 ? g4[0] : gi == 1 ? g4[1] : gi == 2 ? g4[2] : g4[3];
-                const uint32_t dsel = gi == 0 ? d4[0] : gi == 1 ? d4[1] : gi == 2 ? d4[2] : d4[3];
-                const uint32_t base = (gsel >> sh) & 3u;
-                const uint32_t dsym = (dsel >> sh) & 3u;
-                const uint32_t y = ((ci ? y2[1] : y2[0]) >> csh) & 3u;
-                f_hi = ((f_hi << 2) | (f_lo >> 30)) & kmask_hi;
-                f_lo = ((f_lo << 2) | base) & kmask_lo;
-                const uint32_t cb = (3u - base) << rc_sh;
-                r_lo2 = ((r_lo2 >> 2) | (r_hi2 << 30)) | (cb & ~rc_in_hi);
-                r_hi2 = (r_hi2 >> 2) | (cb & rc_in_hi);
-                d_hi = ((d_hi << 2) | (d_lo >> 30)) & kmask_hi;
-                d_lo = ((d_lo << 2) | dsym) & kmask_lo;
-                const bool valid = t < n2;
-                const bool ok = valid && seeded2;
-                const bool clean = y & 1u;                                   // bk_device.h cell_yf / cell_yr
-                const bool id_known = ok && id_ok && (y & 2u);               // previous id +-1 along an unbroken stretch
-                id = id_known ? id + ddir : id;
-                id_ok = id_known;
-                const uint32_t dbits = (d_lo | (d_lo >> 1)) & 0x55555555u, dbits_hi = (d_hi | (d_hi >> 1)) & 0x55555555u;
-                const uint32_t n_diff = (uint32_t)__popc(dbits) + (uint32_t)__popc(dbits_hi);
-                // one base differs from a clean reference k-mer whose id is known: provably not a reference k-mer, and
-                // that k-mer is its only possible neighbour (bk_device.h, amb) -- a single-k-mer S run
-                const bool simple = id_known && clean && n_diff == 1;
-                if (simple) {
-                    const int from_right = dbits ? (__builtin_ctz(dbits) >> 1) : 16 + (__builtin_ctz(dbits_hi) >> 1);
-                    const int bsh = 2 * from_right;             // the differing base, as the read has it
-                    const uint32_t br = (bsh >= 32 ? f_hi >> (bsh - 32) : f_lo >> bsh) & 3u;
-                    if (!BK_ABLATE(a, 2))
-                        v_point(v_counters, id, fwd2 ? (uint32_t)(k - 1 - from_right) : (uint32_t)from_right, fwd2 ? br : 3u - br,
-                                fwd2 ? 0u : 1u, omin, span);
-                }
-                // everything else (no diagonal, several differences, dirty neighbourhoods, unknown id, no reference
-                // k-mer at the cell) is resolved by the slow pipeline
-                // ... except two differences from a reference k-mer that has no other reference k-mer form within distance 3:
-                // such a k-mer is neither a reference k-mer nor one base away from one (triangle inequality) -- it touches
-                // nothing (full_kmer_stats: only the statistics table wants it)
-                // one base differs at a cell whose reference k-mer is known but not clean (other reference k-mers nearby, or the
-                // other orientation of a repeat): the answer was worked out at create (DirtyAns) -- queue (id, position and base in
-                // the orientation of the canonical reference k-mer, read orientation) for the DirtyPipe
-                const uint32_t code = ((ci ? c2[1] : c2[0]) >> csh) & 3u;
-                const bool dfast = have_ans && id_known && !clean && n_diff == 1 && code != 0u;
-                {
-                    const unsigned long long dm = __ballot(dfast);
-                    if (dm) {
-                        if (dfast) {
-                            const int from_right = dbits ? (__builtin_ctz(dbits) >> 1) : 16 + (__builtin_ctz(dbits_hi) >> 1);
-                            const int bsh = 2 * from_right;
-                            const uint32_t br = (bsh >= 32 ? f_hi >> (bsh - 32) : f_lo >> bsh) & 3u;             // the differing base as read
-                            const uint32_t o = fwd2 ? (uint32_t)(k - 1 - from_right) : (uint32_t)from_right;      // offset along the reference
-                            const uint32_t bfw = fwd2 ? br : 3u - br;                                             // base on its forward strand
-                            const bool rcq = code == 2u;                                                          // the cell's k-mer was reverse-complemented
-                            const uint32_t jq = rcq ? km1 - o : o, bq = rcq ? 3u - bfw : bfw;
-                            const bool lt = f_hi < r_hi2 || (f_hi == r_hi2 && f_lo < r_lo2);                      // lcb.rs:90-94
-                            qdq[qd + lane_prefix(dm)] = make_uint2(id, jq | (bq << 5) | (lt ? 0u : 1u << 7));
-                        }
-                        qd += (uint32_t)__popcll(dm);
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                    if (qd >= 32u) {
-                        while (dpipe.stage) dirty_advance();
-                        start_dirty_batch();
-                    } else if (dpipe.stage) {
-                        dirty_advance();
-                    }
-                }
-                const bool dead = ok && n_diff == 2u && ((c3 >> t) & 1u);
-                const bool miss = valid && !simple && !dfast && !(dead && !STATS) && !BK_ABLATE(a, 3);
-                BK_DBG(a, 16, dfast, 1); BK_DBG(a, 17, ok && !id_known && n_diff == 1 && code != 0u, 1);
-                BK_DBG(a, 4, valid, 1); BK_DBG(a, 5, simple, 1); BK_DBG(a, 6, valid && !simple && dead, 1); BK_DBG(a, 7, miss, 1);
-                BK_DBG(a, 12 + (n_diff > 3u ? 3u : n_diff), miss && ok, 1);
-                const unsigned long long mm = __ballot(miss);
-                if (mm) {
-                    if (miss) {
-                        const bool lt = f_hi < r_hi2 || (f_hi == r_hi2 && f_lo < r_lo2);   // lcb.rs:90-94
-                        const uint64_t cc = lt ? (((uint64_t)f_hi << 32) | f_lo) : (((uint64_t)r_hi2 << 32) | r_lo2);
-                        q[qn + lane_prefix(mm)] = cc | (lt ? 0ull : 1ull << 62) | (dead ? 1ull << 63 : 0ull);
-                    }
-                    qn += (uint32_t)__popcll(mm);
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (qn >= 32u) {
-                    // enough for a batch: retire the batch in flight (it advanced with the steps / words since), then take
-                    // up to 64 k-mers off the queue and issue the first loads of the new batch
-                    pipe.finish(ix, v_counters, count_exact, kt);
-                    start_slow_batch();
-                } else if (pipe.stage) {
-                    pipe.advance(ix, v_counters, count_exact, kt);
+                slow = false;
+                BK_DBG(a, 5, true, 1);
+            } else if (answers) {
+                // not clean (other reference k-mers nearby, or the other orientation of a repeat): worked out at create
+                const bool rcq = (fl & 3u) == 2u;                               // the cell's k-mer was reverse-complemented
+                const uint32_t jq = rcq ? km1 - o : o, bq = rcq ? 3u - bfw : bfw;
+                const uint2 ans = *reinterpret_cast<const uint2*>(answers + ((size_t)id * (uint32_t)k + jq) * 4u + bq);
+                const uint32_t kind = ans.y & 3u;
+                if (!(ans.y & kAnsNone)) {
+                    slow = false;
+                    if (kind == 1u) atomicAdd(a.counters + ans.x + isrc, 1ull);
+                    else if (kind == 2u) {
+                        vp = ans.x + (((isrc ^ (ans.y >> 2)) & 1u) ? (uint32_t)span + 1u : 0u);
+                        if (ans.y & 8u) vm = vp + 1u;
+                    } else if (kind == 3u) atomicAdd(v_counters + ans.x + isrc, 1ull);
+                    else if (STATS) { slow = true; stat_only = true; }          // touches nothing: only the statistics table wants it
+                    BK_DBG(a, 16, true, 1);
                 }
             }
-            continue;
+        } else if (has && n_diff == 2u && (fl & kCellClean3)) {
+            // two differences from a reference k-mer that has no other reference k-mer form within distance 3: neither a
+            // reference k-mer nor one base away from one (triangle inequality) -- it touches nothing
+            slow = STATS;
+            stat_only = true;
+            BK_DBG(a, 6, true, 1);
         }
-        if (done) break;
-        if (have_recs) {
-            if (need_load) {
-                unsigned int* row = a.l2_bits + (size_t)(rec == 0xffffffffu ? 0u : rec) * nw;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    bw[j] = (rec != 0xffffffffu && wg + j < nw) ? row[wg + j] : 0u;
-                    if (bw[j]) row[wg + j] = 0u;
-                }
-                wi = 0;
-                need_load = false;
-            }
-            uint32_t bits = bw[0];
-#pragma unroll
-            for (int j = 1; j < 8; ++j) bits = wi == (uint32_t)j ? bw[j] : bits;
-            if (!__ballot(bits != 0u)) {
-                if (++wi == 8u || wg + wi >= nw) {
-                    wg += 8u;
-                    if (wg >= nw) have_recs = false; else need_load = true;
-                }
-                continue;
-            }
-            // the next marked run of each lane's word, at most `chunk` k-mers of it
-            const bool has = bits != 0u;
-            const uint32_t s0 = has ? (uint32_t)__builtin_ctz(bits) : 0u;
-            const uint32_t rest = ~(bits >> s0);
-            const uint32_t run = min(rest ? (uint32_t)__builtin_ctz(rest) : 32u, chunk);
-            if (has) bits &= ~((run == 32u ? 0xffffffffu : (1u << run) - 1u) << s0);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) bw[j] = wi == (uint32_t)j ? bits : bw[j];
-            const unsigned long long hm = __ballot(has);
-            if (has) cq[qc + lane_prefix(hm)] = make_uint2(rec, ((wg + wi) * 32u + s0) | (run << 16));
-            qc += (uint32_t)__popcll(hm);
+        {
+            // +1 / -1 pairs on one counter cancel: the -1 of a k-mer is the +1 of the next k-mer of its run (a read along the
+            // reference: offsets fall as the k-mers advance) or of the previous one (against it).  Only k-mers of one record pair
+            // up, each +1 / -1 with at most one partner, and both lanes of a pair come to the same conclusion.
+            const uint32_t vp_up = (uint32_t)__shfl_up((int)vp, 1), vm_up = (uint32_t)__shfl_up((int)vm, 1), rec_up = (uint32_t)__shfl_up((int)rec, 1);
+            const uint32_t vp_dn = (uint32_t)__shfl_down((int)vp, 1), vm_dn = (uint32_t)__shfl_down((int)vm, 1), rec_dn = (uint32_t)__shfl_down((int)rec, 1);
+            const bool same_up = lane > 0 && rec_up == rec, same_dn = lane < 63 && rec_dn == rec;
+            const bool p_gone = fwd ? (same_dn && vm_dn == vp) : (same_up && vm_up == vp);
+            const bool m_gone = fwd ? (same_up && vp_up == vm) : (same_dn && vp_dn == vm);
+            if (vp != 0xffffffffu && !p_gone) atomicAdd(v_counters + vp, 1ull);
+            if (vm != 0xffffffffu && !m_gone) atomicAdd(v_counters + vm, ~0ull);
+        }
+        if (BK_ABLATE(a, 3)) slow = false;
+        const unsigned long long mm = __ballot(slow);
+        if (mm) {
+            BK_DBG(a, 7, slow, 1);
+            if (slow) q[qn + lane_prefix(mm)] = c | ((unsigned long long)isrc << 62) | (stat_only ? 1ull << 63 : 0ull);
+            qn += (uint32_t)__popcll(mm);
             __builtin_amdgcn_wave_barrier();
-            continue;
+            if (qn >= 64u) slow_batch();
         }
-        if (qr >= 64u || (any_done && qr != 0u)) {
-            // the next 64 marked records, one per lane
-            const uint32_t nb = min(qr, 64u);
-            rec = (uint32_t)lane < nb ? rq[lane] : 0xffffffffu;
-            const uint32_t rest = qr - nb;
+    };
+
+    uint32_t qr = 0, qk = 0;   // wave-uniform fills of the record and k-mer queues
+    auto take_kmers = [&]() {
+        const uint32_t n = min(qk, 64u);
+        process_kmers(n);   // reads kq[0, n)
+        const uint32_t rest = qk - n;
+        unsigned long long t[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) t[j] = (uint32_t)(64 * j + lane) < rest ? kq[64 * (j + 1) + lane] : 0ull;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 3; ++j) if ((uint32_t)(64 * j + lane) < rest) kq[64 * j + lane] = t[j];
+        __builtin_amdgcn_wave_barrier();
+        qk = rest;
+    };
+    // 64 marked records, one per lane: their bitmap words (cleared as they are taken); the marked k-mers of a word go into the
+    // k-mer queue lane after lane, each lane's in rising order
+    auto take_records = [&]() {
+        const uint32_t n = min(qr, 64u);
+        const uint32_t rec = (uint32_t)lane < n ? rq[lane] : 0xffffffffu;
+        {
+            const uint32_t rest = qr - n;
             const uint32_t t = (uint32_t)lane < rest ? rq[64 + lane] : 0u;
             __builtin_amdgcn_wave_barrier();
             if ((uint32_t)lane < rest) rq[lane] = t;
             __builtin_amdgcn_wave_barrier();
             qr = rest;
-            have_recs = true; wg = 0; need_load = true;
-            continue;
         }
-        if (any_done) { done = true; continue; }
-        if (__ballot(anyw != 0u)) {
-            // one marked record of each lane's word into the record queue (qr < 64 here)
-            const bool has = anyw != 0u;
-            const uint32_t b = has ? (uint32_t)__builtin_ctz(anyw) : 0u;
-            anyw &= anyw - 1u;
-            const unsigned long long hm = __ballot(has);
-            if (has) rq[qr + lane_prefix(hm)] = (uint32_t)((blk * kAnyWords + lane) * 32 + b);
-            qr += (uint32_t)__popcll(hm);
-            __builtin_amdgcn_wave_barrier();
-            continue;
+        unsigned int* row = a.l2_bits + (size_t)(rec == 0xffffffffu ? 0u : rec) * nw;
+        for (uint32_t w0 = 0; w0 < nw; w0 += 4u) {
+            uint32_t bw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bw[j] = (rec != 0xffffffffu && w0 + j < nw) ? row[w0 + j] : 0u;
+                if (bw[j]) row[w0 + j] = 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t bits = bw[j];
+                while (__ballot(bits != 0u)) {
+                    // as many whole lanes' k-mers as the queue has room for (at least 64 entries are free here)
+                    const uint32_t p = (uint32_t)__popc(bits);
+                    uint32_t incl = p;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, off); if (lane >= off) incl += t; }
+                    const uint32_t room = (uint32_t)kL2KmerCap - qk;
+                    const bool fits = p != 0u && incl <= room;
+                    const uint32_t base = qk + incl - p;
+                    if (fits) {
+                        uint32_t x = bits, i = 0;
+                        while (x) {
+                            const uint32_t bpos = (uint32_t)__builtin_ctz(x);
+                            x &= x - 1u;
+                            kq[base + i++] = ((unsigned long long)rec << 16) | ((w0 + (uint32_t)j) * 32u + bpos);
+                        }
+                        bits = 0u;
+                    }
+                    const unsigned long long fm = __ballot(fits);
+                    // total taken = inclusive sum of the last fitting lane (fitting lanes form a prefix of the lanes with bits)
+                    const uint32_t taken = fm ? (uint32_t)__shfl((int)incl, 63 - __builtin_clzll(fm)) : 0u;
+                    qk += taken;
+                    __builtin_amdgcn_wave_barrier();
+                    while (qk >= 64u) take_kmers();
+                }
+            }
         }
-        blk += (uint64_t)gridDim.x * kL2Waves;
-        if (blk >= n_blk) { any_done = true; continue; }
-        {
-            const uint64_t i = blk * kAnyWords + lane;
-            anyw = (lane < kAnyWords && i < n_any) ? a.l2_any[i] : 0u;
-            if (anyw) a.l2_any[i] = 0u;
+    };
+
+    const uint64_t n_any = (n_records + 31) / 32;                    // words of l2_any
+    const uint64_t n_blk = (n_any + kAnyWords - 1) / kAnyWords;
+    for (uint64_t blk = (uint64_t)blockIdx.x * kL2Waves + wave; blk < n_blk; blk += (uint64_t)gridDim.x * kL2Waves) {
+        const uint64_t i = blk * kAnyWords + lane;
+        const uint32_t anyw = (lane < kAnyWords && i < n_any) ? a.l2_any[i] : 0u;
+        if (anyw) a.l2_any[i] = 0u;     // taken: l2_any and l2_bits are all zero again when this kernel ends
+        if (!__ballot(anyw != 0u)) continue;
+#pragma unroll
+        for (int j = 0; j < kAnyWords / 2; ++j) {   // record 64 j + lane of the block: bit (lane & 31) of word 2 j + (lane >> 5)
+            const uint32_t wv = (uint32_t)__shfl((int)anyw, 2 * j + (lane >> 5));
+            const bool marked = (wv >> (lane & 31)) & 1u;
+            const unsigned long long hm = __ballot(marked);
+            if (hm) {
+                if (marked) rq[qr + lane_prefix(hm)] = (uint32_t)(blk * (kAnyWords * 32) + 64u * (uint32_t)j + (uint32_t)lane);
+                qr += (uint32_t)__popcll(hm);
+                __builtin_amdgcn_wave_barrier();
+                if (qr >= 64u) take_records();
+            }
         }
     }
-    while (dpipe.stage) dirty_advance();
-    if (qd) {
-        start_dirty_batch();   // qd < 64
-        while (dpipe.stage) dirty_advance();
-    }
-    pipe.finish(ix, v_counters, count_exact, kt);
-    if (qn) {
-        pipe.start(q, qn, lane, ix);   // qn < 64
-        pipe.finish(ix, v_counters, count_exact, kt);
-    }
+    while (qr) take_records();
+    while (qk) take_kmers();
+    while (qn) slow_batch();
 }
 
 // Which genome does the sample look like?  One k-mer (the middle one) of each of the first records: votes[f] += 1 for every

@@ -25,13 +25,31 @@ class Params(C.Structure):
                 ("kmer_table_log2", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class CallParams(C.Structure):  # include/bronko_hip.h bk_call_params
+    _fields_ = [("k", C.c_int32), ("no_end_filter", C.c_int32), ("no_strand_filter", C.c_int32), ("no_strand_balance_filter", C.c_int32),
+                ("min_af", C.c_double), ("strand_balance_ratio", C.c_double), ("strand_odds_max", C.c_double),
+                ("variant_multiplier", C.c_double), ("n_per_strand", C.c_uint64), ("min_depth", C.c_uint64),
+                ("min_variant_depth", C.c_uint64)]
+
+
+class CallRecord(C.Structure):  # bk_call_record
+    _fields_ = [("seq_id", C.c_int32), ("ref_base", C.c_uint8), ("alt_base", C.c_uint8), ("pad", C.c_uint16), ("pos", C.c_uint64),
+                ("fwd_ref", C.c_uint64), ("rev_ref", C.c_uint64), ("fwd_alt", C.c_uint64), ("rev_alt", C.c_uint64),
+                ("depth", C.c_uint64), ("af", C.c_double), ("sor", C.c_double)]
+
+
+class CallSummary(C.Structure):  # bk_call_summary
+    _fields_ = [("file_id", C.c_int32), ("pad", C.c_uint32), ("n_records", C.c_uint64), ("n_major", C.c_uint64), ("n_minor", C.c_uint64),
+                ("covered", C.c_uint64), ("positions", C.c_uint64), ("coverage", C.c_uint64)]
+
+
 # every symbol include/bronko_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = ["bk_abi_version", "bk_last_error", "bk_params_default", "bk_engine_create", "bk_engine_destroy", "bk_engine_fork", "bk_engine_get_stream",
            "bk_engine_set_stream", "bk_total_cells", "bk_n_files", "bk_n_slots", "bk_counter_len", "bk_sample_begin",
            "bk_push_reads_packed", "bk_push_reads_packed_device", "bk_push_reads_ascii", "bk_counters_device_ptr", "bk_sample_finalize",
            "bk_sample_finalize_shard", "bk_shard_sums_device_ptr", "bk_sample_merge_shards",
            "bk_pileup_device_ptr", "bk_sample_download", "bk_sample_finish", "bk_pack_reads", "bk_pack_reads_flat",
-           "bk_timing_enable", "bk_timing_read"]
+           "bk_timing_enable", "bk_timing_read", "bk_call_params_default", "bk_sample_call", "bk_sample_download_calls"]
 
 _libs = {}
 _testing = False
@@ -97,6 +115,11 @@ def load(testing=None):
     L.bk_pack_reads.argtypes = [vp, vp, u64, i32, u32, vp, vp, u64]
     L.bk_pack_reads_flat.restype = u64
     L.bk_pack_reads_flat.argtypes = [vp, vp, u64, i32, u32, vp, vp, u64]
+    L.bk_call_params_default.argtypes = [C.POINTER(CallParams)]
+    L.bk_sample_call.restype = C.c_int
+    L.bk_sample_call.argtypes = [vp, C.c_int, C.POINTER(CallParams)]
+    L.bk_sample_download_calls.restype = C.c_int
+    L.bk_sample_download_calls.argtypes = [vp, C.POINTER(CallSummary), vp, u64]
     L.bk_timing_enable.restype = C.c_int
     L.bk_timing_enable.argtypes = [vp, C.c_int]
     L.bk_timing_read.restype = C.c_int

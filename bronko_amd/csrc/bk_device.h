@@ -57,9 +57,10 @@ struct alignas(8) DirtyAns {
     uint32_t idx;    // kind 1: E counter 2 * id' (+ isrc); kind 2: V counter of direction 0 relative to the V part (+ row length
                      // when isrc ^ rcu); kind 3: pseudo k-mer counter relative to the V part (+ isrc)
     uint32_t meta;   // bits 0-1 kind (0 = touches nothing); bit 2 rcu (kind 2); bit 3 (kind 2): -1 on the next counter as well;
-                     // bit 4: no answer was worked out for this reference k-mer (search instead)
+                     // bit 4: no answer was worked out for this reference k-mer (search instead); bit 5: its neighbours in the
+                     // window sit at more than one position -- it touches several window buckets (finalize: the general path)
 };
-constexpr uint32_t kAnsNone = 16u;
+constexpr uint32_t kAnsNone = 16u, kAnsMulti = 32u;
 // per-cell flags byte (Level 2): bits 0-1 = cell_codes symbol (0 no k-mer of U starts here, 1 canonical as written, 2 reverse-
 // complemented), bit 2 = clean (cell_yf bit 0), bit 3 = cell_clean3
 constexpr uint32_t kCellClean = 4u, kCellClean3 = 8u;

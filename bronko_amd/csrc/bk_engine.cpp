@@ -277,6 +277,14 @@ struct bk_engine {
     bool win_chosen = false;                // for the current sample
     bool plane_stale[2] = {true, true};   // the mate's counter plane still holds an earlier sample (zeroed at its first push / at finalize)
 
+    // after the pileup (bk_sample_call): sequence geometry (shared by forks), per-engine scratch and results
+    DevBuf<uint64_t> genome_len, seq_cell, seq_len_d;
+    DevBuf<int32_t> seq_first, n_seqs_d;
+    int max_seqs_per_file = 0;
+    uint64_t max_file_cells = 0;
+    DevBuf<double> call_freq, call_noise;
+    DevBuf<bk_call_record> call_records;
+    DevBuf<bk_call_summary> call_out;
     DevBuf<unsigned long long> dbg;   // BK_L2_STATS (testing build): tallies of what the scan leaves to Level 2
     int ablate = 0;   // BK_SCAN_ABLATE (measurement aid): see scan_count_kernel
     uint64_t max_launch_records = 0;   // BK_MAX_LAUNCH_RECORDS (testing aid): split pushes into launches of at most this many records
@@ -401,6 +409,20 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     }
     if (cells >= (1ull << 32)) return fail(BK_ERR_UNSUPPORTED, "more than 2^32 reference positions");
     e->total_cells = cells;
+    {   // sequence geometry for the device caller
+        std::vector<uint64_t> g_len(ix->n_files, 0), s_cell, s_len;
+        std::vector<int32_t> s_first(ix->n_files, 0), n_s(ix->n_files, 0);
+        size_t sq = 0;
+        for (int f = 0; f < ix->n_files; f++) {
+            s_first[f] = (int32_t)sq; n_s[f] = ix->n_seqs[f];
+            e->max_seqs_per_file = std::max(e->max_seqs_per_file, (int)ix->n_seqs[f]);
+            for (int s2 = 0; s2 < ix->n_seqs[f]; s2++, sq++) { s_cell.push_back(cell_off[f][s2]); s_len.push_back(ix->seq_lens[sq]); g_len[f] += ix->seq_lens[sq]; }
+            e->max_file_cells = std::max(e->max_file_cells, g_len[f]);
+        }
+        if (s_cell.empty()) { s_cell.push_back(0); s_len.push_back(0); }
+        BK_HIP(e->genome_len.upload(g_len)); BK_HIP(e->seq_cell.upload(s_cell)); BK_HIP(e->seq_len_d.upload(s_len));
+        BK_HIP(e->seq_first.upload(s_first)); BK_HIP(e->n_seqs_d.upload(n_s));
+    }
 
     PhaseClock pc;
     // ---- window buckets -> device slots ------------------------------------------------------------------
@@ -775,7 +797,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             // cell that is not clean are filled in -- the others are never read
             std::vector<uint32_t> owners;   // index into h_u of each filled row
             for (size_t id = 0; id < e->n_full; id++)
-                if (h_needs_ans[id]) owners.push_back(idx_by_id[id]);
+                if (h_needs_ans[id] || h_amb[id]) owners.push_back(idx_by_id[id]);   // (a dirty k-mer without a cell: finalize still asks)
             const size_t per = (size_t)k * 4;
             const bool build = e->W > 0 && (size_t)e->n_full * per * sizeof(bk::DirtyAns) <= ((size_t)16 << 30);
             if (build && !owners.empty()) {
@@ -812,7 +834,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                                 const bool flip = zr < z;              // the canonical form of z is its reverse complement
                                 const uint64_t c = flip ? zr : z;
                                 bool member = false;
-                                uint64_t best = ~0ull; uint32_t best_fi = 0;
+                                uint64_t best = ~0ull; uint32_t best_fi = 0, jmask = 0;
                                 for (auto& f : fl) {
                                     // a form says something about c (the canonical form of z) only in c's orientation: c vs u' is z vs u', or
                                     // rc(z) vs u' = z vs rc(u').  (k = 31 pseudo k-mers are not canonical values: the other pairing does occur.)
@@ -823,9 +845,11 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                                     const int jn = flip ? k - 1 - pp : pp;            // position in c (= in the neighbour's canonical form)
                                     if (jn < e->wstart || jn >= e->wstart + e->W || !((h_valid[f.second >> 1] >> (jn - e->wstart)) & 1u)) continue;
                                     const uint64_t key = ((uint64_t)jn << 32) | row_base[f.second >> 1];
+                                    jmask |= 1u << (jn - e->wstart);
                                     if (key < best) { best = key; best_fi = f.second; }
                                 }
                                 if (member || best == ~0ull) continue;
+                                const uint32_t multi = (jmask & (jmask - 1u)) ? bk::kAnsMulti : 0u;
                                 const int jn = (int)(best >> 32);
                                 const uint32_t pnb = (uint32_t)best, ni = best_fi >> 1;
                                 const uint32_t bc = (uint32_t)(c >> (2 * (k - 1 - jn))) & 3u;
@@ -834,11 +858,11 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                                     const int oo = (rcu ? k - 1 - jn : jn) - e->v_omin;
                                     if (oo < 0 || oo >= e->v_span) continue;            // (v_point's guard)
                                     A.idx = (uint32_t)(bk::v_row_base(pnb + (uint32_t)oo, rcu ? 3u - bc : bc, 0u, e->v_span) + (uint32_t)oo);
-                                    A.meta = 2u | (rcu << 2) | ((oo + 1 < e->v_span) ? 8u : 0u);
+                                    A.meta = 2u | (rcu << 2) | ((oo + 1 < e->v_span) ? 8u : 0u) | multi;
                                 } else {
                                     const uint32_t row = pnb - e->n_full + (uint32_t)__builtin_popcount(h_valid[ni] & ((1u << (jn - e->wstart)) - 1u));
                                     A.idx = (uint32_t)(vreal + ((uint64_t)row * 4 + bc) * 2);
-                                    A.meta = 3u;
+                                    A.meta = 3u | multi;
                                 }
                             }
                         }
@@ -860,7 +884,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                                 const auto it = std::lower_bound(h_u.begin(), h_u.end(), c);
                                 if (it != h_u.end() && *it == c) { want.idx = 2u * id_of[it - h_u.begin()]; want.meta = 1u; }
                                 else {
-                                    uint64_t best = ~0ull; size_t bi = 0;
+                                    uint64_t best = ~0ull; size_t bi = 0; uint32_t jm = 0;
                                     for (int jn = e->wstart; jn < e->wstart + e->W; jn++) for (uint64_t alt = 0; alt < 4; alt++) {
                                         const int s2 = 2 * (k - 1 - jn);
                                         if (((c >> s2) & 3ull) == alt) continue;
@@ -870,8 +894,10 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                                         const size_t ci = ct - h_u.begin();
                                         if (!((h_valid[ci] >> (jn - e->wstart)) & 1u)) continue;
                                         const uint64_t key = ((uint64_t)jn << 32) | row_base[ci];
+                                        jm |= 1u << (jn - e->wstart);
                                         if (key < best) { best = key; bi = ci; }
                                     }
+                                    const uint32_t multi = (jm & (jm - 1u)) ? bk::kAnsMulti : 0u;
                                     if (best != ~0ull) {
                                         const int jn = (int)(best >> 32);
                                         const uint32_t pnb = (uint32_t)best, bc = (uint32_t)(c >> (2 * (k - 1 - jn))) & 3u;
@@ -880,11 +906,11 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                                             const int oo = (rcu ? k - 1 - jn : jn) - e->v_omin;
                                             if (oo >= 0 && oo < e->v_span) {
                                                 want.idx = (uint32_t)(bk::v_row_base(pnb + (uint32_t)oo, rcu ? 3u - bc : bc, 0u, e->v_span) + (uint32_t)oo);
-                                                want.meta = 2u | (rcu << 2) | ((oo + 1 < e->v_span) ? 8u : 0u);
+                                                want.meta = 2u | (rcu << 2) | ((oo + 1 < e->v_span) ? 8u : 0u) | multi;
                                             }
                                         } else {
                                             want.idx = (uint32_t)(vreal + ((uint64_t)(pnb - e->n_full + (uint32_t)__builtin_popcount(h_valid[bi] & ((1u << (jn - e->wstart)) - 1u))) * 4 + bc) * 2);
-                                            want.meta = 3u;
+                                            want.meta = 3u | multi;
                                         }
                                     }
                                 }
@@ -1108,6 +1134,8 @@ int bk_engine_fork(const bk_engine* parent, bk_engine** out) {
     e->slot_of.alias(p->slot_of); e->estat_off.alias(p->estat_off); e->estat.alias(p->estat); e->slot_rec.alias(p->slot_rec); e->amb.alias(p->amb);
     e->pilots.alias(p->pilots); e->table.alias(p->table); e->ent_off.alias(p->ent_off); e->ent_len.alias(p->ent_len); e->entries.alias(p->entries);
     e->occ.alias(p->occ);
+    e->genome_len.alias(p->genome_len); e->seq_cell.alias(p->seq_cell); e->seq_len_d.alias(p->seq_len_d); e->seq_first.alias(p->seq_first);
+    e->n_seqs_d.alias(p->n_seqs_d); e->max_seqs_per_file = p->max_seqs_per_file; e->max_file_cells = p->max_file_cells;
     if (int rc = alloc_sample_state(e.get())) return rc;
     *out = e.release();
     return BK_OK;
@@ -1497,6 +1525,62 @@ int bk_sample_finish(bk_engine* e, int n_mates, uint64_t* fwd_depth, uint64_t* r
     int rc = bk_sample_finalize(e, n_mates);
     if (rc != BK_OK) return rc;
     return bk_sample_download(e, n_mates, fwd_depth, rev_depth, fwd_nk, rev_nk, stats, present, kmer_stats);
+}
+
+// ---- after the pileup, on the device (bk_caller.hip) -----------------------------------------------------------
+void bk_call_params_default(bk_call_params* p) {
+    if (!p) return;
+    p->k = 21;                          // consts.rs:3
+    p->no_end_filter = 0; p->no_strand_filter = 0; p->no_strand_balance_filter = 0;
+    p->min_af = 0.03;                   // consts.rs:8
+    p->strand_balance_ratio = 0.1;      // consts.rs:10
+    p->strand_odds_max = 6.0;           // cli.rs --strand_odds
+    p->variant_multiplier = 1.5;        // consts.rs:15
+    p->n_per_strand = 2; p->min_depth = 300; p->min_variant_depth = 3;
+}
+
+int bk_sample_call(bk_engine* e, int n_mates, const bk_call_params* p) {
+    if (!e || !p) return fail(BK_ERR_INVALID, "null argument");
+    if (n_mates < 1 || n_mates > 2) return fail(BK_ERR_INVALID, "n_mates must be 1 or 2");
+    if (e->in_sample) return fail(BK_ERR_STATE, "bk_sample_call comes after bk_sample_finalize");
+    BK_HIP(hipSetDevice(e->device));
+    const uint64_t cap = std::max<uint64_t>(3 * e->max_file_cells, 1);   // at most three alternative bases per position
+    if (!e->call_out.p) {
+        BK_HIP(e->call_freq.alloc((size_t)e->total_cells * 3));
+        BK_HIP(e->call_noise.alloc((size_t)e->total_cells));
+        BK_HIP(e->call_records.alloc((size_t)cap));
+        BK_HIP(e->call_out.alloc(1));
+    }
+    bk::CallArgs a{};
+    a.prm = *p;
+    a.n_files = e->n_files; a.n_mates = n_mates;
+    a.stats = e->stats.p; a.present = e->present.p;
+    a.genome_len = e->genome_len.p; a.seq_first = e->seq_first.p; a.n_seqs = e->n_seqs_d.p; a.seq_cell = e->seq_cell.p; a.seq_len = e->seq_len_d.p;
+    a.ref_words = e->ref_words.p + bk::scan_ref_pad_words();
+    a.pileup = e->pileup.p; a.plane = (size_t)e->total_cells * 4;
+    a.freq = e->call_freq.p; a.noise = e->call_noise.p; a.records = e->call_records.p; a.record_cap = cap; a.out = e->call_out.p;
+    bk_engine::Span sp(e, 1);
+    bk::launch_call(a, e->max_seqs_per_file, e->max_file_cells, e->stream);
+    BK_HIP(hipGetLastError());
+    return BK_OK;
+}
+
+int bk_sample_download_calls(bk_engine* e, bk_call_summary* summary, bk_call_record* records, uint64_t cap) {
+    if (!e || !summary) return fail(BK_ERR_INVALID, "null argument");
+    if (!e->call_out.p) return fail(BK_ERR_STATE, "bk_sample_download_calls comes after bk_sample_call");
+    BK_HIP(hipSetDevice(e->device));
+    BK_HIP(hipMemcpyAsync(summary, e->call_out.p, sizeof *summary, hipMemcpyDeviceToHost, e->stream));
+    BK_HIP(hipStreamSynchronize(e->stream));
+    const uint64_t n = std::min<uint64_t>(std::min<uint64_t>(summary->n_records, cap), e->call_records.n);
+    if (n && records) {
+        BK_HIP(hipMemcpy(records, e->call_records.p, (size_t)n * sizeof(bk_call_record), hipMemcpyDeviceToHost));
+        std::sort(records, records + n, [](const bk_call_record& x, const bk_call_record& y) {
+            if (x.seq_id != y.seq_id) return x.seq_id < y.seq_id;
+            if (x.pos != y.pos) return x.pos < y.pos;
+            return x.alt_base < y.alt_base;
+        });
+    }
+    return BK_OK;
 }
 
 // ---- K0 host packer ------------------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "../../include/bronko_hip.h"
 #include "bk_device.h"
 
 namespace bk {
@@ -124,6 +125,30 @@ void launch_pack_sums(unsigned long long* sums, const unsigned long long* stats,
                       int n_files, hipStream_t stream);
 void launch_unpack_sums(const unsigned long long* sums, unsigned long long* stats, unsigned char* present, unsigned long long* kstats,
                         int n_files, hipStream_t stream);
+// ---- after the pileup (bk_caller.hip) ----
+typedef bk_call_params CallParamsDev;
+typedef bk_call_record CallRecordDev;
+typedef bk_call_summary CallSummaryDev;
+struct CallArgs {
+    CallParamsDev prm;
+    int32_t n_files, n_mates;
+    const unsigned long long* stats;     // [n_mates][n_files][3]
+    const unsigned char* present;        // [n_mates][n_files]
+    const uint64_t* genome_len;          // [n_files] sum of the file's sequence lengths
+    const int32_t* seq_first;            // [n_files] index of the file's first sequence
+    const int32_t* n_seqs;               // [n_files]
+    const uint64_t* seq_cell;            // [sequences] first cell
+    const uint64_t* seq_len;             // [sequences]
+    const uint32_t* ref_words;           // IndexView::ref_words past its front padding: symbol 0 = cell 0
+    const unsigned long long* pileup;    // 4 planes of `plane` u64
+    size_t plane;
+    double* freq;                        // [total_cells][3] scratch: sorted minor-allele frequencies
+    double* noise;                       // [total_cells] Noise.max per position
+    CallRecordDev* records;
+    uint64_t record_cap;
+    CallSummaryDev* out;
+};
+void launch_call(const CallArgs& a, int max_seqs_per_file, uint64_t max_file_cells, hipStream_t stream);
 size_t finalize_lds_bytes(int n_files);
 size_t finalize_partial_rows();
 

@@ -537,18 +537,27 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 sisrc[sq] = lt ? 0u : 1u;
                 spil[sq] = ix.pilots[phf_bucket(sc[sq], ix.log2nb)];
             }
+            // the loads of the four seeds go out together: perfect-hash entries, then (multi-genome index) where each hit sits in
+            // the genome the LDS window covers
+            uint4 se[kSeeds];
+#pragma unroll
+            for (int sq = 0; sq < kSeeds; ++sq) se[sq] = *reinterpret_cast<const uint4*>(ix.kmer_pos + phf_pos(sc[sq], spil[sq], ix.m));
+            bool shit[kSeeds];
+            uint32_t soc[kSeeds];
+#pragma unroll
+            for (int sq = 0; sq < kSeeds; ++sq) {
+                shit[sq] = len && !had && ((uint64_t)se[sq].x | ((uint64_t)se[sq].y << 32)) == sc[sq];
+                soc[sq] = 0xffffffffu;
+                if (a.occ && shit[sq] && (se[sq].w & kIdMask) < ix.n_full)
+                    soc[sq] = a.occ[(size_t)(se[sq].w & kIdMask) * (uint32_t)a.n_files + (uint32_t)a.win_file];
+            }
             uint32_t best_cell = 0xffffffffu;
 #pragma unroll
             for (int sq = 0; sq < kSeeds; ++sq) {
                 const uint32_t s = spos[sq];
-                const uint4 e = *reinterpret_cast<const uint4*>(ix.kmer_pos + phf_pos(sc[sq], spil[sq], ix.m));
-                uint32_t scell = e.z, src_rc = e.w >> 31;   // where the seed sits: the k-mer's first occurrence ...
-                const bool hit = len && !had && ((uint64_t)e.x | ((uint64_t)e.y << 32)) == sc[sq];
-                if (a.occ && hit && (e.w & kIdMask) < ix.n_full) {
-                    // ... or, in a multi-genome index, its occurrence in the genome the LDS window covers
-                    const uint32_t oc = a.occ[(size_t)(e.w & kIdMask) * (uint32_t)a.n_files + (uint32_t)a.win_file];
-                    if (oc != 0xffffffffu) { scell = oc & 0x7fffffffu; src_rc = oc >> 31; }
-                }
+                uint32_t scell = se[sq].z, src_rc = se[sq].w >> 31;   // where the seed sits: the k-mer's first occurrence ...
+                const bool hit = shit[sq];
+                if (soc[sq] != 0xffffffffu) { scell = soc[sq] & 0x7fffffffu; src_rc = soc[sq] >> 31; }   // ... or its occurrence in the window's genome
                 if (hit && scell < best_cell) {
                     // several seeds may hit (usually all, on one diagonal); prefer the lowest cell
                     const bool f = sisrc[sq] == src_rc;        // same strand as the reference?
@@ -1536,6 +1545,8 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         const uint64_t kmer_p = (uint64_t)idr.x | ((uint64_t)idr.y << 32);
         const uint32_t ambp = idr.w;
         const int o = (int)oo + ix.v_omin;
+        // a unit whose rows are all empty (most of them, with a large index and one sample) costs its loads and this vote only
+        if (!__syncthreads_or(n != 0ull)) continue;
 #pragma unroll
         for (int off = 1; off < 32; off <<= 1) {
             const unsigned long long t = __shfl_up(n, off, 64);   // (lane - off is in the same row whenever oo >= off)
@@ -1559,11 +1570,18 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         const unsigned long long v = n > a.cs ? a.cs : n;       // kmc -cs: reported count saturates
         const uint32_t t = (uint32_t)(j - ix.wstart);
         if (act && dirty) {
-            // u has another reference k-mer within Hamming distance 2: c may touch a second window bucket.  Enumerate its
-            // neighbours; several buckets -> general path (K2b)
-            uint32_t jmask = 0;
-            for_each_neighbour(ix, c, [&](int jj, uint32_t, uint32_t) { jmask |= 1u << (jj - ix.wstart); });
-            if (jmask != (1u << t)) {
+            // u has another reference k-mer within Hamming distance 2: c may touch a second window bucket.  Whether its
+            // neighbours sit at several window positions was worked out with its answer (DirtyAns); without the table,
+            // enumerate them.  Several buckets -> general path (K2b)
+            bool multi;
+            const uint2 ans = ix.dirty_ans ? *reinterpret_cast<const uint2*>(ix.dirty_ans + ((size_t)p * (uint32_t)k + (uint32_t)j) * 4u + bb) : make_uint2(0u, kAnsNone);
+            if (!(ans.y & kAnsNone)) multi = (ans.y & kAnsMulti) != 0u;
+            else {
+                uint32_t jmask = 0;
+                for_each_neighbour(ix, c, [&](int jj, uint32_t, uint32_t) { jmask |= 1u << (jj - ix.wstart); });
+                multi = jmask != (1u << t);
+            }
+            if (multi) {
                 const unsigned int at = atomicAdd(a.n_deferred, 1u);
                 a.deferred[at] = (uint32_t)(wk * rl + oo);
                 act = false;
@@ -1655,6 +1673,8 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     // ~25 pileup cells -- gathered in the workgroup's vote table (LDS) before they go to the pileup
     for (uint64_t g0 = c_lo * W + (uint64_t)blockIdx.x * 256; g0 < n_work; g0 += (uint64_t)gridDim.x * 256) {
       const uint64_t g = g0 + threadIdx.x;
+      // a round whose counters are all zero (most of them, with a large index and one sample) votes for nothing: skip its flush
+      if (!__syncthreads_or(g < n_work && a.counters[g / W] != 0ull)) continue;
       if (g < n_work) do {
         const uint64_t cidx = g / W;
         const uint32_t t = (uint32_t)(g % W);

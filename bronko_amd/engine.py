@@ -203,6 +203,27 @@ class Engine:
         self.sample_finalize(n_mates)
         return self.sample_download(n_mates)
 
+    def call_params(self, **kw):
+        """bk_call_params with the reference's defaults (cli.rs:92-135), k = the engine's; keyword overrides."""
+        p = _ffi.CallParams()
+        self._L.bk_call_params_default(C.byref(p))
+        p.k = self.k
+        for name, v in kw.items():
+            setattr(p, name, v)
+        return p
+
+    def sample_call(self, n_mates=1, params=None):
+        """Reference selection + baseline noise + variant calls on the device for the sample just finalized (asynchronous)."""
+        _check(self._L.bk_sample_call(self.h, n_mates, C.byref(params or self.call_params())), self._L)
+
+    def download_calls(self):
+        """(summary, records) of sample_call: records sorted by (sequence, position, alternative base)."""
+        summ = _ffi.CallSummary()
+        cap = max(1, 3 * self.total_cells)
+        recs = (_ffi.CallRecord * cap)()
+        _check(self._L.bk_sample_download_calls(self.h, C.byref(summ), recs, cap), self._L)
+        return summ, [recs[i] for i in range(min(summ.n_records, cap))]
+
     def timing_enable(self, on=True):
         _check(self._L.bk_timing_enable(self.h, int(on)), self._L)
 

@@ -401,12 +401,25 @@ int run_call(const Args& a) {
     auto complete = [&](bk_engine* e, const std::vector<std::string>& mates) {
         const int n_mates = (int)mates.size();
         Pileup p;
-        p.fwd_depth.resize(cells4); p.rev_depth.resize(cells4); p.fwd_nk.resize(cells4); p.rev_nk.resize(cells4);
         std::vector<uint64_t> stats((size_t)n_mates * n_files * 3), kstats((size_t)n_mates * 4);
         std::vector<uint8_t> present((size_t)n_mates * n_files);
         LOG_INFO(T, "Mapping kmers to all genomes (" + mates[0] + ")");
-        hip_check(bk_sample_finish(e, n_mates, p.fwd_depth.data(), p.rev_depth.data(), p.fwd_nk.data(), p.rev_nk.data(),
-                                   stats.data(), present.data(), kstats.data()), "bk_sample_finish");
+        // finalize, then reference selection + baseline noise + variant calls, all on the device and asynchronous
+        // (bk_sample_call); the pileup arrays only travel when --pileup wants them written
+        hip_check(bk_sample_finalize(e, n_mates), "bk_sample_finalize");
+        bk_call_params dcp;
+        bk_call_params_default(&dcp);
+        dcp.k = cp.k; dcp.no_end_filter = cp.no_end_filter; dcp.no_strand_filter = cp.no_strand_filter;
+        dcp.no_strand_balance_filter = cp.no_strand_balance_filter; dcp.min_af = cp.min_af; dcp.strand_balance_ratio = cp.strand_balance_ratio;
+        dcp.strand_odds_max = cp.strand_odds_max; dcp.variant_multiplier = cp.variant_multiplier; dcp.n_per_strand = cp.n_per_strand;
+        dcp.min_depth = cp.min_depth; dcp.min_variant_depth = cp.min_variant_depth;
+        hip_check(bk_sample_call(e, n_mates, &dcp), "bk_sample_call");
+        if (a.pileup) { p.fwd_depth.resize(cells4); p.rev_depth.resize(cells4); }
+        hip_check(bk_sample_download(e, n_mates, a.pileup ? p.fwd_depth.data() : nullptr, a.pileup ? p.rev_depth.data() : nullptr, nullptr, nullptr,
+                                     stats.data(), present.data(), kstats.data()), "bk_sample_download");
+        std::vector<bk_call_record> drecs((size_t)std::max<uint64_t>(1, 3 * ix.total_cells()));
+        bk_call_summary summ{};
+        hip_check(bk_sample_download_calls(e, &summ, drecs.data(), drecs.size()), "bk_sample_download_calls");
         p.stats.assign(n_files * 3, 0);
         p.present.assign(n_files, 0);
         uint64_t kept = 0;   // KMC "No. of unique counted k-mers", summed over mate files (call.rs:336)
@@ -418,7 +431,7 @@ int run_call(const Args& a) {
         }
         if (!kept_exact) LOG_WARN(T, "k-mer statistics table overflowed (raise BRONKO_KMER_TABLE_LOG2): num_unmapped_kmers is not available for this sample");
         LOG_INFO(T, "Selecting the most representative genome");
-        const int best = pick_best_genome(ix, p.stats, p.present);
+        const int best = summ.file_id;
         if (best < 0) die(T, "Unable to pick a best genome");
         const std::string& gname = ix.files[best].name;
         LOG_INFO(T, "Selected a representative genome: " + gname);
@@ -430,7 +443,27 @@ int run_call(const Args& a) {
                         std::to_string(p.stats[(size_t)best * 3 + 2]) + " unique among refs), " + std::to_string(n_variant) + "/" +
                         std::to_string(kept) + " had a variant");
         LOG_INFO(T, "Calling variants for " + gname);
-        const CallSummary cs = call_variants(ix, best, p, cp);
+        CallSummary cs;
+        cs.n_major = summ.n_major; cs.n_minor = summ.n_minor;
+        cs.breadth = (double)summ.covered / (double)summ.positions;               // call.rs:1144
+        cs.depth = (double)summ.coverage / (double)summ.covered;                  // call.rs:1145 (NaN when nothing is covered)
+        for (uint64_t i = 0; i < std::min<uint64_t>(summ.n_records, drecs.size()); i++) {
+            const bk_call_record& r = drecs[i];
+            // SOR as printed: the reference's expression on the host's libm (the device's ln made the decision; the two agree
+            // to the last ulps, the printed three decimals are the host's)
+            double sor = cp.strand_odds_max + 1.0;
+            if (!cp.no_strand_filter) {                                            // call.rs:1059-1096
+                const double fa = (double)r.fwd_ref + 1.0, fb = (double)r.rev_ref + 1.0, fc = (double)r.fwd_alt + 1.0, fd = (double)r.rev_alt + 1.0;
+                const double min_strand = std::fmin(fa + fc, fb + fd) / (fa + fb + fc + fd);
+                if (!cp.no_strand_balance_filter || min_strand >= cp.strand_balance_ratio) {
+                    const double q = (fa * fd) / (fb * fc);
+                    sor = std::log(q + 1.0 / q) + std::log(std::fmin(fa, fb) / std::fmax(fa, fb)) - std::log(std::fmin(fc, fd) / std::fmax(fc, fd));
+                } else {
+                    sor = -1.0;
+                }
+            }
+            cs.records.push_back(VcfRecord{r.seq_id, r.pos, r.ref_base, r.alt_base, r.fwd_ref, r.rev_ref, r.fwd_alt, r.rev_alt, r.depth, r.af, sor});
+        }
         LOG_INFO(T, "Called " + std::to_string(cs.n_major) + " major variants, " + std::to_string(cs.n_minor) + " minor above maf = " + std::to_string(a.min_af));
         const std::string stem = clean_sample_id(mates[0]);
         try {

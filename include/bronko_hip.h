@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BK_ABI_VERSION 4
+#define BK_ABI_VERSION 5
 
 typedef enum {
     BK_OK = 0,
@@ -181,6 +181,48 @@ int bk_sample_download(bk_engine* e, int n_mates, uint64_t* fwd_depth, uint64_t*
 /* bk_sample_finalize + bk_sample_download */
 int bk_sample_finish(bk_engine* e, int n_mates, uint64_t* fwd_depth, uint64_t* rev_depth, uint64_t* fwd_nk,
                      uint64_t* rev_nk, uint64_t* stats, uint8_t* present, uint64_t* kmer_stats);
+
+/* ---- after the pileup, on the device (optional) ----------------------------------------------
+ * For the sample just finalized, asynchronously on the engine's stream:
+ *     pick_best_genome / pick_best_genome_paired   call.rs:422-502  (ties -> lowest file id; statistics summed over mates)
+ *     get_baseline_noise                           call.rs:799-967  (IEEE doubles in upstream's order; one thread per
+ *                                                                    sequence walks the window, see bk_caller.hip)
+ *     call_variants                                call.rs:969-1150 (one thread per position)
+ * A host with many samples in flight (one engine / fork each) never waits between a sample's reads and its records:
+ *     bk_sample_begin .. bk_push_reads_* .. bk_sample_finalize .. bk_sample_call   (all asynchronous)
+ *     bk_sample_download_calls                                                        (synchronises, copies the records)
+ * The records come back sorted by (sequence, position, alternative base) = upstream's order within a sequence;
+ * breadth = covered / positions, depth = coverage / covered (call.rs:1144-1145).  af is exact (one division); sor is the
+ * device's ln() of exact ratios -- a host that prints it may re-derive it from the DP4 counts. */
+typedef struct {            /* CallArgs fields that reach calling (cli.rs:92-135; defaults consts.rs:2-21) */
+    int32_t  k;
+    int32_t  no_end_filter, no_strand_filter, no_strand_balance_filter;
+    double   min_af;                /* 0.03 */
+    double   strand_balance_ratio;  /* 0.1  */
+    double   strand_odds_max;       /* 6.0  */
+    double   variant_multiplier;    /* 1.5  */
+    uint64_t n_per_strand;          /* 2    */
+    uint64_t min_depth;             /* 300  */
+    uint64_t min_variant_depth;     /* 3    */
+} bk_call_params;
+typedef struct {            /* call.rs:776-789 VcfRecord */
+    int32_t  seq_id;                /* index of the sequence inside the selected genome file */
+    uint8_t  ref_base, alt_base;    /* 2-bit codes (A C G T) */
+    uint16_t pad;
+    uint64_t pos;                   /* 1-based */
+    uint64_t fwd_ref, rev_ref, fwd_alt, rev_alt, depth;
+    double   af, sor;
+} bk_call_record;
+typedef struct {
+    int32_t  file_id;               /* selected genome file, -1 = none (call.rs:229-235: the host reports and exits) */
+    uint32_t pad;
+    uint64_t n_records;             /* records produced (all of them were copied iff <= cap) */
+    uint64_t n_major, n_minor;      /* AF >= 0.5 / below */
+    uint64_t covered, positions, coverage;
+} bk_call_summary;
+void bk_call_params_default(bk_call_params* p);
+int  bk_sample_call(bk_engine* e, int n_mates, const bk_call_params* p);
+int  bk_sample_download_calls(bk_engine* e, bk_call_summary* summary, bk_call_record* records, uint64_t cap);
 
 /* ---- K0: host-side read packer (the step KMC's FASTQ reader performs before counting) ---------------------
  * Splits each ASCII read at every non-ACGT/acgt symbol, drops runs shorter than k, cuts runs longer than

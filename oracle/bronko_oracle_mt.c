@@ -10,9 +10,9 @@
  *            counts one shard in a private open-addressing map -- no locks, the result is the multiset the single-threaded
  *            counter gives.
  *   stage 2  map_kmers over chunks of the kept k-mers in parallel = `kmers.par_chunks(chunk_size).for_each` of
- *            src/call.rs:1279-1281: every thread maps its chunks with orc_map_kmers (the literal restatement) into private
- *            arrays; depth = max, #k-mers and statistics add (the reference does the same through DashMap entries,
- *            call.rs:1341-1357, :1420-1430).
+ *            src/call.rs:1279-1281: every thread maps its chunks into the shared arrays with atomic += 1 / max (the reference
+ *            serialises the same two updates through DashMap entries, call.rs:1341-1357); per-thread statistics are summed
+ *            (call.rs:1420-1430).
  *
  * bench.py's cpu_baseline leg times this on the GPU box's host cores and reports the two stage times separately; the tests
  * check it against the single-threaded orc_sample_pileup bit for bit.
@@ -46,7 +46,7 @@ static void vec_push(vec64* b, uint64_t x) {
     b->v[b->n++] = x;
 }
 
-typedef struct {
+typedef struct job_s {
     /* shared, read-only */
     const orc_index* ix;
     const orc_map_params* mp;
@@ -62,8 +62,8 @@ typedef struct {
     uint64_t* kept_kmers; uint64_t* kept_counts; uint64_t n_kept, n_distinct;
     /* stage 2 */
     const uint64_t* kmers; const uint64_t* counts; uint64_t n_all;
-    uint64_t* pile[4];          /* private arrays, total_cells * 4 each */
-    uint64_t* stats; uint8_t* present;
+    uint64_t* stats; uint8_t* present;   /* per thread, summed afterwards */
+    uint64_t** merge_out;                /* the four shared output arrays */
 } job_t;
 
 static void* stage1a(void* arg) {
@@ -74,7 +74,7 @@ static void* stage1a(void* arg) {
     const uint64_t lo = j->r_lo + n * (uint64_t)j->tid / (uint64_t)j->T, hi = j->r_lo + n * (uint64_t)(j->tid + 1) / (uint64_t)j->T;
     {   /* reserve: the slice's k-mers spread evenly over the shards */
         const uint64_t bases = j->offsets[hi] - j->offsets[lo];
-        const uint64_t per = bases / (uint64_t)j->T + bases / (uint64_t)j->T / 8 + 1024;
+        const uint64_t per = bases / (uint64_t)j->T + bases / (uint64_t)j->T / 8 + 64;
         for (int s = 0; s < j->T; s++) { j->buckets[s].cap = per; j->buckets[s].v = (uint64_t*)malloc(per * 8); j->buckets[s].n = 0; }
     }
     for (uint64_t r = lo; r < hi; r++) {
@@ -155,17 +155,75 @@ static void* stage1b(void* arg) {
     return NULL;
 }
 
+/* map_kmers over this thread's chunks (call.rs:1279-1281 par_chunks), voting straight into the shared arrays: the loop is
+ * orc_map_kmers' (bronko_oracle.c, cited line by line there) with the two updates made atomic -- upstream serialises them
+ * through DashMap entry locks (call.rs:1341-1357, :1366-1383): #k-mers += 1, depth = max(depth, n).  Statistics are
+ * per-thread and summed afterwards (call.rs:1420-1430). */
 static void* stage2(void* arg) {
     job_t* j = (job_t*)arg;
-    /* call.rs:1277: chunk_size = min(10000, len / threads); chunks dealt round-robin to the threads */
-    uint64_t chunk = j->n_all / (uint64_t)j->T;
+    const orc_index* ix = j->ix;
+    const int k = j->k, n_files = orc_index_n_files(ix);
+    const orc_bucket_info* entries = orc_index_entries(ix);
+    uint64_t* hits = (uint64_t*)calloc((size_t)n_files + 1, 8);
+    int* touched = (int*)malloc(sizeof(int) * ((size_t)n_files + 1));
+    int w0, w1;                                                      /* window slice call.rs:1291-1300 */
+    if (j->mp->use_full_kmer) { w0 = 0; w1 = k; }
+    else if (j->mp->n_fixed * 2 + 1 >= k) { w0 = 0; w1 = 0; }
+    else { w0 = j->mp->n_fixed; w1 = k - j->mp->n_fixed - 1; }
+    const uint64_t num_buckets_perfect = (uint64_t)(w1 - w0);       /* call.rs:1302 */
+    uint64_t chunk = j->n_all / (uint64_t)j->T;                      /* call.rs:1277 */
     if (chunk > 10000) chunk = 10000;
     if (chunk == 0) chunk = 1;
+    uint64_t buckets[32];
     for (uint64_t c0 = (uint64_t)j->tid * chunk; c0 < j->n_all; c0 += (uint64_t)j->T * chunk) {
-        const uint64_t n = c0 + chunk <= j->n_all ? chunk : j->n_all - c0;
-        orc_map_kmers(j->ix, j->kmers + c0, j->counts + c0, n, j->mp->n_fixed, j->mp->use_full_kmer,
-                      j->pile[0], j->pile[1], j->pile[2], j->pile[3], j->stats, j->present);
+        const uint64_t c1 = c0 + chunk <= j->n_all ? c0 + chunk : j->n_all;
+        for (uint64_t t = c0; t < c1; t++) {
+            const uint64_t fwd = j->kmers[t], n = j->counts[t];
+            const uint64_t rev = orc_reverse_complement_u64(fwd, k);
+            uint64_t kmer_bin; int rc;
+            if (fwd < rev) { kmer_bin = fwd; rc = 0; } else { kmer_bin = rev; rc = 1; }   /* lcb.rs:90-94 */
+            orc_assign_buckets(kmer_bin, k, buckets);                                     /* call.rs:1289 */
+            int n_touched = 0;
+            for (int b = w0; b < w1; b++) {                                               /* call.rs:1305 */
+                uint64_t first;
+                const uint64_t cnt = orc_index_lookup(ix, buckets[b], &first);            /* call.rs:1307 */
+                for (uint64_t e = 0; e < cnt; e++) {                                      /* call.rs:1309 */
+                    const orc_bucket_info* info = &entries[first + e];
+                    if (hits[info->file_id]++ == 0) touched[n_touched++] = info->file_id; /* call.rs:1316-1318 */
+                    if ((int)info->file_id >= n_files || (int)info->seq_id >= orc_index_n_seqs(ix, info->file_id)) continue;
+                    const uint64_t nuc_x = info->idx, idx = (uint64_t)info->location + nuc_x;   /* call.rs:1328-1334 */
+                    if (idx >= orc_index_seq_len(ix, info->file_id, info->seq_id)) continue;
+                    const uint64_t cell = (orc_index_cell_offset(ix, info->file_id, info->seq_id) + idx) * 4;
+                    uint64_t bit_idx; int forward;
+                    if (info->canonical) {
+                        const uint64_t pos = (uint64_t)k - nuc_x - 1;                     /* call.rs:1332 */
+                        bit_idx = ((kmer_bin >> (2 * ((uint64_t)k - pos - 1))) & 3u) ^ 3u; /* call.rs:1333 */
+                        forward = rc ? 1 : 0;                                             /* call.rs:1336-1357 */
+                    } else {
+                        bit_idx = (kmer_bin >> (2 * ((uint64_t)k - nuc_x - 1))) & 3u;     /* call.rs:1360 */
+                        forward = rc ? 0 : 1;                                             /* call.rs:1363-1383 */
+                    }
+                    uint64_t* nk = (forward ? j->merge_out[2] : j->merge_out[3]) + cell + bit_idx;
+                    uint64_t* dp = (forward ? j->merge_out[0] : j->merge_out[1]) + cell + bit_idx;
+                    __atomic_fetch_add(nk, 1, __ATOMIC_RELAXED);
+                    uint64_t cur = __atomic_load_n(dp, __ATOMIC_RELAXED);
+                    while (cur < n && !__atomic_compare_exchange_n(dp, &cur, n, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+                }
+            }
+            int n_perfect = 0, uniq = -1;                                                 /* call.rs:1390-1418 */
+            for (int q = 0; q < n_touched; q++)
+                if (hits[touched[q]] == num_buckets_perfect) { n_perfect++; uniq = touched[q]; }
+            for (int q = 0; q < n_touched; q++) {
+                const int f = touched[q];
+                j->present[f] = 1;
+                if (hits[f] == num_buckets_perfect) j->stats[f * 3 + 0] += 1;
+                else if (hits[f] > 0) j->stats[f * 3 + 1] += 1;
+                hits[f] = 0;
+            }
+            if (n_perfect == 1) { j->stats[uniq * 3 + 2] += 1; j->present[uniq] = 1; }
+        }
     }
+    free(hits); free(touched);
     return NULL;
 }
 
@@ -184,7 +242,6 @@ void orc_sample_pileup_mt(const orc_index* ix, const orc_map_params* mp, int n_m
     const int T = n_threads < 1 ? 1 : n_threads;
     const int k = orc_index_k(ix);
     const int n_files = orc_index_n_files(ix);
-    const uint64_t cells4 = orc_index_total_cells(ix) * 4;
     uint64_t* out[4] = {fwd_depth, rev_depth, fwd_nk, rev_nk};
     if (stage_seconds) stage_seconds[0] = stage_seconds[1] = 0.0;
     job_t* jobs = (job_t*)calloc((size_t)T, sizeof(job_t));
@@ -217,24 +274,16 @@ void orc_sample_pileup_mt(const orc_index* ix, const orc_map_params* mp, int n_m
         if (kmc_stats) { kmc_stats[4 * m + 0] = n_reads; kmc_stats[4 * m + 1] = n_kmers; kmc_stats[4 * m + 2] = n_distinct; kmc_stats[4 * m + 3] = n_all; }
         const double t1 = now_s();
         for (int t = 0; t < T; t++) {
-            jobs[t].kmers = kmers; jobs[t].counts = counts; jobs[t].n_all = n_all;
-            for (int a = 0; a < 4; a++) jobs[t].pile[a] = (uint64_t*)calloc(cells4 ? cells4 : 1, 8);
+            jobs[t].kmers = kmers; jobs[t].counts = counts; jobs[t].n_all = n_all; jobs[t].merge_out = out;
             jobs[t].stats = (uint64_t*)calloc((size_t)n_files * 3 + 1, 8);
             jobs[t].present = (uint8_t*)calloc((size_t)n_files + 1, 1);
         }
         run_all(jobs, T, stage2);
         for (int t = 0; t < T; t++) {
-            for (uint64_t i = 0; i < cells4; i++) {
-                if (jobs[t].pile[0][i] > out[0][i]) out[0][i] = jobs[t].pile[0][i];   /* depth = max */
-                if (jobs[t].pile[1][i] > out[1][i]) out[1][i] = jobs[t].pile[1][i];
-                out[2][i] += jobs[t].pile[2][i];                                       /* #k-mers add */
-                out[3][i] += jobs[t].pile[3][i];
-            }
             for (int f = 0; f < n_files; f++) {
                 for (int q = 0; q < 3; q++) stats[((size_t)m * n_files + f) * 3 + q] += jobs[t].stats[f * 3 + q];
                 if (jobs[t].present[f]) present[(size_t)m * n_files + f] = 1;
             }
-            for (int a = 0; a < 4; a++) free(jobs[t].pile[a]);
             free(jobs[t].stats); free(jobs[t].present);
         }
         free(kmers); free(counts);

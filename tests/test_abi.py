@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
         L = _ffi.load(testing=testing)
         for s in declared:
             assert hasattr(L, s), s
-        assert L.bk_abi_version() == 4
+        assert L.bk_abi_version() == 5
 
 
 def test_release_library_reads_no_environment_variable():
@@ -36,6 +36,12 @@ def test_release_library_reads_no_environment_variable():
 def test_bucket_info_layout_matches_repr_c():
     assert C.sizeof(_ffi.BucketInfo) == 12                        # build.rs:52-60
     assert _ffi.BucketInfo.location.offset == 4 and _ffi.BucketInfo.idx.offset == 8
+
+
+def test_call_record_layout():
+    assert C.sizeof(_ffi.CallRecord) == 72 and _ffi.CallRecord.pos.offset == 8 and _ffi.CallRecord.af.offset == 56
+    assert C.sizeof(_ffi.CallParams) == 72 and _ffi.CallParams.min_af.offset == 16
+    assert C.sizeof(_ffi.CallSummary) == 56
 
 
 def test_pack_reads_contract():

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Scan kernel time under the ablation switches of the -DBK_TESTING build (BK_SCAN_ABLATE: 1 = Level 1 only, 2 = no V atomics,
+4 = without Level 2) for config 2 or 3 shapes.  usage: tools/scan_ablate.py [2|3]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from bronko_amd import Params, synth, _ffi
+from bronko_amd.hostlib import HostIndex
+_ffi.use_testing_library(True)
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+n = 1000000
+names = ["wuhan_ref.fasta", "OM223929.1.fasta", "ON765678.1.fasta", "PX392231.1.fasta"]
+paths = [os.path.join(ROOT, "tests", "golden", "4_sarscov2", x) for x in names]
+dev = torch.device("cuda", 0)
+if cfg == 2:
+    paths = paths[:1]
+    g, isnv = synth.sample_genome(synth.read_fasta_bytes(paths[0]), 2)
+    mates = [synth.single_end_codes_torch(g, n, 150, 2000006, isnv=isnv, device=dev)]
+else:
+    g, isnv = synth.sample_genome(synth.read_fasta_bytes(paths[2]), 3)
+    mates = list(synth.paired_codes_torch(g, n, 150, 3, isnv=isnv, device=dev))
+packed = [synth.pack_codes_torch(c) for c in mates]
+torch.cuda.synchronize()
+for ab in ("0", "1", "2", "4"):
+    os.environ["BK_SCAN_ABLATE"] = ab
+    ix = HostIndex.build(21, paths, threads=4)
+    eng = ix.engine(Params())
+    for rep in range(4):
+        if rep == 1:
+            eng.timing_enable(1); eng.timing_read(reset=True)
+        eng.sample_begin()
+        for m, (w, l) in enumerate(packed):
+            eng.push_reads_device(m, w.data_ptr(), w.shape[1], l.data_ptr(), n)
+        eng.sample_finalize(len(packed))
+    ms, cnt = eng.timing_read(reset=True)
+    print("config %d ablate %s: scan %.3f ms per launch, level2+fold %.3f, finalize %.3f per sample" % (cfg, ab, ms[0] / max(cnt[0], 1), ms[3] / max(cnt[3], 1), ms[1] / 3), flush=True)
+    eng.close()

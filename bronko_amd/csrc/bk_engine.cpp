@@ -229,7 +229,13 @@ struct bk_engine {
     DevBuf<unsigned int> fin_partials;      // per-workgroup finalize tallies (small genome sets only)
     DevBuf<unsigned long long> ktab_keys;   // full_kmer_stats: open-addressing table of non-index-touching k-mers
     DevBuf<unsigned int> ktab_cnt;
-    DevBuf<unsigned long long> ktab_out;    // [2 mates][2] distinct, kept  + [4] overflow flag
+    DevBuf<unsigned long long> ktab_out;    // [2 mates][2] distinct, kept  + [4] overflow flag + [8 ..] tallies of new keys
+    uint32_t ktab_log2 = 0;                 // current capacity (grows with the sample: ensure_ktab_room)
+    unsigned long long* h_fill = nullptr;   // pinned copy of the tallies, refreshed after every push
+    hipEvent_t fill_ev = nullptr;
+    bool fill_pending = false;              // a copy of the tallies is in flight / unread
+    uint64_t fill_known = 0, fill_unknown_upper = 0;   // keys in the table at the last reading; k-mers pushed since (upper bound on new keys)
+    std::vector<std::pair<unsigned long long*, unsigned int*>> ktab_old;   // outgrown tables, freed at the next sample / destroy
     DevBuf<uint32_t> slot_of, estat_off, estat;
     DevBuf<bk::SlotRec> slot_rec;
     DevBuf<uint8_t> amb;
@@ -332,8 +338,11 @@ static int alloc_sample_state(bk_engine* e) {
         if (prm->kmer_table_log2 < 10 || prm->kmer_table_log2 > 31) return fail(BK_ERR_INVALID, "kmer_table_log2 out of range");
         BK_HIP(e->ktab_keys.alloc((size_t)1 << prm->kmer_table_log2));
         BK_HIP(e->ktab_cnt.alloc((size_t)1 << prm->kmer_table_log2));
+        e->ktab_log2 = prm->kmer_table_log2;
+        BK_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_fill), bk::ktab_fill_words() * sizeof(unsigned long long), hipHostMallocDefault));
+        BK_HIP(hipEventCreateWithFlags(&e->fill_ev, hipEventDisableTiming));
     }
-    BK_HIP(e->ktab_out.alloc(8));
+    BK_HIP(e->ktab_out.alloc(8 + bk::ktab_fill_words()));
     if (e->n_files <= 64) BK_HIP(e->fin_partials.alloc(bk::finalize_partial_rows() * ((size_t)e->n_files * 3 + 2)));
     BK_HIP(e->deferred.alloc(bk::v_plane_len(e->n_full, e->v_span, e->n_prows)));
     BK_HIP(e->n_deferred.alloc(2));   // one per mate file
@@ -1153,6 +1162,9 @@ void bk_engine_destroy(bk_engine* e) {
         if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
+    for (auto& o : e->ktab_old) { (void)hipFree(o.first); (void)hipFree(o.second); }
+    if (e->h_fill) (void)hipHostFree(e->h_fill);
+    if (e->fill_ev) (void)hipEventDestroy(e->fill_ev);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
@@ -1182,8 +1194,14 @@ int bk_sample_begin(bk_engine* e) {
     bk::launch_zero_small(e->stats.p, e->stats.n, e->kstats.p, e->kstats.n, e->ktab_out.p, e->ktab_out.n, e->present.p, e->present.n,
                           e->n_deferred.p, e->n_deferred.n, e->stream);
     if (e->ktab_keys.p) {
+        if (!e->ktab_old.empty()) {   // tables the previous sample outgrew
+            BK_HIP(hipStreamSynchronize(e->stream));
+            for (auto& o : e->ktab_old) { (void)hipFree(o.first); (void)hipFree(o.second); }
+            e->ktab_old.clear();
+        }
         BK_HIP(hipMemsetAsync(e->ktab_keys.p, 0xff, e->ktab_keys.n * sizeof(unsigned long long), e->stream));
         BK_HIP(hipMemsetAsync(e->ktab_cnt.p, 0, e->ktab_cnt.n * sizeof(unsigned int), e->stream));
+        e->fill_known = 0; e->fill_unknown_upper = 0; e->fill_pending = false;
     }
     e->pushed_records[0] = e->pushed_records[1] = 0;
     e->in_sample = true;
@@ -1199,9 +1217,51 @@ static int zero_plane_if_stale(bk_engine* e, int mate) {
     return BK_OK;
 }
 
+// full_kmer_stats: the statistics table holds every distinct k-mer that touches no window bucket -- as many as the sample has
+// sequencing errors, unknown in advance.  Its load stays below one half: before a batch of at most `upper` k-mers is pushed,
+// the keys it holds (read back from the device tallies after every push; the engine only waits for that reading when the
+// bound says the batch might not fit) plus `upper` must fit, else the table is rehashed into one four times larger.
+static int ensure_ktab_room(bk_engine* e, uint64_t upper) {
+    if (!e->ktab_keys.p) return BK_OK;
+    const uint64_t cap = 1ull << e->ktab_log2;
+    if (e->fill_known + e->fill_unknown_upper + upper > cap / 2) {
+        if (e->fill_pending) {
+            BK_HIP(hipEventSynchronize(e->fill_ev));
+            uint64_t f = 0;
+            for (uint32_t i = 0; i < bk::ktab_fill_words(); i++) f += e->h_fill[i];
+            e->fill_known = f; e->fill_unknown_upper = 0; e->fill_pending = false;
+        }
+        uint32_t nl = e->ktab_log2;
+        while (nl < 31 && e->fill_known + e->fill_unknown_upper + upper > (1ull << nl) / 2) nl += 2;
+        if (nl > 31) nl = 31;
+        if (nl != e->ktab_log2) {
+            unsigned long long* nk = nullptr; unsigned int* nc = nullptr;
+            BK_HIP(hipMalloc(reinterpret_cast<void**>(&nk), ((size_t)1 << nl) * sizeof(unsigned long long)));
+            BK_HIP(hipMalloc(reinterpret_cast<void**>(&nc), ((size_t)1 << nl) * sizeof(unsigned int)));
+            BK_HIP(hipMemsetAsync(nk, 0xff, ((size_t)1 << nl) * sizeof(unsigned long long), e->stream));
+            BK_HIP(hipMemsetAsync(nc, 0, ((size_t)1 << nl) * sizeof(unsigned int), e->stream));
+            bk::launch_ktab_rehash(e->ktab_keys.p, e->ktab_cnt.p, e->ktab_log2, nk, nc, nl, e->ktab_out.p + 4, e->stream);
+            e->ktab_old.emplace_back(e->ktab_keys.p, e->ktab_cnt.p);   // still read by the rehash in flight
+            e->ktab_keys.p = nk; e->ktab_keys.n = (size_t)1 << nl;
+            e->ktab_cnt.p = nc; e->ktab_cnt.n = (size_t)1 << nl;
+            e->ktab_log2 = nl;
+        }
+    }
+    e->fill_unknown_upper += upper;
+    return BK_OK;
+}
+static int note_ktab_fill(bk_engine* e) {   // after a push: a fresh copy of the tallies
+    if (!e->ktab_keys.p) return BK_OK;
+    BK_HIP(hipMemcpyAsync(e->h_fill, e->ktab_out.p + 8, bk::ktab_fill_words() * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+    BK_HIP(hipEventRecord(e->fill_ev, e->stream));
+    e->fill_pending = true;
+    return BK_OK;
+}
+
 static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t stride_words, const uint16_t* d_lens, uint64_t n,
-                       const unsigned long long* n_records_dev = nullptr) {
+                       const unsigned long long* n_records_dev = nullptr, uint64_t kmers_upper = 0) {
     if (int rc = zero_plane_if_stale(e, mate)) return rc;
+    if (int rc = ensure_ktab_room(e, kmers_upper ? kmers_upper : n * (uint64_t)stride_words * 16)) return rc;
     bk::ScanArgs a{};
     a.n_records_dev = n_records_dev;
     a.ixp = e->d_view.p;
@@ -1214,7 +1274,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.slabs = e->slabs.p;
     a.n_lds_bins = e->n_lds_bins;
     a.ref_in_lds = e->ref_in_lds ? 1 : 0;
-    a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->params.kmer_table_log2;
+    a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->ktab_log2;
     a.ktab_overflow = e->ktab_out.p + 4; a.mate = (uint32_t)mate;
     a.occ = e->occ.p; a.n_files = e->n_files;
     if (test_env("BK_L2_STATS") && !e->dbg.p) { BK_HIP(e->dbg.alloc(32)); BK_HIP(hipMemsetAsync(e->dbg.p, 0, 32 * sizeof(unsigned long long), e->stream)); }
@@ -1224,7 +1284,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
         bk::launch_count_kmers(a, e->stream);
         BK_HIP(hipGetLastError());
         if (!n_records_dev) e->pushed_records[mate] += n;
-        return BK_OK;
+        return note_ktab_fill(e);
     }
     if (e->occ.p && !e->win_chosen && n > 0) {
         // first records of the sample vote for the genome they look like (one synchronisation per sample); the LDS window
@@ -1295,7 +1355,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     }
     BK_HIP(hipGetLastError());
     if (!n_records_dev) e->pushed_records[mate] += n;
-    return BK_OK;
+    return note_ktab_fill(e);
 }
 
 int bk_push_reads_ascii(bk_engine* e, int mate, const uint8_t* buf, const uint64_t* offsets, uint64_t n_reads) {
@@ -1353,7 +1413,7 @@ int bk_push_reads_ascii(bk_engine* e, int mate, const uint8_t* buf, const uint64
         bk::launch_pack_reads(pa, e->stream);
         bk::launch_add_u64(e->kstats.p + mate * 4 + 0, sl.d_nrec.p, e->stream);   // records pushed, tallied on the device
     }
-    int rc = push_device(e, mate, sl.d_words.p, stride, sl.d_lens.p, cap, sl.d_nrec.p);
+    int rc = push_device(e, mate, sl.d_words.p, stride, sl.d_lens.p, cap, sl.d_nrec.p, total);   // (a batch holds fewer k-mers than bases)
     if (rc != BK_OK) return rc;
     BK_HIP(hipEventRecord(sl.done, e->stream));
     sl.busy = true;
@@ -1429,7 +1489,7 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
         a.partials = e->fin_partials.p;
         a.deferred = e->deferred.p;
         a.n_deferred = e->n_deferred.p + m;
-        a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->params.kmer_table_log2;
+        a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->ktab_log2;
         a.ktab_overflow = e->ktab_out.p + 4; a.mate = (uint32_t)m;
         if (int rc = zero_plane_if_stale(e, m)) return rc;
         bk_engine::Span sp(e, 1);
@@ -1437,7 +1497,7 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
     }
     if (e->ktab_keys.p) {
         bk_engine::Span sp(e, 1);
-        bk::launch_ktab_stats(e->ktab_keys.p, e->ktab_cnt.p, e->params.kmer_table_log2, e->params.ci, e->params.cx, e->ktab_out.p, e->stream);
+        bk::launch_ktab_stats(e->ktab_keys.p, e->ktab_cnt.p, e->ktab_log2, e->params.ci, e->params.cx, e->ktab_out.p, e->stream);
     }
     BK_HIP(hipGetLastError());
     e->in_sample = false;

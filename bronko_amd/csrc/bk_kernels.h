@@ -116,6 +116,9 @@ hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t strea
 void launch_fold(const FoldArgs& f, hipStream_t stream);
 void launch_ktab_stats(const unsigned long long* keys, const unsigned int* cnt, uint32_t log2n, unsigned long long ci,
                        unsigned long long cx, unsigned long long* out, hipStream_t stream);
+void launch_ktab_rehash(const unsigned long long* okeys, const unsigned int* ocnt, uint32_t olog2, unsigned long long* nkeys, unsigned int* ncnt,
+                        uint32_t nlog2, unsigned long long* overflow, hipStream_t stream);
+uint32_t ktab_fill_words();   // tallies of new keys behind the overflow word: ktab_out[8 ..]
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
 // one launch zeroes the engine's small per-sample buffers
 void launch_zero_small(unsigned long long* a, size_t na, unsigned long long* b, size_t nb, unsigned long long* c, size_t nc,

@@ -159,20 +159,46 @@ struct KmerTable {
     uint32_t mate;
 };
 
+constexpr uint32_t kKtabFillWords = 1024;   // new-key tallies behind the overflow flag: overflow[4 + i], spread so that no word is hot
 __device__ __forceinline__ void ktab_insert(const KmerTable& t, uint64_t c, uint32_t isrc, unsigned int n) {
     const unsigned long long key = c | ((unsigned long long)isrc << 63) | ((unsigned long long)t.mate << 62);
-    const uint32_t mask = (1u << t.log2n) - 1u;   // log2n <= 32 handled by the host (<= 34 uses 64-bit below)
+    const uint64_t mask = (1ull << t.log2n) - 1ull;
     uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> (64 - t.log2n);
     for (uint32_t probes = 0; probes < 4096; ++probes) {
         const unsigned long long old = atomicCAS(t.keys + h, ~0ull, key);
         if (old == ~0ull || old == key) {
             if (t.cnt[h] < 0xf0000000u) atomicAdd(t.cnt + h, n);   // saturates far above any -cx
+            if (old == ~0ull) atomicAdd(t.overflow + 4 + (h & (kKtabFillWords - 1u)), 1ull);   // the engine grows the table by its fill
             return;
         }
-        h = (h + 1) & (uint64_t)mask;
+        h = (h + 1) & mask;
     }
-    *t.overflow = 1ull;   // table (nearly) full: statistics are reported as unavailable
+    *t.overflow = 1ull;   // (the engine keeps the load below one half: unreachable unless the table cannot grow any more)
 }
+
+// old table -> a larger one (same keys, same counts; the fill tallies stay as they are)
+__global__ __launch_bounds__(256) void ktab_rehash_kernel(const unsigned long long* __restrict__ okeys, const unsigned int* __restrict__ ocnt, uint64_t on,
+                                                          unsigned long long* nkeys, unsigned int* ncnt, uint32_t nlog2, unsigned long long* overflow) {
+    const uint64_t mask = (1ull << nlog2) - 1ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < on; i += (uint64_t)gridDim.x * 256) {
+        const unsigned long long key = okeys[i];
+        if (key == ~0ull) continue;
+        uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> (64 - nlog2);
+        uint32_t probes = 0;
+        for (; probes < 65536; ++probes) {
+            const unsigned long long old = atomicCAS(nkeys + h, ~0ull, key);
+            if (old == ~0ull) { ncnt[h] = ocnt[i]; break; }   // keys of the old table are distinct
+            h = (h + 1) & mask;
+        }
+        if (probes == 65536) *overflow = 1ull;
+    }
+}
+void launch_ktab_rehash(const unsigned long long* okeys, const unsigned int* ocnt, uint32_t olog2, unsigned long long* nkeys, unsigned int* ncnt,
+                        uint32_t nlog2, unsigned long long* overflow, hipStream_t stream) {
+    const uint64_t on = 1ull << olog2;
+    hipLaunchKernelGGL(ktab_rehash_kernel, dim3((unsigned)std::min<uint64_t>((on + 255) / 256, 256 * 16)), dim3(256), 0, stream, okeys, ocnt, on, nkeys, ncnt, nlog2, overflow);
+}
+uint32_t ktab_fill_words() { return kKtabFillWords; }
 
 __global__ __launch_bounds__(256) void ktab_stats_kernel(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ cnt,
                                                          uint64_t n, unsigned long long ci, unsigned long long cx, unsigned long long* out) {

@@ -429,7 +429,8 @@ int run_call(const Args& a) {
             for (size_t f = 0; f < n_files; f++) p.present[f] |= present[(size_t)m * n_files + f];
             if (kstats[(size_t)m * 4 + 3] == ~0ull) kept_exact = false; else kept += kstats[(size_t)m * 4 + 3];
         }
-        if (!kept_exact) LOG_WARN(T, "k-mer statistics table overflowed (raise BRONKO_KMER_TABLE_LOG2): num_unmapped_kmers is not available for this sample");
+        // (the engine grows the table with the sample; only a sample with more than 2^30 distinct erroneous k-mers gets here)
+        if (!kept_exact) die(T, "k-mer statistics table overflowed: num_unmapped_kmers cannot be reported for " + mates[0]);
         LOG_INFO(T, "Selecting the most representative genome");
         const int best = summ.file_id;
         if (best < 0) die(T, "Unable to pick a best genome");

@@ -80,7 +80,8 @@ typedef struct {
     int32_t  full_kmer_stats;/* 1: also count every k-mer that does NOT touch the index in a device hash table, so
                                 that KMC's "No. of unique k-mers" / "No. of unique counted k-mers" (call.rs:1190-1199)
                                 are exact; 0 (default): only index-touching k-mers are counted (pileups identical) */
-    uint32_t kmer_table_log2;/* capacity of that table = 2^kmer_table_log2 distinct k-mers per sample (default 26)  */
+    uint32_t kmer_table_log2;/* initial capacity of that table = 2^kmer_table_log2 slots (default 26); it is rehashed into a
+                                larger one whenever a batch might take its load above one half (up to 2^31 slots)          */
     uint32_t reserved;
 } bk_params;
 
@@ -175,7 +176,7 @@ int bk_pileup_device_ptr(bk_engine* e, void** d_ptr);
  *   kmer_stats : n_mates * 4 u64 = [0] records pushed, [1] k-mer occurrences scanned (KMC "Total no. of k-mers"),
  *                [2] distinct k-mers ("No. of unique k-mers"), [3] distinct k-mers kept by -ci/-cx ("No. of unique
  *                counted k-mers").  With full_kmer_stats = 0, [2] = 0 and [3] counts index-touching k-mers only;
- *                if the k-mer table overflowed, [2] = [3] = UINT64_MAX.                                         */
+ *                if the k-mer table could not grow any further and overflowed, [2] = [3] = UINT64_MAX.                */
 int bk_sample_download(bk_engine* e, int n_mates, uint64_t* fwd_depth, uint64_t* rev_depth, uint64_t* fwd_nk,
                        uint64_t* rev_nk, uint64_t* stats, uint8_t* present, uint64_t* kmer_stats);
 /* bk_sample_finalize + bk_sample_download */

@@ -256,12 +256,16 @@ def test_full_kmer_statistics_match_the_kmc_contract(oracle, golden_dir):
     assert res.kmer_stats[:, 3].tolist() == pile.kmc_stats[:, 3].tolist()     # unique counted k-mers
     assert res.kmer_stats[0, 2] > res.kmer_stats[0, 3] > 10000
     eng.close()
-    # a table that is too small reports "unavailable" instead of a wrong number; pileups are unaffected
-    eng = helpers.engine_from_oracle_index(ix, Params(full_kmer_stats=True, kmer_table_log2=10))
-    res = helpers.hip_sample(eng, mates, 21)
-    helpers.assert_same_pileup(res, pile)
-    assert res.kmer_stats[0, 3] == np.iinfo(np.uint64).max
-    eng.close()
+    # a table that starts far too small is rehashed into larger ones as the sample grows (several times here, also between the
+    # batches of one mate file and on the device-packing path): same exact statistics, pileups unaffected
+    for kw in ({}, {"batch": 700}, {"batch": 1500, "ascii_path": True}):
+        eng = helpers.engine_from_oracle_index(ix, Params(full_kmer_stats=True, kmer_table_log2=10))
+        for _ in range(2):   # (the second sample starts with the grown table)
+            res = helpers.hip_sample(eng, mates, 21, **kw)
+            helpers.assert_same_pileup(res, pile)
+            assert res.kmer_stats[:, 2].tolist() == pile.kmc_stats[:, 2].tolist()
+            assert res.kmer_stats[:, 3].tolist() == pile.kmc_stats[:, 3].tolist()
+        eng.close()
     ix.close()
 
 
@@ -593,3 +597,77 @@ def test_randomised_indexes_and_reads():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "60", "11"], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+def _device_batches(gen, n_batches, dev):
+    import torch
+    out = []
+    for b in range(n_batches):
+        mates = gen(b)
+        out.append([synth.pack_codes_torch(c) for c in mates])
+    torch.cuda.synchronize()
+    return out
+
+
+def test_config3_full_size_ten_million_pairs(oracle, sars_paths):
+    """BASELINE configs[2] at full size: the 4-strain index, 10,000,000 pairs (2 x 150 bp) derived from ON765678.1, seed 3,
+    generated on the GPU in ten batches of 1 M pairs (the generator bench.py uses).  The oracle needs minutes and tens of GB
+    for 20 M reads, so: (a) the first 1 M-pair batch alone against the oracle (all cores), bit for bit; (b) the whole sample
+    through size-independent properties -- every k-mer scanned (2 x 10 M x 130), the result does not depend on the order in
+    which the batches are pushed, depth can only grow and #k-mers only grow from (a) to the whole sample, and the selected
+    genome is ON765678.1."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, nb = 1000000, 10
+    ix = oracle.Index.build(21, sars_paths)
+    eng = helpers.engine_from_oracle_index(ix)
+    fork = eng.fork()
+    gm, isnv = synth.sample_genome(synth.read_fasta_bytes(sars_paths[2]), 3)
+    batches = _device_batches(lambda b: synth.paired_codes_torch(gm, n, 150, 3, isnv=isnv, device=dev, row0=b * n), nb, dev)
+
+    def run(e, order):
+        e.sample_begin()
+        for b in order:
+            for m, (w, l) in enumerate(batches[b]):
+                e.push_reads_device(m, w.data_ptr(), w.shape[1], l.data_ptr(), n)
+        return e.sample_finish(2)
+
+    # (a) one batch against the oracle
+    c1, c2 = synth.paired_codes_torch(gm, n, 150, 3, isnv=isnv, device=dev, row0=0)
+    mates = [synth.BASES[c.to(torch.uint8).cpu().numpy()] for c in (c1, c2)]
+    pile, _ = oracle.sample_pileup_mt(ix, mates, os.cpu_count() or 8)
+    first = run(eng, [0])
+    helpers.assert_same_pileup(first, pile)
+    # (b) the whole sample, two push orders on two engines
+    full = run(eng, list(range(nb)))
+    other = run(fork, list(reversed(range(nb))))
+    for name in ("fwd_depth", "rev_depth", "fwd_nk", "rev_nk", "stats", "present"):
+        assert np.array_equal(getattr(full, name), getattr(other, name)), name
+    assert full.kmer_stats[:, 1].tolist() == [nb * n * 130, nb * n * 130]
+    assert full.kmer_stats[:, 0].tolist() == [nb * n, nb * n]
+    for name in ("fwd_depth", "rev_depth", "fwd_nk", "rev_nk"):
+        assert np.all(getattr(full, name) >= getattr(first, name)), name
+    assert oracle.pick_best_genome(ix, full.stats.sum(axis=0), full.present.max(axis=0)) == 2
+    fork.close()
+    eng.close()
+    ix.close()
+
+
+def test_config5_hundred_strains_k31(oracle, sars_paths):
+    """BASELINE configs[4] shape: 100 synthetic strains (wuhan_ref + 300 substitutions each), k = 31 -- 37 M window buckets, 8 M
+    alias keys of the u64 bucket-id wrap, a 2.9 GB counter plane, tables far beyond the L2 -- and 200,000 reads of one sample
+    derived from strain 7, against the oracle bit for bit (pileups of all 100 genomes, per-genome statistics, selection)."""
+    files = synth.strain_files(synth.read_fasta_bytes(sars_paths[0]), 100)
+    ix = oracle.Index.build_mem(31, files)
+    eng = helpers.engine_from_oracle_index(ix)
+    gm, isnv = synth.sample_genome(files[7][1][0][1], 5)
+    codes = synth.single_end_codes(gm, 200000, 150, 55, isnv=isnv)
+    words, lens = synth.pack_codes(codes)
+    eng.sample_begin()
+    eng.push_reads(0, words, lens)
+    res = eng.sample_finish(1)
+    pile, _ = oracle.sample_pileup_mt(ix, [synth.BASES[codes]], os.cpu_count() or 8)
+    helpers.assert_same_pileup(res, pile)
+    assert oracle.pick_best_genome(ix, pile.stats.sum(axis=0), pile.present.max(axis=0)) == 7
+    eng.close()
+    ix.close()

@@ -360,6 +360,10 @@ static int alloc_sample_state(bk_engine* e) {
 extern "C" {
 
 int bk_abi_version(void) { return BK_ABI_VERSION; }
+int bk_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
+}
 const char* bk_last_error(void) { return g_err.c_str(); }
 
 void bk_params_default(bk_params* p) {

@@ -351,9 +351,29 @@ int run_call(const Args& a) {
             die(T, "Database k is not the same as provided, please set -k to " + std::to_string(ix.k) + " or build a new index");
     }
 
-    // decoded index -> GPU engine (include/bronko_hip.h)
-    Engine eng;
-    {
+    // decoded index -> GPU engine(s) (include/bronko_hip.h).  Samples are independent (call.rs:212 / :297 handle them one after
+    // the other), so with several GPUs whole samples go to the devices in turn -- no collective; every device holds its own
+    // copy of the tables.  BRONKO_DEVICES=0,1,.. names the devices (default: all visible ones; a device may be named more
+    // than once: as many independent lanes on it), BRONKO_DEVICE=d the single device of earlier versions.
+    std::vector<int> devices;
+    if (const char* dl = getenv("BRONKO_DEVICES")) {
+        for (const char* q = dl; *q;) {
+            char* end = nullptr;
+            const long d = strtol(q, &end, 10);
+            if (end == q) break;
+            devices.push_back((int)d);
+            q = *end == ',' ? end + 1 : end;
+        }
+    } else if (const char* dv = getenv("BRONKO_DEVICE")) {
+        devices.push_back(atoi(dv));
+    } else {
+        const int nd = bk_device_count();
+        for (int d = 0; d < std::max(nd, 1); d++) devices.push_back(d);
+    }
+    if (devices.empty()) devices.push_back(0);
+    const size_t n_samples_total = a.reads.size() + a.first_pairs.size();
+    if (devices.size() > std::max<size_t>(n_samples_total, 1)) devices.resize(std::max<size_t>(n_samples_total, 1));   // no more lanes than samples
+    auto make_engine = [&](int device, Engine& out) {
         std::vector<int32_t> n_seqs;
         std::vector<uint64_t> seq_lens;
         std::vector<const uint8_t*> seqs;
@@ -370,8 +390,21 @@ int run_call(const Args& a) {
         p.n_fixed = (int32_t)a.n_fixed; p.use_full_kmer = a.use_full_kmer ? 1 : 0; p.ci = (uint64_t)a.min_kmers;
         p.full_kmer_stats = 1;   // KMC's "unique counted k-mers" feeds num_unmapped_kmers and the <0.2 warning (call.rs:242-248)
         if (const char* tl = getenv("BRONKO_KMER_TABLE_LOG2")) p.kmer_table_log2 = (uint32_t)atoi(tl);
-        if (const char* dv = getenv("BRONKO_DEVICE")) p.device = atoi(dv);
-        hip_check(bk_engine_create(&d, &p, &eng.e), "bk_engine_create");
+        p.device = device;
+        hip_check(bk_engine_create(&d, &p, &out.e), "bk_engine_create");
+    };
+    struct Lane { int device = 0; Engine eng, fork; std::vector<size_t> mine; };
+    std::vector<Lane> lanes(devices.size());
+    for (size_t l = 0; l < lanes.size(); l++) lanes[l].device = devices[l];
+    if (lanes.size() > 1) {
+        std::string names;
+        for (int d : devices) names += (names.empty() ? "" : ",") + std::to_string(d);
+        LOG_INFO(T, "Samples go to " + std::to_string(lanes.size()) + " GPU lanes in turn (devices " + names + ")");
+    }
+    {
+        std::vector<std::thread> th;   // table construction is host work: the lanes' engines are created side by side
+        for (auto& ln : lanes) th.emplace_back([&make_engine, &ln] { make_engine(ln.device, ln.eng); });
+        for (auto& t : th) t.join();
     }
 
     CallParams cp;
@@ -382,8 +415,8 @@ int run_call(const Args& a) {
 
     const size_t n_files = ix.files.size();
     const uint64_t cells4 = ix.total_cells() * 4;
-    std::vector<OverviewRow> overview;
-    std::vector<SampleCalls> all_calls;   // --alignment
+    std::vector<OverviewRow> overview(n_samples_total);     // by sample, in input order
+    std::vector<SampleCalls> all_calls(a.alignment ? n_samples_total : 0);   // --alignment
 
     // one sample = one -r file (call.rs:213-293) or one R1/R2 pair (call.rs:298-386); outputs are named after R1.
     // A sample has two halves: ingest (parse the FASTQ files, push the reads: host-bound, the scan runs behind it) and
@@ -398,7 +431,7 @@ int run_call(const Args& a) {
         LOG_INFO(T, std::to_string(total_reads) + " reads counted from " + mates[0]);
         return total_reads;
     };
-    auto complete = [&](bk_engine* e, const std::vector<std::string>& mates) {
+    auto complete = [&](bk_engine* e, const std::vector<std::string>& mates, size_t sample_id) {
         const int n_mates = (int)mates.size();
         Pileup p;
         std::vector<uint64_t> stats((size_t)n_mates * n_files * 3), kstats((size_t)n_mates * 4);
@@ -472,26 +505,35 @@ int run_call(const Args& a) {
             LOG_INFO(T, "Writing output to VCF");
             write_vcf(a.output + "/" + stem + ".vcf", mates[0], ix, best, cs.records);
         } catch (const std::exception& ex) { die(T, ex.what()); }
-        overview.push_back(OverviewRow{mates[0], gname, cs.n_major, cs.n_minor, cs.breadth, cs.depth, n_perfect, n_variant, n_unmapped});
-        if (a.alignment) all_calls.push_back(SampleCalls{mates[0], gname, cs.breadth, cs.records});
+        overview[sample_id] = OverviewRow{mates[0], gname, cs.n_major, cs.n_minor, cs.breadth, cs.depth, n_perfect, n_variant, n_unmapped};
+        if (a.alignment) all_calls[sample_id] = SampleCalls{mates[0], gname, cs.breadth, cs.records};
     };
 
     std::vector<std::vector<std::string>> samples;
     for (const auto& r : a.reads) samples.push_back({r});
     for (size_t i = 0; i < a.first_pairs.size(); i++) samples.push_back({a.first_pairs[i], a.second_pairs[i]});
-    Engine fork;
-    if (samples.size() > 1) hip_check(bk_engine_fork(eng.e, &fork.e), "bk_engine_fork");
-    std::thread worker;     // completes the previous sample
-    for (size_t i = 0; i < samples.size(); i++) {
-        const auto& mates = samples[i];
-        LOG_INFO(T, mates.size() == 1 ? "Processing " + mates[0] : "Processing paired reads " + mates[0] + ", " + mates[1]);
-        bk_engine* e = (i & 1) ? fork.e : eng.e;     // (its previous sample, i - 2, was completed before sample i - 1's worker started)
-        ingest(e, mates);
+    for (size_t i = 0; i < samples.size(); i++) lanes[i % lanes.size()].mine.push_back(i);
+    auto run_lane = [&](Lane& ln) {
+        if (ln.mine.size() > 1) hip_check(bk_engine_fork(ln.eng.e, &ln.fork.e), "bk_engine_fork");
+        std::thread worker;     // completes the lane's previous sample
+        for (size_t n = 0; n < ln.mine.size(); n++) {
+            const size_t i = ln.mine[n];
+            const auto& mates = samples[i];
+            LOG_INFO(T, mates.size() == 1 ? "Processing " + mates[0] : "Processing paired reads " + mates[0] + ", " + mates[1]);
+            bk_engine* e = (n & 1) ? ln.fork.e : ln.eng.e;   // (its previous sample, n - 2, was completed before sample n - 1's worker started)
+            ingest(e, mates);
+            if (worker.joinable()) worker.join();
+            worker = std::thread([&complete, e, &mates, i] { complete(e, mates, i); });
+        }
         if (worker.joinable()) worker.join();
-        worker = std::thread([&complete, e, &mates] { complete(e, mates); });
+        if (ln.fork.e) { bk_engine_destroy(ln.fork.e); ln.fork.e = nullptr; }   // (the fork goes before its parent)
+    };
+    if (lanes.size() == 1) run_lane(lanes[0]);
+    else {
+        std::vector<std::thread> th;
+        for (auto& ln : lanes) th.emplace_back([&run_lane, &ln] { run_lane(ln); });
+        for (auto& t : th) t.join();
     }
-    if (worker.joinable()) worker.join();
-    if (fork.e) { bk_engine_destroy(fork.e); fork.e = nullptr; }   // (the fork goes before its parent)
     LOG_INFO(T, "Printing overview");
     try { write_overview_tsv(a.output + "/bronko_overview.tsv", overview); }
     catch (const std::exception& e) { die(T, e.what()); }

@@ -88,6 +88,9 @@ typedef struct {
 typedef struct bk_engine bk_engine;
 
 int         bk_abi_version(void);
+/* Number of visible HIP devices (0 when there is none or the runtime cannot be initialised).  A host with several samples
+ * creates one engine per device and deals whole samples to them (call.rs:212 / :297: samples are independent). */
+int         bk_device_count(void);
 const char* bk_last_error(void);
 void        bk_params_default(bk_params* p);
 

@@ -181,3 +181,35 @@ def test_call_three_samples_overlapped(oracle, golden_dir, tmp_path):
         perfect, variant, unmapped, nmaj, nmin, br, dc = ov_want
         assert ov[1 + i].split("\t")[2:] == [str(nmaj), str(nmin), "%.4f" % br, "%.4f" % dc, str(perfect), str(variant), str(unmapped)]
     ix.close()
+
+
+def test_call_samples_dealt_to_several_gpu_lanes(oracle, golden_dir, tmp_path):
+    """Whole samples per GPU, no collective (call.rs:212: samples are independent): with several devices `bronko call` deals the
+    samples to one engine (+ fork) per device in turn.  BRONKO_DEVICES=0,0 runs two such lanes on the one GPU of the test box --
+    the same code path as two GPUs: five samples, lanes of three and two, every output equal to the oracle's, overview in
+    input order."""
+    g = synth.read_fasta_bytes(os.path.join(golden_dir, "HPV16.fa"))
+    ix = oracle.Index.load(os.path.join(golden_dir, "hpv.bkdb"))
+    paths, samples = [], []
+    for i in range(5):
+        gm, isnv = synth.sample_genome(g, 80 + i, n_snp=2 + i, n_isnv=3)
+        reads = synth.codes_to_ascii(synth.single_end_codes(gm, 5000 + 1500 * i, 150, 180 + i, isnv=isnv))
+        p = str(tmp_path / ("lane%d.fastq.gz" % i))
+        write_fastq_gz(p, reads, "l%d" % i)
+        paths.append(p)
+        samples.append(reads)
+    out = str(tmp_path / "out")
+    env = dict(os.environ, BRONKO_DEVICES="0,0")
+    res = subprocess.run([BRONKO, "call", "-d", os.path.join(golden_dir, "hpv.bkdb"), "-r"] + paths + ["--pileup", "-o", out],
+                         capture_output=True, text=True, env=env)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "2 GPU lanes" in res.stdout + res.stderr
+    odir = str(tmp_path / "oracle")
+    os.makedirs(odir)
+    ov = open(os.path.join(out, "bronko_overview.tsv")).read().splitlines()
+    assert [line.split("\t")[0] for line in ov[1:]] == paths
+    for i in range(5):
+        stem, best, n, ov_want = oracle_outputs(oracle, ix, [samples[i]], odir, paths[i])
+        for ext in (".vcf", ".tsv"):
+            assert open(os.path.join(out, stem + ext), "rb").read() == open(os.path.join(odir, stem + ext), "rb").read(), (i, ext)
+    ix.close()

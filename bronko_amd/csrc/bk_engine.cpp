@@ -253,8 +253,13 @@ struct bk_engine {
     DevBuf<unsigned long long> stats;       // [2][n_files][3]
     DevBuf<unsigned char> present;          // [2][n_files]
     DevBuf<unsigned long long> kstats;      // [2][4]
-    DevBuf<uint32_t> stage_words;
-    DevBuf<uint16_t> stage_lens;
+    // bk_push_reads_packed: two staging slots, so that the copy of a batch overlaps the scan of the previous one
+    struct StageSlot {
+        DevBuf<uint32_t> words; DevBuf<uint16_t> lens;
+        uint8_t* h = nullptr; size_t h_cap = 0;     // pinned host copy of the caller's batch (words, then lens)
+        hipEvent_t done = nullptr; bool busy = false;
+    } stage[2];
+    int next_stage = 0;
 
     // asynchronous ASCII ingest (bk_push_reads_ascii): pinned staging + device buffers per slot
     struct IngestSlot {
@@ -1167,6 +1172,7 @@ void bk_engine_destroy(bk_engine* e) {
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     for (auto& o : e->ktab_old) { (void)hipFree(o.first); (void)hipFree(o.second); }
+    for (auto& st : e->stage) { if (st.done) (void)hipEventDestroy(st.done); if (st.h) (void)hipHostFree(st.h); }
     if (e->h_fill) (void)hipHostFree(e->h_fill);
     if (e->fill_ev) (void)hipEventDestroy(e->fill_ev);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
@@ -1444,17 +1450,33 @@ int bk_push_reads_packed(bk_engine* e, int mate, const uint32_t* words, uint32_t
     if (n > (1ull << 32) / ((uint64_t)stride_words * 16)) return fail(BK_ERR_INVALID, "batch too large: push at most 2^32 bases per call");
     BK_HIP(hipSetDevice(e->device));
     const size_t nw = (size_t)n * stride_words;
-    if (e->stage_words.n < nw) { BK_HIP(hipStreamSynchronize(e->stream)); BK_HIP(e->stage_words.alloc(nw + nw / 4)); }
-    if (e->stage_lens.n < n) { BK_HIP(hipStreamSynchronize(e->stream)); BK_HIP(e->stage_lens.alloc(n + n / 4)); }
-    BK_HIP(hipStreamSynchronize(e->stream));   // staging buffers are reused: wait for the scan that reads them
+    bk_engine::StageSlot& sl = e->stage[e->next_stage];
+    e->next_stage ^= 1;
+    if (!sl.done) BK_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (sl.busy) { BK_HIP(hipEventSynchronize(sl.done)); sl.busy = false; }   // the scan that read this slot two pushes ago
+    if (sl.words.n < nw) BK_HIP(sl.words.alloc(nw + nw / 4));
+    if (sl.lens.n < n) BK_HIP(sl.lens.alloc(n + n / 4));
     {
+        // the caller's buffer is free when this call returns: the batch is copied into the slot's pinned host buffer, from where
+        // it travels asynchronously (an asynchronous copy straight from pageable memory would still be reading the caller's pages)
+        const size_t bytes_w = nw * sizeof(uint32_t), bytes_l = (size_t)n * sizeof(uint16_t);
+        if (sl.h_cap < bytes_w + bytes_l) {
+            if (sl.h) BK_HIP(hipHostFree(sl.h));
+            sl.h = nullptr;
+            sl.h_cap = bytes_w + bytes_l + (bytes_w + bytes_l) / 4;
+            BK_HIP(hipHostMalloc(reinterpret_cast<void**>(&sl.h), sl.h_cap, hipHostMallocDefault));
+        }
+        std::memcpy(sl.h, words, bytes_w);
+        std::memcpy(sl.h + bytes_w, lens, bytes_l);
         bk_engine::Span sp(e, 2);
-        BK_HIP(hipMemcpyAsync(e->stage_words.p, words, nw * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-        BK_HIP(hipMemcpyAsync(e->stage_lens.p, lens, n * sizeof(uint16_t), hipMemcpyHostToDevice, e->stream));
+        BK_HIP(hipMemcpyAsync(sl.words.p, sl.h, bytes_w, hipMemcpyHostToDevice, e->stream));
+        BK_HIP(hipMemcpyAsync(sl.lens.p, sl.h + bytes_w, bytes_l, hipMemcpyHostToDevice, e->stream));
     }
-    int rc = push_device(e, mate, e->stage_words.p, stride_words, e->stage_lens.p, n);
+    int rc = push_device(e, mate, sl.words.p, stride_words, sl.lens.p, n);
     if (rc != BK_OK) return rc;
-    BK_HIP(hipStreamSynchronize(e->stream));   // host buffer (and staging) free on return
+    BK_HIP(hipEventRecord(sl.done, e->stream));
+    sl.busy = true;
+    if (test_env("BK_SYNC_PUSH")) BK_HIP(hipStreamSynchronize(e->stream));
     return BK_OK;
 }
 
@@ -1530,6 +1552,10 @@ int bk_sample_finalize_shard(bk_engine* e, int n_mates, int shard, int n_shards)
     const uint64_t part = e->plane_len / (uint64_t)n_shards;
     int rc = finalize_part(e, n_mates, part * shard, part * (shard + 1));
     if (rc != BK_OK) return rc;
+    for (int m = 0; m < n_mates; m++) {   // the records this rank pushed join the device tally, so that the sum over ranks is the sample's
+        if (e->pushed_records[m]) bk::launch_add_const_u64(e->kstats.p + m * 4 + 0, e->pushed_records[m], e->stream);
+        e->pushed_records[m] = 0;
+    }
     bk::launch_pack_sums(e->shard_sums.p, e->stats.p, e->present.p, e->kstats.p, e->n_files, e->stream);
     BK_HIP(hipGetLastError());
     return BK_OK;

@@ -101,6 +101,7 @@ void launch_pack_reads(const PackArgs& a, hipStream_t stream);
 void launch_pick_window(const ScanArgs& a, uint64_t n_probe, unsigned int* votes, hipStream_t stream);
 void launch_count_kmers(const ScanArgs& a, hipStream_t stream);   // empty window: kmer_total += k-mer occurrences, nothing else
 void launch_add_u64(unsigned long long* dst, const unsigned long long* src, hipStream_t stream);   // *dst += *src
+void launch_add_const_u64(unsigned long long* dst, unsigned long long v, hipStream_t stream);        // *dst += v
 uint32_t scan_grid(uint64_t n_records, int n_cus);
 uint32_t scan_l2_words(uint32_t stride_words, int k);   // bitmap words per record (ScanArgs::l2_words)
 uint64_t scan_max_records(uint32_t grid);   // most records one launch_scan_count may be given

@@ -140,6 +140,10 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(PackArgs a) {
 }
 
 __global__ void add_u64_kernel(unsigned long long* dst, const unsigned long long* src) { *dst += *src; }
+__global__ void add_const_u64_kernel(unsigned long long* dst, unsigned long long v) { *dst += v; }
+void launch_add_const_u64(unsigned long long* dst, unsigned long long v, hipStream_t stream) {
+    hipLaunchKernelGGL(add_const_u64_kernel, dim3(1), dim3(1), 0, stream, dst, v);
+}
 void launch_add_u64(unsigned long long* dst, const unsigned long long* src, hipStream_t stream) {
     hipLaunchKernelGGL(add_u64_kernel, dim3(1), dim3(1), 0, stream, dst, src);
 }

@@ -95,6 +95,9 @@ class ShardedFinalize:
         self.out = torch.empty(part, dtype=torch.int32 if narrow else torch.int64, device=device) if world > 1 else None
 
     def __call__(self):
+        if self.planes and self.planes[0].is_cuda and torch.cuda.current_stream().cuda_stream != self.eng.stream_ptr():
+            raise RuntimeError("ShardedFinalize: torch's current stream is not the engine's stream -- the collectives would not be "
+                               "ordered against the engine's kernels (use torch.cuda.stream(ExternalStream(eng.stream_ptr())))")
         for m, plane in enumerate(self.planes):
             self.eng.counters_ptr(m)   # (a plane this rank pushed nothing to is zeroed by this call)
             reduce_scatter_plane(plane, self.rank, self.world, self.out, self.narrow)

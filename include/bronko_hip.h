@@ -135,6 +135,8 @@ uint64_t bk_counter_len(const bk_engine* e);     /* u64 elements in one counter 
 int bk_sample_begin(bk_engine* e);
 int bk_push_reads_packed(bk_engine* e, int mate, const uint32_t* words, uint32_t stride_words,
                          const uint16_t* lens, uint64_t n_records);
+/* (bk_push_reads_packed stages the batch through one of two device buffers: the copy of a batch overlaps the scan of the
+ * previous one; the call blocks only when both are still in use.) */
 /* Same, for a batch that is already resident in device memory (no copy; asynchronous on the engine stream). */
 int bk_push_reads_packed_device(bk_engine* e, int mate, const void* d_words, uint32_t stride_words,
                                 const void* d_lens, uint64_t n_records);

@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--wide", action="store_true", help="N > 1: move the counter plane as 64-bit integers even when 32 bits would do")
     ap.add_argument("--in-flight", type=int, default=3, help="samples in flight per GPU (bk_engine_fork: shared index tables, own counter "
                     "planes / outputs / stream); 1 = strictly one sample after the other")
+    ap.add_argument("--selected-only", action="store_true", help="bk_params.pileup_selected_only: votes for the selected genome only (two finalize "
+                    "passes); what `bronko call` runs with -- the default is the reference's literal map_kmers: every genome's rows")
     ap.add_argument("--dry-run", action="store_true", help="launcher check without a GPU: start the ranks, form the process group (use "
                     "--backend gloo), all-reduce the rank ids, print n_gpus / rccl_ranks and stop -- no hot path, no number")
     ap.add_argument("--backend", default="nccl", help="testing aid: 'gloo' lets several ranks share one GPU (rank r uses GPU r mod #GPUs)")
@@ -195,7 +197,7 @@ def main():
         ix = HostIndex.build_mem(k, files, threads=min(32, os.cpu_count() or 4))
         ref_paths = None
     t_index = time.perf_counter()
-    eng = ix.engine(Params(device=local_rank))
+    eng = ix.engine(Params(device=local_rank, pileup_selected_only=args.selected_only))
     t_engine = time.perf_counter()
 
     # ---- synthetic samples, generated on the GPU (bronko_amd.synth: the same splitmix64 streams as the numpy generator) ----
@@ -412,6 +414,7 @@ def main():
         "config": {"workload": workload, "baseline_config": cfg, "k": k, "read_len": rl, "samples_per_step": sps,
                    "reads_per_sample": reads_per_sample_total, "reads_per_gpu_per_sample": reads_per_sample_rank, "mates": n_mates,
                    "samples_in_flight": len(engs), "resident_input_bytes": resident,
+                   "pileup_rows": "selected genome only (bk_params.pileup_selected_only)" if args.selected_only else "every genome (call.rs:1305-1384)",
                    "parallelism": ("single GPU" if world == 1 else
                                    "whole samples per GPU over %d GPUs, no collective" % world if not sharded_reads else
                                    ("one sample's reads sharded over %d GPUs; RCCL reduce-scatter(sum) of the k-mer counter plane%s, sharded finalize, "

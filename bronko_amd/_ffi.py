@@ -22,7 +22,7 @@ class IndexDesc(C.Structure):
 class Params(C.Structure):
     _fields_ = [("n_fixed", C.c_int32), ("use_full_kmer", C.c_int32), ("ci", C.c_uint64), ("cs", C.c_uint64),
                 ("cx", C.c_uint64), ("device", C.c_int32), ("full_kmer_stats", C.c_int32),
-                ("kmer_table_log2", C.c_uint32), ("reserved", C.c_uint32)]
+                ("kmer_table_log2", C.c_uint32), ("pileup_selected_only", C.c_uint32)]
 
 
 class CallParams(C.Structure):  # include/bronko_hip.h bk_call_params

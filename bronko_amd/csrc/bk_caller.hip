@@ -226,6 +226,10 @@ __global__ __launch_bounds__(256) void call_kernel(CallArgs a) {
     }
 }
 
+void launch_select_genome(const CallArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(select_genome_kernel, dim3(1), dim3(64), 0, stream, a);
+}
+
 void launch_call(const CallArgs& a, int max_seqs_per_file, uint64_t max_file_cells, hipStream_t stream) {
     hipLaunchKernelGGL(select_genome_kernel, dim3(1), dim3(64), 0, stream, a);
     hipLaunchKernelGGL(noise_kernel, dim3((unsigned)(max_seqs_per_file > 0 ? max_seqs_per_file : 1)), dim3(256), 0, stream, a);

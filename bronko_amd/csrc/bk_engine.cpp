@@ -296,6 +296,7 @@ struct bk_engine {
     DevBuf<double> call_freq, call_noise;
     DevBuf<bk_call_record> call_records;
     DevBuf<bk_call_summary> call_out;
+    DevBuf<bk_call_summary> sel_out;        // pileup_selected_only: the genome selected between the two finalize passes
     DevBuf<unsigned long long> dbg;   // BK_L2_STATS (testing build): tallies of what the scan leaves to Level 2
     int ablate = 0;   // BK_SCAN_ABLATE (measurement aid): see scan_count_kernel
     uint64_t max_launch_records = 0;   // BK_MAX_LAUNCH_RECORDS (testing aid): split pushes into launches of at most this many records
@@ -349,7 +350,7 @@ static int alloc_sample_state(bk_engine* e) {
     }
     BK_HIP(e->ktab_out.alloc(8 + bk::ktab_fill_words()));
     if (e->n_files <= 64) BK_HIP(e->fin_partials.alloc(bk::finalize_partial_rows() * ((size_t)e->n_files * 3 + 2)));
-    BK_HIP(e->deferred.alloc(bk::v_plane_len(e->n_full, e->v_span, e->n_prows)));
+    BK_HIP(e->deferred.alloc(bk::v_plane_len(e->n_full, e->v_span, e->n_prows) * (prm->pileup_selected_only ? 2 : 1)));   // (one list per mate file when it is kept between two passes)
     BK_HIP(e->n_deferred.alloc(2));   // one per mate file
     BK_HIP(e->pileup.alloc(e->total_cells * 4 * 4));
     BK_HIP(e->stats.alloc((size_t)2 * e->n_files * 3));
@@ -381,7 +382,7 @@ void bk_params_default(bk_params* p) {
     p->device = 0;
     p->full_kmer_stats = 0;
     p->kmer_table_log2 = 26;
-    p->reserved = 0;
+    p->pileup_selected_only = 0;
 }
 
 int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** out) {
@@ -1500,26 +1501,43 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
     if (!e->in_sample) return fail(BK_ERR_STATE, "bk_sample_finalize called before bk_sample_begin");
     if (n_mates < 1 || n_mates > 2) return fail(BK_ERR_INVALID, "n_mates must be 1 or 2");
     BK_HIP(hipSetDevice(e->device));
-    for (int m = 0; m < n_mates; m++) {   // R1 then R2 into the same arrays (call.rs:316-317)
-        bk::FinalizeArgs a{};
-        a.ix = e->view();
-        a.counters = e->counters[m].p;
-        a.elem_lo = elem_lo; a.elem_hi = elem_hi;
-        a.ci = e->params.ci; a.cs = e->params.cs; a.cx = e->params.cx;
-        a.pileup = e->pileup.p;
-        a.plane = (size_t)e->total_cells * 4;
-        a.stats = e->stats.p + (size_t)m * e->n_files * 3;
-        a.present = e->present.p + (size_t)m * e->n_files;
-        a.kept_total = e->kstats.p + m * 4 + 3;
-        a.distinct_total = e->kstats.p + m * 4 + 2;
-        a.partials = e->fin_partials.p;
-        a.deferred = e->deferred.p;
-        a.n_deferred = e->n_deferred.p + m;
-        a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->ktab_log2;
-        a.ktab_overflow = e->ktab_out.p + 4; a.mate = (uint32_t)m;
-        if (int rc = zero_plane_if_stale(e, m)) return rc;
-        bk_engine::Span sp(e, 1);
-        bk::launch_finalize(a, e->stream);
+    // bk_params.pileup_selected_only (several genome files): first the statistics of every genome without a single vote, then the
+    // genome is selected on the device (call.rs:422-502), then the votes -- only the BucketInfos of that genome
+    const bool two_pass = e->params.pileup_selected_only != 0 && e->n_files > 1;
+    if (two_pass && (elem_lo != 0 || elem_hi != e->plane_len)) return fail(BK_ERR_UNSUPPORTED, "pileup_selected_only cannot be combined with a sharded finalize");
+    if (two_pass && !e->sel_out.p) BK_HIP(e->sel_out.alloc(1));
+    for (int pass = 0; pass < (two_pass ? 2 : 1); pass++) {
+        for (int m = 0; m < n_mates; m++) {   // R1 then R2 into the same arrays (call.rs:316-317)
+            bk::FinalizeArgs a{};
+            a.ix = e->view();
+            a.counters = e->counters[m].p;
+            a.elem_lo = elem_lo; a.elem_hi = elem_hi;
+            a.ci = e->params.ci; a.cs = e->params.cs; a.cx = e->params.cx;
+            a.pileup = e->pileup.p;
+            a.plane = (size_t)e->total_cells * 4;
+            a.stats = e->stats.p + (size_t)m * e->n_files * 3;
+            a.present = e->present.p + (size_t)m * e->n_files;
+            a.kept_total = e->kstats.p + m * 4 + 3;
+            a.distinct_total = e->kstats.p + m * 4 + 2;
+            a.partials = e->fin_partials.p;
+            a.deferred = e->deferred.p + (two_pass ? (size_t)m * (e->deferred.n / 2) : 0);   // (kept from the first pass to the second)
+            a.n_deferred = e->n_deferred.p + m;
+            a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->ktab_log2;
+            a.ktab_overflow = e->ktab_out.p + 4; a.mate = (uint32_t)m;
+            a.mode = two_pass ? pass + 1 : 0;
+            a.sel = two_pass ? &e->sel_out.p->file_id : nullptr;
+            a.sel_file = -1;
+            if (pass == 0) { if (int rc = zero_plane_if_stale(e, m)) return rc; }
+            bk_engine::Span sp(e, 1);
+            bk::launch_finalize(a, e->stream);
+        }
+        if (two_pass && pass == 0) {
+            bk::CallArgs c{};
+            c.n_files = e->n_files; c.n_mates = n_mates; c.stats = e->stats.p; c.present = e->present.p; c.genome_len = e->genome_len.p;
+            c.out = e->sel_out.p;
+            bk_engine::Span sp(e, 1);
+            bk::launch_select_genome(c, e->stream);
+        }
     }
     if (e->ktab_keys.p) {
         bk_engine::Span sp(e, 1);
@@ -1529,9 +1547,12 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
     e->in_sample = false;
     if (e->dbg.p) {   // BK_L2_STATS (testing build)
         unsigned long long h[32];
+        unsigned int nd[2] = {0, 0};
+        BK_HIP(hipMemcpyAsync(nd, e->n_deferred.p, sizeof nd, hipMemcpyDeviceToHost, e->stream));
         BK_HIP(hipMemcpyAsync(h, e->dbg.p, sizeof h, hipMemcpyDeviceToHost, e->stream));
         BK_HIP(hipMemsetAsync(e->dbg.p, 0, sizeof h, e->stream));
         BK_HIP(hipStreamSynchronize(e->stream));
+        fprintf(stderr, "[bk] finalize: %u + %u k-mers deferred to the general kernel\n", nd[0], nd[1]);
         fprintf(stderr, "[bk] scan marked: no-diagonal %llu, dirty-head %llu, clean-head %llu, pairs %llu | level 2: k-mers %llu in %llu chunks, simple %llu, dead %llu, "
                 "dirty answers %llu (one difference but id unknown: %llu), slow %llu (diffs 0/1/2/3+ with a diagonal: %llu/%llu/%llu/%llu) -> member %llu, neighbour %llu, nothing %llu\n",
                 h[0], h[1], h[2], h[3], h[4], h[11], h[5], h[6], h[16], h[17], h[7], h[12], h[13], h[14], h[15], h[8], h[9], h[10]);

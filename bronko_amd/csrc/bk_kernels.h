@@ -73,6 +73,11 @@ struct FinalizeArgs {
     uint32_t ktab_log2;
     unsigned long long* ktab_overflow;
     uint32_t mate;
+    // bk_params.pileup_selected_only: 0 = statistics and votes in one pass; 1 = statistics only (first pass); 2 = votes only, and
+    // only for BucketInfos of genome file *sel (second pass, after the genome was selected from the statistics)
+    int mode;
+    const int* sel;
+    int sel_file;                   // = *sel, read by each kernel of the second pass
 };
 
 struct FoldArgs {
@@ -153,6 +158,7 @@ struct CallArgs {
     CallSummaryDev* out;
 };
 void launch_call(const CallArgs& a, int max_seqs_per_file, uint64_t max_file_cells, hipStream_t stream);
+void launch_select_genome(const CallArgs& a, hipStream_t stream);   // the first kernel of launch_call alone: a.out->file_id
 size_t finalize_lds_bytes(int n_files);
 size_t finalize_partial_rows();
 

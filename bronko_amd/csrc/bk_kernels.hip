@@ -1279,6 +1279,7 @@ void launch_fold(const FoldArgs& f, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------ K2
 // The vote of call.rs:1327-1384 for one BucketInfo.
 __device__ __forceinline__ void vote(const FinalizeArgs& a, const DevEntry& e, uint64_t c, uint32_t isrc, int k, unsigned long long v) {
+    if (a.mode == 1 || (a.mode == 2 && (int)e.file != a.sel_file)) return;   // statistics pass / votes for the selected genome only
     uint32_t bit_idx;
     bool forward;
     if (e.canonical) {
@@ -1291,6 +1292,30 @@ __device__ __forceinline__ void vote(const FinalizeArgs& a, const DevEntry& e, u
     const size_t cell = (size_t)e.cell * 4 + bit_idx;
     atomicAdd(a.pileup + (forward ? 2 : 3) * a.plane + cell, 1ull);   // #kmers  += 1
     atomicMax(a.pileup + (forward ? 0 : 1) * a.plane + cell, v);      // depth = max(depth, n)
+}
+
+// Second pass of bk_params.pileup_selected_only: the entries of a bucket are sorted by genome file -- the first one of `file`
+// (or cnt), by bisection
+__device__ __forceinline__ uint32_t first_of_file(const DevEntry* __restrict__ ent, uint32_t cnt, int file) {
+    uint32_t lo = 0, hi = cnt;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((int)ent[mid].file < file) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// lstats[idx] += 1 from every active lane: the lanes of a wave walk the entry lists of their buckets in step, and with many
+// genomes that share a k-mer they name the same genome at the same time -- one LDS atomic for all lanes that agree with the
+// first active one instead of up to 64 on one address
+__device__ __forceinline__ void tally(uint32_t* lstats, uint32_t idx) {
+    const unsigned long long active = __ballot(true);
+    const int leader = __builtin_ctzll(active);
+    const uint32_t lidx = (uint32_t)__shfl((int)idx, leader);
+    const bool same = idx == lidx;
+    const unsigned long long sm = __ballot(same);
+    if (!same) atomicAdd(&lstats[idx], 1u);
+    else if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&lstats[idx], (uint32_t)__popcll(sm));
 }
 
 // End of a finalize workgroup: per-genome tallies (LDS) and the kept / distinct k-mer tallies either go to this
@@ -1371,6 +1396,7 @@ __device__ __forceinline__ void vt_clear(const VoteTable& vt) {   // whole workg
 // the vote of call.rs:1327-1384 (see vote()), into the table
 __device__ __forceinline__ void vt_vote(const VoteTable& vt, uint32_t par, const FinalizeArgs& a, const DevEntry& e, uint64_t c, uint32_t isrc,
                                         int k, unsigned long long v) {
+    if (a.mode == 1 || (a.mode == 2 && (int)e.file != a.sel_file)) return;   // statistics pass / votes for the selected genome only
     uint32_t bit_idx;
     bool forward;
     if (e.canonical) { bit_idx = ((uint32_t)(c >> (2 * e.idx)) & 3u) ^ 3u; forward = isrc != 0; }
@@ -1453,6 +1479,8 @@ __device__ __forceinline__ void v_kmer_of_counter(const IndexView& ix, const uns
 // skipped -- with full_kmer_stats they join the k-mer statistics table, like every other k-mer that touches nothing.
 __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (a.mode == 2) { a.sel_file = *a.sel; if (a.sel_file < 0) return; }   // second pass: votes for the selected genome only
+    const bool do_stats = a.mode != 2;                                       // (its statistics were tallied by the first pass)
     const IndexView& ix = a.ix;
     uint32_t* lstats = reinterpret_cast<uint32_t*>(smem);   // [n_files][3] block-local tallies + 2 scratch words
     const VoteTable vt = vt_make(smem + (((size_t)ix.n_files * 3 + 2) * sizeof(uint32_t) + 15) / 16 * 16);
@@ -1485,6 +1513,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
     };
     // the vote of call.rs:1327-1384 (see vote()), gathered
     auto vote_acc = [&](const DevEntry& e, uint64_t c, uint32_t isrc, unsigned long long v) {
+        if (a.mode == 1 || (a.mode == 2 && (int)e.file != a.sel_file)) return;
         uint32_t bit_idx;
         bool forward;
         if (e.canonical) { bit_idx = ((uint32_t)(c >> (2 * e.idx)) & 3u) ^ 3u; forward = isrc != 0; }
@@ -1498,9 +1527,9 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
 
     // one kept k-mer: c = reference k-mer p with base changed at window position t, read in orientation isrc, n times
     auto map_one = [&](uint32_t p, uint32_t t, uint64_t c, uint32_t isrc, unsigned long long n, uint64_t vi) {
-        distinct += 1;
+        if (do_stats) distinct += 1;
         if (n < a.ci || n > a.cx) return;                        // kmc -ci / -cx act on the true count
-        ++kept;
+        if (do_stats) ++kept;
         const unsigned long long v = n > a.cs ? a.cs : n;       // kmc -cs: reported count saturates
         // It can touch a second window bucket only if another reference k-mer lies at Hamming distance 2 from u
         // (amb[p], precomputed); otherwise its one bucket is u's own bucket at t.  Ambiguous u: enumerate the
@@ -1509,8 +1538,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
             uint32_t jmask = 0;   // window positions at which c has a neighbouring reference k-mer
             for_each_neighbour(ix, c, [&](int jj, uint32_t, uint32_t) { jmask |= 1u << (jj - ix.wstart); });
             if (jmask != (1u << t)) {
-                const unsigned int at = atomicAdd(a.n_deferred, 1u);
-                a.deferred[at] = (uint32_t)vi;
+                if (do_stats) { const unsigned int at = atomicAdd(a.n_deferred, 1u); a.deferred[at] = (uint32_t)vi; }
                 return;
             }
         }
@@ -1537,10 +1565,11 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
                 en = ix.entries[off + q];
                 if (en.file != file) break;
             }
+            if (!do_stats) continue;
             if (run == (uint32_t)ix.W) { atomicAdd(&lstats[file * 3 + 0], 1u); ++n_perfect; perfect_file = file; }
             else atomicAdd(&lstats[file * 3 + 1], 1u);
         }
-        if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
+        if (do_stats && n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
     };
 
     // v_span lanes per row, lane oo = offset: the row's prefix sums by shuffles, then every lane maps its own
@@ -1593,10 +1622,10 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         const uint64_t rc = revcomp_kmer(c, k);
         const bool alive = j >= ix.wstart && j < ix.wstart + ix.W && c < rc;
         if (act && !alive) {
-            if (kt.keys) ktab_insert(kt, c < rc ? c : rc, c < rc ? isrc : isrc ^ 1u, (unsigned int)(n > 0xf0000000ull ? 0xf0000000ull : n));
+            if (kt.keys && do_stats) ktab_insert(kt, c < rc ? c : rc, c < rc ? isrc : isrc ^ 1u, (unsigned int)(n > 0xf0000000ull ? 0xf0000000ull : n));
             act = false;
         }
-        if (act) { distinct += 1; if (n < a.ci || n > a.cx) act = false; else ++kept; }   // kmc -ci / -cx act on the true count
+        if (act) { distinct += do_stats; if (n < a.ci || n > a.cx) act = false; else kept += do_stats; }   // kmc -ci / -cx act on the true count
         const unsigned long long v = n > a.cs ? a.cs : n;       // kmc -cs: reported count saturates
         const uint32_t t = (uint32_t)(j - ix.wstart);
         if (act && dirty) {
@@ -1612,8 +1641,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
                 multi = jmask != (1u << t);
             }
             if (multi) {
-                const unsigned int at = atomicAdd(a.n_deferred, 1u);
-                a.deferred[at] = (uint32_t)(wk * rl + oo);
+                if (do_stats) { const unsigned int at = atomicAdd(a.n_deferred, 1u); a.deferred[at] = (uint32_t)(wk * rl + oo); }
                 act = false;
             }
         }
@@ -1632,19 +1660,26 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         {
             // one hit in that genome: "variant" unless the window is a single bucket.  Tallied once per wave for the genome of
             // the wave's first voter (64 lanes adding 1 to the same LDS word would serialise), one by one for the others
-            const unsigned long long sm = __ballot(single);
+            const unsigned long long sm = __ballot(single && do_stats);
             if (sm) {
                 const int lf = __builtin_ctzll(sm);
-                const bool same = single && first.file == (uint16_t)__shfl((int)first.file, lf);
+                const bool same = single && do_stats && first.file == (uint16_t)__shfl((int)first.file, lf);
                 const uint32_t n_same = (uint32_t)__popcll(__ballot(same));
-                const uint32_t add = same ? ((int)(threadIdx.x & 63u) == lf ? n_same : 0u) : (single ? 1u : 0u);
+                const uint32_t add = same ? ((int)(threadIdx.x & 63u) == lf ? n_same : 0u) : (single && do_stats ? 1u : 0u);
                 if (add) {
                     if (ix.W == 1) { atomicAdd(&lstats[first.file * 3 + 0], add); atomicAdd(&lstats[first.file * 3 + 2], add); }
                     else atomicAdd(&lstats[first.file * 3 + 1], add);
                 }
             }
         }
-        if (act && cnt > 1u) {
+        if (act && cnt > 1u && !do_stats) {
+            // second pass: the selected genome's entries of the bucket only
+            for (uint32_t x = first_of_file(ix.entries + r.x, cnt, a.sel_file); x < cnt; ++x) {
+                const DevEntry en = ix.entries[r.x + x];
+                if ((int)en.file != a.sel_file) break;
+                vt_vote(vt, par, a, en, c, isrc, k, v);
+            }
+        } else if (act && cnt > 1u) {
             // entries of one bucket are grouped by file (index build appends file by file): run lengths = hits per file
             uint32_t n_perfect = 0, perfect_file = 0;
             for (uint32_t x = 0; x < cnt;) {
@@ -1659,8 +1694,9 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
                     en = ix.entries[r.x + x];
                     if (en.file != file) break;
                 }
-                if (run == (uint32_t)ix.W) { atomicAdd(&lstats[file * 3 + 0], 1u); ++n_perfect; perfect_file = file; }
-                else atomicAdd(&lstats[file * 3 + 1], 1u);
+                const bool perfect = run == (uint32_t)ix.W;
+                tally(lstats, file * 3 + (perfect ? 0u : 1u));
+                if (perfect) { ++n_perfect; perfect_file = file; }
             }
             if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
         }
@@ -1677,7 +1713,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         flush(0); flush(1);
     }
     __syncthreads();
-    finalize_epilogue(a, lstats, kept, distinct, lstats + ix.n_files * 3, (int)blockIdx.x);
+    if (do_stats) finalize_epilogue(a, lstats, kept, distinct, lstats + ix.n_files * 3, (int)blockIdx.x);
 }
 
 // K2e: the E counters (reference k-mers).  A reference k-mer owns all W of its window buckets (slot_of), and its
@@ -1686,6 +1722,8 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
 // the BucketInfos of that bucket; the bucket-0 thread also tallies the statistics.
 __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (a.mode == 2) { a.sel_file = *a.sel; if (a.sel_file < 0) return; }   // second pass: votes for the selected genome only
+    const bool do_stats = a.mode != 2;
     const IndexView& ix = a.ix;
     uint32_t* lstats = reinterpret_cast<uint32_t*>(smem);   // [n_files][3] block-local tallies + 2 scratch words
     const VoteTable vt = vt_make(smem + (((size_t)ix.n_files * 3 + 2) * sizeof(uint32_t) + 15) / 16 * 16);
@@ -1709,13 +1747,13 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
         const uint64_t cidx = g / W;
         const uint32_t t = (uint32_t)(g % W);
         const unsigned long long n = a.counters[cidx];
-        distinct += (n != 0 && t == 0);
+        distinct += (n != 0 && t == 0 && do_stats);
         if (n == 0 || n < a.ci || n > a.cx) break;              // kmc -ci / -cx act on the true count
         const unsigned long long v = n > a.cs ? a.cs : n;       // kmc -cs: reported count saturates
         const uint32_t id = (uint32_t)(cidx >> 1), isrc = (uint32_t)cidx & 1u;
         const uint4 idr = *reinterpret_cast<const uint4*>(ix.id_rec + id);
         const uint64_t c = (uint64_t)idr.x | ((uint64_t)idr.y << 32);
-        {
+        if (a.mode != 1) {   // (the statistics pass casts no votes: a reference k-mer's statistics come from estat below)
             const uint32_t j = (uint32_t)ix.wstart + t;
             const uint4 r = (idr.w & kIdSimple) ? make_uint4(0u, 1u, idr.z + j, (idr.w >> 16) | (j << 16) | (((idr.w >> 1) & 1u) << 24))
                                                 : *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)id * W + t);
@@ -1724,17 +1762,23 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
             if (r.y && r.y <= kVoteMaxEntries) {               // a few genomes: still worth the table
                 vt_vote(vt, par, a, first, c, isrc, k, v);
                 for (uint32_t q = 1; q < r.y; ++q) vt_vote(vt, par, a, ix.entries[r.x + q], c, isrc, k, v);
+            } else if (r.y && !do_stats) {                     // second pass: the selected genome's entries only
+                for (uint32_t q = first_of_file(ix.entries + r.x, r.y, a.sel_file); q < r.y; ++q) {
+                    const DevEntry en = ix.entries[r.x + q];
+                    if ((int)en.file != a.sel_file) break;
+                    vt_vote(vt, par, a, en, c, isrc, k, v);
+                }
             } else if (r.y) {                                  // many: as many cells, it would overflow
                 vote(a, first, c, isrc, k, v);
                 for (uint32_t q = 1; q < r.y; ++q) vote(a, ix.entries[r.x + q], c, isrc, k, v);
             }
         }
-        if (t == 0) {
+        if (t == 0 && do_stats) {
             ++kept;
             uint32_t n_perfect = 0, perfect_file = 0;
             for (uint32_t q = ix.estat_off[id]; q < ix.estat_off[id + 1]; ++q) {   // (file << 1) | perfect
                 const uint32_t e = ix.estat[q];
-                atomicAdd(&lstats[(e >> 1) * 3 + ((e & 1u) ? 0 : 1)], 1u);
+                tally(lstats, (e >> 1) * 3 + ((e & 1u) ? 0u : 1u));
                 if (e & 1u) { ++n_perfect; perfect_file = e >> 1; }
             }
             if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
@@ -1747,9 +1791,9 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     for (uint64_t cidx = max(c_lo, 2ull * ix.n_full) + (uint64_t)blockIdx.x * 256 + threadIdx.x; cidx < c_hi; cidx += (uint64_t)gridDim.x * 256) {
         const unsigned long long n = a.counters[cidx];
         if (n == 0) continue;
-        distinct += 1;
+        distinct += do_stats;
         if (n < a.ci || n > a.cx) continue;
-        ++kept;
+        kept += do_stats;
         const unsigned long long v = n > a.cs ? a.cs : n;
         const uint32_t id = (uint32_t)(cidx >> 1), isrc = (uint32_t)cidx & 1u;
         const uint64_t c = ix.kmer_of[id];
@@ -1758,6 +1802,7 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
             const uint32_t off = ix.ent_off[s], cnt = ix.ent_len[s];
             for (uint32_t q = 0; q < cnt; ++q) vote(a, ix.entries[off + q], c, isrc, k, v);
         }
+        if (!do_stats) continue;
         uint32_t n_perfect = 0, perfect_file = 0;
         for (uint32_t q = ix.estat_off[id]; q < ix.estat_off[id + 1]; ++q) {   // (file << 1) | perfect
             const uint32_t e = ix.estat[q];
@@ -1767,7 +1812,7 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
         if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
     }
     __syncthreads();
-    finalize_epilogue(a, lstats, kept, distinct, lstats + ix.n_files * 3, a.row_exact + (int)blockIdx.x);
+    if (do_stats) finalize_epilogue(a, lstats, kept, distinct, lstats + ix.n_files * 3, a.row_exact + (int)blockIdx.x);
 }
 
 // K2b: one wave per workgroup and per k-mer, for the V counters K2a deferred (k-mers that touch several window
@@ -1778,6 +1823,8 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
 // serialise on one global atomic word).
 __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (a.mode == 2) { a.sel_file = *a.sel; if (a.sel_file < 0) return; }   // second pass: votes for the selected genome only
+    const bool do_stats = a.mode != 2;
     const IndexView& ix = a.ix;
     uint32_t* hits = reinterpret_cast<uint32_t*>(smem);                       // [n_files]
     uint32_t* touched = hits + ix.n_files;                                      // [n_files]
@@ -1805,22 +1852,25 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
             v_kmer_of_counter(ix, a.counters + ix.v_off, ci - n_e, p_, t_, c, isrc, v);
             v = v > a.cs ? a.cs : v;                              // kmc -cs: reported count saturates
 
+            int s = -1;   // lane t: the k-mer's bucket at window position t, if the index has it
             if (lane < ix.W) {
-                int s;
                 if (ci < n_e) {
                     s = (int)ix.slot_of[(size_t)(ci >> 1) * ix.W + lane];   // a reference k-mer owns all its buckets
                 } else {
                     const int sh = 2 * (k - 1 - (ix.wstart + lane));
                     s = probe_table(ix.table + (size_t)lane * S, ix.log2s, c & ~(3ull << sh));
                 }
-                if (s >= 0) {
-                    const uint32_t off = ix.ent_off[s], cnt = ix.ent_len[s];
-                    for (uint32_t q = 0; q < cnt; ++q) {
-                        const DevEntry e = ix.entries[off + q];
-                        // call.rs:1316-1318 per_genome_bucket_hits
-                        if (atomicAdd(&hits[e.file], 1u) == 0u) touched[atomicAdd(ntouched, 1u)] = e.file;
-                        vote(a, e, c, isrc, k, v);
-                    }
+            }
+            // the buckets found, one after the other; the BucketInfos of a bucket (one per genome that has the k-mer: up to
+            // hundreds) spread over the lanes
+            for (unsigned long long bm = __ballot(s >= 0); bm; bm &= bm - 1ull) {
+                const int sb = __shfl(s, __builtin_ctzll(bm));
+                const uint32_t off = ix.ent_off[sb], cnt = ix.ent_len[sb];
+                for (uint32_t q = (uint32_t)lane; q < cnt; q += 64u) {
+                    const DevEntry e = ix.entries[off + q];
+                    // call.rs:1316-1318 per_genome_bucket_hits
+                    if (atomicAdd(&hits[e.file], 1u) == 0u) touched[atomicAdd(ntouched, 1u)] = e.file;
+                    vote(a, e, c, isrc, k, v);
                 }
             }
             __syncthreads();
@@ -1835,12 +1885,12 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
                     const uint32_t h = hits[g];
                     hits[g] = 0;
                     perfect = h == (uint32_t)ix.W;
-                    lstats[g * 3 + (perfect ? 0 : 1)] += 1;   // g is distinct per lane within one k-mer
+                    if (do_stats) lstats[g * 3 + (perfect ? 0 : 1)] += 1;   // g is distinct per lane within one k-mer
                     if (perfect) my_perfect = (int)g;
                 }
                 n_perfect += (uint32_t)__popcll(__ballot(perfect));
             }
-            if (n_perfect == 1 && my_perfect >= 0) lstats[my_perfect * 3 + 2] += 1;
+            if (do_stats && n_perfect == 1 && my_perfect >= 0) lstats[my_perfect * 3 + 2] += 1;
             __syncthreads();
             if (lane == 0) *ntouched = 0;
             __syncthreads();
@@ -1849,11 +1899,11 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
     __syncthreads();
     if (lane == 0) { ntouched[0] = 0; ntouched[1] = 0; }
     __syncthreads();
-    finalize_epilogue(a, lstats, 0u, 0u, ntouched, a.row_general + (int)blockIdx.x);
+    if (do_stats) finalize_epilogue(a, lstats, 0u, 0u, ntouched, a.row_general + (int)blockIdx.x);
 }
 
 size_t finalize_lds_bytes(int n_files) { return ((size_t)n_files * 5 + 4) * sizeof(uint32_t); }
-constexpr unsigned kFinVariantBlocks = 256 * 8, kFinExactBlocks = 256 * 8, kFinGeneralBlocks = 256 * 4;
+constexpr unsigned kFinVariantBlocks = 256 * 8, kFinExactBlocks = 256 * 8, kFinGeneralBlocks = 256 * 16;
 size_t finalize_partial_rows() { return (size_t)kFinVariantBlocks + kFinExactBlocks + kFinGeneralBlocks; }
 
 void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
@@ -1878,10 +1928,11 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     a.row_exact = (int)b_var;
     hipLaunchKernelGGL(finalize_exact_kernel, dim3(b_ex), dim3(256), lds_votes, stream, a);
     // K2b (deferred k-mers only; the kernel reads their number on the device)
-    unsigned b_gen = (unsigned)std::min<size_t>(kFinGeneralBlocks, 256 * std::max<size_t>(1, (160u * 1024u) / lds));
+    // (few genomes: multi-bucket k-mers are rare, a small grid starts and ends quickly; many: one k-mer in eight takes this path)
+    unsigned b_gen = (unsigned)std::min<size_t>(a.ix.n_files >= 8 ? kFinGeneralBlocks : kFinGeneralBlocks / 4, 256 * std::max<size_t>(1, (160u * 1024u) / lds));
     a.row_general = (int)(b_var + b_ex);
     hipLaunchKernelGGL(finalize_general_kernel, dim3(b_gen), dim3(64), lds, stream, a);
-    if (a.partials) {
+    if (a.partials && a.mode != 2) {
         const int cols = a.ix.n_files * 3 + 2;
         hipLaunchKernelGGL(finalize_reduce_kernel, dim3((unsigned)cols), dim3(256), 0, stream, a, (int)(b_var + b_ex + b_gen));
     }

@@ -35,11 +35,12 @@ def _check(rc, L=None):
 
 
 def Params(n_fixed=2, use_full_kmer=False, ci=3, cs=1000000, cx=1000000000, device=0, full_kmer_stats=False,
-           kmer_table_log2=None):
+           kmer_table_log2=None, pileup_selected_only=False):
     p = _ffi.Params()
     _ffi.load().bk_params_default(C.byref(p))
     p.n_fixed, p.use_full_kmer, p.ci, p.cs, p.cx, p.device = n_fixed, int(use_full_kmer), ci, cs, cx, device
     p.full_kmer_stats = int(full_kmer_stats)
+    p.pileup_selected_only = int(pileup_selected_only)
     if kmer_table_log2 is not None:
         p.kmer_table_log2 = kmer_table_log2
     return p

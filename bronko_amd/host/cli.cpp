@@ -388,6 +388,7 @@ int run_call(const Args& a) {
         bk_params p;
         bk_params_default(&p);
         p.n_fixed = (int32_t)a.n_fixed; p.use_full_kmer = a.use_full_kmer ? 1 : 0; p.ci = (uint64_t)a.min_kmers;
+        p.pileup_selected_only = 1;   // calls, pileup TSV and overview read the selected genome's rows only (call.rs:229-293)
         p.full_kmer_stats = 1;   // KMC's "unique counted k-mers" feeds num_unmapped_kmers and the <0.2 warning (call.rs:242-248)
         if (const char* tl = getenv("BRONKO_KMER_TABLE_LOG2")) p.kmer_table_log2 = (uint32_t)atoi(tl);
         p.device = device;

@@ -82,7 +82,11 @@ typedef struct {
                                 are exact; 0 (default): only index-touching k-mers are counted (pileups identical) */
     uint32_t kmer_table_log2;/* initial capacity of that table = 2^kmer_table_log2 slots (default 26); it is rehashed into a
                                 larger one whenever a batch might take its load above one half (up to 2^31 slots)          */
-    uint32_t reserved;
+    uint32_t pileup_selected_only;/* 1: with several genome files, map_kmers' votes are cast for the SELECTED genome only (two passes:
+                                per-genome statistics of all genomes, pick_best_genome on the device, then the votes): the
+                                statistics and the selected genome's pileup rows are what the reference computes, the rows of
+                                the other genomes stay zero -- nothing downstream of call.rs:229-235 reads them.  0 (default):
+                                every genome's rows, as call.rs:1305-1384 fills them */
 } bk_params;
 
 typedef struct bk_engine bk_engine;

@@ -671,3 +671,40 @@ def test_config5_hundred_strains_k31(oracle, sars_paths):
     assert oracle.pick_best_genome(ix, pile.stats.sum(axis=0), pile.present.max(axis=0)) == 7
     eng.close()
     ix.close()
+
+
+def test_votes_for_the_selected_genome_only(oracle, sars_paths):
+    """bk_params.pileup_selected_only (what `bronko call` runs with): two finalize passes -- statistics of every genome, the genome
+    picked on the device, then votes for that genome alone.  Statistics, presence flags and the selected genome's rows equal the
+    oracle's; every other genome's rows stay zero.  Four SARS-CoV-2 strains (k = 21, paired) and twelve HPV16 strains (k = 31)."""
+    from bronko_amd import Params
+    cases = []
+    ix = oracle.Index.build(21, sars_paths)
+    gm, isnv = synth.sample_genome(synth.read_fasta_bytes(sars_paths[1]), 71)
+    c1, c2 = synth.paired_codes(gm, 20000, 150, 71, isnv=isnv)
+    cases.append((ix, [synth.codes_to_ascii(c1), synth.codes_to_ascii(c2)], 21, 1))
+    files = _mutated_strains(synth.read_fasta_bytes(os.path.join(helpers.GOLDEN, "HPV16.fa")), 12, 60, 90)
+    ix2 = oracle.Index.build_mem(31, files)
+    gm, isnv = synth.sample_genome(files[5][1][0][1], 72)
+    cases.append((ix2, [synth.codes_to_ascii(synth.single_end_codes(gm, 15000, 150, 72, isnv=isnv))], 31, 5))
+    for ix, mates, k, want in cases:
+        pile = oracle.sample_pileup(ix, mates)
+        best = oracle.pick_best_genome(ix, pile.stats.sum(axis=0), pile.present.max(axis=0))
+        assert best == want
+        eng = helpers.engine_from_oracle_index(ix, Params(pileup_selected_only=True))
+        for rep in range(2):
+            res = helpers.hip_sample(eng, mates, k)
+            assert np.array_equal(res.stats, pile.stats) and np.array_equal(res.present, pile.present)
+            lo, n = ix.genome_cells(best)
+            for name in ("fwd_depth", "rev_depth", "fwd_nk", "rev_nk"):
+                got, ref = getattr(res, name), getattr(pile, name)
+                assert np.array_equal(got[lo * 4:(lo + n) * 4], ref[lo * 4:(lo + n) * 4]), name
+                assert not got[:lo * 4].any() and not got[(lo + n) * 4:].any(), name
+        # ... and the device's calls on those rows are the oracle's
+        recs, out, nrec, nmaj, nmin, breadth, depth = oracle.call_variants(ix, best, pile, oracle.default_call_params(k))
+        eng.sample_call(len(mates))
+        summ, drecs = eng.download_calls()
+        assert (summ.file_id, summ.n_records, summ.n_major, summ.n_minor) == (best, nrec, nmaj, nmin)
+        oracle.lib().orc_free(out)
+        eng.close()
+        ix.close()

@@ -10,7 +10,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bronko_amd import Params, synth  # noqa: E402
+from bronko_amd import Params, synth, _ffi  # noqa: E402
+if os.environ.get("BK_L2_STATS"):
+    _ffi.use_testing_library(True)
 from bronko_amd.hostlib import HostIndex  # noqa: E402
 
 n_strains = int(sys.argv[1]) if len(sys.argv) > 1 else 30

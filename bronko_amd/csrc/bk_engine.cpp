@@ -282,6 +282,8 @@ struct bk_engine {
     // multi-genome indexes: the LDS window (difference array + Level 1's arrays) sits on the genome the sample looks like
     DevBuf<uint32_t> occ;                   // [n_full][n_files] first occurrence of each reference k-mer in each genome file
     DevBuf<unsigned int> win_votes;         // [n_files]
+    DevBuf<uint32_t> win_sel;               // {win_file, win_lo} of the current sample, chosen on the device
+    DevBuf<uint32_t> file_cell_lo_d;        // [n_files] (shared by forks)
     std::vector<uint32_t> file_cell_lo;     // first cell of each genome file
     uint32_t win_lo = 0;
     int win_file = 0;
@@ -357,7 +359,7 @@ static int alloc_sample_state(bk_engine* e) {
     BK_HIP(e->present.alloc((size_t)2 * e->n_files));
     BK_HIP(e->kstats.alloc(8));
     BK_HIP(e->slabs.alloc((size_t)e->n_cus * std::max<uint32_t>(e->n_lds_bins, 1)));
-    if (e->n_files > 1) BK_HIP(e->win_votes.alloc((size_t)e->n_files));
+    if (e->n_files > 1) { BK_HIP(e->win_votes.alloc((size_t)e->n_files)); BK_HIP(e->win_sel.upload(std::vector<uint32_t>(2, 0u))); }
     BK_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
     return BK_OK;
@@ -983,6 +985,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 }
             }
             BK_HIP(e->occ.upload(h_occ));
+            BK_HIP(e->file_cell_lo_d.upload(e->file_cell_lo));
         }
         {
             std::vector<uint8_t> h_amb2(h_amb);
@@ -1152,7 +1155,7 @@ int bk_engine_fork(const bk_engine* parent, bk_engine** out) {
     e->half_hi.pilots.alias(p->half_hi.pilots); e->half_hi.dir.alias(p->half_hi.dir); e->half_hi.cand.alias(p->half_hi.cand);
     e->slot_of.alias(p->slot_of); e->estat_off.alias(p->estat_off); e->estat.alias(p->estat); e->slot_rec.alias(p->slot_rec); e->amb.alias(p->amb);
     e->pilots.alias(p->pilots); e->table.alias(p->table); e->ent_off.alias(p->ent_off); e->ent_len.alias(p->ent_len); e->entries.alias(p->entries);
-    e->occ.alias(p->occ);
+    e->occ.alias(p->occ); e->file_cell_lo_d.alias(p->file_cell_lo_d);
     e->genome_len.alias(p->genome_len); e->seq_cell.alias(p->seq_cell); e->seq_len_d.alias(p->seq_len_d); e->seq_first.alias(p->seq_first);
     e->n_seqs_d.alias(p->n_seqs_d); e->max_seqs_per_file = p->max_seqs_per_file; e->max_file_cells = p->max_file_cells;
     if (int rc = alloc_sample_state(e.get())) return rc;
@@ -1298,22 +1301,18 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
         return note_ktab_fill(e);
     }
     if (e->occ.p && !e->win_chosen && n > 0) {
-        // first records of the sample vote for the genome they look like (one synchronisation per sample); the LDS window
-        // goes on that genome and stays there for the sample.  Any choice gives the same counts -- this is about speed.
-        a.win_file = 0; a.win_lo = 0;
+        // first records of the sample vote for the genome they look like; the LDS window goes on that genome and stays there for
+        // the sample.  Vote and choice are made on the device (the scan reads the window from device memory): no host round trip
+        // between a sample's first push and its scan.  Any choice gives the same counts -- this is about speed.
+        a.win_file = 0; a.win_lo = 0; a.win_dev = nullptr;
         BK_HIP(hipMemsetAsync(e->win_votes.p, 0, e->win_votes.n * sizeof(unsigned int), e->stream));
-        bk::launch_pick_window(a, 16384, e->win_votes.p, e->stream);
-        std::vector<unsigned int> votes(e->win_votes.n);
-        BK_HIP(hipMemcpyAsync(votes.data(), e->win_votes.p, votes.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));
-        BK_HIP(hipStreamSynchronize(e->stream));
-        int best = 0;
-        for (int f = 1; f < e->n_files; f++) if (votes[f] > votes[best]) best = f;
-        if (const char* wf = test_env("BK_WINDOW_FILE")) best = std::max(0, std::min(e->n_files - 1, atoi(wf)));   // testing aid
-        e->win_file = best;
-        e->win_lo = e->file_cell_lo[best] & ~31u;
+        int forced = -1;
+        if (const char* wf = test_env("BK_WINDOW_FILE")) forced = std::max(0, atoi(wf));   // testing aid
+        bk::launch_pick_window(a, 16384, e->win_votes.p, e->file_cell_lo_d.p, forced, e->win_sel.p, e->stream);
         e->win_chosen = true;
     }
-    a.win_file = e->win_file; a.win_lo = e->occ.p ? e->win_lo : 0u;
+    a.win_file = 0; a.win_lo = 0;
+    a.win_dev = e->occ.p ? e->win_sel.p : nullptr;
     // a launch takes at most scan_max_records records (bound on what one workgroup's 16-bit LDS bins can receive), and no
     // more than keeps Level 2's bitmap below 1 GiB
     a.l2_words = bk::scan_l2_words(stride_words, e->k);
@@ -1358,7 +1357,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
             else BK_HIP(bk::launch_level2(a, e->n_cus, e->stream));
             // per-cell bin slabs -> u64 plane
             bk::FoldArgs f{};
-            f.slabs = e->slabs.p; f.n_slabs = grid; f.n_lds_bins = e->n_lds_bins; f.id_at = e->id_at.p; f.cell_codes = e->cell_codes.p + bk::scan_ref_pad_words(); f.win_lo = a.win_lo;
+            f.slabs = e->slabs.p; f.n_slabs = grid; f.n_lds_bins = e->n_lds_bins; f.id_at = e->id_at.p; f.cell_codes = e->cell_codes.p + bk::scan_ref_pad_words(); f.win_lo = a.win_lo; f.win_dev = a.win_dev;
             f.counters = e->counters[mate].p;
             bk::launch_fold(f, e->stream);
         }

@@ -37,6 +37,7 @@ struct ScanArgs {
     uint32_t l2_words;              // = scan_l2_words(stride_words, k)
     uint32_t n_lds_bins;            // exact hits at cells [win_lo, win_lo + n_lds_bins) are counted in LDS
     uint32_t win_lo;                // first cell of that window (a multiple of 32): the genome the sample looks like
+    const uint32_t* win_dev;        // multi-genome index: {win_file, win_lo} chosen on the device per sample (overrides the two fields)
     const uint32_t* occ;            // [n_full][n_files] cell | rc << 31 of the k-mer's first occurrence in each genome file
                                     // (0xffffffff: none), or null; with win_file, seeds land on that genome's copy of a k-mer
     int32_t win_file, n_files;
@@ -86,6 +87,7 @@ struct FoldArgs {
     uint32_t n_lds_bins;
     const uint32_t* id_at;          // cell -> id (bins are per cell)
     uint32_t win_lo;                // slab cell i is cell win_lo + i
+    const uint32_t* win_dev;        // ... or {win_file, win_lo} chosen on the device
     const uint32_t* cell_codes;     // IndexView::cell_codes + its front padding: symbol 0 = cell 0
     unsigned long long* counters;
 };
@@ -103,7 +105,8 @@ struct PackArgs {
 };
 void launch_pack_reads(const PackArgs& a, hipStream_t stream);
 // votes[f] += number of the first records' middle k-mers that occur in genome file f (which genome does the sample look like?)
-void launch_pick_window(const ScanArgs& a, uint64_t n_probe, unsigned int* votes, hipStream_t stream);
+void launch_pick_window(const ScanArgs& a, uint64_t n_probe, unsigned int* votes, const uint32_t* file_cell_lo, int forced, uint32_t* win,
+                        hipStream_t stream);
 void launch_count_kmers(const ScanArgs& a, hipStream_t stream);   // empty window: kmer_total += k-mer occurrences, nothing else
 void launch_add_u64(unsigned long long* dst, const unsigned long long* src, hipStream_t stream);   // *dst += *src
 void launch_add_const_u64(unsigned long long* dst, unsigned long long v, hipStream_t stream);        // *dst += v

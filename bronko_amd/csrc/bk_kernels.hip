@@ -456,7 +456,9 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     const uint32_t total = a.total_cells;
     // Level 1 only ever looks at cells below n_lds_bins (a read whose diagonal leaves them goes to Level 2 as a whole), so
     // that is all the LDS copies of the per-cell arrays hold: front pad, the first n_lds_bins cells, back pad
-    const uint32_t win_lo = a.win_lo;
+    // the LDS window: chosen on the device for a multi-genome index (choose_window_kernel), else the engine's constant
+    const uint32_t win_lo = a.win_dev ? a.win_dev[1] : a.win_lo;
+    const uint32_t win_file = a.win_dev ? a.win_dev[0] : (uint32_t)a.win_file;
     const uint32_t lds_cells = min(total - win_lo, a.n_lds_bins);
     const uint32_t n_refw = kRefPadWords + (lds_cells + 15) / 16 + kRefBackWords;
     const uint32_t n_bitw = kBitPadWords + (lds_cells + 31) / 32 + kBitBackWords;
@@ -547,7 +549,9 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
         dg = 0;
         // round 0: kSeeds k-mers evenly spaced from the first to the last; round 1, only when some lane found nothing (an
         // error in every seed: one read in 10^4 at 0.5 % errors): the midpoints between them.  A read without a diagonal costs
-        // ~100 slow-path searches, so the rare second round pays.
+        // ~100 slow-path searches, so the rare second round pays.  (Two seeds per round and more rounds -- 2.95 lookups per read
+        // instead of 4.02 -- was measured in round 2 and is slower, 0.155 against 0.139 ms: half of the tiles then pay a second
+        // chain of dependent loads; the seeds are latency, not instructions.)
         for (int round = 0; round < 2 && maxlen; ++round) {
             if (round == 1 && !__ballot(len != 0u && !seeded)) break;
             const bool had = seeded;   // round 1 is for the lanes round 0 left without a diagonal
@@ -579,7 +583,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 shit[sq] = len && !had && ((uint64_t)se[sq].x | ((uint64_t)se[sq].y << 32)) == sc[sq];
                 soc[sq] = 0xffffffffu;
                 if (a.occ && shit[sq] && (se[sq].w & kIdMask) < ix.n_full)
-                    soc[sq] = a.occ[(size_t)(se[sq].w & kIdMask) * (uint32_t)a.n_files + (uint32_t)a.win_file];
+                    soc[sq] = a.occ[(size_t)(se[sq].w & kIdMask) * (uint32_t)a.n_files + win_file];
             }
             uint32_t best_cell = 0xffffffffu;
 #pragma unroll
@@ -812,11 +816,16 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 const uint32_t VAL32 = (hi >= 32u ? 0xffffffffu : (1u << hi) - 1u) & (lo >= 32u ? 0u : ~((1u << lo) - 1u));
                 // A: some mismatch among the k bases that end at step b.  The flag of base i0 + b - t sits at bit 32 + b - t of
                 // (h_hi : h_lo)
-                uint32_t A = h_hi;
-                if (KT) {
-#pragma unroll
-                    for (int t = 1; t < (KT ? KT : 2); ++t) A |= __builtin_amdgcn_alignbit(h_hi, h_lo, (uint32_t)(32 - t));
+                uint32_t A;
+                if (KT >= 16) {
+                    // OR of the flags of the k bases that end at each step = the upper half of OR_{t<k} (H << t): by doubling,
+                    // t < 2, 4, 8, 16, then one more shift by k - 16 (five 64-bit shift-or steps instead of k - 1 funnel shifts)
+                    unsigned long long Y = ((unsigned long long)h_hi << 32) | h_lo;
+                    Y |= Y << 1; Y |= Y << 2; Y |= Y << 4; Y |= Y << 8;
+                    Y |= Y << (KT - 16);
+                    A = (uint32_t)(Y >> 32);
                 } else {
+                    A = h_hi;
                     for (int t = 1; t < k; ++t) A |= __builtin_amdgcn_alignbit(h_hi, h_lo, (uint32_t)(32 - t));
                 }
                 E32 = ~A & HAS32 & VAL32;
@@ -1149,8 +1158,20 @@ __global__ __launch_bounds__(256) void pick_window_kernel(ScanArgs a, uint64_t n
         for (int f = 0; f < a.n_files; ++f) if (oc[f] != 0xffffffffu) atomicAdd(votes + f, 1u);
     }
 }
-void launch_pick_window(const ScanArgs& a, uint64_t n_probe, unsigned int* votes, hipStream_t stream) {
+// ... and the choice itself, on the device (no host round trip between a sample's first push and its scan): the genome with the
+// most votes (lowest id on ties), its first cell rounded down to a multiple of 32; `forced` >= 0 overrides (testing build)
+__global__ void choose_window_kernel(const unsigned int* votes, int n_files, const uint32_t* file_cell_lo, int forced, uint32_t* win) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int best = 0;
+    for (int f = 1; f < n_files; ++f) if (votes[f] > votes[best]) best = f;
+    if (forced >= 0) best = forced < n_files ? forced : n_files - 1;
+    win[0] = (uint32_t)best;
+    win[1] = file_cell_lo[best] & ~31u;
+}
+void launch_pick_window(const ScanArgs& a, uint64_t n_probe, unsigned int* votes, const uint32_t* file_cell_lo, int forced, uint32_t* win,
+                        hipStream_t stream) {
     hipLaunchKernelGGL(pick_window_kernel, dim3(64), dim3(256), 0, stream, a, n_probe, votes);
+    hipLaunchKernelGGL(choose_window_kernel, dim3(1), dim3(64), 0, stream, votes, a.n_files, file_cell_lo, forced, win);
 }
 
 // Empty window (n_fixed * 2 + 1 >= k, call.rs:1291-1300): no k-mer can touch the index.  KMC's total is still wanted, and with
@@ -1258,7 +1279,7 @@ __global__ __launch_bounds__(256) void fold_kernel(FoldArgs f) {
             s1 += v >> 16;
         }
         if (s0 | s1) {
-            const uint64_t cell = f.win_lo + i;
+            const uint64_t cell = (f.win_dev ? f.win_dev[1] : f.win_lo) + i;
             const uint32_t id = f.id_at[cell];   // a counted cell always has a reference k-mer
             const uint32_t rc = ((f.cell_codes[cell >> 4] >> (2 * (cell & 15))) & 3u) == 2u ? 1u : 0u;
             if (s0) atomicAdd(f.counters + 2 * (size_t)id + rc, s0);

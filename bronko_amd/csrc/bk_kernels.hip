@@ -1140,6 +1140,9 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
 // Which genome does the sample look like?  One k-mer (the middle one) of each of the first records: votes[f] += 1 for every
 // genome file the k-mer occurs in.  The engine puts the LDS window on the genome with the most votes.
 __global__ __launch_bounds__(256) void pick_window_kernel(ScanArgs a, uint64_t n_probe, unsigned int* votes) {
+    extern __shared__ unsigned int lvotes[];   // [n_files] this workgroup's tallies (thousands of k-mers vote for the same few genomes)
+    for (int f = threadIdx.x; f < a.n_files; f += 256) lvotes[f] = 0u;
+    __syncthreads();
     const IndexView& ix = *a.ixp;
     uint64_t n_records = a.n_records;
     if (a.n_records_dev) n_records = min((uint64_t)*a.n_records_dev, a.n_records);
@@ -1155,8 +1158,10 @@ __global__ __launch_bounds__(256) void pick_window_kernel(ScanArgs a, uint64_t n
         const uint4 e = *reinterpret_cast<const uint4*>(ix.kmer_pos + phf_pos(c, ix.pilots[phf_bucket(c, ix.log2nb)], ix.m));
         if (((uint64_t)e.x | ((uint64_t)e.y << 32)) != c || (e.w & kIdMask) >= ix.n_full) continue;
         const uint32_t* oc = a.occ + (size_t)(e.w & kIdMask) * (uint32_t)a.n_files;
-        for (int f = 0; f < a.n_files; ++f) if (oc[f] != 0xffffffffu) atomicAdd(votes + f, 1u);
+        for (int f = 0; f < a.n_files; ++f) if (oc[f] != 0xffffffffu) atomicAdd(&lvotes[f], 1u);
     }
+    __syncthreads();
+    for (int f = threadIdx.x; f < a.n_files; f += 256) if (lvotes[f]) atomicAdd(votes + f, lvotes[f]);
 }
 // ... and the choice itself, on the device (no host round trip between a sample's first push and its scan): the genome with the
 // most votes (lowest id on ties), its first cell rounded down to a multiple of 32; `forced` >= 0 overrides (testing build)
@@ -1170,7 +1175,7 @@ __global__ void choose_window_kernel(const unsigned int* votes, int n_files, con
 }
 void launch_pick_window(const ScanArgs& a, uint64_t n_probe, unsigned int* votes, const uint32_t* file_cell_lo, int forced, uint32_t* win,
                         hipStream_t stream) {
-    hipLaunchKernelGGL(pick_window_kernel, dim3(64), dim3(256), 0, stream, a, n_probe, votes);
+    hipLaunchKernelGGL(pick_window_kernel, dim3(64), dim3(256), (size_t)a.n_files * sizeof(unsigned int), stream, a, n_probe, votes);
     hipLaunchKernelGGL(choose_window_kernel, dim3(1), dim3(64), 0, stream, votes, a.n_files, file_cell_lo, forced, win);
 }
 

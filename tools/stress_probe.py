@@ -14,10 +14,10 @@ eng = ix.engine(Params())
 dev = torch.device("cuda", 0)
 gm, isnv = synth.sample_genome(ref, 2)
 def run(tag, codes):
-    w, l = synth.pack_codes(codes)
-    dw = torch.from_numpy(w.view(np.int32)).to(dev); dl = torch.from_numpy(l.view(np.int16)).to(dev)
+    dw, dl = synth.pack_codes_torch(codes)
+    torch.cuda.synchronize()
     def step():
-        eng.sample_begin(); eng.push_reads_device(0, dw.data_ptr(), w.shape[1], dl.data_ptr(), len(l)); eng.sample_finalize(1)
+        eng.sample_begin(); eng.push_reads_device(0, dw.data_ptr(), dw.shape[1], dl.data_ptr(), dl.numel()); eng.sample_finalize(1)
     for _ in range(3): step()
     torch.cuda.synchronize()
     eng.timing_enable(1); eng.timing_read(reset=True)
@@ -26,14 +26,14 @@ def run(tag, codes):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 10
     ms, n = eng.timing_read(reset=True); eng.timing_enable(0)
-    print("%-34s %7.3f ms/sample  %6.2f G bases/s   scan %.3f finalize %.3f" % (tag, dt * 1e3, codes.size / dt / 1e9, ms[0] / 10, ms[1] / 10), flush=True)
+    print("%-34s %7.3f ms/sample  %6.2f G bases/s   scan %.3f finalize %.3f" % (tag, dt * 1e3, codes.numel() / dt / 1e9, ms[0] / 10, ms[1] / 10), flush=True)
 N = 500000
-run("150 bp, 0.5 % errors", synth.single_end_codes(gm, N, 150, 5, err=0.005, isnv=isnv))
-run("150 bp, 2 % errors", synth.single_end_codes(gm, N, 150, 5, err=0.02, isnv=isnv))
-run("150 bp, 5 % errors", synth.single_end_codes(gm, N, 150, 5, err=0.05, isnv=isnv))
-run("250 bp, 0.5 % errors", synth.single_end_codes(gm, N * 150 // 250, 250, 5, err=0.005, isnv=isnv))
-run("1000 bp, 1 % errors", synth.single_end_codes(gm, N * 150 // 1000, 1000, 5, err=0.01, isnv=isnv))
-rnd = (synth.splitmix64(99, N * 150) & np.uint64(3)).astype(np.uint8).reshape(N, 150)
+run("150 bp, 0.5 % errors", synth.single_end_codes_torch(gm, N, 150, 5, err=0.005, isnv=isnv, device=dev))
+run("150 bp, 2 % errors", synth.single_end_codes_torch(gm, N, 150, 5, err=0.02, isnv=isnv, device=dev))
+run("150 bp, 5 % errors", synth.single_end_codes_torch(gm, N, 150, 5, err=0.05, isnv=isnv, device=dev))
+run("250 bp, 0.5 % errors", synth.single_end_codes_torch(gm, N * 150 // 250, 250, 5, err=0.005, isnv=isnv, device=dev))
+run("1000 bp, 1 % errors", synth.single_end_codes_torch(gm, N * 150 // 1000, 1000, 5, err=0.01, isnv=isnv, device=dev))
+rnd = (synth._t_splitmix64(99, N * 150, dev) & 3).reshape(N, 150)
 run("150 bp, random (not the reference)", rnd)
-mix = synth.single_end_codes(gm, N, 150, 5, err=0.005, isnv=isnv); mix[::2] = rnd[::2]
+mix = synth.single_end_codes_torch(gm, N, 150, 5, err=0.005, isnv=isnv, device=dev); mix[::2] = rnd[::2]
 run("150 bp, half random", mix)

@@ -19,7 +19,7 @@ out = {"build_id": bench.source_build_id(), "config": 2, "workload_reads": 10000
        "traffic_bytes_per_launch": scan_h["hbm_read_bytes"] + scan_h["hbm_write_bytes"],
        "valu_wave_insts_per_launch": scan_s.get("SQ_INSTS_VALU"), "salu_wave_insts_per_launch": scan_s.get("SQ_INSTS_SALU"),
        "lds_wave_insts_per_launch": scan_s.get("SQ_INSTS_LDS"), "waves_per_launch": scan_s.get("SQ_WAVES"),
-       "captured": "profiles/r02_%s_pmc_hbm.json / _pmc_sq.json (tools/profile_round.sh, one sample at a time)" % sys.argv[3],
+       "captured": "gpurun_out/%s_pmc_hbm.json / _pmc_sq.json (tools/profile_round.sh %s, one sample at a time)" % (sys.argv[3], sys.argv[3]),
        "all_kernels_hbm_bytes_per_launch": {k.split("(")[0][-60:]: v.get("hbm_read_bytes", 0) + v.get("hbm_write_bytes", 0) for k, v in hbm.items()}}
 json.dump(out, sys.stdout, indent=1)
 print()

@@ -4,4 +4,4 @@ The product is the C-ABI library `libbronko_hip.so` (include/bronko_hip.h) plus 
 bronko_amd/host/.  This Python package is a thin ctypes mirror of that ABI used by tests and bench.py; it
 has no compute of its own and fails loudly if the HIP library is missing.
 """
-from .engine import BronkoError, Engine, Params, lib_path, pack_reads  # noqa: F401
+from .engine import BronkoError, Engine, Params, build_index_device, lib_path, pack_reads  # noqa: F401

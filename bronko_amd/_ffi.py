@@ -43,13 +43,19 @@ class CallSummary(C.Structure):  # bk_call_summary
                 ("covered", C.c_uint64), ("positions", C.c_uint64), ("coverage", C.c_uint64)]
 
 
+class BuiltIndex(C.Structure):  # bk_built_index
+    _fields_ = [("n_buckets", C.c_uint64), ("n_entries", C.c_uint64), ("bucket_ids", C.c_void_p), ("bucket_off", C.c_void_p),
+                ("entries", C.c_void_p)]
+
+
 # every symbol include/bronko_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = ["bk_abi_version", "bk_device_count", "bk_last_error", "bk_params_default", "bk_engine_create", "bk_engine_destroy", "bk_engine_fork", "bk_engine_get_stream",
            "bk_engine_set_stream", "bk_total_cells", "bk_n_files", "bk_n_slots", "bk_counter_len", "bk_sample_begin",
            "bk_push_reads_packed", "bk_push_reads_packed_device", "bk_push_reads_ascii", "bk_counters_device_ptr", "bk_sample_finalize",
            "bk_sample_finalize_shard", "bk_shard_sums_device_ptr", "bk_sample_merge_shards",
            "bk_pileup_device_ptr", "bk_sample_download", "bk_sample_finish", "bk_pack_reads", "bk_pack_reads_flat",
-           "bk_timing_enable", "bk_timing_read", "bk_call_params_default", "bk_sample_call", "bk_sample_download_calls"]
+           "bk_timing_enable", "bk_timing_read", "bk_call_params_default", "bk_sample_call", "bk_sample_download_calls",
+           "bk_build_index", "bk_built_index_free", "bk_build_last_error"]
 
 _libs = {}
 _testing = False
@@ -121,6 +127,10 @@ def load(testing=None):
     L.bk_sample_call.argtypes = [vp, C.c_int, C.POINTER(CallParams)]
     L.bk_sample_download_calls.restype = C.c_int
     L.bk_sample_download_calls.argtypes = [vp, C.POINTER(CallSummary), vp, u64]
+    L.bk_build_index.restype = C.c_int
+    L.bk_build_index.argtypes = [i32, i32, vp, vp, vp, i32, C.POINTER(BuiltIndex)]
+    L.bk_built_index_free.argtypes = [C.POINTER(BuiltIndex)]
+    L.bk_build_last_error.restype = C.c_char_p
     L.bk_timing_enable.restype = C.c_int
     L.bk_timing_enable.argtypes = [vp, C.c_int]
     L.bk_timing_read.restype = C.c_int

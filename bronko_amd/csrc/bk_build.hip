@@ -1,0 +1,149 @@
+// bk_build.hip -- build_indexes (/root/reference/src/build.rs:145-231) on the device.
+//
+// The reference walks every k-mer of every sequence, canonicalises it, computes its k bucket ids (assign_buckets, lcb.rs:1-45)
+// and appends a BucketInfo to each bucket's list (build.rs:191-204); the lists of the files are concatenated in file order
+// (build.rs:223-228).  So a bucket's list is ordered by (file, sequence, location) -- the order in which the pairs are generated
+// when the k-mers are taken in (file, sequence, location) order.  Here: one thread per k-mer writes its k (bucket id, BucketInfo)
+// pairs at their place in that generation order, a STABLE radix sort by bucket id (rocPRIM, a plain library sort) groups them
+// without disturbing the order inside a bucket, and the host cuts the sorted run into buckets while it copies it out.  100 strains
+// at k = 31 (93 M pairs): well under a second against 5 s on 32 host threads.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "../../include/bronko_hip.h"
+#include "../host/lcb.hpp"
+
+namespace {
+
+struct SeqRow { unsigned long long byte_off, len, kmer_off; unsigned int file, seq; };   // kmer_off: k-mers of the sequences before it
+
+// pair value: file << 46 | seq << 38 | location << 6 | idx << 1 | canonical
+__global__ __launch_bounds__(256) void gen_pairs_kernel(const unsigned char* __restrict__ bases, const SeqRow* __restrict__ rows, int n_rows,
+                                                        unsigned long long n_kmers, int k, unsigned long long* __restrict__ keys,
+                                                        unsigned long long* __restrict__ vals) {
+    for (unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x; g < n_kmers; g += (unsigned long long)gridDim.x * 256) {
+        int lo = 0, hi = n_rows - 1;                 // the last sequence whose k-mers start at or before g
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (rows[mid].kmer_off <= g) lo = mid; else hi = mid - 1;
+        }
+        const SeqRow r = rows[lo];
+        const unsigned long long i = g - r.kmer_off;                              // location of the k-mer in its sequence
+        const unsigned char* s = bases + r.byte_off + i;
+        unsigned long long fwd = 0;
+        for (int t = 0; t < k; ++t) fwd = (fwd << 2) | bronko::nt_to_bits(s[t]);  // kmer_to_u64 (lcb.rs:67-74; non-ACGT -> A)
+        const bronko::Canon c = bronko::canonical_u64(fwd, k);                    // build.rs:193
+        unsigned long long ids[32];
+        bronko::assign_buckets(c.kmer, k, reinterpret_cast<uint64_t*>(ids));      // build.rs:194
+        const unsigned long long base = ((unsigned long long)r.file << 46) | ((unsigned long long)r.seq << 38) | (i << 6) | (c.rc ? 1ull : 0ull);
+        for (int j = 0; j < k; ++j) {                                             // build.rs:196-204
+            keys[g * (unsigned long long)k + j] = ids[j];
+            vals[g * (unsigned long long)k + j] = base | ((unsigned long long)j << 1);
+        }
+    }
+}
+
+thread_local char g_build_err[512];
+
+}  // namespace
+
+extern "C" {
+
+const char* bk_build_last_error(void) { return g_build_err; }
+
+void bk_built_index_free(bk_built_index* ix) {
+    if (!ix) return;
+    free(ix->bucket_ids); free(ix->bucket_off); free(ix->entries);
+    ix->bucket_ids = nullptr; ix->bucket_off = nullptr; ix->entries = nullptr; ix->n_buckets = ix->n_entries = 0;
+}
+
+int bk_build_index(int32_t k, int32_t n_files, const int32_t* n_seqs, const uint64_t* seq_lens, const uint8_t* const* seqs, int32_t device,
+                   bk_built_index* out) {
+#define BB_FAIL(code, ...) do { snprintf(g_build_err, sizeof g_build_err, __VA_ARGS__); return (code); } while (0)
+#define BB_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); BB_FAIL(BK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    if (!out || !n_seqs || (n_files > 0 && (!seq_lens || !seqs))) BB_FAIL(BK_ERR_INVALID, "null argument");
+    std::memset(out, 0, sizeof *out);
+    if (k < 3 || k > 31 || (k & 1) == 0) BB_FAIL(BK_ERR_INVALID, "Invalid kmer size %d", k);
+    if (n_files < 0 || n_files > 65536) BB_FAIL(BK_ERR_INVALID, "n_files out of range (file_id is u16)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) BB_FAIL(BK_ERR_NO_DEVICE, "no HIP device %d", device);
+    unsigned char* d_bases = nullptr; SeqRow* d_rows = nullptr;
+    unsigned long long *d_k0 = nullptr, *d_k1 = nullptr, *d_v0 = nullptr, *d_v1 = nullptr; void* d_tmp = nullptr;
+    auto cleanup = [&] { (void)hipFree(d_bases); (void)hipFree(d_rows); (void)hipFree(d_k0); (void)hipFree(d_k1); (void)hipFree(d_v0); (void)hipFree(d_v1); (void)hipFree(d_tmp); };
+    (void)hipSetDevice(device);
+
+    std::vector<SeqRow> rows;
+    unsigned long long bytes = 0, n_kmers = 0;
+    size_t sq = 0;
+    for (int f = 0; f < n_files; f++) {
+        if (n_seqs[f] < 0 || n_seqs[f] > 256) BB_FAIL(BK_ERR_INVALID, "file %d: more than 256 sequences (seq_id is u8)", f);
+        for (int s = 0; s < n_seqs[f]; s++, sq++) {
+            const unsigned long long len = seq_lens[sq];
+            if (len >= (1ull << 32)) BB_FAIL(BK_ERR_UNSUPPORTED, "sequence longer than 2^32 (location is u32)");
+            if (len >= (unsigned long long)k) {   // (upstream would panic on a shorter one; nothing to index)
+                rows.push_back(SeqRow{bytes, len, n_kmers, (unsigned)f, (unsigned)s});
+                n_kmers += len - (unsigned long long)k + 1;
+            }
+            bytes += len;
+        }
+    }
+    const unsigned long long n_pairs = n_kmers * (unsigned long long)k;
+    out->bucket_off = (uint64_t*)malloc(sizeof(uint64_t));
+    if (!out->bucket_off) BB_FAIL(BK_ERR_INVALID, "out of memory");
+    out->bucket_off[0] = 0;
+    if (n_pairs == 0) return BK_OK;
+    if (n_pairs >= (1ull << 33)) BB_FAIL(BK_ERR_UNSUPPORTED, "index too large for the device build (%llu pairs)", n_pairs);
+
+    std::vector<unsigned char> h_bases(bytes);
+    {
+        size_t q = 0; unsigned long long at = 0;
+        for (int f = 0; f < n_files; f++) for (int s = 0; s < n_seqs[f]; s++, q++) { std::memcpy(h_bases.data() + at, seqs[q], seq_lens[q]); at += seq_lens[q]; }
+    }
+    BB_HIP(hipMalloc((void**)&d_bases, bytes ? bytes : 1));
+    BB_HIP(hipMalloc((void**)&d_rows, rows.size() * sizeof(SeqRow)));
+    BB_HIP(hipMalloc((void**)&d_k0, n_pairs * 8)); BB_HIP(hipMalloc((void**)&d_k1, n_pairs * 8));
+    BB_HIP(hipMalloc((void**)&d_v0, n_pairs * 8)); BB_HIP(hipMalloc((void**)&d_v1, n_pairs * 8));
+    BB_HIP(hipMemcpy(d_bases, h_bases.data(), bytes, hipMemcpyHostToDevice));
+    BB_HIP(hipMemcpy(d_rows, rows.data(), rows.size() * sizeof(SeqRow), hipMemcpyHostToDevice));
+    const unsigned grid = (unsigned)std::min<unsigned long long>((n_kmers + 255) / 256, 1u << 16);
+    hipLaunchKernelGGL(gen_pairs_kernel, dim3(grid), dim3(256), 0, 0, d_bases, d_rows, (int)rows.size(), n_kmers, (int)k, d_k0, d_v0);
+    BB_HIP(hipGetLastError());
+    size_t tmp_bytes = 0;
+    BB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (size_t)n_pairs, 0, 64, 0));
+    BB_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
+    BB_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (size_t)n_pairs, 0, 64, 0));   // stable: keeps (file, seq, location) inside a bucket
+    BB_HIP(hipDeviceSynchronize());
+    std::vector<unsigned long long> h_k(n_pairs), h_v(n_pairs);
+    BB_HIP(hipMemcpy(h_k.data(), d_k1, n_pairs * 8, hipMemcpyDeviceToHost));
+    BB_HIP(hipMemcpy(h_v.data(), d_v1, n_pairs * 8, hipMemcpyDeviceToHost));
+    cleanup();
+
+    uint64_t nb = 0;
+    for (unsigned long long i = 0; i < n_pairs; i++) nb += (i == 0 || h_k[i] != h_k[i - 1]);
+    free(out->bucket_off);
+    out->bucket_ids = (uint64_t*)malloc(nb * sizeof(uint64_t));
+    out->bucket_off = (uint64_t*)malloc((nb + 1) * sizeof(uint64_t));
+    out->entries = (bk_bucket_info*)calloc(n_pairs, sizeof(bk_bucket_info));   // (padding bytes zero)
+    if (!out->bucket_ids || !out->bucket_off || !out->entries) { bk_built_index_free(out); BB_FAIL(BK_ERR_INVALID, "out of memory"); }
+    uint64_t b = 0;
+    for (unsigned long long i = 0; i < n_pairs; i++) {
+        if (i == 0 || h_k[i] != h_k[i - 1]) { out->bucket_ids[b] = h_k[i]; out->bucket_off[b] = i; b++; }
+        const unsigned long long v = h_v[i];
+        bk_bucket_info& e = out->entries[i];
+        e.file_id = (uint16_t)(v >> 46); e.seq_id = (uint8_t)(v >> 38); e.location = (uint32_t)(v >> 6); e.idx = (uint8_t)((v >> 1) & 31u); e.canonical = (uint8_t)(v & 1u);
+    }
+    out->bucket_off[nb] = n_pairs;
+    out->n_buckets = nb; out->n_entries = n_pairs;
+    return BK_OK;
+#undef BB_HIP
+#undef BB_FAIL
+}
+
+}  // extern "C"

@@ -66,6 +66,30 @@ def pack_reads(reads, k, stride_words=None):
     return words[:n], lens[:n]
 
 
+def build_index_device(k, files, device=0):
+    """bk_build_index: build_indexes (build.rs:145-231) on the GPU.  files = [(file_name, [(seq_name, seq_bytes), ...]), ...];
+    returns (bucket_ids u64[n], bucket_off u64[n + 1], entries BucketInfo[m]) -- what Engine() takes."""
+    L = _ffi.load()
+    n_seqs = np.array([len(f[1]) for f in files] + [0], np.int32)
+    seqs = [bytes(s[1]) for f in files for s in f[1]]
+    seq_lens = np.array([len(s) for s in seqs] + [0], np.uint64)
+    bufs = [C.create_string_buffer(s, max(len(s), 1)) for s in seqs]
+    ptrs = (C.c_void_p * max(len(bufs), 1))(*[C.addressof(b) for b in bufs])
+    out = _ffi.BuiltIndex()
+    rc = L.bk_build_index(k, len(files), n_seqs.ctypes.data, seq_lens.ctypes.data, C.addressof(ptrs), device, C.byref(out))
+    if rc != 0:
+        raise BronkoError(rc, L.bk_build_last_error().decode(errors="replace"))
+    try:
+        nb, ne = out.n_buckets, out.n_entries
+        ids = np.ctypeslib.as_array(C.cast(out.bucket_ids, C.POINTER(C.c_uint64)), shape=(nb,)).copy() if nb else np.zeros(0, np.uint64)
+        off = np.ctypeslib.as_array(C.cast(out.bucket_off, C.POINTER(C.c_uint64)), shape=(nb + 1,)).copy()
+        ent = (np.ctypeslib.as_array(C.cast(out.entries, C.POINTER(C.c_uint8)), shape=(ne * 12,)).copy().view(BUCKET_INFO_DTYPE)
+               if ne else np.zeros(0, BUCKET_INFO_DTYPE))
+    finally:
+        L.bk_built_index_free(C.byref(out))
+    return ids, off, ent
+
+
 class SampleResult:
     """Outputs of one sample: the four OutputData arrays (call.rs:1235-1239,1451-1454) + map_kmers' stats."""
 

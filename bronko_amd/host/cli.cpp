@@ -199,6 +199,43 @@ void check_common(const Args& a, const char* target) {
 }
 
 // ---- bronko build (build.rs:102-120) ------------------------------------------------------------------------
+// build_indexes (build.rs:145-231): on the GPU when one is visible (bk_build_index: one thread per k-mer, stable device sort), on
+// host threads otherwise -- `bronko build` also runs on a machine without a GPU; the result is the same index either way
+// (BRONKO_BUILD_ON_HOST=1 forces the host path).
+Index build_index_any(const char* T, int k, const std::vector<std::string>& genomes, int threads) {
+    std::vector<FileMeta> files = read_genomes(genomes);
+    if (!getenv("BRONKO_BUILD_ON_HOST") && bk_device_count() > 0) {
+        if (files.size() > 65536) throw std::runtime_error("more than 65536 genome files (file_id is u16)");
+        std::vector<int32_t> n_seqs;
+        std::vector<uint64_t> seq_lens;
+        std::vector<const uint8_t*> seqs;
+        for (const auto& f : files) {
+            if (f.sequences.size() > 256) throw std::runtime_error(f.name + ": more than 256 sequences (seq_id is u8)");
+            n_seqs.push_back((int32_t)f.sequences.size());
+            for (const auto& s : f.sequences) { seq_lens.push_back(s.len); seqs.push_back(s.seq.data()); }
+        }
+        if (seqs.empty()) { seq_lens.push_back(0); seqs.push_back(nullptr); }
+        int device = 0;
+        if (const char* dv = getenv("BRONKO_DEVICE")) device = atoi(dv);
+        bk_built_index b{};
+        if (bk_build_index(k, (int32_t)files.size(), n_seqs.data(), seq_lens.data(), seqs.data(), device, &b) == BK_OK) {
+            LOG_TRACE(T, "index built on the GPU: " + std::to_string(b.n_buckets) + " buckets, " + std::to_string(b.n_entries) + " entries");
+            Index ix;
+            ix.k = k; ix.meta_k = k;
+            ix.ids.assign(b.bucket_ids, b.bucket_ids + b.n_buckets);
+            ix.off.assign(b.bucket_off, b.bucket_off + b.n_buckets + 1);
+            ix.entries.resize(b.n_entries);
+            static_assert(sizeof(BucketInfo) == sizeof(bk_bucket_info), "BucketInfo layouts must agree");
+            if (b.n_entries) std::memcpy(ix.entries.data(), b.entries, b.n_entries * sizeof(BucketInfo));
+            bk_built_index_free(&b);
+            ix.files = std::move(files);
+            return ix;
+        }
+        LOG_WARN(T, std::string("GPU index build unavailable (") + bk_build_last_error() + "), building on the host");
+    }
+    return build_indexes_mem(k, std::move(files), threads);
+}
+
 int run_build(const Args& a) {
     const char* T = "bronko::build";
     init_logging(a);
@@ -208,7 +245,7 @@ int run_build(const Args& a) {
     check_common(a, T);
     LOG_INFO(T, "Building indexes from fasta files");
     Index ix;
-    try { ix = build_indexes((int)a.kmer, a.genomes, (int)a.threads); }
+    try { ix = build_index_any(T, (int)a.kmer, a.genomes, (int)a.threads); }
     catch (const std::exception& e) { die(T, std::string(e.what()) + " | Reference failed to build"); }
     const std::string out = a.output + ".bkdb";
     LOG_INFO(T, "Saving index to " + out);
@@ -341,7 +378,7 @@ int run_call(const Args& a) {
     Index ix;
     if (a.has_genomes) {                                            // call.rs:170-178
         LOG_INFO(T, "Creating bronko index from provided reference genomes");
-        try { ix = build_indexes((int)a.kmer, a.genomes, (int)a.threads); }
+        try { ix = build_index_any(T, (int)a.kmer, a.genomes, (int)a.threads); }
         catch (const std::exception& e) { die(T, std::string(e.what()) + " | Reference failed to build"); }
     } else {                                                        // call.rs:179-200
         LOG_INFO(T, "Reading in provided bronko index");

@@ -124,7 +124,7 @@ Index build_indexes_mem(int k, std::vector<FileMeta> files, int threads) {
     return ix;
 }
 
-Index build_indexes(int k, const std::vector<std::string>& genomes, int threads) {
+std::vector<FileMeta> read_genomes(const std::vector<std::string>& genomes) {
     std::vector<FileMeta> files(genomes.size());
     for (size_t f = 0; f < genomes.size(); f++) {
         std::vector<FastaRecord> recs;
@@ -139,7 +139,11 @@ Index build_indexes(int k, const std::vector<std::string>& genomes, int threads)
             files[f].sequences.push_back(std::move(sm));
         }
     }
-    return build_indexes_mem(k, std::move(files), threads);
+    return files;
+}
+
+Index build_indexes(int k, const std::vector<std::string>& genomes, int threads) {
+    return build_indexes_mem(k, read_genomes(genomes), threads);
 }
 
 // ---- .bkdb: bincode 2 standard config = little endian, varint integers ----------------------

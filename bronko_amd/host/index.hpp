@@ -47,6 +47,7 @@ struct Index {
 struct FastaRecord { std::string header; std::vector<uint8_t> seq; };
 std::vector<FastaRecord> read_fasta(const std::string& path);      // throws std::runtime_error
 
+std::vector<FileMeta> read_genomes(const std::vector<std::string>& genomes);       // the FASTA side of build.rs:155-189 (throws)
 Index build_indexes(int k, const std::vector<std::string>& genomes, int threads);  // build.rs:145-231
 Index build_indexes_mem(int k, std::vector<FileMeta> files, int threads);
 void  save_index(const Index& ix, const std::string& path);                          // build.rs:122-143

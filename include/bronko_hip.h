@@ -234,6 +234,23 @@ void bk_call_params_default(bk_call_params* p);
 int  bk_sample_call(bk_engine* e, int n_mates, const bk_call_params* p);
 int  bk_sample_download_calls(bk_engine* e, bk_call_summary* summary, bk_call_record* records, uint64_t cap);
 
+/* ---- build_indexes on the device (optional) -----------------------------------------------------
+ * build.rs:145-231 for the metadata sequences given like bk_index_desc gives them: one thread per k-mer writes its k
+ * (bucket id, BucketInfo) pairs in generation order, a stable device radix sort groups them by bucket id (inside a bucket the
+ * reference's order -- file, sequence, location -- survives), the host cuts the run into buckets.  The result is what
+ * bk_index_desc takes: bucket ids ascending, bucket_off[n_buckets + 1], entries.  Arrays are malloc'ed; release them with
+ * bk_built_index_free.  Message of a failure: bk_build_last_error(). */
+typedef struct {
+    uint64_t n_buckets, n_entries;
+    uint64_t* bucket_ids;
+    uint64_t* bucket_off;
+    bk_bucket_info* entries;
+} bk_built_index;
+int  bk_build_index(int32_t k, int32_t n_files, const int32_t* n_seqs, const uint64_t* seq_lens, const uint8_t* const* seqs,
+                    int32_t device, bk_built_index* out);
+void bk_built_index_free(bk_built_index* ix);
+const char* bk_build_last_error(void);
+
 /* ---- K0: host-side read packer (the step KMC's FASTQ reader performs before counting) ---------------------
  * Splits each ASCII read at every non-ACGT/acgt symbol, drops runs shorter than k, cuts runs longer than
  * 16*stride_words into chunks overlapping by k-1 bases (so every k-mer occurrence is kept exactly once), and

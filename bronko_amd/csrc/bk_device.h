@@ -76,11 +76,14 @@ BK_HD uint32_t hash_key(uint64_t key, uint32_t log2s) {
 // position and a lookup is exactly two loads (pilot, key) with no probe chain -- no lane of a wave waits for
 // another lane's collisions.
 BK_HD uint32_t phf_bucket(uint64_t x, uint32_t log2nb) { return hash_key(x, log2nb); }
-BK_HD uint32_t phf_pos(uint64_t x, uint32_t pilot, uint32_t m) {
+// The table is 2^log2p independent sub-tables of msub positions each (the host builds them on as many threads: 9 M keys of a
+// 100-strain index took 8 s on one); the buckets of sub-table s are the ones whose index starts with s.
+BK_HD uint32_t phf_pos(uint64_t x, uint32_t pilot, uint32_t msub, uint32_t log2nb, uint32_t log2p) {
     // (the pilot enters before the multiplication: two keys whose products agree in the upper half for one pilot part for another)
     uint32_t h = (uint32_t)(((x ^ ((uint64_t)pilot * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull) >> 32);
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    return (uint32_t)(((uint64_t)h * m) >> 32);
+    const uint32_t sub = log2p ? phf_bucket(x, log2nb) >> (log2nb - log2p) : 0u;
+    return sub * msub + (uint32_t)(((uint64_t)h * msub) >> 32);
 }
 
 // Perfect-hash table entry of a reference k-mer: key, where it first occurs in the reference, and its id.
@@ -117,8 +120,9 @@ struct HalfView {
     const uint16_t* pilots;   // [1 << log2nb]
     const HalfDir*  dir;      // [m]
     const NbEntry*  cand;     // reference k-mers sorted by this half
-    uint32_t m;
+    uint32_t m;               // positions per sub-table (phf_pos)
     uint32_t log2nb;
+    uint32_t log2p;           // 2^log2p sub-tables
 };
 
 // Everything the kernels need to know about the index; passed by value.
@@ -173,8 +177,9 @@ struct IndexView {
     const uint32_t*  ent_len;  // [n_slots]
     const DevEntry*  entries;  // [n_entries in window]
     uint64_t n_slots;
-    uint32_t m;                // positions of kmer_pos (>= |U|)
+    uint32_t m;                // positions of kmer_pos per sub-table (phf_pos)
     uint32_t log2nb;           // pilots has 1 << log2nb buckets
+    uint32_t log2p;            // kmer_pos is 2^log2p sub-tables
     uint32_t log2s;            // S = 1 << log2s positions per window sub-table
     int32_t  lo_bases;         // bases in the low half (k / 2)
     int32_t  k;

@@ -86,6 +86,25 @@ const char* test_env(const char* name) { return getenv(name); }
 const char* test_env(const char*) { return nullptr; }
 #endif
 
+// std::sort on `nt` host threads: sorted chunks, then pairwise merges level by level
+template <typename T, typename Cmp>
+void parallel_sort(std::vector<T>& v, Cmp cmp, unsigned nt) {
+    if (nt < 2 || v.size() < (size_t)nt * 65536) { std::sort(v.begin(), v.end(), cmp); return; }
+    std::vector<size_t> cut(nt + 1);
+    for (unsigned i = 0; i <= nt; i++) cut[i] = v.size() * i / nt;
+    {
+        std::vector<std::thread> th;
+        for (unsigned i = 0; i < nt; i++) th.emplace_back([&, i] { std::sort(v.begin() + cut[i], v.begin() + cut[i + 1], cmp); });
+        for (auto& t : th) t.join();
+    }
+    for (unsigned step = 1; step < nt; step *= 2) {
+        std::vector<std::thread> th;
+        for (unsigned i = 0; i + step < nt; i += 2 * step)
+            th.emplace_back([&, i, step] { std::inplace_merge(v.begin() + cut[i], v.begin() + cut[i + step], v.begin() + cut[std::min(i + 2 * step, nt)], cmp); });
+        for (auto& t : th) t.join();
+    }
+}
+
 // BK_CREATE_TIMING=1 (testing build): wall-clock of the phases of bk_engine_create on stderr (host-side table construction)
 struct PhaseClock {
     bool on = test_env("BK_CREATE_TIMING") != nullptr;
@@ -150,51 +169,67 @@ bool unrank128(u128 r1, int k, uint64_t* v_out, int* pos_out) {
     return false;
 }
 
-// Perfect hash of distinct keys (bk_device.h phf_*): buckets of ~4 keys, largest first, smallest free pilot.
-// On success pos[i] is the position of keys[i] in a table of m >= n positions.
-bool build_phf(const std::vector<uint64_t>& keys, std::vector<uint16_t>& pilots, uint32_t& log2nb, uint32_t& m_out, std::vector<uint32_t>& pos) {
+// Perfect hash of distinct keys (bk_device.h phf_*): buckets of ~4 keys, largest first, smallest free pilot.  Large key sets are
+// cut into 2^log2p sub-tables by the leading bits of the bucket index and built on as many host threads; every sub-table has
+// msub positions.  On success pos[i] is the position of keys[i] in a table of (msub << log2p) positions.
+bool build_phf(const std::vector<uint64_t>& keys, std::vector<uint16_t>& pilots, uint32_t& log2nb, uint32_t& msub_out, uint32_t& log2p_out,
+               std::vector<uint32_t>& pos) {
     const size_t n = keys.size();
     uint32_t log2nb0 = 0;
     while ((4ull << log2nb0) < n) log2nb0++;
     pos.assign(n, 0);
-    std::vector<uint8_t> used;
-    std::vector<uint32_t> trial;
-    // A construction can fail only when a bucket finds no pilot among 65536: first the table grows (m), then the buckets
-    // shrink (twice as many, half the keys each) -- the device reads both sizes from the view, so any outcome is a valid
+    // A construction can fail only when a bucket finds no pilot among 65536: first the tables grow (msub), then the buckets
+    // shrink (twice as many, half the keys each) -- the device reads all sizes from the view, so any outcome is a valid
     // table; an index is never refused because of its hash.
     for (uint32_t extra = 0; extra <= 6; extra++) {
         log2nb = log2nb0 + extra;
         if (log2nb > 30) break;
-        const size_t nb = (size_t)1 << log2nb;
-        std::vector<std::vector<uint32_t>> bucket(nb);
-        for (size_t i = 0; i < n; i++) bucket[bk::phf_bucket(keys[i], log2nb)].push_back((uint32_t)i);
-        std::vector<uint32_t> order(nb);
-        for (size_t i = 0; i < nb; i++) order[i] = (uint32_t)i;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return bucket[a].size() > bucket[b].size(); });
-        uint64_t m = std::max<uint64_t>(64, (uint64_t)((double)n / 0.97) + 1);
-        for (int attempt = 0; attempt <= 8 && m < (1ull << 31); attempt++, m += m / 8 + 1) {
-            used.assign(m, 0);
+        const uint32_t log2p = n >= (1u << 20) && log2nb >= 10 ? 5u : 0u;
+        const size_t P = (size_t)1 << log2p;
+        const size_t nb = (size_t)1 << log2nb, nb_sub = nb >> log2p;
+        // keys by bucket (counting sort), buckets by sub-table
+        std::vector<uint32_t> b_of(n), b_cnt(nb + 1, 0u), by_bucket(n);
+        for (size_t i = 0; i < n; i++) { b_of[i] = bk::phf_bucket(keys[i], log2nb); b_cnt[b_of[i] + 1]++; }
+        for (size_t x = 0; x < nb; x++) b_cnt[x + 1] += b_cnt[x];
+        { std::vector<uint32_t> at(b_cnt.begin(), b_cnt.end() - 1); for (size_t i = 0; i < n; i++) by_bucket[at[b_of[i]]++] = (uint32_t)i; }
+        uint64_t max_sub = 0;
+        for (size_t sp = 0; sp < P; sp++) max_sub = std::max<uint64_t>(max_sub, b_cnt[(sp + 1) * nb_sub] - b_cnt[sp * nb_sub]);
+        uint64_t msub = std::max<uint64_t>(64, (uint64_t)((double)max_sub / 0.97) + 1);
+        for (int attempt = 0; attempt <= 8 && (msub << log2p) < (1ull << 31); attempt++, msub += msub / 8 + 1) {
             pilots.assign(nb, 0);
-            bool ok = true;
-            for (uint32_t b : order) {
-                const auto& members = bucket[b];
-                if (members.empty()) break;
-                uint32_t pilot = 0;
-                for (; pilot < 65536; pilot++) {
-                    trial.clear();
-                    bool good = true;
-                    for (uint32_t i : members) {
-                        const uint32_t p = bk::phf_pos(keys[i], pilot, (uint32_t)m);
-                        if (used[p] || std::find(trial.begin(), trial.end(), p) != trial.end()) { good = false; break; }
-                        trial.push_back(p);
+            std::atomic<bool> ok{true};
+            auto build_sub = [&](size_t sp) {
+                std::vector<uint32_t> order(nb_sub);
+                for (size_t x = 0; x < nb_sub; x++) order[x] = (uint32_t)(sp * nb_sub + x);
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return b_cnt[x + 1] - b_cnt[x] > b_cnt[y + 1] - b_cnt[y]; });
+                std::vector<uint8_t> used(msub, 0);
+                std::vector<uint32_t> trial;
+                for (uint32_t bkt : order) {
+                    const uint32_t m0 = b_cnt[bkt], m1 = b_cnt[bkt + 1];
+                    if (m0 == m1) break;
+                    uint32_t pilot = 0;
+                    for (; pilot < 65536; pilot++) {
+                        trial.clear();
+                        bool good = true;
+                        for (uint32_t q = m0; q < m1; q++) {
+                            const uint32_t p = bk::phf_pos(keys[by_bucket[q]], pilot, (uint32_t)msub, log2nb, 0u);   // position inside the sub-table
+                            if (used[p] || std::find(trial.begin(), trial.end(), p) != trial.end()) { good = false; break; }
+                            trial.push_back(p);
+                        }
+                        if (good) break;
                     }
-                    if (good) break;
+                    if (pilot == 65536) { ok = false; return; }
+                    pilots[bkt] = (uint16_t)pilot;
+                    for (uint32_t q = m0; q < m1; q++) { pos[by_bucket[q]] = (uint32_t)(sp * msub) + trial[q - m0]; used[trial[q - m0]] = 1; }
                 }
-                if (pilot == 65536) { ok = false; break; }
-                pilots[b] = (uint16_t)pilot;
-                for (size_t q = 0; q < members.size(); q++) { pos[members[q]] = trial[q]; used[trial[q]] = 1; }
+            };
+            if (P == 1) build_sub(0);
+            else {
+                std::vector<std::thread> th;
+                for (size_t sp = 0; sp < P; sp++) th.emplace_back(build_sub, sp);
+                for (auto& t : th) t.join();
             }
-            if (ok) { m_out = (uint32_t)m; return true; }
+            if (ok) { msub_out = (uint32_t)msub; log2p_out = log2p; return true; }
         }
     }
     return false;
@@ -206,7 +241,7 @@ struct bk_engine {
     bk_params params{};
     int k = 0, wstart = 0, W = 0, n_files = 0;
     uint64_t total_cells = 0, n_slots = 0;
-    uint32_t log2s = 4, log2nb = 0, m = 1, n_u = 0, n_full = 0, n_lds_bins = 0;
+    uint32_t log2s = 4, log2nb = 0, log2p = 0, m = 1, n_u = 0, n_full = 0, n_lds_bins = 0;
     uint64_t n_prows = 0;  // V rows of the pseudo k-mers (bk_device.h)
     int v_omin = 0, v_span = 0;
     uint64_t v_off = 0, plane_len = 0;      // counter_plane_layout (bk_device.h)
@@ -224,7 +259,7 @@ struct bk_engine {
     DevBuf<bk::DirtyAns> dirty_ans;
     DevBuf<uint8_t> cell_flags;
     DevBuf<uint32_t> ref_words, cell_codes, cell_has, cell_clean, cell_clean3, cell_yf, cell_yr, id_at;
-    struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0; } half_lo, half_hi;
+    struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0, log2p = 0; } half_lo, half_hi;
     DevBuf<unsigned int> deferred, n_deferred;
     DevBuf<unsigned int> fin_partials;      // per-workgroup finalize tallies (small genome sets only)
     DevBuf<unsigned long long> ktab_keys;   // full_kmer_stats: open-addressing table of non-index-touching k-mers
@@ -309,11 +344,11 @@ struct bk_engine {
 
     bk::IndexView view() const {
         bk::IndexView v{};
-        v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb;
+        v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb; v.log2p = log2p;
         v.kmer_of = kmer_of.p; v.id_rec = id_rec.p; v.dirty_ans = dirty_ans.p; v.cell_flags = cell_flags.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_clean3 = cell_clean3.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
         v.n_full = n_full; v.n_prows = n_prows; v.prow_id = prow_id.p; v.prow_t = prow_t.p; v.v_omin = v_omin; v.v_span = v_span; v.v_off = v_off;
-        v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb};
-        v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb};
+        v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb, half_lo.log2p};
+        v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb, half_hi.log2p};
         v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.slot_rec = slot_rec.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
         v.table = table.p; v.ent_off = ent_off.p; v.ent_len = ent_len.p;
         v.entries = entries.p; v.n_slots = n_slots; v.log2s = log2s; v.k = k; v.wstart = wstart; v.W = W; v.n_files = n_files;
@@ -740,7 +775,8 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     std::vector<uint64_t>* near = collect ? &(*collect)[part] : nullptr;
                     const int c0 = (part * k) / parts, c1 = ((part + 1) * k) / parts;
                     const uint64_t mask = (((1ull << (2 * (c1 - c0))) - 1ull) << (2 * c0));
-                    std::sort(fs.begin(), fs.end(), [&](const Form& x, const Form& y) { return (x.w & mask) < (y.w & mask); });
+                    parallel_sort(fs, [&](const Form& x, const Form& y) { return (x.w & mask) < (y.w & mask); },
+                                  std::max(1u, std::min(8u, std::thread::hardware_concurrency() / (unsigned)parts)));
                     for (size_t a0 = 0; a0 < fs.size();) {
                         size_t a1 = a0 + 1;
                         while (a1 < fs.size() && (fs[a1].w & mask) == (fs[a0].w & mask)) a1++;
@@ -952,8 +988,8 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         // perfect hash over U
         std::vector<uint16_t> h_pilots;
         std::vector<uint32_t> u_pos;
-        if (!build_phf(h_u, h_pilots, e->log2nb, e->m, u_pos)) return fail(BK_ERR_HIP, "internal error: perfect hash construction failed after every fallback");
-        std::vector<bk::KmerPos> t_pos(e->m, bk::KmerPos{bk::kEmptyKey, kNone, 0u});
+        if (!build_phf(h_u, h_pilots, e->log2nb, e->m, e->log2p, u_pos)) return fail(BK_ERR_HIP, "internal error: perfect hash construction failed after every fallback");
+        std::vector<bk::KmerPos> t_pos((size_t)e->m << e->log2p, bk::KmerPos{bk::kEmptyKey, kNone, 0u});
         std::vector<uint64_t> h_kmer_of(std::max<size_t>(h_u.size(), 1), bk::kEmptyKey);
         for (size_t i = 0; i < h_u.size(); i++) {
             t_pos[u_pos[i]] = bk::KmerPos{h_u[i], first_cell[i], id_of[i] | (first_rc[i] ? 0x80000000u : 0u)};
@@ -1022,8 +1058,8 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 }
                 bk_engine::HalfBufs& hb = which == 0 ? e->half_lo : e->half_hi;
                 std::vector<uint32_t> hpos;
-                if (!build_phf(halves, hh[which].hp, hb.log2nb, hb.m, hpos)) { hh[which].ok = false; return; }
-                hh[which].dir.assign(hb.m, bk::HalfDir{0u, 0u, 0u, 0u});
+                if (!build_phf(halves, hh[which].hp, hb.log2nb, hb.m, hb.log2p, hpos)) { hh[which].ok = false; return; }
+                hh[which].dir.assign((size_t)hb.m << hb.log2p, bk::HalfDir{0u, 0u, 0u, 0u});
                 for (size_t i = 0; i < halves.size(); i++) hh[which].dir[hpos[i]] = bk::HalfDir{(uint32_t)halves[i], first[i], count[i], 0u};
             };
             std::thread t0(build_half, 0);
@@ -1042,20 +1078,24 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         // slot_of[id*W + t]: the window bucket (wstart+t, u masked) of reference k-mer id -- every reference k-mer
         // owns all of its buckets, so finalize needs no table probe for them (pseudo k-mers: empty_slot where none).
         std::vector<uint32_t> h_slot_of((size_t)std::max<size_t>(h_u.size(), 1) * std::max(e->W, 1), empty_slot);
-        for (size_t i = 0; i < h_u.size(); i++)
-            for (int t = 0; t < e->W; t++) h_slot_of[(size_t)id_of[i] * e->W + t] = slot_by_index[i * e->W + t];
+        parallel_for(h_u.size(), [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; i++)
+                for (int t = 0; t < e->W; t++) h_slot_of[(size_t)id_of[i] * e->W + t] = slot_by_index[i * e->W + t];
+        });
         std::vector<uint32_t>().swap(slot_by_index);
         BK_HIP(e->slot_of.upload(h_slot_of));
         {
             std::vector<bk::SlotRec> h_rec((size_t)std::max<size_t>(e->n_full, 1) * std::max(e->W, 1));
-            for (size_t id = 0; id < e->n_full; id++)
-                for (int t = 0; t < e->W; t++) {
-                    const uint32_t sl = h_slot_of[id * e->W + t];
-                    bk::SlotRec r{};
-                    r.off = h_off[sl]; r.len = h_len[sl];
-                    if (r.len) r.first = h_ent[r.off];
-                    h_rec[id * e->W + t] = r;
-                }
+            parallel_for(e->n_full, [&](size_t id0, size_t id1) {
+                for (size_t id = id0; id < id1; id++)
+                    for (int t = 0; t < e->W; t++) {
+                        const uint32_t sl = h_slot_of[id * e->W + t];
+                        bk::SlotRec r{};
+                        r.off = h_off[sl]; r.len = h_len[sl];
+                        if (r.len) r.first = h_ent[r.off];
+                        h_rec[id * e->W + t] = r;
+                    }
+            });
             BK_HIP(e->slot_rec.upload(h_rec));
             // IdRec: k-mer, first cell, flags; "simple" = each of the W buckets holds the k-mer's own single occurrence and nothing else
             std::vector<bk::IdRec> h_idrec(std::max<size_t>(h_u.size(), 1), bk::IdRec{bk::kEmptyKey, 0u, 0u});
@@ -1081,22 +1121,36 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         // hence perfect (== W) / variant -- a property of the index alone
         std::vector<uint32_t> h_estat_off(h_u.size() + 1, 0u), h_estat;
         {
-            std::vector<uint32_t> hits(e->n_files, 0u), touched;
-            for (size_t id = 0; id < h_u.size(); id++) {
-                touched.clear();
-                for (int t = 0; t < e->W; t++) {
-                    const uint32_t sl = h_slot_of[id * e->W + t];
-                    for (uint32_t q = 0; q < h_len[sl]; q++) {
-                        const uint32_t file = h_ent[h_off[sl] + q].file;
-                        if (hits[file]++ == 0) touched.push_back(file);
+            // per id, independently: chunks on host threads, each with its own list, joined in id order
+            const size_t n_ids = h_u.size();
+            const unsigned nt = n_ids < 65536 ? 1u : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+            std::vector<std::vector<uint32_t>> part(nt);
+            std::vector<uint32_t> n_of(n_ids, 0u);
+            auto work = [&](unsigned t) {
+                std::vector<uint32_t> hits(e->n_files, 0u), touched;
+                for (size_t id = n_ids * t / nt; id < n_ids * (t + 1) / nt; id++) {
+                    touched.clear();
+                    for (int w = 0; w < e->W; w++) {
+                        const uint32_t sl = h_slot_of[id * e->W + w];
+                        for (uint32_t q = 0; q < h_len[sl]; q++) {
+                            const uint32_t file = h_ent[h_off[sl] + q].file;
+                            if (hits[file]++ == 0) touched.push_back(file);
+                        }
                     }
+                    for (uint32_t file : touched) {
+                        part[t].push_back((file << 1) | (hits[file] == (uint32_t)e->W ? 1u : 0u));
+                        hits[file] = 0;
+                    }
+                    n_of[id] = (uint32_t)touched.size();
                 }
-                for (uint32_t file : touched) {
-                    h_estat.push_back((file << 1) | (hits[file] == (uint32_t)e->W ? 1u : 0u));
-                    hits[file] = 0;
-                }
-                h_estat_off[id + 1] = (uint32_t)h_estat.size();
-            }
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+            work(0);
+            for (auto& t : th) t.join();
+            for (size_t id = 0; id < n_ids; id++) h_estat_off[id + 1] = h_estat_off[id] + n_of[id];
+            h_estat.reserve(h_estat_off[n_ids]);
+            for (auto& v : part) { h_estat.insert(h_estat.end(), v.begin(), v.end()); std::vector<uint32_t>().swap(v); }
         }
         BK_HIP(e->estat_off.upload(h_estat_off));
         BK_HIP(e->estat.upload(h_estat));
@@ -1141,12 +1195,13 @@ int bk_engine_fork(const bk_engine* parent, bk_engine** out) {
     std::unique_ptr<bk_engine> e(new bk_engine());
     const bk_engine* p = parent;
     e->params = p->params; e->k = p->k; e->wstart = p->wstart; e->W = p->W; e->n_files = p->n_files;
-    e->total_cells = p->total_cells; e->n_slots = p->n_slots; e->log2s = p->log2s; e->log2nb = p->log2nb; e->m = p->m;
+    e->total_cells = p->total_cells; e->n_slots = p->n_slots; e->log2s = p->log2s; e->log2nb = p->log2nb; e->log2p = p->log2p; e->m = p->m;
     e->n_u = p->n_u; e->n_full = p->n_full; e->n_lds_bins = p->n_lds_bins; e->n_prows = p->n_prows;
     e->v_omin = p->v_omin; e->v_span = p->v_span; e->v_off = p->v_off; e->plane_len = p->plane_len;
     e->ref_in_lds = p->ref_in_lds; e->lo_bases = p->lo_bases; e->n_cus = p->n_cus; e->device = p->device;
     e->file_cell_lo = p->file_cell_lo; e->ablate = p->ablate; e->max_launch_records = p->max_launch_records;
-    e->half_lo.m = p->half_lo.m; e->half_lo.log2nb = p->half_lo.log2nb; e->half_hi.m = p->half_hi.m; e->half_hi.log2nb = p->half_hi.log2nb;
+    e->half_lo.m = p->half_lo.m; e->half_lo.log2nb = p->half_lo.log2nb; e->half_lo.log2p = p->half_lo.log2p;
+    e->half_hi.m = p->half_hi.m; e->half_hi.log2nb = p->half_hi.log2nb; e->half_hi.log2p = p->half_hi.log2p;
     // the index tables are immutable after bk_engine_create: the fork reads the parent's
     e->prow_id.alias(p->prow_id); e->prow_t.alias(p->prow_t); e->kmer_pos.alias(p->kmer_pos); e->d_view.alias(p->d_view); e->kmer_of.alias(p->kmer_of); e->id_rec.alias(p->id_rec); e->dirty_ans.alias(p->dirty_ans); e->cell_flags.alias(p->cell_flags);
     e->ref_words.alias(p->ref_words); e->cell_codes.alias(p->cell_codes); e->cell_has.alias(p->cell_has); e->cell_clean.alias(p->cell_clean);

@@ -63,7 +63,7 @@ __device__ __forceinline__ int single_diff_pos(uint64_t a, uint64_t b, int k) {
 
 __device__ __forceinline__ HalfDir half_lookup(const HalfView& hv, uint64_t half) {
     const uint32_t pilot = hv.pilots[phf_bucket(half, hv.log2nb)];
-    const uint4 e = *reinterpret_cast<const uint4*>(hv.dir + phf_pos(half, pilot, hv.m));
+    const uint4 e = *reinterpret_cast<const uint4*>(hv.dir + phf_pos(half, pilot, hv.m, hv.log2nb, hv.log2p));
     HalfDir d;
     d.key = e.x; d.off = e.y; d.cnt = (e.x == (uint32_t)half) ? e.z : 0u; d.pad = 0u;
     return d;
@@ -379,9 +379,9 @@ struct SlowPipe {
         const uint64_t lo = c & ((1ull << lo_bits) - 1ull), hi = c >> lo_bits;
         if (stage == 1) {
             const uint32_t pu = b0.x, pl = b0.y, ph = b0.z;
-            b0 = *reinterpret_cast<const uint4*>(ix.kmer_pos + phf_pos(c, pu, ix.m));
-            b1 = *reinterpret_cast<const uint4*>(ix.lo.dir + phf_pos(lo, pl, ix.lo.m));
-            b2 = *reinterpret_cast<const uint4*>(ix.hi.dir + phf_pos(hi, ph, ix.hi.m));
+            b0 = *reinterpret_cast<const uint4*>(ix.kmer_pos + phf_pos(c, pu, ix.m, ix.log2nb, ix.log2p));
+            b1 = *reinterpret_cast<const uint4*>(ix.lo.dir + phf_pos(lo, pl, ix.lo.m, ix.lo.log2nb, ix.lo.log2p));
+            b2 = *reinterpret_cast<const uint4*>(ix.hi.dir + phf_pos(hi, ph, ix.hi.m, ix.hi.log2nb, ix.hi.log2p));
             stage = 2;
         } else if (stage == 2) {
             const bool member = have && !stat_only && ((uint64_t)b0.x | ((uint64_t)b0.y << 32)) == c;   // a reference k-mer after all
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
             // the genome the LDS window covers
             uint4 se[kSeeds];
 #pragma unroll
-            for (int sq = 0; sq < kSeeds; ++sq) se[sq] = *reinterpret_cast<const uint4*>(ix.kmer_pos + phf_pos(sc[sq], spil[sq], ix.m));
+            for (int sq = 0; sq < kSeeds; ++sq) se[sq] = *reinterpret_cast<const uint4*>(ix.kmer_pos + phf_pos(sc[sq], spil[sq], ix.m, ix.log2nb, ix.log2p));
             bool shit[kSeeds];
             uint32_t soc[kSeeds];
 #pragma unroll
@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(256) void pick_window_kernel(ScanArgs a, uint64_t n
         const uint64_t g = read_symbols_at(a.words + r * a.stride_words, (len - (uint32_t)k) / 2u, a.stride_words - 1u) & kmask;
         const uint64_t rr = ~g & kmask, ff = rev2_64(g) >> (64 - 2 * k);
         const uint64_t c = ff < rr ? ff : rr;
-        const uint4 e = *reinterpret_cast<const uint4*>(ix.kmer_pos + phf_pos(c, ix.pilots[phf_bucket(c, ix.log2nb)], ix.m));
+        const uint4 e = *reinterpret_cast<const uint4*>(ix.kmer_pos + phf_pos(c, ix.pilots[phf_bucket(c, ix.log2nb)], ix.m, ix.log2nb, ix.log2p));
         if (((uint64_t)e.x | ((uint64_t)e.y << 32)) != c || (e.w & kIdMask) >= ix.n_full) continue;
         const uint32_t* oc = a.occ + (size_t)(e.w & kIdMask) * (uint32_t)a.n_files;
         for (int f = 0; f < a.n_files; ++f) if (oc[f] != 0xffffffffu) atomicAdd(&lvotes[f], 1u);
@@ -1616,6 +1616,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
     const uint64_t nq = (uint64_t)ix.n_full + (uint32_t)ix.v_span;
     const uint64_t n_units = ((nq + 2 * RPW - 1) / (2 * RPW)) * 16;   // unit u: q block u / 16 (2 RPW values of q), parity (u / 8) & 1, (base, direction) u & 7
     uint32_t par = 0;
+    const bool sparse_plane = ix.n_files > 1;
     for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         const uint64_t qrow = (u >> 4) * (2 * RPW) + ((u >> 3) & 1ull) + 2ull * hw;
         const uint64_t wk = qrow * 8 + (u & 7ull);
@@ -1631,7 +1632,8 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         const uint32_t ambp = idr.w;
         const int o = (int)oo + ix.v_omin;
         // a unit whose rows are all empty (most of them, with a large index and one sample) costs its loads and this vote only
-        if (!__syncthreads_or(n != 0ull)) continue;
+        // (asked only where it pays: a single genome's plane is three quarters full and the extra barrier costs 5 %)
+        if (sparse_plane && !__syncthreads_or(n != 0ull)) continue;
 #pragma unroll
         for (int off = 1; off < 32; off <<= 1) {
             const unsigned long long t = __shfl_up(n, off, 64);   // (lane - off is in the same row whenever oo >= off)
@@ -1768,7 +1770,7 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     for (uint64_t g0 = c_lo * W + (uint64_t)blockIdx.x * 256; g0 < n_work; g0 += (uint64_t)gridDim.x * 256) {
       const uint64_t g = g0 + threadIdx.x;
       // a round whose counters are all zero (most of them, with a large index and one sample) votes for nothing: skip its flush
-      if (!__syncthreads_or(g < n_work && a.counters[g / W] != 0ull)) continue;
+      if (ix.n_files > 1 && !__syncthreads_or(g < n_work && a.counters[g / W] != 0ull)) continue;
       if (g < n_work) do {
         const uint64_t cidx = g / W;
         const uint32_t t = (uint32_t)(g % W);
@@ -1955,7 +1957,7 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     hipLaunchKernelGGL(finalize_exact_kernel, dim3(b_ex), dim3(256), lds_votes, stream, a);
     // K2b (deferred k-mers only; the kernel reads their number on the device)
     // (few genomes: multi-bucket k-mers are rare, a small grid starts and ends quickly; many: one k-mer in eight takes this path)
-    unsigned b_gen = (unsigned)std::min<size_t>(a.ix.n_files >= 8 ? kFinGeneralBlocks : kFinGeneralBlocks / 4, 256 * std::max<size_t>(1, (160u * 1024u) / lds));
+    unsigned b_gen = (unsigned)std::min<size_t>(a.ix.n_files >= 8 ? kFinGeneralBlocks : kFinGeneralBlocks / 16, 256 * std::max<size_t>(1, (160u * 1024u) / lds));
     a.row_general = (int)(b_var + b_ex);
     hipLaunchKernelGGL(finalize_general_kernel, dim3(b_gen), dim3(64), lds, stream, a);
     if (a.partials && a.mode != 2) {

@@ -488,7 +488,9 @@ int run_call(const Args& a) {
         if (a.pileup) { p.fwd_depth.resize(cells4); p.rev_depth.resize(cells4); }
         hip_check(bk_sample_download(e, n_mates, a.pileup ? p.fwd_depth.data() : nullptr, a.pileup ? p.rev_depth.data() : nullptr, nullptr, nullptr,
                                      stats.data(), present.data(), kstats.data()), "bk_sample_download");
-        std::vector<bk_call_record> drecs((size_t)std::max<uint64_t>(1, 3 * ix.total_cells()));
+        uint64_t longest = 1;   // at most three alternative bases per position of the selected genome
+        for (size_t f = 0; f < n_files; f++) longest = std::max<uint64_t>(longest, ix.genome_len(f));
+        std::vector<bk_call_record> drecs((size_t)(3 * longest));
         bk_call_summary summ{};
         hip_check(bk_sample_download_calls(e, &summ, drecs.data(), drecs.size()), "bk_sample_download_calls");
         p.stats.assign(n_files * 3, 0);

@@ -278,7 +278,7 @@ def main():
     engs = [eng] + [eng.fork() for _ in range(n_fly - 1)]
     streams = [torch.cuda.ExternalStream(e.stream_ptr(), device=dev) for e in engs]
     torch.cuda.set_stream(streams[0])
-    counters = [[torch.as_tensor(_DevArray(e.counters_ptr(m), e.counter_len, "<i8"), device=dev) for m in range(n_mates)] for e in engs]
+    counters = [[torch.as_tensor(_DevArray(e.counters_ptr(m), e.counter_len, "<i8"), device=dev) for m in range(n_mates)] for e in engs] if sharded_reads else None
 
     # one sample's reads sharded over ranks: reduce-scatter of the counter plane + each rank maps its part + max / sum of the small
     # pileups (include/bronko_hip.h); --allreduce selects the plain form (all-reduce the plane, every rank maps everything)

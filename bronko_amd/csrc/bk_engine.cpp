@@ -284,6 +284,10 @@ struct bk_engine {
     DevBuf<uint32_t> ent_off, ent_len;
     DevBuf<bk::DevEntry> entries;
     DevBuf<unsigned long long> counters[2];
+    // sparse finalize (large indexes): per mate file the touch bitmaps the counter writers set and the lists finalize walks
+    bool sparse = false;
+    DevBuf<unsigned int> touch_v[2], touch_p[2], touch_e[2], v_list[2], p_list[2], e_list[2], n_list[2];
+    bool plane_used[2] = {false, false};   // counters were added to since the planes were last known to be all zero
     DevBuf<unsigned long long> pileup;      // 4 planes
     DevBuf<unsigned long long> stats;       // [2][n_files][3]
     DevBuf<unsigned char> present;          // [2][n_files]
@@ -376,6 +380,21 @@ struct bk_engine {
 static int alloc_sample_state(bk_engine* e) {
     const bk_params* prm = &e->params;
     for (int m = 0; m < 2; m++) BK_HIP(e->counters[m].alloc(e->plane_len));
+    // A plane of a large index is a thousandth full after a sample: above 16 M counters (128 MB) the writers note what they touch
+    // and finalize walks lists and clears what it read instead of scanning and zeroing planes (BK_SPARSE_FINALIZE forces it in
+    // the testing build)
+    e->sparse = e->W > 0 && (e->plane_len >= (16ull << 20) || test_env("BK_SPARSE_FINALIZE") != nullptr);
+    if (e->sparse) {
+        const uint64_t n_rows = bk::v_real_rows(e->n_full, e->v_span);
+        for (int m = 0; m < 2; m++) {
+            BK_HIP(hipMemset(e->counters[m].p, 0, e->counters[m].n * sizeof(unsigned long long)));
+            BK_HIP(e->touch_v[m].alloc(n_rows / 32 + 1)); BK_HIP(e->touch_p[m].alloc(e->n_prows / 32 + 1)); BK_HIP(e->touch_e[m].alloc((size_t)e->n_u / 32 + 1));
+            BK_HIP(hipMemset(e->touch_v[m].p, 0, e->touch_v[m].n * 4)); BK_HIP(hipMemset(e->touch_p[m].p, 0, e->touch_p[m].n * 4));
+            BK_HIP(hipMemset(e->touch_e[m].p, 0, e->touch_e[m].n * 4));
+            BK_HIP(e->v_list[m].alloc(n_rows)); BK_HIP(e->p_list[m].alloc(e->n_prows)); BK_HIP(e->e_list[m].alloc(e->n_u));
+            BK_HIP(e->n_list[m].alloc(4));
+        }
+    }
     BK_HIP(e->shard_sums.alloc((size_t)2 * e->n_files * 5 + 8));
     if (prm->full_kmer_stats) {
         if (prm->kmer_table_log2 < 10 || prm->kmer_table_log2 > 31) return fail(BK_ERR_INVALID, "kmer_table_log2 out of range");
@@ -386,7 +405,9 @@ static int alloc_sample_state(bk_engine* e) {
         BK_HIP(hipEventCreateWithFlags(&e->fill_ev, hipEventDisableTiming));
     }
     BK_HIP(e->ktab_out.alloc(8 + bk::ktab_fill_words()));
-    if (e->n_files <= 64) BK_HIP(e->fin_partials.alloc(bk::finalize_partial_rows() * ((size_t)e->n_files * 3 + 2)));
+    // one row of per-genome tallies per finalize workgroup (8192 rows: 10 MB at 100 genomes); without it every workgroup adds its
+    // tallies to the same few cache lines of `stats` with global atomics -- 2 ms per kernel at 100 genomes
+    if (e->n_files <= 2048) BK_HIP(e->fin_partials.alloc(bk::finalize_partial_rows() * ((size_t)e->n_files * 3 + 2)));
     BK_HIP(e->deferred.alloc(bk::v_plane_len(e->n_full, e->v_span, e->n_prows) * (prm->pileup_selected_only ? 2 : 1)));   // (one list per mate file when it is kept between two passes)
     BK_HIP(e->n_deferred.alloc(2));   // one per mate file
     BK_HIP(e->pileup.alloc(e->total_cells * 4 * 4));
@@ -1278,6 +1299,20 @@ int bk_sample_begin(bk_engine* e) {
 }
 
 static int zero_plane_if_stale(bk_engine* e, int mate) {
+    if (e->sparse) {
+        // the planes are all zero between samples (finalize clears what it read); only a sample that was begun and never
+        // finalized leaves something behind
+        if (e->plane_stale[mate] && e->plane_used[mate]) {
+            bk_engine::Span sp(e, 2);
+            BK_HIP(hipMemsetAsync(e->counters[mate].p, 0, std::max<size_t>(e->counters[mate].n, 1) * sizeof(unsigned long long), e->stream));
+            BK_HIP(hipMemsetAsync(e->touch_v[mate].p, 0, e->touch_v[mate].n * 4, e->stream));
+            BK_HIP(hipMemsetAsync(e->touch_p[mate].p, 0, e->touch_p[mate].n * 4, e->stream));
+            BK_HIP(hipMemsetAsync(e->touch_e[mate].p, 0, e->touch_e[mate].n * 4, e->stream));
+            e->plane_used[mate] = false;
+        }
+        e->plane_stale[mate] = false;
+        return BK_OK;
+    }
     if (e->plane_stale[mate]) {
         bk_engine::Span sp(e, 2);
         BK_HIP(hipMemsetAsync(e->counters[mate].p, 0, std::max<size_t>(e->counters[mate].n, 1) * sizeof(unsigned long long), e->stream));
@@ -1346,6 +1381,11 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->ktab_log2;
     a.ktab_overflow = e->ktab_out.p + 4; a.mate = (uint32_t)mate;
     a.occ = e->occ.p; a.n_files = e->n_files;
+    if (e->sparse) {
+        a.touch_v = e->touch_v[mate].p; a.touch_p = e->touch_p[mate].p; a.touch_e = e->touch_e[mate].p;
+        a.rl_recip = ~0ull / (unsigned long long)(e->v_span + 1) + 1ull;   // ceil(2^64 / row length) (a row length is no power of two > 1 ... or is: then +1 is still exact for 32-bit indices)
+        e->plane_used[mate] = true;
+    }
     if (test_env("BK_L2_STATS") && !e->dbg.p) { BK_HIP(e->dbg.alloc(32)); BK_HIP(hipMemsetAsync(e->dbg.p, 0, 32 * sizeof(unsigned long long), e->stream)); }
     a.dbg = e->dbg.p;
     if (e->W <= 0) {
@@ -1412,7 +1452,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
             else BK_HIP(bk::launch_level2(a, e->n_cus, e->stream));
             // per-cell bin slabs -> u64 plane
             bk::FoldArgs f{};
-            f.slabs = e->slabs.p; f.n_slabs = grid; f.n_lds_bins = e->n_lds_bins; f.id_at = e->id_at.p; f.cell_codes = e->cell_codes.p + bk::scan_ref_pad_words(); f.win_lo = a.win_lo; f.win_dev = a.win_dev;
+            f.slabs = e->slabs.p; f.n_slabs = grid; f.n_lds_bins = e->n_lds_bins; f.id_at = e->id_at.p; f.cell_codes = e->cell_codes.p + bk::scan_ref_pad_words(); f.win_lo = a.win_lo; f.win_dev = a.win_dev; f.touch_e = a.touch_e;
             f.counters = e->counters[mate].p;
             bk::launch_fold(f, e->stream);
         }
@@ -1537,6 +1577,7 @@ int bk_push_reads_packed(bk_engine* e, int mate, const uint32_t* words, uint32_t
 
 int bk_counters_device_ptr(bk_engine* e, int mate, void** d_ptr) {
     if (!e || !d_ptr || mate < 0 || mate > 1) return fail(BK_ERR_INVALID, "bad argument");
+    if (e->sparse) return fail(BK_ERR_UNSUPPORTED, "an index this large keeps its counter planes sparse: shard whole samples over GPUs, not one sample's reads");
     if (e->in_sample) {   // a mate file nothing was pushed for yet: its plane is zeroed lazily -- now, before the caller reduces it
         BK_HIP(hipSetDevice(e->device));
         if (int rc = zero_plane_if_stale(e, mate)) return rc;
@@ -1560,6 +1601,15 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
     const bool two_pass = e->params.pileup_selected_only != 0 && e->n_files > 1;
     if (two_pass && (elem_lo != 0 || elem_hi != e->plane_len)) return fail(BK_ERR_UNSUPPORTED, "pileup_selected_only cannot be combined with a sharded finalize");
     if (two_pass && !e->sel_out.p) BK_HIP(e->sel_out.alloc(1));
+    if (e->sparse && (elem_lo != 0 || elem_hi != e->plane_len)) return fail(BK_ERR_UNSUPPORTED, "an index this large cannot be finalized in shards");
+    if (e->sparse) {
+        for (int m = 0; m < n_mates; m++) {
+            bk_engine::Span sp(e, 1);
+            BK_HIP(hipMemsetAsync(e->n_list[m].p, 0, 4 * sizeof(unsigned int), e->stream));
+            bk::launch_compact_touched(e->touch_v[m].p, bk::v_real_rows(e->n_full, e->v_span), e->touch_p[m].p, e->n_prows, e->touch_e[m].p, e->n_u,
+                                       e->v_list[m].p, e->p_list[m].p, e->e_list[m].p, e->n_list[m].p, e->stream);
+        }
+    }
     for (int pass = 0; pass < (two_pass ? 2 : 1); pass++) {
         for (int m = 0; m < n_mates; m++) {   // R1 then R2 into the same arrays (call.rs:316-317)
             bk::FinalizeArgs a{};
@@ -1578,6 +1628,7 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             a.n_deferred = e->n_deferred.p + m;
             a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->ktab_log2;
             a.ktab_overflow = e->ktab_out.p + 4; a.mate = (uint32_t)m;
+            if (e->sparse) { a.v_list = e->v_list[m].p; a.p_list = e->p_list[m].p; a.e_list = e->e_list[m].p; a.n_list = e->n_list[m].p; }
             a.mode = two_pass ? pass + 1 : 0;
             a.sel = two_pass ? &e->sel_out.p->file_id : nullptr;
             a.sel_file = -1;
@@ -1591,6 +1642,14 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             c.out = e->sel_out.p;
             bk_engine::Span sp(e, 1);
             bk::launch_select_genome(c, e->stream);
+        }
+    }
+    if (e->sparse) {   // the maps are done: what they read is zeroed again, the planes are all zero for the next sample
+        for (int m = 0; m < n_mates; m++) {
+            bk_engine::Span sp(e, 1);
+            bk::launch_clear_touched(e->counters[m].p, e->v_off, bk::v_real_len(e->n_full, e->v_span), (uint32_t)e->v_span + 1u, e->v_list[m].p,
+                                     e->p_list[m].p, e->e_list[m].p, e->n_list[m].p, e->stream);
+            e->plane_used[m] = false;
         }
     }
     if (e->ktab_keys.p) {
@@ -1607,6 +1666,12 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
         BK_HIP(hipMemsetAsync(e->dbg.p, 0, sizeof h, e->stream));
         BK_HIP(hipStreamSynchronize(e->stream));
         fprintf(stderr, "[bk] finalize: %u + %u k-mers deferred to the general kernel\n", nd[0], nd[1]);
+        if (e->sparse) {
+            unsigned int nl[4];
+            BK_HIP(hipMemcpy(nl, e->n_list[0].p, sizeof nl, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[bk] sparse finalize (mate file 0): %u V rows of %llu, %u pseudo rows of %llu, %u ids of %u touched\n", nl[0],
+                    (unsigned long long)bk::v_real_rows(e->n_full, e->v_span), nl[1], (unsigned long long)e->n_prows, nl[2], e->n_u);
+        }
         fprintf(stderr, "[bk] scan marked: no-diagonal %llu, dirty-head %llu, clean-head %llu, pairs %llu | level 2: k-mers %llu in %llu chunks, simple %llu, dead %llu, "
                 "dirty answers %llu (one difference but id unknown: %llu), slow %llu (diffs 0/1/2/3+ with a diagonal: %llu/%llu/%llu/%llu) -> member %llu, neighbour %llu, nothing %llu\n",
                 h[0], h[1], h[2], h[3], h[4], h[11], h[5], h[6], h[16], h[17], h[7], h[12], h[13], h[14], h[15], h[8], h[9], h[10]);

@@ -49,6 +49,13 @@ struct ScanArgs {
     uint32_t ktab_log2;
     unsigned long long* ktab_overflow;
     uint32_t mate;
+    // Large indexes ("sparse finalize"): whoever adds to a counter also sets the bit of its V row / pseudo row / reference k-mer, so
+    // that finalize walks the touched ones instead of a plane of which a thousandth is non-zero, and clears what it read (no
+    // plane memset).  Null for small indexes (dense finalize).
+    unsigned int* touch_v;          // [v_real_rows / 32 + 1] bit per V row of the reference k-mers
+    unsigned int* touch_p;          // [n_prows / 32 + 1]     bit per pseudo k-mer row (8 counters)
+    unsigned int* touch_e;          // [n_u / 32 + 1]         bit per id (its two E counters)
+    unsigned long long rl_recip;    // ceil(2^64 / (v_span + 1)): counter index -> row by __umul64hi
     int ablate;                     // measurement aid (-DBK_TESTING build only): 1 = Level 1 only, 2 = no V atomics, 3 = no slow path
     unsigned long long* dbg;        // -DBK_TESTING build, BK_L2_STATS=1: [32] tallies of what is left to Level 2 and why; null otherwise
 };
@@ -76,6 +83,11 @@ struct FinalizeArgs {
     uint32_t mate;
     // bk_params.pileup_selected_only: 0 = statistics and votes in one pass; 1 = statistics only (first pass); 2 = votes only, and
     // only for BucketInfos of genome file *sel (second pass, after the genome was selected from the statistics)
+    // sparse finalize (see ScanArgs::touch_v): the touched rows / ids, listed by launch_compact_touched; null = walk the plane
+    const unsigned int* v_list;     // V rows of the reference k-mers
+    const unsigned int* p_list;     // pseudo rows
+    const unsigned int* e_list;     // ids
+    const unsigned int* n_list;     // [3] their lengths
     int mode;
     const int* sel;
     int sel_file;                   // = *sel, read by each kernel of the second pass
@@ -88,6 +100,7 @@ struct FoldArgs {
     const uint32_t* id_at;          // cell -> id (bins are per cell)
     uint32_t win_lo;                // slab cell i is cell win_lo + i
     const uint32_t* win_dev;        // ... or {win_file, win_lo} chosen on the device
+    unsigned int* touch_e;          // sparse finalize: bit per id that received a count (null: dense)
     const uint32_t* cell_codes;     // IndexView::cell_codes + its front padding: symbol 0 = cell 0
     unsigned long long* counters;
 };
@@ -129,6 +142,11 @@ void launch_ktab_rehash(const unsigned long long* okeys, const unsigned int* ocn
                         uint32_t nlog2, unsigned long long* overflow, hipStream_t stream);
 uint32_t ktab_fill_words();   // tallies of new keys behind the overflow word: ktab_out[8 ..]
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
+// sparse finalize: touch bitmaps -> lists (the bitmaps are cleared on the way); lists -> their counters zeroed again
+void launch_compact_touched(unsigned int* touch_v, uint64_t n_rows, unsigned int* touch_p, uint64_t n_prows, unsigned int* touch_e, uint64_t n_ids,
+                            unsigned int* v_list, unsigned int* p_list, unsigned int* e_list, unsigned int* n_list, hipStream_t stream);
+void launch_clear_touched(unsigned long long* counters, uint64_t v_off, uint64_t v_real_len, uint32_t rl, const unsigned int* v_list,
+                          const unsigned int* p_list, const unsigned int* e_list, const unsigned int* n_list, hipStream_t stream);
 // one launch zeroes the engine's small per-sample buffers
 void launch_zero_small(unsigned long long* a, size_t na, unsigned long long* b, size_t nb, unsigned long long* c, size_t nc,
                        unsigned char* d, size_t nd, unsigned int* e, size_t ne, hipStream_t stream);

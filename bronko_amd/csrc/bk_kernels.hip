@@ -328,10 +328,17 @@ __device__ __forceinline__ uint32_t bits32_at(const uint32_t* __restrict__ w, in
 
 // +1 on "reference k-mer id with base b (forward strand of the reference) at offset o, read in direction d": a
 // single-k-mer run of its V row
+// sparse finalize (ScanArgs::touch_v): set bit `i` of a touch bitmap (null: dense finalize, nothing to note)
+__device__ __forceinline__ void touch(unsigned int* bm, uint32_t i) {
+    // (looked at first: most rows are touched many times a sample and a stale 0 only costs the atomic it would have cost anyway)
+    if (bm && !(__builtin_nontemporal_load(bm + (i >> 5)) >> (i & 31u) & 1u)) atomicOr(bm + (i >> 5), 1u << (i & 31u));
+}
+
 __device__ __forceinline__ void v_point(unsigned long long* __restrict__ v_counters, uint32_t id, uint32_t o, uint32_t b, uint32_t d,
-                                        int omin, int span) {
+                                        int omin, int span, unsigned int* touch_v = nullptr) {
     const uint32_t oo = o - (uint32_t)omin;
     if (oo >= (uint32_t)span) return;   // offsets outside the layout touch no window bucket
+    touch(touch_v, ((id + oo) * 4u + b) * 2u + d);
     unsigned long long* row = v_counters + v_row_base(id + oo, b, d, span) + oo;
     atomicAdd(row, 1ull);
     if (oo + 1u < (uint32_t)span) atomicAdd(row + 1, ~0ull);   // (slot `span` is never read)
@@ -353,6 +360,8 @@ struct SlowPipe {
     //   after stage 2: b0 = entry of U, b1 = low directory entry, b2 = high directory entry
     //   after stage 3: b0 = first low candidate, b1 = first high candidate, b2 = {low off, low cnt, high off, high cnt}
     uint4 b0{}, b1{}, b2{};
+    unsigned int* touch_v = nullptr; unsigned int* touch_p = nullptr;   // sparse finalize (ScanArgs::touch_v); the caller's
+                                                                        // count_exact notes reference k-mers itself
 #ifdef BK_TESTING
     unsigned long long* dbg = nullptr;   // BK_L2_STATS tallies
 #endif
@@ -417,9 +426,10 @@ struct SlowPipe {
                 if (p < ix.n_full) {
                     // in reference coordinates: offset from the k-mer's start, base on the forward strand, read direction
                     const uint32_t rcu = bvalid >> 31;
-                    v_point(v_counters, p, (uint32_t)(rcu ? k - 1 - j : j), rcu ? 3u - b : b, isrc ^ rcu, ix.v_omin, ix.v_span);
+                    v_point(v_counters, p, (uint32_t)(rcu ? k - 1 - j : j), rcu ? 3u - b : b, isrc ^ rcu, ix.v_omin, ix.v_span, touch_v);
                 } else {
                     const uint32_t row = p - ix.n_full + (uint32_t)__popc(bvalid & ((1u << (j - wlo)) - 1u));
+                    touch(touch_p, row);
                     atomicAdd(v_counters + v_real_len(ix.n_full, ix.v_span) + ((uint64_t)row * 4 + b) * 2 + isrc, 1ull);
                 }
             } else if (have && kt.keys) {
@@ -440,7 +450,8 @@ struct SlowPipe {
 };
 
 // KT: k as a compile-time constant for the common sizes (the window loop of Level 1 unrolls), 0 = any k
-template <bool REF_LDS, bool STATS, int KT>
+// SPARSE: the V rows written are noted in ScanArgs::touch_v (sparse finalize of a large index)
+template <bool REF_LDS, bool STATS, int KT, bool SPARSE>
 __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned int* range_s = reinterpret_cast<unsigned int*>(smem);
@@ -729,6 +740,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                         if (lo2 <= hi2 && !BK_ABLATE(a, 2)) {
                             const uint32_t idS = id_first + ddir * (uint32_t)s_lo;
                             unsigned long long* row = v_counters + v_row_base(idS + o_first - (uint32_t)omin, fwd2 ? br : 3u - br, fwd2 ? 0u : 1u, span);
+                            if constexpr (SPARSE) touch(a.touch_v, ((idS + o_first - (uint32_t)omin) * 4u + (fwd2 ? br : 3u - br)) * 2u + (fwd2 ? 0u : 1u));
                             atomicAdd(row + (lo2 - omin), 1ull);
                             if (hi2 - omin + 1 < span) atomicAdd(row + (hi2 - omin + 1), ~0ull);   // (slot `span` is never read)
                         }
@@ -896,7 +908,7 @@ constexpr int kL2Waves = kL2Block / 64;
 constexpr int kL2QueueCap = 128;            // record / slow queues: a batch is taken at 64 pending, a round adds <= 64
 constexpr int kL2KmerCap = 256;             // k-mer queue
 constexpr int kAnyWords = 8;                // words of l2_any a wave takes at a time (256 records)
-template <bool STATS, int KT>
+template <bool STATS, int KT, bool SPARSE>
 __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
     __shared__ unsigned long long queue_c[kL2Waves * kL2QueueCap];   // slow-path queue: canonical k-mer | orientation << 62 | stat_only << 63
     __shared__ unsigned int rec_q[kL2Waves * kL2QueueCap];
@@ -921,11 +933,12 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
 
     // slow path: +1 on the E counter of reference k-mer `id` read in orientation `isrc`
     auto count_exact = [&](bool hit, uint32_t /*cell*/, uint32_t id, uint32_t isrc, uint32_t /*rc_first*/) {
-        if (hit) atomicAdd(a.counters + 2 * (size_t)id + isrc, 1ull);
+        if (hit) { if constexpr (SPARSE) touch(a.touch_e, id); atomicAdd(a.counters + 2 * (size_t)id + isrc, 1ull); }
         BK_DBG(a, 8, hit, 1);
     };
     uint32_t qn = 0;   // wave-uniform fill of the slow-path queue
     SlowPipe pipe;
+    pipe.touch_v = a.touch_v; pipe.touch_p = a.touch_p;
 #ifdef BK_TESTING
     pipe.dbg = a.dbg;
 #endif
@@ -980,6 +993,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
         // a V counter of the reference k-mers' part: +1 at vp, -1 at vm (0xffffffff: none)
         uint32_t vp = 0xffffffffu, vm = 0xffffffffu;
         if (has && n_diff == 0u) {
+            if constexpr (SPARSE) touch(a.touch_e, id);
             atomicAdd(a.counters + 2 * (size_t)id + isrc, 1ull);                // the read k-mer IS the cell's reference k-mer
             slow = false;
             BK_DBG(a, 8, true, 1);
@@ -1006,11 +1020,14 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
                 const uint32_t kind = ans.y & 3u;
                 if (!(ans.y & kAnsNone)) {
                     slow = false;
-                    if (kind == 1u) atomicAdd(a.counters + ans.x + isrc, 1ull);
+                    if (kind == 1u) { if constexpr (SPARSE) touch(a.touch_e, ans.x >> 1); atomicAdd(a.counters + ans.x + isrc, 1ull); }
                     else if (kind == 2u) {
                         vp = ans.x + (((isrc ^ (ans.y >> 2)) & 1u) ? (uint32_t)span + 1u : 0u);
                         if (ans.y & 8u) vm = vp + 1u;
-                    } else if (kind == 3u) atomicAdd(v_counters + ans.x + isrc, 1ull);
+                    } else if (kind == 3u) {
+                        if constexpr (SPARSE) touch(a.touch_p, (uint32_t)((ans.x - v_real_len(ix.n_full, span)) >> 3));
+                        atomicAdd(v_counters + ans.x + isrc, 1ull);
+                    }
                     else if (STATS) { slow = true; stat_only = true; }          // touches nothing: only the statistics table wants it
                     BK_DBG(a, 16, true, 1);
                 }
@@ -1031,8 +1048,11 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
             const bool same_up = lane > 0 && rec_up == rec, same_dn = lane < 63 && rec_dn == rec;
             const bool p_gone = fwd ? (same_dn && vm_dn == vp) : (same_up && vm_up == vp);
             const bool m_gone = fwd ? (same_up && vp_up == vm) : (same_dn && vp_dn == vm);
-            if (vp != 0xffffffffu && !p_gone) atomicAdd(v_counters + vp, 1ull);
-            if (vm != 0xffffffffu && !m_gone) atomicAdd(v_counters + vm, ~0ull);
+            const bool p_live = vp != 0xffffffffu && !p_gone, m_live = vm != 0xffffffffu && !m_gone;
+            if (SPARSE && (p_live || m_live))      // (vp and vm lie in one row; row = counter / row length, by the reciprocal)
+                touch(a.touch_v, (uint32_t)__umul64hi((unsigned long long)(p_live ? vp : vm), a.rl_recip));
+            if (p_live) atomicAdd(v_counters + vp, 1ull);
+            if (m_live) atomicAdd(v_counters + vm, ~0ull);
         }
         if (BK_ABLATE(a, 3)) slow = false;
         const unsigned long long mm = __ballot(slow);
@@ -1242,10 +1262,12 @@ hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t strea
     const size_t lds = scan_lds_bytes(a.n_lds_bins, a.ref_in_lds != 0, a.total_cells);
     const bool stats = a.ktab_keys != nullptr;
     void (*kern)(ScanArgs);
-#define BK_PICK(KT) (a.ref_in_lds ? (stats ? scan_count_kernel<true, true, KT> : scan_count_kernel<true, false, KT>) \
-                                  : (stats ? scan_count_kernel<false, true, KT> : scan_count_kernel<false, false, KT>))
+#define BK_PICK2(KT, SP) (a.ref_in_lds ? (stats ? scan_count_kernel<true, true, KT, SP> : scan_count_kernel<true, false, KT, SP>) \
+                                       : (stats ? scan_count_kernel<false, true, KT, SP> : scan_count_kernel<false, false, KT, SP>))
+#define BK_PICK(KT) (!a.touch_v ? BK_PICK2(KT, false) : BK_PICK2(KT, true))
     kern = a.k == 21 ? BK_PICK(21) : a.k == 31 ? BK_PICK(31) : BK_PICK(0);
 #undef BK_PICK
+#undef BK_PICK2
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kScanBlock), lds, stream, a);
@@ -1256,7 +1278,8 @@ hipError_t launch_level2(const ScanArgs& a, int n_cus, hipStream_t stream) {
     if (a.n_records == 0 || a.W <= 0) return hipSuccess;
     const bool stats = a.ktab_keys != nullptr;
     void (*kern)(ScanArgs);
-#define BK_PICK(KT) (stats ? level2_kernel<true, KT> : level2_kernel<false, KT>)
+#define BK_PICK(KT) (!a.touch_v ? (stats ? level2_kernel<true, KT, false> : level2_kernel<false, KT, false>) \
+                                : (stats ? level2_kernel<true, KT, true> : level2_kernel<false, KT, true>))
     kern = a.k == 21 ? BK_PICK(21) : a.k == 31 ? BK_PICK(31) : BK_PICK(0);
 #undef BK_PICK
     const uint64_t blks = (a.n_records + 32 * kAnyWords - 1) / (32 * kAnyWords);     // a wave takes kAnyWords words of l2_any at a time
@@ -1287,6 +1310,7 @@ __global__ __launch_bounds__(256) void fold_kernel(FoldArgs f) {
             const uint64_t cell = (f.win_dev ? f.win_dev[1] : f.win_lo) + i;
             const uint32_t id = f.id_at[cell];   // a counted cell always has a reference k-mer
             const uint32_t rc = ((f.cell_codes[cell >> 4] >> (2 * (cell & 15))) & 3u) == 2u ? 1u : 0u;
+            touch(f.touch_e, id);
             if (s0) atomicAdd(f.counters + 2 * (size_t)id + rc, s0);
             if (s1) atomicAdd(f.counters + 2 * (size_t)id + (1u - rc), s1);
         }
@@ -1614,13 +1638,25 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
     const uint32_t hw = (threadIdx.x >> 6) * gpw + grp;          // which of the workgroup's rows
     const uint32_t RPW = 4u * gpw;                               // rows per workgroup and unit
     const uint64_t nq = (uint64_t)ix.n_full + (uint32_t)ix.v_span;
-    const uint64_t n_units = ((nq + 2 * RPW - 1) / (2 * RPW)) * 16;   // unit u: q block u / 16 (2 RPW values of q), parity (u / 8) & 1, (base, direction) u & 7
+    // sparse finalize: the touched rows from the list, RPW at a time, instead of every row of the plane
+    const uint64_t n_listed = a.v_list ? a.n_list[0] : 0ull;
+    const uint64_t n_units = a.v_list ? (n_listed + RPW - 1) / RPW
+                                      : ((nq + 2 * RPW - 1) / (2 * RPW)) * 16;   // unit u: q block u / 16 (2 RPW values of q), parity (u / 8) & 1, (base, direction) u & 7
     uint32_t par = 0;
-    const bool sparse_plane = ix.n_files > 1;
+    const bool sparse_plane = ix.n_files > 1 && !a.v_list;
     for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const uint64_t qrow = (u >> 4) * (2 * RPW) + ((u >> 3) & 1ull) + 2ull * hw;
-        const uint64_t wk = qrow * 8 + (u & 7ull);
-        const bool in_row = lane_on && qrow < nq && wk >= row_lo && wk < row_hi;
+        uint64_t qrow, wk;
+        bool in_row;
+        if (a.v_list) {
+            const uint64_t li = u * RPW + hw;
+            in_row = lane_on && li < n_listed;
+            wk = in_row ? a.v_list[li] : 0ull;
+            qrow = wk >> 3;
+        } else {
+            qrow = (u >> 4) * (2 * RPW) + ((u >> 3) & 1ull) + 2ull * hw;
+            wk = qrow * 8 + (u & 7ull);
+            in_row = lane_on && qrow < nq && wk >= row_lo && wk < row_hi;
+        }
         unsigned long long n = in_row ? vc[wk * rl + oo] : 0ull;
         // What this lane needs besides its count depends on the row's coordinates only: the reference k-mer's record (k-mer,
         // first cell, flags -- one 16-byte load, consecutive ids across the lanes) goes out together with the row's load.
@@ -1731,8 +1767,10 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         vt_flush(vt, par, a);
         par ^= 1u;
     }
-    // the pseudo k-mers' counters (k = 31 only), one thread each
-    for (uint64_t x = px_lo + (uint64_t)blockIdx.x * 256 + threadIdx.x; x < px_hi; x += (uint64_t)gridDim.x * 256) {
+    // the pseudo k-mers' counters (k = 31 only), one thread each (sparse finalize: the 8 counters of each touched row)
+    const uint64_t px_n = a.p_list ? (uint64_t)a.n_list[1] * 8ull : px_hi;
+    for (uint64_t xi = (a.p_list ? 0ull : px_lo) + (uint64_t)blockIdx.x * 256 + threadIdx.x; xi < px_n; xi += (uint64_t)gridDim.x * 256) {
+        const uint64_t x = a.p_list ? (uint64_t)a.p_list[xi >> 3] * 8ull + (xi & 7ull) : xi;
         const uint64_t vi = real_len + x;
         if (vc[vi] == 0) continue;
         uint32_t p, t, isrc; uint64_t c; unsigned long long n;
@@ -1762,17 +1800,22 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     const uint32_t W = (uint32_t)ix.W;
     const uint64_t c_lo = min(a.elem_lo, e_plane_len(ix.n_u)), c_hi = min(a.elem_hi, e_plane_len(ix.n_u));   // this shard's E counters
     const uint64_t r_hi = min(c_hi, 2ull * ix.n_full);          // E counters of reference k-mers proper end here
-    const uint64_t n_work = r_hi * W;
+    // sparse finalize: the two counters of every touched id (reference k-mers first in the loop below, pseudo k-mers after)
+    const uint64_t n_ids_listed = a.e_list ? a.n_list[2] : 0ull;
+    const uint64_t n_work = a.e_list ? n_ids_listed * 2ull * W : r_hi * W;
     unsigned int kept = 0, distinct = 0;
     uint32_t par = 0;
     // 256 consecutive (counter, bucket) pairs per workgroup and round: ~8 consecutive reference k-mers, whose votes fall on
     // ~25 pileup cells -- gathered in the workgroup's vote table (LDS) before they go to the pileup
-    for (uint64_t g0 = c_lo * W + (uint64_t)blockIdx.x * 256; g0 < n_work; g0 += (uint64_t)gridDim.x * 256) {
+    for (uint64_t g0 = (a.e_list ? 0ull : c_lo * W) + (uint64_t)blockIdx.x * 256; g0 < n_work; g0 += (uint64_t)gridDim.x * 256) {
       const uint64_t g = g0 + threadIdx.x;
+      // the counter of this (counter, bucket) pair; a listed id may be a pseudo k-mer: those are mapped by the loop below
+      uint64_t cidx = g < n_work ? g / W : 0ull;
+      bool mine = g < n_work;
+      if (a.e_list && mine) { const uint32_t lid = a.e_list[cidx >> 1]; mine = lid < ix.n_full; cidx = 2ull * lid + (cidx & 1ull); }
       // a round whose counters are all zero (most of them, with a large index and one sample) votes for nothing: skip its flush
-      if (ix.n_files > 1 && !__syncthreads_or(g < n_work && a.counters[g / W] != 0ull)) continue;
-      if (g < n_work) do {
-        const uint64_t cidx = g / W;
+      if (ix.n_files > 1 && !a.e_list && !__syncthreads_or(mine && a.counters[cidx] != 0ull)) continue;
+      if (mine) do {
         const uint32_t t = (uint32_t)(g % W);
         const unsigned long long n = a.counters[cidx];
         distinct += (n != 0 && t == 0 && do_stats);
@@ -1816,7 +1859,10 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
       par ^= 1u;
     }
     // pseudo k-mers (k = 31): nearly all of their counters are zero -- one thread per counter, the buckets in a loop
-    for (uint64_t cidx = max(c_lo, 2ull * ix.n_full) + (uint64_t)blockIdx.x * 256 + threadIdx.x; cidx < c_hi; cidx += (uint64_t)gridDim.x * 256) {
+    const uint64_t pc_n = a.e_list ? n_ids_listed * 2ull : c_hi;
+    for (uint64_t ci = (a.e_list ? 0ull : max(c_lo, 2ull * ix.n_full)) + (uint64_t)blockIdx.x * 256 + threadIdx.x; ci < pc_n; ci += (uint64_t)gridDim.x * 256) {
+        uint64_t cidx = ci;
+        if (a.e_list) { const uint32_t lid = a.e_list[ci >> 1]; if (lid < ix.n_full) continue; cidx = 2ull * lid + (ci & 1ull); }
         const unsigned long long n = a.counters[cidx];
         if (n == 0) continue;
         distinct += do_stats;
@@ -1928,6 +1974,52 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
     if (lane == 0) { ntouched[0] = 0; ntouched[1] = 0; }
     __syncthreads();
     if (do_stats) finalize_epilogue(a, lstats, 0u, 0u, ntouched, a.row_general + (int)blockIdx.x);
+}
+
+// Sparse finalize: the set bits of a touch bitmap -> a list of indices (order is irrelevant); every word read is cleared, so the
+// bitmap is all zero again for the next sample.  One append per wave (ballot + prefix popcount).
+__global__ __launch_bounds__(256) void compact_touched_kernel(unsigned int* bm, uint64_t n_bits, unsigned int* list, unsigned int* n_out) {
+    const uint64_t n_words = (n_bits + 31) / 32;
+    for (uint64_t w0 = (uint64_t)blockIdx.x * 256; w0 < n_words; w0 += (uint64_t)gridDim.x * 256) {
+        const uint64_t w = w0 + threadIdx.x;
+        uint32_t bits = w < n_words ? bm[w] : 0u;
+        if (bits) bm[w] = 0u;
+        while (__ballot(bits != 0u)) {
+            const bool on = bits != 0u;
+            const uint32_t b = on ? (uint32_t)__builtin_ctz(bits) : 0u;
+            bits &= bits - 1u;
+            const unsigned long long m = __ballot(on);
+            unsigned int base = 0;
+            if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m)) base = atomicAdd(n_out, (unsigned int)__popcll(m));
+            base = (unsigned int)__shfl((int)base, __builtin_ctzll(m));
+            if (on) list[base + lane_prefix(m)] = (uint32_t)(w * 32 + b);
+        }
+    }
+}
+void launch_compact_touched(unsigned int* touch_v, uint64_t n_rows, unsigned int* touch_p, uint64_t n_prows, unsigned int* touch_e, uint64_t n_ids,
+                            unsigned int* v_list, unsigned int* p_list, unsigned int* e_list, unsigned int* n_list, hipStream_t stream) {
+    auto go = [&](unsigned int* bm, uint64_t n, unsigned int* list, unsigned int* cnt) {
+        if (!n) return;
+        const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(((n + 31) / 32 + 255) / 256, 2048));
+        hipLaunchKernelGGL(compact_touched_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, bm, n, list, cnt);
+    };
+    go(touch_v, n_rows, v_list, n_list + 0);
+    go(touch_p, n_prows, p_list, n_list + 1);
+    go(touch_e, n_ids, e_list, n_list + 2);
+}
+// ... and when a sample's maps are done: the listed rows / counters are zeroed again (the plane holds nothing else)
+__global__ __launch_bounds__(256) void clear_touched_kernel(unsigned long long* counters, uint64_t v_off, uint64_t v_real, uint32_t rl,
+                                                            const unsigned int* v_list, const unsigned int* p_list, const unsigned int* e_list,
+                                                            const unsigned int* n_list) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, nt = (uint64_t)gridDim.x * 256;
+    unsigned long long* vc = counters + v_off;
+    for (uint64_t i = t; i < (uint64_t)n_list[0] * rl; i += nt) vc[(uint64_t)v_list[i / rl] * rl + i % rl] = 0ull;
+    for (uint64_t i = t; i < (uint64_t)n_list[1] * 8ull; i += nt) vc[v_real + (uint64_t)p_list[i >> 3] * 8ull + (i & 7ull)] = 0ull;
+    for (uint64_t i = t; i < (uint64_t)n_list[2] * 2ull; i += nt) counters[2ull * e_list[i >> 1] + (i & 1ull)] = 0ull;
+}
+void launch_clear_touched(unsigned long long* counters, uint64_t v_off, uint64_t v_real_len, uint32_t rl, const unsigned int* v_list,
+                          const unsigned int* p_list, const unsigned int* e_list, const unsigned int* n_list, hipStream_t stream) {
+    hipLaunchKernelGGL(clear_touched_kernel, dim3(2048), dim3(256), 0, stream, counters, v_off, v_real_len, rl, v_list, p_list, e_list, n_list);
 }
 
 size_t finalize_lds_bytes(int n_files) { return ((size_t)n_files * 5 + 4) * sizeof(uint32_t); }

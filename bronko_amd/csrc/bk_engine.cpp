@@ -392,7 +392,7 @@ static int alloc_sample_state(bk_engine* e) {
             BK_HIP(hipMemset(e->touch_v[m].p, 0, e->touch_v[m].n * 4)); BK_HIP(hipMemset(e->touch_p[m].p, 0, e->touch_p[m].n * 4));
             BK_HIP(hipMemset(e->touch_e[m].p, 0, e->touch_e[m].n * 4));
             BK_HIP(e->v_list[m].alloc(n_rows)); BK_HIP(e->p_list[m].alloc(e->n_prows)); BK_HIP(e->e_list[m].alloc(e->n_u));
-            BK_HIP(e->n_list[m].alloc(4));
+            BK_HIP(e->n_list[m].alloc(8));
         }
     }
     BK_HIP(e->shard_sums.alloc((size_t)2 * e->n_files * 5 + 8));
@@ -1605,9 +1605,9 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
     if (e->sparse) {
         for (int m = 0; m < n_mates; m++) {
             bk_engine::Span sp(e, 1);
-            BK_HIP(hipMemsetAsync(e->n_list[m].p, 0, 4 * sizeof(unsigned int), e->stream));
+            BK_HIP(hipMemsetAsync(e->n_list[m].p, 0, 8 * sizeof(unsigned int), e->stream));
             bk::launch_compact_touched(e->touch_v[m].p, bk::v_real_rows(e->n_full, e->v_span), e->touch_p[m].p, e->n_prows, e->touch_e[m].p, e->n_u,
-                                       e->v_list[m].p, e->p_list[m].p, e->e_list[m].p, e->n_list[m].p, e->stream);
+                                       e->n_full, e->v_list[m].p, e->p_list[m].p, e->e_list[m].p, e->n_list[m].p, e->stream);
         }
     }
     for (int pass = 0; pass < (two_pass ? 2 : 1); pass++) {
@@ -1648,7 +1648,7 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
         for (int m = 0; m < n_mates; m++) {
             bk_engine::Span sp(e, 1);
             bk::launch_clear_touched(e->counters[m].p, e->v_off, bk::v_real_len(e->n_full, e->v_span), (uint32_t)e->v_span + 1u, e->v_list[m].p,
-                                     e->p_list[m].p, e->e_list[m].p, e->n_list[m].p, e->stream);
+                                     e->p_list[m].p, e->e_list[m].p, e->n_list[m].p, e->n_u, e->stream);
             e->plane_used[m] = false;
         }
     }
@@ -1667,10 +1667,10 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
         BK_HIP(hipStreamSynchronize(e->stream));
         fprintf(stderr, "[bk] finalize: %u + %u k-mers deferred to the general kernel\n", nd[0], nd[1]);
         if (e->sparse) {
-            unsigned int nl[4];
+            unsigned int nl[8];
             BK_HIP(hipMemcpy(nl, e->n_list[0].p, sizeof nl, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[bk] sparse finalize (mate file 0): %u V rows of %llu, %u pseudo rows of %llu, %u ids of %u touched\n", nl[0],
-                    (unsigned long long)bk::v_real_rows(e->n_full, e->v_span), nl[1], (unsigned long long)e->n_prows, nl[2], e->n_u);
+            fprintf(stderr, "[bk] sparse finalize (mate file 0): %u V rows of %llu, %u pseudo rows of %llu, %u reference k-mers of %u and %u pseudo k-mers of %u touched\n",
+                    nl[0], (unsigned long long)bk::v_real_rows(e->n_full, e->v_span), nl[4], (unsigned long long)e->n_prows, nl[2], e->n_full, nl[3], e->n_u - e->n_full);
         }
         fprintf(stderr, "[bk] scan marked: no-diagonal %llu, dirty-head %llu, clean-head %llu, pairs %llu | level 2: k-mers %llu in %llu chunks, simple %llu, dead %llu, "
                 "dirty answers %llu (one difference but id unknown: %llu), slow %llu (diffs 0/1/2/3+ with a diagonal: %llu/%llu/%llu/%llu) -> member %llu, neighbour %llu, nothing %llu\n",

@@ -87,7 +87,7 @@ struct FinalizeArgs {
     const unsigned int* v_list;     // V rows of the reference k-mers
     const unsigned int* p_list;     // pseudo rows
     const unsigned int* e_list;     // ids
-    const unsigned int* n_list;     // [3] their lengths
+    const unsigned int* n_list;     // their lengths: [0] v_list, [2] reference k-mer ids (front of e_list), [3] pseudo k-mer ids (its tail), [4] p_list
     int mode;
     const int* sel;
     int sel_file;                   // = *sel, read by each kernel of the second pass
@@ -144,9 +144,9 @@ uint32_t ktab_fill_words();   // tallies of new keys behind the overflow word: k
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
 // sparse finalize: touch bitmaps -> lists (the bitmaps are cleared on the way); lists -> their counters zeroed again
 void launch_compact_touched(unsigned int* touch_v, uint64_t n_rows, unsigned int* touch_p, uint64_t n_prows, unsigned int* touch_e, uint64_t n_ids,
-                            unsigned int* v_list, unsigned int* p_list, unsigned int* e_list, unsigned int* n_list, hipStream_t stream);
+                            uint64_t n_full, unsigned int* v_list, unsigned int* p_list, unsigned int* e_list, unsigned int* n_list, hipStream_t stream);
 void launch_clear_touched(unsigned long long* counters, uint64_t v_off, uint64_t v_real_len, uint32_t rl, const unsigned int* v_list,
-                          const unsigned int* p_list, const unsigned int* e_list, const unsigned int* n_list, hipStream_t stream);
+                          const unsigned int* p_list, const unsigned int* e_list, const unsigned int* n_list, uint64_t n_ids, hipStream_t stream);
 // one launch zeroes the engine's small per-sample buffers
 void launch_zero_small(unsigned long long* a, size_t na, unsigned long long* b, size_t nb, unsigned long long* c, size_t nc,
                        unsigned char* d, size_t nd, unsigned int* e, size_t ne, hipStream_t stream);

@@ -1743,6 +1743,28 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
                 if ((int)en.file != a.sel_file) break;
                 vt_vote(vt, par, a, en, c, isrc, k, v);
             }
+        } else if (act && cnt > 1u && a.mode == 1) {
+            // statistics pass, no votes: the genomes of the bucket and how often each is there.  Four entries are asked for at a
+            // time (the walk over ~100 genomes' entries is a chain of dependent loads otherwise: latency, not bandwidth)
+            uint32_t n_perfect = 0, perfect_file = 0, cur = first.file, run = 1;
+            auto close = [&]() {
+                const bool perfect = run == (uint32_t)ix.W;
+                tally(lstats, cur * 3 + (perfect ? 0u : 1u));
+                if (perfect) { ++n_perfect; perfect_file = cur; }
+            };
+            for (uint32_t x = 1; x < cnt; x += 4u) {
+                uint32_t f[4];
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; i++) f[i] = ix.entries[r.x + min(x + i, cnt - 1u)].file;
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; i++) {
+                    if (x + i >= cnt) break;
+                    if (f[i] != cur) { close(); cur = f[i]; run = 0; }
+                    ++run;
+                }
+            }
+            close();
+            if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
         } else if (act && cnt > 1u) {
             // entries of one bucket are grouped by file (index build appends file by file): run lengths = hits per file
             uint32_t n_perfect = 0, perfect_file = 0;
@@ -1768,7 +1790,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         par ^= 1u;
     }
     // the pseudo k-mers' counters (k = 31 only), one thread each (sparse finalize: the 8 counters of each touched row)
-    const uint64_t px_n = a.p_list ? (uint64_t)a.n_list[1] * 8ull : px_hi;
+    const uint64_t px_n = a.p_list ? (uint64_t)a.n_list[4] * 8ull : px_hi;
     for (uint64_t xi = (a.p_list ? 0ull : px_lo) + (uint64_t)blockIdx.x * 256 + threadIdx.x; xi < px_n; xi += (uint64_t)gridDim.x * 256) {
         const uint64_t x = a.p_list ? (uint64_t)a.p_list[xi >> 3] * 8ull + (xi & 7ull) : xi;
         const uint64_t vi = real_len + x;
@@ -1801,8 +1823,11 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     const uint64_t c_lo = min(a.elem_lo, e_plane_len(ix.n_u)), c_hi = min(a.elem_hi, e_plane_len(ix.n_u));   // this shard's E counters
     const uint64_t r_hi = min(c_hi, 2ull * ix.n_full);          // E counters of reference k-mers proper end here
     // sparse finalize: the two counters of every touched id (reference k-mers first in the loop below, pseudo k-mers after)
-    const uint64_t n_ids_listed = a.e_list ? a.n_list[2] : 0ull;
-    const uint64_t n_work = a.e_list ? n_ids_listed * 2ull * W : r_hi * W;
+    const uint64_t n_ids_listed = a.e_list ? a.n_list[2] : 0ull, n_pseudo_listed = a.e_list ? a.n_list[3] : 0ull;
+    // ... and its statistics pass casts no votes: 8 lanes per counter share the walk over the k-mer's genomes (estat)
+    const bool stats_walk = a.e_list && a.mode == 1;
+    const uint32_t Wd = stats_walk ? 8u : W;                   // lanes per counter
+    const uint64_t n_work = a.e_list ? n_ids_listed * 2ull * Wd : r_hi * W;
     unsigned int kept = 0, distinct = 0;
     uint32_t par = 0;
     // 256 consecutive (counter, bucket) pairs per workgroup and round: ~8 consecutive reference k-mers, whose votes fall on
@@ -1810,9 +1835,28 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     for (uint64_t g0 = (a.e_list ? 0ull : c_lo * W) + (uint64_t)blockIdx.x * 256; g0 < n_work; g0 += (uint64_t)gridDim.x * 256) {
       const uint64_t g = g0 + threadIdx.x;
       // the counter of this (counter, bucket) pair; a listed id may be a pseudo k-mer: those are mapped by the loop below
-      uint64_t cidx = g < n_work ? g / W : 0ull;
-      bool mine = g < n_work;
-      if (a.e_list && mine) { const uint32_t lid = a.e_list[cidx >> 1]; mine = lid < ix.n_full; cidx = 2ull * lid + (cidx & 1ull); }
+      uint64_t cidx = g < n_work ? g / Wd : 0ull;
+      const bool mine = g < n_work;
+      if (a.e_list && mine) cidx = 2ull * a.e_list[cidx >> 1] + (cidx & 1ull);
+      if (stats_walk) {
+          // (the 8 lanes of a counter are neighbours in one wave and take every branch together)
+          const unsigned long long n = mine ? a.counters[cidx] : 0ull;
+          const uint32_t t = (uint32_t)(g & 7ull);
+          distinct += (n != 0 && t == 0);
+          if (n == 0 || n < a.ci || n > a.cx) continue;
+          kept += (t == 0);
+          const uint32_t id = (uint32_t)(cidx >> 1);
+          uint32_t n_perfect = 0, perfect_file = 0;
+          for (uint32_t q = ix.estat_off[id] + t, qe = ix.estat_off[id + 1]; q < qe; q += 8u) {   // (file << 1) | perfect
+              const uint32_t e = ix.estat[q];
+              tally(lstats, (e >> 1) * 3 + ((e & 1u) ? 0u : 1u));
+              if (e & 1u) { ++n_perfect; perfect_file = e >> 1; }
+          }
+          uint32_t tot = n_perfect;
+          tot += (uint32_t)__shfl_xor((int)tot, 1); tot += (uint32_t)__shfl_xor((int)tot, 2); tot += (uint32_t)__shfl_xor((int)tot, 4);
+          if (tot == 1 && n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
+          continue;
+      }
       // a round whose counters are all zero (most of them, with a large index and one sample) votes for nothing: skip its flush
       if (ix.n_files > 1 && !a.e_list && !__syncthreads_or(mine && a.counters[cidx] != 0ull)) continue;
       if (mine) do {
@@ -1859,10 +1903,9 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
       par ^= 1u;
     }
     // pseudo k-mers (k = 31): nearly all of their counters are zero -- one thread per counter, the buckets in a loop
-    const uint64_t pc_n = a.e_list ? n_ids_listed * 2ull : c_hi;
+    const uint64_t pc_n = a.e_list ? n_pseudo_listed * 2ull : c_hi;
     for (uint64_t ci = (a.e_list ? 0ull : max(c_lo, 2ull * ix.n_full)) + (uint64_t)blockIdx.x * 256 + threadIdx.x; ci < pc_n; ci += (uint64_t)gridDim.x * 256) {
-        uint64_t cidx = ci;
-        if (a.e_list) { const uint32_t lid = a.e_list[ci >> 1]; if (lid < ix.n_full) continue; cidx = 2ull * lid + (ci & 1ull); }
+        const uint64_t cidx = a.e_list ? 2ull * a.e_list[ix.n_u - 1u - (uint32_t)(ci >> 1)] + (ci & 1ull) : ci;   // (the tail of the list)
         const unsigned long long n = a.counters[cidx];
         if (n == 0) continue;
         distinct += do_stats;
@@ -1871,10 +1914,14 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
         const unsigned long long v = n > a.cs ? a.cs : n;
         const uint32_t id = (uint32_t)(cidx >> 1), isrc = (uint32_t)cidx & 1u;
         const uint64_t c = ix.kmer_of[id];
-        for (uint32_t t = 0; t < W; ++t) {
+        if (a.mode != 1) for (uint32_t t = 0; t < W; ++t) {
             const uint32_t s = ix.slot_of[(size_t)id * W + t];
             const uint32_t off = ix.ent_off[s], cnt = ix.ent_len[s];
-            for (uint32_t q = 0; q < cnt; ++q) vote(a, ix.entries[off + q], c, isrc, k, v);
+            for (uint32_t q = a.mode == 2 ? first_of_file(ix.entries + off, cnt, a.sel_file) : 0u; q < cnt; ++q) {
+                const DevEntry en = ix.entries[off + q];
+                if (a.mode == 2 && (int)en.file != a.sel_file) break;
+                vote(a, en, c, isrc, k, v);
+            }
         }
         if (!do_stats) continue;
         uint32_t n_perfect = 0, perfect_file = 0;
@@ -1977,53 +2024,65 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
 }
 
 // Sparse finalize: the set bits of a touch bitmap -> a list of indices (order is irrelevant); every word read is cleared, so the
-// bitmap is all zero again for the next sample.  One append per wave (ballot + prefix popcount).
-__global__ __launch_bounds__(256) void compact_touched_kernel(unsigned int* bm, uint64_t n_bits, unsigned int* list, unsigned int* n_out) {
+// bitmap is all zero again for the next sample.  Indices below `split` are appended at the front of the list (n_out[0] of them),
+// the others from its last slot `cap - 1` downwards (n_out[1]): K2e maps reference k-mers and pseudo k-mers differently.  One
+// append per wave and side: popcounts, a prefix sum over the lanes, one atomic by the last lane.
+__global__ __launch_bounds__(256) void compact_touched_kernel(unsigned int* bm, uint64_t n_bits, unsigned int* list, unsigned int* n_out,
+                                                              uint64_t split, uint64_t cap) {
     const uint64_t n_words = (n_bits + 31) / 32;
+    const int lane = threadIdx.x & 63;
     for (uint64_t w0 = (uint64_t)blockIdx.x * 256; w0 < n_words; w0 += (uint64_t)gridDim.x * 256) {
         const uint64_t w = w0 + threadIdx.x;
-        uint32_t bits = w < n_words ? bm[w] : 0u;
+        const uint32_t bits = w < n_words ? bm[w] : 0u;
+        if (!__ballot(bits != 0u)) continue;
         if (bits) bm[w] = 0u;
-        while (__ballot(bits != 0u)) {
-            const bool on = bits != 0u;
-            const uint32_t b = on ? (uint32_t)__builtin_ctz(bits) : 0u;
-            bits &= bits - 1u;
-            const unsigned long long m = __ballot(on);
-            unsigned int base = 0;
-            if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m)) base = atomicAdd(n_out, (unsigned int)__popcll(m));
-            base = (unsigned int)__shfl((int)base, __builtin_ctzll(m));
-            if (on) list[base + lane_prefix(m)] = (uint32_t)(w * 32 + b);
+        const uint32_t lo_mask = w * 32 + 32 <= split ? ~0u : w * 32 >= split ? 0u : (1u << (uint32_t)(split - w * 32)) - 1u;
+        uint32_t lo = bits & lo_mask, hi = bits & ~lo_mask;
+        const uint32_t n_lo = (uint32_t)__popc(lo), n_hi = (uint32_t)__popc(hi);
+        uint32_t inc = n_lo | (n_hi << 16);   // (<= 32 * 64 each: both sums in one word)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)inc, d); if (lane >= d) inc += up; }
+        uint32_t base_lo = 0, base_hi = 0;
+        if (lane == 63) {
+            if (inc & 0xffffu) base_lo = atomicAdd(n_out, inc & 0xffffu);
+            if (inc >> 16) base_hi = atomicAdd(n_out + 1, inc >> 16);
         }
+        base_lo = (uint32_t)__shfl((int)base_lo, 63) + (inc & 0xffffu) - n_lo;
+        base_hi = (uint32_t)__shfl((int)base_hi, 63) + (inc >> 16) - n_hi;
+        for (; lo; lo &= lo - 1u) list[base_lo++] = (uint32_t)(w * 32) + (uint32_t)__builtin_ctz(lo);
+        for (; hi; hi &= hi - 1u) list[cap - 1 - base_hi++] = (uint32_t)(w * 32) + (uint32_t)__builtin_ctz(hi);
     }
 }
 void launch_compact_touched(unsigned int* touch_v, uint64_t n_rows, unsigned int* touch_p, uint64_t n_prows, unsigned int* touch_e, uint64_t n_ids,
-                            unsigned int* v_list, unsigned int* p_list, unsigned int* e_list, unsigned int* n_list, hipStream_t stream) {
-    auto go = [&](unsigned int* bm, uint64_t n, unsigned int* list, unsigned int* cnt) {
+                            uint64_t n_full, unsigned int* v_list, unsigned int* p_list, unsigned int* e_list, unsigned int* n_list, hipStream_t stream) {
+    auto go = [&](unsigned int* bm, uint64_t n, unsigned int* list, unsigned int* cnt, uint64_t split) {
         if (!n) return;
         const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(((n + 31) / 32 + 255) / 256, 2048));
-        hipLaunchKernelGGL(compact_touched_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, bm, n, list, cnt);
+        hipLaunchKernelGGL(compact_touched_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, bm, n, list, cnt, split, n);
     };
-    go(touch_v, n_rows, v_list, n_list + 0);
-    go(touch_p, n_prows, p_list, n_list + 1);
-    go(touch_e, n_ids, e_list, n_list + 2);
+    // n_list: [0] V rows, [1] (unused), [2] reference k-mer ids (front of e_list), [3] pseudo k-mer ids (its tail), [4] pseudo rows
+    go(touch_v, n_rows, v_list, n_list + 0, ~0ull);
+    go(touch_p, n_prows, p_list, n_list + 4, ~0ull);
+    go(touch_e, n_ids, e_list, n_list + 2, n_full);
 }
 // ... and when a sample's maps are done: the listed rows / counters are zeroed again (the plane holds nothing else)
 __global__ __launch_bounds__(256) void clear_touched_kernel(unsigned long long* counters, uint64_t v_off, uint64_t v_real, uint32_t rl,
                                                             const unsigned int* v_list, const unsigned int* p_list, const unsigned int* e_list,
-                                                            const unsigned int* n_list) {
+                                                            const unsigned int* n_list, uint64_t n_ids) {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, nt = (uint64_t)gridDim.x * 256;
     unsigned long long* vc = counters + v_off;
     for (uint64_t i = t; i < (uint64_t)n_list[0] * rl; i += nt) vc[(uint64_t)v_list[i / rl] * rl + i % rl] = 0ull;
-    for (uint64_t i = t; i < (uint64_t)n_list[1] * 8ull; i += nt) vc[v_real + (uint64_t)p_list[i >> 3] * 8ull + (i & 7ull)] = 0ull;
+    for (uint64_t i = t; i < (uint64_t)n_list[4] * 8ull; i += nt) vc[v_real + (uint64_t)p_list[i >> 3] * 8ull + (i & 7ull)] = 0ull;
     for (uint64_t i = t; i < (uint64_t)n_list[2] * 2ull; i += nt) counters[2ull * e_list[i >> 1] + (i & 1ull)] = 0ull;
+    for (uint64_t i = t; i < (uint64_t)n_list[3] * 2ull; i += nt) counters[2ull * e_list[n_ids - 1 - (i >> 1)] + (i & 1ull)] = 0ull;
 }
 void launch_clear_touched(unsigned long long* counters, uint64_t v_off, uint64_t v_real_len, uint32_t rl, const unsigned int* v_list,
-                          const unsigned int* p_list, const unsigned int* e_list, const unsigned int* n_list, hipStream_t stream) {
-    hipLaunchKernelGGL(clear_touched_kernel, dim3(2048), dim3(256), 0, stream, counters, v_off, v_real_len, rl, v_list, p_list, e_list, n_list);
+                          const unsigned int* p_list, const unsigned int* e_list, const unsigned int* n_list, uint64_t n_ids, hipStream_t stream) {
+    hipLaunchKernelGGL(clear_touched_kernel, dim3(2048), dim3(256), 0, stream, counters, v_off, v_real_len, rl, v_list, p_list, e_list, n_list, n_ids);
 }
 
 size_t finalize_lds_bytes(int n_files) { return ((size_t)n_files * 5 + 4) * sizeof(uint32_t); }
-constexpr unsigned kFinVariantBlocks = 256 * 8, kFinExactBlocks = 256 * 8, kFinGeneralBlocks = 256 * 16;
+constexpr unsigned kFinVariantBlocks = 256 * 8, kFinExactBlocks = 256 * 8, kFinGeneralBlocks = 256 * 32;
 size_t finalize_partial_rows() { return (size_t)kFinVariantBlocks + kFinExactBlocks + kFinGeneralBlocks; }
 
 void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
@@ -2049,7 +2108,7 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     hipLaunchKernelGGL(finalize_exact_kernel, dim3(b_ex), dim3(256), lds_votes, stream, a);
     // K2b (deferred k-mers only; the kernel reads their number on the device)
     // (few genomes: multi-bucket k-mers are rare, a small grid starts and ends quickly; many: one k-mer in eight takes this path)
-    unsigned b_gen = (unsigned)std::min<size_t>(a.ix.n_files >= 8 ? kFinGeneralBlocks : kFinGeneralBlocks / 16, 256 * std::max<size_t>(1, (160u * 1024u) / lds));
+    unsigned b_gen = (unsigned)std::min<size_t>(a.ix.n_files >= 8 ? kFinGeneralBlocks : kFinGeneralBlocks / 32, 256 * std::max<size_t>(1, (160u * 1024u) / lds));
     a.row_general = (int)(b_var + b_ex);
     hipLaunchKernelGGL(finalize_general_kernel, dim3(b_gen), dim3(64), lds, stream, a);
     if (a.partials && a.mode != 2) {

@@ -708,3 +708,43 @@ def test_votes_for_the_selected_genome_only(oracle, sars_paths):
         oracle.lib().orc_free(out)
         eng.close()
         ix.close()
+
+
+@pytest.mark.parametrize("selected_only", [False, True])
+def test_sparse_finalize_on_a_small_index(oracle, sars_paths, monkeypatch, testing_lib, selected_only):
+    """An index above 16 M counters finalizes from touch lists (bk_engine.cpp alloc_sample_state); BK_SPARSE_FINALIZE forces that
+    path here, on four SARS-CoV-2 strains with paired reads and on twelve HPV16 strains at k = 31 (pseudo k-mers).  The engine is
+    used for a sample that is begun, pushed and abandoned, then for two whole samples: each equals the oracle's."""
+    from bronko_amd import Params, pack_reads
+    monkeypatch.setenv("BK_SPARSE_FINALIZE", "1")
+    cases = []
+    ix = oracle.Index.build(21, sars_paths)
+    gm, isnv = synth.sample_genome(synth.read_fasta_bytes(sars_paths[2]), 81)
+    c1, c2 = synth.paired_codes(gm, 15000, 150, 81, isnv=isnv)
+    cases.append((ix, [synth.codes_to_ascii(c1), synth.codes_to_ascii(c2)], 21))
+    files = _mutated_strains(synth.read_fasta_bytes(os.path.join(helpers.GOLDEN, "HPV16.fa")), 12, 60, 91)
+    ix2 = oracle.Index.build_mem(31, files)
+    gm, isnv = synth.sample_genome(files[7][1][0][1], 82)
+    cases.append((ix2, [synth.codes_to_ascii(synth.single_end_codes(gm, 12000, 150, 82, isnv=isnv))], 31))
+    for ix, mates, k in cases:
+        pile = oracle.sample_pileup(ix, mates)
+        best = oracle.pick_best_genome(ix, pile.stats.sum(axis=0), pile.present.max(axis=0))
+        eng = helpers.engine_from_oracle_index(ix, Params(pileup_selected_only=selected_only))
+        eng.sample_begin()                                   # abandoned: its counts must not leak into the next sample
+        words, lens = pack_reads(mates[0][:3000], k, None)
+        eng.push_reads(0, words, lens)
+        for rep in range(2):
+            res = helpers.hip_sample(eng, mates, k)
+            assert np.array_equal(res.stats, pile.stats) and np.array_equal(res.present, pile.present)
+            if not selected_only:
+                helpers.assert_same_pileup(res, pile)
+                continue
+            lo, n = ix.genome_cells(best)
+            for name in ("fwd_depth", "rev_depth", "fwd_nk", "rev_nk"):
+                got, ref = getattr(res, name), getattr(pile, name)
+                assert np.array_equal(got[lo * 4:(lo + n) * 4], ref[lo * 4:(lo + n) * 4]), name
+                assert not got[:lo * 4].any() and not got[(lo + n) * 4:].any(), name
+        with pytest.raises(Exception):
+            eng.counters_ptr(0)                              # sharding one sample's reads needs the dense plane
+        eng.close()
+        ix.close()

@@ -12,10 +12,13 @@ dev = torch.device("cuda", 0)
 g, isnv = synth.sample_genome(synth.read_fasta_bytes(paths[0]), 2)
 c = synth.single_end_codes_torch(g, 1000000, 150, 2000006, isnv=isnv, device=dev)
 w, l = synth.pack_codes_torch(c)
-for mode in sys.argv[1:] or ["release", "testing", "stats"]:
+for mode in sys.argv[1:] or ["release", "testing", "sparse", "stats"]:
     _ffi.use_testing_library(mode != "release")
+    os.environ.pop("BK_SPARSE_FINALIZE", None)
     if mode == "stats":
         os.environ["BK_L2_STATS"] = "1"
+    if mode == "sparse":                       # the touch-list finalize of large indexes, forced onto this small one
+        os.environ["BK_SPARSE_FINALIZE"] = "1"
     ix = HostIndex.build(21, paths, threads=4)
     eng = ix.engine(Params())
     for rep in range(3):

@@ -54,7 +54,7 @@ SYMBOLS = ["bk_abi_version", "bk_device_count", "bk_last_error", "bk_params_defa
            "bk_push_reads_packed", "bk_push_reads_packed_device", "bk_push_reads_ascii", "bk_counters_device_ptr", "bk_sample_finalize",
            "bk_sample_finalize_shard", "bk_shard_sums_device_ptr", "bk_sample_merge_shards",
            "bk_pileup_device_ptr", "bk_sample_download", "bk_sample_finish", "bk_pack_reads", "bk_pack_reads_flat",
-           "bk_timing_enable", "bk_timing_read", "bk_call_params_default", "bk_sample_call", "bk_sample_download_calls",
+           "bk_timing_enable", "bk_timing_read", "bk_call_params_default", "bk_sample_call", "bk_sample_download_calls", "bk_sample_download_noise",
            "bk_build_index", "bk_built_index_free", "bk_build_last_error"]
 
 _libs = {}
@@ -127,6 +127,8 @@ def load(testing=None):
     L.bk_sample_call.argtypes = [vp, C.c_int, C.POINTER(CallParams)]
     L.bk_sample_download_calls.restype = C.c_int
     L.bk_sample_download_calls.argtypes = [vp, C.POINTER(CallSummary), vp, u64]
+    L.bk_sample_download_noise.restype = C.c_int
+    L.bk_sample_download_noise.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.bk_build_index.restype = C.c_int
     L.bk_build_index.argtypes = [i32, i32, vp, vp, vp, i32, C.POINTER(BuiltIndex)]
     L.bk_built_index_free.argtypes = [C.POINTER(BuiltIndex)]

@@ -46,37 +46,44 @@ __global__ void select_genome_kernel(CallArgs a) {
     a.out->n_records = 0; a.out->n_major = 0; a.out->n_minor = 0; a.out->covered = 0; a.out->positions = 0; a.out->coverage = 0;
 }
 
-// get_baseline_noise for sequence blockIdx.x of the selected genome.  All threads: the sorted minor-allele frequencies of
-// every position (call.rs:831-845).  Thread 0: the sliding window (call.rs:848-962), writing Noise.max per position.
+// get_baseline_noise for sequence blockIdx.x of the selected genome (call.rs:799-967).  The reference walks the positions with
+// a window of the last 100: running sums of the minor-allele frequencies in it (position by position -- any other order of the
+// same additions rounds differently) and a table of the ten largest values (a state machine of its own: an evicted value is
+// removed, the eleventh largest does not move up).  Both are chains over ~30 k positions, so what counts is the latency of a
+// step; a first version that kept the table in LDS and walked with one thread took 66 ms for SARS-CoV-2.  Here:
+//   * all threads: the sorted minor-allele frequencies of the next kNoiseChunk positions (call.rs:831-845) into LDS, with the
+//     100 positions before them -- the value that leaves the window is read from there, no ring buffer;
+//   * wave 0, 64 positions at a time: every lane carries the same running sums, lane q < 10 holds table entry q; removal and
+//     insertion are a ballot, a count of trailing zeros and a one-lane DPP shift; the state after each position (sums, table)
+//     is left in LDS;
+//   * wave 0, one lane per position of those 64: the Thompson-tau stripping (call.rs:917-950: divisions, square roots) from
+//     that state -- independent of the other positions.
 constexpr int kNoiseWindow = 100, kNoiseTop = kNoiseWindow / 10, kNoiseHalf = kNoiseWindow / 2;   // call.rs:802-804,824
+constexpr int kNoiseChunk = 1024;
+// the value of lane - 1 / lane + 1 within the row of 16 lanes (0 at the row's ends): the table is 10 lanes of one row
+__device__ __forceinline__ double row_from_below(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)u, 0x111, 0xf, 0xf, true);           // row_shr:1
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(u >> 32), 0x111, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double row_from_above(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)u, 0x101, 0xf, 0xf, true);           // row_shl:1
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(u >> 32), 0x101, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __global__ __launch_bounds__(256) void noise_kernel(CallArgs a) {
-    __shared__ double ring[kNoiseWindow * 3];
-    __shared__ unsigned char flagged[kNoiseWindow * 3];
-    __shared__ double top[kNoiseTop];
     __shared__ double tau_s[kNoiseWindow * 3 + 1];
+    __shared__ double fr_s[(kNoiseChunk + kNoiseWindow) * 3];   // positions base - 100 .. base + chunk
+    __shared__ double st_s[64], st_s2[64], st_top[64 * kNoiseTop];   // the state after each of 64 positions
+    __shared__ unsigned int st_n[64];
     const int file = a.out->file_id;
     if (file < 0 || (int)blockIdx.x >= a.n_seqs[file]) return;
     const int sq = a.seq_first[file] + (int)blockIdx.x;
     const uint64_t cell0 = a.seq_cell[sq], len = a.seq_len[sq];
     const unsigned long long* fd = a.pileup + 0 * a.plane + cell0 * 4;
     const unsigned long long* rd = a.pileup + 1 * a.plane + cell0 * 4;
-    double* fr = a.freq + cell0 * 3;
-    for (uint64_t i = threadIdx.x; i < len; i += blockDim.x) {
-        unsigned long long c0 = fd[i * 4 + 0] + rd[i * 4 + 0], c1 = fd[i * 4 + 1] + rd[i * 4 + 1];
-        unsigned long long c2 = fd[i * 4 + 2] + rd[i * 4 + 2], c3 = fd[i * 4 + 3] + rd[i * 4 + 3];
-        unsigned long long t;   // descending (a sorting network; equal values are interchangeable)
-        if (c0 < c1) { t = c0; c0 = c1; c1 = t; }
-        if (c2 < c3) { t = c2; c2 = c3; c3 = t; }
-        if (c0 < c2) { t = c0; c0 = c2; c2 = t; }
-        if (c1 < c3) { t = c1; c1 = c3; c3 = t; }
-        if (c1 < c2) { t = c1; c1 = c2; c2 = t; }
-        const unsigned long long depth = c0 + c1 + c2 + c3;
-        fr[i * 3 + 0] = depth ? __ddiv_rn((double)c1, (double)depth) : 0.0;
-        fr[i * 3 + 1] = depth ? __ddiv_rn((double)c2, (double)depth) : 0.0;
-        fr[i * 3 + 2] = depth ? __ddiv_rn((double)c3, (double)depth) : 0.0;
-    }
-    for (int i = threadIdx.x; i < kNoiseWindow * 3; i += blockDim.x) { ring[i] = 0.0; flagged[i] = 0; }
-    for (int i = threadIdx.x; i < kNoiseTop; i += blockDim.x) top[i] = 0.0;
     for (int n = threadIdx.x; n <= kNoiseWindow * 3; n += blockDim.x) {   // thompson_tau(n), call.rs:922-929
         double tau = INFINITY;
         if (n > 2) {
@@ -85,63 +92,110 @@ __global__ __launch_bounds__(256) void noise_kernel(CallArgs a) {
         }
         tau_s[n] = tau;
     }
-    __threadfence_block();
-    __syncthreads();
-    if (threadIdx.x != 0) return;
 
     double* out = a.noise + cell0;
-    unsigned long long n = 0;
+    const int lane = threadIdx.x & 63;
+    const bool in_table = threadIdx.x < (unsigned)kNoiseTop;
+    unsigned int n = 0;          // wave 0: the same in every lane
     double s = 0.0, s2 = 0.0;
-    for (uint64_t i = 0; i < len + kNoiseHalf; ++i) {
-        const size_t slot0 = (size_t)(i % kNoiseWindow) * 3;
-        for (int r = 1; r < 4; ++r) {                               // minor ranks 1..3, call.rs:848
-            const size_t slot = slot0 + (size_t)(r - 1);
-            const double old = ring[slot];
-            if (old > 0.0) {                                        // evict, call.rs:853-870
-                n -= 1; s -= old; s2 -= old * old;
-                if (flagged[slot]) {
-                    for (int q = 0; q < kNoiseTop; ++q) {
-                        if (fabs(top[q] - old) < 1e-12) {
-                            for (int z = q; z + 1 < kNoiseTop; ++z) top[z] = top[z + 1];
-                            top[kNoiseTop - 1] = 0.0;
-                            break;
+    double top = 0.0;            // wave 0, lane q < 10: entry q of the table (descending, zeros behind the values); 0 elsewhere
+    for (uint64_t base = 0; base < len + kNoiseHalf; base += kNoiseChunk) {
+        __syncthreads();   // (the walk over the previous chunk is done; the tau table is written)
+        for (int64_t j = threadIdx.x; j < kNoiseChunk + kNoiseWindow; j += blockDim.x) {
+            const int64_t i = (int64_t)base - kNoiseWindow + j;
+            double f1 = 0.0, f2 = 0.0, f3 = 0.0;
+            if (i >= 0 && (uint64_t)i < len) {
+                unsigned long long c0 = fd[i * 4 + 0] + rd[i * 4 + 0], c1 = fd[i * 4 + 1] + rd[i * 4 + 1];
+                unsigned long long c2 = fd[i * 4 + 2] + rd[i * 4 + 2], c3 = fd[i * 4 + 3] + rd[i * 4 + 3];
+                unsigned long long t;   // descending (a sorting network; equal values are interchangeable)
+                if (c0 < c1) { t = c0; c0 = c1; c1 = t; }
+                if (c2 < c3) { t = c2; c2 = c3; c3 = t; }
+                if (c0 < c2) { t = c0; c0 = c2; c2 = t; }
+                if (c1 < c3) { t = c1; c1 = c3; c3 = t; }
+                if (c1 < c2) { t = c1; c1 = c2; c2 = t; }
+                const unsigned long long depth = c0 + c1 + c2 + c3;
+                if (depth) { f1 = __ddiv_rn((double)c1, (double)depth); f2 = __ddiv_rn((double)c2, (double)depth); f3 = __ddiv_rn((double)c3, (double)depth); }
+            }
+            fr_s[j * 3 + 0] = f1; fr_s[j * 3 + 1] = f2; fr_s[j * 3 + 2] = f3;
+        }
+        __syncthreads();
+        if (threadIdx.x >= 64) continue;
+        const uint64_t i_end = min(base + (uint64_t)kNoiseChunk, len + (uint64_t)kNoiseHalf);
+        for (uint64_t b0 = base; b0 < i_end; b0 += 64) {
+            const int nb = (int)min((uint64_t)64, i_end - b0);
+            // (the six values of a position are asked for one position ahead: they depend on nothing the walk computes)
+            const double* cur0 = fr_s + (size_t)(b0 - base + kNoiseWindow) * 3;   // position b0; cur - 300: b0 - 100
+            double nold[3] = {cur0[0 - kNoiseWindow * 3], cur0[1 - kNoiseWindow * 3], cur0[2 - kNoiseWindow * 3]};
+            double nmaf[3] = {cur0[0], cur0[1], cur0[2]};
+            for (int t = 0; t < nb; ++t) {
+                const double olds[3] = {nold[0], nold[1], nold[2]}, mafs[3] = {nmaf[0], nmaf[1], nmaf[2]};
+                if (t + 1 < nb) {
+                    const double* nx = cur0 + (size_t)(t + 1) * 3;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) { nold[r] = nx[r - kNoiseWindow * 3]; nmaf[r] = nx[r]; }
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {                           // minor ranks 1..3, call.rs:848
+                    const double old = olds[r];                         // what position i - 100 put there (0: nothing)
+                    if (old > 0.0) {                                    // evict, call.rs:853-870 (a value above 0 is always flagged)
+                        n -= 1; s -= old; s2 -= old * old;
+                        // the first entry equal to it goes, the entries behind it move up
+                        const unsigned long long hit = __ballot(in_table && fabs(top - old) < 1e-12);
+                        if (hit) {
+                            const double above = row_from_above(top);
+                            if (in_table && lane >= __builtin_ctzll(hit)) top = lane + 1 < kNoiseTop ? above : 0.0;
                         }
                     }
-                    flagged[slot] = 0;
+                    const double maf = mafs[r];                         // (zeros past the sequence's end)
+                    if (maf > 0.0) {                                    // insert, call.rs:873-890
+                        n += 1; s += maf; s2 += maf * maf;
+                        // from the bottom up while it is larger: the table is sorted, so those entries are its tail
+                        const unsigned long long larger = __ballot(in_table && maf > top);
+                        // lowest entry of the tail: one above the highest entry that is not smaller
+                        const unsigned long long not_larger = ~larger & ((1ull << kNoiseTop) - 1ull);
+                        const int p = not_larger ? 64 - (int)__builtin_clzll(not_larger) : 0;
+                        if (p < kNoiseTop) {
+                            const double below = row_from_below(top);
+                            if (in_table && lane > p) top = below;
+                            if (lane == p) top = maf;
+                        }
+                    }
                 }
+                if (lane == 0) { st_n[t] = n; st_s[t] = s; st_s2[t] = s2; }
+                if (in_table) st_top[t * kNoiseTop + lane] = top;
             }
-            const double maf = i < len ? fr[i * 3 + (r - 1)] : 0.0;
-            if (maf > 0.0) {                                        // insert, call.rs:873-890
-                n += 1; s += maf; s2 += maf * maf;
-                for (int q = kNoiseTop - 1; q >= 0; --q) {
-                    if (!(maf > top[q])) break;
-                    if (q + 1 < kNoiseTop) top[q + 1] = top[q];
-                    top[q] = maf;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the state is read by other lanes of this wave)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // strip outliers (call.rs:917-950), one lane per position, from the state the walk left after it
+            if (lane < nb) {
+                const uint64_t i = b0 + (uint64_t)lane;
+                const unsigned int n0 = st_n[lane];
+                const double s0 = st_s[lane], s20 = st_s2[lane];
+                const double* tp = st_top + lane * kNoiseTop;
+                double mu = 0.0, var = 0.0;
+                if (n0 != 0) { mu = __ddiv_rn(s0, (double)n0); var = __ddiv_rn(s20, (double)n0) - mu * mu; }   // population variance, call.rs:901-907
+                int idx = 0;
+                unsigned int cn = n0;
+                double cs = s0, cs2 = s20;
+                while (idx < kNoiseTop && tp[idx] != 0.0) {
+                    const double cand = tp[idx];
+                    const double tau = cn <= (unsigned int)(kNoiseWindow * 3) ? tau_s[cn] : NAN;
+                    if (!(fabs(cand - mu) > tau * __dsqrt_rn(var))) break;
+                    cs -= cand;
+                    cs2 -= cand;                                        // sic (call.rs:936): the value, not its square
+                    cn -= 1;
+                    if (cn > 0) { mu = __ddiv_rn(cs, (double)cn); var = __ddiv_rn(cs2, (double)cn) - mu * mu; }
+                    else { mu = 0.0; var = 0.0; }
+                    idx++;
                 }
-                flagged[slot] = 1;                                  // set whether or not it entered the table
-            } else {
-                flagged[slot] = 0;
+                if (i >= (uint64_t)kNoiseHalf && i - kNoiseHalf < len)  // call.rs:953-962
+                    out[i - kNoiseHalf] = idx < kNoiseTop ? tp[idx] : 0.0;
             }
-            ring[slot] = maf;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        double mu = 0.0, var = 0.0;
-        if (n != 0) { mu = __ddiv_rn(s, (double)n); var = __ddiv_rn(s2, (double)n) - mu * mu; }   // population variance, call.rs:901-907
-        int idx = 0;
-        unsigned long long cn = n;
-        double cs = s, cs2 = s2;
-        while (idx < kNoiseTop && top[idx] != 0.0) {                // strip outliers, call.rs:917-950
-            const double cand = top[idx];
-            const double tau = cn <= (unsigned long long)(kNoiseWindow * 3) ? tau_s[cn] : NAN;
-            if (!(fabs(cand - mu) > tau * __dsqrt_rn(var))) break;
-            cs -= cand;
-            cs2 -= cand;                                            // sic (call.rs:936): the value, not its square
-            cn -= 1;
-            if (cn > 0) { mu = __ddiv_rn(cs, (double)cn); var = __ddiv_rn(cs2, (double)cn) - mu * mu; }
-            else { mu = 0.0; var = 0.0; }
-            idx++;
-        }
-        if (i >= (uint64_t)kNoiseHalf && i - kNoiseHalf < len)      // call.rs:953-962
-            out[i - kNoiseHalf] = idx < kNoiseTop ? top[idx] : 0.0;
     }
 }
 

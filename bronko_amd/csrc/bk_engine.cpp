@@ -1672,6 +1672,7 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             fprintf(stderr, "[bk] sparse finalize (mate file 0): %u V rows of %llu, %u pseudo rows of %llu, %u reference k-mers of %u and %u pseudo k-mers of %u touched\n",
                     nl[0], (unsigned long long)bk::v_real_rows(e->n_full, e->v_span), nl[4], (unsigned long long)e->n_prows, nl[2], e->n_full, nl[3], e->n_u - e->n_full);
         }
+        fprintf(stderr, "[bk] scan N batches: %llu with %llu pieces (%.1f per batch), %llu of them forced by a tile's end\n", h[20], h[21], h[20] ? (double)h[21] / (double)h[20] : 0.0, h[22]);
         fprintf(stderr, "[bk] scan marked: no-diagonal %llu, dirty-head %llu, clean-head %llu, pairs %llu | level 2: k-mers %llu in %llu chunks, simple %llu, dead %llu, "
                 "dirty answers %llu (one difference but id unknown: %llu), slow %llu (diffs 0/1/2/3+ with a diagonal: %llu/%llu/%llu/%llu) -> member %llu, neighbour %llu, nothing %llu\n",
                 h[0], h[1], h[2], h[3], h[4], h[11], h[5], h[6], h[16], h[17], h[7], h[12], h[13], h[14], h[15], h[8], h[9], h[10]);
@@ -1810,6 +1811,21 @@ int bk_sample_download_calls(bk_engine* e, bk_call_summary* summary, bk_call_rec
             return x.alt_base < y.alt_base;
         });
     }
+    return BK_OK;
+}
+
+int bk_sample_download_noise(bk_engine* e, double* out, uint64_t cap, uint64_t* n) {
+    if (!e || !n) return fail(BK_ERR_INVALID, "null argument");
+    if (!e->call_out.p) return fail(BK_ERR_STATE, "bk_sample_download_noise comes after bk_sample_call");
+    BK_HIP(hipSetDevice(e->device));
+    bk_call_summary summ;
+    BK_HIP(hipMemcpyAsync(&summ, e->call_out.p, sizeof summ, hipMemcpyDeviceToHost, e->stream));
+    BK_HIP(hipStreamSynchronize(e->stream));
+    *n = 0;
+    if (summ.file_id < 0 || summ.file_id >= e->n_files) return BK_OK;
+    const uint64_t lo = e->file_cell_lo[(size_t)summ.file_id], hi = summ.file_id + 1 < e->n_files ? e->file_cell_lo[(size_t)summ.file_id + 1] : e->total_cells;
+    *n = hi - lo;
+    if (out && cap) BK_HIP(hipMemcpy(out, e->call_noise.p + lo, (size_t)std::min<uint64_t>(cap, hi - lo) * sizeof(double), hipMemcpyDeviceToHost));
     return BK_OK;
 }
 

@@ -642,6 +642,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 // still wants them).  K-mers without a mismatch (a read off the LDS window), at dirty cells or without a diagonal
                 // go to Level 2 as a chunk; what is left of the piece comes back here.
                 const uint32_t nb2 = min(qs, 64u);
+                BK_DBG(a, 20, lane == 0, 1); BK_DBG(a, 21, lane == 0, nb2); BK_DBG(a, 22, lane == 0 && qs < 64u, 1);
                 const uint32_t ent = (uint32_t)lane < nb2 ? rqs[lane] : 0u;
                 {   // move the rest of the queue down
                     const uint32_t rest = qs - nb2;
@@ -857,7 +858,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     // ---- epilogue: difference array -> per-cell counts (prefix sum over the workgroup), written as this workgroup's slab ----
     if (threadIdx.x == 0) *block_kmers = 0;
     __syncthreads();
-    {
+    if (!BK_ABLATE(a, 8)) {   // (8: without the prefix sum and the slab)
         const uint32_t nb = a.n_lds_bins;
         const uint32_t per = (nb + kScanBlock - 1) / kScanBlock;
         const uint32_t b0 = min(threadIdx.x * per, nb), b1 = min(b0 + per, nb);

@@ -249,6 +249,13 @@ class Engine:
         _check(self._L.bk_sample_download_calls(self.h, C.byref(summ), recs, cap), self._L)
         return summ, [recs[i] for i in range(min(summ.n_records, cap))]
 
+    def download_noise(self):
+        """Noise.max per position of the genome sample_call selected (diagnostic; call.rs:953-962)."""
+        n = C.c_uint64(0)
+        out = np.zeros(max(1, self.total_cells), np.float64)
+        _check(self._L.bk_sample_download_noise(self.h, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n)), self._L)
+        return out[:n.value]
+
     def timing_enable(self, on=True):
         _check(self._L.bk_timing_enable(self.h, int(on)), self._L)
 

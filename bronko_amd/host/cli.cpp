@@ -298,6 +298,8 @@ struct BatchQueue {
     std::mutex m;
     std::condition_variable cv;
     std::deque<FastqBatch> q;
+    std::vector<FastqBatch> spare;   // consumed batches, handed back: their 40 MB buffers are reused instead of being unmapped and
+                                     // mapped again (with dozens of lanes the page faults of fresh buffers cost more than the parsing)
     static constexpr size_t kDepth = 3;
     void put(FastqBatch&& b) {
         std::unique_lock<std::mutex> lk(m);
@@ -313,9 +315,22 @@ struct BatchQueue {
         cv.notify_all();
         return b;
     }
+    void recycle(FastqBatch&& b) {
+        std::unique_lock<std::mutex> lk(m);
+        if (spare.size() < kDepth + 2) spare.push_back(std::move(b));
+    }
+    FastqBatch fresh() {
+        FastqBatch b;
+        {
+            std::unique_lock<std::mutex> lk(m);
+            if (!spare.empty()) { b = std::move(spare.back()); spare.pop_back(); }
+        }
+        b.buf.clear(); b.off.clear(); b.off.push_back(0); b.last = false; b.error.clear();
+        return b;
+    }
 };
 void parse_fastq(const std::string& path, BatchQueue& out) {
-    constexpr uint64_t kBatchReads = 1u << 18;
+    constexpr uint64_t kBatchReads = 1u << 16;   // (10 MB of bases: the engine pins three staging slots of that size per lane)
     FastqBatch cur;
     try {
         GzLineReader in(path);
@@ -325,7 +340,7 @@ void parse_fastq(const std::string& path, BatchQueue& out) {
             if ((ln++ & 3) != 1) continue;           // 4-line FASTQ records: @id / sequence / + / quality
             cur.buf += line;
             cur.off.push_back(cur.buf.size());
-            if (++n % kBatchReads == 0) { out.put(std::move(cur)); cur = FastqBatch(); }
+            if (++n % kBatchReads == 0) { out.put(std::move(cur)); cur = out.fresh(); }
         }
     } catch (const std::exception& e) {
         cur = FastqBatch();
@@ -352,6 +367,7 @@ uint64_t push_fastqs(bk_engine* e, const std::vector<std::string>& mates) {
                 n_reads += b.off.size() - 1;
             }
             if (b.last) { done[m] = true; left--; }
+            else queues[m].recycle(std::move(b));   // (bk_push_reads_ascii has copied it to its pinned ring)
         }
     }
     for (auto& t : readers) t.join();
@@ -389,9 +405,14 @@ int run_call(const Args& a) {
     }
 
     // decoded index -> GPU engine(s) (include/bronko_hip.h).  Samples are independent (call.rs:212 / :297 handle them one after
-    // the other), so with several GPUs whole samples go to the devices in turn -- no collective; every device holds its own
-    // copy of the tables.  BRONKO_DEVICES=0,1,.. names the devices (default: all visible ones; a device may be named more
-    // than once: as many independent lanes on it), BRONKO_DEVICE=d the single device of earlier versions.
+    // the other), so whole samples are dealt to *lanes* in turn -- no collective.  A lane is a host thread that ingests its
+    // samples (gunzip + parse are host work: ~1 M reads/s per FASTQ file, a thousand times slower than the scan behind them)
+    // into its own pair of engines; the lanes of one device share that device's tables (bk_engine_fork), every device holds
+    // its own copy.  BRONKO_DEVICES=0,1,.. names the devices (default: all visible ones; naming a device twice doubles its
+    // lanes), BRONKO_DEVICE=d the single device of earlier versions, BRONKO_LANES=n the lanes per device (default: -t / 2
+    // over the devices, at most 16 -- a 256-thread host inflates 8 gzip streams side by side at full speed and 32 at half --
+    // and no more than fit a quarter of the device's memory: a lane keeps two samples'
+    // counter planes there -- 0.2 GB for one SARS-CoV-2 genome, 9 GB for a hundred at k = 31).
     std::vector<int> devices;
     if (const char* dl = getenv("BRONKO_DEVICES")) {
         for (const char* q = dl; *q;) {
@@ -431,18 +452,47 @@ int run_call(const Args& a) {
         p.device = device;
         hip_check(bk_engine_create(&d, &p, &out.e), "bk_engine_create");
     };
-    struct Lane { int device = 0; Engine eng, fork; std::vector<size_t> mine; };
+    struct Lane { int device = 0; int parent = -1; Engine eng, fork; std::vector<size_t> mine; };   // parent: the lane whose engine built the device's tables
+    std::vector<Engine> first(devices.size());   // the first engine of every device named: its tables, and what a sample's state weighs
+    std::vector<int> first_dev(devices.size(), -1);
+    {
+        std::vector<std::thread> th;   // table construction is host work: the devices' engines are created side by side
+        for (size_t l = 0; l < devices.size(); l++) {
+            bool seen = false;
+            for (size_t q = 0; q < l; q++) seen = seen || devices[q] == devices[l];
+            if (!seen) { first_dev[l] = devices[l]; th.emplace_back([&make_engine, &devices, &first, l] { make_engine(devices[l], first[l]); }); }
+        }
+        for (auto& t : th) t.join();
+    }
+    {
+        size_t per_device = std::min<size_t>(16, std::max<size_t>(1, (size_t)a.threads / 2 / devices.size()));
+        for (const auto& f : first) {
+            if (!f.e) continue;
+            const double per_engine = 3.0 * 8.0 * (double)bk_counter_len(f.e) + 64.0 * (double)bk_total_cells(f.e) + 64e6;   // planes, lists, pileups, scratch
+            per_device = std::min<size_t>(per_device, std::max<size_t>(1, (size_t)(64e9 / (2.0 * per_engine))));
+        }
+        if (const char* nl = getenv("BRONKO_LANES")) per_device = std::max<size_t>(1, (size_t)atoi(nl));
+        std::vector<int> lanes_on;
+        for (size_t r = 0; r < per_device; r++)                       // device-major rounds: every device gets a lane before any gets two
+            for (int d : devices) lanes_on.push_back(d);
+        if (lanes_on.size() > std::max<size_t>(n_samples_total, 1)) lanes_on.resize(std::max<size_t>(n_samples_total, 1));
+        devices.swap(lanes_on);
+    }
     std::vector<Lane> lanes(devices.size());
-    for (size_t l = 0; l < lanes.size(); l++) lanes[l].device = devices[l];
+    for (size_t l = 0; l < lanes.size(); l++) {
+        lanes[l].device = devices[l];
+        for (size_t q = 0; q < l && lanes[l].parent < 0; q++)
+            if (lanes[q].device == devices[l]) lanes[l].parent = (int)(lanes[q].parent < 0 ? q : (size_t)lanes[q].parent);
+    }
     if (lanes.size() > 1) {
         std::string names;
         for (int d : devices) names += (names.empty() ? "" : ",") + std::to_string(d);
         LOG_INFO(T, "Samples go to " + std::to_string(lanes.size()) + " GPU lanes in turn (devices " + names + ")");
     }
-    {
-        std::vector<std::thread> th;   // table construction is host work: the lanes' engines are created side by side
-        for (auto& ln : lanes) th.emplace_back([&make_engine, &ln] { make_engine(ln.device, ln.eng); });
-        for (auto& t : th) t.join();
+    for (auto& ln : lanes) {
+        if (ln.parent >= 0) { hip_check(bk_engine_fork(lanes[(size_t)ln.parent].eng.e, &ln.eng.e), "bk_engine_fork"); continue; }
+        for (size_t q = 0; q < first.size(); q++)
+            if (first[q].e && !ln.eng.e && first_dev[q] == ln.device) std::swap(ln.eng.e, first[q].e);
     }
 
     CallParams cp;
@@ -572,6 +622,12 @@ int run_call(const Args& a) {
     else {
         std::vector<std::thread> th;
         for (auto& ln : lanes) th.emplace_back([&run_lane, &ln] { run_lane(ln); });
+        for (auto& t : th) t.join();
+    }
+    {   // (forks go before the engine they were forked from; side by side: releasing dozens of engines one after the other takes a second)
+        std::vector<std::thread> th;
+        for (auto& ln : lanes)
+            if (ln.parent >= 0 && ln.eng.e) th.emplace_back([&ln] { bk_engine_destroy(ln.eng.e); ln.eng.e = nullptr; });
         for (auto& t : th) t.join();
     }
     LOG_INFO(T, "Printing overview");

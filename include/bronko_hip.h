@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BK_ABI_VERSION 5
+#define BK_ABI_VERSION 6
 
 typedef enum {
     BK_OK = 0,
@@ -233,6 +233,10 @@ typedef struct {
 void bk_call_params_default(bk_call_params* p);
 int  bk_sample_call(bk_engine* e, int n_mates, const bk_call_params* p);
 int  bk_sample_download_calls(bk_engine* e, bk_call_summary* summary, bk_call_record* records, uint64_t cap);
+/* Diagnostic: Noise.max of get_baseline_noise (call.rs:953-962) for every position of the genome bk_sample_call selected, in
+ * (sequence, position) order -- what call_variants' AF filter compared with (call.rs:1107).  `cap` doubles at `out`; returns
+ * the number of positions through *n (0 when no genome was selected).  Synchronises. */
+int  bk_sample_download_noise(bk_engine* e, double* out, uint64_t cap, uint64_t* n);
 
 /* ---- build_indexes on the device (optional) -----------------------------------------------------
  * build.rs:145-231 for the metadata sequences given like bk_index_desc gives them: one thread per k-mer writes its k

@@ -259,6 +259,11 @@ class Index:
         n = sum(L.orc_index_seq_len(self.h, f, s) for s in range(ns))
         return first, n
 
+    def sequence_cells(self, f):
+        """[(first_cell, length)] of the sequences of file f"""
+        L = lib()
+        return [(L.orc_index_cell_offset(self.h, f, s), L.orc_index_seq_len(self.h, f, s)) for s in range(L.orc_index_n_seqs(self.h, f))]
+
 
 def count_kmers(k, reads, ci=3, cs=1000000, cx=1000000000):
     """KMC contract on a list of ASCII reads -> (kmers u64[], counts u64[], stats[4])"""

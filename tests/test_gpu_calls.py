@@ -37,6 +37,16 @@ def _compare(oracle, ix, eng, mates, k, **overrides):
         assert abs(d.sor - o["sor"]) <= 1e-12 * max(1.0, abs(o["sor"]))
         assert "%.3f" % d.sor == "%.3f" % o["sor"]
     oracle.lib().orc_free(out)
+    # Noise.max of every position of the selected genome, bit for bit (every sequence of the genome is its own walk)
+    if best >= 0:
+        lo, ncell = ix.genome_cells(best)
+        want = []
+        for s_lo, s_n in ix.sequence_cells(best):
+            want.append(oracle.baseline_noise(pile.fwd_depth[s_lo * 4:(s_lo + s_n) * 4], pile.rev_depth[s_lo * 4:(s_lo + s_n) * 4])[0])
+        want = np.concatenate(want) if want else np.zeros(0)
+        got = eng.download_noise()
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint64), want.view(np.uint64)), \
+            "noise differs at %s" % np.nonzero(got.view(np.uint64) != want.view(np.uint64))[0][:5]
     return n
 
 

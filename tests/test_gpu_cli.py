@@ -183,11 +183,12 @@ def test_call_three_samples_overlapped(oracle, golden_dir, tmp_path):
     ix.close()
 
 
-def test_call_samples_dealt_to_several_gpu_lanes(oracle, golden_dir, tmp_path):
-    """Whole samples per GPU, no collective (call.rs:212: samples are independent): with several devices `bronko call` deals the
-    samples to one engine (+ fork) per device in turn.  BRONKO_DEVICES=0,0 runs two such lanes on the one GPU of the test box --
-    the same code path as two GPUs: five samples, lanes of three and two, every output equal to the oracle's, overview in
-    input order."""
+@pytest.mark.parametrize("lane_env,n_lanes", [({"BRONKO_DEVICES": "0,0"}, 2), ({"BRONKO_LANES": "3"}, 3)])
+def test_call_samples_dealt_to_several_gpu_lanes(oracle, golden_dir, tmp_path, lane_env, n_lanes):
+    """Whole samples per GPU, no collective (call.rs:212: samples are independent): `bronko call` deals the samples to lanes in
+    turn -- host threads that ingest into their own engine (+ fork); the lanes of one device share its tables.
+    BRONKO_DEVICES=0,0 runs two lanes on the one GPU of the test box (the code path of two GPUs), BRONKO_LANES=3 three lanes
+    on it (what -t 6 gives): five samples, every output equal to the oracle's, overview in input order."""
     g = synth.read_fasta_bytes(os.path.join(golden_dir, "HPV16.fa"))
     ix = oracle.Index.load(os.path.join(golden_dir, "hpv.bkdb"))
     paths, samples = [], []
@@ -199,11 +200,11 @@ def test_call_samples_dealt_to_several_gpu_lanes(oracle, golden_dir, tmp_path):
         paths.append(p)
         samples.append(reads)
     out = str(tmp_path / "out")
-    env = dict(os.environ, BRONKO_DEVICES="0,0")
+    env = dict(os.environ, **lane_env)
     res = subprocess.run([BRONKO, "call", "-d", os.path.join(golden_dir, "hpv.bkdb"), "-r"] + paths + ["--pileup", "-o", out],
                          capture_output=True, text=True, env=env)
     assert res.returncode == 0, res.stdout + res.stderr
-    assert "2 GPU lanes" in res.stdout + res.stderr
+    assert "%d GPU lanes" % n_lanes in res.stdout + res.stderr
     odir = str(tmp_path / "oracle")
     os.makedirs(odir)
     ov = open(os.path.join(out, "bronko_overview.tsv")).read().splitlines()

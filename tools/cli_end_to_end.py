@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""`bronko call` end to end: FASTQ.gz files on disk -> VCFs, wall time of the whole command (gunzip + parse on host threads,
+PCIe, the GPU path, calls, output files).  Writes S synthetic samples of N reads (config-2 shape: wuhan_ref, 150 bp single-end,
+0.5 % errors) as real .fastq.gz files under a scratch directory, then times the binary with 1 lane and with the default lanes.
+usage: tools/cli_end_to_end.py [samples 16] [reads 1000000] [threads 32]"""
+import gzip, os, subprocess, sys, tempfile, time
+from multiprocessing import Pool
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from bronko_amd import synth
+
+REF = os.path.join(ROOT, "tests", "golden", "4_sarscov2", "wuhan_ref.fasta")
+BIN = os.path.join(ROOT, "bronko_amd", "bin", "bronko")
+
+
+def write_sample(arg):
+    path, n, seed = arg
+    g, isnv = synth.sample_genome(synth.read_fasta_bytes(REF), seed)
+    codes = synth.single_end_codes(g, n, 150, 7000003 + seed, isnv=isnv)
+    seqs = synth.BASES[codes]                                   # u8 [n][150]
+    rec = np.empty((n, 4 + 8 + 1 + 150 + 3 + 150 + 1), np.uint8)   # "@r" + 8 hex digits + \n seq \n+\n qual \n
+    hexd = np.frombuffer(b"0123456789abcdef", np.uint8)
+    idx = np.arange(n, dtype=np.uint32)
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("r"); rec[:, 2] = ord("e"); rec[:, 3] = ord("a")
+    for d in range(8):
+        rec[:, 4 + d] = hexd[(idx >> np.uint32(4 * (7 - d))) & np.uint32(15)]
+    rec[:, 12] = 10
+    rec[:, 13:163] = seqs
+    rec[:, 163] = 10; rec[:, 164] = ord("+"); rec[:, 165] = 10
+    q = np.random.default_rng(seed).random((n, 150))            # binned qualities as current instruments write them
+    rec[:, 166:316] = np.where(q < 0.90, ord("F"), np.where(q < 0.96, ord(":"), np.where(q < 0.99, ord(","), ord("#"))))
+    rec[:, 316] = 10
+    with gzip.open(path, "wb", compresslevel=1) as f:
+        f.write(rec.tobytes())
+    return os.path.getsize(path)
+
+
+def main():
+    S = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
+    T = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+    tmp = tempfile.mkdtemp(prefix="bronko_e2e_")
+    paths = [os.path.join(tmp, "sample%02d.fastq.gz" % s) for s in range(S)]
+    t0 = time.time()
+    with Pool(min(S, 16)) as pool:
+        sizes = pool.map(write_sample, [(p, N, 100 + s) for s, p in enumerate(paths)])
+    print("wrote %d samples x %d reads: %.1f MB of .fastq.gz (%.1f MB of FASTQ text) in %.0f s" % (S, N, sum(sizes) / 1e6, S * N * 317 / 1e6, time.time() - t0), flush=True)
+    for lanes in ("1", None):
+        env = dict(os.environ)
+        env.pop("BRONKO_LANES", None)
+        if lanes:
+            env["BRONKO_LANES"] = lanes
+        out = os.path.join(tmp, "out_%s" % (lanes or "default"))
+        t0 = time.time()
+        r = subprocess.run([BIN, "call", "-g", REF, "-r"] + paths + ["-t", str(T), "-o", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        dt = time.time() - t0
+        if r.returncode != 0:
+            print(r.stderr.decode()[-2000:])
+            raise SystemExit("bronko call failed")
+        n_vcf = len([f for f in os.listdir(out) if f.endswith(".vcf")])
+        print("bronko call, %s lanes per device (-t %d): %.2f s wall for %d samples (%d VCFs) = %.2f M reads/s end to end" %
+              (lanes or "default", T, dt, S, n_vcf, S * N / dt / 1e6), flush=True)
+    a = open(os.path.join(tmp, "out_1", "sample00.vcf")).read().split("\n", 3)[-1]
+    b = open(os.path.join(tmp, "out_default", "sample00.vcf")).read().split("\n", 3)[-1]
+    print("same VCF body with 1 lane and with the default lanes:", a == b)
+    subprocess.run(["rm", "-rf", tmp])
+
+
+if __name__ == "__main__":
+    main()

@@ -261,6 +261,7 @@ struct bk_engine {
     DevBuf<uint32_t> ref_words, cell_codes, cell_has, cell_clean, cell_clean3, cell_yf, cell_yr, id_at;
     struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0, log2p = 0; } half_lo, half_hi;
     DevBuf<unsigned int> deferred, n_deferred;
+    DevBuf<unsigned long long> deferred_n;   // dense planes: the deferred k-mers' counts (K2a zeroes the counters it reads)
     DevBuf<unsigned int> fin_partials;      // per-workgroup finalize tallies (small genome sets only)
     DevBuf<unsigned long long> ktab_keys;   // full_kmer_stats: open-addressing table of non-index-touching k-mers
     DevBuf<unsigned int> ktab_cnt;
@@ -410,6 +411,13 @@ static int alloc_sample_state(bk_engine* e) {
     if (e->n_files <= 2048) BK_HIP(e->fin_partials.alloc(bk::finalize_partial_rows() * ((size_t)e->n_files * 3 + 2)));
     BK_HIP(e->deferred.alloc(bk::v_plane_len(e->n_full, e->v_span, e->n_prows) * (prm->pileup_selected_only ? 2 : 1)));   // (one list per mate file when it is kept between two passes)
     BK_HIP(e->n_deferred.alloc(2));   // one per mate file
+    if (!e->sparse) {
+        // dense planes: K2a zeroes the V counters as it reads them and the (small) E part is zeroed behind K2e, so a plane is
+        // clean again when its sample is finalized -- no 37 MB memset per sample (config 2); the deferred k-mers' counts
+        // travel with their indices
+        BK_HIP(e->deferred_n.alloc(e->deferred.n));
+        for (int m = 0; m < 2; m++) BK_HIP(hipMemset(e->counters[m].p, 0, std::max<size_t>(e->counters[m].n, 1) * sizeof(unsigned long long)));
+    }
     BK_HIP(e->pileup.alloc(e->total_cells * 4 * 4));
     BK_HIP(e->stats.alloc((size_t)2 * e->n_files * 3));
     BK_HIP(e->present.alloc((size_t)2 * e->n_files));
@@ -1314,8 +1322,11 @@ static int zero_plane_if_stale(bk_engine* e, int mate) {
         return BK_OK;
     }
     if (e->plane_stale[mate]) {
-        bk_engine::Span sp(e, 2);
-        BK_HIP(hipMemsetAsync(e->counters[mate].p, 0, std::max<size_t>(e->counters[mate].n, 1) * sizeof(unsigned long long), e->stream));
+        if (e->plane_used[mate]) {   // (a sample that was abandoned, or finalized in shards: whole samples leave their planes clean)
+            bk_engine::Span sp(e, 2);
+            BK_HIP(hipMemsetAsync(e->counters[mate].p, 0, std::max<size_t>(e->counters[mate].n, 1) * sizeof(unsigned long long), e->stream));
+            e->plane_used[mate] = false;
+        }
         e->plane_stale[mate] = false;
     }
     return BK_OK;
@@ -1381,10 +1392,10 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->ktab_log2;
     a.ktab_overflow = e->ktab_out.p + 4; a.mate = (uint32_t)mate;
     a.occ = e->occ.p; a.n_files = e->n_files;
+    e->plane_used[mate] = true;
     if (e->sparse) {
         a.touch_v = e->touch_v[mate].p; a.touch_p = e->touch_p[mate].p; a.touch_e = e->touch_e[mate].p;
-        a.rl_recip = ~0ull / (unsigned long long)(e->v_span + 1) + 1ull;   // ceil(2^64 / row length) (a row length is no power of two > 1 ... or is: then +1 is still exact for 32-bit indices)
-        e->plane_used[mate] = true;
+        a.rl_recip = ~0ull / (unsigned long long)(e->v_span + 1) + 1ull;   // ceil(2^64 / row length): exact quotients for 32-bit counter indices
     }
     if (test_env("BK_L2_STATS") && !e->dbg.p) { BK_HIP(e->dbg.alloc(32)); BK_HIP(hipMemsetAsync(e->dbg.p, 0, 32 * sizeof(unsigned long long), e->stream)); }
     a.dbg = e->dbg.p;
@@ -1582,6 +1593,7 @@ int bk_counters_device_ptr(bk_engine* e, int mate, void** d_ptr) {
         BK_HIP(hipSetDevice(e->device));
         if (int rc = zero_plane_if_stale(e, mate)) return rc;
     }
+    e->plane_used[mate] = true;   // (the caller may write it: collectives)
     *d_ptr = e->counters[mate].p;
     return BK_OK;
 }
@@ -1602,6 +1614,7 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
     if (two_pass && (elem_lo != 0 || elem_hi != e->plane_len)) return fail(BK_ERR_UNSUPPORTED, "pileup_selected_only cannot be combined with a sharded finalize");
     if (two_pass && !e->sel_out.p) BK_HIP(e->sel_out.alloc(1));
     if (e->sparse && (elem_lo != 0 || elem_hi != e->plane_len)) return fail(BK_ERR_UNSUPPORTED, "an index this large cannot be finalized in shards");
+    const bool clean_dense = !e->sparse && elem_lo == 0 && elem_hi == e->plane_len;   // this call maps whole planes: it leaves them zeroed
     if (e->sparse) {
         for (int m = 0; m < n_mates; m++) {
             bk_engine::Span sp(e, 1);
@@ -1629,6 +1642,8 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->ktab_log2;
             a.ktab_overflow = e->ktab_out.p + 4; a.mate = (uint32_t)m;
             if (e->sparse) { a.v_list = e->v_list[m].p; a.p_list = e->p_list[m].p; a.e_list = e->e_list[m].p; a.n_list = e->n_list[m].p; }
+            a.deferred_n = e->deferred_n.p ? e->deferred_n.p + (two_pass ? (size_t)m * (e->deferred_n.n / 2) : 0) : nullptr;
+            a.clear_v = clean_dense && pass == (two_pass ? 1 : 0);
             a.mode = two_pass ? pass + 1 : 0;
             a.sel = two_pass ? &e->sel_out.p->file_id : nullptr;
             a.sel_file = -1;
@@ -1642,6 +1657,15 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             c.out = e->sel_out.p;
             bk_engine::Span sp(e, 1);
             bk::launch_select_genome(c, e->stream);
+        }
+    }
+    if (clean_dense) {   // K2a zeroed the V counters; the E part (two counters per reference k-mer) goes here
+        for (int m = 0; m < n_mates; m++) {
+            if (e->plane_used[m]) {
+                bk_engine::Span sp(e, 2);
+                BK_HIP(hipMemsetAsync(e->counters[m].p, 0, (size_t)std::min<uint64_t>(e->v_off, e->plane_len) * sizeof(unsigned long long), e->stream));
+            }
+            e->plane_used[m] = false;
         }
     }
     if (e->sparse) {   // the maps are done: what they read is zeroed again, the planes are all zero for the next sample

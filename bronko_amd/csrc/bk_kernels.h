@@ -74,6 +74,9 @@ struct FinalizeArgs {
     unsigned int* partials;         // [finalize_partial_rows()][n_files*3 + 2] per-workgroup tallies, or null: use atomics
     int row_exact, row_general;     // first partials row of K2e / K2b (set by launch_finalize)
     unsigned int* deferred;         // [v_plane_len] V counter indices K2a hands to K2b
+    unsigned long long* deferred_n; // ... and their counts (clear_v: K2b cannot read them from the plane any more); may be null
+    int clear_v;                    // K2a zeroes every V counter it reads (dense planes, the whole plane in this call, last pass):
+                                    // the plane needs no memset before the next sample
     unsigned int* n_deferred;       // [1], zeroed before each finalize
     // full_kmer_stats: k-mers recorded in V rows that cannot touch the index join the statistics table (null = off)
     unsigned long long* ktab_keys;

@@ -1498,7 +1498,7 @@ __device__ __forceinline__ void v_kmer_of_counter(const IndexView& ix, const uns
         const uint64_t row = vi / rl;
         const uint32_t oo = (uint32_t)(vi % rl);
         n = 0;
-        for (uint32_t x = 0; x <= oo; ++x) n += vc[row * rl + x];
+        if (vc) for (uint32_t x = 0; x <= oo; ++x) n += vc[row * rl + x];   // (null: the caller has the count)
         p = (uint32_t)(row >> 3) - oo;
         const uint32_t rcid = (ix.amb[p] >> 1) & 1u;
         const int o = (int)oo + ix.v_omin;
@@ -1513,7 +1513,7 @@ __device__ __forceinline__ void v_kmer_of_counter(const IndexView& ix, const uns
         bb = (uint32_t)(x >> 1) & 3u;
         p = ix.prow_id[x >> 3];
         t = ix.prow_t[x >> 3];
-        n = vc[vi];
+        n = vc ? vc[vi] : 0ull;
     }
     const int sh = 2 * (k - 1 - (ix.wstart + (int)t));
     c = (ix.kmer_of[p] & ~(3ull << sh)) | ((uint64_t)bb << sh);
@@ -1530,7 +1530,7 @@ __device__ __forceinline__ void v_kmer_of_counter(const IndexView& ix, const uns
 // skipped -- with full_kmer_stats they join the k-mer statistics table, like every other k-mer that touches nothing.
 __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (a.mode == 2) { a.sel_file = *a.sel; if (a.sel_file < 0) return; }   // second pass: votes for the selected genome only
+    if (a.mode == 2) { a.sel_file = *a.sel; if (a.sel_file < 0 && !a.clear_v) return; }   // (no genome selected: no votes, but the plane is still to be cleared)   // second pass: votes for the selected genome only
     const bool do_stats = a.mode != 2;                                       // (its statistics were tallied by the first pass)
     const IndexView& ix = a.ix;
     uint32_t* lstats = reinterpret_cast<uint32_t*>(smem);   // [n_files][3] block-local tallies + 2 scratch words
@@ -1543,7 +1543,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
     const uint64_t n_rows = v_real_rows(ix.n_full, ix.v_span);
     const uint64_t real_len = v_real_len(ix.n_full, ix.v_span);
     const uint32_t rl = (uint32_t)ix.v_span + 1u;
-    const unsigned long long* __restrict__ vc = a.counters + ix.v_off;
+    unsigned long long* __restrict__ vc = const_cast<unsigned long long*>(a.counters) + ix.v_off;   // (written only under clear_v)
     const KmerTable kt{a.ktab_keys, a.ktab_cnt, a.ktab_log2, a.ktab_overflow, a.mate};
     unsigned int kept = 0, distinct = 0;
     // this shard's rows and pseudo counters (elem_lo / elem_hi are multiples of the row length, like v_off)
@@ -1589,7 +1589,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
             uint32_t jmask = 0;   // window positions at which c has a neighbouring reference k-mer
             for_each_neighbour(ix, c, [&](int jj, uint32_t, uint32_t) { jmask |= 1u << (jj - ix.wstart); });
             if (jmask != (1u << t)) {
-                if (do_stats) { const unsigned int at = atomicAdd(a.n_deferred, 1u); a.deferred[at] = (uint32_t)vi; }
+                if (do_stats) { const unsigned int at = atomicAdd(a.n_deferred, 1u); a.deferred[at] = (uint32_t)vi; if (a.deferred_n) a.deferred_n[at] = n; }
                 return;
             }
         }
@@ -1659,6 +1659,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
             in_row = lane_on && qrow < nq && wk >= row_lo && wk < row_hi;
         }
         unsigned long long n = in_row ? vc[wk * rl + oo] : 0ull;
+        if (a.clear_v && n) vc[wk * rl + oo] = 0ull;   // (every counter is read by exactly one lane of one pass)
         // What this lane needs besides its count depends on the row's coordinates only: the reference k-mer's record (k-mer,
         // first cell, flags -- one 16-byte load, consecutive ids across the lanes) goes out together with the row's load.
         const uint32_t d = (uint32_t)wk & 1u, bf = (uint32_t)(wk >> 1) & 3u, q = (uint32_t)(wk >> 3);
@@ -1706,7 +1707,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
                 multi = jmask != (1u << t);
             }
             if (multi) {
-                if (do_stats) { const unsigned int at = atomicAdd(a.n_deferred, 1u); a.deferred[at] = (uint32_t)(wk * rl + oo); }
+                if (do_stats) { const unsigned int at = atomicAdd(a.n_deferred, 1u); a.deferred[at] = (uint32_t)(wk * rl + oo); if (a.deferred_n) a.deferred_n[at] = n; }
                 act = false;
             }
         }
@@ -1798,6 +1799,7 @@ __global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
         if (vc[vi] == 0) continue;
         uint32_t p, t, isrc; uint64_t c; unsigned long long n;
         v_kmer_of_counter(ix, vc, vi, p, t, c, isrc, n);
+        if (a.clear_v) vc[vi] = 0ull;
         map_one(p, t, c, isrc, n, vi);
         flush(0); flush(1);
     }
@@ -1971,7 +1973,8 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
             unsigned long long v;
             uint64_t c;
             uint32_t isrc, p_, t_;
-            v_kmer_of_counter(ix, a.counters + ix.v_off, ci - n_e, p_, t_, c, isrc, v);
+            v_kmer_of_counter(ix, a.deferred_n ? nullptr : a.counters + ix.v_off, ci - n_e, p_, t_, c, isrc, v);
+            if (a.deferred_n) v = a.deferred_n[item];             // (K2a may have zeroed the row since)
             v = v > a.cs ? a.cs : v;                              // kmc -cs: reported count saturates
 
             int s = -1;   // lane t: the k-mer's bucket at window position t, if the index has it

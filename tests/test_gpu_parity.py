@@ -710,13 +710,16 @@ def test_votes_for_the_selected_genome_only(oracle, sars_paths):
         ix.close()
 
 
+@pytest.mark.parametrize("force_sparse", [True, False])
 @pytest.mark.parametrize("selected_only", [False, True])
-def test_sparse_finalize_on_a_small_index(oracle, sars_paths, monkeypatch, testing_lib, selected_only):
-    """An index above 16 M counters finalizes from touch lists (bk_engine.cpp alloc_sample_state); BK_SPARSE_FINALIZE forces that
-    path here, on four SARS-CoV-2 strains with paired reads and on twelve HPV16 strains at k = 31 (pseudo k-mers).  The engine is
-    used for a sample that is begun, pushed and abandoned, then for two whole samples: each equals the oracle's."""
+def test_planes_are_clean_between_samples(oracle, sars_paths, monkeypatch, testing_lib, selected_only, force_sparse):
+    """No counter plane is zeroed wholesale between samples: finalize clears what it read -- K2a the V counters as it reads them
+    (dense planes), or the touch lists' rows (an index above 16 M counters, bk_engine.cpp alloc_sample_state; BK_SPARSE_FINALIZE
+    forces that path here).  Four SARS-CoV-2 strains with paired reads and twelve HPV16 strains at k = 31 (pseudo k-mers); the
+    engine is used for a sample that is begun, pushed and abandoned, then for two whole samples: each equals the oracle's."""
     from bronko_amd import Params, pack_reads
-    monkeypatch.setenv("BK_SPARSE_FINALIZE", "1")
+    if force_sparse:
+        monkeypatch.setenv("BK_SPARSE_FINALIZE", "1")
     cases = []
     ix = oracle.Index.build(21, sars_paths)
     gm, isnv = synth.sample_genome(synth.read_fasta_bytes(sars_paths[2]), 81)
@@ -744,7 +747,8 @@ def test_sparse_finalize_on_a_small_index(oracle, sars_paths, monkeypatch, testi
                 got, ref = getattr(res, name), getattr(pile, name)
                 assert np.array_equal(got[lo * 4:(lo + n) * 4], ref[lo * 4:(lo + n) * 4]), name
                 assert not got[:lo * 4].any() and not got[(lo + n) * 4:].any(), name
-        with pytest.raises(Exception):
-            eng.counters_ptr(0)                              # sharding one sample's reads needs the dense plane
+        if force_sparse:
+            with pytest.raises(Exception):
+                eng.counters_ptr(0)                          # sharding one sample's reads needs the dense plane
         eng.close()
         ix.close()

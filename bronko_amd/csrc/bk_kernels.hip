@@ -1323,7 +1323,7 @@ void launch_fold(const FoldArgs& f, hipStream_t stream) {
     if (work == 0) return;
     uint64_t blocks = (work + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    const unsigned groups = std::max(1u, std::min(16u, f.n_slabs / 8));
+    const unsigned groups = std::max(1u, std::min(8u, f.n_slabs / 8));
     hipLaunchKernelGGL(fold_kernel, dim3((unsigned)blocks, groups), dim3(256), 0, stream, f);
 }
 

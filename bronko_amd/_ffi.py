@@ -52,7 +52,7 @@ class BuiltIndex(C.Structure):  # bk_built_index
 SYMBOLS = ["bk_abi_version", "bk_device_count", "bk_last_error", "bk_params_default", "bk_engine_create", "bk_engine_destroy", "bk_engine_fork", "bk_engine_get_stream",
            "bk_engine_set_stream", "bk_total_cells", "bk_n_files", "bk_n_slots", "bk_counter_len", "bk_sample_begin",
            "bk_push_reads_packed", "bk_push_reads_packed_device", "bk_push_reads_ascii", "bk_counters_device_ptr", "bk_sample_finalize",
-           "bk_sample_finalize_shard", "bk_shard_sums_device_ptr", "bk_sample_merge_shards",
+           "bk_sample_finalize_shard", "bk_shard_sums_device_ptr", "bk_sample_merge_shards", "bk_kmer_table_partition", "bk_kmer_table_replace",
            "bk_pileup_device_ptr", "bk_sample_download", "bk_sample_finish", "bk_pack_reads", "bk_pack_reads_flat",
            "bk_timing_enable", "bk_timing_read", "bk_call_params_default", "bk_sample_call", "bk_sample_download_calls", "bk_sample_download_noise",
            "bk_build_index", "bk_built_index_free", "bk_build_last_error"]
@@ -108,6 +108,10 @@ def load(testing=None):
     L.bk_sample_finalize.argtypes = [vp, C.c_int]
     L.bk_sample_finalize_shard.restype = C.c_int
     L.bk_sample_finalize_shard.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.bk_kmer_table_partition.restype = C.c_int
+    L.bk_kmer_table_partition.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+    L.bk_kmer_table_replace.restype = C.c_int
+    L.bk_kmer_table_replace.argtypes = [vp, vp, vp, u64]
     L.bk_shard_sums_device_ptr.restype = C.c_int
     L.bk_shard_sums_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.bk_sample_merge_shards.restype = C.c_int

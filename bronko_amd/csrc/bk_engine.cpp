@@ -272,6 +272,9 @@ struct bk_engine {
     bool fill_pending = false;              // a copy of the tallies is in flight / unread
     uint64_t fill_known = 0, fill_unknown_upper = 0;   // keys in the table at the last reading; k-mers pushed since (upper bound on new keys)
     std::vector<std::pair<unsigned long long*, unsigned int*>> ktab_old;   // outgrown tables, freed at the next sample / destroy
+    DevBuf<unsigned long long> xchg_keys, xchg_cursors;   // bk_kmer_table_partition: the table's entries grouped by owner rank
+    DevBuf<unsigned int> xchg_cnt;
+    bool ktab_exchanged = false;            // bk_kmer_table_replace was called in this sample
     DevBuf<uint32_t> slot_of, estat_off, estat;
     DevBuf<bk::SlotRec> slot_rec;
     DevBuf<uint8_t> amb;
@@ -1301,6 +1304,7 @@ int bk_sample_begin(bk_engine* e) {
         BK_HIP(hipMemsetAsync(e->ktab_cnt.p, 0, e->ktab_cnt.n * sizeof(unsigned int), e->stream));
         e->fill_known = 0; e->fill_unknown_upper = 0; e->fill_pending = false;
     }
+    e->ktab_exchanged = false;
     e->pushed_records[0] = e->pushed_records[1] = 0;
     e->in_sample = true;
     return BK_OK;
@@ -1713,10 +1717,13 @@ int bk_sample_finalize_shard(bk_engine* e, int n_mates, int shard, int n_shards)
     if (!e) return fail(BK_ERR_INVALID, "null engine");
     if (n_shards < 1 || (int)bk::kMaxShards % n_shards != 0 || shard < 0 || shard >= n_shards)
         return fail(BK_ERR_INVALID, "n_shards must divide %u and 0 <= shard < n_shards", bk::kMaxShards);
-    if (e->ktab_keys.p && n_shards > 1) return fail(BK_ERR_UNSUPPORTED, "full_kmer_stats is single-GPU only");
+    if (e->ktab_keys.p && n_shards > 1 && !e->ktab_exchanged)
+        return fail(BK_ERR_STATE, "full_kmer_stats with a sharded finalize: exchange the ranks' k-mer statistics tables first "
+                                  "(bk_kmer_table_partition, all-to-all, bk_kmer_table_replace)");
     const uint64_t part = e->plane_len / (uint64_t)n_shards;
     int rc = finalize_part(e, n_mates, part * shard, part * (shard + 1));
     if (rc != BK_OK) return rc;
+    if (e->ktab_keys.p) bk::launch_ktab_totals_to_kstats(e->ktab_out.p, e->kstats.p, n_mates, e->stream);   // (the ranks' totals add up)
     for (int m = 0; m < n_mates; m++) {   // the records this rank pushed join the device tally, so that the sum over ranks is the sample's
         if (e->pushed_records[m]) bk::launch_add_const_u64(e->kstats.p + m * 4 + 0, e->pushed_records[m], e->stream);
         e->pushed_records[m] = 0;
@@ -1724,6 +1731,53 @@ int bk_sample_finalize_shard(bk_engine* e, int n_mates, int shard, int n_shards)
     bk::launch_pack_sums(e->shard_sums.p, e->stats.p, e->present.p, e->kstats.p, e->n_files, e->stream);
     BK_HIP(hipGetLastError());
     return BK_OK;
+}
+
+int bk_kmer_table_partition(bk_engine* e, int n_parts, void** d_keys, void** d_counts, uint64_t* part_off) {
+    if (!e || !d_keys || !d_counts || !part_off) return fail(BK_ERR_INVALID, "null argument");
+    if (n_parts < 1 || n_parts > (int)bk::kMaxShards) return fail(BK_ERR_INVALID, "1 <= n_parts <= %u", bk::kMaxShards);
+    if (!e->ktab_keys.p) return fail(BK_ERR_STATE, "the engine was created without full_kmer_stats");
+    if (!e->in_sample) return fail(BK_ERR_STATE, "bk_kmer_table_partition comes between the pushes and the finalize of a sample");
+    BK_HIP(hipSetDevice(e->device));
+    if (!e->xchg_cursors.p) BK_HIP(e->xchg_cursors.alloc(bk::kMaxShards));
+    BK_HIP(hipMemsetAsync(e->xchg_cursors.p, 0, bk::kMaxShards * sizeof(unsigned long long), e->stream));
+    bk::launch_ktab_count_parts(e->ktab_keys.p, e->ktab_log2, (uint32_t)n_parts, e->xchg_cursors.p, e->stream);
+    unsigned long long counts[bk::kMaxShards];
+    BK_HIP(hipMemcpyAsync(counts, e->xchg_cursors.p, (size_t)n_parts * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+    BK_HIP(hipStreamSynchronize(e->stream));
+    unsigned long long first[bk::kMaxShards];
+    part_off[0] = 0;
+    for (int r = 0; r < n_parts; r++) { first[r] = part_off[r]; part_off[r + 1] = part_off[r] + counts[r]; }
+    const uint64_t total = part_off[n_parts];
+    if (e->xchg_keys.n < total || !e->xchg_keys.p) {
+        BK_HIP(e->xchg_keys.alloc(std::max<uint64_t>(total + total / 4, 1024)));
+        BK_HIP(e->xchg_cnt.alloc(e->xchg_keys.n));
+    }
+    BK_HIP(hipMemcpyAsync(e->xchg_cursors.p, first, (size_t)n_parts * sizeof(unsigned long long), hipMemcpyHostToDevice, e->stream));
+    bk::launch_ktab_scatter_parts(e->ktab_keys.p, e->ktab_cnt.p, e->ktab_log2, (uint32_t)n_parts, e->xchg_cursors.p, e->xchg_keys.p, e->xchg_cnt.p, e->stream);
+    BK_HIP(hipGetLastError());
+    BK_HIP(hipStreamSynchronize(e->stream));   // (`first` is read by the copy above; the caller reads the arrays on its own stream)
+    *d_keys = e->xchg_keys.p; *d_counts = e->xchg_cnt.p;
+    return BK_OK;
+}
+
+int bk_kmer_table_replace(bk_engine* e, const void* d_keys, const void* d_counts, uint64_t n) {
+    if (!e || (n && (!d_keys || !d_counts))) return fail(BK_ERR_INVALID, "null argument");
+    if (!e->ktab_keys.p) return fail(BK_ERR_STATE, "the engine was created without full_kmer_stats");
+    if (!e->in_sample) return fail(BK_ERR_STATE, "bk_kmer_table_replace comes between the pushes and the finalize of a sample");
+    BK_HIP(hipSetDevice(e->device));
+    // an empty table with room for the n entries (and, like after any push, for what finalize adds: the load stays below a half)
+    BK_HIP(hipMemsetAsync(e->ktab_keys.p, 0xff, e->ktab_keys.n * sizeof(unsigned long long), e->stream));
+    BK_HIP(hipMemsetAsync(e->ktab_cnt.p, 0, e->ktab_cnt.n * sizeof(unsigned int), e->stream));
+    BK_HIP(hipMemsetAsync(e->ktab_out.p + 8, 0, bk::ktab_fill_words() * sizeof(unsigned long long), e->stream));
+    if (e->fill_pending) { BK_HIP(hipEventSynchronize(e->fill_ev)); e->fill_pending = false; }
+    e->fill_known = 0; e->fill_unknown_upper = 0;
+    if (int rc = ensure_ktab_room(e, n)) return rc;
+    bk::launch_ktab_import(static_cast<const unsigned long long*>(d_keys), static_cast<const unsigned int*>(d_counts), n, e->ktab_keys.p, e->ktab_cnt.p,
+                           e->ktab_log2, e->ktab_out.p + 4, e->stream);
+    BK_HIP(hipGetLastError());
+    e->ktab_exchanged = true;
+    return note_ktab_fill(e);
 }
 
 int bk_shard_sums_device_ptr(bk_engine* e, void** d_ptr, uint64_t* len) {
@@ -1765,7 +1819,7 @@ int bk_sample_download(bk_engine* e, int n_mates, uint64_t* fwd_depth, uint64_t*
             if (e->ktab_keys.p) {
                 // index-touching k-mers are in the counter plane (kept tally in [3], distinct tally in [2] by finalize);
                 // the rest are in the hash table
-                if (kt[4]) { kmer_stats[m * 4 + 2] = kmer_stats[m * 4 + 3] = ~0ull; }
+                if (kt[4] || kmer_stats[m * 4 + 2] >= (1ull << 56)) { kmer_stats[m * 4 + 2] = kmer_stats[m * 4 + 3] = ~0ull; }   // (2^56: a rank's table overflowed, sharded finalize)
                 else { kmer_stats[m * 4 + 2] += kt[m * 2 + 0]; kmer_stats[m * 4 + 3] += kt[m * 2 + 1]; }
             } else {
                 kmer_stats[m * 4 + 2] = 0;

@@ -143,6 +143,12 @@ void launch_ktab_stats(const unsigned long long* keys, const unsigned int* cnt, 
                        unsigned long long cx, unsigned long long* out, hipStream_t stream);
 void launch_ktab_rehash(const unsigned long long* okeys, const unsigned int* ocnt, uint32_t olog2, unsigned long long* nkeys, unsigned int* ncnt,
                         uint32_t nlog2, unsigned long long* overflow, hipStream_t stream);
+void launch_ktab_count_parts(const unsigned long long* keys, uint32_t log2n, uint32_t n_parts, unsigned long long* counts, hipStream_t stream);
+void launch_ktab_scatter_parts(const unsigned long long* keys, const unsigned int* cnt, uint32_t log2n, uint32_t n_parts, unsigned long long* cursors,
+                               unsigned long long* out_keys, unsigned int* out_cnt, hipStream_t stream);
+void launch_ktab_import(const unsigned long long* in_keys, const unsigned int* in_cnt, uint64_t n, unsigned long long* keys, unsigned int* cnt, uint32_t log2n,
+                        unsigned long long* overflow, hipStream_t stream);
+void launch_ktab_totals_to_kstats(unsigned long long* ktab_out, unsigned long long* kstats, int n_mates, hipStream_t stream);
 uint32_t ktab_fill_words();   // tallies of new keys behind the overflow word: ktab_out[8 ..]
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
 // sparse finalize: touch bitmaps -> lists (the bitmaps are cleared on the way); lists -> their counters zeroed again

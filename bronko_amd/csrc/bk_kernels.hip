@@ -164,8 +164,7 @@ struct KmerTable {
 };
 
 constexpr uint32_t kKtabFillWords = 1024;   // new-key tallies behind the overflow flag: overflow[4 + i], spread so that no word is hot
-__device__ __forceinline__ void ktab_insert(const KmerTable& t, uint64_t c, uint32_t isrc, unsigned int n) {
-    const unsigned long long key = c | ((unsigned long long)isrc << 63) | ((unsigned long long)t.mate << 62);
+__device__ __forceinline__ void ktab_insert_key(const KmerTable& t, unsigned long long key, unsigned int n) {
     const uint64_t mask = (1ull << t.log2n) - 1ull;
     uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> (64 - t.log2n);
     for (uint32_t probes = 0; probes < 4096; ++probes) {
@@ -178,6 +177,84 @@ __device__ __forceinline__ void ktab_insert(const KmerTable& t, uint64_t c, uint
         h = (h + 1) & mask;
     }
     *t.overflow = 1ull;   // (the engine keeps the load below one half: unreachable unless the table cannot grow any more)
+}
+__device__ __forceinline__ void ktab_insert(const KmerTable& t, uint64_t c, uint32_t isrc, unsigned int n) {
+    ktab_insert_key(t, c | ((unsigned long long)isrc << 63) | ((unsigned long long)t.mate << 62), n);
+}
+
+__device__ __forceinline__ uint32_t lane_prefix(unsigned long long m);   // (set bits of m below this lane; defined with the scan's helpers)
+// ---- the statistics tables of ranks that shared one sample's reads (full_kmer_stats with a sharded finalize) ----------------
+// A k-mer that touches no window bucket sits in the table of every rank whose reads held it; the sample's "unique k-mers" /
+// "unique counted k-mers" (call.rs:1190-1199) need each k-mer once with its total count.  Every key has one owner rank (a hash
+// of the key); a rank lists its entries grouped by owner (count, then scatter: one append per wave and owner), the host
+// exchanges the groups (all-to-all), and the rank rebuilds its table from what it received -- equal keys add up.
+__device__ __forceinline__ uint32_t ktab_owner(unsigned long long key, uint32_t n_parts) {
+    return (uint32_t)((((key * 0xD6E8FEB86659FD93ull) >> 32) * (unsigned long long)n_parts) >> 32);
+}
+__global__ __launch_bounds__(256) void ktab_count_parts_kernel(const unsigned long long* __restrict__ keys, uint64_t n, uint32_t n_parts,
+                                                               unsigned long long* counts /* [n_parts], zeroed */) {
+    __shared__ unsigned int h[kMaxShards];
+    for (uint32_t i = threadIdx.x; i < n_parts; i += 256) h[i] = 0u;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const unsigned long long key = keys[i];
+        if (key != ~0ull) atomicAdd(&h[ktab_owner(key, n_parts)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_parts; i += 256) if (h[i]) atomicAdd(counts + i, (unsigned long long)h[i]);
+}
+__global__ __launch_bounds__(256) void ktab_scatter_parts_kernel(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ cnt,
+                                                                 uint64_t n, uint32_t n_parts, unsigned long long* cursors /* [n_parts]: first free slot */,
+                                                                 unsigned long long* out_keys, unsigned int* out_cnt) {
+    const uint64_t n_round = (n + 255) / 256 * 256;   // (whole waves stay in the loop: the appends are per wave)
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_round; i += (uint64_t)gridDim.x * 256) {
+        const unsigned long long key = i < n ? keys[i] : ~0ull;
+        const bool live = key != ~0ull;
+        const uint32_t own = live ? ktab_owner(key, n_parts) : 0u;
+        unsigned long long todo = __ballot(live);
+        while (todo) {
+            const uint32_t p = (uint32_t)__shfl((int)own, __builtin_ctzll(todo));
+            const unsigned long long m = __ballot(live && own == p);
+            unsigned long long base = 0;
+            if ((int)(threadIdx.x & 63u) == __builtin_ctzll(m)) base = atomicAdd(cursors + p, (unsigned long long)__popcll(m));
+            base = __shfl(base, __builtin_ctzll(m));
+            if (live && own == p) { const uint64_t at = base + lane_prefix(m); out_keys[at] = key; out_cnt[at] = cnt[i]; }
+            todo &= ~m;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void ktab_import_kernel(const unsigned long long* __restrict__ in_keys, const unsigned int* __restrict__ in_cnt, uint64_t n,
+                                                          KmerTable t) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) ktab_insert_key(t, in_keys[i], in_cnt[i]);
+}
+void launch_ktab_count_parts(const unsigned long long* keys, uint32_t log2n, uint32_t n_parts, unsigned long long* counts, hipStream_t stream) {
+    const uint64_t n = 1ull << log2n;
+    hipLaunchKernelGGL(ktab_count_parts_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 8)), dim3(256), 0, stream, keys, n, n_parts, counts);
+}
+void launch_ktab_scatter_parts(const unsigned long long* keys, const unsigned int* cnt, uint32_t log2n, uint32_t n_parts, unsigned long long* cursors,
+                               unsigned long long* out_keys, unsigned int* out_cnt, hipStream_t stream) {
+    const uint64_t n = 1ull << log2n;
+    hipLaunchKernelGGL(ktab_scatter_parts_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 8)), dim3(256), 0, stream, keys, cnt, n, n_parts,
+                       cursors, out_keys, out_cnt);
+}
+void launch_ktab_import(const unsigned long long* in_keys, const unsigned int* in_cnt, uint64_t n, unsigned long long* keys, unsigned int* cnt, uint32_t log2n,
+                        unsigned long long* overflow, hipStream_t stream) {
+    if (!n) return;
+    const KmerTable t{keys, cnt, log2n, overflow, 0u};
+    hipLaunchKernelGGL(ktab_import_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 8)), dim3(256), 0, stream, in_keys, in_cnt, n, t);
+}
+// sharded finalize: the table's totals join the device tallies that the ranks add up (kstats[mate][2], [3]); an overflowed table
+// adds 2^56 to both -- no sum of real tallies reaches it, bk_sample_download reports "unavailable" on every rank
+__global__ void ktab_totals_to_kstats_kernel(unsigned long long* ktab_out, unsigned long long* kstats, int n_mates) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int m = 0; m < n_mates; m++) {
+        kstats[m * 4 + 2] += ktab_out[m * 2 + 0] + (ktab_out[4] ? 1ull << 56 : 0ull);
+        kstats[m * 4 + 3] += ktab_out[m * 2 + 1] + (ktab_out[4] ? 1ull << 56 : 0ull);
+        ktab_out[m * 2 + 0] = 0ull; ktab_out[m * 2 + 1] = 0ull;
+    }
+}
+void launch_ktab_totals_to_kstats(unsigned long long* ktab_out, unsigned long long* kstats, int n_mates, hipStream_t stream) {
+    hipLaunchKernelGGL(ktab_totals_to_kstats_kernel, dim3(1), dim3(64), 0, stream, ktab_out, kstats, n_mates);
 }
 
 // old table -> a larger one (same keys, same counts; the fill tallies stay as they are)

@@ -68,11 +68,55 @@ def combine_shard_results(depth, nk, sums):
         _all_reduce(sums, dist.ReduceOp.SUM)
 
 
-class DeviceVector:
-    """__cuda_array_interface__ view of n little-endian 64-bit integers at a device pointer (for torch.as_tensor)."""
+def _all_to_all(out, inp, out_splits, in_splits):
+    """dist.all_to_all_single; staged through host memory with the gloo backend (CPU tests / several test ranks on one GPU)."""
+    if dist.get_backend() == "gloo" and inp.is_cuda:
+        ho, hi = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+        dist.all_to_all_single(ho, hi, out_splits, in_splits)
+        out.copy_(ho)
+    else:
+        dist.all_to_all_single(out, inp, out_splits, in_splits)
 
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+
+def exchange_entries(keys, cnts, in_splits):
+    """All-to-all of (key, count) entries grouped by destination rank: `in_splits[r]` consecutive entries of `keys` (int64) /
+    `cnts` (int32) go to rank r.  Returns what this rank received (keys, counts), groups in rank order."""
+    world = dist.get_world_size()
+    t_in = torch.tensor(in_splits, dtype=torch.int64, device=keys.device)
+    t_out = torch.empty(world, dtype=torch.int64, device=keys.device)
+    _all_to_all(t_out, t_in, [1] * world, [1] * world)
+    out_splits = [int(x) for x in t_out.tolist()]
+    n_recv = sum(out_splits)
+    rk = torch.empty(n_recv, dtype=torch.int64, device=keys.device)
+    rc = torch.empty(n_recv, dtype=torch.int32, device=keys.device)
+    _all_to_all(rk, keys, out_splits, in_splits)
+    _all_to_all(rc, cnts, out_splits, in_splits)
+    return rk, rc
+
+
+def exchange_kmer_tables(eng, rank, world, device):
+    """full_kmer_stats with one sample's reads sharded over ranks (include/bronko_hip.h, bk_kmer_table_partition): every k-mer
+    that touches no window bucket is moved to its owner rank (a hash of the key) -- one all-to-all of (key u64, count u32)
+    entries, the one real exchange step of KMC's distinct / counted totals -- where equal keys add up.  Called between the last
+    push and the sharded finalize (ShardedFinalize does it itself when the engine has the statistics table).  Returns the
+    received tensors: the caller keeps them until the engine's stream has consumed them."""
+    if not (dist.is_available() and dist.is_initialized()) or world == 1:
+        return None
+    kp, cp, off = eng.kmer_table_partition(world)
+    n_send = off[world]
+    keys = torch.as_tensor(DeviceVector(kp, max(n_send, 1)), device=device)[:n_send]
+    cnts = torch.as_tensor(DeviceVector(cp, max(n_send, 1), "<i4"), device=device)[:n_send]
+    rk, rc = exchange_entries(keys, cnts, [off[r + 1] - off[r] for r in range(world)])
+    eng.kmer_table_replace(rk.data_ptr() if len(rk) else 0, rc.data_ptr() if len(rc) else 0, len(rk))
+    return rk, rc
+
+
+class DeviceVector:
+    """__cuda_array_interface__ view of n little-endian integers (64-bit unless typestr says otherwise) at a device pointer (for
+    torch.as_tensor)."""
+
+    def __init__(self, ptr, n, typestr="<i8"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
 class ShardedFinalize:
@@ -98,6 +142,8 @@ class ShardedFinalize:
         if self.planes and self.planes[0].is_cuda and torch.cuda.current_stream().cuda_stream != self.eng.stream_ptr():
             raise RuntimeError("ShardedFinalize: torch's current stream is not the engine's stream -- the collectives would not be "
                                "ordered against the engine's kernels (use torch.cuda.stream(ExternalStream(eng.stream_ptr())))")
+        if self.eng.full_kmer_stats and self.world > 1:
+            self._held = exchange_kmer_tables(self.eng, self.rank, self.world, self.depth.device)   # KMC's distinct / counted totals stay exact
         for m, plane in enumerate(self.planes):
             self.eng.counters_ptr(m)   # (a plane this rank pushed nothing to is zeroed by this call)
             reduce_scatter_plane(plane, self.rank, self.world, self.out, self.narrow)

@@ -208,6 +208,22 @@ class Engine:
         """Map only the shard-th of n_shards equal parts of each counter plane (include/bronko_hip.h)."""
         _check(self._L.bk_sample_finalize_shard(self.h, n_mates, shard, n_shards), self._L)
 
+    def kmer_table_partition(self, n_parts):
+        """full_kmer_stats under a sharded finalize: (device pointer of keys u64, of counts u32, offsets[n_parts + 1]) -- the
+        statistics table's entries grouped by owner rank.  Synchronises."""
+        k, c = C.c_void_p(), C.c_void_p()
+        off = (C.c_uint64 * (n_parts + 1))()
+        _check(self._L.bk_kmer_table_partition(self.h, n_parts, C.byref(k), C.byref(c), off), self._L)
+        return k.value, c.value, list(off)
+
+    def kmer_table_replace(self, keys_ptr, counts_ptr, n):
+        """... and the table rebuilt from the entries this rank owns (device pointers; equal keys add up)."""
+        _check(self._L.bk_kmer_table_replace(self.h, keys_ptr, counts_ptr, n), self._L)
+
+    @property
+    def full_kmer_stats(self):
+        return bool(self.params.full_kmer_stats)
+
     def shard_sums(self):
         """(device pointer, u64 length) of the small additive results of sample_finalize_shard."""
         p, n = C.c_void_p(), C.c_uint64()

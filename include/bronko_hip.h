@@ -175,6 +175,18 @@ int bk_sample_finalize(bk_engine* e, int n_mates);
 int bk_sample_finalize_shard(bk_engine* e, int n_mates, int shard, int n_shards);
 int bk_shard_sums_device_ptr(bk_engine* e, void** d_ptr, uint64_t* len);
 int bk_sample_merge_shards(bk_engine* e);
+/* full_kmer_stats with a sharded finalize (v6): a k-mer that touches no window bucket sits in the statistics table of every
+ * rank whose reads held it, and KMC's "unique (counted) k-mers" (call.rs:1190-1199) want it once, with its total count.  Between
+ * the last push and bk_sample_finalize_shard every rank
+ *   bk_kmer_table_partition(e, n, &keys, &counts, off)   lists its table's entries grouped by owner rank (a hash of the key):
+ *                                                        device arrays of off[n] keys (u64) / counts (u32), group r = entries
+ *                                                        [off[r], off[r + 1]); synchronises (the host sizes the exchange);
+ *   exchanges the groups (all-to-all: group r goes to rank r);
+ *   bk_kmer_table_replace(e, keys, counts, n_received)   rebuilds its table from what it received (equal keys add up).
+ * bk_sample_finalize_shard refuses n_shards > 1 with full_kmer_stats unless the table was replaced in this sample.  The totals
+ * then travel in the bk_shard_sums_device_ptr vector like the other statistics. */
+int bk_kmer_table_partition(bk_engine* e, int n_parts, void** d_keys, void** d_counts, uint64_t* part_off /* [n_parts + 1] */);
+int bk_kmer_table_replace(bk_engine* e, const void* d_keys, const void* d_counts, uint64_t n);
 /* Device pointers of the finalized arrays: 4 planes (fwd depth, rev depth, fwd #kmers, rev #kmers) of
  * total_cells*4 u64 each, contiguous, in (file, seq, pos, base) order. */
 int bk_pileup_device_ptr(bk_engine* e, void** d_ptr);

@@ -115,3 +115,35 @@ def test_reduce_scatter_and_combine_helpers(tmp_path):
         assert torch.equal(got[r]["d2"], torch.maximum(got[0]["depth"], got[1]["depth"]))
         assert torch.equal(got[r]["n2"], got[0]["nk"] + got[1]["nk"])
         assert torch.equal(got[r]["s2"], got[0]["sums"] + got[1]["sums"])
+
+
+def _worker_entries(rank, world, port, out_dir):
+    from bronko_amd.dist import exchange_entries
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(500 + rank)
+        splits = [3 + rank, 0 if rank == 1 else 5, 2]                  # ragged groups, one of them empty
+        keys = torch.randint(0, 2 ** 62, (sum(splits),), generator=g, dtype=torch.int64)
+        cnts = torch.randint(1, 1000, (sum(splits),), generator=g, dtype=torch.int32)
+        rk, rc = exchange_entries(keys, cnts, splits)
+        torch.save({"keys": keys, "cnts": cnts, "splits": splits, "rk": rk, "rc": rc}, os.path.join(out_dir, "e%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_kmer_table_entries_all_to_all(tmp_path):
+    """bronko_amd.dist.exchange_entries (the exchange step of full_kmer_stats under a sharded finalize): group r of every rank
+    arrives at rank r, in rank order, ragged and empty groups included (world_size 3, gloo)."""
+    world = 3
+    port = _free_port()
+    mp.spawn(_worker_entries, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(os.path.join(str(tmp_path), "e%d.pt" % r)) for r in range(world)]
+    for r in range(world):
+        want_k, want_c = [], []
+        for q in range(world):
+            lo = sum(got[q]["splits"][:r])
+            want_k.append(got[q]["keys"][lo:lo + got[q]["splits"][r]])
+            want_c.append(got[q]["cnts"][lo:lo + got[q]["splits"][r]])
+        assert torch.equal(got[r]["rk"], torch.cat(want_k)) and torch.equal(got[r]["rc"], torch.cat(want_c))

@@ -428,14 +428,18 @@ def test_reverse_complement_repeats(oracle):
     ix.close()
 
 
-def test_sharded_finalize_on_one_device(oracle, sars_paths):
+@pytest.mark.parametrize("kmer_stats", [False, True])
+def test_sharded_finalize_on_one_device(oracle, sars_paths, kmer_stats):
     """The cheap multi-GPU form (reduce-scatter + bk_sample_finalize_shard + max / sum of the pileups) simulated on one
     device with four engines standing for four ranks: every "rank" scans its reads; the planes are summed (what the
     reduce-scatter computes) and each rank keeps ONLY its quarter of the sum -- the rest of its plane is overwritten with
     garbage, which a correct shard never reads; the four partial pileups are combined by max / sum, the statistics by
-    sum.  Result must equal the oracle on all reads (4 strains: several genomes, dirty neighbourhoods, deferred k-mers)."""
+    sum.  Result must equal the oracle on all reads (4 strains: several genomes, dirty neighbourhoods, deferred k-mers).
+    kmer_stats: with bk_params.full_kmer_stats the ranks' statistics tables are exchanged first (bk_kmer_table_partition, an
+    all-to-all -- here device copies --, bk_kmer_table_replace) and KMC's distinct / counted totals of the whole sample come out
+    exact on every rank; without the exchange the sharded finalize refuses."""
     import torch
-    from bronko_amd import pack_reads
+    from bronko_amd import pack_reads, Params
     from bronko_amd.dist import DeviceVector
     world = 4
     ix = oracle.Index.build(21, sars_paths)
@@ -443,7 +447,7 @@ def test_sharded_finalize_on_one_device(oracle, sars_paths):
     c1, c2 = synth.paired_codes(gm, 20000, 150, 13, isnv=isnv)
     mates = [synth.codes_to_ascii(c1), synth.codes_to_ascii(c2)]
     pile = oracle.sample_pileup(ix, mates)
-    engs = [helpers.engine_from_oracle_index(ix) for _ in range(world)]
+    engs = [helpers.engine_from_oracle_index(ix, Params(full_kmer_stats=kmer_stats, kmer_table_log2=16)) for _ in range(world)]
     assert engs[0].counter_len % 64 == 0
     for r, e in enumerate(engs):
         e.sample_begin()
@@ -452,6 +456,24 @@ def test_sharded_finalize_on_one_device(oracle, sars_paths):
             w, l = pack_reads(reads[lo:hi], 21)
             e.push_reads(m, w, l)
     torch.cuda.synchronize()
+    if kmer_stats:
+        with pytest.raises(Exception, match="exchange"):
+            engs[0].sample_finalize_shard(2, 0, world)
+        parts = []
+        for e in engs:
+            kp, cp, off = e.kmer_table_partition(world)
+            keys = torch.as_tensor(DeviceVector(kp, max(off[world], 1)), device="cuda:0")
+            cnts = torch.as_tensor(DeviceVector(cp, max(off[world], 1), "<i4"), device="cuda:0")
+            parts.append([(keys[off[r]:off[r + 1]].clone(), cnts[off[r]:off[r + 1]].clone()) for r in range(world)])
+        assert sum(len(p[0]) for p in parts[0]) > 1000                 # (the case is not vacuous)
+        held = []
+        for r, e in enumerate(engs):                                    # "all-to-all": rank r receives group r of every rank
+            rk = torch.cat([parts[q][r][0] for q in range(world)])
+            rc = torch.cat([parts[q][r][1] for q in range(world)])
+            torch.cuda.synchronize()
+            e.kmer_table_replace(rk.data_ptr(), rc.data_ptr(), len(rk))
+            held.append((rk, rc))
+        torch.cuda.synchronize()
     n = engs[0].counter_len
     part = n // world
     for m in range(2):
@@ -482,6 +504,9 @@ def test_sharded_finalize_on_one_device(oracle, sars_paths):
     res = engs[0].sample_download(2)
     helpers.assert_same_pileup(res, pile)
     assert oracle.pick_best_genome(ix, res.stats.sum(axis=0), res.present.max(axis=0)) == 1
+    assert res.kmer_stats[:, 1].tolist() == pile.kmc_stats[:, 1].tolist()
+    if kmer_stats:
+        assert res.kmer_stats[:, 2:4].tolist() == pile.kmc_stats[:, 2:4].tolist(), (res.kmer_stats, pile.kmc_stats)
     for e in engs:
         e.close()
     ix.close()

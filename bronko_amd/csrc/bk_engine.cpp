@@ -67,7 +67,7 @@ struct TimedSpan { hipEvent_t a, b; int kind; };
 // fn(begin, end) over [0, n) on up to hardware_concurrency() threads (capped at 32): host-side table construction only
 template <typename F>
 void parallel_for(size_t n, F&& fn) {
-    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 96u);
     if (n < (size_t)nt * 1024) { fn((size_t)0, n); return; }
     std::vector<std::thread> th;
     const size_t per = (n + nt - 1) / nt;
@@ -620,7 +620,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     };
     {
         const uint64_t nbk = e->W > 0 ? ix->n_buckets : 0;
-        const unsigned nt = nbk < 65536 ? 1u : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+        const unsigned nt = nbk < 65536 ? 1u : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 96u);
         std::vector<ChunkOut> outs(nt);
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; t++) {
@@ -677,18 +677,27 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     // ---- reference k-mer set U ------------------------------------------------------------------------------
     // ids in order of first occurrence in reference order; perfect hash (membership + diagonal seeding);
     // half-key directories (neighbour search); the reference in reference order (diagonal walk); per-id tables.
-    std::sort(h_u.begin(), h_u.end());
+    const unsigned sort_threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    parallel_sort(h_u, std::less<uint64_t>(), sort_threads);
     h_u.erase(std::unique(h_u.begin(), h_u.end()), h_u.end());
     // pseudo k-mers join U (so that the membership / neighbour machinery finds the read k-mers that alias), but they
     // own only the window positions at which the table holds a key for them.  A pseudo value that is a real
     // reference k-mer needs nothing: its alias key is that k-mer's own bucket key.
     std::vector<uint64_t> extra;
-    std::sort(pseudo.begin(), pseudo.end());
+    parallel_sort(pseudo, std::less<uint64_t>(), sort_threads);
     pseudo.erase(std::unique(pseudo.begin(), pseudo.end()), pseudo.end());
-    for (uint64_t v : pseudo)
-        if (!std::binary_search(h_u.begin(), h_u.end(), v)) extra.push_back(v);
-    h_u.insert(h_u.end(), extra.begin(), extra.end());
-    std::sort(h_u.begin(), h_u.end());
+    {
+        std::vector<uint8_t> keep(pseudo.size(), 0);
+        parallel_for(pseudo.size(), [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; i++) keep[i] = std::binary_search(h_u.begin(), h_u.end(), pseudo[i]) ? 0 : 1;
+        });
+        for (size_t i = 0; i < pseudo.size(); i++) if (keep[i]) extra.push_back(pseudo[i]);   // (sorted, like pseudo)
+    }
+    {
+        const size_t mid = h_u.size();
+        h_u.insert(h_u.end(), extra.begin(), extra.end());
+        std::inplace_merge(h_u.begin(), h_u.begin() + (ptrdiff_t)mid, h_u.end());   // two sorted, disjoint runs
+    }
     // bucket (slot) of every k-mer of U at every window position, by table lookup; h_valid = positions with a bucket
     std::vector<uint32_t> h_valid(h_u.size(), 0u);
     std::vector<uint8_t> h_is_pseudo(h_u.size(), 0);
@@ -722,29 +731,50 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         const size_t pad_w = (size_t)bk::scan_ref_pad_words();   // front padding of the two 2-bit arrays
         std::vector<uint32_t> h_refw(pad_w + (cells + 15) / 16 + (size_t)bk::scan_ref_back_words(), 0u), h_brc((cells + 31) / 32 + 1, 0u);
         uint32_t next_id = 0;
-        size_t sq = 0;
-        for (int f = 0; f < ix->n_files; f++) {
-            for (int sidx = 0; sidx < ix->n_seqs[f]; sidx++, sq++) {
-                const uint64_t len = ix->seq_lens[sq];
-                const uint8_t* seq = ix->seqs[sq];
-                const uint64_t c0 = cell_off[f][sidx];
-                for (uint64_t i = 0; i < len; i++) h_refw[pad_w + ((c0 + i) >> 4)] |= (uint32_t)bronko::nt_to_bits(seq[i]) << (2 * ((c0 + i) & 15));
-                if (len < (uint64_t)k) continue;
-                const uint64_t mask = bronko::kmer_mask(k);
-                uint64_t fwd = 0;
-                for (int i = 0; i < k - 1; i++) fwd = (fwd << 2) | bronko::nt_to_bits(seq[i]);
-                for (uint64_t i = 0; i + k <= len; i++) {
-                    fwd = ((fwd << 2) | bronko::nt_to_bits(seq[i + k - 1])) & mask;
-                    const bronko::Canon cn = bronko::canonical_u64(fwd, k);
-                    const auto it = std::lower_bound(h_u.begin(), h_u.end(), cn.kmer);   // h_u is sorted
-                    if (it == h_u.end() || *it != cn.kmer) continue;   // not in the index: never predicted, never counted
-                    const uint32_t ui = (uint32_t)(it - h_u.begin());
-                    const uint64_t cell = c0 + i;
-                    if (id_of[ui] == kNone) { id_of[ui] = next_id++; first_cell[ui] = (uint32_t)cell; first_rc[ui] = cn.rc ? 1 : 0; }
-                    h_id_at[cell] = id_of[ui];
-                    if (cn.rc) h_brc[cell >> 5] |= 1u << (cell & 31);
+        // first every cell's k-mer is looked up in U (the sequences side by side on host threads; h_id_at holds the index into
+        // h_u for the moment), then the ids are handed out in reference order
+        std::vector<uint8_t> cell_rc(std::max<uint64_t>(cells, 1), 0);
+        {
+            struct SeqJob { const uint8_t* seq; uint64_t len, c0; };
+            std::vector<SeqJob> jobs;
+            size_t sq = 0;
+            for (int f = 0; f < ix->n_files; f++)
+                for (int sidx = 0; sidx < ix->n_seqs[f]; sidx++, sq++) {
+                    const uint64_t len = ix->seq_lens[sq], c0 = cell_off[f][sidx];
+                    const uint8_t* seq = ix->seqs[sq];
+                    for (uint64_t i = 0; i < len; i++) h_refw[pad_w + ((c0 + i) >> 4)] |= (uint32_t)bronko::nt_to_bits(seq[i]) << (2 * ((c0 + i) & 15));
+                    // long sequences in pieces (every piece re-reads the k - 1 bases before it)
+                    for (uint64_t a = 0; a + k <= len; a += 65536) jobs.push_back(SeqJob{seq + a, std::min<uint64_t>(len - a, 65536 + (uint64_t)k - 1), c0 + a});
                 }
-            }
+            std::atomic<size_t> next_job{0};
+            auto work = [&] {
+                const uint64_t mask = bronko::kmer_mask(k);
+                for (size_t j = next_job++; j < jobs.size(); j = next_job++) {
+                    const SeqJob& jb = jobs[j];
+                    uint64_t fwd = 0;
+                    for (int i = 0; i < k - 1; i++) fwd = (fwd << 2) | bronko::nt_to_bits(jb.seq[i]);
+                    for (uint64_t i = 0; i + k <= jb.len; i++) {
+                        fwd = ((fwd << 2) | bronko::nt_to_bits(jb.seq[i + k - 1])) & mask;
+                        const bronko::Canon cn = bronko::canonical_u64(fwd, k);
+                        const auto it = std::lower_bound(h_u.begin(), h_u.end(), cn.kmer);   // h_u is sorted
+                        if (it == h_u.end() || *it != cn.kmer) continue;   // not in the index: never predicted, never counted
+                        h_id_at[jb.c0 + i] = (uint32_t)(it - h_u.begin());
+                        cell_rc[jb.c0 + i] = cn.rc ? 1 : 0;
+                    }
+                }
+            };
+            const unsigned nt = jobs.size() < 4 ? 1u : std::min<unsigned>(sort_threads, (unsigned)jobs.size());
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+            work();
+            for (auto& t : th) t.join();
+        }
+        for (uint64_t cell = 0; cell < cells; cell++) {
+            const uint32_t ui = h_id_at[cell];
+            if (ui == kNone) continue;
+            if (id_of[ui] == kNone) { id_of[ui] = next_id++; first_cell[ui] = (uint32_t)cell; first_rc[ui] = cell_rc[cell]; }
+            h_id_at[cell] = id_of[ui];
+            if (cell_rc[cell]) h_brc[cell >> 5] |= 1u << (cell & 31);
         }
         for (size_t i = 0; i < h_u.size(); i++)   // k-mers known only through index entries: ids after the others
             if (id_of[i] == kNone && !h_is_pseudo[i]) id_of[i] = next_id++;
@@ -802,33 +832,52 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 const int parts = dist + 1;   // words at distance <= dist agree on at least one of dist + 1 parts
                 if (collect) collect->assign(parts, {});
                 std::vector<std::thread> th;
+                const unsigned per_part = std::max(1u, std::min(24u, std::thread::hardware_concurrency() / (unsigned)parts));
                 for (int part = 0; part < parts; part++) th.emplace_back([&, part] {   // (flags are only ever set to 1: benign races)
                     std::vector<Form> fs(forms);
                     std::vector<uint64_t>* near = collect ? &(*collect)[part] : nullptr;
                     const int c0 = (part * k) / parts, c1 = ((part + 1) * k) / parts;
                     const uint64_t mask = (((1ull << (2 * (c1 - c0))) - 1ull) << (2 * c0));
-                    parallel_sort(fs, [&](const Form& x, const Form& y) { return (x.w & mask) < (y.w & mask); },
-                                  std::max(1u, std::min(8u, std::thread::hardware_concurrency() / (unsigned)parts)));
-                    for (size_t a0 = 0; a0 < fs.size();) {
-                        size_t a1 = a0 + 1;
-                        while (a1 < fs.size() && (fs[a1].w & mask) == (fs[a0].w & mask)) a1++;
-                        if (a1 - a0 > 4096) {   // pathological low-complexity group: flag all, skip the quadratic pass
-                            for (size_t x = a0; x < a1; x++) { out[fs[x].id] = 1; if (near) h_no_list[fs[x].fi >> 1] = 1; }
-                        } else {
-                            for (size_t x = a0; x < a1; x++)
-                                for (size_t y = x + 1; y < a1; y++) {
-                                    const uint64_t d = fs[x].w ^ fs[y].w;
-                                    if (__builtin_popcountll((d | (d >> 1)) & 0x5555555555555555ull) <= dist) {
-                                        out[fs[x].id] = out[fs[y].id] = 1;   // also catches u vs rc(u) (same id)
-                                        if (near) {   // (owner canonical form << 32) | the other form
-                                            if (!(fs[x].fi & 1u)) near->push_back(((uint64_t)(fs[x].fi >> 1) << 32) | fs[y].fi);
-                                            if (!(fs[y].fi & 1u)) near->push_back(((uint64_t)(fs[y].fi >> 1) << 32) | fs[x].fi);
+                    parallel_sort(fs, [&](const Form& x, const Form& y) { return (x.w & mask) < (y.w & mask); }, per_part);
+                    // the groups (equal parts), dealt to threads in runs of whole groups; every thread collects its own near pairs
+                    const unsigned nt = fs.size() < 262144 ? 1u : per_part;
+                    std::vector<size_t> cut(nt + 1, fs.size());
+                    cut[0] = 0;
+                    for (unsigned t = 1; t < nt; t++) {
+                        size_t a = std::max(fs.size() * t / nt, cut[t - 1]);
+                        while (a < fs.size() && a > 0 && (fs[a].w & mask) == (fs[a - 1].w & mask)) a++;
+                        cut[t] = a;
+                    }
+                    std::vector<std::vector<uint64_t>> mine(nt);
+                    auto scan_groups = [&](size_t lo, size_t hi, std::vector<uint64_t>& out_near) {
+                        for (size_t a0 = lo; a0 < hi;) {
+                            size_t a1 = a0 + 1;
+                            while (a1 < hi && (fs[a1].w & mask) == (fs[a0].w & mask)) a1++;
+                            if (a1 - a0 > 4096) {   // pathological low-complexity group: flag all, skip the quadratic pass
+                                for (size_t x = a0; x < a1; x++) { out[fs[x].id] = 1; if (near) h_no_list[fs[x].fi >> 1] = 1; }
+                            } else {
+                                for (size_t x = a0; x < a1; x++)
+                                    for (size_t y = x + 1; y < a1; y++) {
+                                        const uint64_t d = fs[x].w ^ fs[y].w;
+                                        if (__builtin_popcountll((d | (d >> 1)) & 0x5555555555555555ull) <= dist) {
+                                            out[fs[x].id] = out[fs[y].id] = 1;   // also catches u vs rc(u) (same id)
+                                            if (near) {   // (owner canonical form << 32) | the other form
+                                                if (!(fs[x].fi & 1u)) out_near.push_back(((uint64_t)(fs[x].fi >> 1) << 32) | fs[y].fi);
+                                                if (!(fs[y].fi & 1u)) out_near.push_back(((uint64_t)(fs[y].fi >> 1) << 32) | fs[x].fi);
+                                            }
                                         }
                                     }
-                                }
+                            }
+                            a0 = a1;
                         }
-                        a0 = a1;
+                    };
+                    {
+                        std::vector<std::thread> gt;
+                        for (unsigned t = 1; t < nt; t++) gt.emplace_back([&, t] { scan_groups(cut[t], cut[t + 1], mine[t]); });
+                        scan_groups(cut[0], cut[1], mine[0]);
+                        for (auto& t : gt) t.join();
                     }
+                    if (near) for (auto& v : mine) { near->insert(near->end(), v.begin(), v.end()); std::vector<uint64_t>().swap(v); }
                 });
                 for (auto& t : th) t.join();
             };
@@ -840,7 +889,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             for (auto& v : near_parts) tot += v.size();
             h_near.reserve(tot);
             for (auto& v : near_parts) { h_near.insert(h_near.end(), v.begin(), v.end()); std::vector<uint64_t>().swap(v); }
-            std::sort(h_near.begin(), h_near.end());
+            parallel_sort(h_near, std::less<uint64_t>(), sort_threads);
             h_near.erase(std::unique(h_near.begin(), h_near.end()), h_near.end());
         }
         for (size_t i = 0; i < h_u.size(); i++) if (h_is_pseudo[i]) h_amb3[id_of[i]] = 1;
@@ -1074,10 +1123,10 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 std::vector<uint32_t> order(h_u.size());
                 for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
                 if (which == 0)
-                    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+                    parallel_sort(order, [&](uint32_t x, uint32_t y) {
                         const uint64_t hx = half_of(h_u[x]), hy = half_of(h_u[y]);
                         return hx != hy ? hx < hy : h_u[x] < h_u[y];
-                    });   // (which == 1: h_u is sorted by value, hence by its high half, then by value)
+                    }, sort_threads);   // (which == 1: h_u is sorted by value, hence by its high half, then by value)
                 std::vector<bk::NbEntry>& cand = hh[which].cand;
                 cand.resize(order.size());
                 std::vector<uint64_t> halves;
@@ -1155,7 +1204,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         {
             // per id, independently: chunks on host threads, each with its own list, joined in id order
             const size_t n_ids = h_u.size();
-            const unsigned nt = n_ids < 65536 ? 1u : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+            const unsigned nt = n_ids < 65536 ? 1u : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 96u);
             std::vector<std::vector<uint32_t>> part(nt);
             std::vector<uint32_t> n_of(n_ids, 0u);
             auto work = [&](unsigned t) {

@@ -49,7 +49,7 @@ class BuiltIndex(C.Structure):  # bk_built_index
 
 
 # every symbol include/bronko_hip.h declares (checked by tests/test_abi.py)
-SYMBOLS = ["bk_abi_version", "bk_device_count", "bk_last_error", "bk_params_default", "bk_engine_create", "bk_engine_destroy", "bk_engine_fork", "bk_engine_get_stream",
+SYMBOLS = ["bk_abi_version", "bk_device_count", "bk_device_memory", "bk_last_error", "bk_params_default", "bk_engine_create", "bk_engine_destroy", "bk_engine_fork", "bk_engine_get_stream",
            "bk_engine_set_stream", "bk_total_cells", "bk_n_files", "bk_n_slots", "bk_counter_len", "bk_sample_begin",
            "bk_push_reads_packed", "bk_push_reads_packed_device", "bk_push_reads_ascii", "bk_counters_device_ptr", "bk_sample_finalize",
            "bk_sample_finalize_shard", "bk_shard_sums_device_ptr", "bk_sample_merge_shards", "bk_kmer_table_partition", "bk_kmer_table_replace",
@@ -80,6 +80,8 @@ def load(testing=None):
     vp, u64, i32, u32 = C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32
     L.bk_abi_version.restype = C.c_int
     L.bk_device_count.restype = C.c_int
+    L.bk_device_memory.restype = C.c_int
+    L.bk_device_memory.argtypes = [C.c_int, C.POINTER(u64), C.POINTER(u64)]
     L.bk_last_error.restype = C.c_char_p
     L.bk_params_default.argtypes = [C.POINTER(Params)]
     L.bk_engine_create.restype = C.c_int

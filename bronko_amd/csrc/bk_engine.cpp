@@ -439,6 +439,14 @@ int bk_device_count(void) {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
 }
+int bk_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes) {
+    if (!free_bytes || !total_bytes) return fail(BK_ERR_INVALID, "null argument");
+    BK_HIP(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    BK_HIP(hipMemGetInfo(&f, &t));
+    *free_bytes = f; *total_bytes = t;
+    return BK_OK;
+}
 const char* bk_last_error(void) { return g_err.c_str(); }
 
 void bk_params_default(bk_params* p) {

@@ -411,7 +411,7 @@ int run_call(const Args& a) {
     // its own copy.  BRONKO_DEVICES=0,1,.. names the devices (default: all visible ones; naming a device twice doubles its
     // lanes), BRONKO_DEVICE=d the single device of earlier versions, BRONKO_LANES=n the lanes per device (default: -t / 2
     // over the devices, at most 16 -- a 256-thread host inflates 8 gzip streams side by side at full speed and 32 at half --
-    // and no more than fit a quarter of the device's memory: a lane keeps two samples'
+    // and no more than fit six tenths of the device's free memory: a lane keeps two samples'
     // counter planes there -- 0.2 GB for one SARS-CoV-2 genome, 9 GB for a hundred at k = 31).
     std::vector<int> devices;
     if (const char* dl = getenv("BRONKO_DEVICES")) {
@@ -466,10 +466,14 @@ int run_call(const Args& a) {
     }
     {
         size_t per_device = std::min<size_t>(16, std::max<size_t>(1, (size_t)a.threads / 2 / devices.size()));
-        for (const auto& f : first) {
-            if (!f.e) continue;
-            const double per_engine = 3.0 * 8.0 * (double)bk_counter_len(f.e) + 64.0 * (double)bk_total_cells(f.e) + 64e6;   // planes, lists, pileups, scratch
-            per_device = std::min<size_t>(per_device, std::max<size_t>(1, (size_t)(64e9 / (2.0 * per_engine))));
+        for (size_t q = 0; q < first.size(); q++) {
+            if (!first[q].e) continue;
+            // what a lane's two engines keep on the device: two counter planes, the deferred lists and touch lists (as much
+            // again), pileups, the k-mer statistics table (it starts at 0.8 GB) -- against six tenths of what the device has free
+            const double per_engine = 4.0 * 8.0 * (double)bk_counter_len(first[q].e) + 64.0 * (double)bk_total_cells(first[q].e) + 1.0e9;
+            uint64_t free_b = 0, total_b = 0;
+            if (bk_device_memory(first_dev[q], &free_b, &total_b) != 0) free_b = 64ull << 30;
+            per_device = std::min<size_t>(per_device, std::max<size_t>(1, (size_t)(0.6 * (double)free_b / (2.0 * per_engine))));
         }
         if (const char* nl = getenv("BRONKO_LANES")) per_device = std::max<size_t>(1, (size_t)atoi(nl));
         std::vector<int> lanes_on;
@@ -489,10 +493,14 @@ int run_call(const Args& a) {
         for (int d : devices) names += (names.empty() ? "" : ",") + std::to_string(d);
         LOG_INFO(T, "Samples go to " + std::to_string(lanes.size()) + " GPU lanes in turn (devices " + names + ")");
     }
-    for (auto& ln : lanes) {
-        if (ln.parent >= 0) { hip_check(bk_engine_fork(lanes[(size_t)ln.parent].eng.e, &ln.eng.e), "bk_engine_fork"); continue; }
-        for (size_t q = 0; q < first.size(); q++)
+    for (auto& ln : lanes)
+        for (size_t q = 0; q < first.size() && ln.parent < 0; q++)
             if (first[q].e && !ln.eng.e && first_dev[q] == ln.device) std::swap(ln.eng.e, first[q].e);
+    {
+        std::vector<std::thread> th;   // (a fork allocates and zeroes a sample's planes: gigabytes with a large index)
+        for (auto& ln : lanes)
+            if (ln.parent >= 0) th.emplace_back([&lanes, &ln] { hip_check(bk_engine_fork(lanes[(size_t)ln.parent].eng.e, &ln.eng.e), "bk_engine_fork"); });
+        for (auto& t : th) t.join();
     }
 
     CallParams cp;

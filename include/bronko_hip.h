@@ -95,6 +95,9 @@ int         bk_abi_version(void);
 /* Number of visible HIP devices (0 when there is none or the runtime cannot be initialised).  A host with several samples
  * creates one engine per device and deals whole samples to them (call.rs:212 / :297: samples are independent). */
 int         bk_device_count(void);
+/* Free and total memory of a device in bytes (v6): a host that runs several engines per device (bk_engine_fork: every fork holds
+ * a sample's counter planes and outputs) sizes their number by it. */
+int         bk_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);
 const char* bk_last_error(void);
 void        bk_params_default(bk_params* p);
 

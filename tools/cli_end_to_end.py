@@ -2,7 +2,9 @@
 """`bronko call` end to end: FASTQ.gz files on disk -> VCFs, wall time of the whole command (gunzip + parse on host threads,
 PCIe, the GPU path, calls, output files).  Writes S synthetic samples of N reads (config-2 shape: wuhan_ref, 150 bp single-end,
 0.5 % errors) as real .fastq.gz files under a scratch directory, then times the binary with 1 lane and with the default lanes.
-usage: tools/cli_end_to_end.py [samples 16] [reads 1000000] [threads 32]"""
+With a fourth argument N > 1 the references are N synthetic strains (wuhan_ref + 300 substitutions each, k = 31: BASELINE
+config 5's shape) written as FASTA files, sample s is derived from strain s mod N.
+usage: tools/cli_end_to_end.py [samples 16] [reads 1000000] [threads 32] [strains 1]"""
 import gzip, os, subprocess, sys, tempfile, time
 from multiprocessing import Pool
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,8 +17,8 @@ BIN = os.path.join(ROOT, "bronko_amd", "bin", "bronko")
 
 
 def write_sample(arg):
-    path, n, seed = arg
-    g, isnv = synth.sample_genome(synth.read_fasta_bytes(REF), seed)
+    path, n, seed, base = arg
+    g, isnv = synth.sample_genome(base, seed)
     codes = synth.single_end_codes(g, n, 150, 7000003 + seed, isnv=isnv)
     seqs = synth.BASES[codes]                                   # u8 [n][150]
     rec = np.empty((n, 4 + 8 + 1 + 150 + 3 + 150 + 1), np.uint8)   # "@r" + 8 hex digits + \n seq \n+\n qual \n
@@ -36,16 +38,36 @@ def write_sample(arg):
     return os.path.getsize(path)
 
 
+def prepare(tmp, S, N, NS):
+    """Writes the reference FASTA files (NS > 1: synthetic strains) and S samples of N reads as .fastq.gz under tmp.
+    Returns (reference paths, extra arguments, sample paths)."""
+    wuhan = synth.read_fasta_bytes(REF)
+    if NS > 1:
+        files = synth.strain_files(wuhan, NS)
+        refs, bases, kk = [], [], ["-k", "31"]
+        for name, seqs in files:
+            fp = os.path.join(tmp, name + ".fasta")
+            with open(fp, "wb") as f:
+                for sn, sq in seqs:
+                    f.write(b">" + sn.encode() + b"\n" + bytes(sq) + b"\n")
+            refs.append(fp); bases.append(bytes(seqs[0][1]))
+    else:
+        refs, bases, kk = [REF], [wuhan], []
+    paths = [os.path.join(tmp, "sample%02d.fastq.gz" % s) for s in range(S)]
+    t0 = time.time()
+    with Pool(min(S, 16)) as pool:
+        sizes = pool.map(write_sample, [(p, N, 100 + s, bases[s % len(bases)]) for s, p in enumerate(paths)])
+    print("wrote %d samples x %d reads: %.1f MB of .fastq.gz (%.1f MB of FASTQ text) in %.0f s" % (S, N, sum(sizes) / 1e6, S * N * 317 / 1e6, time.time() - t0), flush=True)
+    return refs, kk, paths
+
+
 def main():
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
     T = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+    NS = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     tmp = tempfile.mkdtemp(prefix="bronko_e2e_")
-    paths = [os.path.join(tmp, "sample%02d.fastq.gz" % s) for s in range(S)]
-    t0 = time.time()
-    with Pool(min(S, 16)) as pool:
-        sizes = pool.map(write_sample, [(p, N, 100 + s) for s, p in enumerate(paths)])
-    print("wrote %d samples x %d reads: %.1f MB of .fastq.gz (%.1f MB of FASTQ text) in %.0f s" % (S, N, sum(sizes) / 1e6, S * N * 317 / 1e6, time.time() - t0), flush=True)
+    refs, kk, paths = prepare(tmp, S, N, NS)
     for lanes in ("1", None):
         env = dict(os.environ)
         env.pop("BRONKO_LANES", None)
@@ -53,14 +75,14 @@ def main():
             env["BRONKO_LANES"] = lanes
         out = os.path.join(tmp, "out_%s" % (lanes or "default"))
         t0 = time.time()
-        r = subprocess.run([BIN, "call", "-g", REF, "-r"] + paths + ["-t", str(T), "-o", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        r = subprocess.run([BIN, "call", "-g"] + refs + ["-r"] + paths + kk + ["-t", str(T), "-o", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         dt = time.time() - t0
         if r.returncode != 0:
             print(r.stderr.decode()[-2000:])
             raise SystemExit("bronko call failed")
         n_vcf = len([f for f in os.listdir(out) if f.endswith(".vcf")])
-        print("bronko call, %s lanes per device (-t %d): %.2f s wall for %d samples (%d VCFs) = %.2f M reads/s end to end" %
-              (lanes or "default", T, dt, S, n_vcf, S * N / dt / 1e6), flush=True)
+        print("bronko call, %d reference genome(s), %s lanes per device (-t %d): %.2f s wall for %d samples (%d VCFs) = %.2f M reads/s end to end" %
+              (len(refs), lanes or "default", T, dt, S, n_vcf, S * N / dt / 1e6), flush=True)
     a = open(os.path.join(tmp, "out_1", "sample00.vcf")).read().split("\n", 3)[-1]
     b = open(os.path.join(tmp, "out_default", "sample00.vcf")).read().split("\n", 3)[-1]
     print("same VCF body with 1 lane and with the default lanes:", a == b)

@@ -5,9 +5,7 @@ import sys, os, time, subprocess
 sys.path.insert(0, ".")
 import tools.cli_end_to_end as t
 os.makedirs("/tmp/e2e", exist_ok=True)
-from multiprocessing import Pool
-paths = ["/tmp/e2e/s%02d.fastq.gz" % i for i in range(32)]
-with Pool(16) as p: p.map(t.write_sample, [(q, 1000000, 300 + i) for i, q in enumerate(paths)])
+refs, kk, paths = t.prepare("/tmp/e2e", 32, 1000000, 1)
 print("nproc", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)))
 for n in (1, 8, 32):
     t0 = time.time()

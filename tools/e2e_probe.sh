@@ -1,20 +1,20 @@
-# Where `bronko call`'s wall time goes with many samples: its log lines stamped as they arrive (32 x 1 M reads, 32 lanes)
+# Where `bronko call`'s wall time goes with many samples: its log lines stamped as they arrive.
+# SAMPLES (32) x 1 M reads, LANES per device (default: the binary's own choice), STRAINS (1; 100 = BASELINE config 5's references)
 cd $GRAFT_REPO_ROOT
 python - <<'PY'
-import sys, os, time, subprocess
+import sys, os, re, time, subprocess
 sys.path.insert(0, ".")
 import tools.cli_end_to_end as t
 os.makedirs("/tmp/e2e", exist_ok=True)
-from multiprocessing import Pool
-paths = ["/tmp/e2e/s%02d.fastq.gz" % i for i in range(32)]
-with Pool(16) as p: p.map(t.write_sample, [(q, 1000000, 300 + i) for i, q in enumerate(paths)])
-env = dict(os.environ, BRONKO_LANES=os.environ.get("LANES", "32"))
+S, NS = int(os.environ.get("SAMPLES", "32")), int(os.environ.get("STRAINS", "1"))
+refs, kk, paths = t.prepare("/tmp/e2e", S, 1000000, NS)
+env = dict(os.environ)
+if "LANES" in os.environ: env["BRONKO_LANES"] = os.environ["LANES"]
 t0 = time.time()
-pr = subprocess.Popen([t.BIN, "call", "-g", t.REF, "-r"] + paths + ["-t", "64", "-o", "/tmp/e2e/out"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+pr = subprocess.Popen([t.BIN, "call", "-g"] + refs + ["-r"] + paths + kk + ["-t", "64", "-o", "/tmp/e2e/out"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
 seen = {}
 for line in pr.stdout:
     line = line.decode().rstrip()
-    import re
     key = re.sub(r"[0-9]+", "#", line.split("/tmp")[0])[:70]
     seen.setdefault(key, []).append(time.time() - t0)
 pr.wait()

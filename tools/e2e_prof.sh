@@ -5,12 +5,10 @@ import sys, os
 sys.path.insert(0, ".")
 import tools.cli_end_to_end as t
 os.makedirs("/tmp/e2e", exist_ok=True)
-from multiprocessing import Pool
-paths = ["/tmp/e2e/s%02d.fastq.gz" % i for i in range(4)]
-with Pool(4) as p: p.map(t.write_sample, [(q, 1000000, 300 + i) for i, q in enumerate(paths)])
+refs, kk, paths = t.prepare("/tmp/e2e", 4, 1000000, 1)
 PY
 export BRONKO_LANES=1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/e2e_prof -- bronko_amd/bin/bronko call -g tests/golden/4_sarscov2/wuhan_ref.fasta -r /tmp/e2e/s00.fastq.gz /tmp/e2e/s01.fastq.gz /tmp/e2e/s02.fastq.gz /tmp/e2e/s03.fastq.gz -t 8 -o /tmp/e2e/out > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/e2e_prof -- bronko_amd/bin/bronko call -g tests/golden/4_sarscov2/wuhan_ref.fasta -r /tmp/e2e/sample00.fastq.gz /tmp/e2e/sample01.fastq.gz /tmp/e2e/sample02.fastq.gz /tmp/e2e/sample03.fastq.gz -t 8 -o /tmp/e2e/out > /dev/null 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/e2e_prof/**/*kernel_stats.csv", recursive=True)[0]

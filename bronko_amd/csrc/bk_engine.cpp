@@ -579,7 +579,10 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     if (keys.empty()) first_kmer = cn.kmer;
                     keys.emplace_back(j, masked);
                 }
-                if (j >= e->wstart && j < e->wstart + e->W) { any_in_window = true; o.h_u.push_back(cn.kmer); }
+                if (j >= e->wstart && j < e->wstart + e->W) {
+                    any_in_window = true;
+                    if (o.h_u.empty() || o.h_u.back() != cn.kmer) o.h_u.push_back(cn.kmer);   // (a bucket of a many-genome index names one k-mer again and again)
+                }
             }
             // the other exact rank that wraps onto this bucket's id, if the reference did not already put a k-mer there
             int alias_j = -1;
@@ -624,6 +627,9 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             }
             if (o.h_ent.size() >= (1ull << 32)) return o.fail(BK_ERR_UNSUPPORTED, "more than 2^32 index entries in the window");
         }
+        // a reference k-mer is named by every window bucket it owns: each chunk hands over its own distinct ones
+        std::sort(o.h_u.begin(), o.h_u.end());
+        o.h_u.erase(std::unique(o.h_u.begin(), o.h_u.end()), o.h_u.end());
         return true;
     };
     {

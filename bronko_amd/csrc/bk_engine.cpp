@@ -647,17 +647,29 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         uint64_t n_ent = 0;
         for (auto& o : outs) n_ent += o.h_ent.size();
         if (n_ent >= (1ull << 32)) return fail(BK_ERR_UNSUPPORTED, "more than 2^32 index entries in the window");
-        for (auto& o : outs) {
-            const uint32_t base = (uint32_t)h_ent.size();
-            h_ent.insert(h_ent.end(), o.h_ent.begin(), o.h_ent.end());
-            h_slot_key.insert(h_slot_key.end(), o.h_slot_key.begin(), o.h_slot_key.end());
-            h_slot_t.insert(h_slot_t.end(), o.h_slot_t.begin(), o.h_slot_t.end());
-            h_len.insert(h_len.end(), o.h_len.begin(), o.h_len.end());
-            for (uint32_t off : o.h_off) h_off.push_back(base + off);
-            h_u.insert(h_u.end(), o.h_u.begin(), o.h_u.end());
-            pseudo.insert(pseudo.end(), o.pseudo.begin(), o.pseudo.end());
-            for (size_t t = 0; t < per_t.size() && t < o.per_t.size(); t++) per_t[t] += o.per_t[t];
-            o = ChunkOut();   // free
+        // the chunks' lists back to back, in chunk order: where each goes is a prefix sum, the copies run side by side
+        std::vector<size_t> e0(nt + 1, h_ent.size()), s0(nt + 1, h_slot_key.size()), u0(nt + 1, h_u.size()), p0(nt + 1, pseudo.size());
+        for (unsigned t = 0; t < nt; t++) {
+            e0[t + 1] = e0[t] + outs[t].h_ent.size(); s0[t + 1] = s0[t] + outs[t].h_slot_key.size();
+            u0[t + 1] = u0[t] + outs[t].h_u.size(); p0[t + 1] = p0[t] + outs[t].pseudo.size();
+            for (size_t w = 0; w < per_t.size() && w < outs[t].per_t.size(); w++) per_t[w] += outs[t].per_t[w];
+        }
+        h_ent.resize(e0[nt]); h_slot_key.resize(s0[nt]); h_slot_t.resize(s0[nt]); h_len.resize(s0[nt]); h_off.resize(s0[nt]);
+        h_u.resize(u0[nt]); pseudo.resize(p0[nt]);
+        {
+            std::vector<std::thread> cp;
+            for (unsigned t = 0; t < nt; t++) cp.emplace_back([&, t] {
+                ChunkOut& o = outs[t];
+                std::copy(o.h_ent.begin(), o.h_ent.end(), h_ent.begin() + (ptrdiff_t)e0[t]);
+                std::copy(o.h_slot_key.begin(), o.h_slot_key.end(), h_slot_key.begin() + (ptrdiff_t)s0[t]);
+                std::copy(o.h_slot_t.begin(), o.h_slot_t.end(), h_slot_t.begin() + (ptrdiff_t)s0[t]);
+                std::copy(o.h_len.begin(), o.h_len.end(), h_len.begin() + (ptrdiff_t)s0[t]);
+                for (size_t i = 0; i < o.h_off.size(); i++) h_off[s0[t] + i] = (uint32_t)e0[t] + o.h_off[i];
+                std::copy(o.h_u.begin(), o.h_u.end(), h_u.begin() + (ptrdiff_t)u0[t]);
+                std::copy(o.pseudo.begin(), o.pseudo.end(), pseudo.begin() + (ptrdiff_t)p0[t]);
+                o = ChunkOut();   // free
+            });
+            for (auto& t : cp) t.join();
         }
     }
     pc.lap("buckets -> slots (+aliases)");
@@ -670,17 +682,31 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     while ((1ull << e->log2s) < 2 * max_t) e->log2s++;   // load factor <= 0.5
     const size_t S = (size_t)1 << e->log2s;
     std::vector<bk::TableSlot> h_table((size_t)std::max(e->W, 1) * S, bk::TableSlot{bk::kEmptyKey, 0u, 0u});
-    for (uint64_t s = 0; s < e->n_slots; s++) {
-        bk::TableSlot* sub = h_table.data() + (size_t)h_slot_t[s] * S;
-        uint32_t h = bk::hash_key(h_slot_key[s], e->log2s);
-        while (sub[h].key != bk::kEmptyKey) {
-            if (sub[h].key == h_slot_key[s]) {
-                if (k == 31) break;   // an alias key that coincides with a real key (same wrapped id, same bucket): keep the first
-                return fail(BK_ERR_INVALID, "duplicate window bucket in the index");
+    {
+        // one sub-table per window position: each is filled by its own host thread, in slot order (the first of equal keys stays)
+        std::atomic<bool> dup{false};
+        auto fill = [&](int t0, int t1) {
+            for (uint64_t s = 0; s < e->n_slots; s++) {
+                const int t = h_slot_t[s];
+                if (t < t0 || t >= t1) continue;
+                bk::TableSlot* sub = h_table.data() + (size_t)t * S;
+                uint32_t h = bk::hash_key(h_slot_key[s], e->log2s);
+                while (sub[h].key != bk::kEmptyKey) {
+                    if (sub[h].key == h_slot_key[s]) {
+                        if (k != 31) dup = true;   // (k = 31: an alias key that coincides with a real key -- same wrapped id, same bucket: keep the first)
+                        break;
+                    }
+                    h = (h + 1) & (uint32_t)(S - 1);
+                }
+                if (sub[h].key == bk::kEmptyKey) { sub[h].key = h_slot_key[s]; sub[h].slot = (uint32_t)s; }
             }
-            h = (h + 1) & (uint32_t)(S - 1);
-        }
-        if (sub[h].key == bk::kEmptyKey) { sub[h].key = h_slot_key[s]; sub[h].slot = (uint32_t)s; }
+        };
+        const int nth = e->n_slots < 262144 ? 1 : std::max(1, std::min<int>(e->W, (int)std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (int q = 1; q < nth; q++) th.emplace_back(fill, e->W * q / nth, e->W * (q + 1) / nth);
+        fill(0, e->W / nth > 0 ? e->W / nth : e->W);
+        for (auto& t : th) t.join();
+        if (dup) return fail(BK_ERR_INVALID, "duplicate window bucket in the index");
     }
     pc.lap("window tables");
     // a slot with no entries: "this k-mer has no bucket at that window position" (pseudo k-mers)
@@ -1143,12 +1169,15 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     }, sort_threads);   // (which == 1: h_u is sorted by value, hence by its high half, then by value)
                 std::vector<bk::NbEntry>& cand = hh[which].cand;
                 cand.resize(order.size());
+                parallel_for(order.size(), [&](size_t i0, size_t i1) {   // (the gather through `order` is what costs: host threads)
+                    for (size_t i = i0; i < i1; i++)
+                        cand[i] = bk::NbEntry{h_u[order[i]], row_base[order[i]], (h_valid[order[i]] & 0x7fffffffu) | (first_rc[order[i]] ? 0x80000000u : 0u)};
+                });
                 std::vector<uint64_t> halves;
                 std::vector<uint32_t> first, count;
                 for (size_t i = 0; i < order.size(); i++) {
-                    const uint64_t u = h_u[order[i]];
-                    cand[i] = bk::NbEntry{u, row_base[order[i]], (h_valid[order[i]] & 0x7fffffffu) | (first_rc[order[i]] ? 0x80000000u : 0u)};
-                    if (halves.empty() || halves.back() != half_of(u)) { halves.push_back(half_of(u)); first.push_back((uint32_t)i); count.push_back(0); }
+                    const uint64_t hf = half_of(cand[i].u);
+                    if (halves.empty() || halves.back() != hf) { halves.push_back(hf); first.push_back((uint32_t)i); count.push_back(0); }
                     count.back()++;
                 }
                 bk_engine::HalfBufs& hb = which == 0 ? e->half_lo : e->half_hi;

@@ -1605,7 +1605,7 @@ __device__ __forceinline__ void v_kmer_of_counter(const IndexView& ix, const uns
 // A row also holds k-mers that cannot touch the index: the difference outside the window, or a k-mer whose canonical form
 // lies on the other strand than its neighbour's (scan_count records what the reads contain, not what it means).  They are
 // skipped -- with full_kmer_stats they join the k-mer statistics table, like every other k-mer that touches nothing.
-__global__ __launch_bounds__(256) void finalize_variant_kernel(FinalizeArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void finalize_variant_kernel(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (a.mode == 2) { a.sel_file = *a.sel; if (a.sel_file < 0 && !a.clear_v) return; }   // (no genome selected: no votes, but the plane is still to be cleared)   // second pass: votes for the selected genome only
     const bool do_stats = a.mode != 2;                                       // (its statistics were tallied by the first pass)

@@ -107,6 +107,14 @@ class SampleResult:
         return self.fwd_depth, self.rev_depth, self.fwd_nk, self.rev_nk
 
 
+def device_memory(device=0):
+    """(free, total) bytes of a device (bk_device_memory): what the CLI sizes its number of ingest lanes by."""
+    L = _ffi.load()
+    f, t = C.c_uint64(), C.c_uint64()
+    _check(L.bk_device_memory(device, C.byref(f), C.byref(t)), L)
+    return f.value, t.value
+
+
 class Engine:
     def __init__(self, k, bucket_ids, bucket_off, entries, files, params=None):
         """files: [(file_name, [(seq_name, seq_bytes), ...]), ...] = ViralMetadata (build.rs:46-50)"""

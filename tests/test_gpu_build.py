@@ -63,3 +63,10 @@ def test_engine_on_a_device_built_index(oracle, golden_dir):
     helpers.assert_same_pileup(helpers.hip_sample(eng, [reads], 21), oracle.sample_pileup(ix, [reads]))
     eng.close()
     ix.close()
+
+
+def test_device_memory_query():
+    """bk_device_memory: free <= total, and an MI355X reports far more than the tables of the tests."""
+    from bronko_amd.engine import device_memory
+    free, total = device_memory(0)
+    assert 0 < free <= total and total > (64 << 30)

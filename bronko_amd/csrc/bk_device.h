@@ -199,9 +199,10 @@ struct IndexView {
 // consecutive ids along the reference -- into non-reference k-mers, each differing from "its" reference k-mer at a different
 // offset o from the k-mer's start along the reference (o = j for a k-mer that is canonical as written, k-1-j for one that
 // was reverse-complemented; j = position in the canonical k-mer).  id + o is the same for all of them.  So the plane is a set
-// of rows (q = id + o - omin, base b on the reference's forward strand, direction d of the read: 0 along / 1 against the
-// reference), each a DIFFERENCE ARRAY over o: the number of occurrences of "(q - o, o, b) read in direction d" is the prefix
-// sum row[0] + ... + row[o - omin].  A read with one error adds +1 at the first offset its k-mers cover and -1 after the last
+// of rows (q = id + o - omin, alternative a = which of the three OTHER bases stands there -- (base XOR reference base) - 1, the
+// same on either strand (complementing both leaves the XOR): the reference base itself can never be counted here, so a
+// position has 3 x 2 rows, not 4 x 2 --, direction d of the read: 0 along / 1 against the reference), each a DIFFERENCE ARRAY over o: the number of occurrences of "(q - o, o, b) read in direction d" is the prefix
+// sum row[0] + ... + row[o - omin] (b = reference base of k-mer q - o at offset o, XOR (a + 1)).  A read with one error adds +1 at the first offset its k-mers cover and -1 after the last
 // -- two atomics for up to k k-mers; a single k-mer is +1 at o, -1 at o + 1.  finalize takes the prefix sums and derives each
 // k-mer (its canonical form and orientation included) from the row coordinates.
 BK_HD uint64_t e_plane_len(uint32_t n_u) { return 2ull * n_u; }
@@ -212,10 +213,14 @@ BK_HD int v_layout_span(int k, int wstart, int W, bool all_offsets) {
     const int hi1 = wstart + W - 1, hi2 = k - 1 - wstart;
     return (hi1 > hi2 ? hi1 : hi2) - v_layout_omin(k, wstart, W, false) + 1;
 }
-BK_HD uint64_t v_real_rows(uint32_t n_full, int span) { return span > 0 ? ((uint64_t)n_full + (uint32_t)span) * 8ull : 0ull; }
+constexpr uint32_t kVRowsPerPos = 6;   // 3 alternative bases x 2 read directions
+BK_HD uint64_t v_real_rows(uint32_t n_full, int span) { return span > 0 ? ((uint64_t)n_full + (uint32_t)span) * kVRowsPerPos : 0ull; }
 BK_HD uint64_t v_real_len(uint32_t n_full, int span) { return v_real_rows(n_full, span) * (uint64_t)(span + 1); }
-// first counter of row (q, b, d); the row has span + 1 counters (the last only ever receives a -1)
-BK_HD uint64_t v_row_base(uint32_t q, uint32_t b, uint32_t d, int span) { return (((uint64_t)q * 4ull + b) * 2ull + d) * (uint64_t)(span + 1); }
+// which alternative: base b where the reference has r (both on the same strand, either one); 0..2 (b == r is never counted)
+BK_HD uint32_t v_alt(uint32_t b, uint32_t r) { return ((b ^ r) & 3u) - 1u; }
+BK_HD uint32_t v_row_index(uint32_t q, uint32_t alt, uint32_t d) { return (q * 3u + alt) * 2u + d; }
+// first counter of row (q, alt, d); the row has span + 1 counters (the last only ever receives a -1)
+BK_HD uint64_t v_row_base(uint32_t q, uint32_t alt, uint32_t d, int span) { return (((uint64_t)q * 3ull + alt) * 2ull + d) * (uint64_t)(span + 1); }
 BK_HD uint64_t v_plane_len(uint32_t n_full, int span, uint64_t n_prows) { return v_real_len(n_full, span) + n_prows * 8ull; }
 // The whole plane: [ E | padding | V rows | pseudo counters | padding ].  The V part starts at a multiple of the row length
 // and the total is a multiple of kMaxShards row lengths, so that cutting the plane into n equal parts (n dividing kMaxShards:

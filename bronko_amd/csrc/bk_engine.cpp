@@ -1035,7 +1035,8 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                                     const uint32_t rcu = first_rc[ni] ? 1u : 0u;
                                     const int oo = (rcu ? k - 1 - jn : jn) - e->v_omin;
                                     if (oo < 0 || oo >= e->v_span) continue;            // (v_point's guard)
-                                    A.idx = (uint32_t)(bk::v_row_base(pnb + (uint32_t)oo, rcu ? 3u - bc : bc, 0u, e->v_span) + (uint32_t)oo);
+                                    const uint32_t nbc = (uint32_t)(h_u[ni] >> (2 * (k - 1 - jn))) & 3u;   // the neighbour's own base there
+                                    A.idx = (uint32_t)(bk::v_row_base(pnb + (uint32_t)oo, bk::v_alt(bc, nbc), 0u, e->v_span) + (uint32_t)oo);
                                     A.meta = 2u | (rcu << 2) | ((oo + 1 < e->v_span) ? 8u : 0u) | multi;
                                 } else {
                                     const uint32_t row = pnb - e->n_full + (uint32_t)__builtin_popcount(h_valid[ni] & ((1u << (jn - e->wstart)) - 1u));
@@ -1083,7 +1084,8 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                                             const uint32_t rcu = first_rc[bi] ? 1u : 0u;
                                             const int oo = (rcu ? k - 1 - jn : jn) - e->v_omin;
                                             if (oo >= 0 && oo < e->v_span) {
-                                                want.idx = (uint32_t)(bk::v_row_base(pnb + (uint32_t)oo, rcu ? 3u - bc : bc, 0u, e->v_span) + (uint32_t)oo);
+                                                const uint32_t nbc = (uint32_t)(h_u[bi] >> (2 * (k - 1 - jn))) & 3u;
+                                                want.idx = (uint32_t)(bk::v_row_base(pnb + (uint32_t)oo, bk::v_alt(bc, nbc), 0u, e->v_span) + (uint32_t)oo);
                                                 want.meta = 2u | (rcu << 2) | ((oo + 1 < e->v_span) ? 8u : 0u) | multi;
                                             }
                                         } else {

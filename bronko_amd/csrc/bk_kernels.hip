@@ -411,12 +411,12 @@ __device__ __forceinline__ void touch(unsigned int* bm, uint32_t i) {
     if (bm && !(__builtin_nontemporal_load(bm + (i >> 5)) >> (i & 31u) & 1u)) atomicOr(bm + (i >> 5), 1u << (i & 31u));
 }
 
-__device__ __forceinline__ void v_point(unsigned long long* __restrict__ v_counters, uint32_t id, uint32_t o, uint32_t b, uint32_t d,
+__device__ __forceinline__ void v_point(unsigned long long* __restrict__ v_counters, uint32_t id, uint32_t o, uint32_t alt, uint32_t d,
                                         int omin, int span, unsigned int* touch_v = nullptr) {
     const uint32_t oo = o - (uint32_t)omin;
     if (oo >= (uint32_t)span) return;   // offsets outside the layout touch no window bucket
-    touch(touch_v, ((id + oo) * 4u + b) * 2u + d);
-    unsigned long long* row = v_counters + v_row_base(id + oo, b, d, span) + oo;
+    touch(touch_v, v_row_index(id + oo, alt, d));
+    unsigned long long* row = v_counters + v_row_base(id + oo, alt, d, span) + oo;
     atomicAdd(row, 1ull);
     if (oo + 1u < (uint32_t)span) atomicAdd(row + 1, ~0ull);   // (slot `span` is never read)
 }
@@ -484,12 +484,13 @@ struct SlowPipe {
             const int k = ix.k, wlo = ix.wstart, whi = ix.wstart + ix.W;
             const uint32_t off_lo = b2.x, cnt_lo = b2.y, off_hi = b2.z, cnt_hi = b2.w;
             uint64_t best = ~0ull;   // (j << 32) | NbEntry::p, smallest wins
-            uint32_t bvalid = 0;
+            uint32_t bvalid = 0, bref = 0;   // ... its valid mask and its own base at j
             auto consider = [&](const uint4& e) {
-                const int j = single_diff_pos((uint64_t)e.x | ((uint64_t)e.y << 32), c, k);
+                const uint64_t eu = (uint64_t)e.x | ((uint64_t)e.y << 32);
+                const int j = single_diff_pos(eu, c, k);
                 if (j >= wlo && j < whi && ((e.w >> (j - wlo)) & 1u)) {   // the neighbour owns a bucket at j
                     const uint64_t key = ((uint64_t)j << 32) | e.z;
-                    if (key < best) { best = key; bvalid = e.w; }
+                    if (key < best) { best = key; bvalid = e.w; bref = (uint32_t)(eu >> (2 * (k - 1 - j))) & 3u; }
                 }
             };
             if (cnt_lo) consider(b0);
@@ -503,7 +504,7 @@ struct SlowPipe {
                 if (p < ix.n_full) {
                     // in reference coordinates: offset from the k-mer's start, base on the forward strand, read direction
                     const uint32_t rcu = bvalid >> 31;
-                    v_point(v_counters, p, (uint32_t)(rcu ? k - 1 - j : j), rcu ? 3u - b : b, isrc ^ rcu, ix.v_omin, ix.v_span, touch_v);
+                    v_point(v_counters, p, (uint32_t)(rcu ? k - 1 - j : j), v_alt(b, bref), isrc ^ rcu, ix.v_omin, ix.v_span, touch_v);
                 } else {
                     const uint32_t row = p - ix.n_full + (uint32_t)__popc(bvalid & ((1u << (j - wlo)) - 1u));
                     touch(touch_p, row);
@@ -764,11 +765,13 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                     if (n1 == 0) head = an ? min(dirty_len, (int)n2) : (int)n2;
                 }
                 uint64_t F;   // mismatch flags of the read bases s_first + [0, 64) the first n1 k-mers cover
+                uint64_t xa, xb;   // read XOR reference along those bases (2 bits per base): which other base stands at a mismatch
                 {
                     // read base s_first + t <-> reference base c_first + t (fwd) / complement of base c_first + k - 1 - t
                     const uint64_t ra = fwd2 ? symbols_at(refw, c_first) : ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 31));
                     const uint64_t rb = fwd2 ? symbols_at(refw, c_first + 32) : ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 63));
                     const uint64_t da = ga ^ ra, db = gb ^ rb;
+                    xa = da; xb = db;
                     const uint32_t f_lo = even_bits((uint32_t)(da | (da >> 1))) | (even_bits((uint32_t)((da | (da >> 1)) >> 32)) << 16);
                     const uint32_t f_hi = even_bits((uint32_t)(db | (db >> 1))) | (even_bits((uint32_t)((db | (db >> 1)) >> 32)) << 16);
                     const uint32_t L = n1 ? (uint32_t)n1 + km1 : 0u;   // bases they cover
@@ -808,7 +811,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                     const int s_lo = max(max(ti - kk, tprev + 1), 0), s_hi = min(min(ti, tn - k), cutn - 1);
                     if (act && s_hi >= s_lo) {
                         const uint32_t tpos = (uint32_t)(ti - s_lo);    // offset of the differing base in the run's first k-mer
-                        const uint32_t br = (uint32_t)((ti < 32 ? ga : gb) >> (2u * ((uint32_t)ti & 31u))) & 3u;
+                        // which of the three other bases: read XOR reference at the mismatch, the same on either strand (bk_device.h)
+                        const uint32_t alt = ((uint32_t)((ti < 32 ? xa : xb) >> (2u * ((uint32_t)ti & 31u))) & 3u) - 1u;
                         const uint32_t nm1 = (uint32_t)(s_hi - s_lo);
                         // offsets (along the reference, from each k-mer's start) the run's k-mers have the difference at
                         const uint32_t o_first = fwd2 ? tpos : km1 - tpos;
@@ -817,8 +821,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                         const int lo2 = max((int)o_lo, omin), hi2 = min((int)o_hi, omin + span - 1);
                         if (lo2 <= hi2 && !BK_ABLATE(a, 2)) {
                             const uint32_t idS = id_first + ddir * (uint32_t)s_lo;
-                            unsigned long long* row = v_counters + v_row_base(idS + o_first - (uint32_t)omin, fwd2 ? br : 3u - br, fwd2 ? 0u : 1u, span);
-                            if constexpr (SPARSE) touch(a.touch_v, ((idS + o_first - (uint32_t)omin) * 4u + (fwd2 ? br : 3u - br)) * 2u + (fwd2 ? 0u : 1u));
+                            unsigned long long* row = v_counters + v_row_base(idS + o_first - (uint32_t)omin, alt, fwd2 ? 0u : 1u, span);
+                            if constexpr (SPARSE) touch(a.touch_v, v_row_index(idS + o_first - (uint32_t)omin, alt, fwd2 ? 0u : 1u));
                             atomicAdd(row + (lo2 - omin), 1ull);
                             if (hi2 - omin + 1 < span) atomicAdd(row + (hi2 - omin + 1), ~0ull);   // (slot `span` is never read)
                         }
@@ -1080,12 +1084,13 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
             const uint32_t br = (uint32_t)(g >> (2u * t)) & 3u;                 // ... and the read's base there
             const uint32_t o = fwd ? t : km1 - t;                               // offset along the reference from the cell
             const uint32_t bfw = fwd ? br : 3u - br;                            // base on the reference's forward strand
+            const uint32_t alt = ((uint32_t)(da >> (2u * t)) & 3u) - 1u;        // which of the three other bases: read XOR reference (bk_device.h)
             if (fl & kCellClean) {
                 // a clean reference k-mer of known id: provably not a reference k-mer, and that k-mer is its only possible
                 // neighbour (bk_device.h, amb) -- a single-k-mer S run (v_point)
                 const uint32_t oo = o - (uint32_t)omin;
                 if (oo < (uint32_t)span && !BK_ABLATE(a, 2)) {                  // offsets outside the layout touch no window bucket
-                    vp = (uint32_t)(v_row_base(id + oo, bfw, fwd ? 0u : 1u, span) + oo);
+                    vp = (uint32_t)(v_row_base(id + oo, alt, fwd ? 0u : 1u, span) + oo);
                     if (oo + 1u < (uint32_t)span) vm = vp + 1u;                 // (slot `span` is never read)
                 }
                 slow = false;
@@ -1576,13 +1581,14 @@ __device__ __forceinline__ void v_kmer_of_counter(const IndexView& ix, const uns
         const uint32_t oo = (uint32_t)(vi % rl);
         n = 0;
         if (vc) for (uint32_t x = 0; x <= oo; ++x) n += vc[row * rl + x];   // (null: the caller has the count)
-        p = (uint32_t)(row >> 3) - oo;
+        const uint32_t r6 = (uint32_t)(row % kVRowsPerPos);           // (alternative << 1) | direction
+        p = (uint32_t)(row / kVRowsPerPos) - oo;
         const uint32_t rcid = (ix.amb[p] >> 1) & 1u;
         const int o = (int)oo + ix.v_omin;
         const int j = rcid ? k - 1 - o : o;
-        const uint32_t bf = (uint32_t)(row >> 1) & 3u;
-        bb = rcid ? 3u - bf : bf;
-        isrc = ((uint32_t)row & 1u) ^ rcid;
+        const uint32_t own = (uint32_t)(ix.kmer_of[p] >> (2 * (k - 1 - j))) & 3u;   // the reference k-mer's own base there (canonical form)
+        bb = own ^ ((r6 >> 1) + 1u);                                                // the alternative: XOR, the same on either strand
+        isrc = (r6 & 1u) ^ rcid;
         t = (uint32_t)(j - ix.wstart);
     } else {
         const uint64_t x = vi - real_len;
@@ -1719,7 +1725,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // sparse finalize: the touched rows from the list, RPW at a time, instead of every row of the plane
     const uint64_t n_listed = a.v_list ? a.n_list[0] : 0ull;
     const uint64_t n_units = a.v_list ? (n_listed + RPW - 1) / RPW
-                                      : ((nq + 2 * RPW - 1) / (2 * RPW)) * 16;   // unit u: q block u / 16 (2 RPW values of q), parity (u / 8) & 1, (base, direction) u & 7
+                                      : ((nq + 2 * RPW - 1) / (2 * RPW)) * 12;   // unit u: q block u / 12 (2 RPW values of q), parity (u / 6) & 1, (alternative, direction) u % 6
     uint32_t par = 0;
     const bool sparse_plane = ix.n_files > 1 && !a.v_list;
     for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
@@ -1729,17 +1735,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const uint64_t li = u * RPW + hw;
             in_row = lane_on && li < n_listed;
             wk = in_row ? a.v_list[li] : 0ull;
-            qrow = wk >> 3;
+            qrow = wk / kVRowsPerPos;
         } else {
-            qrow = (u >> 4) * (2 * RPW) + ((u >> 3) & 1ull) + 2ull * hw;
-            wk = qrow * 8 + (u & 7ull);
+            qrow = (u / 12) * (2 * RPW) + ((u / 6) & 1ull) + 2ull * hw;
+            wk = qrow * kVRowsPerPos + (u % 6);
             in_row = lane_on && qrow < nq && wk >= row_lo && wk < row_hi;
         }
         unsigned long long n = in_row ? vc[wk * rl + oo] : 0ull;
         if (a.clear_v && n) vc[wk * rl + oo] = 0ull;   // (every counter is read by exactly one lane of one pass)
         // What this lane needs besides its count depends on the row's coordinates only: the reference k-mer's record (k-mer,
         // first cell, flags -- one 16-byte load, consecutive ids across the lanes) goes out together with the row's load.
-        const uint32_t d = (uint32_t)wk & 1u, bf = (uint32_t)(wk >> 1) & 3u, q = (uint32_t)(wk >> 3);
+        const uint32_t r6 = (uint32_t)(wk % kVRowsPerPos), d = r6 & 1u, alt = r6 >> 1, q = (uint32_t)(wk / kVRowsPerPos);
         const bool inq = in_row && oo < (uint32_t)ix.v_span && q >= oo && q - oo < ix.n_full;
         const uint32_t p = inq ? q - oo : 0u;
         const uint4 idr = *reinterpret_cast<const uint4*>(ix.id_rec + p);
@@ -1758,9 +1764,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const uint32_t rcid = (ambp >> 1) & 1u;
         const bool dirty = ambp & 1u;
         const int j = rcid ? k - 1 - o : o;
-        const uint32_t bb = rcid ? 3u - bf : bf;
-        const uint32_t isrc = d ^ rcid;
         const int sh = 2 * (k - 1 - (act ? j : 0));
+        // the base that stands there instead of the reference k-mer's own: own XOR (alternative + 1), on either strand
+        const uint32_t bb = ((uint32_t)(kmer_p >> sh) & 3u) ^ (alt + 1u);
+        const uint32_t isrc = d ^ rcid;
         const uint64_t c = (kmer_p & ~(3ull << sh)) | ((uint64_t)bb << sh);
         const uint64_t rc = revcomp_kmer(c, k);
         const bool alive = j >= ix.wstart && j < ix.wstart + ix.W && c < rc;

@@ -62,8 +62,15 @@ struct alignas(8) DirtyAns {
 };
 constexpr uint32_t kAnsNone = 16u, kAnsMulti = 32u;
 // per-cell flags byte (Level 2): bits 0-1 = cell_codes symbol (0 no k-mer of U starts here, 1 canonical as written, 2 reverse-
-// complemented), bit 2 = clean (cell_yf bit 0), bit 3 = cell_clean3
-constexpr uint32_t kCellClean = 4u, kCellClean3 = 8u;
+// complemented), bit 2 = clean (cell_yf bit 0), bit 3 = cell_clean3, bit 4 = the cell stands in the orientation of its k-mer's
+// first occurrence (the coordinates the answer table is laid out in)
+constexpr uint32_t kCellClean = 4u, kCellClean3 = 8u, kCellFirstOri = 16u;
+// The answer table (DirtyAns) in reference coordinates of the k-mer's first occurrence: offset o of the changed base from the
+// k-mer's start along the reference, base b on the forward strand.  Laid out by diagonal, [id + o][b][o]: the k-mers of a read
+// that cover one sequencing error have consecutive ids and falling offsets -- their answers are neighbours in memory (8 bytes
+// apart) instead of k * 32 bytes apart, which is what Level 2's one random load per k-mer costs on a many-genome index.
+BK_HD size_t ans_index(uint32_t id, uint32_t o, uint32_t b, int k) { return (((size_t)id + o) * 4u + b) * (size_t)k + o; }
+BK_HD size_t ans_table_len(uint32_t n_full, int k) { return ((size_t)n_full + (size_t)k) * 4u * (size_t)k; }
 
 // Multiplicative hash into a table of 2^log2s positions.
 BK_HD uint32_t hash_key(uint64_t key, uint32_t log2s) {
@@ -139,8 +146,8 @@ struct IndexView {
     const KmerPos*   kmer_pos; // [m] perfect-hash table of U (membership test, diagonal seeding)
     const uint64_t*  kmer_of;  // [n_u] id -> canonical k-mer
     const IdRec*     id_rec;   // [n_u] id -> k-mer, first cell, flags (see IdRec)
-    const DirtyAns*  dirty_ans;// [n_full][k][4] (see DirtyAns), indexed (id * k + j) * 4 + bb; rows of k-mers all of whose cells are
-                               // clean are never read; null when the table was not built (index too large)
+    const DirtyAns*  dirty_ans;// [n_full + k][4][k] (see DirtyAns, ans_index); entries of k-mers all of whose cells are clean are
+                               // never read; null when the table was not built (index too large)
     const uint8_t*   cell_flags;// [total_cells] per-cell flags byte (see kCellClean)
     // the reference in reference order, for the diagonal walk of scan_count (staged in LDS when it fits):
     const uint32_t*  ref_words;   // 2-bit packed bases of all cells (nt_to_bits, 16 per word, LSB first), padded in front

@@ -956,7 +956,8 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             h_has[bpad_w + (c >> 5)] |= 1u << (c & 31);
             if (clean) h_clean[bpad_w + (c >> 5)] |= 1u << (c & 31);
             else h_needs_ans[h_id_at[c]] = 1;
-            h_cflags[c] = (uint8_t)((rc_here ? 2u : 1u) | (clean ? bk::kCellClean : 0u) | (h_amb3[h_id_at[c]] ? 0u : bk::kCellClean3));
+            h_cflags[c] = (uint8_t)((rc_here ? 2u : 1u) | (clean ? bk::kCellClean : 0u) | (h_amb3[h_id_at[c]] ? 0u : bk::kCellClean3) |
+                                    (rc_here == rc_of_id[h_id_at[c]] ? bk::kCellFirstOri : 0u));
             if (!h_amb3[h_id_at[c]]) h_clean3[bpad_w + (c >> 5)] |= 1u << (c & 31);
             h_yf[wi] |= (clean | (from_prev ? 2u : 0u)) << sh;
             h_yr[wi] |= (clean | (to_next ? 2u : 0u)) << sh;
@@ -976,10 +977,14 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             std::vector<uint32_t> owners;   // index into h_u of each filled row
             for (size_t id = 0; id < e->n_full; id++)
                 if (h_needs_ans[id] || h_amb[id]) owners.push_back(idx_by_id[id]);   // (a dirty k-mer without a cell: finalize still asks)
-            const size_t per = (size_t)k * 4;
-            const bool build = e->W > 0 && (size_t)e->n_full * per * sizeof(bk::DirtyAns) <= ((size_t)16 << 30);
+            const bool build = e->W > 0 && bk::ans_table_len(e->n_full, k) * sizeof(bk::DirtyAns) <= ((size_t)16 << 30);
             if (build && !owners.empty()) {
-                std::vector<bk::DirtyAns> h_ans((size_t)e->n_full * per, bk::DirtyAns{0u, 0u});
+                std::vector<bk::DirtyAns> h_ans(bk::ans_table_len(e->n_full, k), bk::DirtyAns{0u, 0u});
+                // entry of "reference k-mer id (index i into h_u) with base bb at position j of its canonical form" (bk_device.h ans_index)
+                auto ans_at = [&](uint32_t i, int j, uint32_t bb) -> bk::DirtyAns& {
+                    const bool rc1 = first_rc[i] != 0;
+                    return h_ans[bk::ans_index(id_of[i], (uint32_t)(rc1 ? k - 1 - j : j), rc1 ? 3u - bb : bb, k)];
+                };
                 const uint64_t vreal = bk::v_real_len(e->n_full, e->v_span);
                 auto diff1 = [&](uint64_t a, uint64_t b) -> int {   // position (from the left) of the single differing base, or -1
                     const uint64_t x = a ^ b, y = (x | (x >> 1)) & 0x5555555555555555ull;
@@ -991,9 +996,8 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     for (size_t r = r0; r < r1; r++) {
                         const uint32_t i = owners[r];
                         const uint64_t u = h_u[i];
-                        const size_t row = id_of[i];
                         if (h_no_list[i]) {   // a low-complexity group too large to enumerate: no near list, no answers
-                            for (size_t x = 0; x < per; x++) h_ans[row * per + x] = bk::DirtyAns{0u, bk::kAnsNone};
+                            for (int j = 0; j < k; j++) for (uint32_t bb = 0; bb < 4; bb++) ans_at(i, j, bb) = bk::DirtyAns{0u, bk::kAnsNone};
                             continue;
                         }
                         fl.clear();
@@ -1006,7 +1010,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                             const int sh = 2 * (k - 1 - j);
                             for (uint32_t bb = 0; bb < 4; bb++) {
                                 if (((u >> sh) & 3ull) == bb) continue;
-                                bk::DirtyAns& A = h_ans[(row * (size_t)k + j) * 4 + bb];
+                                bk::DirtyAns& A = ans_at(i, j, bb);
                                 const uint64_t z = (u & ~(3ull << sh)) | ((uint64_t)bb << sh);
                                 const uint64_t zr = bronko::reverse_complement_u64(z, k);
                                 const bool flip = zr < z;              // the canonical form of z is its reverse complement
@@ -1094,7 +1098,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                                         }
                                     }
                                 }
-                                const bk::DirtyAns& got = h_ans[((size_t)id_of[owners[r]] * (size_t)k + j) * 4 + bb];
+                                const bk::DirtyAns& got = ans_at(owners[r], j, bb);
                                 if (got.idx != want.idx || got.meta != want.meta) {
                                     if (bad++ < 5) fprintf(stderr, "[bk] dirty answer differs: id %u j %d bb %u: table (%u, %u) definition (%u, %u)\n", id_of[owners[r]], j, bb, got.idx, got.meta, want.idx, want.meta);
                                 }

@@ -1097,9 +1097,9 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
                 BK_DBG(a, 5, true, 1);
             } else if (answers) {
                 // not clean (other reference k-mers nearby, or the other orientation of a repeat): worked out at create
-                const bool rcq = (fl & 3u) == 2u;                               // the cell's k-mer was reverse-complemented
-                const uint32_t jq = rcq ? km1 - o : o, bq = rcq ? 3u - bfw : bfw;
-                const uint2 ans = *reinterpret_cast<const uint2*>(answers + ((size_t)id * (uint32_t)k + jq) * 4u + bq);
+                // (in the coordinates of the k-mer's first occurrence; a cell on the other strand of a reverse-complement repeat mirrors)
+                const bool first_ori = (fl & kCellFirstOri) != 0u;
+                const uint2 ans = *reinterpret_cast<const uint2*>(answers + ans_index(id, first_ori ? o : km1 - o, first_ori ? bfw : 3u - bfw, k));
                 const uint32_t kind = ans.y & 3u;
                 if (!(ans.y & kAnsNone)) {
                     slow = false;
@@ -1783,7 +1783,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             // neighbours sit at several window positions was worked out with its answer (DirtyAns); without the table,
             // enumerate them.  Several buckets -> general path (K2b)
             bool multi;
-            const uint2 ans = ix.dirty_ans ? *reinterpret_cast<const uint2*>(ix.dirty_ans + ((size_t)p * (uint32_t)k + (uint32_t)j) * 4u + bb) : make_uint2(0u, kAnsNone);
+            const uint2 ans = ix.dirty_ans ? *reinterpret_cast<const uint2*>(ix.dirty_ans + ans_index(p, (uint32_t)o, rcid ? 3u - bb : bb, k)) : make_uint2(0u, kAnsNone);
             if (!(ans.y & kAnsNone)) multi = (ans.y & kAnsMulti) != 0u;
             else {
                 uint32_t jmask = 0;

@@ -1755,10 +1755,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         // a unit whose rows are all empty (most of them, with a large index and one sample) costs its loads and this vote only
         // (asked only where it pays: a single genome's plane is three quarters full and the extra barrier costs 5 %)
         if (sparse_plane && !__syncthreads_or(n != 0ull)) continue;
+        // the row's running sums.  Counts and their differences are small almost always: when every value of the wave lies in
+        // (-2^26, 2^26) the sums of up to 32 of them fit 32 bits and the shuffles move one word instead of two
+        if (!a.wide_prefix && !__any((n + (1ull << 26)) >> 27)) {
+            int v = (int)(unsigned int)n;
 #pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
-            const unsigned long long t = __shfl_up(n, off, 64);   // (lane - off is in the same row whenever oo >= off)
-            if (oo >= (uint32_t)off) n += t;
+            for (int off = 1; off < 32; off <<= 1) {
+                const int t = __shfl_up(v, off, 64);   // (lane - off is in the same row whenever oo >= off)
+                if (oo >= (uint32_t)off) v += t;
+            }
+            n = (unsigned long long)(long long)v;      // (a k-mer's count: never negative)
+        } else {
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                const unsigned long long t = __shfl_up(n, off, 64);
+                if (oo >= (uint32_t)off) n += t;
+            }
         }
         bool act = inq && n != 0;
         const uint32_t rcid = (ambp >> 1) & 1u;

@@ -1746,7 +1746,6 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             if (e->sparse) { a.v_list = e->v_list[m].p; a.p_list = e->p_list[m].p; a.e_list = e->e_list[m].p; a.n_list = e->n_list[m].p; }
             a.deferred_n = e->deferred_n.p ? e->deferred_n.p + (two_pass ? (size_t)m * (e->deferred_n.n / 2) : 0) : nullptr;
             a.clear_v = clean_dense && pass == (two_pass ? 1 : 0);
-            a.wide_prefix = test_env("BK_WIDE_PREFIX") ? 1 : 0;
             a.mode = two_pass ? pass + 1 : 0;
             a.sel = two_pass ? &e->sel_out.p->file_id : nullptr;
             a.sel_file = -1;

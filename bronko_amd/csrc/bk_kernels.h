@@ -75,7 +75,6 @@ struct FinalizeArgs {
     int row_exact, row_general;     // first partials row of K2e / K2b (set by launch_finalize)
     unsigned int* deferred;         // [v_plane_len] V counter indices K2a hands to K2b
     unsigned long long* deferred_n; // ... and their counts (clear_v: K2b cannot read them from the plane any more); may be null
-    int wide_prefix;                // testing build (BK_WIDE_PREFIX): K2a takes its 64-bit prefix sums even when 32 bits would do
     int clear_v;                    // K2a zeroes every V counter it reads (dense planes, the whole plane in this call, last pass):
                                     // the plane needs no memset before the next sample
     unsigned int* n_deferred;       // [1], zeroed before each finalize

@@ -1729,23 +1729,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     uint32_t par = 0;
     const bool sparse_plane = ix.n_files > 1 && !a.v_list;
     for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
-        uint64_t qrow, wk;
+        // (row indices fit 32 bits -- a plane of 2^32 counters is refused at create --: divisions by 6 on 32-bit words, not 64)
+        uint32_t q, r6;
+        uint64_t wk;
         bool in_row;
         if (a.v_list) {
             const uint64_t li = u * RPW + hw;
             in_row = lane_on && li < n_listed;
-            wk = in_row ? a.v_list[li] : 0ull;
-            qrow = wk / kVRowsPerPos;
+            const uint32_t w32 = in_row ? a.v_list[li] : 0u;
+            q = w32 / kVRowsPerPos; r6 = w32 - q * kVRowsPerPos;
+            wk = w32;
         } else {
-            qrow = (u / 12) * (2 * RPW) + ((u / 6) & 1ull) + 2ull * hw;
-            wk = qrow * kVRowsPerPos + (u % 6);
+            const uint32_t u32 = (uint32_t)u, u6 = u32 / 6u;    // (wave-uniform)
+            r6 = u32 - u6 * 6u;
+            const uint64_t qrow = (uint64_t)(u6 >> 1) * (2 * RPW) + (u6 & 1u) + 2ull * hw;
+            wk = qrow * kVRowsPerPos + r6;
             in_row = lane_on && qrow < nq && wk >= row_lo && wk < row_hi;
+            q = (uint32_t)qrow;
         }
         unsigned long long n = in_row ? vc[wk * rl + oo] : 0ull;
         if (a.clear_v && n) vc[wk * rl + oo] = 0ull;   // (every counter is read by exactly one lane of one pass)
         // What this lane needs besides its count depends on the row's coordinates only: the reference k-mer's record (k-mer,
         // first cell, flags -- one 16-byte load, consecutive ids across the lanes) goes out together with the row's load.
-        const uint32_t r6 = (uint32_t)(wk % kVRowsPerPos), d = r6 & 1u, alt = r6 >> 1, q = (uint32_t)(wk / kVRowsPerPos);
+        const uint32_t d = r6 & 1u, alt = r6 >> 1;
         const bool inq = in_row && oo < (uint32_t)ix.v_span && q >= oo && q - oo < ix.n_full;
         const uint32_t p = inq ? q - oo : 0u;
         const uint4 idr = *reinterpret_cast<const uint4*>(ix.id_rec + p);
@@ -1755,22 +1761,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         // a unit whose rows are all empty (most of them, with a large index and one sample) costs its loads and this vote only
         // (asked only where it pays: a single genome's plane is three quarters full and the extra barrier costs 5 %)
         if (sparse_plane && !__syncthreads_or(n != 0ull)) continue;
-        // the row's running sums.  Counts and their differences are small almost always: when every value of the wave lies in
-        // (-2^26, 2^26) the sums of up to 32 of them fit 32 bits and the shuffles move one word instead of two
-        if (!a.wide_prefix && !__any((n + (1ull << 26)) >> 27)) {
-            int v = (int)(unsigned int)n;
 #pragma unroll
-            for (int off = 1; off < 32; off <<= 1) {
-                const int t = __shfl_up(v, off, 64);   // (lane - off is in the same row whenever oo >= off)
-                if (oo >= (uint32_t)off) v += t;
-            }
-            n = (unsigned long long)(long long)v;      // (a k-mer's count: never negative)
-        } else {
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) {
-                const unsigned long long t = __shfl_up(n, off, 64);
-                if (oo >= (uint32_t)off) n += t;
-            }
+        for (int off = 1; off < 32; off <<= 1) {
+            const unsigned long long t = __shfl_up(n, off, 64);   // (lane - off is in the same row whenever oo >= off)
+            if (oo >= (uint32_t)off) n += t;
         }
         bool act = inq && n != 0;
         const uint32_t rcid = (ambp >> 1) & 1u;

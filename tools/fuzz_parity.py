@@ -61,9 +61,8 @@ for it in range(first, first + iters):
     # reference read from global memory, pushes split into several launches
     stats = bool(rng.random() < 0.25)
     prm = Params(ci=int(rng.choice([1, 1, 1, 2, 3])), n_fixed=n_fixed, use_full_kmer=int(full), full_kmer_stats=stats, kmer_table_log2=21)
-    for var in ("BK_LDS_BINS", "BK_REF_IN_LDS", "BK_MAX_LAUNCH_RECORDS", "BK_SPARSE_FINALIZE", "BK_WIDE_PREFIX"):
+    for var in ("BK_LDS_BINS", "BK_REF_IN_LDS", "BK_MAX_LAUNCH_RECORDS", "BK_SPARSE_FINALIZE"):
         os.environ.pop(var, None)
-    if rng.random() < 0.15: os.environ["BK_WIDE_PREFIX"] = "1"               # K2a's 64-bit prefix sums (counts of 2^26 and more)
     if rng.random() < 0.4: os.environ["BK_SPARSE_FINALIZE"] = "1"          # touch lists instead of plane scans (large indexes)
     if rng.random() < 0.2: os.environ["BK_LDS_BINS"] = str(int(rng.integers(64, 2000)))
     if rng.random() < 0.1: os.environ["BK_REF_IN_LDS"] = "0"
@@ -109,7 +108,7 @@ for it in range(first, first + iters):
         bad += 1
         print("MISMATCH it=%d seed=%d k=%d n_fixed=%d full=%d files=%d reads=%d err=%.3f mates=%d batch=%s ascii=%d stats=%d env=%s: %s" %
               (it, seed0, k, n_fixed, full, len(files), len(reads), err, len(mates), batch, ascii_path, stats,
-               {v: os.environ[v] for v in ("BK_LDS_BINS", "BK_REF_IN_LDS", "BK_MAX_LAUNCH_RECORDS", "BK_SPARSE_FINALIZE", "BK_WIDE_PREFIX") if v in os.environ}, str(e)[:300]), flush=True)
+               {v: os.environ[v] for v in ("BK_LDS_BINS", "BK_REF_IN_LDS", "BK_MAX_LAUNCH_RECORDS", "BK_SPARSE_FINALIZE") if v in os.environ}, str(e)[:300]), flush=True)
     eng.close(); ix.close()
 print("%d iterations, %d mismatches, %.0f s" % (iters, bad, time.time() - t0))
 sys.exit(1 if bad else 0)

@@ -346,7 +346,7 @@ def main():
     # The same samples strictly one after the other on one engine, every kernel kind bracketed: a single sample's turnaround and
     # each kernel's own duration with nothing running next to it -- the figure the roofline object is about (in the timed
     # region above a scan shares the CUs with the other samples' kernels).
-    n_serial = max(2, min(8, args.steps * sps))
+    n_serial = max(2, min(32 if reads_per_sample_rank <= 2000000 else 8, args.steps * sps))   # (32 short samples: the average of 8 moved by 10 % from run to run)
     run_sample(0, 0)
     fence()
     timing(1)

@@ -334,11 +334,10 @@ void parse_fastq(const std::string& path, BatchQueue& out) {
     FastqBatch cur;
     try {
         GzLineReader in(path);
-        std::string line;
-        uint64_t ln = 0, n = 0;
-        while (in.next(line)) {
-            if ((ln++ & 3) != 1) continue;           // 4-line FASTQ records: @id / sequence / + / quality
-            cur.buf += line;
+        uint64_t n = 0;
+        for (uint64_t ln = 0;; ln++) {               // 4-line FASTQ records: @id / sequence / + / quality
+            if ((ln & 3) != 1) { if (!in.skip_next()) break; continue; }
+            if (!in.append_next(cur.buf)) break;     // (the sequence line goes straight into the batch)
             cur.off.push_back(cur.buf.size());
             if (++n % kBatchReads == 0) { out.put(std::move(cur)); cur = out.fresh(); }
         }

@@ -2,6 +2,8 @@
 #pragma once
 #include <zlib.h>
 
+#include <cstring>
+
 #include <stdexcept>
 #include <string>
 
@@ -45,7 +47,38 @@ public:
         return true;
     }
 
+    // The next line appended to `dst` (no terminator) / passed over without a copy; false at end of file.  FASTQ ingest copies one
+    // line in four, straight into the batch it is pushed from.
+    bool append_next(std::string& dst) { return scan(&dst); }
+    bool skip_next() { return scan(nullptr); }
+
 private:
+    bool scan(std::string* dst) {
+        bool any = false;
+        const size_t start = dst ? dst->size() : 0;
+        for (;;) {
+            if (pos_ == len_) {
+                const int n = gzread(g_, buf_, sizeof buf_);
+                if (n < 0) throw std::runtime_error("read error in " + path_);
+                if (n == 0) break;
+                pos_ = 0; len_ = (size_t)n;
+            }
+            any = true;
+            const char* p = buf_ + pos_;
+            const char* nl = (const char*)memchr(p, '\n', len_ - pos_);
+            if (nl) {
+                if (dst) dst->append(p, nl - p);
+                pos_ += (size_t)(nl - p) + 1;
+                break;
+            }
+            if (dst) dst->append(p, len_ - pos_);
+            pos_ = len_;
+        }
+        if (!any) return false;
+        if (dst) while (dst->size() > start && dst->back() == '\r') dst->pop_back();
+        return true;
+    }
+
     std::string path_;
     gzFile g_ = nullptr;
     char buf_[1 << 16];

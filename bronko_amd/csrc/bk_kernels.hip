@@ -2055,6 +2055,31 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
     const uint64_t n_e = e_plane_len(ix.n_u);
     const uint64_t n_items = *a.n_deferred;   // the E counters are mapped by K2e
 
+    if (a.mode == 2) {
+        // Second pass (votes for the selected genome only, no statistics): nothing crosses lanes, so every lane takes a k-mer of
+        // its own -- 64 chains of dependent loads in flight per wave instead of one -- and walks the window positions: probe the
+        // bucket, find the selected genome's BucketInfos in it (sorted by genome: bisection), vote.
+        for (uint64_t item = (uint64_t)blockIdx.x * 64 + (uint32_t)lane; item < n_items; item += (uint64_t)gridDim.x * 64) {
+            unsigned long long v;
+            uint64_t c;
+            uint32_t isrc, p_, t_;
+            v_kmer_of_counter(ix, a.deferred_n ? nullptr : a.counters + ix.v_off, a.deferred[item], p_, t_, c, isrc, v);
+            if (a.deferred_n) v = a.deferred_n[item];
+            v = v > a.cs ? a.cs : v;
+            for (int t = 0; t < ix.W; ++t) {
+                const int sh = 2 * (k - 1 - (ix.wstart + t));
+                const int sb = probe_table(ix.table + (size_t)t * S, ix.log2s, c & ~(3ull << sh));
+                if (sb < 0) continue;
+                const uint32_t off = ix.ent_off[sb], cnt = ix.ent_len[sb];
+                for (uint32_t q = first_of_file(ix.entries + off, cnt, a.sel_file); q < cnt; ++q) {
+                    const DevEntry e = ix.entries[off + q];
+                    if ((int)e.file != a.sel_file) break;
+                    vote(a, e, c, isrc, k, v);
+                }
+            }
+        }
+        return;
+    }
     // deferred items all passed the thresholds in K2a; one item per wave at a time, dealt round-robin so that a few
     // thousand items spread over the whole grid
     for (uint64_t item = blockIdx.x; item < n_items; item += gridDim.x) {

@@ -46,7 +46,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5], help="BASELINE.json configs[] entry (1-based as in SURVEY.md §8d)")
     ap.add_argument("--reads", type=int, default=1000000, help="reads (config 3: pairs) per batch = per GPU per sample in config 2")
     ap.add_argument("--read-len", type=int, default=150)
@@ -347,7 +347,8 @@ def main():
     # each kernel's own duration with nothing running next to it -- the figure the roofline object is about (in the timed
     # region above a scan shares the CUs with the other samples' kernels).
     n_serial = max(2, min(32 if reads_per_sample_rank <= 2000000 else 8, args.steps * sps))   # (32 short samples: the average of 8 moved by 10 % from run to run)
-    run_sample(0, 0)
+    for i in range(8):   # (untimed: the chip settles into running one sample at a time)
+        run_sample(i, 0)
     fence()
     timing(1)
     timing_read()

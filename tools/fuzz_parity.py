@@ -60,7 +60,9 @@ for it in range(first, first + iters):
     # how the engine is driven: exact k-mer statistics table, a small LDS window (cells outside it go through Level 2), the
     # reference read from global memory, pushes split into several launches
     stats = bool(rng.random() < 0.25)
-    prm = Params(ci=int(rng.choice([1, 1, 1, 2, 3])), n_fixed=n_fixed, use_full_kmer=int(full), full_kmer_stats=stats, kmer_table_log2=21)
+    sel_only = bool(len(files) > 1 and rng.random() < 0.3)   # two finalize passes, votes for the selected genome only
+    prm = Params(ci=int(rng.choice([1, 1, 1, 2, 3])), n_fixed=n_fixed, use_full_kmer=int(full), full_kmer_stats=stats, kmer_table_log2=21,
+                 pileup_selected_only=sel_only)
     for var in ("BK_LDS_BINS", "BK_REF_IN_LDS", "BK_MAX_LAUNCH_RECORDS", "BK_SPARSE_FINALIZE"):
         os.environ.pop(var, None)
     if rng.random() < 0.4: os.environ["BK_SPARSE_FINALIZE"] = "1"          # touch lists instead of plane scans (large indexes)
@@ -100,14 +102,24 @@ for it in range(first, first + iters):
         res = helpers.hip_sample(eng, mates, k, batch=batch, ascii_path=ascii_path)
     pile = orc.sample_pileup(ix, mates, n_fixed=n_fixed, use_full_kmer=full, ci=int(prm.ci))
     try:
-        helpers.assert_same_pileup(res, pile)
+        if sel_only:
+            # statistics of every genome; rows of the selected genome only (the others stay zero)
+            assert np.array_equal(res.stats, pile.stats) and np.array_equal(res.present, pile.present), ("stats", res.stats.tolist(), pile.stats.tolist())
+            best = orc.pick_best_genome(ix, pile.stats.sum(axis=0), pile.present.max(axis=0))
+            lo, ncell = ix.genome_cells(best) if best >= 0 else (0, 0)
+            for name in ("fwd_depth", "rev_depth", "fwd_nk", "rev_nk"):
+                got, ref = getattr(res, name), getattr(pile, name)
+                assert np.array_equal(got[lo * 4:(lo + ncell) * 4], ref[lo * 4:(lo + ncell) * 4]), (name, "selected genome", best)
+                assert not got[:lo * 4].any() and not got[(lo + ncell) * 4:].any(), (name, "other genomes")
+        else:
+            helpers.assert_same_pileup(res, pile)
         assert res.kmer_stats[:, 1].tolist() == pile.kmc_stats[:, 1].tolist(), ("total k-mers", res.kmer_stats[:, 1], pile.kmc_stats[:, 1])
         if stats:
             assert res.kmer_stats[:, 2:4].tolist() == pile.kmc_stats[:, 2:4].tolist(), ("kmc stats", res.kmer_stats, pile.kmc_stats)
     except AssertionError as e:
         bad += 1
-        print("MISMATCH it=%d seed=%d k=%d n_fixed=%d full=%d files=%d reads=%d err=%.3f mates=%d batch=%s ascii=%d stats=%d env=%s: %s" %
-              (it, seed0, k, n_fixed, full, len(files), len(reads), err, len(mates), batch, ascii_path, stats,
+        print("MISMATCH it=%d seed=%d k=%d n_fixed=%d full=%d files=%d reads=%d err=%.3f mates=%d batch=%s ascii=%d stats=%d sel_only=%d env=%s: %s" %
+              (it, seed0, k, n_fixed, full, len(files), len(reads), err, len(mates), batch, ascii_path, stats, sel_only,
                {v: os.environ[v] for v in ("BK_LDS_BINS", "BK_REF_IN_LDS", "BK_MAX_LAUNCH_RECORDS", "BK_SPARSE_FINALIZE") if v in os.environ}, str(e)[:300]), flush=True)
     eng.close(); ix.close()
 print("%d iterations, %d mismatches, %.0f s" % (iters, bad, time.time() - t0))

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- reads/sec through the k-mer -> pileup hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5]
 
 One SAMPLE = one pass of the hot path over the reads of one sample, inputs already resident in HBM:
     bk_sample_begin  ->  bk_push_reads_packed_device per read batch (scan_count + level2 kernels)
     [-> RCCL reduce-scatter(sum) of the k-mer counter plane when one sample's reads are sharded over ranks]
     ->  bk_sample_finalize (KMC thresholds + map_kmers kernels).  Outputs stay in HBM.
-One STEP = `samples_per_step` samples (config.samples_per_step; 32 for config 2, so that the K timed steps are >= 100 ms of
+One STEP = `samples_per_step` samples (config.samples_per_step; 288 for config 2, so that the K = 20 timed steps are >= 1 s of
 GPU work and the driver's sampler sees them).  Samples are independent (call.rs:212 handles a run's samples one after the
 other): `--in-flight` engines on the same device tables (bk_engine_fork) take them in turn, each on its own stream.  The read
 batches rotate over >= 8 distinct synthetic batches (> 256 MiB in all), so no batch is served from the Infinity Cache.
@@ -18,7 +18,11 @@ value = reads of all K steps / wall time of the K steps (barrier + synchronize o
            once per sample, every rank maps its part, the small pileups are combined (max / sum).
 --config 3 (configs[2]): the four golden SARS-CoV-2 genomes k=21, one sample = 10,000,000 pairs (2 x 150 bp) derived from
            ON765678.1, seed 3 (reference selection + pileup).  N > 1: the sample's 1M-pair batches are dealt to the ranks.
+--config 4 (configs[3]): wuhan_ref k=21, ONE sample of 200 x 1,000,000 reads, seed 4; rank r pushes the batches b = r (mod N);
+           N > 1: one reduce-scatter of the counter plane per sample, sharded finalize.  N = 1 keeps the 8.4 GB of records resident.
 --config 5 (configs[4]): 100 synthetic strains k=31, 64 samples x 1,000,000 reads, whole samples per GPU (no collective).
+The default run (config 2, one GPU) also measures configs 3 and 5 (literal and selected-only) on a few samples each and reports
+them under "other_configs", and feeds the config-2 steps once more from device-resident ASCII through K0 ("value_with_k0").
 
 --gpus N > 1 started with plain `python` spawns N ranks itself (before anything touches the GPU); under torchrun
 (RANK / WORLD_SIZE in the environment) it is one of the ranks.  It fails loudly when N ranks cannot be had.
@@ -47,17 +51,21 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5], help="BASELINE.json configs[] entry (1-based as in SURVEY.md §8d)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[] entry (1-based as in SURVEY.md §8d)")
     ap.add_argument("--reads", type=int, default=1000000, help="reads (config 3: pairs) per batch = per GPU per sample in config 2")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--samples-per-step", type=int, default=0, help="0 = the config's default (32 / 1 / 64)")
-    ap.add_argument("--batches", type=int, default=0, help="distinct read batches resident in HBM (0 = the config's default: 8 / 10 / 64)")
+    ap.add_argument("--samples-per-step", type=int, default=0, help="0 = the config's default (288 / 1 / 1 / 64)")
+    ap.add_argument("--batches", type=int, default=0, help="distinct read batches resident in HBM (0 = the config's default: 8 / 10 / 200 / 64)")
     ap.add_argument("--strains", type=int, default=100, help="config 5: number of synthetic strains")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all host cores)")
     ap.add_argument("--cpu-sample", type=int, default=1000000, help="reads (pairs) per pass through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--allreduce", action="store_true", help="N > 1: all-reduce the counter plane instead of reduce-scatter + sharded finalize")
-    ap.add_argument("--wide", action="store_true", help="N > 1: move the counter plane as 64-bit integers even when 32 bits would do")
+    ap.add_argument("--width", default="auto", choices=["auto", "16", "32", "64"], help="N > 1: bits per counter on the wire (bk_shard_transport). auto = "
+                    "measured during the warm-up (bk_shard_measure), then fixed for the timed region; a width that is too narrow is detected, never silent")
+    ap.add_argument("--share", type=int, default=0, help="bk_engine_set_share: the scans of the engines in flight run side by side on 1/SHARE of the CUs "
+                    "each (0 = the number of engines in flight for configs 2 and 4, else 1 = every scan on the whole chip)")
+    ap.add_argument("--no-other-configs", action="store_true", help="config 2 on one GPU: skip the bounded measurements of configs 3 and 5 and the K0 figure")
     ap.add_argument("--in-flight", type=int, default=3, help="samples in flight per GPU (bk_engine_fork: shared index tables, own counter "
                     "planes / outputs / stream); 1 = strictly one sample after the other")
     ap.add_argument("--selected-only", action="store_true", help="bk_params.pileup_selected_only: votes for the selected genome only (two finalize "
@@ -121,6 +129,388 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
+class Workload:
+    """Index, engine and device-resident synthetic samples of one BASELINE config on this rank (built once; the bounded
+    "other_configs" legs reuse it: config 5's selected-only run forks the literal run's engine with other parameters)."""
+
+    def __init__(self, cfg, args, rank, world, local_rank, dev, reads, batches, selected_only=False, keep_ascii=False):
+        import torch
+        from bronko_amd import Params, synth
+        from bronko_amd.hostlib import HostIndex
+        self.cfg, self.rank, self.world = cfg, rank, world
+        rl = self.rl = args.read_len
+        t_setup = time.perf_counter()
+        self.files = None
+        if cfg in (2, 4):
+            self.k, self.n_mates = 21, 1
+            self.ref_paths = [os.path.join(GOLDEN, "wuhan_ref.fasta")]
+            self.ix = HostIndex.build(self.k, self.ref_paths, threads=4)
+        elif cfg == 3:
+            self.k, self.n_mates = 21, 2
+            self.ref_paths = [os.path.join(GOLDEN, n) for n in STRAINS4]
+            self.ix = HostIndex.build(self.k, self.ref_paths, threads=4)
+        else:
+            self.k, self.n_mates = 31, 1
+            self.files = synth.strain_files(synth.read_fasta_bytes(os.path.join(GOLDEN, "wuhan_ref.fasta")), args.strains)
+            self.ix = HostIndex.build_mem(self.k, self.files, threads=min(32, os.cpu_count() or 4))
+            self.ref_paths = None
+        t_index = time.perf_counter()
+        self.eng = self.ix.engine(Params(device=local_rank, pileup_selected_only=selected_only))
+        self.selected_only = selected_only
+        t_engine = time.perf_counter()
+
+        # ---- synthetic samples, generated on the GPU (bronko_amd.synth: the same splitmix64 streams as the numpy generator) ----
+        # samples[i] = list of (mate, words tensor, lens tensor, n_records); every rank builds only what it will push
+        self.samples, self.keep, self.ascii = [], [], []
+        k = self.k
+        if cfg == 2:
+            # SURVEY.md §8d config 2: reference + 20 SNPs + 20 iSNVs, 0.5 % substitution errors.  Batch b of rank r: seed 2*1000003 + r
+            # + 7919 b (batch 0 is round 1's batch).  A sample is one batch per rank = `world` shards of one sample.
+            genome, isnv = synth.sample_genome(synth.read_fasta_bytes(self.ref_paths[0]), 2)
+            nb = batches or 8
+            for b in range(nb):
+                codes = synth.single_end_codes_torch(genome, reads, rl, 2 * 1000003 + rank + 7919 * b, err=0.005, isnv=isnv, device=dev)
+                w, l = synth.pack_codes_torch(codes)
+                if b == 0 and rank == 0:
+                    self.keep = [codes[:args.cpu_sample].to(torch.uint8).cpu().numpy()]
+                if keep_ascii:   # the same reads as sequence lines resident in HBM: what K0 (pack_reads_kernel) starts from
+                    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+                    self.ascii.append((lut[codes.long()].reshape(-1).contiguous(),
+                                       (torch.arange(reads + 1, dtype=torch.int64, device=dev) * rl).contiguous()))
+                self.samples.append([(0, w, l, reads)])
+                del codes
+            self.sps = args.samples_per_step or 288
+            self.reads_per_sample_rank = reads
+            self.reads_per_sample_total = reads * world
+            self.scaling = "weak"
+            self.sharded_reads = world > 1
+            self.workload = ("BASELINE configs[1]: SARS-CoV-2 single ref (wuhan_ref, 29903 bp), k=21, n_fixed=2, samples of %d synthetic %d bp "
+                             "single-end reads per GPU, 0.5%% substitution errors, seed 2; %d distinct batches rotate" % (reads, rl, nb))
+        elif cfg == 3:
+            genome, isnv = synth.sample_genome(synth.read_fasta_bytes(self.ref_paths[2]), 3)
+            nb = batches or 10
+            pushes = []
+            for b in range(nb):
+                if b % world != rank:
+                    continue
+                c1, c2 = synth.paired_codes_torch(genome, reads, rl, 3, err=0.005, isnv=isnv, device=dev, row0=b * reads)
+                for m, c in enumerate((c1, c2)):
+                    w, l = synth.pack_codes_torch(c)
+                    pushes.append((m, w, l, reads))
+                if b == 0 and rank == 0:
+                    self.keep = [c1[:args.cpu_sample].to(torch.uint8).cpu().numpy(), c2[:args.cpu_sample].to(torch.uint8).cpu().numpy()]
+                del c1, c2
+            self.samples.append(pushes)
+            self.sps = args.samples_per_step or 1
+            self.reads_per_sample_rank = sum(p[3] for p in pushes)
+            self.reads_per_sample_total = 2 * nb * reads
+            self.scaling = "strong"
+            self.sharded_reads = world > 1
+            self.workload = ("BASELINE configs[2]: 4 SARS-CoV-2 strains (wuhan_ref, OM223929.1, ON765678.1, PX392231.1), k=21, one sample = %d "
+                             "synthetic pairs (2 x %d bp, fragment 300) derived from ON765678.1, seed 3, pushed as %d batches of %d pairs per mate; "
+                             "reference selection + pileup" % (nb * reads, rl, nb, reads))
+        elif cfg == 4:
+            # SURVEY.md §8d config 4: as config 2 but ONE sample of 200 M reads, seed 4, in 1 M-read batches dealt round-robin to the
+            # ranks (batch b: seed 4*1000003 + 7919 b).  At N = 1 all 200 batches (8.4 GB of records) stay resident.
+            genome, isnv = synth.sample_genome(synth.read_fasta_bytes(self.ref_paths[0]), 4)
+            nb = batches or 200
+            pushes = []
+            for b in range(nb):
+                if b % world != rank:
+                    continue
+                codes = synth.single_end_codes_torch(genome, reads, rl, 4 * 1000003 + 7919 * b, err=0.005, isnv=isnv, device=dev)
+                w, l = synth.pack_codes_torch(codes)
+                if b == 0 and rank == 0:
+                    self.keep = [codes[:args.cpu_sample].to(torch.uint8).cpu().numpy()]
+                pushes.append((0, w, l, reads))
+                del codes
+            self.samples.append(pushes)
+            self.sps = args.samples_per_step or 1
+            self.reads_per_sample_rank = sum(p[3] for p in pushes)
+            self.reads_per_sample_total = nb * reads
+            self.scaling = "strong"
+            self.sharded_reads = world > 1
+            self.workload = ("BASELINE configs[3]: SARS-CoV-2 single ref (wuhan_ref), k=21, ONE sample of %d synthetic %d bp single-end reads, "
+                             "0.5%% substitution errors, seed 4, pushed as %d batches of %d reads dealt round-robin to the ranks"
+                             % (nb * reads, rl, nb, reads))
+        else:
+            nb = batches or 64
+            for s in range(nb):
+                if s % world != rank:
+                    continue
+                src = s % args.strains
+                genome, isnv = synth.sample_genome(self.files[src][1][0][1], 5 + s)
+                codes = synth.single_end_codes_torch(genome, reads, rl, 5 * 1000003 + s, err=0.005, isnv=isnv, device=dev)
+                w, l = synth.pack_codes_torch(codes)
+                if s == 0 and rank == 0:
+                    self.keep = [codes[:args.cpu_sample].to(torch.uint8).cpu().numpy()]
+                self.samples.append([(0, w, l, reads)])
+                del codes
+            self.sps = args.samples_per_step or len(self.samples)
+            self.reads_per_sample_rank = reads
+            self.reads_per_sample_total = reads
+            self.scaling = "strong"
+            self.sharded_reads = False
+            self.workload = ("BASELINE configs[4]: %d synthetic strains (wuhan_ref + 300 substitutions each), k=31, %d samples x %d synthetic %d bp "
+                             "single-end reads (sample s derived from strain s mod %d), whole samples per GPU" % (args.strains, nb, reads, rl, args.strains))
+        torch.cuda.synchronize()
+        t_data = time.perf_counter()
+        self.reads, self.n_batches = reads, nb
+        self.resident = sum(w.numel() * 4 + l.numel() * 2 for smp in self.samples for (_, w, l, _) in smp)
+        self.setup_s = {"index_build": t_index - t_setup, "engine_create": t_engine - t_index, "synthetic_reads_on_gpu": t_data - t_engine}
+
+
+def measure(wl, args, dev, dist, steps, warmup, sps=None, eng=None, selected_only=None, bounded=False, from_ascii=False):
+    """Time `steps` steps of the workload (after `warmup`): the dict of the JSON line, without the CPU baseline.  bounded: the
+    short form used for the "other_configs" legs (no one-at-a-time phase beyond 3 samples)."""
+    import torch
+    from bronko_amd.dist import ShardedFinalize, allreduce_counters
+    rank, world, cfg, rl, k, n_mates = wl.rank, wl.world, wl.cfg, wl.rl, wl.k, wl.n_mates
+    eng = eng or wl.eng
+    selected_only = wl.selected_only if selected_only is None else selected_only
+    sps = sps or wl.sps
+    samples = wl.samples
+    sharded_reads = wl.sharded_reads
+
+    # ---- engines: samples in flight --------------------------------------------------------------------------------------
+    # Each engine launches on its own HIP stream (created with the engine); torch sees it as an ExternalStream and every torch /
+    # torch.distributed operation on the engine's buffers is enqueued on it: the collectives are ordered against the kernels by
+    # the stream.
+    n_fly = max(1, args.in_flight)
+    engs = [eng] + [eng.fork() for _ in range(n_fly - 1)]
+    share = args.share or 1
+    for e in engs:
+        e.set_share(share)
+    streams = [torch.cuda.ExternalStream(e.stream_ptr(), device=dev) for e in engs]
+    torch.cuda.set_stream(streams[0])
+    sharded = sharded_reads and not args.allreduce
+    counters = [[torch.as_tensor(_DevArray(e.counters_ptr(m), e.counter_len, "<i8"), device=dev) for m in range(n_mates)] for e in engs] \
+        if sharded_reads and not sharded else None
+
+    # one sample's reads sharded over ranks: the engine packs the counter plane for the wire, ONE reduce-scatter per mate file, each
+    # rank maps its part, max / sum of the small pileups (include/bronko_hip.h); --allreduce selects the plain form (all-reduce the
+    # plane, every rank maps everything)
+    if sharded and 64 % world != 0:
+        raise SystemExit("bench.py: the sharded finalize needs a rank count that divides 64 (got %d); use --allreduce" % world)
+    width = "auto" if args.width == "auto" else int(args.width)
+    shard_fin = [ShardedFinalize(e, n_mates, rank, world, dev, width=width, time_comm=True) for e in engs] if sharded else None
+
+    def run_sample(i, j):
+        e = engs[j]
+        with torch.cuda.stream(streams[j]):
+            e.sample_begin()
+            if from_ascii:
+                bases, offs = wl.ascii[i % len(wl.ascii)]
+                e.push_reads_ascii_device(0, bases.data_ptr(), offs.data_ptr(), wl.reads, wl.reads * rl, rl)
+            else:
+                for (m, w, l, n) in samples[i % len(samples)]:
+                    e.push_reads_device(m, w.data_ptr(), w.shape[1], l.data_ptr(), n)
+            if sharded:
+                shard_fin[j]()   # RCCL over xGMI: reduce-scatter(sum) + 3 small all-reduces
+                return
+            if sharded_reads:
+                for m in range(n_mates):
+                    e.counters_ptr(m)                    # (a plane nothing was pushed to is zeroed by this call)
+                    allreduce_counters(counters[j][m])   # RCCL over xGMI: ONE all-reduce(sum) of the u64 k-mer occurrence counters
+            e.sample_finalize(n_mates)
+
+    state = {"i": 0}
+
+    def step(pool):
+        for _ in range(sps):
+            i = state["i"]
+            state["i"] = i + 1
+            run_sample(i, i % pool)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timing(kind):
+        for e in engs:
+            e.timing_enable(kind)
+
+    def timing_read():
+        tot_ms, tot_n = [0.0] * 4, [0] * 4
+        for e in engs:
+            ms, n = e.timing_read(reset=True)
+            tot_ms = [a + b for a, b in zip(tot_ms, ms)]
+            tot_n = [a + b for a, b in zip(tot_n, n)]
+        return tot_ms, tot_n
+
+    for _ in range(warmup):
+        step(len(engs))
+    fence()
+    widths = None
+    if sharded:
+        # the width the warm-up's samples needed ("auto" measured every plane); the timed region runs at that fixed width -- no
+        # measuring pass, no host synchronisation per sample -- and a counter that does not fit is detected on the device
+        widths = sorted({w for f in shard_fin for w in f.last_widths}) or [64]
+        if width == "auto":
+            w = torch.tensor([max(widths)], dtype=torch.int64, device=dev)
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            for f in shard_fin:
+                f.width = int(w.item())
+        for f in shard_fin:
+            f.comm_ms()
+    # timed region: only the dominant kernel is bracketed by HIP events (on its launch stream, two records per launch)
+    timing(2)
+    timing_read()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(len(engs))
+    fence()
+    dt = time.perf_counter() - t0
+    kms_fly, kn_fly = timing_read()
+    comm = None
+    if sharded:
+        rs_ms = cb_ms = 0.0
+        n_ev = 0
+        for f in shard_fin:
+            a, b, n = f.comm_ms()
+            rs_ms, cb_ms, n_ev = rs_ms + a, cb_ms + b, n_ev + n
+        over = any(e.transport_overflow() for e in engs)
+        flag = torch.tensor([1 if over else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            raise SystemExit("bench.py: a counter did not fit the %d-bit transport in the timed region; rerun with a wider --width" % shard_fin[0].width)
+        comm = {"width_bits": shard_fin[0].width, "plane_bytes": int(eng.counter_len * 8), "bytes_on_the_wire_per_rank_per_sample": int(shard_fin[0].bytes_sent),
+                "reduce_scatter_ms_per_sample": rs_ms / max(n_ev, 1), "combine_ms_per_sample": cb_ms / max(n_ev, 1),
+                "comm_ms_per_sample": (rs_ms + cb_ms) / max(n_ev, 1),
+                "measured": "HIP events on the engine's stream around the reduce-scatter(s) and around the three small all-reduces; includes waiting for the slowest rank"}
+    last_engine = (state["i"] - 1) % len(engs)
+    res = engs[last_engine].sample_download(n_mates, arrays=False)   # sanity: the last timed sample really produced its statistics
+    # The same samples strictly one after the other on one engine (on the whole chip), every kernel kind bracketed: a single
+    # sample's turnaround and each kernel's own duration with nothing running next to it -- the figure the roofline object is
+    # about (in the timed region a scan shares the CUs with the other samples' kernels).
+    n_serial = 3 if bounded else max(2, min(32 if wl.reads_per_sample_rank <= 2000000 else 8, steps * sps))   # (32 short samples: the average of 8 moved by 10 % from run to run)
+    engs[0].set_share(1)
+    for i in range(3 if bounded else 8):   # (untimed: the chip settles into running one sample at a time)
+        run_sample(i, 0)
+    fence()
+    timing(1)
+    timing_read()
+    ts0 = time.perf_counter()
+    for i in range(n_serial):
+        run_sample(i, 0)
+    fence()
+    serial_ms = (time.perf_counter() - ts0) / n_serial * 1e3
+    kms_solo, kn_solo = timing_read()
+    timing(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    n_samples_timed = steps * sps
+    if cfg == 5:
+        total_reads = n_samples_timed * wl.reads_per_sample_total * world   # every rank runs `sps` whole samples per step
+    else:
+        total_reads = n_samples_timed * wl.reads_per_sample_total
+    value = total_reads / dt
+
+    launches_per_sample = max(kn_solo[0] // max(n_serial, 1), 1)
+    reads_per_launch = wl.reads_per_sample_rank / launches_per_sample
+    scan_ms = kms_solo[0] / max(kn_solo[0], 1)
+    scan_ms_fly = kms_fly[0] / max(kn_fly[0], 1)
+    algo_bytes = ALGO_BYTES_PER_READ * reads_per_launch
+    achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    per_sample = lambda ms: ms / max(n_serial, 1)   # noqa: E731
+    out = {
+        "metric": "reads/sec through call k-mer->pileup, SARS-CoV-2 k=%d" % k,
+        "value": value,
+        "unit": "reads/s",
+        "n_gpus": world,
+        "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3,
+        "ms_per_sample": dt / n_samples_timed * 1e3,
+        "serial_ms_per_sample": serial_ms,   # one sample at a time on one engine (not the headline: see config.samples_in_flight)
+        "higher_is_better": True,
+        "scaling": wl.scaling,
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {"workload": wl.workload, "baseline_config": cfg, "k": k, "read_len": rl, "samples_per_step": sps,
+                   "reads_per_sample": wl.reads_per_sample_total, "reads_per_gpu_per_sample": wl.reads_per_sample_rank, "mates": n_mates,
+                   "samples_in_flight": len(engs), "scan_cu_share": share, "resident_input_bytes": wl.resident,
+                   "input": "sequence lines (ASCII) resident in HBM -> K0 pack_reads_kernel -> records" if from_ascii else "2-bit packed records resident in HBM",
+                   "pileup_rows": "selected genome only (bk_params.pileup_selected_only)" if selected_only else "every genome (call.rs:1305-1384)",
+                   "parallelism": ("single GPU" if world == 1 else
+                                   "whole samples per GPU over %d GPUs, no collective" % world if not sharded_reads else
+                                   ("one sample's reads sharded over %d GPUs; RCCL reduce-scatter(sum) of the k-mer counter plane packed to %d-bit "
+                                    "elements by the engine, sharded finalize, all-reduce(max / sum) of the pileups" % (world, shard_fin[0].width)) if sharded else
+                                   "one sample's reads sharded over %d GPUs; RCCL all-reduce(sum) of the k-mer counter plane" % world)},
+        "roofline": {"bound": "hbm", "kernel": "scan_count_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                     "avg_kernel_ms": scan_ms, "launches": kn_solo[0],
+                     "measured": "HIP events around the kernel on its launch stream, samples run one at a time on the whole chip after the timed region",
+                     # timed region: from the record before a scan launch to the record behind it on its stream -- the kernel sharing
+                     # the CUs with the other samples' kernels AND whatever time it waited for CUs: not a kernel duration
+                     "avg_ms_in_flight_incl_queueing": scan_ms_fly, "launches_in_flight": kn_fly[0],
+                     "reads_per_launch": reads_per_launch, "algorithmic_bytes_per_launch": algo_bytes},
+        # per sample, one sample at a time (solo): what each kernel kind costs with nothing next to it
+        "kernels_ms_per_sample_solo": {"scan_count": per_sample(kms_solo[0]), "finalize": per_sample(kms_solo[1]),
+                                       "memset_copy": per_sample(kms_solo[2]), "level2": per_sample(kms_solo[3])},
+        "check": {"perfect_kmers": [int(x) for x in res.stats.sum(axis=0)[:, 0][:8]], "variant_kmers": [int(x) for x in res.stats.sum(axis=0)[:, 1][:8]],
+                  "kmers_scanned": [int(x) for x in res.kmer_stats[:, 1]]},
+    }
+    if comm:
+        out["comm"] = comm
+    torch.cuda.set_stream(torch.cuda.default_stream(dev))   # (the engines' streams die with them)
+    for e in reversed(engs[1:]):
+        e.close()
+    return out
+
+
+def cpu_baseline(wl, args):
+    """CPU baseline = the oracle (C restatement of bronko v0.1.0: exact strand-specific k-mer counting standing in for `kmc -t`,
+    then map_kmers over chunks in parallel as call.rs:1279-1281) on a bounded sample of the same workload, on this box's host
+    cores.  Checker code, timed here only as the reported baseline -- it is never on the product path."""
+    from bronko_amd import synth
+    from oracle import oracle as orc
+    ncpu = os.cpu_count() or 1
+    threads = args.cpu_threads or ncpu
+    oix = orc.Index.build_mem(wl.k, wl.files) if wl.cfg == 5 else orc.Index.build(wl.k, wl.ref_paths)
+    mates = [synth.BASES[c] for c in wl.keep]
+    n_s = len(mates[0])
+    passes, cdt, s1, s2 = 0, 0.0, 0.0, 0.0
+    while passes < 8 and (cdt < 4.0 or passes < 2):
+        c0 = time.perf_counter()
+        _, secs = orc.sample_pileup_mt(oix, mates, threads)
+        cdt += time.perf_counter() - c0
+        s1 += secs[0]
+        s2 += secs[1]
+        passes += 1
+    n1 = min(n_s, 150000)
+    c0 = time.perf_counter()
+    orc.sample_pileup_mt(oix, [m[:n1] for m in mates], 1)
+    one = time.perf_counter() - c0
+    return {"value": n_s * len(mates) * passes / cdt, "unit": "reads/s", "cores": threads, "kind": "port",
+            "sample": "%d passes over the first %d %s of batch 0: CPU restatement of bronko v0.1.0 (not the upstream "
+                      "binary), %d threads of %d host cores, %.1f s in total"
+                      % (passes, n_s, "pairs" if len(mates) == 2 else "reads", threads, ncpu, cdt),
+            "stage_seconds_per_pass": {"count_all_kmers (kmc stand-in)": s1 / passes, "map_kmers": s2 / passes},
+            "single_thread_value": n1 * len(mates) / one, "single_thread_sample": "%d reads, 1 thread" % (n1 * len(mates))}
+
+
+def pmc_traffic(cfg, reads, rl, build_id):
+    """HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure is the one measured
+    with rocprofv3 (separate --pmc passes) on this workload and build, committed under profiles/."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if tj.get("build_id") != build_id:
+            return None, None, "profiles/pmc_traffic.json was captured for build %s, this is %s: not reported" % (tj.get("build_id"), build_id)
+        if tj.get("config", 2) != cfg or tj.get("workload_reads") != reads or tj.get("read_len") != rl:
+            return None, None, "profiles/pmc_traffic.json is for another workload: not reported"
+        return tj["traffic_bytes_per_launch"], tj.get("valu_wave_insts_per_launch"), "rocprofv3 --pmc passes of this build (%s)" % tj.get("captured", "profiles/")
+    except (OSError, ValueError, KeyError):
+        return None, None, "profiles/pmc_traffic.json absent"
+
+
 def main():
     args = parse_args()
     bad_env = sorted(k for k in os.environ if k.startswith("BK_"))
@@ -173,310 +563,78 @@ def main():
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
 
-    from bronko_amd import Params, synth
-    from bronko_amd.dist import ShardedFinalize, allreduce_counters
-    from bronko_amd.hostlib import HostIndex
+    from bronko_amd import Params
 
     cfg = args.config
-    rl = args.read_len
-    t_setup = time.perf_counter()
-    # ---- index + engine --------------------------------------------------------------------------------------------------
-    if cfg == 2:
-        k, n_mates = 21, 1
-        ref_paths = [os.path.join(GOLDEN, "wuhan_ref.fasta")]
-        ix = HostIndex.build(k, ref_paths, threads=4)
-        files = None
-    elif cfg == 3:
-        k, n_mates = 21, 2
-        ref_paths = [os.path.join(GOLDEN, n) for n in STRAINS4]
-        ix = HostIndex.build(k, ref_paths, threads=4)
-        files = None
-    else:
-        k, n_mates = 31, 1
-        files = synth.strain_files(synth.read_fasta_bytes(os.path.join(GOLDEN, "wuhan_ref.fasta")), args.strains)
-        ix = HostIndex.build_mem(k, files, threads=min(32, os.cpu_count() or 4))
-        ref_paths = None
-    t_index = time.perf_counter()
-    eng = ix.engine(Params(device=local_rank, pileup_selected_only=args.selected_only))
-    t_engine = time.perf_counter()
-
-    # ---- synthetic samples, generated on the GPU (bronko_amd.synth: the same splitmix64 streams as the numpy generator) ----
-    # samples[i] = list of (mate, words tensor, lens tensor, n_records); every rank builds only what it will push
-    samples = []
-    keep = []          # codes of the first batch, for the CPU baseline (rank 0)
-    if cfg == 2:
-        # reference + 20 SNPs + 20 iSNVs, 0.5 % substitution errors.  Batch b of rank r: seed 2*1000003 + r
-        # + 7919 b (batch 0 is round 1's batch).  A sample is one batch per rank = `world` shards of one sample.
-        genome, isnv = synth.sample_genome(synth.read_fasta_bytes(ref_paths[0]), 2)
-        nb = args.batches or 8
-        for b in range(nb):
-            codes = synth.single_end_codes_torch(genome, args.reads, rl, 2 * 1000003 + rank + 7919 * b, err=0.005, isnv=isnv, device=dev)
-            w, l = synth.pack_codes_torch(codes)
-            if b == 0 and rank == 0:
-                keep = [codes[:args.cpu_sample].to(torch.uint8).cpu().numpy()]
-            samples.append([(0, w, l, args.reads)])
-            del codes
-        sps = args.samples_per_step or 32
-        reads_per_sample_rank = args.reads
-        reads_per_sample_total = args.reads * world
-        scaling = "weak"
-        sharded_reads = world > 1
-        workload = ("BASELINE configs[1]: SARS-CoV-2 single ref (wuhan_ref, 29903 bp), k=21, n_fixed=2, samples of %d synthetic %d bp "
-                    "single-end reads per GPU, 0.5%% substitution errors, seed 2; %d distinct batches rotate" % (args.reads, rl, nb))
-    elif cfg == 3:
-        genome, isnv = synth.sample_genome(synth.read_fasta_bytes(ref_paths[2]), 3)
-        nb = args.batches or 10
-        pushes = []
-        for b in range(nb):
-            if b % world != rank:
-                continue
-            c1, c2 = synth.paired_codes_torch(genome, args.reads, rl, 3, err=0.005, isnv=isnv, device=dev, row0=b * args.reads)
-            for m, c in enumerate((c1, c2)):
-                w, l = synth.pack_codes_torch(c)
-                pushes.append((m, w, l, args.reads))
-            if b == 0 and rank == 0:
-                keep = [c1[:args.cpu_sample].to(torch.uint8).cpu().numpy(), c2[:args.cpu_sample].to(torch.uint8).cpu().numpy()]
-            del c1, c2
-        samples.append(pushes)
-        sps = args.samples_per_step or 1
-        reads_per_sample_rank = sum(p[3] for p in pushes)
-        reads_per_sample_total = 2 * nb * args.reads
-        scaling = "strong"
-        sharded_reads = world > 1
-        workload = ("BASELINE configs[2]: 4 SARS-CoV-2 strains (wuhan_ref, OM223929.1, ON765678.1, PX392231.1), k=21, one sample = %d "
-                    "synthetic pairs (2 x %d bp, fragment 300) derived from ON765678.1, seed 3, pushed as %d batches of %d pairs per mate; "
-                    "reference selection + pileup" % (nb * args.reads, rl, nb, args.reads))
-    else:
-        nb = args.batches or 64
-        for s in range(nb):
-            if s % world != rank:
-                continue
-            src = s % args.strains
-            genome, isnv = synth.sample_genome(files[src][1][0][1], 5 + s)
-            codes = synth.single_end_codes_torch(genome, args.reads, rl, 5 * 1000003 + s, err=0.005, isnv=isnv, device=dev)
-            w, l = synth.pack_codes_torch(codes)
-            if s == 0 and rank == 0:
-                keep = [codes[:args.cpu_sample].to(torch.uint8).cpu().numpy()]
-            samples.append([(0, w, l, args.reads)])
-            del codes
-        sps = args.samples_per_step or len(samples)
-        reads_per_sample_rank = args.reads
-        reads_per_sample_total = args.reads
-        scaling = "strong"
-        sharded_reads = False
-        workload = ("BASELINE configs[4]: %d synthetic strains (wuhan_ref + 300 substitutions each), k=31, %d samples x %d synthetic %d bp "
-                    "single-end reads (sample s derived from strain s mod %d), whole samples per GPU" % (args.strains, nb, args.reads, rl, args.strains))
-    torch.cuda.synchronize()
-    t_data = time.perf_counter()
-    resident = sum(w.numel() * 4 + l.numel() * 2 for smp in samples for (_, w, l, _) in smp)
-
-    # ---- engines: samples in flight --------------------------------------------------------------------------------------
-    # Each engine launches on its own HIP stream (created with the engine); torch sees it as an ExternalStream and every torch /
-    # torch.distributed operation on the engine's buffers is enqueued on it: the collectives are ordered against the kernels by
-    # the stream.
-    n_fly = max(1, args.in_flight)
-    engs = [eng] + [eng.fork() for _ in range(n_fly - 1)]
-    streams = [torch.cuda.ExternalStream(e.stream_ptr(), device=dev) for e in engs]
-    torch.cuda.set_stream(streams[0])
-    counters = [[torch.as_tensor(_DevArray(e.counters_ptr(m), e.counter_len, "<i8"), device=dev) for m in range(n_mates)] for e in engs] if sharded_reads else None
-
-    # one sample's reads sharded over ranks: reduce-scatter of the counter plane + each rank maps its part + max / sum of the small
-    # pileups (include/bronko_hip.h); --allreduce selects the plain form (all-reduce the plane, every rank maps everything)
-    sharded = sharded_reads and not args.allreduce
-    if sharded and 64 % world != 0:
-        raise SystemExit("bench.py: the sharded finalize needs a rank count that divides 64 (got %d); use --allreduce" % world)
-    narrow = reads_per_sample_total * max(rl - k + 1, 1) < 2 ** 31 and not args.wide
-    shard_fin = [ShardedFinalize(e, n_mates, rank, world, dev, narrow=narrow) for e in engs] if sharded else None
-
-    def run_sample(i, j):
-        e = engs[j]
-        with torch.cuda.stream(streams[j]):
-            e.sample_begin()
-            for (m, w, l, n) in samples[i % len(samples)]:
-                e.push_reads_device(m, w.data_ptr(), w.shape[1], l.data_ptr(), n)
-            if sharded:
-                shard_fin[j]()   # RCCL over xGMI: reduce-scatter(sum) + 3 small all-reduces
-                return
-            if sharded_reads:
-                for m in range(n_mates):
-                    e.counters_ptr(m)                    # (a plane nothing was pushed to is zeroed by this call)
-                    allreduce_counters(counters[j][m])   # RCCL over xGMI: ONE all-reduce(sum) of the u64 k-mer occurrence counters
-            e.sample_finalize(n_mates)
-
-    state = {"i": 0}
-
-    def step(pool):
-        for _ in range(sps):
-            i = state["i"]
-            state["i"] = i + 1
-            run_sample(i, i % pool)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timing(kind):
-        for e in engs:
-            e.timing_enable(kind)
-
-    def timing_read():
-        tot_ms, tot_n = [0.0] * 4, [0] * 4
-        for e in engs:
-            ms, n = e.timing_read(reset=True)
-            tot_ms = [a + b for a, b in zip(tot_ms, ms)]
-            tot_n = [a + b for a, b in zip(tot_n, n)]
-        return tot_ms, tot_n
-
-    for _ in range(args.warmup):
-        step(len(engs))
-    fence()
-    # timed region: only the dominant kernel is bracketed by HIP events (on its launch stream, two records per launch)
-    timing(2)
-    timing_read()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(len(engs))
-    fence()
-    dt = time.perf_counter() - t0
-    kms_fly, kn_fly = timing_read()
-    last_engine = (state["i"] - 1) % len(engs)
-    res = engs[last_engine].sample_download(n_mates, arrays=False)   # sanity: the last timed sample really produced its statistics
-    # The same samples strictly one after the other on one engine, every kernel kind bracketed: a single sample's turnaround and
-    # each kernel's own duration with nothing running next to it -- the figure the roofline object is about (in the timed
-    # region above a scan shares the CUs with the other samples' kernels).
-    n_serial = max(2, min(32 if reads_per_sample_rank <= 2000000 else 8, args.steps * sps))   # (32 short samples: the average of 8 moved by 10 % from run to run)
-    for i in range(8):   # (untimed: the chip settles into running one sample at a time)
-        run_sample(i, 0)
-    fence()
-    timing(1)
-    timing_read()
-    ts0 = time.perf_counter()
-    for i in range(n_serial):
-        run_sample(i, 0)
-    fence()
-    serial_ms = (time.perf_counter() - ts0) / n_serial * 1e3
-    kms_solo, kn_solo = timing_read()
-    timing(0)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    n_samples_timed = args.steps * sps
-    if cfg == 5:
-        total_reads = n_samples_timed * reads_per_sample_total * world   # every rank runs `sps` whole samples per step
-    else:
-        total_reads = n_samples_timed * reads_per_sample_total
-    value = total_reads / dt
-
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure is the one measured
-    # with rocprofv3 (separate --pmc passes) on this workload and build, committed under profiles/
+    extras = cfg == 2 and world == 1 and not args.no_other_configs and not args.selected_only
+    wl = Workload(cfg, args, rank, world, local_rank, dev, args.reads, args.batches, selected_only=args.selected_only, keep_ascii=extras)
+    out = measure(wl, args, dev, dist, args.steps, args.warmup)
     build_id = source_build_id()
-    traffic = valu_insts = None
-    traffic_note = "profiles/pmc_traffic.json absent"
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if tj.get("build_id") != build_id:
-            traffic_note = "profiles/pmc_traffic.json was captured for build %s, this is %s: not reported" % (tj.get("build_id"), build_id)
-        elif tj.get("config", 2) != cfg or tj.get("workload_reads") != args.reads or tj.get("read_len") != rl:
-            traffic_note = "profiles/pmc_traffic.json is for another workload: not reported"
-        else:
-            traffic = tj["traffic_bytes_per_launch"]
-            valu_insts = tj.get("valu_wave_insts_per_launch")
-            traffic_note = "rocprofv3 --pmc passes of this build (%s)" % tj.get("captured", "profiles/")
-    except (OSError, ValueError, KeyError):
-        pass
+    traffic, valu_insts, note = pmc_traffic(cfg, args.reads, args.read_len, build_id)
+    rf = out["roofline"]
+    rf["traffic"], rf["traffic_source"] = traffic, note
+    # the kernel is VALU-issue bound, not HBM bound: wave-instructions per launch from the committed PMC
+    # pass; a wave64 VALU instruction occupies one of the chip's 1024 SIMDs for 4 cycles
+    rf["valu_wave_insts_per_launch"] = valu_insts
+    rf["valu_busy_frac"] = (valu_insts * 4 / (1024 * 2.4e9) / (rf["avg_kernel_ms"] * 1e-3)) if valu_insts and rf["avg_kernel_ms"] > 0 else None
+    out["build"] = {"source_sha256_16": build_id}
+    out["setup_s"] = wl.setup_s
 
-    launches_per_sample = max(kn_solo[0] // max(n_serial, 1), 1)
-    reads_per_launch = reads_per_sample_rank / launches_per_sample
-    scan_ms = kms_solo[0] / max(kn_solo[0], 1)
-    scan_ms_fly = kms_fly[0] / max(kn_fly[0], 1)
-    algo_bytes = ALGO_BYTES_PER_READ * reads_per_launch
-    achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    per_sample = lambda ms: ms / max(n_serial, 1)   # noqa: E731
-    out = {
-        "metric": "reads/sec through call k-mer->pileup, SARS-CoV-2 k=%d" % k,
-        "value": value,
-        "unit": "reads/s",
-        "n_gpus": world,
-        "rccl_ranks": dist.get_world_size() if world > 1 else 1,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
-        "ms_per_sample": dt / n_samples_timed * 1e3,
-        "serial_ms_per_sample": serial_ms,   # one sample at a time on one engine (not the headline: see config.samples_in_flight)
-        "higher_is_better": True,
-        "scaling": scaling,
-        "vs_baseline": None,
-        "dtype": "u64",
-        "data": "synthetic",
-        "config": {"workload": workload, "baseline_config": cfg, "k": k, "read_len": rl, "samples_per_step": sps,
-                   "reads_per_sample": reads_per_sample_total, "reads_per_gpu_per_sample": reads_per_sample_rank, "mates": n_mates,
-                   "samples_in_flight": len(engs), "resident_input_bytes": resident,
-                   "pileup_rows": "selected genome only (bk_params.pileup_selected_only)" if args.selected_only else "every genome (call.rs:1305-1384)",
-                   "parallelism": ("single GPU" if world == 1 else
-                                   "whole samples per GPU over %d GPUs, no collective" % world if not sharded_reads else
-                                   ("one sample's reads sharded over %d GPUs; RCCL reduce-scatter(sum) of the k-mer counter plane%s, sharded finalize, "
-                                    "all-reduce(max / sum) of the pileups" % (world, " as int32" if narrow else "")) if sharded else
-                                   "one sample's reads sharded over %d GPUs; RCCL all-reduce(sum) of the k-mer counter plane" % world)},
-        "roofline": {"bound": "hbm", "kernel": "scan_count_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                     "avg_kernel_ms": scan_ms, "launches": kn_solo[0],
-                     "measured": "HIP events around the kernel on its launch stream, samples run one at a time after the timed region",
-                     "avg_kernel_ms_in_flight": scan_ms_fly, "launches_in_flight": kn_fly[0],   # timed region: sharing the CUs
-                     "reads_per_launch": reads_per_launch, "algorithmic_bytes_per_launch": algo_bytes,
-                     # the kernel is VALU-issue bound, not HBM bound: wave-instructions per launch from the
-                     # committed PMC pass; a wave64 VALU instruction occupies one of the chip's 1024 SIMDs for 4 cycles
-                     "valu_wave_insts_per_launch": valu_insts,
-                     "valu_busy_frac": (valu_insts * 4 / (1024 * 2.4e9) / (scan_ms * 1e-3)) if valu_insts and scan_ms > 0 else None},
-        # per sample, one sample at a time (solo): what each kernel kind costs with nothing next to it
-        "kernels_ms_per_sample_solo": {"scan_count": per_sample(kms_solo[0]), "finalize": per_sample(kms_solo[1]),
-                                       "memset_copy": per_sample(kms_solo[2]), "level2": per_sample(kms_solo[3])},
-        "check": {"perfect_kmers": [int(x) for x in res.stats.sum(axis=0)[:, 0][:8]], "variant_kmers": [int(x) for x in res.stats.sum(axis=0)[:, 1][:8]],
-                  "kmers_scanned": [int(x) for x in res.kmer_stats[:, 1]]},
-        "build": {"source_sha256_16": build_id},
-        "setup_s": {"index_build": t_index - t_setup, "engine_create": t_engine - t_index, "synthetic_reads_on_gpu": t_data - t_engine},
-    }
-
+    if extras:
+        # SURVEY.md §8(d) words the metric as K0..K2: the same steps once more, fed from sequence lines resident in HBM through
+        # pack_reads_kernel (no PCIe).  Algorithmic bytes of that figure: 150 B of ASCII read + 40 B of records written and read.
+        k0 = measure(wl, args, dev, dist, max(2, args.steps // 4), 1, from_ascii=True, bounded=True)
+        out["value_with_k0"] = {"value": k0["value"], "unit": "reads/s", "ms_per_sample": k0["ms_per_sample"], "serial_ms_per_sample": k0["serial_ms_per_sample"],
+                                "input": k0["config"]["input"], "algorithmic_bytes_per_read": args.read_len + ALGO_BYTES_PER_READ, "check": k0["check"],
+                                "k0_ms_per_sample_solo": k0["kernels_ms_per_sample_solo"]["memset_copy"]}
+        wl.ascii = []
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # CPU baseline = the oracle (C restatement of bronko v0.1.0: exact strand-specific k-mer counting standing in for `kmc -t`,
-        # then map_kmers over chunks in parallel as call.rs:1279-1281) on a bounded sample of the same workload, on this box's
-        # host cores.  Checker code, timed here only as the reported baseline -- it is never on the product path.
-        from oracle import oracle as orc
-        ncpu = os.cpu_count() or 1
-        threads = args.cpu_threads or ncpu
-        oix = orc.Index.build_mem(k, files) if cfg == 5 else orc.Index.build(k, ref_paths)
-        mates = [synth.BASES[c] for c in keep]
-        n_s = len(mates[0])
-        passes, cdt, s1, s2 = 0, 0.0, 0.0, 0.0
-        while passes < 8 and (cdt < 4.0 or passes < 2):
-            c0 = time.perf_counter()
-            _, secs = orc.sample_pileup_mt(oix, mates, threads)
-            cdt += time.perf_counter() - c0
-            s1 += secs[0]
-            s2 += secs[1]
-            passes += 1
-        n1 = min(n_s, 150000)
-        c0 = time.perf_counter()
-        orc.sample_pileup_mt(oix, [m[:n1] for m in mates], 1)
-        one = time.perf_counter() - c0
-        out["cpu_baseline"] = {"value": n_s * len(mates) * passes / cdt, "unit": "reads/s", "cores": threads, "kind": "port",
-                               "sample": "%d passes over the first %d %s of batch 0: CPU restatement of bronko v0.1.0 (not the upstream "
-                                         "binary), %d threads of %d host cores, %.1f s in total"
-                                         % (passes, n_s, "pairs" if len(mates) == 2 else "reads", threads, ncpu, cdt),
-                               "stage_seconds_per_pass": {"count_all_kmers (kmc stand-in)": s1 / passes, "map_kmers": s2 / passes},
-                               "single_thread_value": n1 * len(mates) / one, "single_thread_sample": "%d reads, 1 thread" % (n1 * len(mates))}
+        out["cpu_baseline"] = cpu_baseline(wl, args)
     elif rank == 0:
         out["cpu_baseline"] = None
+
+    if extras:
+        # BASELINE configs 3 and 5 in the line the driver records: a few timed samples each after one warm-up sample (bounded: the
+        # whole default run stays below ~90 s); the full-length figures come from `bench.py --config 3 / 5`.
+        def brief(o, cpu=None):
+            r = o["roofline"]
+            d = {"value": o["value"], "unit": "reads/s", "ms_per_sample": o["ms_per_sample"], "serial_ms_per_sample": o["serial_ms_per_sample"],
+                 "samples_timed": o["steps"] * o["config"]["samples_per_step"], "reads_per_sample": o["config"]["reads_per_sample"],
+                 "workload": o["config"]["workload"], "pileup_rows": o["config"]["pileup_rows"], "check": o["check"],
+                 "scan": {"avg_kernel_ms": r["avg_kernel_ms"], "reads_per_launch": r["reads_per_launch"], "achieved_GBps": r["achieved"], "frac": r["frac"]},
+                 "kernels_ms_per_sample_solo": o["kernels_ms_per_sample_solo"]}
+            if cpu:
+                d["cpu_baseline"] = cpu
+            return d
+        others = {}
+        wl.eng.close()
+        del wl
+        torch.cuda.empty_cache()
+        a3 = argparse.Namespace(**vars(args))
+        a3.samples_per_step, a3.cpu_sample = 1, 200000
+        w3 = Workload(3, a3, rank, world, local_rank, dev, 1000000, 10)
+        others["3"] = brief(measure(w3, a3, dev, dist, 3, 1, bounded=True))
+        w3.eng.close()
+        del w3
+        torch.cuda.empty_cache()
+        a5 = argparse.Namespace(**vars(args))
+        a5.samples_per_step = 1
+        w5 = Workload(5, a5, rank, world, local_rank, dev, 1000000, 4)
+        others["5_literal"] = brief(measure(w5, a5, dev, dist, 3, 1, bounded=True))
+        sel = w5.eng.fork(Params(device=local_rank, pileup_selected_only=True))
+        others["5_selected_only"] = brief(measure(w5, a5, dev, dist, 3, 1, eng=sel, selected_only=True, bounded=True))
+        sel.close()
+        others["5_literal"]["setup_s"] = w5.setup_s
+        out["other_configs"] = others
+        w5.eng.close()
+    else:
+        wl.eng.close()
 
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
-    for e in reversed(engs):
-        e.close()
 
 
 if __name__ == "__main__":

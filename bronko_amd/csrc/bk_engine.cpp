@@ -245,11 +245,22 @@ struct bk_engine {
     uint64_t n_prows = 0;  // V rows of the pseudo k-mers (bk_device.h)
     int v_omin = 0, v_span = 0;
     uint64_t v_off = 0, plane_len = 0;      // counter_plane_layout (bk_device.h)
-    DevBuf<unsigned long long> shard_sums;  // sharded finalize: [stats 2*n_files*3 | present 2*n_files | kstats 8]
+    DevBuf<unsigned long long> shard_sums;  // sharded finalize: [stats 2*n_files*3 | present 2*n_files | kstats 8 | transport flag]
+    // sharded finalize, transport of the planes (bk_shard_transport / bk_shard_received): the packed plane of the mate file being
+    // exchanged, the part the reduce-scatter leaves here, and per mate file the received part widened to u64 again -- what
+    // bk_sample_finalize_shard maps (the plane itself stays as the scans left it)
+    DevBuf<unsigned char> xport_send, xport_recv;
+    DevBuf<unsigned long long> reduced[2];
+    DevBuf<unsigned long long> xport_flag;  // [0] a packer of this sample met a counter too large for its width, [1] sticky copy after
+                                            // the ranks' sums were merged, [2..3] bk_shard_measure: max E count, max |V element|
+    bool xport_ever = false;                // some sample of this engine went through bk_shard_transport (bk_sample_download then looks at the flag)
+    int reduced_shards[2] = {0, 0};         // > 0: reduced[m] holds part `reduced_shard[m]` of that many for the current sample
+    int reduced_shard[2] = {0, 0};
     DevBuf<uint32_t> prow_id;
     DevBuf<uint8_t> prow_t;
     bool ref_in_lds = false;
     int lo_bases = 0, n_cus = 256;
+    int scan_share = 1;                     // bk_engine_set_share: this engine's scans take n_cus / scan_share workgroups
     int device = 0;
 
     DevBuf<bk::KmerPos> kmer_pos;
@@ -316,6 +327,7 @@ struct bk_engine {
         bool busy = false;
     };
     IngestSlot slots[3];
+    IngestSlot dev_ascii;                   // bk_push_reads_ascii_device: the packed records of the batch being scanned (device buffers only)
     int next_slot = 0;
     hipStream_t copy_stream = nullptr;
 
@@ -399,7 +411,9 @@ static int alloc_sample_state(bk_engine* e) {
             BK_HIP(e->n_list[m].alloc(8));
         }
     }
-    BK_HIP(e->shard_sums.alloc((size_t)2 * e->n_files * 5 + 8));
+    BK_HIP(e->shard_sums.alloc((size_t)2 * e->n_files * 5 + 9));
+    BK_HIP(e->xport_flag.alloc(4));
+    BK_HIP(hipMemset(e->xport_flag.p, 0, 4 * sizeof(unsigned long long)));
     if (prm->full_kmer_stats) {
         if (prm->kmer_table_log2 < 10 || prm->kmer_table_log2 > 31) return fail(BK_ERR_INVALID, "kmer_table_log2 out of range");
         BK_HIP(e->ktab_keys.alloc((size_t)1 << prm->kmer_table_log2));
@@ -1319,12 +1333,18 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     return BK_OK;
 }
 
-int bk_engine_fork(const bk_engine* parent, bk_engine** out) {
+int bk_engine_fork(const bk_engine* parent, bk_engine** out) { return bk_engine_fork_params(parent, nullptr, out); }
+
+int bk_engine_fork_params(const bk_engine* parent, const bk_params* prm, bk_engine** out) {
     if (!parent || !out) return fail(BK_ERR_INVALID, "null argument");
+    if (prm && (prm->n_fixed != parent->params.n_fixed || (prm->use_full_kmer != 0) != (parent->params.use_full_kmer != 0) ||
+                prm->device != parent->params.device || (prm->full_kmer_stats != 0) != (parent->params.full_kmer_stats != 0)))
+        return fail(BK_ERR_INVALID, "bk_engine_fork_params: n_fixed, use_full_kmer, full_kmer_stats and device shape the shared tables and must equal the parent's");
+    if (prm && prm->cs == 0) return fail(BK_ERR_INVALID, "cs must be >= 1");
     BK_HIP(hipSetDevice(parent->device));
     std::unique_ptr<bk_engine> e(new bk_engine());
     const bk_engine* p = parent;
-    e->params = p->params; e->k = p->k; e->wstart = p->wstart; e->W = p->W; e->n_files = p->n_files;
+    e->params = prm ? *prm : p->params; e->k = p->k; e->wstart = p->wstart; e->W = p->W; e->n_files = p->n_files;
     e->total_cells = p->total_cells; e->n_slots = p->n_slots; e->log2s = p->log2s; e->log2nb = p->log2nb; e->log2p = p->log2p; e->m = p->m;
     e->n_u = p->n_u; e->n_full = p->n_full; e->n_lds_bins = p->n_lds_bins; e->n_prows = p->n_prows;
     e->v_omin = p->v_omin; e->v_span = p->v_span; e->v_off = p->v_off; e->plane_len = p->plane_len;
@@ -1376,6 +1396,13 @@ int bk_engine_set_stream(bk_engine* e, void* hip_stream) {
     return BK_OK;
 }
 
+int bk_engine_set_share(bk_engine* e, int engines_side_by_side) {
+    if (!e) return fail(BK_ERR_INVALID, "null engine");
+    if (engines_side_by_side < 1 || engines_side_by_side > 16) return fail(BK_ERR_INVALID, "1 <= engines_side_by_side <= 16");
+    e->scan_share = engines_side_by_side;
+    return BK_OK;
+}
+
 void* bk_engine_get_stream(const bk_engine* e) { return e ? reinterpret_cast<void*>(e->stream) : nullptr; }
 
 uint64_t bk_total_cells(const bk_engine* e) { return e ? e->total_cells : 0; }
@@ -1403,6 +1430,7 @@ int bk_sample_begin(bk_engine* e) {
         e->fill_known = 0; e->fill_unknown_upper = 0; e->fill_pending = false;
     }
     e->ktab_exchanged = false;
+    e->reduced_shards[0] = e->reduced_shards[1] = 0;
     e->pushed_records[0] = e->pushed_records[1] = 0;
     e->in_sample = true;
     return BK_OK;
@@ -1526,7 +1554,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.l2_words = bk::scan_l2_words(stride_words, e->k);
     const uint64_t l2_cap = std::max<uint64_t>(64, ((1ull << 30) / sizeof(unsigned int)) / a.l2_words);
     for (uint64_t base = 0; base < n;) {
-        const uint32_t grid = bk::scan_grid(n - base, e->n_cus);
+        const uint32_t grid = bk::scan_grid(n - base, std::max(e->n_cus / std::max(e->scan_share, 1), std::min(e->n_cus, 16)));
         uint64_t take = std::min<uint64_t>(std::min<uint64_t>(n - base, bk::scan_max_records(grid)), l2_cap);
         if (e->max_launch_records) take = std::min<uint64_t>(take, e->max_launch_records);
         if (e->l2_bits.n < take * a.l2_words || e->l2_diag.n < take) {
@@ -1638,6 +1666,41 @@ int bk_push_reads_ascii(bk_engine* e, int mate, const uint8_t* buf, const uint64
     return BK_OK;
 }
 
+int bk_push_reads_ascii_device(bk_engine* e, int mate, const void* d_bases, const void* d_offsets, uint64_t n_reads, uint64_t total_bases,
+                               uint32_t longest_read) {
+    if (!e) return fail(BK_ERR_INVALID, "null engine");
+    if (!e->in_sample) return fail(BK_ERR_STATE, "bk_push_reads_* called before bk_sample_begin");
+    if (mate < 0 || mate > 1) return fail(BK_ERR_INVALID, "mate must be 0 or 1");
+    if (n_reads == 0) return BK_OK;
+    if (!d_bases || !d_offsets) return fail(BK_ERR_INVALID, "bad read batch");
+    if (total_bases >= (1ull << 32)) return fail(BK_ERR_INVALID, "batch too large: push at most 2^32 bases per call");
+    BK_HIP(hipSetDevice(e->device));
+    // (everything is ordered by the engine's stream: the records of the previous batch were consumed by its scan before this
+    // batch's packer starts, so one set of record buffers does)
+    bk_engine::IngestSlot& sl = e->dev_ascii;
+    const uint64_t longest = std::max<uint64_t>(longest_read, (uint64_t)e->k);
+    const uint32_t stride = (uint32_t)std::min<uint64_t>((longest + 15) / 16, 4095);
+    const uint64_t maxb = std::min<uint64_t>((uint64_t)stride * 16, 65535);
+    const uint64_t cap = n_reads + total_bases / (uint64_t)e->k + total_bases / (maxb - (uint64_t)(e->k - 1)) + 16;   // bound on the records
+    if (sl.d_words.n < cap * stride || sl.d_lens.n < cap) {
+        BK_HIP(hipStreamSynchronize(e->stream));
+        BK_HIP(sl.d_words.alloc(cap * stride + cap * stride / 4));
+        BK_HIP(sl.d_lens.alloc(cap + cap / 4));
+    }
+    if (!sl.d_nrec.p) BK_HIP(sl.d_nrec.alloc(1));
+    BK_HIP(hipMemsetAsync(sl.d_nrec.p, 0, sizeof(unsigned long long), e->stream));
+    {
+        bk::PackArgs pa{};
+        pa.bases = static_cast<const uint8_t*>(d_bases); pa.offsets = static_cast<const unsigned long long*>(d_offsets); pa.n_reads = n_reads;
+        pa.k = e->k; pa.stride_words = stride;
+        pa.words = sl.d_words.p; pa.lens = sl.d_lens.p; pa.cap = cap; pa.n_records = sl.d_nrec.p;
+        bk_engine::Span sp(e, 2);
+        bk::launch_pack_reads(pa, e->stream);
+        bk::launch_add_u64(e->kstats.p + mate * 4 + 0, sl.d_nrec.p, e->stream);   // records pushed, tallied on the device
+    }
+    return push_device(e, mate, sl.d_words.p, stride, sl.d_lens.p, cap, sl.d_nrec.p, total_bases);
+}
+
 int bk_push_reads_packed_device(bk_engine* e, int mate, const void* d_words, uint32_t stride_words, const void* d_lens, uint64_t n) {
     if (!e) return fail(BK_ERR_INVALID, "null engine");
     if (!e->in_sample) return fail(BK_ERR_STATE, "bk_push_reads_* called before bk_sample_begin");
@@ -1716,7 +1779,8 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
     if (two_pass && (elem_lo != 0 || elem_hi != e->plane_len)) return fail(BK_ERR_UNSUPPORTED, "pileup_selected_only cannot be combined with a sharded finalize");
     if (two_pass && !e->sel_out.p) BK_HIP(e->sel_out.alloc(1));
     if (e->sparse && (elem_lo != 0 || elem_hi != e->plane_len)) return fail(BK_ERR_UNSUPPORTED, "an index this large cannot be finalized in shards");
-    const bool clean_dense = !e->sparse && elem_lo == 0 && elem_hi == e->plane_len;   // this call maps whole planes: it leaves them zeroed
+    const bool via_reduced = e->reduced_shards[0] > 0 || e->reduced_shards[1] > 0;   // (the planes themselves are not what is mapped: they are zeroed at the next push)
+    const bool clean_dense = !e->sparse && elem_lo == 0 && elem_hi == e->plane_len && !via_reduced;   // this call maps whole planes: it leaves them zeroed
     if (e->sparse) {
         for (int m = 0; m < n_mates; m++) {
             bk_engine::Span sp(e, 1);
@@ -1730,6 +1794,8 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             bk::FinalizeArgs a{};
             a.ix = e->view();
             a.counters = e->counters[m].p;
+            // (a part that came through bk_shard_received lives in its own buffer: element i of the plane is reduced[i - elem_lo])
+            if (e->reduced_shards[m] > 0) a.counters = e->reduced[m].p - elem_lo;
             a.elem_lo = elem_lo; a.elem_hi = elem_hi;
             a.ci = e->params.ci; a.cs = e->params.cs; a.cx = e->params.cx;
             a.pileup = e->pileup.p;
@@ -1808,6 +1874,7 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
 
 int bk_sample_finalize(bk_engine* e, int n_mates) {
     if (!e) return fail(BK_ERR_INVALID, "null engine");
+    if (e->reduced_shards[0] > 1 || e->reduced_shards[1] > 1) return fail(BK_ERR_STATE, "this sample's planes went through bk_shard_transport: finalize it with bk_sample_finalize_shard");
     return finalize_part(e, n_mates, 0, e->plane_len);
 }
 
@@ -1819,6 +1886,10 @@ int bk_sample_finalize_shard(bk_engine* e, int n_mates, int shard, int n_shards)
         return fail(BK_ERR_STATE, "full_kmer_stats with a sharded finalize: exchange the ranks' k-mer statistics tables first "
                                   "(bk_kmer_table_partition, all-to-all, bk_kmer_table_replace)");
     const uint64_t part = e->plane_len / (uint64_t)n_shards;
+    for (int m = 0; m < n_mates; m++)
+        if (e->reduced_shards[m] > 0 && (e->reduced_shards[m] != n_shards || e->reduced_shard[m] != shard))
+            return fail(BK_ERR_STATE, "bk_sample_finalize_shard(%d of %d): mate file %d received part %d of %d (bk_shard_received)", shard, n_shards, m,
+                        e->reduced_shard[m], e->reduced_shards[m]);
     int rc = finalize_part(e, n_mates, part * shard, part * (shard + 1));
     if (rc != BK_OK) return rc;
     if (e->ktab_keys.p) bk::launch_ktab_totals_to_kstats(e->ktab_out.p, e->kstats.p, n_mates, e->stream);   // (the ranks' totals add up)
@@ -1826,7 +1897,7 @@ int bk_sample_finalize_shard(bk_engine* e, int n_mates, int shard, int n_shards)
         if (e->pushed_records[m]) bk::launch_add_const_u64(e->kstats.p + m * 4 + 0, e->pushed_records[m], e->stream);
         e->pushed_records[m] = 0;
     }
-    bk::launch_pack_sums(e->shard_sums.p, e->stats.p, e->present.p, e->kstats.p, e->n_files, e->stream);
+    bk::launch_pack_sums(e->shard_sums.p, e->stats.p, e->present.p, e->kstats.p, e->n_files, e->xport_flag.p, e->stream);
     BK_HIP(hipGetLastError());
     return BK_OK;
 }
@@ -1881,15 +1952,98 @@ int bk_kmer_table_replace(bk_engine* e, const void* d_keys, const void* d_counts
 int bk_shard_sums_device_ptr(bk_engine* e, void** d_ptr, uint64_t* len) {
     if (!e || !d_ptr || !len) return fail(BK_ERR_INVALID, "null argument");
     *d_ptr = e->shard_sums.p;
-    *len = (uint64_t)2 * e->n_files * 5 + 8;
+    *len = (uint64_t)2 * e->n_files * 5 + 9;
     return BK_OK;
 }
 
 int bk_sample_merge_shards(bk_engine* e) {
     if (!e) return fail(BK_ERR_INVALID, "null engine");
     BK_HIP(hipSetDevice(e->device));
-    bk::launch_unpack_sums(e->shard_sums.p, e->stats.p, e->present.p, e->kstats.p, e->n_files, e->stream);
+    bk::launch_unpack_sums(e->shard_sums.p, e->stats.p, e->present.p, e->kstats.p, e->n_files, e->xport_flag.p, e->stream);
     BK_HIP(hipGetLastError());
+    return BK_OK;
+}
+
+static int shard_args_ok(bk_engine* e, int mate, int n_shards, int width) {
+    if (!e || mate < 0 || mate > 1) return fail(BK_ERR_INVALID, "bad argument");
+    if (n_shards < 1 || (int)bk::kMaxShards % n_shards != 0) return fail(BK_ERR_INVALID, "n_shards must divide %u", bk::kMaxShards);
+    if (width != 16 && width != 32 && width != 64) return fail(BK_ERR_INVALID, "width must be 16, 32 or 64");
+    if (e->sparse) return fail(BK_ERR_UNSUPPORTED, "an index this large keeps its counter planes sparse: shard whole samples over GPUs, not one sample's reads");
+    if (!e->in_sample) return fail(BK_ERR_STATE, "the transport of a plane comes between the pushes and the finalize of a sample");
+    return BK_OK;
+}
+
+int bk_shard_measure(bk_engine* e, int mate, void** d_max) {
+    if (!d_max) return fail(BK_ERR_INVALID, "null argument");
+    if (int rc = shard_args_ok(e, mate, 1, 64)) return rc;
+    BK_HIP(hipSetDevice(e->device));
+    if (int rc = zero_plane_if_stale(e, mate)) return rc;
+    BK_HIP(hipMemsetAsync(e->xport_flag.p + 2, 0, 2 * sizeof(unsigned long long), e->stream));
+    bk::launch_xport_measure(e->counters[mate].p, e->plane_len, e->v_off, e->xport_flag.p + 2, e->stream);
+    BK_HIP(hipGetLastError());
+    *d_max = e->xport_flag.p + 2;
+    return BK_OK;
+}
+
+int bk_shard_transport(bk_engine* e, int mate, int n_shards, int width, void** d_send, uint64_t* part_bytes, void** d_recv) {
+    if (!d_send || !part_bytes || !d_recv) return fail(BK_ERR_INVALID, "null argument");
+    if (int rc = shard_args_ok(e, mate, n_shards, width)) return rc;
+    BK_HIP(hipSetDevice(e->device));
+    if (int rc = zero_plane_if_stale(e, mate)) return rc;   // (a mate file nothing was pushed for: its plane is zeroed lazily -- now)
+    e->plane_used[mate] = true;
+    e->xport_ever = true;
+    if (e->reduced_shards[0] == 0 && e->reduced_shards[1] == 0)   // first transport of this sample
+        BK_HIP(hipMemsetAsync(e->xport_flag.p, 0, sizeof(unsigned long long), e->stream));
+    const uint64_t part = e->plane_len / (uint64_t)n_shards;
+    if (e->reduced[mate].n < part) {   // (buffers are sized once per shape and stay where they are: a host may keep views of them)
+        BK_HIP(hipStreamSynchronize(e->stream));
+        BK_HIP(e->reduced[mate].alloc(part));
+    }
+    const uint64_t pb = bk::xport_part_bytes(e->plane_len, e->v_off, (uint32_t)n_shards, width);
+    *part_bytes = pb;
+    if (width == 64) {   // nothing to pack: the plane itself is the send buffer and the received part is the reduced part
+        *d_send = e->counters[mate].p;
+        *d_recv = e->reduced[mate].p;
+        return BK_OK;
+    }
+    const uint64_t need_send = bk::xport_part_bytes(e->plane_len, e->v_off, (uint32_t)n_shards, 32) * (uint64_t)n_shards;   // (the larger of the two widths)
+    if (e->xport_send.n < need_send || e->xport_recv.n < need_send / (uint64_t)n_shards) {
+        BK_HIP(hipStreamSynchronize(e->stream));
+        BK_HIP(e->xport_send.alloc(need_send));
+        BK_HIP(e->xport_recv.alloc(need_send / (uint64_t)n_shards));
+    }
+    bk_engine::Span sp(e, 2);
+    bk::launch_xport_pack(e->counters[mate].p, e->plane_len, e->v_off, (uint32_t)n_shards, width, e->xport_send.p, e->xport_flag.p, e->stream);
+    BK_HIP(hipGetLastError());
+    *d_send = e->xport_send.p;
+    *d_recv = e->xport_recv.p;
+    return BK_OK;
+}
+
+int bk_shard_received(bk_engine* e, int mate, int shard, int n_shards, int width) {
+    if (int rc = shard_args_ok(e, mate, n_shards, width)) return rc;
+    if (shard < 0 || shard >= n_shards) return fail(BK_ERR_INVALID, "0 <= shard < n_shards");
+    const uint64_t part = e->plane_len / (uint64_t)n_shards;
+    if (e->reduced[mate].n < part || (width != 64 && !e->xport_recv.p)) return fail(BK_ERR_STATE, "bk_shard_received without bk_shard_transport");
+    BK_HIP(hipSetDevice(e->device));
+    if (width != 64) {
+        bk_engine::Span sp(e, 2);
+        bk::launch_xport_unpack(e->xport_recv.p, e->plane_len, e->v_off, (uint32_t)n_shards, (uint32_t)shard, width, e->reduced[mate].p, e->stream);
+        BK_HIP(hipGetLastError());
+    }
+    e->reduced_shards[mate] = n_shards;
+    e->reduced_shard[mate] = shard;
+    return BK_OK;
+}
+
+int bk_transport_overflow(bk_engine* e, int* overflowed) {
+    if (!e || !overflowed) return fail(BK_ERR_INVALID, "null argument");
+    BK_HIP(hipSetDevice(e->device));
+    unsigned long long f[2] = {0, 0};
+    BK_HIP(hipMemcpyAsync(f, e->xport_flag.p, sizeof f, hipMemcpyDeviceToHost, e->stream));
+    BK_HIP(hipMemsetAsync(e->xport_flag.p + 1, 0, sizeof(unsigned long long), e->stream));
+    BK_HIP(hipStreamSynchronize(e->stream));
+    *overflowed = f[1] != 0;
     return BK_OK;
 }
 
@@ -1910,7 +2064,14 @@ int bk_sample_download(bk_engine* e, int n_mates, uint64_t* fwd_depth, uint64_t*
     }
     unsigned long long kt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (kmer_stats) BK_HIP(hipMemcpyAsync(kt, e->ktab_out.p, sizeof kt, hipMemcpyDeviceToHost, e->stream));
+    unsigned long long xf = 0;
+    if (e->xport_ever) {
+        BK_HIP(hipMemcpyAsync(&xf, e->xport_flag.p + 1, sizeof xf, hipMemcpyDeviceToHost, e->stream));
+        BK_HIP(hipMemsetAsync(e->xport_flag.p + 1, 0, sizeof xf, e->stream));
+    }
     BK_HIP(hipStreamSynchronize(e->stream));
+    if (xf) return fail(BK_ERR_RANGE, "a counter of this (or an earlier, unchecked) sample did not fit the width its plane was exchanged at: the results are "
+                                      "invalid -- repeat the sample with a wider bk_shard_transport (bk_shard_measure tells which width is safe)");
     if (kmer_stats) {
         for (int m = 0; m < n_mates; m++) {
             kmer_stats[m * 4 + 0] += e->pushed_records[m];   // + the device-side tally of bk_push_reads_ascii batches

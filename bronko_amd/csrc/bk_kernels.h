@@ -161,9 +161,17 @@ void launch_zero_small(unsigned long long* a, size_t na, unsigned long long* b, 
                        unsigned char* d, size_t nd, unsigned int* e, size_t ne, hipStream_t stream);
 // shard_sums <-> {stats, present, kstats}: the small additive results of a sharded finalize as one u64 vector
 void launch_pack_sums(unsigned long long* sums, const unsigned long long* stats, const unsigned char* present, const unsigned long long* kstats,
-                      int n_files, hipStream_t stream);
+                      int n_files, unsigned long long* xflag, hipStream_t stream);
 void launch_unpack_sums(const unsigned long long* sums, unsigned long long* stats, unsigned char* present, unsigned long long* kstats,
-                        int n_files, hipStream_t stream);
+                        int n_files, unsigned long long* xflag, hipStream_t stream);
+// sharded finalize: a counter plane packed for the reduce-scatter (16- or 32-bit elements, n_parts parts) and a received part
+// widened again; xflag[0] is raised when an element does not fit (bk_kernels.hip, xport_pack_kernel)
+uint64_t xport_part_bytes(uint64_t plane_len, uint64_t v_off, uint32_t n_parts, int width);
+void launch_xport_measure(const unsigned long long* plane, uint64_t plane_len, uint64_t v_off, unsigned long long* out, hipStream_t stream);
+void launch_xport_pack(const unsigned long long* plane, uint64_t plane_len, uint64_t v_off, uint32_t n_parts, int width, void* buf, unsigned long long* flag,
+                       hipStream_t stream);
+void launch_xport_unpack(const void* recv, uint64_t plane_len, uint64_t v_off, uint32_t n_parts, uint32_t shard, int width, unsigned long long* reduced,
+                         hipStream_t stream);
 // ---- after the pileup (bk_caller.hip) ----
 typedef bk_call_params CallParamsDev;
 typedef bk_call_record CallRecordDev;

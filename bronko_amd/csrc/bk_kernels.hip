@@ -2250,29 +2250,138 @@ void launch_zero_small(unsigned long long* a, size_t na, unsigned long long* b, 
     hipLaunchKernelGGL(zero_small_kernel, dim3(16), dim3(256), 0, stream, a, na, b, nb, c, nc, d, nd, e, ne);
 }
 
-// ---- sharded finalize: the small additive results as one u64 vector [stats 2*n_files*3 | present 2*n_files | kstats 8]
+// ---- sharded finalize: the small additive results as one u64 vector [stats 2*n_files*3 | present 2*n_files | kstats 8 | flag]
+// (flag: a transport packer of this sample met a counter too large for its width, see xport_pack_kernel; summed over the ranks
+// like the rest, so that every rank knows)
 __global__ void pack_sums_kernel(unsigned long long* sums, const unsigned long long* stats, const unsigned char* present,
-                                 const unsigned long long* kstats, int n_files) {
+                                 const unsigned long long* kstats, int n_files, unsigned long long* xflag) {
     const int n_s = 2 * n_files * 3, n_p = 2 * n_files;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_s + n_p + 8; i += gridDim.x * blockDim.x)
-        sums[i] = i < n_s ? stats[i] : i < n_s + n_p ? (unsigned long long)present[i - n_s] : kstats[i - n_s - n_p];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_s + n_p + 9; i += gridDim.x * blockDim.x)
+        sums[i] = i < n_s ? stats[i] : i < n_s + n_p ? (unsigned long long)present[i - n_s] : i < n_s + n_p + 8 ? kstats[i - n_s - n_p] : xflag[0];
 }
 __global__ void unpack_sums_kernel(const unsigned long long* sums, unsigned long long* stats, unsigned char* present,
-                                   unsigned long long* kstats, int n_files) {
+                                   unsigned long long* kstats, int n_files, unsigned long long* xflag) {
     const int n_s = 2 * n_files * 3, n_p = 2 * n_files;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_s + n_p + 8; i += gridDim.x * blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_s + n_p + 9; i += gridDim.x * blockDim.x) {
         if (i < n_s) stats[i] = sums[i];
         else if (i < n_s + n_p) present[i - n_s] = sums[i] ? 1 : 0;
-        else kstats[i - n_s - n_p] = sums[i];
+        else if (i < n_s + n_p + 8) kstats[i - n_s - n_p] = sums[i];
+        else { if (sums[i]) xflag[1] = 1ull; xflag[0] = 0ull; }   // [1]: sticky until bk_transport_overflow reads it
     }
 }
 void launch_pack_sums(unsigned long long* sums, const unsigned long long* stats, const unsigned char* present, const unsigned long long* kstats,
-                      int n_files, hipStream_t stream) {
-    hipLaunchKernelGGL(pack_sums_kernel, dim3(8), dim3(256), 0, stream, sums, stats, present, kstats, n_files);
+                      int n_files, unsigned long long* xflag, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_sums_kernel, dim3(8), dim3(256), 0, stream, sums, stats, present, kstats, n_files, xflag);
 }
 void launch_unpack_sums(const unsigned long long* sums, unsigned long long* stats, unsigned char* present, unsigned long long* kstats,
-                        int n_files, hipStream_t stream) {
-    hipLaunchKernelGGL(unpack_sums_kernel, dim3(8), dim3(256), 0, stream, sums, stats, present, kstats, n_files);
+                        int n_files, unsigned long long* xflag, hipStream_t stream) {
+    hipLaunchKernelGGL(unpack_sums_kernel, dim3(8), dim3(256), 0, stream, sums, stats, present, kstats, n_files, xflag);
+}
+
+// ---- sharded finalize: a counter plane on its way to the other ranks (bk_shard_measure / bk_shard_transport / bk_shard_received)
+// The plane's u64 elements are counts (E part, pseudo rows) and differences of counts (V rows) that wrap modulo 2^64; read as
+// signed numbers they are small.  A reduce-scatter(sum) over n ranks of a narrower copy gives the same sums as long as every
+// true sum fits the narrower type:
+//   width 32   every element as int32.
+//   width 16   two 16-bit lanes per int32 word (RCCL has no 16-bit integer type, and none is needed: lanes that hold unsigned
+//              numbers whose sums stay below 2^16 add up inside a 32-bit addition without carrying into each other).  A V
+//              element v, |v| <= L = 32767 / n, travels as v + L; the receiver takes n L off the sum.  An E count c < 2^32
+//              travels as four 8-bit digits (c >> 8 q) & 255, one per lane -- sums of at most 64 digits stay below 2^14 -- and
+//              the receiver puts sum_q digit_q << 8 q back together.
+// Part p of the transport buffer holds the plane's elements [p P, (p + 1) P) (P = plane length / n; never cuts a V row) and is
+// padded to the size of part 0, the one with the most E elements.  The packers check the sufficient local condition
+// |element| <= (type's maximum) / n and raise *flag otherwise: the flag travels with the sample's statistics to every rank.
+struct XportGeom {
+    uint64_t plane_len, part_len, v_off;   // v_off: elements below it are E counts (or the zero padding behind them)
+    uint32_t n_parts;
+    uint64_t part_elems;                   // transport elements per part (16-bit lanes or int32)
+};
+BK_HD uint64_t xport_e_in_part(const XportGeom& g, uint64_t p) {
+    const uint64_t lo = p * g.part_len;
+    return g.v_off > lo ? (g.v_off - lo < g.part_len ? g.v_off - lo : g.part_len) : 0ull;
+}
+__global__ __launch_bounds__(256) void xport_measure_kernel(const unsigned long long* __restrict__ plane, XportGeom g, unsigned long long* out /* [2] max E, max |V| */) {
+    unsigned long long me = 0, mv = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < g.plane_len; i += (uint64_t)gridDim.x * 256) {
+        const unsigned long long v = plane[i];
+        if (i < g.v_off) me = max(me, v);
+        else { const long long sv = (long long)v; mv = max(mv, (unsigned long long)(sv < 0 ? -sv : sv)); }
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) { me = max(me, (unsigned long long)__shfl_xor(me, off)); mv = max(mv, (unsigned long long)__shfl_xor(mv, off)); }
+    if ((threadIdx.x & 63) == 0) { if (me) atomicMax(out, me); if (mv) atomicMax(out + 1, mv); }
+}
+template <int WIDTH>
+__global__ __launch_bounds__(256) void xport_pack_kernel(const unsigned long long* __restrict__ plane, XportGeom g, void* buf, unsigned long long* flag) {
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < g.plane_len; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t p = i / g.part_len, j = i - p * g.part_len;
+        const unsigned long long v = plane[i];
+        const long long sv = (long long)v;
+        if (WIDTH == 32) {
+            bad |= sv > (long long)(0x7fffffffll / g.n_parts) || sv < -(long long)(0x7fffffffll / g.n_parts);
+            static_cast<int*>(buf)[p * g.part_elems + j] = (int)sv;
+        } else {
+            const uint64_t n_e = xport_e_in_part(g, p);
+            unsigned short* part = static_cast<unsigned short*>(buf) + p * g.part_elems;
+            const long long lim = 32767 / g.n_parts;
+            if (j < n_e) {
+                bad |= v >> 32 != 0ull;
+                *reinterpret_cast<uint2*>(part + 4 * j) = make_uint2((uint32_t)(v & 255u) | ((uint32_t)((v >> 8) & 255u) << 16),
+                                                                      (uint32_t)((v >> 16) & 255u) | ((uint32_t)((v >> 24) & 255u) << 16));
+            } else {
+                bad |= sv > lim || sv < -lim;
+                part[4 * n_e + (j - n_e)] = (unsigned short)(sv + lim);
+            }
+        }
+    }
+    if (WIDTH == 16) {   // the padding lanes behind each part's elements
+        for (uint64_t p = blockIdx.x; p < g.n_parts; p += gridDim.x) {
+            const uint64_t used = g.part_len + 3 * xport_e_in_part(g, p);
+            unsigned short* part = static_cast<unsigned short*>(buf) + p * g.part_elems;
+            for (uint64_t x = used + threadIdx.x; x < g.part_elems; x += 256) part[x] = 0;
+        }
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1ull);
+}
+template <int WIDTH>
+__global__ __launch_bounds__(256) void xport_unpack_kernel(const void* __restrict__ recv, XportGeom g, uint32_t shard, unsigned long long* reduced) {
+    const uint64_t n_e = xport_e_in_part(g, shard);
+    for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < g.part_len; j += (uint64_t)gridDim.x * 256) {
+        long long v;
+        if (WIDTH == 32) v = static_cast<const int*>(recv)[j];
+        else if (j < n_e) {
+            const unsigned short* d = static_cast<const unsigned short*>(recv) + 4 * j;
+            v = (long long)d[0] + ((long long)d[1] << 8) + ((long long)d[2] << 16) + ((long long)d[3] << 24);
+        } else v = (long long)static_cast<const unsigned short*>(recv)[4 * n_e + (j - n_e)] - (long long)(32767 / g.n_parts) * g.n_parts;
+        reduced[j] = (unsigned long long)v;
+    }
+}
+static XportGeom xport_geom(uint64_t plane_len, uint64_t v_off, uint32_t n_parts, int width) {
+    XportGeom g{plane_len, plane_len / n_parts, v_off, n_parts, 0};
+    g.part_elems = width == 16 ? (g.part_len + 3 * xport_e_in_part(g, 0) + 3) / 4 * 4 : g.part_len;   // (parts stay 8-byte aligned)
+    return g;
+}
+uint64_t xport_part_bytes(uint64_t plane_len, uint64_t v_off, uint32_t n_parts, int width) {
+    return width == 64 ? plane_len / n_parts * 8 : xport_geom(plane_len, v_off, n_parts, width).part_elems * (uint64_t)(width / 8);
+}
+void launch_xport_measure(const unsigned long long* plane, uint64_t plane_len, uint64_t v_off, unsigned long long* out, hipStream_t stream) {
+    hipLaunchKernelGGL(xport_measure_kernel, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((plane_len + 255) / 256, 2048))), dim3(256), 0, stream, plane,
+                       xport_geom(plane_len, v_off, 1, 32), out);
+}
+void launch_xport_pack(const unsigned long long* plane, uint64_t plane_len, uint64_t v_off, uint32_t n_parts, int width, void* buf, unsigned long long* flag,
+                       hipStream_t stream) {
+    const XportGeom g = xport_geom(plane_len, v_off, n_parts, width);
+    const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((plane_len + 255) / 256, 4096)));
+    if (width == 16) hipLaunchKernelGGL(xport_pack_kernel<16>, grid, dim3(256), 0, stream, plane, g, buf, flag);
+    else hipLaunchKernelGGL(xport_pack_kernel<32>, grid, dim3(256), 0, stream, plane, g, buf, flag);
+}
+void launch_xport_unpack(const void* recv, uint64_t plane_len, uint64_t v_off, uint32_t n_parts, uint32_t shard, int width, unsigned long long* reduced,
+                         hipStream_t stream) {
+    const XportGeom g = xport_geom(plane_len, v_off, n_parts, width);
+    const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((g.part_len + 255) / 256, 4096)));
+    if (width == 16) hipLaunchKernelGGL(xport_unpack_kernel<16>, grid, dim3(256), 0, stream, recv, g, shard, reduced);
+    else hipLaunchKernelGGL(xport_unpack_kernel<32>, grid, dim3(256), 0, stream, recv, g, shard, reduced);
 }
 
 }  // namespace bk

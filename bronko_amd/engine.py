@@ -144,13 +144,17 @@ class Engine:
         self.n_slots = L.bk_n_slots(h)
         self.counter_len = L.bk_counter_len(h)
 
-    def fork(self):
+    def fork(self, params=None):
         """A second engine on the same device tables with its own counter planes, outputs and stream (bk_engine_fork):
-        alternate independent samples over the two so that one's scan overlaps the other's finalize."""
+        alternate independent samples over the two so that one's scan overlaps the other's finalize.  params: the fork's own
+        ci / cs / cx / pileup_selected_only (bk_engine_fork_params; what shapes the tables must equal the parent's)."""
         h = C.c_void_p()
-        _check(self._L.bk_engine_fork(self.h, C.byref(h)), self._L)
+        if params is None:
+            _check(self._L.bk_engine_fork(self.h, C.byref(h)), self._L)
+        else:
+            _check(self._L.bk_engine_fork_params(self.h, C.byref(params), C.byref(h)), self._L)
         e = object.__new__(Engine)
-        e._L, e.h, e.k, e.params = self._L, h, self.k, self.params
+        e._L, e.h, e.k, e.params = self._L, h, self.k, params if params is not None else self.params
         e.n_files, e.total_cells, e.n_slots, e.counter_len = self.n_files, self.total_cells, self.n_slots, self.counter_len
         e._parent = self   # the parent's tables must outlive the fork
         return e
@@ -165,6 +169,10 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def set_share(self, engines_side_by_side):
+        """bk_engine_set_share: this engine's scans take a 1/n share of the CUs (n engines run samples side by side)."""
+        _check(self._L.bk_engine_set_share(self.h, int(engines_side_by_side)), self._L)
 
     def set_stream(self, stream_ptr):
         _check(self._L.bk_engine_set_stream(self.h, C.c_void_p(stream_ptr)), self._L)
@@ -195,6 +203,11 @@ class Engine:
         off[1:] = np.cumsum([len(r) for r in reads])
         _check(self._L.bk_push_reads_ascii(self.h, mate, flat.ctypes.data, off.ctypes.data, len(reads)), self._L)
 
+    def push_reads_ascii_device(self, mate, d_bases_ptr, d_offsets_ptr, n_reads, total_bases, longest_read):
+        """bk_push_reads_ascii_device: sequence lines resident in device memory, packed (K0) and scanned on the engine's stream."""
+        _check(self._L.bk_push_reads_ascii_device(self.h, mate, C.c_void_p(d_bases_ptr), C.c_void_p(d_offsets_ptr), n_reads, total_bases,
+                                                  longest_read), self._L)
+
     def push_reads_device(self, mate, d_words_ptr, stride_words, d_lens_ptr, n_records):
         _check(self._L.bk_push_reads_packed_device(self.h, mate, C.c_void_p(d_words_ptr), stride_words,
                                                    C.c_void_p(d_lens_ptr), n_records), self._L)
@@ -215,6 +228,28 @@ class Engine:
     def sample_finalize_shard(self, n_mates, shard, n_shards):
         """Map only the shard-th of n_shards equal parts of each counter plane (include/bronko_hip.h)."""
         _check(self._L.bk_sample_finalize_shard(self.h, n_mates, shard, n_shards), self._L)
+
+    def shard_measure(self, mate):
+        """Device pointer of two u64: the largest E count and the largest |V element| of this rank's plane (asynchronous; the
+        host all-reduces them with MAX and picks the transport width: include/bronko_hip.h)."""
+        p = C.c_void_p()
+        _check(self._L.bk_shard_measure(self.h, mate, C.byref(p)), self._L)
+        return p.value
+
+    def shard_transport(self, mate, n_shards, width):
+        """Pack the plane for the reduce-scatter: (send pointer, bytes per part, receive pointer); width 16 / 32 / 64 bits."""
+        s, r, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        _check(self._L.bk_shard_transport(self.h, mate, n_shards, width, C.byref(s), C.byref(n), C.byref(r)), self._L)
+        return s.value, n.value, r.value
+
+    def shard_received(self, mate, shard, n_shards, width):
+        _check(self._L.bk_shard_received(self.h, mate, shard, n_shards, width), self._L)
+
+    def transport_overflow(self):
+        """True when some sample since the last call met a counter too large for the width its plane was exchanged at."""
+        f = C.c_int(0)
+        _check(self._L.bk_transport_overflow(self.h, C.byref(f)), self._L)
+        return bool(f.value)
 
     def kmer_table_partition(self, n_parts):
         """full_kmer_stats under a sharded finalize: (device pointer of keys u64, of counts u32, offsets[n_parts + 1]) -- the

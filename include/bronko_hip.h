@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BK_ABI_VERSION 6
+#define BK_ABI_VERSION 7
 
 typedef enum {
     BK_OK = 0,
@@ -38,7 +38,8 @@ typedef enum {
     BK_ERR_NO_DEVICE = -2, /* no HIP device / not gfx950                   */
     BK_ERR_HIP = -3,       /* a HIP runtime call failed                    */
     BK_ERR_UNSUPPORTED = -4,
-    BK_ERR_STATE = -5      /* call order violated (e.g. push before begin) */
+    BK_ERR_STATE = -5,     /* call order violated (e.g. push before begin) */
+    BK_ERR_RANGE = -6      /* a counter did not fit the width its plane was exchanged at (bk_shard_transport) */
 } bk_status;
 
 /* build.rs:52-60  `#[repr(C)] struct BucketInfo` -- same field order, same layout (12 bytes) */
@@ -112,6 +113,16 @@ void bk_engine_destroy(bk_engine* e);
  * with many samples alternates them over two engines: sample i+1's scan overlaps sample i's finalize on the
  * device.  Same parameters as the parent.  Destroy the forks before the parent. */
 int  bk_engine_fork(const bk_engine* parent, bk_engine** out);
+/* The same with parameters of its own (v7): ci / cs / cx, pileup_selected_only and kmer_table_log2 belong to a sample's state and
+ * may differ from the parent's; n_fixed, use_full_kmer, full_kmer_stats and device shape the shared tables and must not
+ * (BK_ERR_INVALID).  E.g. one index, `--min-kmers 3` and `--min-kmers 5` samples side by side. */
+int  bk_engine_fork_params(const bk_engine* parent, const bk_params* params, bk_engine** out);
+
+/* A hint (v7): this engine is one of `engines_side_by_side` engines (a parent and its forks, one sample each) whose samples run at
+ * the same time on the device.  Its scan kernel -- one workgroup per CU, it takes a CU's whole LDS -- is then launched on a
+ * 1/engines_side_by_side share of the CUs, so that the engines' scans run side by side on disjoint CUs instead of one after the
+ * other, each workgroup amortising its set-up over more reads.  Results do not depend on it.  Default 1: the whole chip. */
+int bk_engine_set_share(bk_engine* e, int engines_side_by_side);
 
 /* Launch all work of this engine on an existing HIP stream (hipStream_t passed as void*); NULL restores the
  * engine's own stream.  Lets a host that already owns a stream (e.g. PyTorch's current stream) order and
@@ -144,6 +155,11 @@ int bk_push_reads_packed(bk_engine* e, int mate, const uint32_t* words, uint32_t
                          const uint16_t* lens, uint64_t n_records);
 /* (bk_push_reads_packed stages the batch through one of two device buffers: the copy of a batch overlaps the scan of the
  * previous one; the call blocks only when both are still in use.) */
+/* K0 from device memory (v7): the sequence lines are already resident (d_bases: bytes back to back, d_offsets: u64[n_reads + 1]);
+ * the engine packs them into 2-bit records on its stream and scans them -- no copy, no host work beyond the launches.
+ * total_bases = offsets[n_reads] - offsets[0] and longest_read (bases; sizes the record stride) are the host's to know. */
+int bk_push_reads_ascii_device(bk_engine* e, int mate, const void* d_bases, const void* d_offsets, uint64_t n_reads,
+                               uint64_t total_bases, uint32_t longest_read);
 /* Same, for a batch that is already resident in device memory (no copy; asynchronous on the engine stream). */
 int bk_push_reads_packed_device(bk_engine* e, int mate, const void* d_words, uint32_t stride_words,
                                 const void* d_lens, uint64_t n_records);
@@ -178,6 +194,31 @@ int bk_sample_finalize(bk_engine* e, int n_mates);
 int bk_sample_finalize_shard(bk_engine* e, int n_mates, int shard, int n_shards);
 int bk_shard_sums_device_ptr(bk_engine* e, void** d_ptr, uint64_t* len);
 int bk_sample_merge_shards(bk_engine* e);
+/* Transport of the planes for the sharded finalize (v7).  The u64 elements of a plane are counts and differences of counts; as
+ * signed numbers they are small, and a reduce-scatter of a narrower copy moves a half or a quarter of the bytes over xGMI.  The
+ * engine packs and widens on its own stream -- no host-side temporaries -- and leaves the plane itself untouched:
+ *   bk_shard_measure(e, mate, &d_max)        optional.  d_max -> two u64 on the device: the largest E count and the largest |V
+ *                                            element| of this rank's plane (asynchronous).  The host all-reduces them (MAX) and
+ *                                            picks the width: 16 needs max|V| * n <= 32767 and max E < 2^32; 32 needs
+ *                                            max(E, |V|) * n <= 2^31 - 1; 64 always fits.
+ *   bk_shard_transport(e, mate, n, width, &d_send, &part_bytes, &d_recv)
+ *                                            packs the plane (asynchronous) into n parts of part_bytes bytes at d_send: int32
+ *                                            words that hold two 16-bit lanes each (width 16: a V element v as v + 32767 / n,
+ *                                            an E count as four 8-bit digits -- unsigned lanes whose sums stay below 2^16 add
+ *                                            up inside 32-bit additions; RCCL has no 16-bit integer type), int32 elements
+ *                                            (32), or the plane itself (64: d_send is the plane).  The host reduce-scatters(sum)
+ *                                            d_send -- element type int32 for widths 16 and 32, int64 for 64 -- leaving this
+ *                                            rank's part at d_recv.  A packer that meets an element beyond (lane maximum) / n
+ *                                            raises a flag that travels with bk_shard_sums_device_ptr to every rank.
+ *   bk_shard_received(e, mate, shard, n, width)  widens the received part (asynchronous); bk_sample_finalize_shard(.., shard, n)
+ *                                            then maps it instead of the plane's own elements.
+ *   bk_transport_overflow(e, &flag)          synchronises; flag = some sample since the last call met such an element (its results are
+ *                                            garbage: repeat it wider).  bk_sample_download reports the same as BK_ERR_RANGE.
+ * Pointers stay valid for the engine's lifetime once returned for a given (n, width). */
+int bk_shard_measure(bk_engine* e, int mate, void** d_max);
+int bk_shard_transport(bk_engine* e, int mate, int n_shards, int width, void** d_send, uint64_t* part_bytes, void** d_recv);
+int bk_shard_received(bk_engine* e, int mate, int shard, int n_shards, int width);
+int bk_transport_overflow(bk_engine* e, int* overflowed);
 /* full_kmer_stats with a sharded finalize (v6): a k-mer that touches no window bucket sits in the statistics table of every
  * rank whose reads held it, and KMC's "unique (counted) k-mers" (call.rs:1190-1199) want it once, with its total count.  Between
  * the last push and bk_sample_finalize_shard every rank

@@ -34,6 +34,51 @@ def hip_sample(eng, mates_ascii, k, stride_words=None, batch=None, ascii_path=Fa
     return eng.sample_finish(len(mates_ascii))
 
 
+def sharded_finalize_on_one_device(engs, n_mates, width):
+    """The sharded finalize of include/bronko_hip.h with len(engs) engines on ONE device standing for as many ranks, each of
+    which has scanned its share of the sample: bk_shard_transport packs every plane, the reduce-scatter is simulated (typed,
+    wrapping sums of the send buffers; part r to rank r), bk_shard_received widens, bk_sample_finalize_shard maps, the small
+    results are combined (max / sum) and installed on every rank.  Afterwards every engine's sample_download is the sample's."""
+    import torch
+    from bronko_amd.dist import DeviceVector
+    world = len(engs)
+    item, tstr = (8, "<i8") if width == 64 else (4, "<i4")
+    cells4 = engs[0].total_cells * 4
+    for m in range(n_mates):
+        bufs = []
+        for e in engs:
+            sp, pb, rp = e.shard_transport(m, world, width)
+            bufs.append((torch.as_tensor(DeviceVector(sp, pb // item * world, tstr), device="cuda:0"),
+                         torch.as_tensor(DeviceVector(rp, pb // item, tstr), device="cuda:0")))
+        torch.cuda.synchronize()
+        total = bufs[0][0].clone()
+        for send, _ in bufs[1:]:
+            total += send                                                  # (wraps like the collective's sum)
+        n = bufs[0][1].numel()
+        for r, (_, recv) in enumerate(bufs):
+            recv.copy_(total[r * n:(r + 1) * n])
+        torch.cuda.synchronize()
+        for r, e in enumerate(engs):
+            e.shard_received(m, r, world, width)
+    piles, sums = [], []
+    for r, e in enumerate(engs):
+        e.sample_finalize_shard(n_mates, r, world)
+        piles.append(torch.as_tensor(DeviceVector(e.pileup_ptr(), 4 * cells4), device="cuda:0"))
+        sp, sn = e.shard_sums()
+        sums.append(torch.as_tensor(DeviceVector(sp, sn), device="cuda:0"))
+    torch.cuda.synchronize()
+    depth = torch.stack([p[:2 * cells4] for p in piles]).max(dim=0).values
+    nk = torch.stack([p[2 * cells4:] for p in piles]).sum(dim=0)
+    ssum = torch.stack(sums).sum(dim=0)
+    for r, e in enumerate(engs):
+        piles[r][:2 * cells4] = depth
+        piles[r][2 * cells4:] = nk
+        sums[r].copy_(ssum)
+    torch.cuda.synchronize()
+    for e in engs:
+        e.sample_merge_shards()
+
+
 def assert_same_pileup(res, pile):
     for name in ("fwd_depth", "rev_depth", "fwd_nk", "rev_nk"):
         a, b = getattr(res, name), getattr(pile, name)

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
         L = _ffi.load(testing=testing)
         for s in declared:
             assert hasattr(L, s), s
-        assert L.bk_abi_version() == 6
+        assert L.bk_abi_version() == 7
 
 
 def test_release_library_reads_no_environment_variable():

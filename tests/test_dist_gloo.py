@@ -147,3 +147,69 @@ def test_kmer_table_entries_all_to_all(tmp_path):
             want_k.append(got[q]["keys"][lo:lo + got[q]["splits"][r]])
             want_c.append(got[q]["cnts"][lo:lo + got[q]["splits"][r]])
         assert torch.equal(got[r]["rk"], torch.cat(want_k)) and torch.equal(got[r]["rc"], torch.cat(want_c))
+
+
+def _lanes16_pack(plane, v_off, world):
+    """numpy restatement of the engine's 16-bit transport (bk_kernels.hip, xport_pack_kernel<16>) for ONE part holding the whole
+    plane: E counts (elements below v_off) as four 8-bit digits, V elements biased by L = 32767 // world, two 16-bit lanes per
+    int32 word."""
+    lim = 32767 // world
+    e = plane[:v_off].astype(np.uint64)
+    lanes = np.zeros(4 * v_off + (len(plane) - v_off), np.uint16)
+    for q in range(4):
+        lanes[q:4 * v_off:4] = ((e >> np.uint64(8 * q)) & np.uint64(255)).astype(np.uint16)
+    lanes[4 * v_off:] = (plane[v_off:] + lim).astype(np.uint16)
+    if len(lanes) % 2:
+        lanes = np.concatenate([lanes, np.zeros(1, np.uint16)])
+    return lanes.view(np.int32).copy()
+
+
+def _lanes16_unpack(words, n, v_off, world):
+    lanes = words.view(np.uint16).astype(np.int64)
+    e = sum(lanes[q:4 * v_off:4] << (8 * q) for q in range(4))
+    v = lanes[4 * v_off:4 * v_off + (n - v_off)] - (32767 // world) * world
+    return np.concatenate([e, v])
+
+
+def _worker_lanes(rank, world, port, out_dir):
+    from bronko_amd.dist import pick_width, reduce_scatter_typed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(700 + rank)
+        v_off, n = 40, 400
+        lim = 32767 // world
+        plane = np.concatenate([rng.integers(0, 2 ** 32, v_off, dtype=np.int64),              # E counts: anything below 2^32
+                                rng.integers(-lim, lim + 1, n - v_off, dtype=np.int64)])       # V elements: differences, up to the bound
+        plane[v_off] = lim if rank == 0 else -lim                                              # (the extremes)
+        plane[v_off + 1] = lim
+        mx = torch.tensor([int(plane[:v_off].max()), int(np.abs(plane[v_off:]).max())], dtype=torch.int64)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        width = pick_width(int(mx[0]), int(mx[1]), world)
+        # the whole plane as one part, sent as `world` copies of it so that every rank receives the full sum
+        words = _lanes16_pack(plane, v_off, world)
+        send = torch.from_numpy(np.tile(words, world))
+        recv = torch.empty(len(words), dtype=torch.int32)
+        reduce_scatter_typed(send, recv, rank, world)
+        got = _lanes16_unpack(recv.numpy(), n, v_off, world)
+        np.savez(os.path.join(out_dir, "l%d.npz" % rank), plane=plane, got=got, width=width)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sixteen_bit_lanes_add_up_inside_int32_sums(tmp_path):
+    """The width-16 transport of the sharded finalize (no 16-bit integer type in RCCL): unsigned 16-bit lanes, two per int32 word,
+    whose sums stay below 2^16 -- V elements biased by 32767 // world, E counts as four 8-bit digits -- summed as int32 by the
+    collective (gloo here, world_size 2) and put back together give the exact 64-bit sums, at the bound of what pick_width
+    admits; pick_width itself on the all-reduced maxima."""
+    from bronko_amd.dist import pick_width
+    world = 2
+    mp.spawn(_worker_lanes, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(os.path.join(str(tmp_path), "l%d.npz" % r)) for r in range(world)]
+    total = got[0]["plane"] + got[1]["plane"]
+    for r in range(world):
+        assert np.array_equal(got[r]["got"], total), r
+        assert int(got[r]["width"]) == 16
+    assert pick_width(2 ** 32, 1, 2) == 64 and pick_width(10, 16384, 2) == 32 and pick_width(10, 16383, 2) == 16
+    assert pick_width(2 ** 31, 5, 2) == 16 and pick_width(2 ** 30, 2 ** 30, 2) == 64 and pick_width(0, 0, 64) == 16

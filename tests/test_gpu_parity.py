@@ -512,6 +512,67 @@ def test_sharded_finalize_on_one_device(oracle, sars_paths, kmer_stats):
     ix.close()
 
 
+@pytest.mark.parametrize("width", [16, 32, 64])
+def test_sharded_finalize_through_the_engine_side_transport(oracle, sars_paths, width):
+    """bk_shard_transport / bk_shard_received (ABI v7): four engines stand for four ranks; every rank's plane is packed by the
+    engine for the wire (16-bit lanes in int32 words, int32, or the plane itself), the reduce-scatter is simulated on the one
+    device (typed wrapping sums of the four send buffers, part r to rank r), the engine widens the received part and
+    bk_sample_finalize_shard maps it -- the planes themselves are never modified.  Result = the oracle's on all reads.  Then a
+    sample with a k-mer count beyond the lane range of width 16 / 4 ranks: packers raise the flag, it travels with the
+    statistics, bk_sample_download refuses on every rank (BK_ERR_RANGE) -- and the same sample at width 32 is the oracle's."""
+    import torch
+    from bronko_amd import BronkoError, pack_reads
+    from bronko_amd.dist import DeviceVector, pick_width
+    world = 4
+    ix = oracle.Index.build(21, sars_paths)
+    gm, isnv = synth.sample_genome(synth.read_fasta_bytes(sars_paths[1]), 13)
+    c1, c2 = synth.paired_codes(gm, 20000, 150, 13, isnv=isnv)
+    mates = [synth.codes_to_ascii(c1), synth.codes_to_ascii(c2)]
+    hot = bytearray(synth.read_fasta_bytes(sars_paths[1])[5000:5150])
+    hot[70] = ord("A") if hot[70] != ord("A") else ord("C")               # one substitution, seen 40,000 times: a V count far above 32767 / 4
+    heavy = [mates[0] + [bytes(hot)] * 40000, mates[1]]
+    engs = [helpers.engine_from_oracle_index(ix) for _ in range(world)]
+    def run(sample, w):
+        for r, e in enumerate(engs):
+            e.sample_begin()
+            for m, reads in enumerate(sample):
+                lo, hi = len(reads) * r // world, len(reads) * (r + 1) // world
+                wd, ln = pack_reads(reads[lo:hi], 21)
+                e.push_reads(m, wd, ln)
+        helpers.sharded_finalize_on_one_device(engs, 2, w)
+
+    pile = oracle.sample_pileup(ix, mates)
+    for rep in range(2):                                                   # (twice: the planes are zeroed at the next sample's first push)
+        run(mates, width)
+        for e in engs:
+            helpers.assert_same_pileup(e.sample_download(2), pile)
+            assert not e.transport_overflow()
+    # what bk_shard_measure says about this sample
+    for e in engs:
+        e.sample_begin()
+        wd, ln = pack_reads(heavy[0], 21)
+        e.push_reads(0, wd, ln)
+    ptrs = [e.shard_measure(0) for e in engs]
+    torch.cuda.synchronize()                                               # (the measuring kernels run on the engines' streams)
+    mx = [torch.as_tensor(DeviceVector(p, 2), device="cuda:0").tolist() for p in ptrs]
+    assert all(40000 <= m[1] <= 40010 for m in mx) and all(m[0] > 0 for m in mx), mx      # (+ the odd sequencing error that recreates the substitution)
+    assert pick_width(max(m[0] for m in mx), 40000, world) == 32 and pick_width(100, 8191, 4) == 16 and pick_width(2 ** 32, 1, 1) == 64
+    if width == 16:
+        run(heavy, 16)
+        for e in engs:
+            with pytest.raises(BronkoError) as ei:
+                e.sample_download(2)
+            assert ei.value.status == -6                                   # BK_ERR_RANGE, on every rank
+            assert not e.transport_overflow()                              # (reported once)
+        run(heavy, 32)
+        want = oracle.sample_pileup(ix, heavy)
+        for e in engs:
+            helpers.assert_same_pileup(e.sample_download(2), want)
+    for e in engs:
+        e.close()
+    ix.close()
+
+
 def test_long_reads_with_indels_and_chimeras(oracle, sars_paths):
     """Reads that leave their seed diagonal: 1000 bp reads (63-word records) with deletions, insertions and chimeric joins of
     both strands.  Level 1 proves what lies on the diagonal of the chosen seed; everything behind an indel / breakpoint is
@@ -675,6 +736,97 @@ def test_config3_full_size_ten_million_pairs(oracle, sars_paths):
     assert oracle.pick_best_genome(ix, full.stats.sum(axis=0), full.present.max(axis=0)) == 2
     fork.close()
     eng.close()
+    ix.close()
+
+
+def test_config4_two_hundred_million_reads(oracle, sars_paths):
+    """BASELINE configs[3] on one GPU: wuhan_ref k = 21, ONE sample of 200,000,000 x 150 bp reads, seed 4, generated on the GPU
+    in 200 batches of 1 M reads (bench.py --config 4's generator; 8.4 GB of records resident) -- 2.6 * 10^10 k-mer occurrences,
+    per-k-mer counts of several 10^5, every push one launch among hundreds.  The oracle cannot follow, so:
+    (a) the first batch alone against the oracle, bit for bit;
+    (b) the whole sample by properties: every k-mer scanned, two push orders on parent and fork identical, nothing shrinks from
+        (a) to the whole sample;
+    (c) the same sample on a fork with cs = 100,000 (kmc -cs, call.rs:1173): depth = min(depth, cs) cell by cell, the cap is
+        reached, #k-mers and statistics unchanged;
+    (d) the sample's reads dealt to four engines standing for four ranks, sharded finalize through the engine-side transport:
+        bk_shard_measure says 32 bits (a quarter of a 16-bit lane does not hold these counts), the result is the whole sample's;
+        forced to 16 bits the packers raise the flag and bk_sample_download refuses on every rank."""
+    import torch
+    from bronko_amd import BronkoError, Params
+    from bronko_amd.dist import DeviceVector, pick_width
+    dev = torch.device("cuda", 0)
+    n, nb = 1000000, 200
+    ix = oracle.Index.build(21, [sars_paths[0]])
+    eng = helpers.engine_from_oracle_index(ix)
+    fork = eng.fork()
+    gm, isnv = synth.sample_genome(synth.read_fasta_bytes(sars_paths[0]), 4)
+    gen = lambda b: synth.single_end_codes_torch(gm, n, 150, 4 * 1000003 + 7919 * b, err=0.005, isnv=isnv, device=dev)   # noqa: E731
+    batches = []
+    for b in range(nb):
+        batches.append(synth.pack_codes_torch(gen(b)))
+    torch.cuda.synchronize()
+
+    def run(e, order):
+        e.sample_begin()
+        for b in order:
+            w, l = batches[b]
+            e.push_reads_device(0, w.data_ptr(), w.shape[1], l.data_ptr(), n)
+        return e.sample_finish(1)
+
+    # (a)
+    pile, _ = oracle.sample_pileup_mt(ix, [synth.BASES[gen(0).to(torch.uint8).cpu().numpy()]], os.cpu_count() or 8)
+    first = run(eng, [0])
+    helpers.assert_same_pileup(first, pile)
+    # (b)
+    full = run(eng, list(range(nb)))
+    other = run(fork, list(reversed(range(nb))))
+    names = ("fwd_depth", "rev_depth", "fwd_nk", "rev_nk", "stats", "present")
+    for name in names:
+        assert np.array_equal(getattr(full, name), getattr(other, name)), name
+    assert int(full.kmer_stats[0, 1]) == nb * n * 130 == 26000000000 and int(full.kmer_stats[0, 0]) == nb * n
+    for name in names[:4]:
+        assert np.all(getattr(full, name) >= getattr(first, name)), name
+    top = int(max(full.fwd_depth.max(), full.rev_depth.max()))
+    assert 200000 < top < 1000000                                          # counts of several 10^5, below kmc's -cs
+    # (c)
+    cs = 100000
+    capped_eng = eng.fork(Params(cs=cs))
+    capped = run(capped_eng, list(range(nb)))
+    for name in ("fwd_depth", "rev_depth"):
+        assert np.array_equal(getattr(capped, name), np.minimum(getattr(full, name), cs)), name
+    assert int(capped.fwd_depth.max()) == cs
+    for name in names[2:]:
+        assert np.array_equal(getattr(capped, name), getattr(full, name)), name
+    capped_eng.close()
+    # (d)
+    engs = [eng, fork, eng.fork(), eng.fork()]
+    for r, e in enumerate(engs):
+        e.sample_begin()
+        for b in range(r, nb, len(engs)):
+            w, l = batches[b]
+            e.push_reads_device(0, w.data_ptr(), w.shape[1], l.data_ptr(), n)
+    ptrs = [e.shard_measure(0) for e in engs]
+    torch.cuda.synchronize()                                               # (the measuring kernels run on the engines' streams)
+    mx = np.array([torch.as_tensor(DeviceVector(p, 2), device=dev).tolist() for p in ptrs]).max(axis=0)
+    assert pick_width(int(mx[0]), int(mx[1]), len(engs)) == 32, mx
+    helpers.sharded_finalize_on_one_device(engs, 1, 32)
+    for e in engs:
+        got = e.sample_download(1)
+        for name in names:
+            assert np.array_equal(getattr(got, name), getattr(full, name)), name
+        assert int(got.kmer_stats[0, 1]) == nb * n * 130 and int(got.kmer_stats[0, 0]) == nb * n
+    for r, e in enumerate(engs):
+        e.sample_begin()
+        for b in range(r, nb, len(engs)):
+            w, l = batches[b]
+            e.push_reads_device(0, w.data_ptr(), w.shape[1], l.data_ptr(), n)
+    helpers.sharded_finalize_on_one_device(engs, 1, 16)
+    for e in engs:
+        with pytest.raises(BronkoError) as ei:
+            e.sample_download(1)
+        assert ei.value.status == -6                                       # BK_ERR_RANGE
+    for e in reversed(engs):
+        e.close()
     ix.close()
 
 

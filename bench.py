@@ -63,8 +63,6 @@ def parse_args():
     ap.add_argument("--allreduce", action="store_true", help="N > 1: all-reduce the counter plane instead of reduce-scatter + sharded finalize")
     ap.add_argument("--width", default="auto", choices=["auto", "16", "32", "64"], help="N > 1: bits per counter on the wire (bk_shard_transport). auto = "
                     "measured during the warm-up (bk_shard_measure), then fixed for the timed region; a width that is too narrow is detected, never silent")
-    ap.add_argument("--share", type=int, default=0, help="bk_engine_set_share: the scans of the engines in flight run side by side on 1/SHARE of the CUs "
-                    "each (0 = the number of engines in flight for configs 2 and 4, else 1 = every scan on the whole chip)")
     ap.add_argument("--no-other-configs", action="store_true", help="config 2 on one GPU: skip the bounded measurements of configs 3 and 5 and the K0 figure")
     ap.add_argument("--in-flight", type=int, default=3, help="samples in flight per GPU (bk_engine_fork: shared index tables, own counter "
                     "planes / outputs / stream); 1 = strictly one sample after the other")
@@ -278,9 +276,6 @@ def measure(wl, args, dev, dist, steps, warmup, sps=None, eng=None, selected_onl
     # the stream.
     n_fly = max(1, args.in_flight)
     engs = [eng] + [eng.fork() for _ in range(n_fly - 1)]
-    share = args.share or 1
-    for e in engs:
-        e.set_share(share)
     streams = [torch.cuda.ExternalStream(e.stream_ptr(), device=dev) for e in engs]
     torch.cuda.set_stream(streams[0])
     sharded = sharded_reads and not args.allreduce
@@ -386,7 +381,6 @@ def measure(wl, args, dev, dist, steps, warmup, sps=None, eng=None, selected_onl
     # sample's turnaround and each kernel's own duration with nothing running next to it -- the figure the roofline object is
     # about (in the timed region a scan shares the CUs with the other samples' kernels).
     n_serial = 3 if bounded else max(2, min(32 if wl.reads_per_sample_rank <= 2000000 else 8, steps * sps))   # (32 short samples: the average of 8 moved by 10 % from run to run)
-    engs[0].set_share(1)
     for i in range(3 if bounded else 8):   # (untimed: the chip settles into running one sample at a time)
         run_sample(i, 0)
     fence()
@@ -436,7 +430,7 @@ def measure(wl, args, dev, dist, steps, warmup, sps=None, eng=None, selected_onl
         "data": "synthetic",
         "config": {"workload": wl.workload, "baseline_config": cfg, "k": k, "read_len": rl, "samples_per_step": sps,
                    "reads_per_sample": wl.reads_per_sample_total, "reads_per_gpu_per_sample": wl.reads_per_sample_rank, "mates": n_mates,
-                   "samples_in_flight": len(engs), "scan_cu_share": share, "resident_input_bytes": wl.resident,
+                   "samples_in_flight": len(engs), "resident_input_bytes": wl.resident,
                    "input": "sequence lines (ASCII) resident in HBM -> K0 pack_reads_kernel -> records" if from_ascii else "2-bit packed records resident in HBM",
                    "pileup_rows": "selected genome only (bk_params.pileup_selected_only)" if selected_only else "every genome (call.rs:1305-1384)",
                    "parallelism": ("single GPU" if world == 1 else

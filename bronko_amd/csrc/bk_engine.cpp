@@ -260,7 +260,6 @@ struct bk_engine {
     DevBuf<uint8_t> prow_t;
     bool ref_in_lds = false;
     int lo_bases = 0, n_cus = 256;
-    int scan_share = 1;                     // bk_engine_set_share: this engine's scans take n_cus / scan_share workgroups
     int device = 0;
 
     DevBuf<bk::KmerPos> kmer_pos;
@@ -1396,13 +1395,6 @@ int bk_engine_set_stream(bk_engine* e, void* hip_stream) {
     return BK_OK;
 }
 
-int bk_engine_set_share(bk_engine* e, int engines_side_by_side) {
-    if (!e) return fail(BK_ERR_INVALID, "null engine");
-    if (engines_side_by_side < 1 || engines_side_by_side > 16) return fail(BK_ERR_INVALID, "1 <= engines_side_by_side <= 16");
-    e->scan_share = engines_side_by_side;
-    return BK_OK;
-}
-
 void* bk_engine_get_stream(const bk_engine* e) { return e ? reinterpret_cast<void*>(e->stream) : nullptr; }
 
 uint64_t bk_total_cells(const bk_engine* e) { return e ? e->total_cells : 0; }
@@ -1554,7 +1546,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.l2_words = bk::scan_l2_words(stride_words, e->k);
     const uint64_t l2_cap = std::max<uint64_t>(64, ((1ull << 30) / sizeof(unsigned int)) / a.l2_words);
     for (uint64_t base = 0; base < n;) {
-        const uint32_t grid = bk::scan_grid(n - base, std::max(e->n_cus / std::max(e->scan_share, 1), std::min(e->n_cus, 16)));
+        const uint32_t grid = bk::scan_grid(n - base, e->n_cus);
         uint64_t take = std::min<uint64_t>(std::min<uint64_t>(n - base, bk::scan_max_records(grid)), l2_cap);
         if (e->max_launch_records) take = std::min<uint64_t>(take, e->max_launch_records);
         if (e->l2_bits.n < take * a.l2_words || e->l2_diag.n < take) {

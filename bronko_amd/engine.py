@@ -170,10 +170,6 @@ class Engine:
         except Exception:
             pass
 
-    def set_share(self, engines_side_by_side):
-        """bk_engine_set_share: this engine's scans take a 1/n share of the CUs (n engines run samples side by side)."""
-        _check(self._L.bk_engine_set_share(self.h, int(engines_side_by_side)), self._L)
-
     def set_stream(self, stream_ptr):
         _check(self._L.bk_engine_set_stream(self.h, C.c_void_p(stream_ptr)), self._L)
 

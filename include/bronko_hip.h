@@ -118,12 +118,6 @@ int  bk_engine_fork(const bk_engine* parent, bk_engine** out);
  * (BK_ERR_INVALID).  E.g. one index, `--min-kmers 3` and `--min-kmers 5` samples side by side. */
 int  bk_engine_fork_params(const bk_engine* parent, const bk_params* params, bk_engine** out);
 
-/* A hint (v7): this engine is one of `engines_side_by_side` engines (a parent and its forks, one sample each) whose samples run at
- * the same time on the device.  Its scan kernel -- one workgroup per CU, it takes a CU's whole LDS -- is then launched on a
- * 1/engines_side_by_side share of the CUs, so that the engines' scans run side by side on disjoint CUs instead of one after the
- * other, each workgroup amortising its set-up over more reads.  Results do not depend on it.  Default 1: the whole chip. */
-int bk_engine_set_share(bk_engine* e, int engines_side_by_side);
-
 /* Launch all work of this engine on an existing HIP stream (hipStream_t passed as void*); NULL restores the
  * engine's own stream.  Lets a host that already owns a stream (e.g. PyTorch's current stream) order and
  * time the engine's kernels. */

@@ -162,6 +162,10 @@ struct IndexView {
                                   // that starts at q is in U and "clean" (see amb); bit 1 = id(q) == id(q-1) + 1
     const uint32_t*  cell_yr;     // ... for a walk against it: bit 0 the same; bit 1 = id(q) == id(q+1) - 1
     const uint32_t*  id_at;       // [total_cells] id of the k-mer starting at cell q (0xffffffff: none)
+    const uint32_t*  cell_fast;   // 1 bit per cell, layout of cell_has: the k-mer that starts at q is in U, "clean", and its id is
+                                  // q + cell_blk[q >> 6].x (modulo 2^32) -- what the scan needs to count an isolated mismatch on the spot
+    const uint2*     cell_blk;    // per block of 64 cells (two entries of padding behind): x = id_at[q] - q of the block's first clean
+                                  // cell; y = the first cell >= 64 * block at which no k-mer of U starts (sequence tails)
     uint32_t total_cells;
     uint32_t n_u;                 // |U| = number of ids
     uint32_t n_full;              // ids < n_full are reference k-mers (W V rows each); the rest are k = 31 pseudo k-mers

@@ -268,7 +268,8 @@ struct bk_engine {
     DevBuf<bk::IdRec> id_rec;
     DevBuf<bk::DirtyAns> dirty_ans;
     DevBuf<uint8_t> cell_flags;
-    DevBuf<uint32_t> ref_words, cell_codes, cell_has, cell_clean, cell_clean3, cell_yf, cell_yr, id_at;
+    DevBuf<uint32_t> ref_words, cell_codes, cell_has, cell_clean, cell_clean3, cell_yf, cell_yr, id_at, cell_fast;
+    DevBuf<uint2> cell_blk;
     struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0, log2p = 0; } half_lo, half_hi;
     DevBuf<unsigned int> deferred, n_deferred;
     DevBuf<unsigned long long> deferred_n;   // dense planes: the deferred k-mers' counts (K2a zeroes the counters it reads)
@@ -290,7 +291,8 @@ struct bk_engine {
     DevBuf<uint8_t> amb;
     DevBuf<uint16_t> pilots;
     DevBuf<unsigned int> slabs;             // [n_cus][n_lds_bins] workgroup histograms of the last scan launch
-    DevBuf<unsigned int> l2_bits;           // scan -> Level 2: one bit per k-mer of each record of a launch (bk_kernels.h ScanArgs), all zero between launches
+    DevBuf<unsigned int> n_bits, n_any;     // scan -> Level 2: one bit per k-mer of each record of a launch / per record (bk_kernels.h ScanArgs): the N runs; all zero between launches
+    DevBuf<unsigned int> l2_bits;           // Level 2's first pass -> its second: the k-mers looked at one by one, same layout
     DevBuf<unsigned int> l2_any;            // ... one bit per record: its row has bits
     DevBuf<uint2> l2_diag;                  // ... and each record's diagonal
     uint64_t kmers_since_fold = 0;
@@ -364,7 +366,7 @@ struct bk_engine {
     bk::IndexView view() const {
         bk::IndexView v{};
         v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb; v.log2p = log2p;
-        v.kmer_of = kmer_of.p; v.id_rec = id_rec.p; v.dirty_ans = dirty_ans.p; v.cell_flags = cell_flags.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_clean3 = cell_clean3.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
+        v.kmer_of = kmer_of.p; v.id_rec = id_rec.p; v.dirty_ans = dirty_ans.p; v.cell_flags = cell_flags.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_clean3 = cell_clean3.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.cell_fast = cell_fast.p; v.cell_blk = cell_blk.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
         v.n_full = n_full; v.n_prows = n_prows; v.prow_id = prow_id.p; v.prow_t = prow_t.p; v.v_omin = v_omin; v.v_span = v_span; v.v_off = v_off;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb, half_lo.log2p};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb, half_hi.log2p};
@@ -976,6 +978,28 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             h_yr[wi] |= (clean | (to_next ? 2u : 0u)) << sh;
         }
 
+        // what the scan needs to count an isolated mismatch on the spot (bk_device.h cell_fast / cell_blk): per block of 64 cells the
+        // constant id - cell of its clean cells and the end of the stretch of cells that carry a reference k-mer
+        std::vector<uint32_t> h_fast(h_has.size(), 0u);
+        std::vector<uint2> h_blk((cells + 63) / 64 + 3, make_uint2(0u, (uint32_t)cells));
+        {
+            uint32_t next_none = (uint32_t)cells;
+            for (uint64_t c = cells; c-- > 0;) {
+                if (h_id_at[c] == kNone) next_none = (uint32_t)c;
+                if ((c & 63) == 0) h_blk[c >> 6].y = next_none;
+            }
+            for (uint64_t c = 0; c < cells; c++) {
+                if (!(h_cflags[c] & bk::kCellClean)) continue;
+                const uint32_t delta = h_id_at[c] - (uint32_t)c;
+                uint2& b = h_blk[c >> 6];
+                if (b.x == 0u && delta != 0u) {   // (0 is also "not set yet": a block whose first clean cell has delta 0 keeps it)
+                    bool first = true;
+                    for (uint64_t q = (c >> 6) << 6; q < c; q++) if (h_cflags[q] & bk::kCellClean) { first = false; break; }
+                    if (first) b.x = delta;
+                }
+                if (delta == b.x) h_fast[bpad_w + (c >> 5)] |= 1u << (c & 31);
+            }
+        }
         pc.lap("per-cell arrays");
         // ---- dirty answers (bk_device.h DirtyAns): for every reference k-mer with a cell that is not clean, what "this k-mer with
         // base bb at position j" is -- worked out from its near list (every reference k-mer form within Hamming distance 2: a
@@ -1144,6 +1168,8 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         BK_HIP(e->cell_clean3.upload(h_clean3));
         BK_HIP(e->cell_yf.upload(h_yf));
         BK_HIP(e->cell_yr.upload(h_yr));
+        BK_HIP(e->cell_fast.upload(h_fast));
+        BK_HIP(e->cell_blk.upload(h_blk));
         BK_HIP(e->cell_codes.upload(h_codes));
         BK_HIP(e->cell_flags.upload(h_cflags));
         BK_HIP(e->id_at.upload(h_id_at));
@@ -1309,11 +1335,12 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         if (const char* rl = test_env("BK_REF_IN_LDS")) e->ref_in_lds = atoi(rl) != 0;
         uint64_t nb = std::min<uint64_t>(e->total_cells, budget / sizeof(unsigned int));
         if (e->ref_in_lds) {
-            nb = std::min<uint64_t>(e->total_cells, budget * 8 / 35);   // 4.375 bytes per cell ...
+            nb = std::min<uint64_t>(e->total_cells, budget * 32 / 141);   // 4 + 1/4 + 1/8 + 1/32 bytes per cell ...
             while (nb > 0 && nb * sizeof(unsigned int) + bk::scan_ref_lds_bytes((uint32_t)nb) > budget) nb -= std::min<uint64_t>(nb, 64);   // ... and the paddings
         }
         e->n_lds_bins = (uint32_t)nb;
         if (const char* nl = test_env("BK_LDS_BINS")) e->n_lds_bins = std::min<uint32_t>(e->n_lds_bins, (uint32_t)atol(nl));
+        if (e->n_lds_bins < e->total_cells) e->n_lds_bins &= ~63u;   // (a window is a whole number of 64-cell blocks unless it holds everything)
     }
     pc.lap("estat + LDS policy");
 
@@ -1355,6 +1382,7 @@ int bk_engine_fork_params(const bk_engine* parent, const bk_params* prm, bk_engi
     e->prow_id.alias(p->prow_id); e->prow_t.alias(p->prow_t); e->kmer_pos.alias(p->kmer_pos); e->d_view.alias(p->d_view); e->kmer_of.alias(p->kmer_of); e->id_rec.alias(p->id_rec); e->dirty_ans.alias(p->dirty_ans); e->cell_flags.alias(p->cell_flags);
     e->ref_words.alias(p->ref_words); e->cell_codes.alias(p->cell_codes); e->cell_has.alias(p->cell_has); e->cell_clean.alias(p->cell_clean);
     e->cell_clean3.alias(p->cell_clean3); e->cell_yf.alias(p->cell_yf); e->cell_yr.alias(p->cell_yr); e->id_at.alias(p->id_at);
+    e->cell_fast.alias(p->cell_fast); e->cell_blk.alias(p->cell_blk);
     e->half_lo.pilots.alias(p->half_lo.pilots); e->half_lo.dir.alias(p->half_lo.dir); e->half_lo.cand.alias(p->half_lo.cand);
     e->half_hi.pilots.alias(p->half_hi.pilots); e->half_hi.dir.alias(p->half_hi.dir); e->half_hi.cand.alias(p->half_hi.cand);
     e->slot_of.alias(p->slot_of); e->estat_off.alias(p->estat_off); e->estat.alias(p->estat); e->slot_rec.alias(p->slot_rec); e->amb.alias(p->amb);
@@ -1503,7 +1531,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.n_records_dev = n_records_dev;
     a.ixp = e->d_view.p;
     a.k = e->k; a.wstart = e->wstart; a.W = e->W; a.v_omin = e->v_omin; a.v_span = e->v_span; a.v_off = e->v_off; a.total_cells = (uint32_t)e->total_cells; a.n_u = e->n_u;
-    a.ref_words = e->ref_words.p; a.cell_codes = e->cell_codes.p; a.cell_has = e->cell_has.p; a.cell_clean = e->cell_clean.p; a.cell_clean3 = e->cell_clean3.p; a.cell_yf = e->cell_yf.p; a.cell_yr = e->cell_yr.p; a.id_at = e->id_at.p;
+    a.ref_words = e->ref_words.p; a.cell_codes = e->cell_codes.p; a.cell_has = e->cell_has.p; a.cell_clean = e->cell_clean.p; a.cell_clean3 = e->cell_clean3.p; a.cell_yf = e->cell_yf.p; a.cell_yr = e->cell_yr.p; a.id_at = e->id_at.p; a.cell_fast = e->cell_fast.p; a.cell_blk = e->cell_blk.p;
     a.words = d_words; a.lens = d_lens; a.n_records = n; a.stride_words = stride_words;
     a.counters = e->counters[mate].p;
     a.kmer_total = e->kstats.p + mate * 4 + 1;
@@ -1553,12 +1581,16 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
             BK_HIP(hipStreamSynchronize(e->stream));
             const uint64_t recs = std::min<uint64_t>(std::max<uint64_t>(take + take / 4, 1 << 16), l2_cap);
             BK_HIP(e->l2_bits.alloc((size_t)recs * a.l2_words));
+            BK_HIP(e->n_bits.alloc((size_t)recs * a.l2_words));
             BK_HIP(e->l2_diag.alloc((size_t)recs));
             BK_HIP(e->l2_any.alloc((size_t)(recs + 31) / 32));
+            BK_HIP(e->n_any.alloc((size_t)(recs + 31) / 32));
             BK_HIP(hipMemsetAsync(e->l2_bits.p, 0, e->l2_bits.n * sizeof(unsigned int), e->stream));
             BK_HIP(hipMemsetAsync(e->l2_any.p, 0, e->l2_any.n * sizeof(unsigned int), e->stream));
+            BK_HIP(hipMemsetAsync(e->n_bits.p, 0, e->n_bits.n * sizeof(unsigned int), e->stream));
+            BK_HIP(hipMemsetAsync(e->n_any.p, 0, e->n_any.n * sizeof(unsigned int), e->stream));
         }
-        a.l2_bits = e->l2_bits.p; a.l2_diag = e->l2_diag.p; a.l2_any = e->l2_any.p;
+        a.l2_bits = e->l2_bits.p; a.l2_diag = e->l2_diag.p; a.l2_any = e->l2_any.p; a.n_bits = e->n_bits.p; a.n_any = e->n_any.p;
         a.rec_base = base; a.n_records = take;
         {
             bk_engine::Span sp(e, 0);
@@ -1569,18 +1601,18 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
             // the k-mers the scan left marked (it clears the marks it takes)
             if (test_env("BK_L2_COUNT")) {   // debugging aid: how much is left to Level 2
                 std::vector<unsigned int> hb((size_t)take * a.l2_words), ha((size_t)(take + 31) / 32);
-                BK_HIP(hipMemcpyAsync(hb.data(), e->l2_bits.p, hb.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));
-                BK_HIP(hipMemcpyAsync(ha.data(), e->l2_any.p, ha.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));
+                BK_HIP(hipMemcpyAsync(hb.data(), e->n_bits.p, hb.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));
+                BK_HIP(hipMemcpyAsync(ha.data(), e->n_any.p, ha.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));
                 BK_HIP(hipStreamSynchronize(e->stream));
                 uint64_t nk = 0, nr = 0, runs = 0;
                 for (size_t i = 0; i < hb.size(); i++) { nk += (uint64_t)__builtin_popcount(hb[i]); runs += (uint64_t)__builtin_popcount(hb[i] & ~(hb[i] << 1)); }
                 for (unsigned int w : ha) nr += (uint64_t)__builtin_popcount(w);
-                fprintf(stderr, "[bk] level 2: %llu of %llu records marked, %llu k-mers in %llu runs (per 32-bit word)\n", (unsigned long long)nr,
+                fprintf(stderr, "[bk] left to level 2 by the scan: %llu of %llu records marked, %llu k-mers in %llu N runs (per 32-bit word)\n", (unsigned long long)nr,
                         (unsigned long long)take, (unsigned long long)nk, (unsigned long long)runs);
             }
             if (e->ablate == 1 || e->ablate == 4) {   // measurement aids: without Level 2
-                BK_HIP(hipMemsetAsync(e->l2_bits.p, 0, (size_t)take * a.l2_words * sizeof(unsigned int), e->stream));
-                BK_HIP(hipMemsetAsync(e->l2_any.p, 0, e->l2_any.n * sizeof(unsigned int), e->stream));
+                BK_HIP(hipMemsetAsync(e->n_bits.p, 0, (size_t)take * a.l2_words * sizeof(unsigned int), e->stream));
+                BK_HIP(hipMemsetAsync(e->n_any.p, 0, e->n_any.n * sizeof(unsigned int), e->stream));
             }
             else BK_HIP(bk::launch_level2(a, e->n_cus, e->stream));
             // per-cell bin slabs -> u64 plane
@@ -1856,6 +1888,7 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             fprintf(stderr, "[bk] sparse finalize (mate file 0): %u V rows of %llu, %u pseudo rows of %llu, %u reference k-mers of %u and %u pseudo k-mers of %u touched\n",
                     nl[0], (unsigned long long)bk::v_real_rows(e->n_full, e->v_span), nl[4], (unsigned long long)e->n_prows, nl[2], e->n_full, nl[3], e->n_u - e->n_full);
         }
+        fprintf(stderr, "[bk] scan: %llu mismatches counted, %llu items processed, %llu E gaps before a mismatch, %llu behind the last\n", h[23], h[24], h[25], h[26]);
         fprintf(stderr, "[bk] scan N batches: %llu with %llu pieces (%.1f per batch), %llu of them forced by a tile's end\n", h[20], h[21], h[20] ? (double)h[21] / (double)h[20] : 0.0, h[22]);
         fprintf(stderr, "[bk] scan marked: no-diagonal %llu, dirty-head %llu, clean-head %llu, pairs %llu | level 2: k-mers %llu in %llu chunks, simple %llu, dead %llu, "
                 "dirty answers %llu (one difference but id unknown: %llu), slow %llu (diffs 0/1/2/3+ with a diagonal: %llu/%llu/%llu/%llu) -> member %llu, neighbour %llu, nothing %llu\n",

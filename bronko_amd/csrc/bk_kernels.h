@@ -21,6 +21,8 @@ struct ScanArgs {
     const uint32_t* cell_yf;        // IndexView::cell_yf / cell_yr (same padding) / id_at
     const uint32_t* cell_yr;
     const uint32_t* id_at;
+    const uint32_t* cell_fast;      // IndexView::cell_fast (1 bit per cell, padded like cell_has) / cell_blk (one entry per 64 cells)
+    const uint2* cell_blk;
     const uint32_t* words;          // [n_records][stride_words] 2-bit packed, 16 bases per word, LSB first
     const uint16_t* lens;           // [n_records] valid bases
     uint64_t rec_base;              // this launch covers records [rec_base, rec_base + n_records)
@@ -29,10 +31,16 @@ struct ScanArgs {
     uint32_t stride_words;
     unsigned long long* counters;   // u64 plane [E | V] (bk_device.h)
     unsigned int* slabs;            // [grid][n_lds_bins] packed (rc<<16 | fwd) per-cell bins of each workgroup
-    // Level 2's work list, per launch: one bit per k-mer of each record (set by the scan, taken and cleared by
-    // launch_level2) and each record's diagonal
-    unsigned int* l2_bits;          // [n_records][l2_words], all zero between launches
-    unsigned int* l2_any;           // [ceil(n_records / 32)] bit per record: some bit of its row is set; all zero between launches
+    // Level 2's work lists, per launch: one bit per k-mer of each record and one bit per record that has any -- all zero between
+    // launches (launch_level2 clears what it takes) -- and the diagonal of every marked record.
+    //   n_bits / n_any   set by the scan: the k-mers of the N runs it does not settle itself (several mismatches in reach of each
+    //                    other, cells that are not "fast", reads off the LDS window or without a diagonal); level2's first pass
+    //                    resolves them run by run (S runs, dead pairs) and marks what is left in
+    //   l2_bits / l2_any the k-mers that are looked at one by one (level2's second pass).
+    unsigned int* n_bits;           // [n_records][l2_words]
+    unsigned int* n_any;            // [ceil(n_records / 32)]
+    unsigned int* l2_bits;          // [n_records][l2_words]
+    unsigned int* l2_any;           // [ceil(n_records / 32)]
     uint2* l2_diag;                 // [n_records] {cell of the reference k-mer aligned with read k-mer 0, bit 0 same strand | bit 1 known}
     uint32_t l2_words;              // = scan_l2_words(stride_words, k)
     uint32_t n_lds_bins;            // exact hits at cells [win_lo, win_lo + n_lds_bins) are counted in LDS

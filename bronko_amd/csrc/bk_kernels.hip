@@ -22,6 +22,9 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 #include "bk_device.h"
 #include "bk_kernels.h"
@@ -316,27 +319,29 @@ void launch_ktab_stats(const unsigned long long* keys, const unsigned int* cnt, 
 // Persistent workgroups of 16 waves (one per CU: the LDS arrays take most of the CU's 160 KB); each wave takes
 // tiles of 64 records, one record per lane.  Nothing is counted k-mer by k-mer unless it has to be.
 //
-// Level 1 -- word-parallel verification along a diagonal.  A few seed k-mers of the read (evenly spaced, looked
-// up in the perfect hash of U; a second round at the midpoints for the rare read whose seeds all carry an error)
-// give its diagonal: read k-mer s <-> reference cell dg + s (same strand) or dg - s (opposite strand).  Then, 32
-// bases at a time, the read words are XORed with the reference words aligned to them (packed reference in LDS,
-// funnel shifts; reversed and complemented for the opposite strand) and folded to one mismatch flag per base.  A
-// k-step shift-and-or over the flag history says, for the 32 k-mers that end in these words at once, whether their
-// window holds a mismatch; with one per-cell bit from LDS ("a reference k-mer starts here") every k-mer is
-//   E  exact      no mismatch, a reference k-mer starts at the cell: the read k-mer IS that reference k-mer;
-//   N  not        everything else.
-// Consecutive k-mers of one kind form a run.
-//   E run   cells c0..c1 each seen once more in this read's direction: +1 at c0, -1 at c1 + 1 in a per-cell
-//           DIFFERENCE array in LDS (low half-word: reads along the reference, high half-word: against it).  The
-//           workgroup turns it into per-cell counts with one prefix sum at the end (epilogue) and writes them as a
-//           slab; fold adds slab cell c into E[id_at[c]] (orientation = the cell's, flipped for the high half).
-//   N run   queued (lane, first k-mer, length) in pieces of <= 65 - k k-mers -- a piece lies in 64 read bases -- and done
-//           64 pieces at a time, one per lane ("N batch", see there): the k-mers that cover one mismatch and nothing
-//           else are an S run -- one row of the V plane (bk_device.h), +1 at the first offset, -1 after the last,
-//           whatever the length; what the N batch cannot settle is marked for Level 2 (level2_kernel): one bit per
-//           k-mer in l2_bits[record], one bit per record in l2_any.
-// Reads without a usable diagonal (no seed hit, diagonal leaving the reference, cells beyond the LDS array) are N
-// runs as a whole.
+// Diagonal.  A few seed k-mers of the read (evenly spaced, looked up in the perfect hash of U; a second round at the
+// midpoints for the rare read whose seeds all carry an error) give its diagonal: read k-mer s <-> reference cell dg + s
+// (same strand) or dg - s (opposite strand).
+// Mismatches.  160 bases at a time (a whole 150 bp read), the read words are XORed with the reference words aligned to
+// them (packed reference in LDS, funnel shifts; reversed and complemented for the opposite strand) and folded to one
+// mismatch flag per base.  Everything else follows from the flags, mismatch by mismatch (a loop of as many passes as the
+// lane with the most mismatches needs -- three or four per tile at 0.5 % errors):
+//   E run   the k-mers between two mismatches (more than k apart) hold none: they ARE the reference k-mers of their cells.
+//           Cells c0..c1 each seen once more in this read's direction: +1 at c0, -1 at c1 + 1 in a per-cell DIFFERENCE array
+//           in LDS (low half-word: reads along the reference, high half-word: against it).  The workgroup turns it into
+//           per-cell counts with one prefix sum at the end (epilogue) and writes them as a slab; fold adds slab cell c into
+//           E[id_at[c]] (orientation = the cell's, flipped for the high half).
+//   S run   a mismatch with no other within k - 1 bases on either side: the up to k k-mers that hold it hold nothing else.
+//           If all their cells are "fast" (IndexView::cell_fast: clean, ids = cell + one constant) they are one row of the V
+//           plane (bk_device.h): +1 at the first offset, -1 after the last, whatever the run's length -- two global atomics,
+//           no table is read.
+//   N run   everything else -- mismatches in reach of each other, cells that are not fast, reads off the LDS window or
+//           without a diagonal: the run's k-mers are marked in n_bits[record] (one bit per k-mer, one bit per record in n_any)
+//           and resolved by level2_kernel, which takes them run by run first and k-mer by k-mer for what that leaves.
+// Until round 3 this kernel also queued the N runs in LDS and resolved them itself, 64 at a time ("N batch"), and told E
+// from N k-mer by k-mer (a k-step shift-or over the flags, then one pass per run boundary): 2400 VALU instructions per tile
+// and a dependent chain of global loads per batch against 1000 now; the batch code lives on in level2_kernel, where it
+// sees a tenth of the runs.
 //
 // LDS difference array: one 32-bit word per cell, value = (runs starting - runs ending) of reads along the
 // reference + 65536 * the same for reads against it, modulo 2^32.  The prefix sum S_c = F_c + 65536 R_c is exact
@@ -350,16 +355,14 @@ void launch_ktab_stats(const unsigned long long* keys, const unsigned int* cnt, 
 // global memory instead (REF_LDS = false).
 constexpr int kScanBlock = 1024;
 constexpr int kScanWaves = kScanBlock / 64;
-constexpr int kRangeCap = 128;              // N queue: a batch starts at 64 pending, a round adds <= 64
-constexpr int kNIters = 8;                  // mismatches of a piece the N batch resolves in one pass
+constexpr int kNIters = 8;                  // mismatches of a piece the N batch (level2_kernel) resolves in one pass
 constexpr uint32_t kMaxRecordsPerGroup = 16384;
 constexpr int kSeeds = 4;
 constexpr int kRefPadWords = 4;             // words of padding in front of the 2-bit per-cell arrays (64 cells)
 constexpr int kRefBackWords = 6;            // ... and behind them (96 cells)
 constexpr int kBitPadWords = 2;             // the same 64 cells for the 1-bit per-cell arrays
 constexpr int kBitBackWords = 3;
-constexpr size_t kRangeBytes = (size_t)kScanWaves * kRangeCap * sizeof(unsigned int);
-constexpr size_t kScanLdsFixed = kRangeBytes + 16 + 64;
+constexpr size_t kScanLdsFixed = 16 + 64 + 4 * kScanBlock + 8;   // k-mer tally, wave totals of the epilogue, the item owners, alignment of the block entries
 
 // number of set bits of a wave mask below this lane
 __device__ __forceinline__ uint32_t lane_prefix(unsigned long long m) {
@@ -527,58 +530,71 @@ struct SlowPipe {
     }
 };
 
-// KT: k as a compile-time constant for the common sizes (the window loop of Level 1 unrolls), 0 = any k
+// KT: k as a compile-time constant for the common sizes, 0 = any k
 // SPARSE: the V rows written are noted in ScanArgs::touch_v (sparse finalize of a large index)
-template <bool REF_LDS, bool STATS, int KT, bool SPARSE>
+template <bool REF_LDS, int KT, bool SPARSE>
 __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned int* range_s = reinterpret_cast<unsigned int*>(smem);
-    unsigned int* block_kmers = reinterpret_cast<unsigned int*>(smem + kRangeBytes);   // 16 B reserved
+    unsigned int* block_kmers = reinterpret_cast<unsigned int*>(smem);   // 16 B reserved
     unsigned int* scan_tmp = block_kmers + 4;       // 16 words: wave totals of the epilogue's prefix sum
-    unsigned int* bins = scan_tmp + 16;             // [n_lds_bins + 1] the per-cell difference array
-    unsigned int* lds_ref = bins + a.n_lds_bins + 1;   // REF_LDS: padded ref words, then the padded bit array
+    unsigned int* own_all = scan_tmp + 16;          // [16 waves][64] which lane owns each of the items of a pass (below)
+    unsigned int* bins = own_all + kScanBlock;      // [n_lds_bins + 1] the per-cell difference array
+    unsigned int* lds_ref = bins + a.n_lds_bins + 1;   // REF_LDS: padded ref words, the padded fast-bit array, the block entries
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform by construction: tell the compiler
-    unsigned int* const rqs = range_s + wave * kRangeCap;
+    unsigned int* const own_s = own_all + wave * 64;
 
     const uint32_t total = a.total_cells;
-    // Level 1 only ever looks at cells below n_lds_bins (a read whose diagonal leaves them goes to Level 2 as a whole), so
-    // that is all the LDS copies of the per-cell arrays hold: front pad, the first n_lds_bins cells, back pad
-    // the LDS window: chosen on the device for a multi-genome index (choose_window_kernel), else the engine's constant
+    // the LDS window (a multiple of 64 cells from the start): chosen on the device for a multi-genome index
+    // (choose_window_kernel), else the engine's constant.  The scan only ever settles reads whose cells all lie in it, so that is
+    // all the LDS copies of the per-cell arrays hold: front pad, the window's cells, back pad
     const uint32_t win_lo = a.win_dev ? a.win_dev[1] : a.win_lo;
     const uint32_t win_file = a.win_dev ? a.win_dev[0] : (uint32_t)a.win_file;
     const uint32_t lds_cells = min(total - win_lo, a.n_lds_bins);
     const uint32_t n_refw = kRefPadWords + (lds_cells + 15) / 16 + kRefBackWords;
     const uint32_t n_bitw = kBitPadWords + (lds_cells + 31) / 32 + kBitBackWords;
+    const uint32_t n_blk = (lds_cells + 63) / 64 + 2;
+    const uint32_t blk_w0 = (a.n_lds_bins + 1 + n_refw + 2u * n_bitw + 1u) & ~1u;   // (8-byte aligned: smem + 4176 bytes + 4 * blk_w0)
     for (uint32_t i = threadIdx.x; i <= a.n_lds_bins; i += kScanBlock) bins[i] = 0u;
     if (REF_LDS) {
         for (uint32_t i = threadIdx.x; i < n_refw; i += kScanBlock) lds_ref[i] = a.ref_words[(win_lo >> 4) + i];
-        for (uint32_t i = threadIdx.x; i < n_bitw; i += kScanBlock) lds_ref[n_refw + i] = a.cell_has[(win_lo >> 5) + i];
+        for (uint32_t i = threadIdx.x; i < n_bitw; i += kScanBlock) lds_ref[n_refw + i] = a.cell_fast[(win_lo >> 5) + i];
+        for (uint32_t i = threadIdx.x; i < n_bitw; i += kScanBlock) lds_ref[n_refw + n_bitw + i] = a.cell_clean3[(win_lo >> 5) + i];
+        for (uint32_t i = threadIdx.x; i < 2 * n_blk; i += kScanBlock) bins[blk_w0 + i] = reinterpret_cast<const uint32_t*>(a.cell_blk + (win_lo >> 6))[i];
     }
     __syncthreads();
-    // Level 1's arrays: symbol / bit 0 is cell win_lo; negative positions down to -64 are readable (padding or earlier cells)
+    // symbol / bit 0 is cell win_lo; negative positions down to -64 are readable (padding or earlier cells)
     const unsigned int* refw1 = (REF_LDS ? lds_ref : a.ref_words + (win_lo >> 4)) + kRefPadWords;
-    const unsigned int* hasw = (REF_LDS ? lds_ref + n_refw : a.cell_has + (win_lo >> 5)) + kBitPadWords;
-    const unsigned int* refw = a.ref_words + kRefPadWords;   // the batches: any cell, symbol 0 = cell 0 (global, cached)
-    const unsigned int* yfw = a.cell_yf + kRefPadWords;   // batches only (global memory, L1 / L2 cached)
-    const unsigned int* yrw = a.cell_yr + kRefPadWords;
-    const unsigned int* c3w = a.cell_clean3 + kBitPadWords;
+    const unsigned int* fastw = (REF_LDS ? lds_ref + n_refw : a.cell_fast + (win_lo >> 5)) + kBitPadWords;
+    const unsigned int* c3w = (REF_LDS ? lds_ref + n_refw + n_bitw : a.cell_clean3 + (win_lo >> 5)) + kBitPadWords;
+    const uint2* blkw = REF_LDS ? reinterpret_cast<const uint2*>(bins + blk_w0) : a.cell_blk + (win_lo >> 6);   // entry 0 = the block of cell win_lo
 
     const int k = KT ? KT : a.k;
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;  // k <= 31
     const uint32_t km1 = (uint32_t)k - 1u;
-    const uint32_t piece = 65u - (uint32_t)k;                       // most k-mers of an N run the N batch looks at together (64 bases)
     const int omin = a.v_omin, span = a.v_span;
     unsigned long long* const v_counters = a.counters + a.v_off;
     const uint32_t last_word = a.stride_words - 1u;
 
     uint32_t nkm = 0;  // k-mer occurrences of this lane's records
-    uint32_t qs = 0;   // wave-uniform: fill of the N queue
     const IndexView& ix = *a.ixp;
-    // k-mers [s, s + n) of record `rec` (index within this launch) are left to Level 2: set their bits
-    // (the record's diagonal goes with the mark: Level 2 reads l2_diag only for marked records, so nothing is written for
-    // the others -- about one record in eight on the benchmark has a mark)
+    // k-mers [sk, sk + n) of record `rec` (index within this launch) are an N run left to level2_kernel: set their bits (the
+    // record's diagonal goes with the mark: nothing is written for the records without one)
+    auto n_mark = [&](bool on, uint32_t rec, uint32_t sk, uint32_t n, int32_t dgm, uint32_t flm) {
+        if (!on) return;
+        unsigned int* row = a.n_bits + (size_t)rec * a.l2_words;
+        atomicOr(a.n_any + (rec >> 5), 1u << (rec & 31u));
+        a.l2_diag[rec] = make_uint2((uint32_t)dgm, flm);
+        uint32_t w = sk >> 5, bit = sk & 31u, left = n;
+        while (left) {
+            const uint32_t take = min(left, 32u - bit);
+            atomicOr(row + w, (take == 32u ? 0xffffffffu : (1u << take) - 1u) << bit);
+            left -= take; ++w; bit = 0u;
+        }
+    };
+
+    // ... or, one by one, to its second pass (l2_bits): the k-mers that hold two mismatches and cannot be discarded
     auto l2_mark = [&](bool on, uint32_t rec, uint32_t sk, uint32_t n, int32_t dgm, uint32_t flm) {
         if (!on) return;
         unsigned int* row = a.l2_bits + (size_t)rec * a.l2_words;
@@ -591,6 +607,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
             left -= take; ++w; bit = 0u;
         }
     };
+    const bool stats = a.ktab_keys != nullptr;   // full_kmer_stats: k-mers that touch nothing are still wanted by the statistics table (level2_kernel)
 
     uint64_t n_records = a.n_records;
     if (a.n_records_dev) {
@@ -600,23 +617,13 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     const uint32_t* const words0 = a.words + a.rec_base * a.stride_words;
     const uint16_t* const lens0 = a.lens + a.rec_base;
     const uint64_t n_tiles = (n_records + 63) / 64;
-
-    // per-lane state of the current and of the previous tile (queued runs name their record by lane and tile parity)
-    uint32_t r32 = 0, pr32 = 0;         // record index within this launch (a launch has < 2^32 records)
-    int32_t dg = 0, pdg = 0;            // cell of the reference k-mer aligned with read k-mer 0: k-mer s <-> dg + s (fwd) / dg - s
-    uint32_t dfl = 0, pdfl = 0;         // bit 0: same strand as the reference; bit 1: the diagonal is known ("seeded")
-    uint32_t parity = 0;                // wave-uniform: parity of the current tile
     uint32_t pf_sink = 0;               // destination of the prefetch loads (never read)
-    uint32_t olds = 0;                  // wave-uniform: queued N pieces that belong to the previous tile
+    constexpr uint32_t kNoPos = 0x40000000u;
 
-    for (uint64_t tile = (uint64_t)blockIdx.x * kScanWaves + wave;; tile += (uint64_t)gridDim.x * kScanWaves) {
-        const bool fin = tile >= n_tiles;   // one empty tile after the last: it flushes the queues
-        pr32 = r32; pdg = dg; pdfl = dfl;
-        parity ^= 1u;
-        olds = qs;
+    for (uint64_t tile = (uint64_t)blockIdx.x * kScanWaves + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * kScanWaves) {
         const uint64_t r = tile * 64 + lane;
-        const bool live = !fin && r < n_records;
-        r32 = live ? (uint32_t)r : 0u;
+        const bool live = r < n_records;
+        const uint32_t r32 = live ? (uint32_t)r : 0u;   // record index within this launch (a launch has < 2^32 records)
         uint32_t len = live ? (uint32_t)lens0[r32] : 0u;
         if (len < (uint32_t)k) len = 0u;   // no k-mer
         uint32_t maxlen = len;
@@ -624,7 +631,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
         for (int off = 32; off; off >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, off));
         maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxlen);
         const uint32_t* __restrict__ w = words0 + (uint64_t)r32 * a.stride_words;
-        nkm += len ? len - km1 : 0u;
+        const uint32_t nk = len ? len - km1 : 0u;   // k-mers of the record
+        nkm += nk;
         {   // touch the next tile's records (one lane per 128-byte line) so that its seed loads find them in cache
             const uint64_t nt = tile + (uint64_t)gridDim.x * kScanWaves;
             const uint64_t first = nt * 64ull * a.stride_words, words_tile = 64ull * a.stride_words;
@@ -632,16 +640,17 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
             if (nt < n_tiles && (uint64_t)lane * 32ull < words_tile && at < n_records * a.stride_words)
                 asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink) : "v"(words0 + at) : "memory");
         }
+        if (!maxlen) continue;
 
         // ---- seeds -> diagonal ----------------------------------------------------------------------------------
-        bool fwd = true, seeded = false, l1ok = false;   // seeded: diagonal known; l1ok: ... and all its cells are in the LDS array
-        dg = 0;
+        bool fwd = true, seeded = false, l1ok = false;   // seeded: diagonal known; l1ok: ... and all its cells are in the LDS window
+        int32_t dg = 0;                                  // cell of the reference k-mer aligned with read k-mer 0: k-mer s <-> dg + s (fwd) / dg - s
         // round 0: kSeeds k-mers evenly spaced from the first to the last; round 1, only when some lane found nothing (an
         // error in every seed: one read in 10^4 at 0.5 % errors): the midpoints between them.  A read without a diagonal costs
         // ~100 slow-path searches, so the rare second round pays.  (Two seeds per round and more rounds -- 2.95 lookups per read
         // instead of 4.02 -- was measured in round 2 and is slower, 0.155 against 0.139 ms: half of the tiles then pay a second
         // chain of dependent loads; the seeds are latency, not instructions.)
-        for (int round = 0; round < 2 && maxlen; ++round) {
+        for (int round = 0; round < 2 && !BK_ABLATE(a, 9); ++round) {   // (9: no seeds at all, 7: nothing behind them, 6: no mismatch loop)
             if (round == 1 && !__ballot(len != 0u && !seeded)) break;
             const bool had = seeded;   // round 1 is for the lanes round 0 left without a diagonal
             uint64_t sc[kSeeds];
@@ -687,252 +696,192 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                     const int64_t d0 = f ? (int64_t)scell - (int64_t)s : (int64_t)scell + (int64_t)s;
                     const int64_t lo_cell = f ? d0 : d0 - (int64_t)(len - (uint32_t)k);
                     const int64_t hi_cell = f ? d0 + (int64_t)(len - (uint32_t)k) : d0;
-                    // the whole read must lie on the reference (hi_cell + k <= total); Level 1 also needs its cells in LDS
+                    // the whole read must lie on the reference (hi_cell + k <= total); to be settled here its cells must lie in the
+                    // LDS window and each of them must carry a reference k-mer (no sequence tail in between: cell_blk)
                     if (lo_cell >= 0 && hi_cell + k <= (int64_t)total) {
                         best_cell = scell; dg = (int32_t)d0; fwd = f; seeded = true;
                         l1ok = lo_cell >= (int64_t)win_lo && hi_cell < (int64_t)win_lo + (int64_t)a.n_lds_bins;
+                        if (l1ok) l1ok = (uint32_t)hi_cell < blkw[((uint32_t)lo_cell >> 6) - (win_lo >> 6)].y;
                     }
                 }
             }
         }
-        dfl = (fwd ? 1u : 0u) | (seeded ? 2u : 0u);
+        const uint32_t dfl = (fwd ? 1u : 0u) | (seeded ? 2u : 0u);
+        if (BK_ABLATE(a, 9) || BK_ABLATE(a, 7)) continue;
+        // a read that cannot be settled here is one N run
+        n_mark(nk != 0u && !l1ok, r32, 0u, nk, dg, dfl);
 
-        // ---- Level 1 / batches: a state machine, all control flow wave-uniform --------------------------------------
-        uint32_t i0 = 0;                // first base of the next Level-1 step (32 bases)
-        uint32_t xn0 = len ? w[0] : 0u, xn1 = len > 16u ? w[1] : 0u;   // the next two read words (loaded a step ahead)
-        uint32_t h_lo = 0xffffffffu, h_hi = 0xffffffffu;   // mismatch flags of the last 64 bases, newest 32 in h_hi
-        uint32_t run_start = 0;         // first k-mer of the lane's open run
-        uint32_t run_type = 0;          // its kind: 0 none, 1 E, 2 N
-        uint32_t pe = 0, pn = 0;        // kind bits of the last k-mer of the previous word (bit 0)
-        uint32_t E32 = 0, N32 = 0, Bd = 0;   // last word: kind of the k-mer of each step, steps where a new run starts
-        uint32_t tw_i0 = 0;             // wave-uniform: first base of that word
-        bool pend = false;              // wave-uniform: some lane still has run boundaries to process
-        bool words_done = maxlen == 0u;
-        for (;;) {
-            const bool flush = !pend && words_done;
-            if (qs >= 64u || (flush && (fin ? qs != 0u : olds != 0u))) {
-                // ================= N batch: one queued piece of an N run per lane (qg < 64 here) ====================
-                // The piece's n <= 65 - k k-mers lie in 64 read bases.  Its leading k-mers whose cells are clean and continue one
-                // id sequence are resolved here, mismatch by mismatch (t_1 < t_2 < ...): the k-mers that hold only t_i are an S
-                // run (two atomics); those that hold t_i and t_i+1 go to Level 2 as a chunk -- unless they hold exactly these two
-                // and every one of their cells has no other reference k-mer form within Hamming distance 3: then they are
-                // neither reference k-mers nor one base away from one and touch nothing (full_kmer_stats: the statistics table
-                // still wants them).  K-mers without a mismatch (a read off the LDS window), at dirty cells or without a diagonal
-                // go to Level 2 as a chunk; what is left of the piece comes back here.
-                const uint32_t nb2 = min(qs, 64u);
-                BK_DBG(a, 20, lane == 0, 1); BK_DBG(a, 21, lane == 0, nb2); BK_DBG(a, 22, lane == 0 && qs < 64u, 1);
-                const uint32_t ent = (uint32_t)lane < nb2 ? rqs[lane] : 0u;
-                {   // move the rest of the queue down
-                    const uint32_t rest = qs - nb2;
-                    const uint32_t t = (uint32_t)lane < rest ? rqs[64 + lane] : 0u;
-                    __builtin_amdgcn_wave_barrier();
-                    if ((uint32_t)lane < rest) rqs[lane] = t;
-                    __builtin_amdgcn_wave_barrier();
-                    qs = rest;
-                }
-                const bool have = (uint32_t)lane < nb2;
-                const bool cur = (ent >> 31) == parity;
-                olds -= (uint32_t)__popcll(__ballot(have && !cur));
-                if (BK_ABLATE(a, 1)) continue;
-                const int src = (int)(ent & 63u);
-                const uint32_t s_first = (ent >> 6) & 0xffffu;
-                const uint32_t n2 = (ent >> 22) & 0xffu;
-                const int32_t dg_c = __shfl(dg, src), dg_p = __shfl(pdg, src);
-                const uint32_t fl_c = (uint32_t)__shfl((int)dfl, src), fl_p = (uint32_t)__shfl((int)pdfl, src);
-                const uint32_t r_c = (uint32_t)__shfl((int)r32, src), r_p = (uint32_t)__shfl((int)pr32, src);
-                const int32_t dg2 = cur ? dg_c : dg_p;
-                const uint32_t fl2 = cur ? fl_c : fl_p;
-                const uint32_t rec2 = cur ? r_c : r_p;
-                const bool fwd2 = fl2 & 1u;
-                const bool an = have && (fl2 & 2u) && n2 + km1 <= 64u;   // analysable: a diagonal, and 64 bases hold it
-                const uint32_t* __restrict__ w2 = words0 + (uint64_t)(have ? rec2 : 0u) * a.stride_words;
-                const int32_t c_first = an ? (fwd2 ? dg2 + (int32_t)s_first : dg2 - (int32_t)s_first) : 0;
-                const uint32_t ddir = fwd2 ? 1u : 0xffffffffu;
-                const uint64_t ga = read_symbols_at(w2, s_first, last_word), gb = read_symbols_at(w2, s_first + 32u, last_word);
-                const uint32_t id_first = a.id_at[c_first];
-                // how many leading k-mers sit at clean cells that continue one id sequence (the first needs no follow bit)
-                int n1;          // ... that many; 0: the first cell is dirty
-                int head = 0;    // leading k-mers that go to Level 2 as one chunk
-                {
-                    const uint64_t y_lo = fwd2 ? symbols_at(yfw, c_first) : rev2_64(symbols_at(yrw, c_first - 31));      // symbol j: cell of k-mer j
-                    const uint64_t y_hi = fwd2 ? symbols_at(yfw, c_first + 32) : rev2_64(symbols_at(yrw, c_first - 63));
-                    const uint64_t e5 = 0x5555555555555555ull;
-                    const uint64_t bad_lo = ~(y_lo & ((y_lo >> 1) | 1ull)) & e5, bad_hi = ~(y_hi & (y_hi >> 1)) & e5;
-                    const int good_len = bad_lo ? (__builtin_ctzll(bad_lo) >> 1) : 32 + (bad_hi ? (__builtin_ctzll(bad_hi) >> 1) : 32);
-                    const uint64_t cl_lo = y_lo & e5, cl_hi = y_hi & e5;
-                    const int dirty_len = cl_lo ? (__builtin_ctzll(cl_lo) >> 1) : 32 + (cl_hi ? (__builtin_ctzll(cl_hi) >> 1) : 32);
-                    n1 = an ? min(good_len, (int)n2) : 0;
-                    if (n1 == 0) head = an ? min(dirty_len, (int)n2) : (int)n2;
-                }
-                uint64_t F;   // mismatch flags of the read bases s_first + [0, 64) the first n1 k-mers cover
-                uint64_t xa, xb;   // read XOR reference along those bases (2 bits per base): which other base stands at a mismatch
-                {
-                    // read base s_first + t <-> reference base c_first + t (fwd) / complement of base c_first + k - 1 - t
-                    const uint64_t ra = fwd2 ? symbols_at(refw, c_first) : ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 31));
-                    const uint64_t rb = fwd2 ? symbols_at(refw, c_first + 32) : ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 63));
-                    const uint64_t da = ga ^ ra, db = gb ^ rb;
-                    xa = da; xb = db;
-                    const uint32_t f_lo = even_bits((uint32_t)(da | (da >> 1))) | (even_bits((uint32_t)((da | (da >> 1)) >> 32)) << 16);
-                    const uint32_t f_hi = even_bits((uint32_t)(db | (db >> 1))) | (even_bits((uint32_t)((db | (db >> 1)) >> 32)) << 16);
-                    const uint32_t L = n1 ? (uint32_t)n1 + km1 : 0u;   // bases they cover
-                    F = (((uint64_t)f_hi << 32) | f_lo) & (L >= 64u ? ~0ull : (1ull << L) - 1ull);
-                }
-                const int kk = (int)km1;
-                int cutn = n1;   // k-mers [0, cutn) of the piece are resolved in this pass
-                uint64_t c3 = 0;   // bit j: the cell of k-mer j has no other reference k-mer form within Hamming distance 3
-                if (!STATS) c3 = fwd2 ? ((uint64_t)bits32_at(c3w, c_first + 32) << 32) | bits32_at(c3w, c_first)
-                                      : ((uint64_t)__builtin_bitreverse32(bits32_at(c3w, c_first - 63)) << 32) | __builtin_bitreverse32(bits32_at(c3w, c_first - 31));
-                if (n1) {
-                    const int t1 = F ? __builtin_ctzll(F) : 1000;
-                    if (t1 > kk) { head = min(t1 - kk, n1); cutn = 0; F = 0ull; }   // leading k-mers without a mismatch
-                }
-                // ---- the head ----
-                BK_DBG(a, !(have && (fl2 & 2u) && n2 + km1 <= 64u) ? 0 : n1 == 0 ? 1 : 2, have && head > 0, head);
-                l2_mark(have && head > 0, rec2, s_first, (uint32_t)head, dg2, fl2);
-                if (have && head > 0) cutn = head;
-                // ---- mismatch by mismatch ----
-                int tprev = -1000, gprev = -1;   // the previous mismatch; the last k-mer already sent to Level 2
-                for (int it = 0; it < kNIters; ++it) {
-                    const bool act = F != 0ull;
-                    if (!__ballot(act)) break;
-                    const int ti = act ? __builtin_ctzll(F) : 0;
-                    F &= F - 1ull;
-                    int tn = F ? __builtin_ctzll(F) : 1000;
-                    const uint64_t F2 = F & (F - 1ull);
-                    const int tn2 = F2 ? __builtin_ctzll(F2) : 1000;
-                    if (act && (tn - ti > k || it == kNIters - 1)) {
-                        // k-mers without a mismatch follow (or the piece has more mismatches than passes): the piece is cut
-                        // after the last k-mer that holds t_i
-                        cutn = min(cutn, ti + 1);
-                        F = 0ull;
-                        if (tn - ti > k) tn = 1000;
-                    }
-                    // S run: the k-mers that hold t_i and nothing else
-                    const int s_lo = max(max(ti - kk, tprev + 1), 0), s_hi = min(min(ti, tn - k), cutn - 1);
-                    if (act && s_hi >= s_lo) {
-                        const uint32_t tpos = (uint32_t)(ti - s_lo);    // offset of the differing base in the run's first k-mer
-                        // which of the three other bases: read XOR reference at the mismatch, the same on either strand (bk_device.h)
-                        const uint32_t alt = ((uint32_t)((ti < 32 ? xa : xb) >> (2u * ((uint32_t)ti & 31u))) & 3u) - 1u;
-                        const uint32_t nm1 = (uint32_t)(s_hi - s_lo);
-                        // offsets (along the reference, from each k-mer's start) the run's k-mers have the difference at
-                        const uint32_t o_first = fwd2 ? tpos : km1 - tpos;
-                        const uint32_t o_lo = fwd2 ? tpos - nm1 : o_first;       // fwd: later k-mers start later, the offset shrinks
-                        const uint32_t o_hi = fwd2 ? tpos : o_first + nm1;
-                        const int lo2 = max((int)o_lo, omin), hi2 = min((int)o_hi, omin + span - 1);
-                        if (lo2 <= hi2 && !BK_ABLATE(a, 2)) {
-                            const uint32_t idS = id_first + ddir * (uint32_t)s_lo;
-                            unsigned long long* row = v_counters + v_row_base(idS + o_first - (uint32_t)omin, alt, fwd2 ? 0u : 1u, span);
-                            if constexpr (SPARSE) touch(a.touch_v, v_row_index(idS + o_first - (uint32_t)omin, alt, fwd2 ? 0u : 1u));
-                            atomicAdd(row + (lo2 - omin), 1ull);
-                            if (hi2 - omin + 1 < span) atomicAdd(row + (hi2 - omin + 1), ~0ull);   // (slot `span` is never read)
-                        }
-                    }
-                    // the k-mers that hold t_i and t_i+1 (those that also hold t_i-1 went with the previous pair)
-                    const int g_lo = max(max(tn - kk, gprev + 1), 0), g_hi = min(ti, cutn - 1);
-                    const bool pair = act && tn - ti <= kk && g_hi >= g_lo;
-                    bool dead = false;
-                    if (!STATS) {
-                        const uint32_t need = pair ? 0xffffffffu >> (31 - (g_hi - g_lo)) : 0u;
-                        dead = tn2 - kk > g_hi && ((uint32_t)(c3 >> (pair ? g_lo : 0)) & need) == need;   // none of them reaches t_i+2
-                    }
-                    BK_DBG(a, 3, pair && !dead, g_hi - g_lo + 1);
-                    l2_mark(pair && !dead, rec2, s_first + (uint32_t)(pair ? g_lo : 0), (uint32_t)(g_hi - g_lo + 1), dg2, fl2);
-                    if (pair) gprev = g_hi;
-                    tprev = ti;
-                }
-                // ---- what is left of the piece comes back ----
-                const bool requeue = have && (uint32_t)cutn < n2;
-                const unsigned long long rm = __ballot(requeue);
-                if (rm) {
-                    if (requeue) rqs[qs + lane_prefix(rm)] = (uint32_t)src | (ent & 0x80000000u) | ((s_first + (uint32_t)cutn) << 6) | ((n2 - (uint32_t)cutn) << 22);
-                    qs += (uint32_t)__popcll(rm);
-                    olds += (uint32_t)__popcll(__ballot(requeue && !cur));
-                }
+        // ---- mismatch flags, 160 bases at a time; mismatch by mismatch --------------------------------------------------
+        const int32_t dgw = dg - (int32_t)win_lo;   // the diagonal in window coordinates
+        // mismatch flags of bases [i0, i0 + 32) (i0 a multiple of 32): read words vs the reference words aligned with them
+        auto mism32 = [&](uint32_t i0) -> uint32_t {
+            const bool act = l1ok && i0 < len;
+            const uint32_t wi = i0 >> 4;
+            const uint32_t x0 = w[min(wi, last_word)], x1 = w[min(wi + 1u, last_word)];
+            const int32_t p0 = act ? (fwd ? dgw + (int32_t)i0 : dgw + (int32_t)km1 - (int32_t)i0 - 31) : 0;
+            const uint32_t sh = 2u * ((uint32_t)p0 & 15u);
+            const uint32_t r0 = refw1[p0 >> 4], r1 = refw1[(p0 >> 4) + 1], r2 = refw1[(p0 >> 4) + 2];
+            const uint32_t ya = __builtin_amdgcn_alignbit(r1, r0, sh), yb = __builtin_amdgcn_alignbit(r2, r1, sh);   // 32 reference bases, rising
+            // against the reference: read base i0 + t <-> complement of reference base p0 + 31 - t
+            const uint32_t d0 = x0 ^ (fwd ? ya : ~rev2_32(yb)), d1 = x1 ^ (fwd ? yb : ~rev2_32(ya));
+            const uint32_t m = even_bits(d0 | (d0 >> 1)) | (even_bits(d1 | (d1 >> 1)) << 16);
+            const uint32_t hi = len > i0 ? min(len - i0, 32u) : 0u;   // bases of the record in these words
+            return act ? m & (hi >= 32u ? 0xffffffffu : (1u << hi) - 1u) : 0u;
+        };
+        // E run over k-mers [g_lo, g_hi]: cells dg + g_lo .. dg + g_hi (fwd) / dg - g_hi .. dg - g_lo
+        auto e_run = [&](bool on, uint32_t g_lo, uint32_t g_hi) {
+            if (!on) return;
+            const uint32_t n = g_hi - g_lo + 1u;
+            const uint32_t c_lo = (uint32_t)(fwd ? dgw + (int32_t)g_lo : dgw - (int32_t)g_hi);
+            const uint32_t inc = fwd ? 1u : 0x10000u;
+            __hip_atomic_fetch_add(&bins[c_lo], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&bins[c_lo + n], 0u - inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        unsigned long long M01 = 0ull, M23 = 0ull;   // flags of the chunk's bases 0..63, 64..127
+        uint32_t M4 = 0u;                            // ... 128..159
+        int32_t tp = -0x20000000;    // the lane's last resolved mismatch (absolute base), far away before the first
+        auto peek3 = [&](unsigned long long m01, unsigned long long m23, uint32_t m4) -> uint32_t {   // lowest flag of the chunk
+            return m01 ? (uint32_t)__builtin_ctzll(m01) : m23 ? 64u + (uint32_t)__builtin_ctzll(m23) : m4 ? 128u + (uint32_t)__builtin_ctz(m4) : kNoPos;
+        };
+        auto pop3 = [&](unsigned long long& m01, unsigned long long& m23, uint32_t& m4) {   // ... taken off
+            const bool z01 = m01 == 0ull, z23 = m23 == 0ull;
+            m4 = (z01 && z23) ? m4 & (m4 - 1u) : m4;
+            m23 = z01 ? m23 & (m23 - 1ull) : m23;
+            m01 &= m01 - 1ull;
+        };
+        for (uint32_t cb = 0;; cb += 128u) {   // (wave-uniform) the chunk covers bases [cb, cb + 160); its first word is carried over
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                if (cb != 0u && j == 0) continue;
+                const uint32_t f = mism32(cb + 32u * (uint32_t)j);
+                if (j == 0) M01 |= (unsigned long long)f; else if (j == 1) M01 |= (unsigned long long)f << 32;
+                else if (j == 2) M23 |= (unsigned long long)f; else if (j == 3) M23 |= (unsigned long long)f << 32;
+                else M4 = f;
+            }
+            const uint32_t scanned = cb + 160u;
+            // A mismatch is resolved once the k - 1 bases behind it are scanned (or the read ends): that far reach the k-mers that
+            // hold it, and whatever they hold of its successors is then known.  What is not resolved lies in the chunk's last
+            // word (k <= 31): the word that is carried over.
+            const bool all_res = scanned >= len;
+            const uint32_t r4 = all_res ? M4 : M4 & ((1u << (32u - km1)) - 1u);   // (flags 128 .. 159 - (k - 1); words 0..3 are always resolved)
+            if (BK_ABLATE(a, 6)) { M01 = 0ull; M23 = 0ull; M4 = 0u; }
+            // ---- one mismatch per lane: the tile's resolved mismatches are dealt out over the wave (a read has 0.75 of them on the
+            // benchmark, the busiest of 64 reads four or five: taken read by read, five passes would run at a sixth of the lanes) ----
+            const uint32_t cnt = BK_ABLATE(a, 6) ? 0u : (uint32_t)__popcll(M01) + (uint32_t)__popcll(M23) + (uint32_t)__popc(r4);
+            BK_DBG(a, 23, cnt != 0u, cnt);
+            uint32_t pin = cnt;   // inclusive prefix sum over the lanes
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)pin, off); if (lane >= off) pin += x; }
+            const uint32_t pex = pin - cnt;
+            const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)pin, 63));
+            for (uint32_t it0 = 0; it0 < n_items; it0 += 64u) {
+                // owner of item it0 + lane: every lane with items writes its number where its first item of this pass sits, a running
+                // maximum spreads it over the items behind
+                own_s[lane] = 0u;
                 __builtin_amdgcn_wave_barrier();
-                continue;
+                if (cnt && pin > it0 && pex < it0 + 64u) own_s[pex > it0 ? pex - it0 : 0u] = (uint32_t)lane;
+                __builtin_amdgcn_wave_barrier();
+                uint32_t ow = own_s[lane];
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)ow, off); if (lane >= off) ow = max(ow, x); }
+                const bool on = it0 + (uint32_t)lane < n_items;
+                const int src = on ? (int)ow : lane;
+                // the owner's read: flags, diagonal, length, record, last mismatch before this chunk's
+                unsigned long long m01 = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(M01 >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)M01, src);
+                unsigned long long m23 = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(M23 >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)M23, src);
+                uint32_t m4 = (uint32_t)__shfl((int)M4, src);
+                const int32_t o_dgw = __shfl(dgw, src);
+                const uint32_t o_fl = (uint32_t)__shfl((int)dfl, src);
+                const uint32_t o_nk = (uint32_t)__shfl((int)nk, src);
+                const uint32_t o_rec = (uint32_t)__shfl((int)r32, src);
+                int32_t tq = __shfl(tp, src);                      // becomes the mismatch before mine
+                const uint32_t o_pex = (uint32_t)__shfl((int)pex, src);   // (every shuffle outside the conditions: a lane that is off may be another's owner)
+                uint32_t jj = on ? it0 + (uint32_t)lane - o_pex : 0u;   // mine is the owner's jj-th of this chunk
+                while (__ballot(jj != 0u)) {
+                    if (jj) { tq = (int32_t)(cb + peek3(m01, m23, m4)); pop3(m01, m23, m4); --jj; }
+                }
+                const bool ofwd = o_fl & 1u;
+                const int32_t t = on ? (int32_t)(cb + peek3(m01, m23, m4)) : 0;
+                pop3(m01, m23, m4);
+                const uint32_t nb = peek3(m01, m23, m4);
+                const int32_t tn = (on && nb != kNoPos) ? (int32_t)(cb + nb) : 0x20000000;   // (an unseen one is out of reach)
+                pop3(m01, m23, m4);
+                const uint32_t nb2 = peek3(m01, m23, m4);
+                const int32_t tn2 = (on && nb2 != kNoPos) ? (int32_t)(cb + nb2) : 0x20000000;
+                BK_DBG(a, 24, on, 1);
+                // The k-mers between the previous mismatch and this one hold none: an E run (they start behind the previous one and
+                // end before this one)
+                const uint32_t done = tq < 0 ? 0u : min((uint32_t)tq, o_nk - 1u) + 1u;
+                {
+                    const bool eg = on && t >= k && (uint32_t)(t - k) >= done && done < o_nk;
+                    const uint32_t g_hi = min((uint32_t)(t - k), o_nk - 1u);
+                    BK_DBG(a, 25, eg, 1);
+                    if (eg) {
+                        const uint32_t c_lo = (uint32_t)(ofwd ? o_dgw + (int32_t)done : o_dgw - (int32_t)g_hi);
+                        const uint32_t inc = ofwd ? 1u : 0x10000u;
+                        __hip_atomic_fetch_add(&bins[c_lo], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&bins[c_lo + (g_hi - done + 1u)], 0u - inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                // The k-mers whose FIRST mismatch is t: they start behind the previous one and hold t.  Every k-mer that holds a
+                // mismatch belongs to exactly one such range.
+                const uint32_t o_lo = (uint32_t)max(max(t - (int32_t)km1, tq + 1), 0), o_hi = min((uint32_t)t, o_nk - 1u);
+                const bool own = on && o_lo <= o_hi;
+                // ... of these, [o_lo, s_hi] hold nothing else -- an S run -- and [m_lo, o_hi] also hold the next mismatch
+                const int32_t s_hi_i = min((int32_t)o_hi, tn - k);
+                const bool has_s = own && s_hi_i >= (int32_t)o_lo;
+                const uint32_t s_hi = has_s ? (uint32_t)s_hi_i : o_lo;
+                const uint32_t m_lo = (uint32_t)max((int32_t)o_lo, tn - (int32_t)km1);
+                const bool has_m = own && m_lo <= o_hi;
+                // their cells, lowest first (window coordinates): all "fast" (clean, ids = cell + one constant)?
+                const int32_t ca = own ? (ofwd ? o_dgw + (int32_t)o_lo : o_dgw - (int32_t)o_hi) : 0;
+                const int32_t cz = own ? (ofwd ? o_dgw + (int32_t)o_hi : o_dgw - (int32_t)o_lo) : 0;
+                const uint32_t need = 0xffffffffu >> (31u - (uint32_t)(cz - ca));   // (at most k <= 31 cells)
+                const uint2 ba = blkw[ca >> 6], bz = blkw[cz >> 6];
+                const bool fast = own && (bits32_at(fastw, ca) & need) == need && ba.x == bz.x && !BK_ABLATE(a, 5);   // (5: every N run to nbatch_kernel)
+                {
+                    // which of the three other bases: read XOR reference at the mismatch, the same on either strand (bk_device.h)
+                    const uint32_t tt = fast && has_s ? (uint32_t)t : 0u;
+                    const uint32_t rw = (words0 + (uint64_t)o_rec * a.stride_words)[min(tt >> 4, last_word)];
+                    const int32_t pr = fast && has_s ? (ofwd ? o_dgw + (int32_t)tt : o_dgw + (int32_t)km1 - (int32_t)tt) : 0;
+                    const uint32_t refb = (refw1[pr >> 4] >> (2u * ((uint32_t)pr & 15u))) & 3u;
+                    const uint32_t alt = ((((rw >> (2u * (tt & 15u))) & 3u) ^ (ofwd ? refb : 3u - refb)) & 3u) - 1u;
+                    const uint32_t tpos = tt - o_lo, nm1 = s_hi - o_lo;   // offset of the differing base in the run's first k-mer
+                    // offsets (along the reference, from each k-mer's start) the run's k-mers have the difference at
+                    const uint32_t of_first = ofwd ? tpos : km1 - tpos;
+                    const uint32_t of_lo = ofwd ? tpos - nm1 : of_first;       // fwd: later k-mers start later, the offset shrinks
+                    const uint32_t of_hi = ofwd ? tpos : of_first + nm1;
+                    const int lo2 = max((int)of_lo, omin), hi2 = min((int)of_hi, omin + span - 1);
+                    if (fast && has_s && lo2 <= hi2 && !BK_ABLATE(a, 2)) {
+                        const uint32_t idS = (uint32_t)(ofwd ? ca : cz) + win_lo + ba.x;   // id of the cell of k-mer o_lo (cell_fast: ids = cell + constant)
+                        unsigned long long* row = v_counters + v_row_base(idS + of_first - (uint32_t)omin, alt, ofwd ? 0u : 1u, span);
+                        if constexpr (SPARSE) touch(a.touch_v, v_row_index(idS + of_first - (uint32_t)omin, alt, ofwd ? 0u : 1u));
+                        atomicAdd(row + (lo2 - omin), 1ull);
+                        if (hi2 - omin + 1 < span) atomicAdd(row + (hi2 - omin + 1), ~0ull);   // (slot `span` is never read)
+                    }
+                }
+                {
+                    // The k-mers that hold t and its successor.  If none of them reaches the successor after that and each of their cells
+                    // has no other reference k-mer form within Hamming distance 3, they hold exactly two differences from a reference
+                    // k-mer that is isolated up to distance 3: neither a reference k-mer nor one base away from one (triangle
+                    // inequality) -- they touch nothing.  Otherwise level2_kernel looks at them one by one.
+                    const bool mm = fast && has_m;
+                    const int32_t ma = mm ? (ofwd ? o_dgw + (int32_t)m_lo : o_dgw - (int32_t)o_hi) : 0;
+                    const uint32_t needm = mm ? 0xffffffffu >> (31u - (o_hi - m_lo)) : 0u;
+                    const bool dead = !stats && tn2 - (int32_t)km1 > (int32_t)o_hi && (bits32_at(c3w, ma) & needm) == needm;
+                    l2_mark(mm && !dead, o_rec, m_lo, o_hi + 1u - m_lo, o_dgw + (int32_t)win_lo, o_fl);
+                }
+                // cells that are not fast: the whole range is an N run for nbatch_kernel
+                n_mark(own && !fast, o_rec, o_lo, o_hi + 1u - o_lo, o_dgw + (int32_t)win_lo, o_fl);
             }
-            if (pend) {
-                // ---- the next run boundary of each lane: close the open run, open the next (qs < 64 here) ----
-                const bool has = Bd != 0u;
-                const uint32_t b = has ? (uint32_t)__builtin_ctz(Bd) : 0u;
-                const uint32_t s = tw_i0 + b - km1;          // the k-mer that ends at that base: first of the new run
-                const uint32_t n = s - run_start;
-                const bool long_n = has && run_type == 2u && n > piece;   // a long N run goes out piece by piece
-                const uint32_t take = long_n ? piece : n;
-                if (has && run_type == 1u) {
-                    // E run over k-mers [run_start, s): cells dg + run_start .. dg + s - 1 (fwd) / dg - s + 1 .. dg - run_start
-                    const uint32_t c_lo = (fwd ? (uint32_t)(dg + (int32_t)run_start) : (uint32_t)(dg - (int32_t)s + 1)) - win_lo;
-                    const uint32_t inc = fwd ? 1u : 0x10000u;
-                    __hip_atomic_fetch_add(&bins[c_lo], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&bins[c_lo + n], 0u - inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                const unsigned long long sm = __ballot(has && run_type == 2u);
-                if (sm) {
-                    if (has && run_type == 2u) rqs[qs + lane_prefix(sm)] = (uint32_t)lane | (run_start << 6) | (take << 22) | (parity << 31);
-                    qs += (uint32_t)__popcll(sm);
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (long_n) {
-                    run_start += piece;                      // the boundary stays: the rest goes out in the next rounds
-                } else if (has) {
-                    run_type = ((E32 >> b) & 1u) ? 1u : ((N32 >> b) & 1u) ? 2u : 0u;
-                    run_start = s;
-                    Bd &= Bd - 1u;
-                }
-                pend = __ballot(Bd != 0u) != 0ull;
-                continue;
-            }
-            if (words_done) break;
-            // ================= Level 1: two read words = 32 bases ================================================
-            {
-                const uint32_t x0 = xn0, x1 = xn1;
-                xn0 = (i0 + 32u < len) ? w[(i0 >> 4) + 2u] : 0u;
-                xn1 = (i0 + 48u < len) ? w[(i0 >> 4) + 3u] : 0u;
-                const bool act = l1ok && i0 < len;
-                // mismatch flags of these 32 bases: read words vs the reference words aligned with them
-                const int32_t dgw = dg - (int32_t)win_lo;   // the diagonal in window coordinates
-                const int32_t p0 = act ? (fwd ? dgw + (int32_t)i0 : dgw + (int32_t)km1 - (int32_t)i0 - 31) : 0;
-                const uint32_t sh = 2u * ((uint32_t)p0 & 15u);
-                const uint32_t r0 = refw1[p0 >> 4], r1 = refw1[(p0 >> 4) + 1], r2 = refw1[(p0 >> 4) + 2];
-                const uint32_t ya = __builtin_amdgcn_alignbit(r1, r0, sh), yb = __builtin_amdgcn_alignbit(r2, r1, sh);   // 32 reference bases, rising
-                // against the reference: read base i0 + t <-> complement of reference base p0 + 31 - t
-                const uint32_t d0 = x0 ^ (fwd ? ya : ~rev2_32(yb)), d1 = x1 ^ (fwd ? yb : ~rev2_32(ya));
-                const uint32_t M32 = act ? even_bits(d0 | (d0 >> 1)) | (even_bits(d1 | (d1 >> 1)) << 16) : 0xffffffffu;   // no usable diagonal: every base "differs"
-                h_lo = h_hi;
-                h_hi = M32;
-                // per-cell bits of the 32 k-mers that end in these words, in step order
-                const int32_t c0 = act ? (fwd ? dgw + (int32_t)i0 - (int32_t)km1 : dgw - (int32_t)i0 + (int32_t)km1 - 31) : 0;
-                const uint32_t hl = bits32_at(hasw, c0);
-                const uint32_t HAS32 = fwd ? hl : __builtin_bitreverse32(hl);
-                // steps that end a k-mer of the read: i0 + b >= k - 1 and i0 + b < len
-                const uint32_t lo = i0 >= km1 ? 0u : min(km1 - i0, 32u);
-                const uint32_t hi = len > i0 ? min(len - i0, 32u) : 0u;
-                const uint32_t VAL32 = (hi >= 32u ? 0xffffffffu : (1u << hi) - 1u) & (lo >= 32u ? 0u : ~((1u << lo) - 1u));
-                // A: some mismatch among the k bases that end at step b.  The flag of base i0 + b - t sits at bit 32 + b - t of
-                // (h_hi : h_lo)
-                uint32_t A;
-                if (KT >= 16) {
-                    // OR of the flags of the k bases that end at each step = the upper half of OR_{t<k} (H << t): by doubling,
-                    // t < 2, 4, 8, 16, then one more shift by k - 16 (five 64-bit shift-or steps instead of k - 1 funnel shifts)
-                    unsigned long long Y = ((unsigned long long)h_hi << 32) | h_lo;
-                    Y |= Y << 1; Y |= Y << 2; Y |= Y << 4; Y |= Y << 8;
-                    Y |= Y << (KT - 16);
-                    A = (uint32_t)(Y >> 32);
-                } else {
-                    A = h_hi;
-                    for (int t = 1; t < k; ++t) A |= __builtin_amdgcn_alignbit(h_hi, h_lo, (uint32_t)(32 - t));
-                }
-                E32 = ~A & HAS32 & VAL32;
-                N32 = VAL32 & ~E32;
-                Bd = (E32 ^ ((E32 << 1) | pe)) | (N32 ^ ((N32 << 1) | pn));   // a new run starts where the kind changes
-                pe = E32 >> 31; pn = N32 >> 31;
-                tw_i0 = i0;
-                pend = __ballot(Bd != 0u) != 0ull;
-                i0 += 32u;
-                words_done = i0 > maxlen;   // one step past the longest read closes every open run
-            }
+            // each lane: its last resolved mismatch; what is not resolved stays
+            if (cnt) tp = (int32_t)cb + (r4 ? 159 - (int32_t)__builtin_clz(r4) : M23 ? 127 - (int32_t)__builtin_clzll(M23) : 63 - (int32_t)__builtin_clzll(M01));
+            if (scanned >= maxlen) break;
+            M01 = (unsigned long long)(M4 & ~r4); M23 = 0ull; M4 = 0u;   // the next chunk starts 128 bases on
         }
-        if (fin) break;
+        const uint32_t done = tp < 0 ? 0u : min((uint32_t)tp, nk - 1u) + 1u;
+        BK_DBG(a, 26, l1ok && done < nk, 1);
+        e_run(l1ok && done < nk, done, nk - 1u);   // behind the last mismatch
     }
     asm volatile("s_waitcnt vmcnt(0)" ::"v"(pf_sink) : "memory");   // the prefetch register stays reserved up to here
 
@@ -965,13 +914,21 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ K1b
-// Level 2: the k-mers the scan left marked (ScanArgs::l2_bits, one bit per k-mer of each record) -- k-mers at cells that are
-// not clean, with several differences that the N batch could not settle, without a usable diagonal, exact k-mers of reads off
-// the LDS window.  One k-mer per lane, nothing rolls: every lane extracts its k-mer and the reference along the record's
-// diagonal straight from the packed words, so the 64 k-mers of a batch are independent and all their loads are in flight
+// What the scan did not settle, in two kernels.
+//
+// nbatch_kernel -- the N runs (ScanArgs::n_bits, one bit per k-mer of each record; n_any, one bit per record): k-mers at cells
+// that are not fast, of reads off the LDS window or without a diagonal.  Cut into pieces of at most 32 k-mers (a piece lies in
+// 64 read bases) and taken 64 pieces at a time, one per lane ("N batch"): the piece's bases are compared with the reference
+// along the diagonal; its leading k-mers whose cells are clean and continue one id sequence are resolved mismatch by mismatch
+// -- the k-mers that hold one mismatch and nothing else are an S run (one row of the V plane, two atomics), the k-mers that
+// hold exactly two at cells isolated up to Hamming distance 3 touch nothing -- and what that cannot settle is marked in
+// l2_bits[record] (one bit per k-mer; l2_any, one bit per record) like the k-mers the scan itself leaves to Level 2.
+//
+// level2_kernel -- the marked k-mers, one per lane, nothing rolls: every lane extracts its k-mer and the reference along the
+// record's diagonal straight from the packed words, so the 64 k-mers of a batch are independent and all their loads are in flight
 // together (this kernel is latency, not arithmetic: about one k-mer in a thousand on the benchmark, one in forty with four
 // strains).
-//   discovery   l2_any (a bit per record) -> marked records (LDS queue) -> their bitmap words -> the marked k-mers, listed
+//   discovery   l2_any -> marked records (LDS queue) -> their bitmap words -> the marked k-mers, listed
 //               (record, k-mer index) in an LDS queue in record order: the k-mers of a marked run sit in neighbouring lanes.
 //               Every bit taken is cleared: the bitmaps are all zero again when the kernel ends.
 //   per k-mer   differences with the reference at its cell along the diagonal, the cell's id and flags (bk_device.h):
@@ -990,6 +947,240 @@ constexpr int kL2Waves = kL2Block / 64;
 constexpr int kL2QueueCap = 128;            // record / slow queues: a batch is taken at 64 pending, a round adds <= 64
 constexpr int kL2KmerCap = 256;             // k-mer queue
 constexpr int kAnyWords = 8;                // words of l2_any a wave takes at a time (256 records)
+constexpr int kNbBlocksPerWave = 4;        // blocks of 256 records a wave of nbatch_kernel takes when there are enough of them
+template <bool STATS, int KT, bool SPARSE>
+__global__ __launch_bounds__(kL2Block) void nbatch_kernel(ScanArgs a) {
+    __shared__ unsigned int rec_q[kL2Waves * kL2QueueCap];
+    __shared__ unsigned long long piece_q[kL2Waves * kL2QueueCap];   // record << 24 | first k-mer << 8 | k-mers
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned int* const rq = rec_q + wave * kL2QueueCap;
+    unsigned long long* const pq = piece_q + wave * kL2QueueCap;
+    const unsigned int* refw = a.ref_words + kRefPadWords;
+    const int k = KT ? KT : a.k;
+    const uint32_t km1 = (uint32_t)k - 1u;
+    const int omin = a.v_omin, span = a.v_span;
+    unsigned long long* const v_counters = a.counters + a.v_off;
+    const uint32_t last_word = a.stride_words - 1u;
+    uint64_t n_records = a.n_records;
+    if (a.n_records_dev) {
+        const uint64_t nd = *a.n_records_dev;
+        n_records = nd > a.rec_base ? min(nd - a.rec_base, a.n_records) : 0ull;
+    }
+    const uint32_t* const words0 = a.words + a.rec_base * a.stride_words;
+    const uint32_t nw = a.l2_words;
+    const uint64_t n_any = (n_records + 31) / 32;                    // words of n_any
+    const uint64_t n_blk = (n_any + kAnyWords - 1) / kAnyWords;
+    {
+        const unsigned int* yfw = a.cell_yf + kRefPadWords;
+        const unsigned int* yrw = a.cell_yr + kRefPadWords;
+        const unsigned int* c3w = a.cell_clean3 + kBitPadWords;
+        const uint32_t piece = 65u - (uint32_t)k;                   // most k-mers of a run the N batch looks at together (64 bases)
+        // k-mers [sk, sk + n) of record `rec` are left to the second pass: set their bits
+        auto l2_mark = [&](bool on, uint32_t rec, uint32_t sk, uint32_t n) {
+            if (!on) return;
+            unsigned int* row = a.l2_bits + (size_t)rec * nw;
+            atomicOr(a.l2_any + (rec >> 5), 1u << (rec & 31u));
+            uint32_t wd = sk >> 5, bit = sk & 31u, left = n;
+            while (left) {
+                const uint32_t take = min(left, 32u - bit);
+                atomicOr(row + wd, (take == 32u ? 0xffffffffu : (1u << take) - 1u) << bit);
+                left -= take; ++wd; bit = 0u;
+            }
+        };
+        uint32_t qp = 0;   // wave-uniform fill of the piece queue
+        // The N batch: up to 64 queued pieces, one per lane.  The piece's n <= 65 - k k-mers lie in 64 read bases.  Its leading
+        // k-mers whose cells are clean and continue one id sequence are resolved here, mismatch by mismatch (t_1 < t_2 < ...): the
+        // k-mers that hold only t_i are an S run (two atomics); those that hold t_i and t_i+1 go to the second pass as a chunk --
+        // unless they hold exactly these two and every one of their cells has no other reference k-mer form within Hamming
+        // distance 3: then they are neither reference k-mers nor one base away from one and touch nothing (full_kmer_stats: the
+        // statistics table still wants them).  K-mers without a mismatch (a read off the LDS window), at dirty cells or without a
+        // diagonal go to the second pass as a chunk; what is left of the piece comes back into the queue.
+        auto n_batch = [&]() {
+            const uint32_t nb2 = min(qp, 64u);
+            BK_DBG(a, 20, lane == 0, 1); BK_DBG(a, 21, lane == 0, nb2); BK_DBG(a, 22, lane == 0 && qp < 64u, 1);
+            const bool have = (uint32_t)lane < nb2;
+            const unsigned long long ent = have ? pq[lane] : 0ull;
+            {   // move the rest of the queue down
+                const uint32_t rest = qp - nb2;
+                const unsigned long long t = (uint32_t)lane < rest ? pq[64 + lane] : 0ull;
+                __builtin_amdgcn_wave_barrier();
+                if ((uint32_t)lane < rest) pq[lane] = t;
+                __builtin_amdgcn_wave_barrier();
+                qp = rest;
+            }
+            const uint32_t rec2 = (uint32_t)(ent >> 24), s_first = (uint32_t)(ent >> 8) & 0xffffu, n2 = (uint32_t)ent & 0xffu;
+            const uint2 dgf = have ? a.l2_diag[rec2] : make_uint2(0u, 0u);
+            const int32_t dg2 = (int32_t)dgf.x;
+            const uint32_t fl2 = dgf.y;
+            const bool fwd2 = fl2 & 1u;
+            const bool an = have && (fl2 & 2u) && n2 + km1 <= 64u;   // analysable: a diagonal, and 64 bases hold it
+            const uint32_t* __restrict__ w2 = words0 + (uint64_t)rec2 * a.stride_words;
+            const int32_t c_first = an ? (fwd2 ? dg2 + (int32_t)s_first : dg2 - (int32_t)s_first) : 0;
+            const uint32_t ddir = fwd2 ? 1u : 0xffffffffu;
+            const uint64_t ga = read_symbols_at(w2, s_first, last_word), gb = read_symbols_at(w2, s_first + 32u, last_word);
+            const uint32_t id_first = a.id_at[c_first];
+            // how many leading k-mers sit at clean cells that continue one id sequence (the first needs no follow bit)
+            int n1;          // ... that many; 0: the first cell is dirty
+            int head = 0;    // leading k-mers that go to the second pass as one chunk
+            {
+                const uint64_t y_lo = fwd2 ? symbols_at(yfw, c_first) : rev2_64(symbols_at(yrw, c_first - 31));      // symbol j: cell of k-mer j
+                const uint64_t y_hi = fwd2 ? symbols_at(yfw, c_first + 32) : rev2_64(symbols_at(yrw, c_first - 63));
+                const uint64_t e5 = 0x5555555555555555ull;
+                const uint64_t bad_lo = ~(y_lo & ((y_lo >> 1) | 1ull)) & e5, bad_hi = ~(y_hi & (y_hi >> 1)) & e5;
+                const int good_len = bad_lo ? (__builtin_ctzll(bad_lo) >> 1) : 32 + (bad_hi ? (__builtin_ctzll(bad_hi) >> 1) : 32);
+                const uint64_t cl_lo = y_lo & e5, cl_hi = y_hi & e5;
+                const int dirty_len = cl_lo ? (__builtin_ctzll(cl_lo) >> 1) : 32 + (cl_hi ? (__builtin_ctzll(cl_hi) >> 1) : 32);
+                n1 = an ? min(good_len, (int)n2) : 0;
+                if (n1 == 0) head = an ? min(dirty_len, (int)n2) : (int)n2;
+            }
+            uint64_t F;   // mismatch flags of the read bases s_first + [0, 64) the first n1 k-mers cover
+            uint64_t xa, xb;   // read XOR reference along those bases (2 bits per base): which other base stands at a mismatch
+            {
+                // read base s_first + t <-> reference base c_first + t (fwd) / complement of base c_first + k - 1 - t
+                const uint64_t ra = fwd2 ? symbols_at(refw, c_first) : ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 31));
+                const uint64_t rb = fwd2 ? symbols_at(refw, c_first + 32) : ~rev2_64(symbols_at(refw, c_first + (int32_t)km1 - 63));
+                const uint64_t da = ga ^ ra, db = gb ^ rb;
+                xa = da; xb = db;
+                const uint32_t f_lo = even_bits((uint32_t)(da | (da >> 1))) | (even_bits((uint32_t)((da | (da >> 1)) >> 32)) << 16);
+                const uint32_t f_hi = even_bits((uint32_t)(db | (db >> 1))) | (even_bits((uint32_t)((db | (db >> 1)) >> 32)) << 16);
+                const uint32_t L = n1 ? (uint32_t)n1 + km1 : 0u;   // bases they cover
+                F = (((uint64_t)f_hi << 32) | f_lo) & (L >= 64u ? ~0ull : (1ull << L) - 1ull);
+            }
+            const int kk = (int)km1;
+            int cutn = n1;   // k-mers [0, cutn) of the piece are resolved in this pass
+            uint64_t c3 = 0;   // bit j: the cell of k-mer j has no other reference k-mer form within Hamming distance 3
+            if (!STATS) c3 = fwd2 ? ((uint64_t)bits32_at(c3w, c_first + 32) << 32) | bits32_at(c3w, c_first)
+                                  : ((uint64_t)__builtin_bitreverse32(bits32_at(c3w, c_first - 63)) << 32) | __builtin_bitreverse32(bits32_at(c3w, c_first - 31));
+            if (n1) {
+                const int t1 = F ? __builtin_ctzll(F) : 1000;
+                if (t1 > kk) { head = min(t1 - kk, n1); cutn = 0; F = 0ull; }   // leading k-mers without a mismatch
+            }
+            // ---- the head ----
+            BK_DBG(a, !(have && (fl2 & 2u) && n2 + km1 <= 64u) ? 0 : n1 == 0 ? 1 : 2, have && head > 0, head);
+            l2_mark(have && head > 0, rec2, s_first, (uint32_t)head);
+            if (have && head > 0) cutn = head;
+            // ---- mismatch by mismatch ----
+            int tprev = -1000, gprev = -1;   // the previous mismatch; the last k-mer already sent to the second pass
+            for (int it = 0; it < kNIters; ++it) {
+                const bool act = F != 0ull;
+                if (!__ballot(act)) break;
+                const int ti = act ? __builtin_ctzll(F) : 0;
+                F &= F - 1ull;
+                int tn = F ? __builtin_ctzll(F) : 1000;
+                const uint64_t F2 = F & (F - 1ull);
+                const int tn2 = F2 ? __builtin_ctzll(F2) : 1000;
+                if (act && (tn - ti > k || it == kNIters - 1)) {
+                    // k-mers without a mismatch follow (or the piece has more mismatches than passes): the piece is cut
+                    // after the last k-mer that holds t_i
+                    cutn = min(cutn, ti + 1);
+                    F = 0ull;
+                    if (tn - ti > k) tn = 1000;
+                }
+                // S run: the k-mers that hold t_i and nothing else
+                const int s_lo = max(max(ti - kk, tprev + 1), 0), s_hi = min(min(ti, tn - k), cutn - 1);
+                if (act && s_hi >= s_lo) {
+                    const uint32_t tpos = (uint32_t)(ti - s_lo);    // offset of the differing base in the run's first k-mer
+                    // which of the three other bases: read XOR reference at the mismatch, the same on either strand (bk_device.h)
+                    const uint32_t alt = ((uint32_t)((ti < 32 ? xa : xb) >> (2u * ((uint32_t)ti & 31u))) & 3u) - 1u;
+                    const uint32_t nm1 = (uint32_t)(s_hi - s_lo);
+                    // offsets (along the reference, from each k-mer's start) the run's k-mers have the difference at
+                    const uint32_t o_first = fwd2 ? tpos : km1 - tpos;
+                    const uint32_t o_lo = fwd2 ? tpos - nm1 : o_first;       // fwd: later k-mers start later, the offset shrinks
+                    const uint32_t o_hi = fwd2 ? tpos : o_first + nm1;
+                    const int lo2 = max((int)o_lo, omin), hi2 = min((int)o_hi, omin + span - 1);
+                    if (lo2 <= hi2 && !BK_ABLATE(a, 2)) {
+                        const uint32_t idS = id_first + ddir * (uint32_t)s_lo;
+                        unsigned long long* row = v_counters + v_row_base(idS + o_first - (uint32_t)omin, alt, fwd2 ? 0u : 1u, span);
+                        if constexpr (SPARSE) touch(a.touch_v, v_row_index(idS + o_first - (uint32_t)omin, alt, fwd2 ? 0u : 1u));
+                        atomicAdd(row + (lo2 - omin), 1ull);
+                        if (hi2 - omin + 1 < span) atomicAdd(row + (hi2 - omin + 1), ~0ull);   // (slot `span` is never read)
+                    }
+                }
+                // the k-mers that hold t_i and t_i+1 (those that also hold t_i-1 went with the previous pair)
+                const int g_lo = max(max(tn - kk, gprev + 1), 0), g_hi = min(ti, cutn - 1);
+                const bool pair = act && tn - ti <= kk && g_hi >= g_lo;
+                bool dead = false;
+                if (!STATS) {
+                    const uint32_t need = pair ? 0xffffffffu >> (31 - (g_hi - g_lo)) : 0u;
+                    dead = tn2 - kk > g_hi && ((uint32_t)(c3 >> (pair ? g_lo : 0)) & need) == need;   // none of them reaches t_i+2
+                }
+                BK_DBG(a, 3, pair && !dead, g_hi - g_lo + 1);
+                l2_mark(pair && !dead, rec2, s_first + (uint32_t)(pair ? g_lo : 0), (uint32_t)(g_hi - g_lo + 1));
+                if (pair) gprev = g_hi;
+                tprev = ti;
+            }
+            // ---- what is left of the piece comes back ----
+            const bool requeue = have && (uint32_t)cutn < n2;
+            const unsigned long long rm = __ballot(requeue);
+            if (rm) {
+                if (requeue) pq[qp + lane_prefix(rm)] = ((unsigned long long)rec2 << 24) | ((unsigned long long)(s_first + (uint32_t)cutn) << 8) | (n2 - (uint32_t)cutn);
+                qp += (uint32_t)__popcll(rm);
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        // 64 marked records, one per lane: the runs of set bits of their n_bits rows (cleared as they are taken), word by word --
+        // a run that crosses a word boundary is two pieces; every piece is a sub-range of a run, any cut gives the same counts
+        auto take_n_records = [&](uint32_t n) {
+            const uint32_t rec = (uint32_t)lane < n ? rq[lane] : 0xffffffffu;
+            unsigned int* row = a.n_bits + (size_t)(rec == 0xffffffffu ? 0u : rec) * nw;
+            for (uint32_t w0 = 0; w0 < nw; w0 += 4u) {   // (four words' loads in flight together)
+                uint32_t bw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bw[j] = (rec != 0xffffffffu && w0 + j < nw) ? row[w0 + j] : 0u;
+                    if (bw[j]) row[w0 + j] = 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t bits = bw[j];
+                    while (__ballot(bits != 0u)) {
+                        const uint32_t st = bits ? (uint32_t)__builtin_ctz(bits) : 0u;
+                        const uint32_t ones = bits ? min((uint32_t)__builtin_ctzll(~(unsigned long long)(bits >> st)), piece) : 0u;   // (length of the run of ones at st, at most to the word's end)
+                        const unsigned long long pm = __ballot(bits != 0u);
+                        if (bits) pq[qp + lane_prefix(pm)] = ((unsigned long long)rec << 24) | ((unsigned long long)((w0 + (uint32_t)j) * 32u + st) << 8) | ones;
+                        qp += (uint32_t)__popcll(pm);
+                        bits &= ~((ones >= 32u ? 0xffffffffu : (1u << ones) - 1u) << st);
+                        __builtin_amdgcn_wave_barrier();
+                        while (qp >= 64u) n_batch();   // (a batch may put up to 64 leftovers back: below 64 again before the next round adds its own)
+                    }
+                }
+            }
+        };
+        uint32_t qrn = 0;   // wave-uniform fill of the record queue
+        // a wave takes kNbBlocksPerWave consecutive blocks of 256 records per turn: their n_any words in one load, 32 of the lanes
+        const uint64_t n_turns = (n_blk + kNbBlocksPerWave - 1) / kNbBlocksPerWave;
+        for (uint64_t turn = (uint64_t)blockIdx.x * kL2Waves + wave; turn < n_turns; turn += (uint64_t)gridDim.x * kL2Waves) {
+            const uint64_t i = turn * (kNbBlocksPerWave * kAnyWords) + lane;
+            const uint32_t anyw = (lane < kNbBlocksPerWave * kAnyWords && i < n_any) ? a.n_any[i] : 0u;
+            if (anyw) a.n_any[i] = 0u;     // taken: n_any and n_bits are all zero again when this kernel ends
+            if (!__ballot(anyw != 0u)) continue;
+#pragma unroll
+            for (int j = 0; j < kNbBlocksPerWave * kAnyWords / 2; ++j) {   // record 64 j + lane of the turn: bit (lane & 31) of word 2 j + (lane >> 5)
+                const uint32_t wv = (uint32_t)__shfl((int)anyw, 2 * j + (lane >> 5));
+                const bool marked = (wv >> (lane & 31)) & 1u;
+                const unsigned long long hm = __ballot(marked);
+                if (hm) {
+                    if (marked) rq[qrn + lane_prefix(hm)] = (uint32_t)(turn * (kNbBlocksPerWave * kAnyWords * 32) + 64u * (uint32_t)j + (uint32_t)lane);
+                    qrn += (uint32_t)__popcll(hm);
+                    __builtin_amdgcn_wave_barrier();
+                    if (qrn >= 64u) {
+                        take_n_records(64u);
+                        const uint32_t rest = qrn - 64u;
+                        const uint32_t t = (uint32_t)lane < rest ? rq[64 + lane] : 0u;
+                        __builtin_amdgcn_wave_barrier();
+                        if ((uint32_t)lane < rest) rq[lane] = t;
+                        __builtin_amdgcn_wave_barrier();
+                        qrn = rest;
+                    }
+                }
+            }
+        }
+        if (qrn) take_n_records(qrn);
+        while (qp) n_batch();
+    }
+}
+
 template <bool STATS, int KT, bool SPARSE>
 __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
     __shared__ unsigned long long queue_c[kL2Waves * kL2QueueCap];   // slow-path queue: canonical k-mer | orientation << 62 | stat_only << 63
@@ -1215,8 +1406,9 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
         }
     };
 
-    const uint64_t n_any = (n_records + 31) / 32;                    // words of l2_any
+    const uint64_t n_any = (n_records + 31) / 32;                    // words of l2_any / n_any
     const uint64_t n_blk = (n_any + kAnyWords - 1) / kAnyWords;
+
     for (uint64_t blk = (uint64_t)blockIdx.x * kL2Waves + wave; blk < n_blk; blk += (uint64_t)gridDim.x * kL2Waves) {
         const uint64_t i = blk * kAnyWords + lane;
         const uint32_t anyw = (lane < kAnyWords && i < n_any) ? a.l2_any[i] : 0u;
@@ -1267,14 +1459,14 @@ __global__ __launch_bounds__(256) void pick_window_kernel(ScanArgs a, uint64_t n
     for (int f = threadIdx.x; f < a.n_files; f += 256) if (lvotes[f]) atomicAdd(votes + f, lvotes[f]);
 }
 // ... and the choice itself, on the device (no host round trip between a sample's first push and its scan): the genome with the
-// most votes (lowest id on ties), its first cell rounded down to a multiple of 32; `forced` >= 0 overrides (testing build)
+// most votes (lowest id on ties), its first cell rounded down to a multiple of 64; `forced` >= 0 overrides (testing build)
 __global__ void choose_window_kernel(const unsigned int* votes, int n_files, const uint32_t* file_cell_lo, int forced, uint32_t* win) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int best = 0;
     for (int f = 1; f < n_files; ++f) if (votes[f] > votes[best]) best = f;
     if (forced >= 0) best = forced < n_files ? forced : n_files - 1;
     win[0] = (uint32_t)best;
-    win[1] = file_cell_lo[best] & ~31u;
+    win[1] = file_cell_lo[best] & ~63u;
 }
 void launch_pick_window(const ScanArgs& a, uint64_t n_probe, unsigned int* votes, const uint32_t* file_cell_lo, int forced, uint32_t* win,
                         hipStream_t stream) {
@@ -1317,10 +1509,11 @@ void launch_count_kmers(const ScanArgs& a, hipStream_t stream) {
 
 // (12 KB of the CU's 160 KB are left free: a workgroup of another stream's finalize kernels fits next to the scan's)
 size_t scan_lds_budget() { return 148u * 1024u - 64u - kScanLdsFixed - sizeof(unsigned int); }
-// LDS bytes of the per-cell arrays Level 1 stages for `cells` cells (reference 2 bits, one 1-bit array, paddings)
+// LDS bytes of the per-cell arrays the scan stages for `cells` cells (reference 2 bits, two 1-bit arrays, one block entry per 64
+// cells; paddings)
 size_t scan_ref_lds_bytes(uint32_t cells) {
-    return ((size_t)(kRefPadWords + (cells + 15) / 16 + kRefBackWords) + (size_t)(kBitPadWords + (cells + 31) / 32 + kBitBackWords)) *
-           sizeof(unsigned int);
+    return ((size_t)(kRefPadWords + (cells + 15) / 16 + kRefBackWords) + 2u * (size_t)(kBitPadWords + (cells + 31) / 32 + kBitBackWords) +
+            2u * ((size_t)(cells + 63) / 64 + 2u)) * sizeof(unsigned int);
 }
 size_t scan_lds_bytes(uint32_t n_lds_bins, bool ref_in_lds, uint32_t total_cells) {
     return kScanLdsFixed + ((size_t)n_lds_bins + 1) * sizeof(unsigned int) +
@@ -1343,16 +1536,26 @@ hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t strea
     if (a.n_records == 0 || a.W <= 0) return hipSuccess;
     if (a.n_records > scan_max_records(grid)) return hipErrorInvalidValue;
     const size_t lds = scan_lds_bytes(a.n_lds_bins, a.ref_in_lds != 0, a.total_cells);
-    const bool stats = a.ktab_keys != nullptr;
     void (*kern)(ScanArgs);
-#define BK_PICK2(KT, SP) (a.ref_in_lds ? (stats ? scan_count_kernel<true, true, KT, SP> : scan_count_kernel<true, false, KT, SP>) \
-                                       : (stats ? scan_count_kernel<false, true, KT, SP> : scan_count_kernel<false, false, KT, SP>))
-#define BK_PICK(KT) (!a.touch_v ? BK_PICK2(KT, false) : BK_PICK2(KT, true))
+#define BK_PICK(KT) (!a.touch_v ? (a.ref_in_lds ? scan_count_kernel<true, KT, false> : scan_count_kernel<false, KT, false>) \
+                                : (a.ref_in_lds ? scan_count_kernel<true, KT, true> : scan_count_kernel<false, KT, true>))
     kern = a.k == 21 ? BK_PICK(21) : a.k == 31 ? BK_PICK(31) : BK_PICK(0);
 #undef BK_PICK
-#undef BK_PICK2
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    {   // the dynamic-LDS limit of a kernel variant is raised once (per process and device), not at every launch
+        static std::mutex mu;
+        static std::vector<std::pair<std::pair<const void*, int>, size_t>> have;   // ((kernel, device), limit set)
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const void* fn = reinterpret_cast<const void*>(kern);
+        std::lock_guard<std::mutex> lock(mu);
+        size_t* cur = nullptr;
+        for (auto& h : have) if (h.first.first == fn && h.first.second == dev) cur = &h.second;
+        if (!cur || *cur < lds) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            if (cur) *cur = lds; else have.push_back({{fn, dev}, lds});
+        }
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kScanBlock), lds, stream, a);
     return hipGetLastError();
 }
@@ -1361,6 +1564,15 @@ hipError_t launch_level2(const ScanArgs& a, int n_cus, hipStream_t stream) {
     if (a.n_records == 0 || a.W <= 0) return hipSuccess;
     const bool stats = a.ktab_keys != nullptr;
     void (*kern)(ScanArgs);
+    {   // the N runs first (they mark k-mers for the kernel below)
+#define BK_PICKN(KT) (!a.touch_v ? (stats ? nbatch_kernel<true, KT, false> : nbatch_kernel<false, KT, false>) \
+                                 : (stats ? nbatch_kernel<true, KT, true> : nbatch_kernel<false, KT, true>))
+        kern = a.k == 21 ? BK_PICKN(21) : a.k == 31 ? BK_PICKN(31) : BK_PICKN(0);
+#undef BK_PICKN
+        const uint64_t turns = (a.n_records + 32 * kAnyWords * kNbBlocksPerWave - 1) / (32 * kAnyWords * kNbBlocksPerWave);
+        const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((turns + kL2Waves - 1) / kL2Waves, (uint64_t)n_cus * 8));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kL2Block), 0, stream, a);
+    }
 #define BK_PICK(KT) (!a.touch_v ? (stats ? level2_kernel<true, KT, false> : level2_kernel<false, KT, false>) \
                                 : (stats ? level2_kernel<true, KT, true> : level2_kernel<false, KT, true>))
     kern = a.k == 21 ? BK_PICK(21) : a.k == 31 ? BK_PICK(31) : BK_PICK(0);

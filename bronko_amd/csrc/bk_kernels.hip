@@ -827,52 +827,66 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 // mismatch belongs to exactly one such range.
                 const uint32_t o_lo = (uint32_t)max(max(t - (int32_t)km1, tq + 1), 0), o_hi = min((uint32_t)t, o_nk - 1u);
                 const bool own = on && o_lo <= o_hi;
-                // ... of these, [o_lo, s_hi] hold nothing else -- an S run -- and [m_lo, o_hi] also hold the next mismatch
-                const int32_t s_hi_i = min((int32_t)o_hi, tn - k);
-                const bool has_s = own && s_hi_i >= (int32_t)o_lo;
-                const uint32_t s_hi = has_s ? (uint32_t)s_hi_i : o_lo;
-                const uint32_t m_lo = (uint32_t)max((int32_t)o_lo, tn - (int32_t)km1);
-                const bool has_m = own && m_lo <= o_hi;
-                // their cells, lowest first (window coordinates): all "fast" (clean, ids = cell + one constant)?
+                // Their cells, lowest first (window coordinates), and which of them are "fast" (clean, ids = cell + one constant).
+                // Usually all: one stretch.  Otherwise the range is taken stretch by stretch -- fast cells as below, the k-mers at the
+                // others are left to level2_kernel one by one (its answer table knows the cells that are not clean).
                 const int32_t ca = own ? (ofwd ? o_dgw + (int32_t)o_lo : o_dgw - (int32_t)o_hi) : 0;
-                const int32_t cz = own ? (ofwd ? o_dgw + (int32_t)o_hi : o_dgw - (int32_t)o_lo) : 0;
-                const uint32_t need = 0xffffffffu >> (31u - (uint32_t)(cz - ca));   // (at most k <= 31 cells)
-                const uint2 ba = blkw[ca >> 6], bz = blkw[cz >> 6];
-                const bool fast = own && (bits32_at(fastw, ca) & need) == need && ba.x == bz.x && !BK_ABLATE(a, 5);   // (5: every N run to nbatch_kernel)
-                {
-                    // which of the three other bases: read XOR reference at the mismatch, the same on either strand (bk_device.h)
-                    const uint32_t tt = fast && has_s ? (uint32_t)t : 0u;
-                    const uint32_t rw = (words0 + (uint64_t)o_rec * a.stride_words)[min(tt >> 4, last_word)];
-                    const int32_t pr = fast && has_s ? (ofwd ? o_dgw + (int32_t)tt : o_dgw + (int32_t)km1 - (int32_t)tt) : 0;
-                    const uint32_t refb = (refw1[pr >> 4] >> (2u * ((uint32_t)pr & 15u))) & 3u;
-                    const uint32_t alt = ((((rw >> (2u * (tt & 15u))) & 3u) ^ (ofwd ? refb : 3u - refb)) & 3u) - 1u;
-                    const uint32_t tpos = tt - o_lo, nm1 = s_hi - o_lo;   // offset of the differing base in the run's first k-mer
-                    // offsets (along the reference, from each k-mer's start) the run's k-mers have the difference at
-                    const uint32_t of_first = ofwd ? tpos : km1 - tpos;
-                    const uint32_t of_lo = ofwd ? tpos - nm1 : of_first;       // fwd: later k-mers start later, the offset shrinks
-                    const uint32_t of_hi = ofwd ? tpos : of_first + nm1;
-                    const int lo2 = max((int)of_lo, omin), hi2 = min((int)of_hi, omin + span - 1);
-                    if (fast && has_s && lo2 <= hi2 && !BK_ABLATE(a, 2)) {
-                        const uint32_t idS = (uint32_t)(ofwd ? ca : cz) + win_lo + ba.x;   // id of the cell of k-mer o_lo (cell_fast: ids = cell + constant)
-                        unsigned long long* row = v_counters + v_row_base(idS + of_first - (uint32_t)omin, alt, ofwd ? 0u : 1u, span);
-                        if constexpr (SPARSE) touch(a.touch_v, v_row_index(idS + of_first - (uint32_t)omin, alt, ofwd ? 0u : 1u));
-                        atomicAdd(row + (lo2 - omin), 1ull);
-                        if (hi2 - omin + 1 < span) atomicAdd(row + (hi2 - omin + 1), ~0ull);   // (slot `span` is never read)
+                const uint32_t n_own = own ? o_hi - o_lo + 1u : 0u;           // (at most k <= 31)
+                uint32_t pat = bits32_at(fastw, ca) & ((1u << n_own) - 1u);   // bit p: the cell ca + p is fast
+                if (BK_ABLATE(a, 5)) pat = 0u;                                // (5: nothing is settled here)
+                // which of the three other bases: read XOR reference at the mismatch, the same on either strand (bk_device.h)
+                const uint32_t tt = own ? (uint32_t)t : 0u;
+                const uint32_t rw = (words0 + (uint64_t)o_rec * a.stride_words)[min(tt >> 4, last_word)];
+                const int32_t pr = own ? (ofwd ? o_dgw + (int32_t)tt : o_dgw + (int32_t)km1 - (int32_t)tt) : 0;
+                const uint32_t refb = (refw1[pr >> 4] >> (2u * ((uint32_t)pr & 15u))) & 3u;
+                const uint32_t alt = ((((rw >> (2u * (tt & 15u))) & 3u) ^ (ofwd ? refb : 3u - refb)) & 3u) - 1u;
+                uint32_t used = 0u;   // cells of the range already dealt with
+                while (__ballot(used < n_own)) {
+                    const bool go = used < n_own;
+                    const uint32_t rest = pat >> used;
+                    const bool ones = rest & 1u;
+                    // the stretch of equal bits at `used`: cells ca + used .. ca + used + ln - 1
+                    const uint32_t ln = go ? min((uint32_t)__builtin_ctz((ones ? ~rest : rest) | (1u << (n_own - used))), n_own - used) : 0u;
+                    const int32_t c0 = ca + (int32_t)used, c1 = c0 + (int32_t)ln - 1;
+                    // ... are the k-mers [x_lo, x_hi] (a read against the reference meets the cells from the top)
+                    const uint32_t x_lo = ofwd ? o_lo + used : o_hi + 1u - used - ln, x_hi = x_lo + ln - 1u;
+                    const uint2 ba = blkw[(go ? c0 : 0) >> 6], bz = blkw[(go ? c1 : 0) >> 6];
+                    const bool fast = go && ones && ba.x == bz.x;
+                    // of these, [x_lo, xs_hi] hold nothing but t -- an S run -- and [xm_lo, x_hi] also hold the next mismatch
+                    const int32_t xs_hi_i = min((int32_t)x_hi, tn - k);
+                    const bool has_s = fast && xs_hi_i >= (int32_t)x_lo;
+                    const uint32_t xs_hi = has_s ? (uint32_t)xs_hi_i : x_lo;
+                    const uint32_t xm_lo = (uint32_t)max((int32_t)x_lo, tn - (int32_t)km1);
+                    const bool has_m = fast && xm_lo <= x_hi;
+                    {
+                        const uint32_t tpos = tt - x_lo, nm1 = xs_hi - x_lo;   // offset of the differing base in the run's first k-mer
+                        // offsets (along the reference, from each k-mer's start) the run's k-mers have the difference at
+                        const uint32_t of_first = ofwd ? tpos : km1 - tpos;
+                        const uint32_t of_lo = ofwd ? tpos - nm1 : of_first;       // fwd: later k-mers start later, the offset shrinks
+                        const uint32_t of_hi = ofwd ? tpos : of_first + nm1;
+                        const int lo2 = max((int)of_lo, omin), hi2 = min((int)of_hi, omin + span - 1);
+                        if (has_s && lo2 <= hi2 && !BK_ABLATE(a, 2)) {
+                            const uint32_t idS = (uint32_t)(ofwd ? c0 : c1) + win_lo + ba.x;   // id of the cell of k-mer x_lo (cell_fast: ids = cell + constant)
+                            unsigned long long* row = v_counters + v_row_base(idS + of_first - (uint32_t)omin, alt, ofwd ? 0u : 1u, span);
+                            if constexpr (SPARSE) touch(a.touch_v, v_row_index(idS + of_first - (uint32_t)omin, alt, ofwd ? 0u : 1u));
+                            atomicAdd(row + (lo2 - omin), 1ull);
+                            if (hi2 - omin + 1 < span) atomicAdd(row + (hi2 - omin + 1), ~0ull);   // (slot `span` is never read)
+                        }
                     }
+                    {
+                        // The k-mers that hold t and its successor.  If none of them reaches the successor after that and each of their
+                        // cells has no other reference k-mer form within Hamming distance 3, they hold exactly two differences from a
+                        // reference k-mer that is isolated up to distance 3: neither a reference k-mer nor one base away from one
+                        // (triangle inequality) -- they touch nothing.  Otherwise level2_kernel looks at them one by one.
+                        const int32_t ma = has_m ? (ofwd ? o_dgw + (int32_t)xm_lo : o_dgw - (int32_t)x_hi) : 0;
+                        const uint32_t needm = has_m ? 0xffffffffu >> (31u - (x_hi - xm_lo)) : 0u;
+                        const bool dead = !stats && tn2 - (int32_t)km1 > (int32_t)x_hi && (bits32_at(c3w, ma) & needm) == needm;
+                        l2_mark(has_m && !dead, o_rec, xm_lo, x_hi + 1u - xm_lo, o_dgw + (int32_t)win_lo, o_fl);
+                    }
+                    // cells that are not fast
+                    l2_mark(go && !fast, o_rec, x_lo, ln, o_dgw + (int32_t)win_lo, o_fl);
+                    used += ln;
                 }
-                {
-                    // The k-mers that hold t and its successor.  If none of them reaches the successor after that and each of their cells
-                    // has no other reference k-mer form within Hamming distance 3, they hold exactly two differences from a reference
-                    // k-mer that is isolated up to distance 3: neither a reference k-mer nor one base away from one (triangle
-                    // inequality) -- they touch nothing.  Otherwise level2_kernel looks at them one by one.
-                    const bool mm = fast && has_m;
-                    const int32_t ma = mm ? (ofwd ? o_dgw + (int32_t)m_lo : o_dgw - (int32_t)o_hi) : 0;
-                    const uint32_t needm = mm ? 0xffffffffu >> (31u - (o_hi - m_lo)) : 0u;
-                    const bool dead = !stats && tn2 - (int32_t)km1 > (int32_t)o_hi && (bits32_at(c3w, ma) & needm) == needm;
-                    l2_mark(mm && !dead, o_rec, m_lo, o_hi + 1u - m_lo, o_dgw + (int32_t)win_lo, o_fl);
-                }
-                // cells that are not fast: the whole range is an N run for nbatch_kernel
-                n_mark(own && !fast, o_rec, o_lo, o_hi + 1u - o_lo, o_dgw + (int32_t)win_lo, o_fl);
             }
             // each lane: its last resolved mismatch; what is not resolved stays
             if (cnt) tp = (int32_t)cb + (r4 ? 159 - (int32_t)__builtin_clz(r4) : M23 ? 127 - (int32_t)__builtin_clzll(M23) : 63 - (int32_t)__builtin_clzll(M01));

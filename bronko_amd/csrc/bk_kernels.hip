@@ -362,7 +362,12 @@ constexpr int kRefPadWords = 4;             // words of padding in front of the 
 constexpr int kRefBackWords = 6;            // ... and behind them (96 cells)
 constexpr int kBitPadWords = 2;             // the same 64 cells for the 1-bit per-cell arrays
 constexpr int kBitBackWords = 3;
-constexpr size_t kScanLdsFixed = 16 + 64 + 4 * kScanBlock + 8;   // k-mer tally, wave totals of the epilogue, the item owners, alignment of the block entries
+// A sample's true variants put thousands of reads on the same few V counters -- every read that covers a fixed SNP adds 1 to one
+// and the same counter --, and same-address global atomics serialise at ~12 ns each: 0.02 ms of the kernel on the benchmark's 40
+// variant sites.  So a workgroup keeps the counters it meets a second time in a small LDS table (direct-mapped; a filter of one
+// bit per hash value says "met before") and adds its totals once at the end; everything else goes out as before.
+constexpr uint32_t kHotSlots = 256, kSeenWords = 1024;
+constexpr size_t kScanLdsFixed = 16 + 64 + 4 * kScanBlock + 4 * (2 * kHotSlots + kSeenWords) + 8;   // k-mer tally, wave totals of the epilogue, the item owners, the hot counters, alignment of the block entries
 
 // number of set bits of a wave mask below this lane
 __device__ __forceinline__ uint32_t lane_prefix(unsigned long long m) {
@@ -538,7 +543,10 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     unsigned int* block_kmers = reinterpret_cast<unsigned int*>(smem);   // 16 B reserved
     unsigned int* scan_tmp = block_kmers + 4;       // 16 words: wave totals of the epilogue's prefix sum
     unsigned int* own_all = scan_tmp + 16;          // [16 waves][64] which lane owns each of the items of a pass (below)
-    unsigned int* bins = own_all + kScanBlock;      // [n_lds_bins + 1] the per-cell difference array
+    unsigned int* hot_key = own_all + kScanBlock;   // [kHotSlots] V counters this workgroup adds to again and again (below), ~0 = free
+    unsigned int* hot_cnt = hot_key + kHotSlots;    // [kHotSlots] ... and what it has for them
+    unsigned int* seen = hot_cnt + kHotSlots;       // [kSeenWords] one bit per hash value: a +1 for such a counter was issued before
+    unsigned int* bins = seen + kSeenWords;         // [n_lds_bins + 1] the per-cell difference array
     unsigned int* lds_ref = bins + a.n_lds_bins + 1;   // REF_LDS: padded ref words, the padded fast-bit array, the block entries
 
     const int lane = threadIdx.x & 63;
@@ -555,8 +563,10 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     const uint32_t n_refw = kRefPadWords + (lds_cells + 15) / 16 + kRefBackWords;
     const uint32_t n_bitw = kBitPadWords + (lds_cells + 31) / 32 + kBitBackWords;
     const uint32_t n_blk = (lds_cells + 63) / 64 + 2;
-    const uint32_t blk_w0 = (a.n_lds_bins + 1 + n_refw + 2u * n_bitw + 1u) & ~1u;   // (8-byte aligned: smem + 4176 bytes + 4 * blk_w0)
+    const uint32_t blk_w0 = (a.n_lds_bins + 1 + n_refw + 2u * n_bitw + 1u) & ~1u;   // (8-byte aligned: bins starts at a multiple of 16 bytes)
     for (uint32_t i = threadIdx.x; i <= a.n_lds_bins; i += kScanBlock) bins[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < kHotSlots; i += kScanBlock) { hot_key[i] = 0xffffffffu; hot_cnt[i] = 0u; }
+    for (uint32_t i = threadIdx.x; i < kSeenWords; i += kScanBlock) seen[i] = 0u;
     if (REF_LDS) {
         for (uint32_t i = threadIdx.x; i < n_refw; i += kScanBlock) lds_ref[i] = a.ref_words[(win_lo >> 4) + i];
         for (uint32_t i = threadIdx.x; i < n_bitw; i += kScanBlock) lds_ref[n_refw + i] = a.cell_fast[(win_lo >> 5) + i];
@@ -867,10 +877,20 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                         const int lo2 = max((int)of_lo, omin), hi2 = min((int)of_hi, omin + span - 1);
                         if (has_s && lo2 <= hi2 && !BK_ABLATE(a, 2)) {
                             const uint32_t idS = (uint32_t)(ofwd ? c0 : c1) + win_lo + ba.x;   // id of the cell of k-mer x_lo (cell_fast: ids = cell + constant)
-                            unsigned long long* row = v_counters + v_row_base(idS + of_first - (uint32_t)omin, alt, ofwd ? 0u : 1u, span);
+                            const uint64_t ci = v_row_base(idS + of_first - (uint32_t)omin, alt, ofwd ? 0u : 1u, span) + (uint32_t)(lo2 - omin);
                             if constexpr (SPARSE) touch(a.touch_v, v_row_index(idS + of_first - (uint32_t)omin, alt, ofwd ? 0u : 1u));
-                            atomicAdd(row + (lo2 - omin), 1ull);
-                            if (hi2 - omin + 1 < span) atomicAdd(row + (hi2 - omin + 1), ~0ull);   // (slot `span` is never read)
+                            // the +1: into the workgroup's table when this counter was met before and its slot is free or its own
+                            const uint32_t hk = (uint32_t)ci * 0x9E3779B1u;
+                            const uint32_t sbit = 1u << (hk >> 27);
+                            bool kept = false;
+                            if (!BK_ABLATE(a, 10) && (__hip_atomic_fetch_or(&seen[(hk >> 17) & (kSeenWords - 1u)], sbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & sbit)) {
+                                const uint32_t hs = (hk >> 9) & (kHotSlots - 1u);
+                                unsigned int expect = 0xffffffffu;
+                                kept = __hip_atomic_compare_exchange_strong(&hot_key[hs], &expect, (uint32_t)ci, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) || expect == (uint32_t)ci;
+                                if (kept) __hip_atomic_fetch_add(&hot_cnt[hs], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                            if (!kept) atomicAdd(v_counters + ci, 1ull);
+                            if (hi2 - omin + 1 < span) atomicAdd(v_counters + ci + (uint32_t)(hi2 - lo2 + 1), ~0ull);   // (slot `span` is never read)
                         }
                     }
                     {
@@ -902,6 +922,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     // ---- epilogue: difference array -> per-cell counts (prefix sum over the workgroup), written as this workgroup's slab ----
     if (threadIdx.x == 0) *block_kmers = 0;
     __syncthreads();
+    if (threadIdx.x < kHotSlots && hot_cnt[threadIdx.x]) atomicAdd(v_counters + hot_key[threadIdx.x], (unsigned long long)hot_cnt[threadIdx.x]);   // the table's totals
     if (!BK_ABLATE(a, 8)) {   // (8: without the prefix sum and the slab)
         const uint32_t nb = a.n_lds_bins;
         const uint32_t per = (nb + kScanBlock - 1) / kScanBlock;

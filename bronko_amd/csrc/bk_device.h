@@ -72,6 +72,18 @@ constexpr uint32_t kCellClean = 4u, kCellClean3 = 8u, kCellFirstOri = 16u;
 BK_HD size_t ans_index(uint32_t id, uint32_t o, uint32_t b, int k) { return (((size_t)id + o) * 4u + b) * (size_t)k + o; }
 BK_HD size_t ans_table_len(uint32_t n_full, int k) { return ((size_t)n_full + (size_t)k) * 4u * (size_t)k; }
 
+// Seed tables of the scan (one per genome file; IndexView::seed_tab): 2^seed_log2 buckets of two entries,
+//   entry = cell (27 bits) | rc << 27 | tag << 28      (~0 = free)
+// for the reference k-mers of that file -- cell where one starts, rc = it was reverse-complemented to become canonical, tag =
+// the low 4 bits of seed_hash(canonical k-mer), bucket = its top seed_log2 bits.  No key is stored: a candidate is verified
+// against the reference itself (the scan has it in LDS).  A k-mer whose bucket was full when it came is not in the table; the
+// scan then falls back on the perfect hash of U.
+BK_HD uint32_t seed_hash(uint64_t x) {
+    uint32_t h = (uint32_t)x * 0x9E3779B1u + (uint32_t)(x >> 32) * 0x85EBCA6Bu;
+    return h ^ (h >> 15);
+}
+constexpr uint32_t kSeedCellBits = 27;
+
 // Multiplicative hash into a table of 2^log2s positions.
 BK_HD uint32_t hash_key(uint64_t key, uint32_t log2s) {
     return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - log2s));
@@ -164,6 +176,8 @@ struct IndexView {
     const uint32_t*  id_at;       // [total_cells] id of the k-mer starting at cell q (0xffffffff: none)
     const uint32_t*  cell_fast;   // 1 bit per cell, layout of cell_has: the k-mer that starts at q is in U, "clean", and its id is
                                   // q + cell_blk[q >> 6].x (modulo 2^32) -- what the scan needs to count an isolated mismatch on the spot
+    const uint2*     seed_tab;    // [n_files << seed_log2] the scan's seed tables (see seed_hash), or null (index too large)
+    uint32_t         seed_log2;
     const uint2*     cell_blk;    // per block of 64 cells (two entries of padding behind): x = id_at[q] - q of the block's first clean
                                   // cell; y = the first cell >= 64 * block at which no k-mer of U starts (sequence tails)
     uint32_t total_cells;

@@ -269,7 +269,8 @@ struct bk_engine {
     DevBuf<bk::DirtyAns> dirty_ans;
     DevBuf<uint8_t> cell_flags;
     DevBuf<uint32_t> ref_words, cell_codes, cell_has, cell_clean, cell_clean3, cell_yf, cell_yr, id_at, cell_fast;
-    DevBuf<uint2> cell_blk;
+    DevBuf<uint2> cell_blk, seed_tab;
+    uint32_t seed_log2 = 0;
     struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0, log2p = 0; } half_lo, half_hi;
     DevBuf<unsigned int> deferred, n_deferred;
     DevBuf<unsigned long long> deferred_n;   // dense planes: the deferred k-mers' counts (K2a zeroes the counters it reads)
@@ -366,7 +367,7 @@ struct bk_engine {
     bk::IndexView view() const {
         bk::IndexView v{};
         v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb; v.log2p = log2p;
-        v.kmer_of = kmer_of.p; v.id_rec = id_rec.p; v.dirty_ans = dirty_ans.p; v.cell_flags = cell_flags.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_clean3 = cell_clean3.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.cell_fast = cell_fast.p; v.cell_blk = cell_blk.p; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
+        v.kmer_of = kmer_of.p; v.id_rec = id_rec.p; v.dirty_ans = dirty_ans.p; v.cell_flags = cell_flags.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_clean3 = cell_clean3.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.cell_fast = cell_fast.p; v.cell_blk = cell_blk.p; v.seed_tab = seed_tab.p; v.seed_log2 = seed_log2; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
         v.n_full = n_full; v.n_prows = n_prows; v.prow_id = prow_id.p; v.prow_t = prow_t.p; v.v_omin = v_omin; v.v_span = v_span; v.v_off = v_off;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb, half_lo.log2p};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb, half_hi.log2p};
@@ -1175,6 +1176,34 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         BK_HIP(e->id_at.upload(h_id_at));
         e->file_cell_lo.assign((size_t)ix->n_files, 0u);
         for (int f = 0; f < ix->n_files; f++) e->file_cell_lo[f] = ix->n_seqs[f] ? (uint32_t)cell_off[f][0] : (uint32_t)cells;
+        // the scan's seed tables (bk_device.h seed_hash): per genome file, where each of its reference k-mers starts
+        if (cells > 0 && cells < (1ull << bk::kSeedCellBits) && e->n_full > 0) {
+            uint64_t max_file_cells = 1;
+            for (int f = 0; f < ix->n_files; f++)
+                max_file_cells = std::max<uint64_t>(max_file_cells, (f + 1 < ix->n_files ? e->file_cell_lo[f + 1] : cells) - e->file_cell_lo[f]);
+            uint32_t L = 6;
+            while ((1ull << L) < max_file_cells) L++;
+            if (((uint64_t)ix->n_files << L) * sizeof(uint2) <= (8ull << 30)) {
+                e->seed_log2 = L;
+                std::vector<uint2> h_seed((size_t)ix->n_files << L, make_uint2(0xffffffffu, 0xffffffffu));
+                parallel_for((size_t)ix->n_files, [&](size_t f0, size_t f1) {
+                    for (size_t f = f0; f < f1; f++) {
+                        const uint64_t c_lo = e->file_cell_lo[f], c_hi = f + 1 < (size_t)ix->n_files ? e->file_cell_lo[f + 1] : cells;
+                        for (uint64_t c = c_lo; c < c_hi; c++) {
+                            const uint32_t id = h_id_at[c];
+                            if (id == kNone || id >= e->n_full) continue;
+                            const uint32_t h = bk::seed_hash(h_kmer_of[id]);
+                            const uint32_t ent = (uint32_t)c | (((h_brc[c >> 5] >> (c & 31)) & 1u) << bk::kSeedCellBits) | ((h & 15u) << 28);
+                            uint2& b = h_seed[(f << L) + (h >> (32 - L))];
+                            auto same = [&](uint32_t o) { return o != 0xffffffffu && h_id_at[o & ((1u << bk::kSeedCellBits) - 1u)] == id; };   // (a repeat: one entry does)
+                            if (same(b.x) || same(b.y)) continue;
+                            if (b.x == 0xffffffffu) b.x = ent; else if (b.y == 0xffffffffu) b.y = ent;   // (else: not in the table)
+                        }
+                    }
+                });
+                BK_HIP(e->seed_tab.upload(h_seed));
+            }
+        }
         if (ix->n_files > 1 && (uint64_t)e->n_full * (uint64_t)ix->n_files <= (1ull << 28)) {
             std::vector<uint32_t> h_occ((size_t)e->n_full * ix->n_files, 0xffffffffu);
             for (int f = 0; f < ix->n_files; f++) {
@@ -1382,7 +1411,7 @@ int bk_engine_fork_params(const bk_engine* parent, const bk_params* prm, bk_engi
     e->prow_id.alias(p->prow_id); e->prow_t.alias(p->prow_t); e->kmer_pos.alias(p->kmer_pos); e->d_view.alias(p->d_view); e->kmer_of.alias(p->kmer_of); e->id_rec.alias(p->id_rec); e->dirty_ans.alias(p->dirty_ans); e->cell_flags.alias(p->cell_flags);
     e->ref_words.alias(p->ref_words); e->cell_codes.alias(p->cell_codes); e->cell_has.alias(p->cell_has); e->cell_clean.alias(p->cell_clean);
     e->cell_clean3.alias(p->cell_clean3); e->cell_yf.alias(p->cell_yf); e->cell_yr.alias(p->cell_yr); e->id_at.alias(p->id_at);
-    e->cell_fast.alias(p->cell_fast); e->cell_blk.alias(p->cell_blk);
+    e->cell_fast.alias(p->cell_fast); e->cell_blk.alias(p->cell_blk); e->seed_tab.alias(p->seed_tab); e->seed_log2 = p->seed_log2;
     e->half_lo.pilots.alias(p->half_lo.pilots); e->half_lo.dir.alias(p->half_lo.dir); e->half_lo.cand.alias(p->half_lo.cand);
     e->half_hi.pilots.alias(p->half_hi.pilots); e->half_hi.dir.alias(p->half_hi.dir); e->half_hi.cand.alias(p->half_hi.cand);
     e->slot_of.alias(p->slot_of); e->estat_off.alias(p->estat_off); e->estat.alias(p->estat); e->slot_rec.alias(p->slot_rec); e->amb.alias(p->amb);
@@ -1531,7 +1560,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.n_records_dev = n_records_dev;
     a.ixp = e->d_view.p;
     a.k = e->k; a.wstart = e->wstart; a.W = e->W; a.v_omin = e->v_omin; a.v_span = e->v_span; a.v_off = e->v_off; a.total_cells = (uint32_t)e->total_cells; a.n_u = e->n_u;
-    a.ref_words = e->ref_words.p; a.cell_codes = e->cell_codes.p; a.cell_has = e->cell_has.p; a.cell_clean = e->cell_clean.p; a.cell_clean3 = e->cell_clean3.p; a.cell_yf = e->cell_yf.p; a.cell_yr = e->cell_yr.p; a.id_at = e->id_at.p; a.cell_fast = e->cell_fast.p; a.cell_blk = e->cell_blk.p;
+    a.ref_words = e->ref_words.p; a.cell_codes = e->cell_codes.p; a.cell_has = e->cell_has.p; a.cell_clean = e->cell_clean.p; a.cell_clean3 = e->cell_clean3.p; a.cell_yf = e->cell_yf.p; a.cell_yr = e->cell_yr.p; a.id_at = e->id_at.p; a.cell_fast = e->cell_fast.p; a.cell_blk = e->cell_blk.p; a.seed_tab = e->seed_tab.p; a.seed_log2 = e->seed_log2;
     a.words = d_words; a.lens = d_lens; a.n_records = n; a.stride_words = stride_words;
     a.counters = e->counters[mate].p;
     a.kmer_total = e->kstats.p + mate * 4 + 1;

@@ -23,6 +23,8 @@ struct ScanArgs {
     const uint32_t* id_at;
     const uint32_t* cell_fast;      // IndexView::cell_fast (1 bit per cell, padded like cell_has) / cell_blk (one entry per 64 cells)
     const uint2* cell_blk;
+    const uint2* seed_tab;          // IndexView::seed_tab / seed_log2
+    uint32_t seed_log2;
     const uint32_t* words;          // [n_records][stride_words] 2-bit packed, 16 bases per word, LSB first
     const uint16_t* lens;           // [n_records] valid bases
     uint64_t rec_base;              // this launch covers records [rec_base, rec_base + n_records)

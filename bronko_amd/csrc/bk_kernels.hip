@@ -629,6 +629,10 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     const uint64_t n_tiles = (n_records + 63) / 64;
     uint32_t pf_sink = 0;               // destination of the prefetch loads (never read)
     constexpr uint32_t kNoPos = 0x40000000u;
+    // the seed table of the window's genome, and where the seeds sit: evenly spaced over the launch's first record
+    const uint2* const seed_tab = a.seed_tab ? a.seed_tab + ((size_t)win_file << a.seed_log2) : nullptr;
+    const uint32_t hint_len = n_records ? (uint32_t)__builtin_amdgcn_readfirstlane((int)lens0[0]) : 0u;
+    const uint32_t hint_span = hint_len >= (uint32_t)k ? hint_len - (uint32_t)k : 0u;
 
     for (uint64_t tile = (uint64_t)blockIdx.x * kScanWaves + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * kScanWaves) {
         const uint64_t r = tile * 64 + lane;
@@ -655,14 +659,64 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
         // ---- seeds -> diagonal ----------------------------------------------------------------------------------
         bool fwd = true, seeded = false, l1ok = false;   // seeded: diagonal known; l1ok: ... and all its cells are in the LDS window
         int32_t dg = 0;                                  // cell of the reference k-mer aligned with read k-mer 0: k-mer s <-> dg + s (fwd) / dg - s
-        // round 0: kSeeds k-mers evenly spaced from the first to the last; round 1, only when some lane found nothing (an
-        // error in every seed: one read in 10^4 at 0.5 % errors): the midpoints between them.  A read without a diagonal costs
-        // ~100 slow-path searches, so the rare second round pays.  (Two seeds per round and more rounds -- 2.95 lookups per read
+        // a candidate diagonal: the whole read must lie on the reference (hi_cell + k <= total); to be settled here its cells must lie
+        // in the LDS window and each of them must carry a reference k-mer (no sequence tail in between: cell_blk)
+        uint32_t best_cell = 0xffffffffu;
+        auto candidate = [&](bool hit, uint32_t scell, bool f, uint32_t s) {
+            if (hit && scell < best_cell) {   // several seeds may hit (usually all, on one diagonal); prefer the lowest cell
+                const int64_t d0 = f ? (int64_t)scell - (int64_t)s : (int64_t)scell + (int64_t)s;
+                const int64_t lo_cell = f ? d0 : d0 - (int64_t)(len - (uint32_t)k);
+                const int64_t hi_cell = f ? d0 + (int64_t)(len - (uint32_t)k) : d0;
+                if (lo_cell >= 0 && hi_cell + k <= (int64_t)total) {
+                    best_cell = scell; dg = (int32_t)d0; fwd = f; seeded = true;
+                    l1ok = lo_cell >= (int64_t)win_lo && hi_cell < (int64_t)win_lo + (int64_t)a.n_lds_bins;
+                    if (l1ok) l1ok = (uint32_t)hi_cell < blkw[((uint32_t)lo_cell >> 6) - (win_lo >> 6)].y;
+                }
+            }
+        };
+        // First the seed table of the window's genome (bk_device.h seed_hash): kSeeds k-mers at positions that do not depend on the
+        // read's length (evenly spaced over the launch's first record: the length load and the seeds' word loads go out together),
+        // one 8-byte bucket each, and the candidate it names is verified against the reference in LDS -- two trips to memory where
+        // the perfect hash of U takes four (length, words, pilot, entry; a fifth for the window genome's copy, occ).
+        if (seed_tab && !BK_ABLATE(a, 9) && !BK_ABLATE(a, 11)) {
+            uint64_t sg[kSeeds], sff[kSeeds];
+            uint32_t sh[kSeeds], sis[kSeeds];
+            uint2 sb[kSeeds];
+#pragma unroll
+            for (int sq = 0; sq < kSeeds; ++sq) {
+                const uint32_t s = (hint_span * (uint32_t)sq) / (uint32_t)(kSeeds - 1);   // (wave-uniform)
+                const uint64_t g = read_symbols_at(w, s, last_word) & kmask;       // base t of the k-mer at bits 2t
+                const uint64_t rr = ~g & kmask;                                      // its reverse complement, first base on top
+                const uint64_t ff = rev2_64(g) >> (64 - 2 * k);                      // the k-mer, first base on top
+                const bool lt = ff < rr;                                             // lcb.rs:90-94
+                sg[sq] = g; sff[sq] = ff; sis[sq] = lt ? 0u : 1u;
+                sh[sq] = seed_hash(lt ? ff : rr);
+                sb[sq] = seed_tab[sh[sq] >> (32u - a.seed_log2)];
+            }
+#pragma unroll
+            for (int sq = 0; sq < kSeeds; ++sq) {
+                const uint32_t s = (hint_span * (uint32_t)sq) / (uint32_t)(kSeeds - 1);
+                const uint32_t tag = sh[sq] & 15u;
+                const uint32_t ent = (sb[sq].x != 0xffffffffu && (sb[sq].x >> 28) == tag) ? sb[sq].x : sb[sq].y;
+                const uint32_t cell = ent & ((1u << kSeedCellBits) - 1u), rc = (ent >> kSeedCellBits) & 1u;
+                // in reach of the staged reference?  (REF_LDS: the window's cells and 64 in front)
+                const bool in_ref = ent != 0xffffffffu && (ent >> 28) == tag && len != 0u && s + (uint32_t)k <= len &&
+                                    cell + 64u >= win_lo && cell + (uint32_t)k <= win_lo + lds_cells;
+                const int32_t cw = in_ref ? (int32_t)cell - (int32_t)win_lo : 0;
+                const uint64_t ref = symbols_at(refw1, cw) & kmask;                  // reference base cell + t at bits 2t
+                const bool same = sis[sq] == rc;                                     // same strand as the reference?
+                candidate(in_ref && ref == (same ? sg[sq] : (~sff[sq] & kmask)), cell, same, s);
+            }
+        }
+        // The lanes that are still without a diagonal (an error in every seed, a k-mer that found its bucket full, a read shorter
+        // than the first record, no seed table): the perfect hash of U.  Round 0: kSeeds k-mers evenly spaced from the read's first
+        // to its last; round 1, only when some lane found nothing again: the midpoints between them.  A read without a diagonal
+        // costs ~100 slow-path searches, so the rare rounds pay.  (Two seeds per round and more rounds -- 2.95 lookups per read
         // instead of 4.02 -- was measured in round 2 and is slower, 0.155 against 0.139 ms: half of the tiles then pay a second
         // chain of dependent loads; the seeds are latency, not instructions.)
         for (int round = 0; round < 2 && !BK_ABLATE(a, 9); ++round) {   // (9: no seeds at all, 7: nothing behind them, 6: no mismatch loop)
-            if (round == 1 && !__ballot(len != 0u && !seeded)) break;
-            const bool had = seeded;   // round 1 is for the lanes round 0 left without a diagonal
+            if (!__ballot(len != 0u && !seeded)) break;
+            const bool had = seeded;   // a round is for the lanes left without a diagonal so far
             uint64_t sc[kSeeds];
             uint32_t sisrc[kSeeds], spil[kSeeds], spos[kSeeds];
 #pragma unroll
@@ -693,27 +747,11 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 if (a.occ && shit[sq] && (se[sq].w & kIdMask) < ix.n_full)
                     soc[sq] = a.occ[(size_t)(se[sq].w & kIdMask) * (uint32_t)a.n_files + win_file];
             }
-            uint32_t best_cell = 0xffffffffu;
 #pragma unroll
             for (int sq = 0; sq < kSeeds; ++sq) {
-                const uint32_t s = spos[sq];
                 uint32_t scell = se[sq].z, src_rc = se[sq].w >> 31;   // where the seed sits: the k-mer's first occurrence ...
-                const bool hit = shit[sq];
                 if (soc[sq] != 0xffffffffu) { scell = soc[sq] & 0x7fffffffu; src_rc = soc[sq] >> 31; }   // ... or its occurrence in the window's genome
-                if (hit && scell < best_cell) {
-                    // several seeds may hit (usually all, on one diagonal); prefer the lowest cell
-                    const bool f = sisrc[sq] == src_rc;        // same strand as the reference?
-                    const int64_t d0 = f ? (int64_t)scell - (int64_t)s : (int64_t)scell + (int64_t)s;
-                    const int64_t lo_cell = f ? d0 : d0 - (int64_t)(len - (uint32_t)k);
-                    const int64_t hi_cell = f ? d0 + (int64_t)(len - (uint32_t)k) : d0;
-                    // the whole read must lie on the reference (hi_cell + k <= total); to be settled here its cells must lie in the
-                    // LDS window and each of them must carry a reference k-mer (no sequence tail in between: cell_blk)
-                    if (lo_cell >= 0 && hi_cell + k <= (int64_t)total) {
-                        best_cell = scell; dg = (int32_t)d0; fwd = f; seeded = true;
-                        l1ok = lo_cell >= (int64_t)win_lo && hi_cell < (int64_t)win_lo + (int64_t)a.n_lds_bins;
-                        if (l1ok) l1ok = (uint32_t)hi_cell < blkw[((uint32_t)lo_cell >> 6) - (win_lo >> 6)].y;
-                    }
-                }
+                candidate(shit[sq], scell, sisrc[sq] == src_rc, spos[sq]);
             }
         }
         const uint32_t dfl = (fwd ? 1u : 0u) | (seeded ? 2u : 0u);

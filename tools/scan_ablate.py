@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Scan kernel time under the ablation switches of the -DBK_TESTING build (BK_SCAN_ABLATE: 2 = no V atomics, 5 = every N run to
-level2_kernel, 6 = no mismatch loop, 10 = no table of hot V counters, 7 = seeds only, 9 = not even the seeds, 8 = without prefix sum and slab, 4 = without Level 2)
+level2_kernel, 6 = no mismatch loop, 10 = no table of hot V counters, 11 = no seed table, 7 = seeds only, 9 = not even the seeds, 8 = without prefix sum and slab, 4 = without Level 2)
 for config 2 or 3 shapes.  usage: tools/scan_ablate.py [2|3] [switches, comma separated]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,7 +23,7 @@ else:
     mates = list(synth.paired_codes_torch(g, n, 150, 3, isnv=isnv, device=dev))
 packed = [synth.pack_codes_torch(c) for c in mates]
 torch.cuda.synchronize()
-for ab in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("0", "10", "2", "6", "7", "9", "8")):
+for ab in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("0", "11", "10", "2", "6", "7", "9")):
     os.environ["BK_SCAN_ABLATE"] = ab
     ix = HostIndex.build(21, paths, threads=4)
     eng = ix.engine(Params())

@@ -1697,20 +1697,19 @@ int bk_push_reads_ascii(bk_engine* e, int mate, const uint8_t* buf, const uint64
     if (sl.d_off.n < n_reads + 1) BK_HIP(sl.d_off.alloc(n_reads + n_reads / 4 + 1024));
     if (sl.d_words.n < cap * stride) BK_HIP(sl.d_words.alloc(cap * stride + cap * stride / 4));
     if (sl.d_lens.n < cap) BK_HIP(sl.d_lens.alloc(cap + cap / 4));
-    if (!sl.d_nrec.p) BK_HIP(sl.d_nrec.alloc(1));
+    if (!sl.d_nrec.p) BK_HIP(sl.d_nrec.alloc(2));
 
     BK_HIP(hipMemcpyAsync(sl.d_bases.p, sl.h_bases, total, hipMemcpyHostToDevice, e->copy_stream));
     BK_HIP(hipMemcpyAsync(sl.d_off.p, sl.h_off, (n_reads + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, e->copy_stream));
     BK_HIP(hipEventRecord(sl.uploaded, e->copy_stream));
     BK_HIP(hipStreamWaitEvent(e->stream, sl.uploaded, 0));
-    BK_HIP(hipMemsetAsync(sl.d_nrec.p, 0, sizeof(unsigned long long), e->stream));
     {
         bk::PackArgs pa{};
         pa.bases = sl.d_bases.p; pa.offsets = sl.d_off.p; pa.n_reads = n_reads; pa.k = e->k; pa.stride_words = stride;
         pa.words = sl.d_words.p; pa.lens = sl.d_lens.p; pa.cap = cap; pa.n_records = sl.d_nrec.p;
         bk_engine::Span sp(e, 2);
         bk::launch_pack_reads(pa, e->stream);
-        bk::launch_add_u64(e->kstats.p + mate * 4 + 0, sl.d_nrec.p, e->stream);   // records pushed, tallied on the device
+        bk::launch_add_u64(e->kstats.p + mate * 4 + 0, sl.d_nrec.p + 1, e->stream);   // records pushed, tallied on the device
     }
     int rc = push_device(e, mate, sl.d_words.p, stride, sl.d_lens.p, cap, sl.d_nrec.p, total);   // (a batch holds fewer k-mers than bases)
     if (rc != BK_OK) return rc;
@@ -1740,8 +1739,7 @@ int bk_push_reads_ascii_device(bk_engine* e, int mate, const void* d_bases, cons
         BK_HIP(sl.d_words.alloc(cap * stride + cap * stride / 4));
         BK_HIP(sl.d_lens.alloc(cap + cap / 4));
     }
-    if (!sl.d_nrec.p) BK_HIP(sl.d_nrec.alloc(1));
-    BK_HIP(hipMemsetAsync(sl.d_nrec.p, 0, sizeof(unsigned long long), e->stream));
+    if (!sl.d_nrec.p) BK_HIP(sl.d_nrec.alloc(2));
     {
         bk::PackArgs pa{};
         pa.bases = static_cast<const uint8_t*>(d_bases); pa.offsets = static_cast<const unsigned long long*>(d_offsets); pa.n_reads = n_reads;
@@ -1749,7 +1747,7 @@ int bk_push_reads_ascii_device(bk_engine* e, int mate, const void* d_bases, cons
         pa.words = sl.d_words.p; pa.lens = sl.d_lens.p; pa.cap = cap; pa.n_records = sl.d_nrec.p;
         bk_engine::Span sp(e, 2);
         bk::launch_pack_reads(pa, e->stream);
-        bk::launch_add_u64(e->kstats.p + mate * 4 + 0, sl.d_nrec.p, e->stream);   // records pushed, tallied on the device
+        bk::launch_add_u64(e->kstats.p + mate * 4 + 0, sl.d_nrec.p + 1, e->stream);   // records pushed, tallied on the device
     }
     return push_device(e, mate, sl.d_words.p, stride, sl.d_lens.p, cap, sl.d_nrec.p, total_bases);
 }

@@ -95,9 +95,13 @@ __device__ __forceinline__ void for_each_neighbour(const IndexView& ix, uint64_t
 }
 
 // ------------------------------------------------------------------------------------------------ K0
-// ASCII reads -> fixed-stride 2-bit records, one thread per read (the host-side twin is bk_pack_reads): split at
-// every non-ACGT/acgt symbol (KMC contract), drop runs shorter than k, cut runs longer than the stride into chunks
-// overlapping by k-1 bases.  Records are appended through one device counter (their order is irrelevant).
+// ASCII reads -> fixed-stride 2-bit records (the host-side twin is bk_pack_reads): split at every non-ACGT/acgt symbol (KMC
+// contract), drop runs shorter than k, cut runs longer than the stride into chunks overlapping by k-1 bases.
+// A read that is one clean run that fits a record -- nearly every read -- goes to the record slot of its own index: no counter,
+// four bytes per step (the 2-bit code of a letter is ((c >> 1) ^ (c >> 2)) & 3 in either case; whether all four are letters is one
+// comparison with the letters the codes stand for), the block's sequence lines staged in LDS with coalesced loads.  Any other
+// read leaves its slot empty (length 0) and appends its records behind the n_reads slots through a device counter, byte by byte
+// as before.  Records are unordered anyway.
 __device__ __forceinline__ int acgt_code(unsigned char c) {
     switch (c | 0x20) {
         case 'a': return 0;
@@ -108,38 +112,100 @@ __device__ __forceinline__ int acgt_code(unsigned char c) {
     }
 }
 
-__global__ __launch_bounds__(256) void pack_reads_kernel(PackArgs a) {
-    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= a.n_reads) return;
-    const uint8_t* s = a.bases + a.offsets[r];
-    const uint64_t len = a.offsets[r + 1] - a.offsets[r];
-    const uint64_t maxb = min((uint64_t)a.stride_words * 16, (uint64_t)65535);
-    uint64_t start = 0;
-    for (uint64_t i = 0; i <= len; ++i) {
-        if (i < len && acgt_code(s[i]) >= 0) continue;
-        const uint64_t run = i - start;            // maximal ACGT run [start, i)
-        if (run >= (uint64_t)a.k) {
-            uint64_t pos = 0;
-            for (;;) {
-                const uint64_t take = min(maxb, run - pos);
-                const unsigned long long rec = atomicAdd(a.n_records, 1ull);
-                if (rec < a.cap) {
-                    uint32_t* w = a.words + rec * a.stride_words;
-                    uint32_t acc = 0;
-                    for (uint64_t j = 0; j < take; ++j) {
-                        acc |= (uint32_t)acgt_code(s[start + pos + j]) << (2 * (j & 15));
-                        if ((j & 15) == 15) { w[j >> 4] = acc; acc = 0; }
-                    }
-                    if (take & 15) w[take >> 4] = acc;
-                    for (uint64_t j = (take + 15) >> 4; j < a.stride_words; ++j) w[j] = 0;
-                    a.lens[rec] = (uint16_t)take;
+constexpr int kPackBlock = 256;
+constexpr uint32_t kPackLdsBytes = 40u * 1024u;   // (256 reads of 150 bases: 38.4 KB; four blocks to a CU)
+__global__ __launch_bounds__(kPackBlock) void pack_reads_kernel(PackArgs a) {
+    extern __shared__ uint4 pk_lds[];
+    __shared__ unsigned int n_real_s;
+    const uint64_t r0 = (uint64_t)blockIdx.x * kPackBlock, r1 = min(r0 + (uint64_t)kPackBlock, a.n_reads);
+    const uint64_t b0 = a.offsets[r0], b1 = a.offsets[r1], end = a.offsets[a.n_reads];
+    const uint64_t a0 = b0 & ~15ull;                       // the block's lines from a 16-byte boundary (device allocations are aligned far beyond)
+    const uint64_t full16 = (end - a0) / 16;               // whole 16-byte units readable from a0
+    const uint64_t n16 = min((b1 - a0 + 15) / 16 + 2, full16);   // (two units more: the last read's last output word looks 16 bytes ahead)
+    const bool staged = n16 * 16 <= kPackLdsBytes;
+    if (threadIdx.x == 0) n_real_s = 0u;
+    if (staged) for (uint64_t i = threadIdx.x; i < n16; i += kPackBlock) pk_lds[i] = reinterpret_cast<const uint4*>(a.bases + a0)[i];
+    __syncthreads();
+    const uint32_t* src32 = staged ? reinterpret_cast<const uint32_t*>(pk_lds) : reinterpret_cast<const uint32_t*>(a.bases + a0);
+    const uint64_t full32 = staged ? n16 * 4 : (end - a0) / 4;   // whole words readable through src32
+    const uint64_t r = r0 + threadIdx.x;
+    unsigned int real = 0;
+    if (r < r1) {
+        const uint64_t o0 = a.offsets[r], len = a.offsets[r + 1] - o0;
+        const uint64_t maxb = min((uint64_t)a.stride_words * 16, (uint64_t)65535);
+        const uint64_t rel = o0 - a0;                      // first byte of the read in the word stream
+        bool done = false;
+        if (len >= (uint64_t)a.k && len <= maxb && rel / 4 + 4 * ((len + 15) / 16) + 1 <= full32) {   // (all words the loop below touches are there)
+            // one record if every symbol is a letter: 16 bases = four realigned words per output word
+            const uint32_t sh = (uint32_t)(rel & 3u);
+            const uint32_t* wsrc = src32 + rel / 4;
+            uint32_t* w = a.words + r * a.stride_words;
+            const uint32_t n_out = (uint32_t)((len + 15) / 16);
+            bool ok = true;
+            uint32_t carry = wsrc[0];
+            uint32_t outs = 0;
+            for (uint32_t q = 0; q < n_out; ++q) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t nxt = wsrc[4 * q + j + 1];
+                    uint32_t x = __builtin_amdgcn_alignbyte(nxt, carry, sh);   // bytes 16 q + 4 j .. + 3 of the read
+                    carry = nxt;
+                    const uint32_t left = (uint32_t)len - (16u * q + 4u * (uint32_t)j);   // bytes of the read from here on (wraps when none)
+                    const uint32_t keep = (16u * q + 4u * (uint32_t)j >= (uint32_t)len) ? 0u : left >= 4u ? 0xffffffffu : (1u << (8u * left)) - 1u;
+                    x = (x & keep) | (0x41414141u & ~keep);   // (behind the read: 'A', code 0)
+                    const uint32_t c = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+                    const uint32_t c0 = c & 0x01010101u, c1 = (c >> 1) & 0x01010101u;
+                    ok &= (x | 0x20202020u) == 0x61616161u + c0 * 2u + c1 * 6u + (c0 & c1) * 11u;   // a c g t = 0x61 + 0, 2, 6, 19
+                    acc |= ((c | (c >> 6) | (c >> 12) | (c >> 18)) & 0xffu) << (8 * j);
                 }
-                if (pos + take >= run) break;
-                pos += take - (uint64_t)(a.k - 1);
+                w[q] = acc;
+                outs = q + 1;
+            }
+            if (ok) {
+                for (uint32_t q = outs; q < a.stride_words; ++q) w[q] = 0;
+                a.lens[r] = (uint16_t)len;
+                real = 1;
+                done = true;
             }
         }
-        start = i + 1;
+        if (!done) {
+            a.lens[r] = 0;   // the slot of its index stays empty; its records, if any, go behind the n_reads slots
+            const uint8_t* s = a.bases + o0;
+            uint64_t start = 0;
+            for (uint64_t i = 0; i <= len; ++i) {
+                if (i < len && acgt_code(s[i]) >= 0) continue;
+                const uint64_t run = i - start;            // maximal ACGT run [start, i)
+                if (run >= (uint64_t)a.k) {
+                    uint64_t pos = 0;
+                    for (;;) {
+                        const uint64_t take = min(maxb, run - pos);
+                        const unsigned long long rec = atomicAdd(a.n_records, 1ull);
+                        if (rec < a.cap) {
+                            uint32_t* w = a.words + rec * a.stride_words;
+                            uint32_t acc = 0;
+                            for (uint64_t j = 0; j < take; ++j) {
+                                acc |= (uint32_t)acgt_code(s[start + pos + j]) << (2 * (j & 15));
+                                if ((j & 15) == 15) { w[j >> 4] = acc; acc = 0; }
+                            }
+                            if (take & 15) w[take >> 4] = acc;
+                            for (uint64_t j = (take + 15) >> 4; j < a.stride_words; ++j) w[j] = 0;
+                            a.lens[rec] = (uint16_t)take;
+                            ++real;
+                        }
+                        if (pos + take >= run) break;
+                        pos += take - (uint64_t)(a.k - 1);
+                    }
+                }
+                start = i + 1;
+            }
+        }
     }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) real += (unsigned int)__shfl_xor((int)real, off);
+    if ((threadIdx.x & 63) == 0 && real) atomicAdd(&n_real_s, real);
+    __syncthreads();
+    if (threadIdx.x == 0 && n_real_s) atomicAdd(a.n_real, (unsigned long long)n_real_s);
 }
 
 __global__ void add_u64_kernel(unsigned long long* dst, const unsigned long long* src) { *dst += *src; }
@@ -151,9 +217,17 @@ void launch_add_u64(unsigned long long* dst, const unsigned long long* src, hipS
     hipLaunchKernelGGL(add_u64_kernel, dim3(1), dim3(1), 0, stream, dst, src);
 }
 
-void launch_pack_reads(const PackArgs& a, hipStream_t stream) {
-    if (a.n_reads == 0) return;
-    hipLaunchKernelGGL(pack_reads_kernel, dim3((unsigned)((a.n_reads + 255) / 256)), dim3(256), 0, stream, a);
+__global__ void set2_u64_kernel(unsigned long long* dst, unsigned long long v0, unsigned long long v1) { dst[0] = v0; dst[1] = v1; }
+// a.n_records[0] = record slots in use when the kernel ends (the n_reads slots of the reads' own indices + what was appended),
+// a.n_real = a.n_records + 1: records that hold a run (what KMC would call its input sequences)
+void launch_pack_reads(const PackArgs& a0, hipStream_t stream) {
+    if (a0.n_reads == 0) return;
+    PackArgs a = a0;
+    a.n_real = a.n_records + 1;
+    hipLaunchKernelGGL(set2_u64_kernel, dim3(1), dim3(1), 0, stream, a.n_records, (unsigned long long)a.n_reads, 0ull);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pack_reads_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPackLdsBytes); attr_set = true; }
+    hipLaunchKernelGGL(pack_reads_kernel, dim3((unsigned)((a.n_reads + kPackBlock - 1) / kPackBlock)), dim3(kPackBlock), kPackLdsBytes, stream, a);
 }
 
 // full_kmer_stats: +1 on a k-mer that does not touch the index, in an open-addressing table keyed by

@@ -3,7 +3,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbronko_hip.so")
+# (BRONKO_HIP_LIB: another build of the same library, for A/B timing of two builds in one run -- tools/ab.sh; the harness reads it, the
+# library itself reads no environment)
+LIB_PATH = os.environ.get("BRONKO_HIP_LIB") or os.path.join(_HERE, "libbronko_hip.so")
 # the -DBK_TESTING build of the same sources: BK_* environment variables that force a code path exist only there
 TESTING_LIB_PATH = os.path.join(_HERE, "libbronko_hip_testing.so")
 

@@ -76,7 +76,12 @@ int bk_build_index(int32_t k, int32_t n_files, const int32_t* n_seqs, const uint
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) BB_FAIL(BK_ERR_NO_DEVICE, "no HIP device %d", device);
     unsigned char* d_bases = nullptr; SeqRow* d_rows = nullptr;
     unsigned long long *d_k0 = nullptr, *d_k1 = nullptr, *d_v0 = nullptr, *d_v1 = nullptr; void* d_tmp = nullptr;
-    auto cleanup = [&] { (void)hipFree(d_bases); (void)hipFree(d_rows); (void)hipFree(d_k0); (void)hipFree(d_k1); (void)hipFree(d_v0); (void)hipFree(d_v1); (void)hipFree(d_tmp); };
+    hipStream_t stream = nullptr;   // a stream of its own: a process with samples in flight on this device is not stalled by the build
+    auto cleanup = [&] {
+        (void)hipFree(d_bases); (void)hipFree(d_rows); (void)hipFree(d_k0); (void)hipFree(d_k1); (void)hipFree(d_v0); (void)hipFree(d_v1); (void)hipFree(d_tmp);
+        d_bases = nullptr; d_rows = nullptr; d_k0 = d_k1 = d_v0 = d_v1 = nullptr; d_tmp = nullptr;
+        if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+    };
     (void)hipSetDevice(device);
 
     std::vector<SeqRow> rows;
@@ -95,11 +100,20 @@ int bk_build_index(int32_t k, int32_t n_files, const int32_t* n_seqs, const uint
         }
     }
     const unsigned long long n_pairs = n_kmers * (unsigned long long)k;
-    out->bucket_off = (uint64_t*)malloc(sizeof(uint64_t));
-    if (!out->bucket_off) BB_FAIL(BK_ERR_INVALID, "out of memory");
-    out->bucket_off[0] = 0;
-    if (n_pairs == 0) return BK_OK;
     if (n_pairs >= (1ull << 33)) BB_FAIL(BK_ERR_UNSUPPORTED, "index too large for the device build (%llu pairs)", n_pairs);
+    if (n_pairs == 0) {
+        out->bucket_off = (uint64_t*)malloc(sizeof(uint64_t));
+        if (!out->bucket_off) BB_FAIL(BK_ERR_INVALID, "out of memory");
+        out->bucket_off[0] = 0;
+        return BK_OK;
+    }
+    {   // 32 bytes per pair for keys and values in two buffers each, the sort's scratch on top: refuse early instead of failing in the middle
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (unsigned long long)free_b < 40ull * n_pairs + bytes + (64ull << 20))
+            BB_FAIL(BK_ERR_UNSUPPORTED, "not enough free device memory for the device build (%llu pairs need about %llu MB, %llu MB free)", n_pairs,
+                    (40ull * n_pairs + bytes) >> 20, (unsigned long long)free_b >> 20);
+    }
+    BB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 
     std::vector<unsigned char> h_bases(bytes);
     {
@@ -110,24 +124,23 @@ int bk_build_index(int32_t k, int32_t n_files, const int32_t* n_seqs, const uint
     BB_HIP(hipMalloc((void**)&d_rows, rows.size() * sizeof(SeqRow)));
     BB_HIP(hipMalloc((void**)&d_k0, n_pairs * 8)); BB_HIP(hipMalloc((void**)&d_k1, n_pairs * 8));
     BB_HIP(hipMalloc((void**)&d_v0, n_pairs * 8)); BB_HIP(hipMalloc((void**)&d_v1, n_pairs * 8));
-    BB_HIP(hipMemcpy(d_bases, h_bases.data(), bytes, hipMemcpyHostToDevice));
-    BB_HIP(hipMemcpy(d_rows, rows.data(), rows.size() * sizeof(SeqRow), hipMemcpyHostToDevice));
+    BB_HIP(hipMemcpyAsync(d_bases, h_bases.data(), bytes, hipMemcpyHostToDevice, stream));
+    BB_HIP(hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(SeqRow), hipMemcpyHostToDevice, stream));
     const unsigned grid = (unsigned)std::min<unsigned long long>((n_kmers + 255) / 256, 1u << 16);
-    hipLaunchKernelGGL(gen_pairs_kernel, dim3(grid), dim3(256), 0, 0, d_bases, d_rows, (int)rows.size(), n_kmers, (int)k, d_k0, d_v0);
+    hipLaunchKernelGGL(gen_pairs_kernel, dim3(grid), dim3(256), 0, stream, d_bases, d_rows, (int)rows.size(), n_kmers, (int)k, d_k0, d_v0);
     BB_HIP(hipGetLastError());
     size_t tmp_bytes = 0;
-    BB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (size_t)n_pairs, 0, 64, 0));
+    BB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (size_t)n_pairs, 0, 64, stream));
     BB_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
-    BB_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (size_t)n_pairs, 0, 64, 0));   // stable: keeps (file, seq, location) inside a bucket
-    BB_HIP(hipDeviceSynchronize());
+    BB_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (size_t)n_pairs, 0, 64, stream));   // stable: keeps (file, seq, location) inside a bucket
     std::vector<unsigned long long> h_k(n_pairs), h_v(n_pairs);
-    BB_HIP(hipMemcpy(h_k.data(), d_k1, n_pairs * 8, hipMemcpyDeviceToHost));
-    BB_HIP(hipMemcpy(h_v.data(), d_v1, n_pairs * 8, hipMemcpyDeviceToHost));
+    BB_HIP(hipMemcpyAsync(h_k.data(), d_k1, n_pairs * 8, hipMemcpyDeviceToHost, stream));
+    BB_HIP(hipMemcpyAsync(h_v.data(), d_v1, n_pairs * 8, hipMemcpyDeviceToHost, stream));
+    BB_HIP(hipStreamSynchronize(stream));
     cleanup();
 
     uint64_t nb = 0;
     for (unsigned long long i = 0; i < n_pairs; i++) nb += (i == 0 || h_k[i] != h_k[i - 1]);
-    free(out->bucket_off);
     out->bucket_ids = (uint64_t*)malloc(nb * sizeof(uint64_t));
     out->bucket_off = (uint64_t*)malloc((nb + 1) * sizeof(uint64_t));
     out->entries = (bk_bucket_info*)calloc(n_pairs, sizeof(bk_bucket_info));   // (padding bytes zero)

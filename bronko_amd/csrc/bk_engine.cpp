@@ -335,6 +335,7 @@ struct bk_engine {
 
     hipStream_t own_stream = nullptr, stream = nullptr;
     bool in_sample = false;
+    int finalized_mates = 0;                // mate files of the sample whose finalize was enqueued last (0: none since bk_sample_begin / create)
     uint64_t pushed_records[2] = {0, 0};
     // multi-genome indexes: the LDS window (difference array + Level 1's arrays) sits on the genome the sample looks like
     DevBuf<uint32_t> occ;                   // [n_full][n_files] first occurrence of each reference k-mer in each genome file
@@ -352,7 +353,7 @@ struct bk_engine {
     DevBuf<int32_t> seq_first, n_seqs_d;
     int max_seqs_per_file = 0;
     uint64_t max_file_cells = 0;
-    DevBuf<double> call_freq, call_noise;
+    DevBuf<double> call_noise;
     DevBuf<bk_call_record> call_records;
     DevBuf<bk_call_summary> call_out;
     DevBuf<bk_call_summary> sel_out;        // pileup_selected_only: the genome selected between the two finalize passes
@@ -1482,6 +1483,7 @@ int bk_sample_begin(bk_engine* e) {
     e->reduced_shards[0] = e->reduced_shards[1] = 0;
     e->pushed_records[0] = e->pushed_records[1] = 0;
     e->in_sample = true;
+    e->finalized_mates = 0;
     return BK_OK;
 }
 
@@ -1901,6 +1903,7 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
     }
     BK_HIP(hipGetLastError());
     e->in_sample = false;
+    e->finalized_mates = n_mates;
     if (e->dbg.p) {   // BK_L2_STATS (testing build)
         unsigned long long h[32];
         unsigned int nd[2] = {0, 0};
@@ -2163,10 +2166,11 @@ int bk_sample_call(bk_engine* e, int n_mates, const bk_call_params* p) {
     if (!e || !p) return fail(BK_ERR_INVALID, "null argument");
     if (n_mates < 1 || n_mates > 2) return fail(BK_ERR_INVALID, "n_mates must be 1 or 2");
     if (e->in_sample) return fail(BK_ERR_STATE, "bk_sample_call comes after bk_sample_finalize");
+    if (e->finalized_mates == 0) return fail(BK_ERR_STATE, "bk_sample_call: no sample has been finalized on this engine");
+    if (e->finalized_mates != n_mates) return fail(BK_ERR_STATE, "bk_sample_call(n_mates = %d): the sample was finalized with %d mate file(s)", n_mates, e->finalized_mates);
     BK_HIP(hipSetDevice(e->device));
     const uint64_t cap = std::max<uint64_t>(3 * e->max_file_cells, 1);   // at most three alternative bases per position
     if (!e->call_out.p) {
-        BK_HIP(e->call_freq.alloc((size_t)e->total_cells * 3));
         BK_HIP(e->call_noise.alloc((size_t)e->total_cells));
         BK_HIP(e->call_records.alloc((size_t)cap));
         BK_HIP(e->call_out.alloc(1));
@@ -2178,7 +2182,7 @@ int bk_sample_call(bk_engine* e, int n_mates, const bk_call_params* p) {
     a.genome_len = e->genome_len.p; a.seq_first = e->seq_first.p; a.n_seqs = e->n_seqs_d.p; a.seq_cell = e->seq_cell.p; a.seq_len = e->seq_len_d.p;
     a.ref_words = e->ref_words.p + bk::scan_ref_pad_words();
     a.pileup = e->pileup.p; a.plane = (size_t)e->total_cells * 4;
-    a.freq = e->call_freq.p; a.noise = e->call_noise.p; a.records = e->call_records.p; a.record_cap = cap; a.out = e->call_out.p;
+    a.noise = e->call_noise.p; a.records = e->call_records.p; a.record_cap = cap; a.out = e->call_out.p;
     bk_engine::Span sp(e, 1);
     bk::launch_call(a, e->max_seqs_per_file, e->max_file_cells, e->stream);
     BK_HIP(hipGetLastError());

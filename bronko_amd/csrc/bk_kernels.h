@@ -201,7 +201,6 @@ struct CallArgs {
     const uint32_t* ref_words;           // IndexView::ref_words past its front padding: symbol 0 = cell 0
     const unsigned long long* pileup;    // 4 planes of `plane` u64
     size_t plane;
-    double* freq;                        // [total_cells][3] scratch: sorted minor-allele frequencies
     double* noise;                       // [total_cells] Noise.max per position
     CallRecordDev* records;
     uint64_t record_cap;

@@ -299,7 +299,8 @@ class Engine:
     def download_calls(self):
         """(summary, records) of sample_call: records sorted by (sequence, position, alternative base)."""
         summ = _ffi.CallSummary()
-        cap = max(1, 3 * self.total_cells)   # (an upper bound: three alternative bases per position of the selected genome)
+        _check(self._L.bk_sample_download_calls(self.h, C.byref(summ), None, 0), self._L)   # (the summary first: how many records there are)
+        cap = max(1, int(summ.n_records))
         recs = (_ffi.CallRecord * cap)()
         _check(self._L.bk_sample_download_calls(self.h, C.byref(summ), recs, cap), self._L)
         return summ, [recs[i] for i in range(min(summ.n_records, cap))]

@@ -83,3 +83,30 @@ def test_no_reads_no_genome(oracle, golden_dir):
     assert summ.file_id == -1 and summ.n_records == 0 and recs == []
     eng.close()
     ix.close()
+
+
+def test_calls_need_a_finalized_sample_with_the_same_mates(oracle, golden_dir):
+    """bk_sample_call refuses (BK_ERR_STATE) on an engine that never finalized a sample -- its pileup is uninitialised memory -- and
+    with another number of mate files than the finalize had; a fork starts as empty as a new engine."""
+    from bronko_amd import BronkoError
+    ix = oracle.Index.load(os.path.join(golden_dir, "hpv.bkdb"))
+    eng = helpers.engine_from_oracle_index(ix)
+    fork = eng.fork()
+    for e in (eng, fork):
+        with pytest.raises(BronkoError) as ei:
+            e.sample_call(1)
+        assert ei.value.status == -5
+    reads = helpers.hpv_reads(3000, seed=5)
+    helpers.hip_sample(eng, [reads], 21)
+    with pytest.raises(BronkoError) as ei:
+        eng.sample_call(2)
+    assert ei.value.status == -5
+    eng.sample_call(1)
+    summ, recs = eng.download_calls()
+    assert summ.file_id == 0 and summ.n_records == len(recs)
+    eng.sample_begin()                       # a sample that was begun: nothing to call yet
+    with pytest.raises(BronkoError):
+        eng.sample_call(1)
+    fork.close()
+    eng.close()
+    ix.close()

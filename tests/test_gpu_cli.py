@@ -184,11 +184,12 @@ def test_call_three_samples_overlapped(oracle, golden_dir, tmp_path):
 
 
 @pytest.mark.parametrize("lane_env,n_lanes", [({"BRONKO_DEVICES": "0,0"}, 2), ({"BRONKO_LANES": "3"}, 3)])
-def test_call_samples_dealt_to_several_gpu_lanes(oracle, golden_dir, tmp_path, lane_env, n_lanes):
+def test_call_samples_dealt_to_several_lanes_on_the_one_gpu_of_the_box(oracle, golden_dir, tmp_path, lane_env, n_lanes):
     """Whole samples per GPU, no collective (call.rs:212: samples are independent): `bronko call` deals the samples to lanes in
     turn -- host threads that ingest into their own engine (+ fork); the lanes of one device share its tables.
-    BRONKO_DEVICES=0,0 runs two lanes on the one GPU of the test box (the code path of two GPUs), BRONKO_LANES=3 three lanes
-    on it (what -t 6 gives): five samples, every output equal to the oracle's, overview in input order."""
+    BRONKO_DEVICES=0,0 runs two lanes on the one GPU of the test box (the code path of two GPUs; a second physical device has
+    never been available to these tests), BRONKO_LANES=3 three lanes on it (what -t 6 gives): five samples, every output equal to
+    the oracle's, overview in input order."""
     g = synth.read_fasta_bytes(os.path.join(golden_dir, "HPV16.fa"))
     ix = oracle.Index.load(os.path.join(golden_dir, "hpv.bkdb"))
     paths, samples = [], []

@@ -846,6 +846,48 @@ def test_config5_hundred_strains_k31(oracle, sars_paths):
     pile, _ = oracle.sample_pileup_mt(ix, [synth.BASES[codes]], os.cpu_count() or 8)
     helpers.assert_same_pileup(res, pile)
     assert oracle.pick_best_genome(ix, pile.stats.sum(axis=0), pile.present.max(axis=0)) == 7
+
+    # what `bronko call` runs with at this size: votes for the selected genome only (two finalize passes, the sparse finalize below
+    # the 2.9 GB planes), on forks of the same tables with parameters of their own (bk_engine_fork_params)
+    from bronko_amd import Params
+    names = ("fwd_depth", "rev_depth", "fwd_nk", "rev_nk")
+
+    def check_selected(got, want, best):
+        assert np.array_equal(got.stats, want.stats) and np.array_equal(got.present, want.present)
+        lo, n = ix.genome_cells(best)
+        for name in names:
+            g, w = getattr(got, name), getattr(want, name)
+            assert np.array_equal(g[lo * 4:(lo + n) * 4], w[lo * 4:(lo + n) * 4]), name
+            assert not g[:lo * 4].any() and not g[(lo + n) * 4:].any(), name
+
+    sel = [eng.fork(Params(pileup_selected_only=True)) for _ in range(3)]
+    sel[0].sample_begin()
+    sel[0].push_reads(0, words, lens)
+    check_selected(sel[0].sample_finish(1), pile, 7)
+    # ... and the config's shape: 64 samples (20,000 reads each, sample s from strain s mod 100) taken in turn by the three forks,
+    # nothing synchronised in between; each against the oracle
+    n_s, per = 64, 20000
+    want = {}
+
+    def settle(s_j):   # the result of sample s_j, taken from its engine just before the engine is reused (or at the end)
+        best = oracle.pick_best_genome(ix, want[s_j].stats.sum(axis=0), want[s_j].present.max(axis=0))
+        assert best == s_j % 100, (s_j, best)
+        check_selected(sel[s_j % len(sel)].sample_download(1), want.pop(s_j), best)
+
+    for s_i in range(n_s):
+        gm_s, isnv_s = synth.sample_genome(files[s_i % 100][1][0][1], 5 + s_i)
+        c = synth.single_end_codes(gm_s, per, 150, 5 * 1000003 + s_i, isnv=isnv_s)
+        want[s_i] = oracle.sample_pileup_mt(ix, [synth.BASES[c]], os.cpu_count() or 8)[0]
+        e = sel[s_i % len(sel)]
+        if s_i >= len(sel):
+            settle(s_i - len(sel))
+        e.sample_begin()
+        e.push_reads(0, *synth.pack_codes(c))
+        e.sample_finalize(1)
+    for s_i in range(n_s - len(sel), n_s):
+        settle(s_i)
+    for e in sel:
+        e.close()
     eng.close()
     ix.close()
 

@@ -1466,9 +1466,8 @@ int bk_sample_begin(bk_engine* e) {
     bk_engine::Span sp(e, 2);
     e->plane_stale[0] = e->plane_stale[1] = true;   // a plane is zeroed when its mate file is first pushed (or finalized unpushed)
     e->win_chosen = false;
-    BK_HIP(hipMemsetAsync(e->pileup.p, 0, std::max<size_t>(e->pileup.n, 1) * sizeof(unsigned long long), e->stream));
     bk::launch_zero_small(e->stats.p, e->stats.n, e->kstats.p, e->kstats.n, e->ktab_out.p, e->ktab_out.n, e->present.p, e->present.n,
-                          e->n_deferred.p, e->n_deferred.n, e->stream);
+                          e->n_deferred.p, e->n_deferred.n, e->pileup.p, e->pileup.n, e->stream);
     if (e->ktab_keys.p) {
         if (!e->ktab_old.empty()) {   // tables the previous sample outgrew
             BK_HIP(hipStreamSynchronize(e->stream));
@@ -1868,6 +1867,13 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             a.mode = two_pass ? pass + 1 : 0;
             a.sel = two_pass ? &e->sel_out.p->file_id : nullptr;
             a.sel_file = -1;
+            // dense planes mapped whole: K2a zeroes the V counters it reads; the E part (two counters per reference k-mer) is zeroed by
+            // the reduce kernel of the mate file's last statistics pass (it runs behind K2e, the E part's only reader in that pass;
+            // a second, votes-only pass reads it again: then the memset below does it)
+            const bool ride = clean_dense && !two_pass && e->fin_partials.p && e->plane_used[m];
+            a.zero_e = ride ? e->counters[m].p : nullptr;
+            a.zero_e_n = ride ? (size_t)std::min<uint64_t>(e->v_off, e->plane_len) : 0;
+            if (ride) e->plane_used[m] = false;
             if (pass == 0) { if (int rc = zero_plane_if_stale(e, m)) return rc; }
             bk_engine::Span sp(e, 1);
             bk::launch_finalize(a, e->stream);

@@ -104,6 +104,8 @@ struct FinalizeArgs {
     int mode;
     const int* sel;
     int sel_file;                   // = *sel, read by each kernel of the second pass
+    unsigned long long* zero_e;     // launch_finalize's last kernel also zeroes zero_e[0, zero_e_n): the plane's E part behind the sample (or null)
+    size_t zero_e_n;
 };
 
 struct FoldArgs {
@@ -168,9 +170,9 @@ void launch_compact_touched(unsigned int* touch_v, uint64_t n_rows, unsigned int
                             uint64_t n_full, unsigned int* v_list, unsigned int* p_list, unsigned int* e_list, unsigned int* n_list, hipStream_t stream);
 void launch_clear_touched(unsigned long long* counters, uint64_t v_off, uint64_t v_real_len, uint32_t rl, const unsigned int* v_list,
                           const unsigned int* p_list, const unsigned int* e_list, const unsigned int* n_list, uint64_t n_ids, hipStream_t stream);
-// one launch zeroes the engine's small per-sample buffers
+// one launch zeroes what a sample starts from: the engine's small per-sample buffers and the pileup arrays (`big`)
 void launch_zero_small(unsigned long long* a, size_t na, unsigned long long* b, size_t nb, unsigned long long* c, size_t nc,
-                       unsigned char* d, size_t nd, unsigned int* e, size_t ne, hipStream_t stream);
+                       unsigned char* d, size_t nd, unsigned int* e, size_t ne, unsigned long long* big, size_t nbig, hipStream_t stream);
 // shard_sums <-> {stats, present, kstats}: the small additive results of a sharded finalize as one u64 vector
 void launch_pack_sums(unsigned long long* sums, const unsigned long long* stats, const unsigned char* present, const unsigned long long* kstats,
                       int n_files, unsigned long long* xflag, hipStream_t stream);

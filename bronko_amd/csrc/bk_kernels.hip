@@ -1840,9 +1840,11 @@ __device__ __forceinline__ void finalize_epilogue(const FinalizeArgs& a, const u
 }
 
 // stats / present / kept / distinct += column sums of the partials rows written by the finalize workgroups
-__global__ __launch_bounds__(256) void finalize_reduce_kernel(FinalizeArgs a, int n_rows) {
+__global__ __launch_bounds__(256) void finalize_reduce_kernel(FinalizeArgs a, int n_rows, unsigned long long* zero_p, size_t zero_n) {
     __shared__ unsigned long long wave_sums[4];
     const int n3 = a.ix.n_files * 3, cols = n3 + 2;
+    // (the last kernel of a sample's last pass also zeroes the E part of the plane behind the sample: dense planes, see K2a's clear_v)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (size_t)gridDim.x * 256) zero_p[i] = 0ull;
     const int col = blockIdx.x;   // one workgroup per column, rows strided over its threads
     unsigned long long s = 0;
     for (int r = threadIdx.x; r < n_rows; r += 256) s += a.partials[(size_t)r * cols + col];
@@ -2591,22 +2593,27 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     hipLaunchKernelGGL(finalize_general_kernel, dim3(b_gen), dim3(64), lds, stream, a);
     if (a.partials && a.mode != 2) {
         const int cols = a.ix.n_files * 3 + 2;
-        hipLaunchKernelGGL(finalize_reduce_kernel, dim3((unsigned)cols), dim3(256), 0, stream, a, (int)(b_var + b_ex + b_gen));
+        hipLaunchKernelGGL(finalize_reduce_kernel, dim3((unsigned)cols), dim3(256), 0, stream, a, (int)(b_var + b_ex + b_gen), a.zero_e, a.zero_e_n);
     }
 }
 
-__global__ void zero_small_kernel(unsigned long long* a, size_t na, unsigned long long* b, size_t nb, unsigned long long* c, size_t nc,
-                                  unsigned char* d, size_t nd, unsigned int* e, size_t ne) {
+// one launch zeroes everything a sample starts from: the pileup arrays (`big`, 16 bytes per thread and step) and the small buffers
+__global__ __launch_bounds__(256) void zero_small_kernel(unsigned long long* a, size_t na, unsigned long long* b, size_t nb, unsigned long long* c, size_t nc,
+                                                         unsigned char* d, size_t nd, unsigned int* e, size_t ne, unsigned long long* big, size_t nbig) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = (size_t)gridDim.x * blockDim.x;
     for (size_t i = t; i < na; i += n) a[i] = 0;
     for (size_t i = t; i < nb; i += n) b[i] = 0;
     for (size_t i = t; i < nc; i += n) c[i] = 0;
     for (size_t i = t; i < nd; i += n) d[i] = 0;
     for (size_t i = t; i < ne; i += n) e[i] = 0;
+    ulonglong2* big2 = reinterpret_cast<ulonglong2*>(big);   // (device allocations are aligned far beyond 16 bytes)
+    for (size_t i = t; i < nbig / 2; i += n) big2[i] = make_ulonglong2(0ull, 0ull);
+    if (t == 0 && (nbig & 1)) big[nbig - 1] = 0;
 }
 void launch_zero_small(unsigned long long* a, size_t na, unsigned long long* b, size_t nb, unsigned long long* c, size_t nc,
-                       unsigned char* d, size_t nd, unsigned int* e, size_t ne, hipStream_t stream) {
-    hipLaunchKernelGGL(zero_small_kernel, dim3(16), dim3(256), 0, stream, a, na, b, nb, c, nc, d, nd, e, ne);
+                       unsigned char* d, size_t nd, unsigned int* e, size_t ne, unsigned long long* big, size_t nbig, hipStream_t stream) {
+    const unsigned grid = (unsigned)std::max<size_t>(16, std::min<size_t>((nbig / 2 + 255) / 256, 2048));
+    hipLaunchKernelGGL(zero_small_kernel, dim3(grid), dim3(256), 0, stream, a, na, b, nb, c, nc, d, nd, e, ne, big, nbig);
 }
 
 // ---- sharded finalize: the small additive results as one u64 vector [stats 2*n_files*3 | present 2*n_files | kstats 8 | flag]

@@ -285,6 +285,43 @@ def test_device_side_packing_and_async_ingest(oracle, hpv):
     # host packing and device packing produce the same number of records
     host = helpers.hip_sample(eng, [reads], 21)
     assert host.kmer_stats[0, 0] == res.kmer_stats[0, 0]
+    # bk_push_reads_ascii_device (ABI v7): the same lines already resident in device memory, two batches, unaligned starts
+    import torch
+    flat = np.frombuffer(b"".join(reads), np.uint8)
+    off = np.zeros(len(reads) + 1, np.int64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    d_flat = torch.from_numpy(flat.copy()).to("cuda:0")
+    torch.cuda.synchronize()
+    eng.sample_begin()
+    cut = len(reads) // 3
+    for lo, hi in ((0, cut), (cut, len(reads))):
+        d_off = torch.from_numpy(off[lo:hi + 1].copy()).to("cuda:0")
+        torch.cuda.synchronize()
+        longest = int((off[lo + 1:hi + 1] - off[lo:hi]).max())
+        eng.push_reads_ascii_device(0, d_flat.data_ptr(), d_off.data_ptr(), hi - lo, int(off[hi] - off[lo]), longest)
+    res2 = eng.sample_finish(1)
+    helpers.assert_same_pileup(res2, pile)
+    assert res2.kmer_stats[0].tolist() == res.kmer_stats[0].tolist()
+
+
+def test_a_fork_with_parameters_of_its_own(oracle, hpv):
+    """bk_engine_fork_params (ABI v7): ci / cs / cx of a fork differ from the parent's -- each equals the oracle run with its own
+    thresholds; what shapes the shared tables (n_fixed, use_full_kmer, full_kmer_stats) must equal the parent's."""
+    from bronko_amd import BronkoError, Params
+    ix, eng = hpv
+    reads = helpers.hpv_reads(12000, seed=77, err=0.01)
+    forks = [(dict(ci=1), eng.fork(Params(ci=1))), (dict(ci=5, cs=40), eng.fork(Params(ci=5, cs=40))), (dict(ci=2, cx=60), eng.fork(Params(ci=2, cx=60)))]
+    try:
+        for kw, f in forks:
+            helpers.assert_same_pileup(helpers.hip_sample(f, [reads], 21), oracle.sample_pileup(ix, [reads], **kw))
+        helpers.assert_same_pileup(helpers.hip_sample(eng, [reads], 21), oracle.sample_pileup(ix, [reads]))   # the parent keeps its own
+        for bad in (Params(n_fixed=3), Params(use_full_kmer=True), Params(full_kmer_stats=True)):
+            with pytest.raises(BronkoError) as ei:
+                eng.fork(bad)
+            assert ei.value.status == -1
+    finally:
+        for _, f in forks:
+            f.close()
 
 
 def test_reference_walk_from_global_memory(oracle, golden_dir, monkeypatch, testing_lib):

@@ -608,16 +608,16 @@ def main():
         a3 = argparse.Namespace(**vars(args))
         a3.samples_per_step, a3.cpu_sample = 1, 200000
         w3 = Workload(3, a3, rank, world, local_rank, dev, 1000000, 10)
-        others["3"] = brief(measure(w3, a3, dev, dist, 3, 1, bounded=True))
+        others["3"] = brief(measure(w3, a3, dev, dist, 4, 1, bounded=True))
         w3.eng.close()
         del w3
         torch.cuda.empty_cache()
         a5 = argparse.Namespace(**vars(args))
         a5.samples_per_step = 1
-        w5 = Workload(5, a5, rank, world, local_rank, dev, 1000000, 4)
-        others["5_literal"] = brief(measure(w5, a5, dev, dist, 3, 1, bounded=True))
+        w5 = Workload(5, a5, rank, world, local_rank, dev, 1000000, 6)
+        others["5_literal"] = brief(measure(w5, a5, dev, dist, 6, 1, bounded=True))
         sel = w5.eng.fork(Params(device=local_rank, pileup_selected_only=True))
-        others["5_selected_only"] = brief(measure(w5, a5, dev, dist, 3, 1, eng=sel, selected_only=True, bounded=True))
+        others["5_selected_only"] = brief(measure(w5, a5, dev, dist, 9, 2, eng=sel, selected_only=True, bounded=True))
         sel.close()
         others["5_literal"]["setup_s"] = w5.setup_s
         out["other_configs"] = others

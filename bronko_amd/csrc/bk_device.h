@@ -176,10 +176,15 @@ struct IndexView {
     const uint32_t*  id_at;       // [total_cells] id of the k-mer starting at cell q (0xffffffff: none)
     const uint32_t*  cell_fast;   // 1 bit per cell, layout of cell_has: the k-mer that starts at q is in U, "clean", and its id is
                                   // q + cell_blk[q >> 6].x (modulo 2^32) -- what the scan needs to count an isolated mismatch on the spot
+    const uint32_t*  cell_nat;    // [(total_cells + k) * 3] per reference position q and alternative a (read base XOR reference base, - 1):
+                                  // bit o = the k-mer that starts at q - o is in U, stands in its first occurrence's orientation, has the
+                                  // id q - o + cell_blk[..].x, and with that other base at q it takes its OWN V row (clean, or its DirtyAns
+                                  // says so) -- cell_fast per (position, offset, base) for cells that are not clean; the k-mers that cover
+                                  // one mismatch all ask the same word.  Null when no answer table was built.
     const uint2*     seed_tab;    // [n_files << seed_log2] the scan's seed tables (see seed_hash), or null (index too large)
     uint32_t         seed_log2;
-    const uint2*     cell_blk;    // per block of 64 cells (two entries of padding behind): x = id_at[q] - q of the block's first clean
-                                  // cell; y = the first cell >= 64 * block at which no k-mer of U starts (sequence tails)
+    const uint2*     cell_blk;    // per block of 64 cells (two entries of padding behind): x = the most common id_at[q] - q among the block's cells
+                                  // that stand in their k-mer's first orientation; y = the first cell >= 64 * block at which no k-mer of U starts (sequence tails)
     uint32_t total_cells;
     uint32_t n_u;                 // |U| = number of ids
     uint32_t n_full;              // ids < n_full are reference k-mers (W V rows each); the rest are k = 31 pseudo k-mers
@@ -193,6 +198,9 @@ struct IndexView {
     const uint32_t*  slot_of;  // [n_u][W] window bucket (slot) of reference k-mer id at window position t
     const SlotRec*   slot_rec; // [n_full][W] the same bucket's entry list, with its first BucketInfo inline (one load for the
                                //             common single-entry bucket)
+    const uint4*     ent_files;  // [n_slots] / slot_files [n_full][W]: bit f = the bucket holds a BucketInfo of genome file f -- exactly one, the
+    const uint4*     slot_files; //   entries sorted by file, so file f's is entry number popcount(bits below f); all zero = not such a bucket
+                                 //   (or more than 128 files, or W == 1: both null): look at the entries.  bk_params.pileup_selected_only.
     const uint8_t*   amb;      // [n_u] bit 1 = the k-mer's first occurrence was reverse-complemented to become canonical; bit 0 = "dirty": another reference k-mer (either strand) lies within Hamming
                                //       distance 2 of it, or it is within distance 2 of its own reverse complement
     const uint32_t*  estat_off;// [n_u + 1] per reference k-mer: its genomes, precomputed from the index alone
@@ -243,6 +251,20 @@ BK_HD uint64_t v_real_rows(uint32_t n_full, int span) { return span > 0 ? ((uint
 BK_HD uint64_t v_real_len(uint32_t n_full, int span) { return v_real_rows(n_full, span) * (uint64_t)(span + 1); }
 // which alternative: base b where the reference has r (both on the same strand, either one); 0..2 (b == r is never counted)
 BK_HD uint32_t v_alt(uint32_t b, uint32_t r) { return ((b ^ r) & 3u) - 1u; }
+// file bitmaps (IndexView::ent_files): is file f there, and which entry of the bucket is its
+BK_HD bool files_any(const uint4& b) { return (b.x | b.y | b.z | b.w) != 0u; }
+BK_HD bool files_has(const uint4& b, uint32_t f) { const uint32_t w = f < 32u ? b.x : f < 64u ? b.y : f < 96u ? b.z : b.w; return (w >> (f & 31u)) & 1u; }
+BK_HD uint32_t files_rank(const uint4& b, uint32_t f) {
+    const uint32_t m = (1u << (f & 31u)) - 1u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t c0 = __popc(b.x), c1 = __popc(b.y), c2 = __popc(b.z);
+    return f < 32u ? __popc(b.x & m) : f < 64u ? c0 + __popc(b.y & m) : f < 96u ? c0 + c1 + __popc(b.z & m) : c0 + c1 + c2 + __popc(b.w & m);
+#else
+    const uint32_t c0 = (uint32_t)__builtin_popcount(b.x), c1 = (uint32_t)__builtin_popcount(b.y), c2 = (uint32_t)__builtin_popcount(b.z);
+    return f < 32u ? (uint32_t)__builtin_popcount(b.x & m) : f < 64u ? c0 + (uint32_t)__builtin_popcount(b.y & m)
+         : f < 96u ? c0 + c1 + (uint32_t)__builtin_popcount(b.z & m) : c0 + c1 + c2 + (uint32_t)__builtin_popcount(b.w & m);
+#endif
+}
 BK_HD uint32_t v_row_index(uint32_t q, uint32_t alt, uint32_t d) { return (q * 3u + alt) * 2u + d; }
 // first counter of row (q, alt, d); the row has span + 1 counters (the last only ever receives a -1)
 BK_HD uint64_t v_row_base(uint32_t q, uint32_t alt, uint32_t d, int span) { return (((uint64_t)q * 3ull + alt) * 2ull + d) * (uint64_t)(span + 1); }

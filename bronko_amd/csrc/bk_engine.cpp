@@ -268,11 +268,11 @@ struct bk_engine {
     DevBuf<bk::IdRec> id_rec;
     DevBuf<bk::DirtyAns> dirty_ans;
     DevBuf<uint8_t> cell_flags;
-    DevBuf<uint32_t> ref_words, cell_codes, cell_has, cell_clean, cell_clean3, cell_yf, cell_yr, id_at, cell_fast;
+    DevBuf<uint32_t> ref_words, cell_codes, cell_has, cell_clean, cell_clean3, cell_yf, cell_yr, id_at, cell_fast, cell_nat;
     DevBuf<uint2> cell_blk, seed_tab;
     uint32_t seed_log2 = 0;
     struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0, log2p = 0; } half_lo, half_hi;
-    DevBuf<unsigned int> deferred, n_deferred;
+    DevBuf<unsigned int> deferred, n_deferred, deferred_mask;
     DevBuf<unsigned long long> deferred_n;   // dense planes: the deferred k-mers' counts (K2a zeroes the counters it reads)
     DevBuf<unsigned int> fin_partials;      // per-workgroup finalize tallies (small genome sets only)
     DevBuf<unsigned long long> ktab_keys;   // full_kmer_stats: open-addressing table of non-index-touching k-mers
@@ -289,6 +289,7 @@ struct bk_engine {
     bool ktab_exchanged = false;            // bk_kmer_table_replace was called in this sample
     DevBuf<uint32_t> slot_of, estat_off, estat;
     DevBuf<bk::SlotRec> slot_rec;
+    DevBuf<uint4> ent_files, slot_files;
     DevBuf<uint8_t> amb;
     DevBuf<uint16_t> pilots;
     DevBuf<unsigned int> slabs;             // [n_cus][n_lds_bins] workgroup histograms of the last scan launch
@@ -303,7 +304,7 @@ struct bk_engine {
     DevBuf<unsigned long long> counters[2];
     // sparse finalize (large indexes): per mate file the touch bitmaps the counter writers set and the lists finalize walks
     bool sparse = false;
-    DevBuf<unsigned int> touch_v[2], touch_p[2], touch_e[2], v_list[2], p_list[2], e_list[2], n_list[2];
+    DevBuf<unsigned int> touch_v[2], touch_b[2], touch_p[2], touch_e[2], v_list[2], p_list[2], e_list[2], n_list[2];
     bool plane_used[2] = {false, false};   // counters were added to since the planes were last known to be all zero
     DevBuf<unsigned long long> pileup;      // 4 planes
     DevBuf<unsigned long long> stats;       // [2][n_files][3]
@@ -368,11 +369,11 @@ struct bk_engine {
     bk::IndexView view() const {
         bk::IndexView v{};
         v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb; v.log2p = log2p;
-        v.kmer_of = kmer_of.p; v.id_rec = id_rec.p; v.dirty_ans = dirty_ans.p; v.cell_flags = cell_flags.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_clean3 = cell_clean3.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.cell_fast = cell_fast.p; v.cell_blk = cell_blk.p; v.seed_tab = seed_tab.p; v.seed_log2 = seed_log2; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
+        v.kmer_of = kmer_of.p; v.id_rec = id_rec.p; v.dirty_ans = dirty_ans.p; v.cell_flags = cell_flags.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_clean3 = cell_clean3.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.cell_fast = cell_fast.p; v.cell_nat = cell_nat.p; v.cell_blk = cell_blk.p; v.seed_tab = seed_tab.p; v.seed_log2 = seed_log2; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
         v.n_full = n_full; v.n_prows = n_prows; v.prow_id = prow_id.p; v.prow_t = prow_t.p; v.v_omin = v_omin; v.v_span = v_span; v.v_off = v_off;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb, half_lo.log2p};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb, half_hi.log2p};
-        v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.slot_rec = slot_rec.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
+        v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.slot_rec = slot_rec.p; v.ent_files = ent_files.p; v.slot_files = slot_files.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
         v.table = table.p; v.ent_off = ent_off.p; v.ent_len = ent_len.p;
         v.entries = entries.p; v.n_slots = n_slots; v.log2s = log2s; v.k = k; v.wstart = wstart; v.W = W; v.n_files = n_files;
         return v;
@@ -410,6 +411,7 @@ static int alloc_sample_state(bk_engine* e) {
             BK_HIP(e->touch_v[m].alloc(n_rows / 32 + 1)); BK_HIP(e->touch_p[m].alloc(e->n_prows / 32 + 1)); BK_HIP(e->touch_e[m].alloc((size_t)e->n_u / 32 + 1));
             BK_HIP(hipMemset(e->touch_v[m].p, 0, e->touch_v[m].n * 4)); BK_HIP(hipMemset(e->touch_p[m].p, 0, e->touch_p[m].n * 4));
             BK_HIP(hipMemset(e->touch_e[m].p, 0, e->touch_e[m].n * 4));
+            BK_HIP(e->touch_b[m].alloc((size_t)e->total_cells / 64 / 32 + 2)); BK_HIP(hipMemset(e->touch_b[m].p, 0, e->touch_b[m].n * 4));
             BK_HIP(e->v_list[m].alloc(n_rows)); BK_HIP(e->p_list[m].alloc(e->n_prows)); BK_HIP(e->e_list[m].alloc(e->n_u));
             BK_HIP(e->n_list[m].alloc(8));
         }
@@ -431,6 +433,7 @@ static int alloc_sample_state(bk_engine* e) {
     if (e->n_files <= 2048) BK_HIP(e->fin_partials.alloc(bk::finalize_partial_rows() * ((size_t)e->n_files * 3 + 2)));
     BK_HIP(e->deferred.alloc(bk::v_plane_len(e->n_full, e->v_span, e->n_prows) * (prm->pileup_selected_only ? 2 : 1)));   // (one list per mate file when it is kept between two passes)
     BK_HIP(e->n_deferred.alloc(2));   // one per mate file
+    if (prm->pileup_selected_only && e->ent_files.p) BK_HIP(e->deferred_mask.alloc(e->deferred.n));
     if (!e->sparse) {
         // dense planes: K2a zeroes the V counters as it reads them and the (small) E part is zeroed behind K2e, so a plane is
         // clean again when its sample is finalized -- no 37 MB memset per sample (config 2); the deferred k-mers' counts
@@ -843,6 +846,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         // with full_kmer_stats the rows keep every offset, so that k-mers differing outside the window are not lost to the statistics
         e->v_omin = bk::v_layout_omin(k, e->wstart, e->W, prm->full_kmer_stats != 0);
         e->v_span = bk::v_layout_span(k, e->wstart, e->W, prm->full_kmer_stats != 0);
+        std::vector<uint32_t> h_nat;
         {
             std::vector<uint32_t> idx_by_id(h_u.size());
             for (size_t i = 0; i < h_u.size(); i++) idx_by_id[id_of[i]] = (uint32_t)i;
@@ -990,17 +994,23 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 if (h_id_at[c] == kNone) next_none = (uint32_t)c;
                 if ((c & 63) == 0) h_blk[c >> 6].y = next_none;
             }
-            for (uint64_t c = 0; c < cells; c++) {
-                if (!(h_cflags[c] & bk::kCellClean)) continue;
-                const uint32_t delta = h_id_at[c] - (uint32_t)c;
-                uint2& b = h_blk[c >> 6];
-                if (b.x == 0u && delta != 0u) {   // (0 is also "not set yet": a block whose first clean cell has delta 0 keeps it)
-                    bool first = true;
-                    for (uint64_t q = (c >> 6) << 6; q < c; q++) if (h_cflags[q] & bk::kCellClean) { first = false; break; }
-                    if (first) b.x = delta;
+            // x: the most common id - cell among the block's cells that stand in their k-mer's first orientation (clean or not:
+            // with many related genomes no cell is clean, and cell_nat below still wants the constant)
+            for (uint64_t b0 = 0; b0 < cells; b0 += 64) {
+                uint32_t best = 0u, best_n = 0u;
+                const uint64_t b1 = std::min<uint64_t>(b0 + 64, cells);
+                for (uint64_t c = b0; c < b1; c++) {
+                    if (!(h_cflags[c] & bk::kCellFirstOri)) continue;
+                    const uint32_t delta = h_id_at[c] - (uint32_t)c;
+                    if (best_n && delta == best) continue;
+                    uint32_t n = 0;
+                    for (uint64_t q = c; q < b1; q++) n += (h_cflags[q] & bk::kCellFirstOri) && h_id_at[q] - (uint32_t)q == delta;
+                    if (n > best_n) { best_n = n; best = delta; }
                 }
-                if (delta == b.x) h_fast[bpad_w + (c >> 5)] |= 1u << (c & 31);
+                h_blk[b0 >> 6].x = best;
             }
+            for (uint64_t c = 0; c < cells; c++)
+                if ((h_cflags[c] & bk::kCellClean) && h_id_at[c] - (uint32_t)c == h_blk[c >> 6].x) h_fast[bpad_w + (c >> 5)] |= 1u << (c & 31);
         }
         pc.lap("per-cell arrays");
         // ---- dirty answers (bk_device.h DirtyAns): for every reference k-mer with a cell that is not clean, what "this k-mer with
@@ -1146,6 +1156,35 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     });
                     if (bad) return fail(BK_ERR_INVALID, "internal: %llu dirty answers disagree with their definition", (unsigned long long)bad.load());
                 }
+                // cell_nat (bk_device.h): per reference position q and alternative a, bit o = "the k-mer that starts at q - o, with
+                // that other base at q, takes its own V row" -- its cell is clean, or its answer says exactly that (or says that it
+                // touches nothing, which is what finalize makes of the own row's count then: position outside the window or
+                // canonical form on the other strand)
+                h_nat.assign(((size_t)cells + (size_t)k) * 3u, 0u);
+                parallel_for((size_t)cells + (size_t)k, [&](size_t q0, size_t q1) {
+                    for (size_t q = q0; q < q1; q++) {
+                        const uint32_t rb = q < cells ? (h_refw[pad_w + (q >> 4)] >> (2 * (q & 15))) & 3u : 0u;
+                        for (int o = 0; o < k; o++) {
+                            if (q < (size_t)o || q - (size_t)o >= cells) continue;
+                            const size_t c = q - (size_t)o;
+                            const uint32_t id = h_id_at[c];
+                            if (id == kNone || !(h_cflags[c] & bk::kCellFirstOri) || id - (uint32_t)c != h_blk[c >> 6].x) continue;
+                            for (uint32_t al = 0; al < 3; al++) {
+                                bool nat = (h_cflags[c] & bk::kCellClean) != 0;
+                                if (!nat) {
+                                    const bk::DirtyAns& A = h_ans[bk::ans_index(id, (uint32_t)o, rb ^ (al + 1u), k)];
+                                    const uint32_t kind = A.meta & 3u;
+                                    const int oo = o - e->v_omin;
+                                    if (A.meta & bk::kAnsNone) nat = false;
+                                    else if (kind == 0u) nat = true;
+                                    else if (kind == 2u && oo >= 0 && oo < e->v_span)
+                                        nat = A.idx == (uint32_t)(bk::v_row_base(id + (uint32_t)oo, al, 0u, e->v_span) + (uint32_t)oo) && ((A.meta >> 2) & 1u) == rc_of_id[id];
+                                }
+                                if (nat) h_nat[q * 3u + al] |= 1u << o;
+                            }
+                        }
+                    }
+                });
                 BK_HIP(e->dirty_ans.upload(h_ans));
             }
             std::vector<uint64_t>().swap(h_near);
@@ -1172,6 +1211,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         BK_HIP(e->cell_yr.upload(h_yr));
         BK_HIP(e->cell_fast.upload(h_fast));
         BK_HIP(e->cell_blk.upload(h_blk));
+        if (!h_nat.empty()) BK_HIP(e->cell_nat.upload(h_nat));
         BK_HIP(e->cell_codes.upload(h_codes));
         BK_HIP(e->cell_flags.upload(h_cflags));
         BK_HIP(e->id_at.upload(h_id_at));
@@ -1296,6 +1336,35 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     }
             });
             BK_HIP(e->slot_rec.upload(h_rec));
+            // Which genome files a bucket holds, as a bitmap (IndexView::ent_files / slot_files): with up to 128 files, for buckets
+            // that hold at most one BucketInfo per file -- the rule with many related genomes.  The statistics pass of
+            // pileup_selected_only then tallies a k-mer's genomes without reading its ~100 entries, and the voting pass finds the
+            // selected genome's entry by a popcount instead of a bisection.  All zero = look at the entries.
+            if (ix->n_files > 1 && ix->n_files <= 128 && e->W > 1 && !h_len.empty()) {
+                std::vector<uint4> h_ef(h_len.size(), make_uint4(0u, 0u, 0u, 0u));
+                parallel_for(h_len.size(), [&](size_t s0, size_t s1) {
+                    for (size_t sl = s0; sl < s1; sl++) {
+                        uint32_t w[4] = {0u, 0u, 0u, 0u};
+                        bool ok = h_len[sl] > 0;
+                        for (uint32_t q = 0; q < h_len[sl] && ok; q++) {
+                            const uint32_t f = h_ent[h_off[sl] + q].file;
+                            ok = f < 128u && (q == 0 || f > h_ent[h_off[sl] + q - 1].file);   // sorted by file, one entry each
+                            w[(f >> 5) & 3u] |= 1u << (f & 31u);
+                        }
+                        if (ok) h_ef[sl] = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
+                });
+                std::vector<uint4> h_sf((size_t)std::max<size_t>(e->n_full, 1) * e->W, make_uint4(0u, 0u, 0u, 0u));
+                parallel_for(e->n_full, [&](size_t id0, size_t id1) {
+                    for (size_t id = id0; id < id1; id++)
+                        for (int t = 0; t < e->W; t++) {
+                            const uint32_t sl = h_slot_of[id * e->W + t];
+                            if (sl != empty_slot) h_sf[id * e->W + t] = h_ef[sl];
+                        }
+                });
+                BK_HIP(e->ent_files.upload(h_ef));
+                BK_HIP(e->slot_files.upload(h_sf));
+            }
             // IdRec: k-mer, first cell, flags; "simple" = each of the W buckets holds the k-mer's own single occurrence and nothing else
             std::vector<bk::IdRec> h_idrec(std::max<size_t>(h_u.size(), 1), bk::IdRec{bk::kEmptyKey, 0u, 0u});
             for (size_t i = 0; i < h_u.size(); i++) {
@@ -1412,10 +1481,10 @@ int bk_engine_fork_params(const bk_engine* parent, const bk_params* prm, bk_engi
     e->prow_id.alias(p->prow_id); e->prow_t.alias(p->prow_t); e->kmer_pos.alias(p->kmer_pos); e->d_view.alias(p->d_view); e->kmer_of.alias(p->kmer_of); e->id_rec.alias(p->id_rec); e->dirty_ans.alias(p->dirty_ans); e->cell_flags.alias(p->cell_flags);
     e->ref_words.alias(p->ref_words); e->cell_codes.alias(p->cell_codes); e->cell_has.alias(p->cell_has); e->cell_clean.alias(p->cell_clean);
     e->cell_clean3.alias(p->cell_clean3); e->cell_yf.alias(p->cell_yf); e->cell_yr.alias(p->cell_yr); e->id_at.alias(p->id_at);
-    e->cell_fast.alias(p->cell_fast); e->cell_blk.alias(p->cell_blk); e->seed_tab.alias(p->seed_tab); e->seed_log2 = p->seed_log2;
+    e->cell_fast.alias(p->cell_fast); e->cell_nat.alias(p->cell_nat); e->cell_blk.alias(p->cell_blk); e->seed_tab.alias(p->seed_tab); e->seed_log2 = p->seed_log2;
     e->half_lo.pilots.alias(p->half_lo.pilots); e->half_lo.dir.alias(p->half_lo.dir); e->half_lo.cand.alias(p->half_lo.cand);
     e->half_hi.pilots.alias(p->half_hi.pilots); e->half_hi.dir.alias(p->half_hi.dir); e->half_hi.cand.alias(p->half_hi.cand);
-    e->slot_of.alias(p->slot_of); e->estat_off.alias(p->estat_off); e->estat.alias(p->estat); e->slot_rec.alias(p->slot_rec); e->amb.alias(p->amb);
+    e->slot_of.alias(p->slot_of); e->estat_off.alias(p->estat_off); e->estat.alias(p->estat); e->slot_rec.alias(p->slot_rec); e->ent_files.alias(p->ent_files); e->slot_files.alias(p->slot_files); e->amb.alias(p->amb);
     e->pilots.alias(p->pilots); e->table.alias(p->table); e->ent_off.alias(p->ent_off); e->ent_len.alias(p->ent_len); e->entries.alias(p->entries);
     e->occ.alias(p->occ); e->file_cell_lo_d.alias(p->file_cell_lo_d);
     e->genome_len.alias(p->genome_len); e->seq_cell.alias(p->seq_cell); e->seq_len_d.alias(p->seq_len_d); e->seq_first.alias(p->seq_first);
@@ -1495,6 +1564,7 @@ static int zero_plane_if_stale(bk_engine* e, int mate) {
             BK_HIP(hipMemsetAsync(e->counters[mate].p, 0, std::max<size_t>(e->counters[mate].n, 1) * sizeof(unsigned long long), e->stream));
             BK_HIP(hipMemsetAsync(e->touch_v[mate].p, 0, e->touch_v[mate].n * 4, e->stream));
             BK_HIP(hipMemsetAsync(e->touch_p[mate].p, 0, e->touch_p[mate].n * 4, e->stream));
+            BK_HIP(hipMemsetAsync(e->touch_b[mate].p, 0, e->touch_b[mate].n * 4, e->stream));
             BK_HIP(hipMemsetAsync(e->touch_e[mate].p, 0, e->touch_e[mate].n * 4, e->stream));
             e->plane_used[mate] = false;
         }
@@ -1561,7 +1631,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.n_records_dev = n_records_dev;
     a.ixp = e->d_view.p;
     a.k = e->k; a.wstart = e->wstart; a.W = e->W; a.v_omin = e->v_omin; a.v_span = e->v_span; a.v_off = e->v_off; a.total_cells = (uint32_t)e->total_cells; a.n_u = e->n_u;
-    a.ref_words = e->ref_words.p; a.cell_codes = e->cell_codes.p; a.cell_has = e->cell_has.p; a.cell_clean = e->cell_clean.p; a.cell_clean3 = e->cell_clean3.p; a.cell_yf = e->cell_yf.p; a.cell_yr = e->cell_yr.p; a.id_at = e->id_at.p; a.cell_fast = e->cell_fast.p; a.cell_blk = e->cell_blk.p; a.seed_tab = e->seed_tab.p; a.seed_log2 = e->seed_log2;
+    a.ref_words = e->ref_words.p; a.cell_codes = e->cell_codes.p; a.cell_has = e->cell_has.p; a.cell_clean = e->cell_clean.p; a.cell_clean3 = e->cell_clean3.p; a.cell_yf = e->cell_yf.p; a.cell_yr = e->cell_yr.p; a.id_at = e->id_at.p; a.cell_fast = e->cell_fast.p; a.cell_nat = e->cell_nat.p; a.cell_blk = e->cell_blk.p; a.seed_tab = e->seed_tab.p; a.seed_log2 = e->seed_log2;
     a.words = d_words; a.lens = d_lens; a.n_records = n; a.stride_words = stride_words;
     a.counters = e->counters[mate].p;
     a.kmer_total = e->kstats.p + mate * 4 + 1;
@@ -1574,7 +1644,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.occ = e->occ.p; a.n_files = e->n_files;
     e->plane_used[mate] = true;
     if (e->sparse) {
-        a.touch_v = e->touch_v[mate].p; a.touch_p = e->touch_p[mate].p; a.touch_e = e->touch_e[mate].p;
+        a.touch_v = e->touch_v[mate].p; a.touch_b = e->touch_b[mate].p; a.touch_p = e->touch_p[mate].p; a.touch_e = e->touch_e[mate].p;
         a.rl_recip = ~0ull / (unsigned long long)(e->v_span + 1) + 1ull;   // ceil(2^64 / row length): exact quotients for 32-bit counter indices
     }
     if (test_env("BK_L2_STATS") && !e->dbg.p) { BK_HIP(e->dbg.alloc(32)); BK_HIP(hipMemsetAsync(e->dbg.p, 0, 32 * sizeof(unsigned long long), e->stream)); }
@@ -1837,6 +1907,8 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
         for (int m = 0; m < n_mates; m++) {
             bk_engine::Span sp(e, 1);
             BK_HIP(hipMemsetAsync(e->n_list[m].p, 0, 8 * sizeof(unsigned int), e->stream));
+            bk::launch_expand_touched_blocks(e->touch_b[m].p, (uint32_t)((e->total_cells + 63) / 64), e->cell_blk.p, e->touch_v[m].p, (uint32_t)e->k,
+                                             (uint64_t)e->n_full + (uint64_t)e->v_span, e->stream);
             bk::launch_compact_touched(e->touch_v[m].p, bk::v_real_rows(e->n_full, e->v_span), e->touch_p[m].p, e->n_prows, e->touch_e[m].p, e->n_u,
                                        e->n_full, e->v_list[m].p, e->p_list[m].p, e->e_list[m].p, e->n_list[m].p, e->stream);
         }
@@ -1859,6 +1931,7 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             a.partials = e->fin_partials.p;
             a.deferred = e->deferred.p + (two_pass ? (size_t)m * (e->deferred.n / 2) : 0);   // (kept from the first pass to the second)
             a.n_deferred = e->n_deferred.p + m;
+            a.deferred_mask = two_pass && e->deferred_mask.p ? e->deferred_mask.p + (size_t)m * (e->deferred_mask.n / 2) : nullptr;
             a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->ktab_log2;
             a.ktab_overflow = e->ktab_out.p + 4; a.mate = (uint32_t)m;
             if (e->sparse) { a.v_list = e->v_list[m].p; a.p_list = e->p_list[m].p; a.e_list = e->e_list[m].p; a.n_list = e->n_list[m].p; }

@@ -23,6 +23,7 @@ struct ScanArgs {
     const uint32_t* id_at;
     const uint32_t* cell_fast;      // IndexView::cell_fast (1 bit per cell, padded like cell_has) / cell_blk (one entry per 64 cells)
     const uint2* cell_blk;
+    const uint32_t* cell_nat;       // IndexView::cell_nat (or null)
     const uint2* seed_tab;          // IndexView::seed_tab / seed_log2
     uint32_t seed_log2;
     const uint32_t* words;          // [n_records][stride_words] 2-bit packed, 16 bases per word, LSB first
@@ -63,6 +64,7 @@ struct ScanArgs {
     // that finalize walks the touched ones instead of a plane of which a thousandth is non-zero, and clears what it read (no
     // plane memset).  Null for small indexes (dense finalize).
     unsigned int* touch_v;          // [v_real_rows / 32 + 1] bit per V row of the reference k-mers
+    unsigned int* touch_b;          // [cells / 64 / 32 + 2] scan_count_kernel: bit per block of 64 cells whose rows it counted into (expanded into touch_v)
     unsigned int* touch_p;          // [n_prows / 32 + 1]     bit per pseudo k-mer row (8 counters)
     unsigned int* touch_e;          // [n_u / 32 + 1]         bit per id (its two E counters)
     unsigned long long rl_recip;    // ceil(2^64 / (v_span + 1)): counter index -> row by __umul64hi
@@ -87,6 +89,8 @@ struct FinalizeArgs {
     unsigned long long* deferred_n; // ... and their counts (clear_v: K2b cannot read them from the plane any more); may be null
     int clear_v;                    // K2a zeroes every V counter it reads (dense planes, the whole plane in this call, last pass):
                                     // the plane needs no memset before the next sample
+    unsigned int* deferred_mask;    // ... pileup_selected_only with file bitmaps: per deferred k-mer, the window positions at which the statistics
+                                    // pass found a bucket (what the voting pass probes); may be null
     unsigned int* n_deferred;       // [1], zeroed before each finalize
     // full_kmer_stats: k-mers recorded in V rows that cannot touch the index join the statistics table (null = off)
     unsigned long long* ktab_keys;
@@ -166,6 +170,7 @@ void launch_ktab_totals_to_kstats(unsigned long long* ktab_out, unsigned long lo
 uint32_t ktab_fill_words();   // tallies of new keys behind the overflow word: ktab_out[8 ..]
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
 // sparse finalize: touch bitmaps -> lists (the bitmaps are cleared on the way); lists -> their counters zeroed again
+void launch_expand_touched_blocks(unsigned int* touch_b, uint32_t n_blocks, const uint2* cell_blk, unsigned int* touch_v, uint32_t span, uint64_t n_q, hipStream_t stream);
 void launch_compact_touched(unsigned int* touch_v, uint64_t n_rows, unsigned int* touch_p, uint64_t n_prows, unsigned int* touch_e, uint64_t n_ids,
                             uint64_t n_full, unsigned int* v_list, unsigned int* p_list, unsigned int* e_list, unsigned int* n_list, hipStream_t stream);
 void launch_clear_touched(unsigned long long* counters, uint64_t v_off, uint64_t v_real_len, uint32_t rl, const unsigned int* v_list,

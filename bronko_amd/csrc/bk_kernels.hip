@@ -440,8 +440,8 @@ constexpr int kBitBackWords = 3;
 // and the same counter --, and same-address global atomics serialise at ~12 ns each: 0.02 ms of the kernel on the benchmark's 40
 // variant sites.  So a workgroup keeps the counters it meets a second time in a small LDS table (direct-mapped; a filter of one
 // bit per hash value says "met before") and adds its totals once at the end; everything else goes out as before.
-constexpr uint32_t kHotSlots = 256, kSeenWords = 1024;
-constexpr size_t kScanLdsFixed = 16 + 64 + 4 * kScanBlock + 4 * (2 * kHotSlots + kSeenWords) + 8;   // k-mer tally, wave totals of the epilogue, the item owners, the hot counters, alignment of the block entries
+constexpr uint32_t kHotSlots = 256, kSeenWords = 1024, kBlkTouchWords = 32;   // (32 words: 1024 blocks of 64 cells, more than an LDS window holds)
+constexpr size_t kScanLdsFixed = 16 + 64 + 4 * kScanBlock + 4 * (2 * kHotSlots + kSeenWords + kBlkTouchWords) + 8;   // k-mer tally, wave totals of the epilogue, the item owners, the hot counters, alignment of the block entries
 
 // number of set bits of a wave mask below this lane
 __device__ __forceinline__ uint32_t lane_prefix(unsigned long long m) {
@@ -490,7 +490,8 @@ __device__ __forceinline__ uint32_t bits32_at(const uint32_t* __restrict__ w, in
 // sparse finalize (ScanArgs::touch_v): set bit `i` of a touch bitmap (null: dense finalize, nothing to note)
 __device__ __forceinline__ void touch(unsigned int* bm, uint32_t i) {
     // (looked at first: most rows are touched many times a sample and a stale 0 only costs the atomic it would have cost anyway)
-    if (bm && !(__builtin_nontemporal_load(bm + (i >> 5)) >> (i & 31u) & 1u)) atomicOr(bm + (i >> 5), 1u << (i & 31u));
+    // (an agent-scope load: from L2, where the atomics land; a non-temporal one went to memory every time)
+    if (bm && !(__hip_atomic_load(bm + (i >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (i & 31u) & 1u)) atomicOr(bm + (i >> 5), 1u << (i & 31u));
 }
 
 __device__ __forceinline__ void v_point(unsigned long long* __restrict__ v_counters, uint32_t id, uint32_t o, uint32_t alt, uint32_t d,
@@ -620,7 +621,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     unsigned int* hot_key = own_all + kScanBlock;   // [kHotSlots] V counters this workgroup adds to again and again (below), ~0 = free
     unsigned int* hot_cnt = hot_key + kHotSlots;    // [kHotSlots] ... and what it has for them
     unsigned int* seen = hot_cnt + kHotSlots;       // [kSeenWords] one bit per hash value: a +1 for such a counter was issued before
-    unsigned int* bins = seen + kSeenWords;         // [n_lds_bins + 1] the per-cell difference array
+    unsigned int* blk_t = seen + kSeenWords;        // [kBlkTouchWords] sparse planes: the window's blocks of 64 cells whose V rows this workgroup counted into
+    unsigned int* bins = blk_t + kBlkTouchWords;    // [n_lds_bins + 1] the per-cell difference array
     unsigned int* lds_ref = bins + a.n_lds_bins + 1;   // REF_LDS: padded ref words, the padded fast-bit array, the block entries
 
     const int lane = threadIdx.x & 63;
@@ -641,6 +643,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     for (uint32_t i = threadIdx.x; i <= a.n_lds_bins; i += kScanBlock) bins[i] = 0u;
     for (uint32_t i = threadIdx.x; i < kHotSlots; i += kScanBlock) { hot_key[i] = 0xffffffffu; hot_cnt[i] = 0u; }
     for (uint32_t i = threadIdx.x; i < kSeenWords; i += kScanBlock) seen[i] = 0u;
+    if (threadIdx.x < kBlkTouchWords) blk_t[threadIdx.x] = 0u;
     if (REF_LDS) {
         for (uint32_t i = threadIdx.x; i < n_refw; i += kScanBlock) lds_ref[i] = a.ref_words[(win_lo >> 4) + i];
         for (uint32_t i = threadIdx.x; i < n_bitw; i += kScanBlock) lds_ref[n_refw + i] = a.cell_fast[(win_lo >> 5) + i];
@@ -955,13 +958,18 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 const int32_t ca = own ? (ofwd ? o_dgw + (int32_t)o_lo : o_dgw - (int32_t)o_hi) : 0;
                 const uint32_t n_own = own ? o_hi - o_lo + 1u : 0u;           // (at most k <= 31)
                 uint32_t pat = bits32_at(fastw, ca) & ((1u << n_own) - 1u);   // bit p: the cell ca + p is fast
-                if (BK_ABLATE(a, 5)) pat = 0u;                                // (5: nothing is settled here)
                 // which of the three other bases: read XOR reference at the mismatch, the same on either strand (bk_device.h)
                 const uint32_t tt = own ? (uint32_t)t : 0u;
                 const uint32_t rw = (words0 + (uint64_t)o_rec * a.stride_words)[min(tt >> 4, last_word)];
                 const int32_t pr = own ? (ofwd ? o_dgw + (int32_t)tt : o_dgw + (int32_t)km1 - (int32_t)tt) : 0;
                 const uint32_t refb = (refw1[pr >> 4] >> (2u * ((uint32_t)pr & 15u))) & 3u;
                 const uint32_t alt = ((((rw >> (2u * (tt & 15u))) & 3u) ^ (ofwd ? refb : 3u - refb)) & 3u) - 1u;
+                // Cells that are not fast (no cell of a many-genome index is clean): per (position of the mismatch, other base) the
+                // offsets at which the k-mer still takes its own row (IndexView::cell_nat) -- one word for all the k-mers of the range,
+                // bit o <-> cell pr - o
+                if (a.cell_nat && own && pat != (1u << n_own) - 1u && !BK_ABLATE(a, 12))
+                    pat |= (__brev(a.cell_nat[((size_t)(pr + (int32_t)win_lo)) * 3u + alt]) >> (31u - (uint32_t)(pr - ca))) & ((1u << n_own) - 1u);
+                if (BK_ABLATE(a, 5)) pat = 0u;                                // (5: nothing is settled here)
                 uint32_t used = 0u;   // cells of the range already dealt with
                 while (__ballot(used < n_own)) {
                     const bool go = used < n_own;
@@ -990,7 +998,12 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                         if (has_s && lo2 <= hi2 && !BK_ABLATE(a, 2)) {
                             const uint32_t idS = (uint32_t)(ofwd ? c0 : c1) + win_lo + ba.x;   // id of the cell of k-mer x_lo (cell_fast: ids = cell + constant)
                             const uint64_t ci = v_row_base(idS + of_first - (uint32_t)omin, alt, ofwd ? 0u : 1u, span) + (uint32_t)(lo2 - omin);
-                            if constexpr (SPARSE) touch(a.touch_v, v_row_index(idS + of_first - (uint32_t)omin, alt, ofwd ? 0u : 1u));
+                            if constexpr (SPARSE) {
+                                // the row is touched: noted per block of 64 cells (a bit per row in device memory, looked at and set
+                                // for every mismatch, took two thirds of this kernel on a 100-strain index), handed on in the epilogue
+                                const uint32_t tb = (uint32_t)(ofwd ? c0 : c1) >> 6;
+                                if (!(blk_t[tb >> 5] >> (tb & 31u) & 1u)) __hip_atomic_fetch_or(&blk_t[tb >> 5], 1u << (tb & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
                             // the +1: into the workgroup's table when this counter was met before and its slot is free or its own
                             const uint32_t hk = (uint32_t)ci * 0x9E3779B1u;
                             const uint32_t sbit = 1u << (hk >> 27);
@@ -1001,8 +1014,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                                 kept = __hip_atomic_compare_exchange_strong(&hot_key[hs], &expect, (uint32_t)ci, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) || expect == (uint32_t)ci;
                                 if (kept) __hip_atomic_fetch_add(&hot_cnt[hs], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
-                            if (!kept) atomicAdd(v_counters + ci, 1ull);
-                            if (hi2 - omin + 1 < span) atomicAdd(v_counters + ci + (uint32_t)(hi2 - lo2 + 1), ~0ull);   // (slot `span` is never read)
+                            if (!kept && !BK_ABLATE(a, 14)) atomicAdd(v_counters + ci, 1ull);
+                            if (hi2 - omin + 1 < span && !BK_ABLATE(a, 14)) atomicAdd(v_counters + ci + (uint32_t)(hi2 - lo2 + 1), ~0ull);   // (slot `span` is never read)
                         }
                     }
                     {
@@ -1035,6 +1048,14 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
     if (threadIdx.x == 0) *block_kmers = 0;
     __syncthreads();
     if (threadIdx.x < kHotSlots && hot_cnt[threadIdx.x]) atomicAdd(v_counters + hot_key[threadIdx.x], (unsigned long long)hot_cnt[threadIdx.x]);   // the table's totals
+    if constexpr (SPARSE) {
+        // blocks whose rows were counted into -> ScanArgs::touch_b (expanded into touch_v's row bits before the rows are listed)
+        const uint32_t b = threadIdx.x;
+        if (b < 32u * kBlkTouchWords && (blk_t[b >> 5] >> (b & 31u) & 1u)) {
+            const uint32_t gb = (win_lo >> 6) + b;
+            if (!(a.touch_b[gb >> 5] >> (gb & 31u) & 1u)) atomicOr(a.touch_b + (gb >> 5), 1u << (gb & 31u));
+        }
+    }
     if (!BK_ABLATE(a, 8)) {   // (8: without the prefix sum and the slab)
         const uint32_t nb = a.n_lds_bins;
         const uint32_t per = (nb + kScanBlock - 1) / kScanBlock;
@@ -2145,6 +2166,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (act) { distinct += do_stats; if (n < a.ci || n > a.cx) act = false; else kept += do_stats; }   // kmc -ci / -cx act on the true count
         const unsigned long long v = n > a.cs ? a.cs : n;       // kmc -cs: reported count saturates
         const uint32_t t = (uint32_t)(j - ix.wstart);
+        bool defer = false;
         if (act && dirty) {
             // u has another reference k-mer within Hamming distance 2: c may touch a second window bucket.  Whether its
             // neighbours sit at several window positions was worked out with its answer (DirtyAns); without the table,
@@ -2157,9 +2179,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 for_each_neighbour(ix, c, [&](int jj, uint32_t, uint32_t) { jmask |= 1u << (jj - ix.wstart); });
                 multi = jmask != (1u << t);
             }
-            if (multi) {
-                if (do_stats) { const unsigned int at = atomicAdd(a.n_deferred, 1u); a.deferred[at] = (uint32_t)(wk * rl + oo); if (a.deferred_n) a.deferred_n[at] = n; }
-                act = false;
+            if (multi) { defer = do_stats; act = false; }
+        }
+        {
+            // the deferred k-mers of the wave are appended together: one returning atomic on the list's counter per wave, not one per
+            // k-mer (with 100 strains one variant k-mer in eight comes here)
+            const unsigned long long dm = __ballot(defer);
+            if (dm) {
+                unsigned int base = 0;
+                if (lane64 == (uint32_t)__builtin_ctzll(dm)) base = atomicAdd(a.n_deferred, (unsigned int)__popcll(dm));
+                base = (unsigned int)__shfl((int)base, __builtin_ctzll(dm));
+                if (defer) {
+                    const unsigned int at = base + (unsigned int)__popcll(dm & ((1ull << lane64) - 1ull));
+                    a.deferred[at] = (uint32_t)(wk * rl + oo);
+                    if (a.deferred_n) a.deferred_n[at] = n;
+                }
             }
         }
         // the bucket (p, t): a "simple" k-mer's is its own single occurrence, known from the record; otherwise the table says
@@ -2171,6 +2205,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const uint32_t cnt = r.y;
         DevEntry first;
         first.cell = r.z; first.file = (uint16_t)(r.w & 0xffffu); first.idx = (uint8_t)(r.w >> 16); first.canonical = (uint8_t)(r.w >> 24);
+        // statistics pass, many genomes: which of them the bucket holds, as a bitmap (IndexView::slot_files) -- the wave tallies the
+        // genomes of all its k-mers together below, one ballot per genome, instead of every lane walking ~100 entries
+        uint4 sfb = make_uint4(0u, 0u, 0u, 0u);
+        if (a.mode == 1 && ix.slot_files) {
+            if (act && cnt > 1u) sfb = ix.slot_files[(size_t)p * ix.W + t];
+            if (__ballot(files_any(sfb))) {
+                for (uint32_t f0 = 0; f0 < (uint32_t)ix.n_files; f0 += 32u) {
+                    const uint32_t wd = f0 == 0u ? sfb.x : f0 == 32u ? sfb.y : f0 == 64u ? sfb.z : sfb.w;
+                    if (!__ballot(wd != 0u)) continue;
+                    const uint32_t fe = min(32u, (uint32_t)ix.n_files - f0);
+                    for (uint32_t b = 0; b < fe; ++b) {
+                        const uint32_t nb = (uint32_t)__popcll(__ballot((wd >> b) & 1u));   // k-mers of the wave whose bucket holds genome f0 + b:
+                        if (nb && lane64 == b) atomicAdd(&lstats[(f0 + b) * 3u + 1u], nb);   // one hit there (W > 1: "variant"), never perfect
+                    }
+                }
+            }
+        }
         // single-entry bucket: the vote of call.rs:1327-1384 (see vote()), merged across the row when possible
         const bool single = act && cnt == 1u;
         if (single) vt_vote(vt, par, a, first, c, isrc, k, v);
@@ -2191,12 +2242,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
         if (act && cnt > 1u && !do_stats) {
             // second pass: the selected genome's entries of the bucket only
+            const uint4 fb = ix.slot_files ? ix.slot_files[(size_t)p * ix.W + t] : make_uint4(0u, 0u, 0u, 0u);
+            if (files_any(fb)) {                               // (one entry per genome: the selected genome's by its rank, if it is there)
+                if (files_has(fb, (uint32_t)a.sel_file)) vt_vote(vt, par, a, ix.entries[r.x + files_rank(fb, (uint32_t)a.sel_file)], c, isrc, k, v);
+            } else
             for (uint32_t x = first_of_file(ix.entries + r.x, cnt, a.sel_file); x < cnt; ++x) {
                 const DevEntry en = ix.entries[r.x + x];
                 if ((int)en.file != a.sel_file) break;
                 vt_vote(vt, par, a, en, c, isrc, k, v);
             }
-        } else if (act && cnt > 1u && a.mode == 1) {
+        } else if (act && cnt > 1u && a.mode == 1 && !files_any(sfb)) {
             // statistics pass, no votes: the genomes of the bucket and how often each is there.  Four entries are asked for at a
             // time (the walk over ~100 genomes' entries is a chain of dependent loads otherwise: latency, not bandwidth)
             uint32_t n_perfect = 0, perfect_file = 0, cur = first.file, run = 1;
@@ -2218,7 +2273,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             }
             close();
             if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
-        } else if (act && cnt > 1u) {
+        } else if (act && cnt > 1u && a.mode != 1) {
             // entries of one bucket are grouped by file (index build appends file by file): run lengths = hits per file
             uint32_t n_perfect = 0, perfect_file = 0;
             for (uint32_t x = 0; x < cnt;) {
@@ -2332,6 +2387,10 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
                 vt_vote(vt, par, a, first, c, isrc, k, v);
                 for (uint32_t q = 1; q < r.y; ++q) vt_vote(vt, par, a, ix.entries[r.x + q], c, isrc, k, v);
             } else if (r.y && !do_stats) {                     // second pass: the selected genome's entries only
+                const uint4 fb = ix.slot_files ? ix.slot_files[(size_t)id * W + t] : make_uint4(0u, 0u, 0u, 0u);
+                if (files_any(fb)) {                           // (one entry per genome: the selected genome's by its rank, if it is there)
+                    if (files_has(fb, (uint32_t)a.sel_file)) vt_vote(vt, par, a, ix.entries[r.x + files_rank(fb, (uint32_t)a.sel_file)], c, isrc, k, v);
+                } else
                 for (uint32_t q = first_of_file(ix.entries + r.x, r.y, a.sel_file); q < r.y; ++q) {
                     const DevEntry en = ix.entries[r.x + q];
                     if ((int)en.file != a.sel_file) break;
@@ -2427,11 +2486,19 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
             v_kmer_of_counter(ix, a.deferred_n ? nullptr : a.counters + ix.v_off, a.deferred[item], p_, t_, c, isrc, v);
             if (a.deferred_n) v = a.deferred_n[item];
             v = v > a.cs ? a.cs : v;
-            for (int t = 0; t < ix.W; ++t) {
+            // (the window positions at which the first pass found a bucket, when it noted them)
+            for (uint32_t tm = a.deferred_mask ? a.deferred_mask[item] : 0xffffffffu >> (32 - ix.W); tm; tm &= tm - 1u) {
+                const int t = __builtin_ctz(tm);
                 const int sh = 2 * (k - 1 - (ix.wstart + t));
                 const int sb = probe_table(ix.table + (size_t)t * S, ix.log2s, c & ~(3ull << sh));
                 if (sb < 0) continue;
-                const uint32_t off = ix.ent_off[sb], cnt = ix.ent_len[sb];
+                const uint32_t off = ix.ent_off[sb];
+                const uint4 fb = ix.ent_files ? ix.ent_files[sb] : make_uint4(0u, 0u, 0u, 0u);
+                if (files_any(fb)) {   // one entry per genome: the selected genome's by its rank, if it is there
+                    if (files_has(fb, (uint32_t)a.sel_file)) vote(a, ix.entries[off + files_rank(fb, (uint32_t)a.sel_file)], c, isrc, k, v);
+                    continue;
+                }
+                const uint32_t cnt = ix.ent_len[sb];
                 for (uint32_t q = first_of_file(ix.entries + off, cnt, a.sel_file); q < cnt; ++q) {
                     const DevEntry e = ix.entries[off + q];
                     if ((int)e.file != a.sel_file) break;
@@ -2441,9 +2508,7 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
         }
         return;
     }
-    // deferred items all passed the thresholds in K2a; one item per wave at a time, dealt round-robin so that a few
-    // thousand items spread over the whole grid
-    for (uint64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    auto wave_item = [&](uint64_t item) {
         {
             const uint64_t ci = n_e + a.deferred[item];          // always a V counter: the E counters are mapped by K2e (n_e: unused offset)
             unsigned long long v;
@@ -2496,7 +2561,50 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
             if (lane == 0) *ntouched = 0;
             __syncthreads();
         }
-    }
+    };
+    if (a.mode == 1 && ix.ent_files) {
+        // Statistics pass with file bitmaps (IndexView::ent_files; many related genomes): every lane takes a k-mer of its own and
+        // walks the window positions -- probe the bucket, OR its genomes into the k-mer's set.  With one BucketInfo per genome and
+        // bucket, and fewer buckets than the window is long, no genome can be "perfect": each genome of the set is one "variant",
+        // tallied for the whole wave with one ballot per genome.  The positions found are noted for the voting pass.  A k-mer
+        // with a bucket that has no bitmap (a genome twice in it), or with all W buckets, takes the wave-per-k-mer path below.
+        for (uint64_t item0 = (uint64_t)blockIdx.x * 64; item0 < n_items; item0 += (uint64_t)gridDim.x * 64) {
+            const uint64_t item = item0 + (uint32_t)lane;
+            const bool on = item < n_items;
+            unsigned long long v = 0;
+            uint64_t c = 0;
+            uint32_t isrc = 0, p_ = 0, t_ = 0;
+            if (on) v_kmer_of_counter(ix, nullptr, a.deferred[item], p_, t_, c, isrc, v);
+            uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+            uint32_t found = 0;
+            bool generic = false;
+            for (int t = 0; t < ix.W; ++t) {
+                const int sh = 2 * (k - 1 - (ix.wstart + t));
+                const int sb = on ? probe_table(ix.table + (size_t)t * S, ix.log2s, c & ~(3ull << sh)) : -1;
+                if (sb < 0) continue;
+                const uint4 fb = ix.ent_files[sb];
+                generic |= !files_any(fb);
+                acc.x |= fb.x; acc.y |= fb.y; acc.z |= fb.z; acc.w |= fb.w;
+                found |= 1u << t;
+            }
+            generic |= found == 0xffffffffu >> (32 - ix.W);
+            if (on && a.deferred_mask) a.deferred_mask[item] = found;
+            if (!on || generic) acc = make_uint4(0u, 0u, 0u, 0u);
+            for (uint32_t f0 = 0; f0 < (uint32_t)ix.n_files; f0 += 32u) {
+                const uint32_t wd = f0 == 0u ? acc.x : f0 == 32u ? acc.y : f0 == 64u ? acc.z : acc.w;
+                if (!__ballot(wd != 0u)) continue;
+                const uint32_t fe = min(32u, (uint32_t)ix.n_files - f0);
+                for (uint32_t b = 0; b < fe; ++b) {
+                    const uint32_t nb = (uint32_t)__popcll(__ballot((wd >> b) & 1u));
+                    if (nb && (uint32_t)lane == b) lstats[(f0 + b) * 3u + 1u] += nb;   // (one wave per workgroup: no atomic needed)
+                }
+            }
+            for (unsigned long long gm = __ballot(on && generic); gm; gm &= gm - 1ull) wave_item(item0 + (uint64_t)__builtin_ctzll(gm));
+        }
+    } else
+    // deferred items all passed the thresholds in K2a; one item per wave at a time, dealt round-robin so that a few
+    // thousand items spread over the whole grid
+    for (uint64_t item = blockIdx.x; item < n_items; item += gridDim.x) wave_item(item);
     __syncthreads();
     if (lane == 0) { ntouched[0] = 0; ntouched[1] = 0; }
     __syncthreads();
@@ -2532,6 +2640,29 @@ __global__ __launch_bounds__(256) void compact_touched_kernel(unsigned int* bm, 
         for (; lo; lo &= lo - 1u) list[base_lo++] = (uint32_t)(w * 32) + (uint32_t)__builtin_ctz(lo);
         for (; hi; hi &= hi - 1u) list[cap - 1 - base_hi++] = (uint32_t)(w * 32) + (uint32_t)__builtin_ctz(hi);
     }
+}
+// The scan notes the V rows it counted into per block of 64 cells (ScanArgs::touch_b): the rows of block gb are q = cell +
+// cell_blk[gb].x + offset, |offset| < k -- all of them are marked here (an over-approximation: rows that hold nothing are
+// read as zeros by finalize and zeroed again).  One wave per block; the block bitmap is cleared.
+__global__ __launch_bounds__(256) void expand_touched_blocks_kernel(unsigned int* touch_b, uint32_t n_blocks, const uint2* cell_blk, unsigned int* touch_v,
+                                                                    uint32_t span, uint64_t n_q) {
+    const uint32_t gb = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;   // one wave per block of 64 cells
+    if (gb >= n_blocks || !((touch_b[gb >> 5] >> (gb & 31u)) & 1u)) return;
+    if (lane == 0) atomicAnd(touch_b + (gb >> 5), ~(1u << (gb & 31u)));
+    const uint32_t q_0 = gb * 64u + cell_blk[gb].x;                    // id of the block's first cell (were it one of the majority)
+    const uint32_t q_lo = q_0 >= span ? q_0 - span : 0u;               // (a run's row is its first k-mer's id + an offset in (-span, span))
+    if ((uint64_t)q_lo >= n_q) return;
+    const uint64_t q_hi = min((uint64_t)q_0 + 64u + span, n_q);        // (exclusive)
+    const uint64_t r0 = (uint64_t)q_lo * kVRowsPerPos, r1 = q_hi * kVRowsPerPos;   // the bits [r0, r1), a word per lane
+    for (uint64_t w = (r0 >> 5) + lane; w * 32u < r1; w += 64u) {
+        const uint64_t lo = max(w * 32u, r0), hi = min(w * 32u + 32u, r1);
+        const uint32_t take = (uint32_t)(hi - lo);
+        atomicOr(touch_v + w, (take == 32u ? 0xffffffffu : (1u << take) - 1u) << (uint32_t)(lo & 31u));
+    }
+}
+void launch_expand_touched_blocks(unsigned int* touch_b, uint32_t n_blocks, const uint2* cell_blk, unsigned int* touch_v, uint32_t span, uint64_t n_q, hipStream_t stream) {
+    if (!n_blocks) return;
+    hipLaunchKernelGGL(expand_touched_blocks_kernel, dim3((n_blocks + 3u) / 4u), dim3(256), 0, stream, touch_b, n_blocks, cell_blk, touch_v, span, n_q);
 }
 void launch_compact_touched(unsigned int* touch_v, uint64_t n_rows, unsigned int* touch_p, uint64_t n_prows, unsigned int* touch_e, uint64_t n_ids,
                             uint64_t n_full, unsigned int* v_list, unsigned int* p_list, unsigned int* e_list, unsigned int* n_list, hipStream_t stream) {

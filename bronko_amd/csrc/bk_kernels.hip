@@ -577,9 +577,20 @@ struct SlowPipe {
                 }
             };
             if (cnt_lo) consider(b0);
-            for (uint32_t i = 1; i < cnt_lo; ++i) consider(*reinterpret_cast<const uint4*>(ix.lo.cand + off_lo + i));   // rare
             if (cnt_hi) consider(b1);
-            for (uint32_t i = 1; i < cnt_hi; ++i) consider(*reinterpret_cast<const uint4*>(ix.hi.cand + off_hi + i));   // rare
+            // the rest of both lists (one candidate each with a single genome; dozens with a hundred strains, where every k-mer of
+            // a strain shares its halves with the other strains' variants): four loads in flight at a time, not one after the other
+            const uint32_t r_lo = cnt_lo ? cnt_lo - 1u : 0u, r_hi = cnt_hi ? cnt_hi - 1u : 0u, tot = r_lo + r_hi;
+            for (uint32_t i = 0; i < tot; i += 4u) {
+                uint4 e[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t ii = min(i + u, tot - 1u);
+                    e[u] = ii < r_lo ? *reinterpret_cast<const uint4*>(ix.lo.cand + off_lo + 1u + ii) : *reinterpret_cast<const uint4*>(ix.hi.cand + off_hi + 1u + (ii - r_lo));
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) if (i + u < tot) consider(e[u]);
+            }
             if (best != ~0ull) {
                 const int j = (int)(best >> 32);
                 const uint32_t p = (uint32_t)best;
@@ -1818,6 +1829,31 @@ __device__ __forceinline__ uint32_t first_of_file(const DevEntry* __restrict__ e
     return lo;
 }
 
+// File bitmaps (IndexView::ent_files) of a wave's k-mers -> lstats[file * 3 + 1] += number of lanes whose bitmap holds the file:
+// one ballot per file, the count written into the file's own lane (v_writelane), one LDS add per word of 32 files.  Every lane of
+// the wave calls it (lanes without a k-mer with an all-zero bitmap).
+template <int B>
+__device__ __forceinline__ void write_lane(int& acc, int nb) { asm("v_writelane_b32 %0, %1, %2" : "+v"(acc) : "s"(nb), "n"(B)); }
+template <int... B>
+__device__ __forceinline__ void tally_word(uint32_t wd, int& acc, std::integer_sequence<int, B...>) {
+    (write_lane<B>(acc, __popcll(__ballot((wd & (1u << B)) != 0u))), ...);
+}
+template <bool ATOMIC>
+__device__ __forceinline__ void tally_files(const uint4& fb, uint32_t* lstats, uint32_t lane, uint32_t n_files) {
+    if (!__ballot(files_any(fb))) return;
+#pragma unroll
+    for (uint32_t w = 0; w < 4u; ++w) {
+        const uint32_t wd = w == 0u ? fb.x : w == 1u ? fb.y : w == 2u ? fb.z : fb.w;
+        if (w * 32u >= n_files || !__ballot(wd != 0u)) continue;
+        int acc = 0;
+        tally_word(wd, acc, std::make_integer_sequence<int, 32>{});
+        const uint32_t f = w * 32u + lane;
+        if (lane < 32u && acc && f < n_files) {
+            if (ATOMIC) atomicAdd(&lstats[f * 3u + 1u], (uint32_t)acc); else lstats[f * 3u + 1u] += (uint32_t)acc;
+        }
+    }
+}
+
 // lstats[idx] += 1 from every active lane: the lanes of a wave walk the entry lists of their buckets in step, and with many
 // genomes that share a k-mer they name the same genome at the same time -- one LDS atomic for all lanes that agree with the
 // first active one instead of up to 64 on one address
@@ -2210,17 +2246,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         uint4 sfb = make_uint4(0u, 0u, 0u, 0u);
         if (a.mode == 1 && ix.slot_files) {
             if (act && cnt > 1u) sfb = ix.slot_files[(size_t)p * ix.W + t];
-            if (__ballot(files_any(sfb))) {
-                for (uint32_t f0 = 0; f0 < (uint32_t)ix.n_files; f0 += 32u) {
-                    const uint32_t wd = f0 == 0u ? sfb.x : f0 == 32u ? sfb.y : f0 == 64u ? sfb.z : sfb.w;
-                    if (!__ballot(wd != 0u)) continue;
-                    const uint32_t fe = min(32u, (uint32_t)ix.n_files - f0);
-                    for (uint32_t b = 0; b < fe; ++b) {
-                        const uint32_t nb = (uint32_t)__popcll(__ballot((wd >> b) & 1u));   // k-mers of the wave whose bucket holds genome f0 + b:
-                        if (nb && lane64 == b) atomicAdd(&lstats[(f0 + b) * 3u + 1u], nb);   // one hit there (W > 1: "variant"), never perfect
-                    }
-                }
-            }
+            tally_files<true>(sfb, lstats, lane64, (uint32_t)ix.n_files);   // one hit in each of its genomes (W > 1: "variant"), never perfect
         }
         // single-entry bucket: the vote of call.rs:1327-1384 (see vote()), merged across the row when possible
         const bool single = act && cnt == 1u;
@@ -2590,15 +2616,7 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
             generic |= found == 0xffffffffu >> (32 - ix.W);
             if (on && a.deferred_mask) a.deferred_mask[item] = found;
             if (!on || generic) acc = make_uint4(0u, 0u, 0u, 0u);
-            for (uint32_t f0 = 0; f0 < (uint32_t)ix.n_files; f0 += 32u) {
-                const uint32_t wd = f0 == 0u ? acc.x : f0 == 32u ? acc.y : f0 == 64u ? acc.z : acc.w;
-                if (!__ballot(wd != 0u)) continue;
-                const uint32_t fe = min(32u, (uint32_t)ix.n_files - f0);
-                for (uint32_t b = 0; b < fe; ++b) {
-                    const uint32_t nb = (uint32_t)__popcll(__ballot((wd >> b) & 1u));
-                    if (nb && (uint32_t)lane == b) lstats[(f0 + b) * 3u + 1u] += nb;   // (one wave per workgroup: no atomic needed)
-                }
-            }
+            tally_files<false>(acc, lstats, (uint32_t)lane, (uint32_t)ix.n_files);   // (one wave per workgroup: no atomic needed)
             for (unsigned long long gm = __ballot(on && generic); gm; gm &= gm - 1ull) wave_item(item0 + (uint64_t)__builtin_ctzll(gm));
         }
     } else

@@ -201,6 +201,11 @@ struct IndexView {
     const uint4*     ent_files;  // [n_slots] / slot_files [n_full][W]: bit f = the bucket holds a BucketInfo of genome file f -- exactly one, the
     const uint4*     slot_files; //   entries sorted by file, so file f's is entry number popcount(bits below f); all zero = not such a bucket
                                  //   (or more than 128 files, or W == 1: both null): look at the entries.  bk_params.pileup_selected_only.
+    const SlotRec*   vslot_rec;    // [n_full + v_span][v_span] slot_rec / slot_files by diagonal, for K2a: the bucket of (id, window position j) at
+    const uint4*     vslot_files;  //   [(id + oo) * v_span + oo], oo = the V-row offset j stands for (first-occurrence coordinates); null with slot_files
+    const uint4*     id_own_files; // [n_full] bit f = in each of the k-mer's W buckets genome f's one BucketInfo is the k-mer's own occurrence in f:
+                                   //   that of bucket t = that of bucket 0 with cell + t, idx + t; null with slot_files
+    const uint4*     estat_files;  // [n_full][2] estat as bitmaps: genomes in which the k-mer is perfect / a variant; null with slot_files
     const uint8_t*   amb;      // [n_u] bit 1 = the k-mer's first occurrence was reverse-complemented to become canonical; bit 0 = "dirty": another reference k-mer (either strand) lies within Hamming
                                //       distance 2 of it, or it is within distance 2 of its own reverse complement
     const uint32_t*  estat_off;// [n_u + 1] per reference k-mer: its genomes, precomputed from the index alone

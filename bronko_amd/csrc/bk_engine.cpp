@@ -289,7 +289,8 @@ struct bk_engine {
     bool ktab_exchanged = false;            // bk_kmer_table_replace was called in this sample
     DevBuf<uint32_t> slot_of, estat_off, estat;
     DevBuf<bk::SlotRec> slot_rec;
-    DevBuf<uint4> ent_files, slot_files;
+    DevBuf<uint4> ent_files, slot_files, vslot_files, id_own_files, estat_files;
+    DevBuf<bk::SlotRec> vslot_rec;
     DevBuf<uint8_t> amb;
     DevBuf<uint16_t> pilots;
     DevBuf<unsigned int> slabs;             // [n_cus][n_lds_bins] workgroup histograms of the last scan launch
@@ -354,6 +355,7 @@ struct bk_engine {
     DevBuf<int32_t> seq_first, n_seqs_d;
     int max_seqs_per_file = 0;
     uint64_t max_file_cells = 0;
+    uint64_t max_file_cells_idx = 0;        // cells of the genome file with the most (pileup rows)
     DevBuf<double> call_noise;
     DevBuf<bk_call_record> call_records;
     DevBuf<bk_call_summary> call_out;
@@ -373,7 +375,7 @@ struct bk_engine {
         v.n_full = n_full; v.n_prows = n_prows; v.prow_id = prow_id.p; v.prow_t = prow_t.p; v.v_omin = v_omin; v.v_span = v_span; v.v_off = v_off;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb, half_lo.log2p};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb, half_hi.log2p};
-        v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.slot_rec = slot_rec.p; v.ent_files = ent_files.p; v.slot_files = slot_files.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
+        v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.slot_rec = slot_rec.p; v.ent_files = ent_files.p; v.slot_files = slot_files.p; v.vslot_rec = vslot_rec.p; v.vslot_files = vslot_files.p; v.id_own_files = id_own_files.p; v.estat_files = estat_files.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
         v.table = table.p; v.ent_off = ent_off.p; v.ent_len = ent_len.p;
         v.entries = entries.p; v.n_slots = n_slots; v.log2s = log2s; v.k = k; v.wstart = wstart; v.W = W; v.n_files = n_files;
         return v;
@@ -1220,6 +1222,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         // the scan's seed tables (bk_device.h seed_hash): per genome file, where each of its reference k-mers starts
         if (cells > 0 && cells < (1ull << bk::kSeedCellBits) && e->n_full > 0) {
             uint64_t max_file_cells = 1;
+            for (int f = 0; f < ix->n_files; f++) e->max_file_cells_idx = std::max<uint64_t>(e->max_file_cells_idx, (f + 1 < ix->n_files ? e->file_cell_lo[f + 1] : cells) - e->file_cell_lo[f]);
             for (int f = 0; f < ix->n_files; f++)
                 max_file_cells = std::max<uint64_t>(max_file_cells, (f + 1 < ix->n_files ? e->file_cell_lo[f + 1] : cells) - e->file_cell_lo[f]);
             uint32_t L = 6;
@@ -1364,6 +1367,61 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 });
                 BK_HIP(e->ent_files.upload(h_ef));
                 BK_HIP(e->slot_files.upload(h_sf));
+                // id_own_files (IndexView): bit f of id = in every one of the k-mer's W buckets genome f's only BucketInfo is the k-mer's
+                // own occurrence in f -- cell, idx and orientation of bucket t are those of bucket 0, t further on.  The voting pass
+                // for the selected genome then needs bucket 0 alone (one load shared by the W lanes of a counter).
+                std::vector<uint4> h_own(std::max<size_t>(e->n_full, 1), make_uint4(0u, 0u, 0u, 0u));
+                parallel_for(e->n_full, [&](size_t id0, size_t id1) {
+                    for (size_t id = id0; id < id1; id++) {
+                        const uint32_t s0 = h_slot_of[id * e->W];
+                        if (s0 == empty_slot || !bk::files_any(h_ef[s0])) continue;
+                        uint32_t w[4] = {h_ef[s0].x, h_ef[s0].y, h_ef[s0].z, h_ef[s0].w};
+                        for (uint32_t q0 = 0; q0 < h_len[s0]; q0++) {   // bucket 0's BucketInfo of f is the occurrence of this very k-mer at cell - wstart
+                            const bk::DevEntry& a0 = h_ent[h_off[s0] + q0];
+                            const bool ok = a0.idx == (uint8_t)e->wstart && a0.cell >= (uint32_t)e->wstart && a0.cell - (uint32_t)e->wstart < cells &&
+                                            h_id_at[a0.cell - (uint32_t)e->wstart] == (uint32_t)id;
+                            if (!ok) w[(a0.file >> 5) & 3u] &= ~(1u << (a0.file & 31u));
+                        }
+                        for (int t = 1; t < e->W; t++) {
+                            const uint32_t st = h_slot_of[id * e->W + t];
+                            if (st == empty_slot || !bk::files_any(h_ef[st])) { w[0] = w[1] = w[2] = w[3] = 0u; break; }
+                            w[0] &= h_ef[st].x; w[1] &= h_ef[st].y; w[2] &= h_ef[st].z; w[3] &= h_ef[st].w;
+                            // both lists hold one entry per file, sorted: walk them together
+                            uint32_t q0 = 0, qt = 0;
+                            const uint32_t n0 = h_len[s0], nt_ = h_len[st];
+                            while (q0 < n0 && qt < nt_) {
+                                const bk::DevEntry& a0 = h_ent[h_off[s0] + q0];
+                                const bk::DevEntry& at = h_ent[h_off[st] + qt];
+                                if (a0.file < at.file) { ++q0; continue; }
+                                if (at.file < a0.file) { ++qt; continue; }
+                                if (at.cell != a0.cell + (uint32_t)t || at.idx != (uint8_t)(a0.idx + t) || at.canonical != a0.canonical)
+                                    w[(a0.file >> 5) & 3u] &= ~(1u << (a0.file & 31u));
+                                ++q0; ++qt;
+                            }
+                        }
+                        h_own[id] = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
+                });
+                BK_HIP(e->id_own_files.upload(h_own));
+                // ... and the same two tables by diagonal for K2a, whose lanes hold the k-mers (id q - oo, offset oo) of one V row:
+                // entry of (id, window position j) at [(id + oo) * v_span + oo], oo = the offset j stands for in the coordinates of
+                // the k-mer's first occurrence -- a row's lanes read neighbouring entries instead of one cache line each
+                {
+                    const size_t span = (size_t)e->v_span, nq = (size_t)e->n_full + span;
+                    std::vector<bk::SlotRec> h_vrec(nq * span);
+                    std::vector<uint4> h_vf(nq * span, make_uint4(0u, 0u, 0u, 0u));
+                    parallel_for(e->n_full, [&](size_t id0, size_t id1) {
+                        for (size_t id = id0; id < id1; id++)
+                            for (int oo = 0; oo < e->v_span; oo++) {
+                                const int o = oo + e->v_omin, j = rc_of_id[id] ? k - 1 - o : o;
+                                if (j < e->wstart || j >= e->wstart + e->W) continue;
+                                h_vrec[(id + (size_t)oo) * span + (size_t)oo] = h_rec[id * e->W + (size_t)(j - e->wstart)];
+                                h_vf[(id + (size_t)oo) * span + (size_t)oo] = h_sf[id * e->W + (size_t)(j - e->wstart)];
+                            }
+                    });
+                    BK_HIP(e->vslot_rec.upload(h_vrec));
+                    BK_HIP(e->vslot_files.upload(h_vf));
+                }
             }
             // IdRec: k-mer, first cell, flags; "simple" = each of the W buckets holds the k-mer's own single occurrence and nothing else
             std::vector<bk::IdRec> h_idrec(std::max<size_t>(h_u.size(), 1), bk::IdRec{bk::kEmptyKey, 0u, 0u});
@@ -1422,6 +1480,19 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         }
         BK_HIP(e->estat_off.upload(h_estat_off));
         BK_HIP(e->estat.upload(h_estat));
+        if (e->n_files > 1 && e->n_files <= 128 && e->W > 1 && e->n_full > 0) {
+            // the same as two bitmaps per reference k-mer (IndexView::estat_files): genomes in which it is perfect, ... a variant
+            std::vector<uint4> h_esf((size_t)e->n_full * 2, make_uint4(0u, 0u, 0u, 0u));
+            parallel_for(e->n_full, [&](size_t id0, size_t id1) {
+                for (size_t id = id0; id < id1; id++)
+                    for (uint32_t q = h_estat_off[id]; q < h_estat_off[id + 1]; q++) {
+                        const uint32_t f = h_estat[q] >> 1;
+                        uint4& b = h_esf[id * 2 + ((h_estat[q] & 1u) ? 0 : 1)];
+                        (f < 32u ? b.x : f < 64u ? b.y : f < 96u ? b.z : b.w) |= 1u << (f & 31u);
+                    }
+            });
+            BK_HIP(e->estat_files.upload(h_esf));
+        }
     }
     {
         hipDeviceProp_t prop;
@@ -1474,7 +1545,7 @@ int bk_engine_fork_params(const bk_engine* parent, const bk_params* prm, bk_engi
     e->n_u = p->n_u; e->n_full = p->n_full; e->n_lds_bins = p->n_lds_bins; e->n_prows = p->n_prows;
     e->v_omin = p->v_omin; e->v_span = p->v_span; e->v_off = p->v_off; e->plane_len = p->plane_len;
     e->ref_in_lds = p->ref_in_lds; e->lo_bases = p->lo_bases; e->n_cus = p->n_cus; e->device = p->device;
-    e->file_cell_lo = p->file_cell_lo; e->ablate = p->ablate; e->max_launch_records = p->max_launch_records;
+    e->file_cell_lo = p->file_cell_lo; e->max_file_cells_idx = p->max_file_cells_idx; e->ablate = p->ablate; e->max_launch_records = p->max_launch_records;
     e->half_lo.m = p->half_lo.m; e->half_lo.log2nb = p->half_lo.log2nb; e->half_lo.log2p = p->half_lo.log2p;
     e->half_hi.m = p->half_hi.m; e->half_hi.log2nb = p->half_hi.log2nb; e->half_hi.log2p = p->half_hi.log2p;
     // the index tables are immutable after bk_engine_create: the fork reads the parent's
@@ -1484,7 +1555,7 @@ int bk_engine_fork_params(const bk_engine* parent, const bk_params* prm, bk_engi
     e->cell_fast.alias(p->cell_fast); e->cell_nat.alias(p->cell_nat); e->cell_blk.alias(p->cell_blk); e->seed_tab.alias(p->seed_tab); e->seed_log2 = p->seed_log2;
     e->half_lo.pilots.alias(p->half_lo.pilots); e->half_lo.dir.alias(p->half_lo.dir); e->half_lo.cand.alias(p->half_lo.cand);
     e->half_hi.pilots.alias(p->half_hi.pilots); e->half_hi.dir.alias(p->half_hi.dir); e->half_hi.cand.alias(p->half_hi.cand);
-    e->slot_of.alias(p->slot_of); e->estat_off.alias(p->estat_off); e->estat.alias(p->estat); e->slot_rec.alias(p->slot_rec); e->ent_files.alias(p->ent_files); e->slot_files.alias(p->slot_files); e->amb.alias(p->amb);
+    e->slot_of.alias(p->slot_of); e->estat_off.alias(p->estat_off); e->estat.alias(p->estat); e->slot_rec.alias(p->slot_rec); e->ent_files.alias(p->ent_files); e->slot_files.alias(p->slot_files); e->vslot_rec.alias(p->vslot_rec); e->vslot_files.alias(p->vslot_files); e->id_own_files.alias(p->id_own_files); e->estat_files.alias(p->estat_files); e->amb.alias(p->amb);
     e->pilots.alias(p->pilots); e->table.alias(p->table); e->ent_off.alias(p->ent_off); e->ent_len.alias(p->ent_len); e->entries.alias(p->entries);
     e->occ.alias(p->occ); e->file_cell_lo_d.alias(p->file_cell_lo_d);
     e->genome_len.alias(p->genome_len); e->seq_cell.alias(p->seq_cell); e->seq_len_d.alias(p->seq_len_d); e->seq_first.alias(p->seq_first);
@@ -1907,6 +1978,9 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
         for (int m = 0; m < n_mates; m++) {
             bk_engine::Span sp(e, 1);
             BK_HIP(hipMemsetAsync(e->n_list[m].p, 0, 8 * sizeof(unsigned int), e->stream));
+#ifdef BK_TESTING
+            if (e->ablate == 15) BK_HIP(hipMemsetAsync(e->touch_b[m].p, 0xff, e->touch_b[m].n * 4, e->stream));   // (15: every block counts as touched)
+#endif
             bk::launch_expand_touched_blocks(e->touch_b[m].p, (uint32_t)((e->total_cells + 63) / 64), e->cell_blk.p, e->touch_v[m].p, (uint32_t)e->k,
                                              (uint64_t)e->n_full + (uint64_t)e->v_span, e->stream);
             bk::launch_compact_touched(e->touch_v[m].p, bk::v_real_rows(e->n_full, e->v_span), e->touch_p[m].p, e->n_prows, e->touch_e[m].p, e->n_u,
@@ -1930,6 +2004,7 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             a.distinct_total = e->kstats.p + m * 4 + 2;
             a.partials = e->fin_partials.p;
             a.deferred = e->deferred.p + (two_pass ? (size_t)m * (e->deferred.n / 2) : 0);   // (kept from the first pass to the second)
+            a.file_cell_lo = e->file_cell_lo_d.p; a.max_file_cells = (uint32_t)e->max_file_cells_idx;
             a.n_deferred = e->n_deferred.p + m;
             a.deferred_mask = two_pass && e->deferred_mask.p ? e->deferred_mask.p + (size_t)m * (e->deferred_mask.n / 2) : nullptr;
             a.ktab_keys = e->ktab_keys.p; a.ktab_cnt = e->ktab_cnt.p; a.ktab_log2 = e->ktab_log2;

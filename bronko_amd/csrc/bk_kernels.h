@@ -85,6 +85,8 @@ struct FinalizeArgs {
     unsigned long long* distinct_total; // optional: += distinct k-mers seen at all (non-zero counters)
     unsigned int* partials;         // [finalize_partial_rows()][n_files*3 + 2] per-workgroup tallies, or null: use atomics
     int row_exact, row_general;     // first partials row of K2e / K2b (set by launch_finalize)
+    const uint32_t* file_cell_lo;   // [n_files] first cell of each genome file, and the cells of the largest one: pileup_selected_only's
+    uint32_t max_file_cells;        // voting pass walks the selected genome's cells (finalize_exact_own_kernel); null / 0 = it does not
     unsigned int* deferred;         // [v_plane_len] V counter indices K2a hands to K2b
     unsigned long long* deferred_n; // ... and their counts (clear_v: K2b cannot read them from the plane any more); may be null
     int clear_v;                    // K2a zeroes every V counter it reads (dense planes, the whole plane in this call, last pass):

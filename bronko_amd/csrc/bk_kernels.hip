@@ -1012,6 +1012,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                             if constexpr (SPARSE) {
                                 // the row is touched: noted per block of 64 cells (a bit per row in device memory, looked at and set
                                 // for every mismatch, took two thirds of this kernel on a 100-strain index), handed on in the epilogue
+                                if (BK_ABLATE(a, 13)) touch(a.touch_v, v_row_index(idS + of_first - (uint32_t)omin, alt, ofwd ? 0u : 1u));   // (13: the row's own bit as well)
                                 const uint32_t tb = (uint32_t)(ofwd ? c0 : c1) >> 6;
                                 if (!(blk_t[tb >> 5] >> (tb & 31u) & 1u)) __hip_atomic_fetch_or(&blk_t[tb >> 5], 1u << (tb & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
@@ -1829,7 +1830,7 @@ __device__ __forceinline__ uint32_t first_of_file(const DevEntry* __restrict__ e
     return lo;
 }
 
-// File bitmaps (IndexView::ent_files) of a wave's k-mers -> lstats[file * 3 + 1] += number of lanes whose bitmap holds the file:
+// File bitmaps (IndexView::ent_files) of a wave's k-mers -> lstats[file * 3 + COL] += number of lanes whose bitmap holds the file:
 // one ballot per file, the count written into the file's own lane (v_writelane), one LDS add per word of 32 files.  Every lane of
 // the wave calls it (lanes without a k-mer with an all-zero bitmap).
 template <int B>
@@ -1838,7 +1839,7 @@ template <int... B>
 __device__ __forceinline__ void tally_word(uint32_t wd, int& acc, std::integer_sequence<int, B...>) {
     (write_lane<B>(acc, __popcll(__ballot((wd & (1u << B)) != 0u))), ...);
 }
-template <bool ATOMIC>
+template <bool ATOMIC, uint32_t COL = 1u>
 __device__ __forceinline__ void tally_files(const uint4& fb, uint32_t* lstats, uint32_t lane, uint32_t n_files) {
     if (!__ballot(files_any(fb))) return;
 #pragma unroll
@@ -1849,7 +1850,7 @@ __device__ __forceinline__ void tally_files(const uint4& fb, uint32_t* lstats, u
         tally_word(wd, acc, std::make_integer_sequence<int, 32>{});
         const uint32_t f = w * 32u + lane;
         if (lane < 32u && acc && f < n_files) {
-            if (ATOMIC) atomicAdd(&lstats[f * 3u + 1u], (uint32_t)acc); else lstats[f * 3u + 1u] += (uint32_t)acc;
+            if (ATOMIC) atomicAdd(&lstats[f * 3u + COL], (uint32_t)acc); else lstats[f * 3u + COL] += (uint32_t)acc;
         }
     }
 }
@@ -2236,7 +2237,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         uint4 r = make_uint4(0u, 0u, 0u, 0u);
         if (act) {
             if (ambp & kIdSimple) r = make_uint4(0u, 1u, idr.z + (uint32_t)j, (ambp >> 16) | ((uint32_t)j << 16) | (rcid << 24));
-            else r = *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)p * ix.W + t);
+            else r = ix.vslot_rec ? *reinterpret_cast<const uint4*>(ix.vslot_rec + (size_t)q * lpr + oo)   // (by diagonal: the row's lanes read neighbours)
+                                  : *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)p * ix.W + t);
         }
         const uint32_t cnt = r.y;
         DevEntry first;
@@ -2245,7 +2247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         // genomes of all its k-mers together below, one ballot per genome, instead of every lane walking ~100 entries
         uint4 sfb = make_uint4(0u, 0u, 0u, 0u);
         if (a.mode == 1 && ix.slot_files) {
-            if (act && cnt > 1u) sfb = ix.slot_files[(size_t)p * ix.W + t];
+            if (act && cnt > 1u) sfb = ix.vslot_files[(size_t)q * lpr + oo];
             tally_files<true>(sfb, lstats, lane64, (uint32_t)ix.n_files);   // one hit in each of its genomes (W > 1: "variant"), never perfect
         }
         // single-entry bucket: the vote of call.rs:1327-1384 (see vote()), merged across the row when possible
@@ -2268,7 +2270,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
         if (act && cnt > 1u && !do_stats) {
             // second pass: the selected genome's entries of the bucket only
-            const uint4 fb = ix.slot_files ? ix.slot_files[(size_t)p * ix.W + t] : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 fb = ix.vslot_files ? ix.vslot_files[(size_t)q * lpr + oo] : make_uint4(0u, 0u, 0u, 0u);
             if (files_any(fb)) {                               // (one entry per genome: the selected genome's by its rank, if it is there)
                 if (files_has(fb, (uint32_t)a.sel_file)) vt_vote(vt, par, a, ix.entries[r.x + files_rank(fb, (uint32_t)a.sel_file)], c, isrc, k, v);
             } else
@@ -2361,41 +2363,13 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     const uint64_t n_ids_listed = a.e_list ? a.n_list[2] : 0ull, n_pseudo_listed = a.e_list ? a.n_list[3] : 0ull;
     // ... and its statistics pass casts no votes: 8 lanes per counter share the walk over the k-mer's genomes (estat)
     const bool stats_walk = a.e_list && a.mode == 1;
-    const uint32_t Wd = stats_walk ? 8u : W;                   // lanes per counter
+    const uint32_t Wd = stats_walk ? (ix.estat_files ? 1u : 8u) : W;   // lanes per counter
     const uint64_t n_work = a.e_list ? n_ids_listed * 2ull * Wd : r_hi * W;
     unsigned int kept = 0, distinct = 0;
     uint32_t par = 0;
-    // 256 consecutive (counter, bucket) pairs per workgroup and round: ~8 consecutive reference k-mers, whose votes fall on
-    // ~25 pileup cells -- gathered in the workgroup's vote table (LDS) before they go to the pileup
-    for (uint64_t g0 = (a.e_list ? 0ull : c_lo * W) + (uint64_t)blockIdx.x * 256; g0 < n_work; g0 += (uint64_t)gridDim.x * 256) {
-      const uint64_t g = g0 + threadIdx.x;
-      // the counter of this (counter, bucket) pair; a listed id may be a pseudo k-mer: those are mapped by the loop below
-      uint64_t cidx = g < n_work ? g / Wd : 0ull;
-      const bool mine = g < n_work;
-      if (a.e_list && mine) cidx = 2ull * a.e_list[cidx >> 1] + (cidx & 1ull);
-      if (stats_walk) {
-          // (the 8 lanes of a counter are neighbours in one wave and take every branch together)
-          const unsigned long long n = mine ? a.counters[cidx] : 0ull;
-          const uint32_t t = (uint32_t)(g & 7ull);
-          distinct += (n != 0 && t == 0);
-          if (n == 0 || n < a.ci || n > a.cx) continue;
-          kept += (t == 0);
-          const uint32_t id = (uint32_t)(cidx >> 1);
-          uint32_t n_perfect = 0, perfect_file = 0;
-          for (uint32_t q = ix.estat_off[id] + t, qe = ix.estat_off[id + 1]; q < qe; q += 8u) {   // (file << 1) | perfect
-              const uint32_t e = ix.estat[q];
-              tally(lstats, (e >> 1) * 3 + ((e & 1u) ? 0u : 1u));
-              if (e & 1u) { ++n_perfect; perfect_file = e >> 1; }
-          }
-          uint32_t tot = n_perfect;
-          tot += (uint32_t)__shfl_xor((int)tot, 1); tot += (uint32_t)__shfl_xor((int)tot, 2); tot += (uint32_t)__shfl_xor((int)tot, 4);
-          if (tot == 1 && n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
-          continue;
-      }
-      // a round whose counters are all zero (most of them, with a large index and one sample) votes for nothing: skip its flush
-      if (ix.n_files > 1 && !a.e_list && !__syncthreads_or(mine && a.counters[cidx] != 0ull)) continue;
-      if (mine) do {
-        const uint32_t t = (uint32_t)(g % W);
+    // one (counter, window bucket) pair
+    auto pair_body = [&](uint64_t cidx, uint32_t t) {
+      do {
         const unsigned long long n = a.counters[cidx];
         distinct += (n != 0 && t == 0 && do_stats);
         if (n == 0 || n < a.ci || n > a.cx) break;              // kmc -ci / -cx act on the true count
@@ -2403,7 +2377,11 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
         const uint32_t id = (uint32_t)(cidx >> 1), isrc = (uint32_t)cidx & 1u;
         const uint4 idr = *reinterpret_cast<const uint4*>(ix.id_rec + id);
         const uint64_t c = (uint64_t)idr.x | ((uint64_t)idr.y << 32);
-        if (a.mode != 1) {   // (the statistics pass casts no votes: a reference k-mer's statistics come from estat below)
+        // second pass, many genomes: a k-mer whose BucketInfos for the selected genome are its own occurrence there, bucket after
+        // bucket (IndexView::id_own_files), has been voted for by finalize_exact_own_kernel
+        const bool by0 = a.mode == 2 && a.file_cell_lo && ix.id_own_files && files_has(ix.id_own_files[id], (uint32_t)a.sel_file);
+        if (by0) {
+        } else if (a.mode != 1) {   // (the statistics pass casts no votes: a reference k-mer's statistics come from estat below)
             const uint32_t j = (uint32_t)ix.wstart + t;
             const uint4 r = (idr.w & kIdSimple) ? make_uint4(0u, 1u, idr.z + j, (idr.w >> 16) | (j << 16) | (((idr.w >> 1) & 1u) << 24))
                                                 : *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)id * W + t);
@@ -2438,6 +2416,81 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
             if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
         }
       } while (false);
+    };
+    // Voting pass of pileup_selected_only over a list of touched k-mers: nearly all of them were voted for by
+    // finalize_exact_own_kernel (IndexView::id_own_files) or fail the thresholds -- one lane per counter finds the few that are
+    // left (k-mers the selected genome does not hold as they are), and only those are spread over W lanes each
+    const bool own_done = a.mode == 2 && a.e_list && a.file_cell_lo && ix.id_own_files;
+    if (own_done) {
+        __shared__ unsigned long long ownq[256];
+        __shared__ unsigned int ownq_n;
+        for (uint64_t g0 = (uint64_t)blockIdx.x * 256; g0 < n_ids_listed * 2ull; g0 += (uint64_t)gridDim.x * 256) {
+            if (threadIdx.x == 0) ownq_n = 0u;
+            __syncthreads();
+            const uint64_t g = g0 + threadIdx.x;
+            if (g < n_ids_listed * 2ull) {
+                const uint64_t cidx = 2ull * a.e_list[g >> 1] + (g & 1ull);
+                const unsigned long long n = a.counters[cidx];
+                if (n != 0 && n >= a.ci && n <= a.cx && !files_has(ix.id_own_files[cidx >> 1], (uint32_t)a.sel_file)) ownq[atomicAdd(&ownq_n, 1u)] = cidx;
+            }
+            __syncthreads();
+            const uint32_t nq = ownq_n * W;
+            for (uint32_t w0 = 0; w0 < nq; w0 += 256u) {
+                const uint32_t w = w0 + threadIdx.x;
+                if (w < nq) pair_body(ownq[w / W], w % W);
+                vt_flush(vt, par, a);
+                par ^= 1u;
+            }
+            __syncthreads();
+        }
+    }
+    // 256 consecutive (counter, bucket) pairs per workgroup and round: ~8 consecutive reference k-mers, whose votes fall on
+    // ~25 pileup cells -- gathered in the workgroup's vote table (LDS) before they go to the pileup
+    for (uint64_t g0 = (a.e_list ? 0ull : c_lo * W) + (uint64_t)blockIdx.x * 256; g0 < n_work && !own_done; g0 += (uint64_t)gridDim.x * 256) {
+      const uint64_t g = g0 + threadIdx.x;
+      // the counter of this (counter, bucket) pair; a listed id may be a pseudo k-mer: those are mapped by the loop below
+      uint64_t cidx = g < n_work ? g / Wd : 0ull;
+      const bool mine = g < n_work;
+      if (a.e_list && mine) cidx = 2ull * a.e_list[cidx >> 1] + (cidx & 1ull);
+      if (stats_walk && ix.estat_files) {
+          // one lane per counter: the genomes in which the k-mer is perfect / a variant as two bitmaps, tallied for the whole wave
+          const unsigned long long n = mine ? a.counters[cidx] : 0ull;
+          distinct += (n != 0);
+          const bool keep = n != 0 && n >= a.ci && n <= a.cx;
+          kept += keep;
+          const uint32_t id = (uint32_t)(cidx >> 1);
+          const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+          const uint4 pf = keep ? ix.estat_files[(size_t)id * 2] : z, vf = keep ? ix.estat_files[(size_t)id * 2 + 1] : z;
+          tally_files<true, 0u>(pf, lstats, threadIdx.x & 63u, (uint32_t)ix.n_files);
+          tally_files<true, 1u>(vf, lstats, threadIdx.x & 63u, (uint32_t)ix.n_files);
+          if (__popc(pf.x) + __popc(pf.y) + __popc(pf.z) + __popc(pf.w) == 1) {   // perfect in exactly one genome: unique to it
+              const uint32_t f = pf.x ? (uint32_t)__builtin_ctz(pf.x) : pf.y ? 32u + (uint32_t)__builtin_ctz(pf.y) : pf.z ? 64u + (uint32_t)__builtin_ctz(pf.z) : 96u + (uint32_t)__builtin_ctz(pf.w);
+              atomicAdd(&lstats[f * 3u + 2u], 1u);
+          }
+          continue;
+      }
+      if (stats_walk) {
+          // (the 8 lanes of a counter are neighbours in one wave and take every branch together)
+          const unsigned long long n = mine ? a.counters[cidx] : 0ull;
+          const uint32_t t = (uint32_t)(g & 7ull);
+          distinct += (n != 0 && t == 0);
+          if (n == 0 || n < a.ci || n > a.cx) continue;
+          kept += (t == 0);
+          const uint32_t id = (uint32_t)(cidx >> 1);
+          uint32_t n_perfect = 0, perfect_file = 0;
+          for (uint32_t q = ix.estat_off[id] + t, qe = ix.estat_off[id + 1]; q < qe; q += 8u) {   // (file << 1) | perfect
+              const uint32_t e = ix.estat[q];
+              tally(lstats, (e >> 1) * 3 + ((e & 1u) ? 0u : 1u));
+              if (e & 1u) { ++n_perfect; perfect_file = e >> 1; }
+          }
+          uint32_t tot = n_perfect;
+          tot += (uint32_t)__shfl_xor((int)tot, 1); tot += (uint32_t)__shfl_xor((int)tot, 2); tot += (uint32_t)__shfl_xor((int)tot, 4);
+          if (tot == 1 && n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
+          continue;
+      }
+      // a round whose counters are all zero (most of them, with a large index and one sample) votes for nothing: skip its flush
+      if (ix.n_files > 1 && !a.e_list && !__syncthreads_or(mine && a.counters[cidx] != 0ull)) continue;
+      if (mine) pair_body(cidx, (uint32_t)(g % W));
       vt_flush(vt, par, a);
       par ^= 1u;
     }
@@ -2456,6 +2509,13 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
         if (a.mode != 1) for (uint32_t t = 0; t < W; ++t) {
             const uint32_t s = ix.slot_of[(size_t)id * W + t];
             const uint32_t off = ix.ent_off[s], cnt = ix.ent_len[s];
+            if (a.mode == 2 && ix.ent_files) {   // (one entry per genome: the selected genome's by its rank -- no bisection in this serial loop)
+                const uint4 fb = ix.ent_files[s];
+                if (files_any(fb)) {
+                    if (files_has(fb, (uint32_t)a.sel_file)) vote(a, ix.entries[off + files_rank(fb, (uint32_t)a.sel_file)], c, isrc, k, v);
+                    continue;
+                }
+            }
             for (uint32_t q = a.mode == 2 ? first_of_file(ix.entries + off, cnt, a.sel_file) : 0u; q < cnt; ++q) {
                 const DevEntry en = ix.entries[off + q];
                 if (a.mode == 2 && (int)en.file != a.sel_file) break;
@@ -2473,6 +2533,60 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     }
     __syncthreads();
     if (do_stats) finalize_epilogue(a, lstats, kept, distinct, lstats + ix.n_files * 3, a.row_exact + (int)blockIdx.x);
+}
+
+// K2e, voting pass of pileup_selected_only with many genomes: the reference k-mers whose BucketInfos for the selected genome are
+// their own occurrence there, bucket after bucket (IndexView::id_own_files) -- nearly every k-mer the sample's reads hold.  One
+// thread per CELL of the selected genome instead of one per (counter, bucket) of every touched k-mer: the k-mer that starts at the
+// cell, its two counters, one BucketInfo (bucket 0's; bucket t's is that one t further on), and its 2 W votes (vote()) into a
+// table in LDS over the positions the workgroup's 256 cells reach, which is then added to the pileup.  finalize_exact_kernel
+// skips these k-mers in that pass.
+constexpr uint32_t kOwnCells = 256, kOwnSpan = kOwnCells + 32;
+__global__ __launch_bounds__(256) void finalize_exact_own_kernel(FinalizeArgs a) {
+    __shared__ unsigned long long mx[8][kOwnSpan];
+    __shared__ unsigned int cnt[8][kOwnSpan];
+    const int sel = *a.sel;
+    if (sel < 0) return;
+    const IndexView& ix = a.ix;
+    const uint32_t c_lo = a.file_cell_lo[sel], c_hi = sel + 1 < ix.n_files ? a.file_cell_lo[sel + 1] : ix.total_cells;
+    const uint32_t c0 = c_lo + blockIdx.x * kOwnCells;
+    if (c0 >= c_hi) return;
+    for (uint32_t i = threadIdx.x; i < 8u * kOwnSpan; i += 256u) { (&mx[0][0])[i] = 0ull; (&cnt[0][0])[i] = 0u; }
+    __syncthreads();
+    const int k = ix.k;
+    const uint32_t W = (uint32_t)ix.W;
+    const uint32_t c = c0 + threadIdx.x;
+    const uint32_t id = c < c_hi ? ix.id_at[c] : 0xffffffffu;
+    if (id < ix.n_full && files_has(ix.id_own_files[id], (uint32_t)sel)) {
+        const uint4 fb = ix.slot_files[(size_t)id * W];
+        const DevEntry e0 = ix.entries[ix.slot_rec[(size_t)id * W].off + files_rank(fb, (uint32_t)sel)];   // cell = c + wstart (checked at create)
+        const uint64_t km = ix.id_rec[id].kmer;
+        const uint32_t q0 = threadIdx.x;                                        // position of its first vote within the table
+        for (uint32_t isrc = 0; isrc < 2u && e0.cell == c + (uint32_t)ix.wstart; ++isrc) {   // (its one occurrence in the genome is at this very cell)
+            const unsigned long long n = a.counters[2 * (size_t)id + isrc];
+            if (n == 0 || n < a.ci || n > a.cx) continue;                        // kmc -ci / -cx act on the true count
+            const unsigned long long v = n > a.cs ? a.cs : n;                   // kmc -cs: reported count saturates
+            for (uint32_t t = 0; t < W; ++t) {
+                const uint32_t idx = (uint32_t)e0.idx + t;                       // (vote(): call.rs:1327-1384)
+                uint32_t bit_idx;
+                bool forward;
+                if (e0.canonical) { bit_idx = ((uint32_t)(km >> (2 * idx)) & 3u) ^ 3u; forward = isrc != 0; }
+                else { bit_idx = (uint32_t)(km >> (2 * (k - 1 - (int)idx))) & 3u; forward = isrc == 0; }
+                const uint32_t row = (forward ? 0u : 4u) + bit_idx;
+                atomicAdd(&cnt[row][q0 + t], 1u);
+                atomicMax(&mx[row][q0 + t], v);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 8u * kOwnSpan; i += 256u) {
+        const uint32_t row = i / kOwnSpan, q = i - row * kOwnSpan;
+        const unsigned int nv = cnt[row][q];
+        if (!nv) continue;
+        const size_t cell = ((size_t)c0 + (uint32_t)ix.wstart + q) * 4 + (row & 3u);
+        atomicAdd(a.pileup + (row < 4u ? 2 : 3) * a.plane + cell, (unsigned long long)nv);   // #kmers
+        atomicMax(a.pileup + (row < 4u ? 0 : 1) * a.plane + cell, mx[row][q]);               // depth
+    }
 }
 
 // K2b: one wave per workgroup and per k-mer, for the V counters K2a deferred (k-mers that touch several window
@@ -2667,11 +2781,13 @@ __global__ __launch_bounds__(256) void expand_touched_blocks_kernel(unsigned int
     const uint32_t gb = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;   // one wave per block of 64 cells
     if (gb >= n_blocks || !((touch_b[gb >> 5] >> (gb & 31u)) & 1u)) return;
     if (lane == 0) atomicAnd(touch_b + (gb >> 5), ~(1u << (gb & 31u)));
-    const uint32_t q_0 = gb * 64u + cell_blk[gb].x;                    // id of the block's first cell (were it one of the majority)
-    const uint32_t q_lo = q_0 >= span ? q_0 - span : 0u;               // (a run's row is its first k-mer's id + an offset in (-span, span))
-    if ((uint64_t)q_lo >= n_q) return;
-    const uint64_t q_hi = min((uint64_t)q_0 + 64u + span, n_q);        // (exclusive)
-    const uint64_t r0 = (uint64_t)q_lo * kVRowsPerPos, r1 = q_hi * kVRowsPerPos;   // the bits [r0, r1), a word per lane
+    // id of the block's first cell, were it one of the majority: negative where the ids restart inside the block (the head of a
+    // genome whose k-mers an earlier genome holds).  (|id - cell| < 2^31: a plane of 2^32 counters is refused at create.)
+    const long long q_0 = (long long)gb * 64 + (long long)(int32_t)cell_blk[gb].x;
+    const long long q_lo = max(q_0 - (long long)span, 0ll);            // (a run's row is its first k-mer's id + an offset in (-span, span))
+    const long long q_hi = min(q_0 + 64 + (long long)span, (long long)n_q);   // (exclusive)
+    if (q_lo >= q_hi) return;
+    const uint64_t r0 = (uint64_t)q_lo * kVRowsPerPos, r1 = (uint64_t)q_hi * kVRowsPerPos;   // the bits [r0, r1), a word per lane
     for (uint64_t w = (r0 >> 5) + lane; w * 32u < r1; w += 64u) {
         const uint64_t lo = max(w * 32u, r0), hi = min(w * 32u + 32u, r1);
         const uint32_t take = (uint32_t)(hi - lo);
@@ -2734,6 +2850,8 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     const uint64_t n_work = e_plane_len(a.ix.n_u) * (uint64_t)a.ix.W;
     const unsigned b_ex = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_work + 255) / 256, kFinExactBlocks));
     a.row_exact = (int)b_var;
+    if (a.mode == 2 && a.file_cell_lo && a.ix.id_own_files && a.max_file_cells)
+        hipLaunchKernelGGL(finalize_exact_own_kernel, dim3((a.max_file_cells + kOwnCells - 1) / kOwnCells), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(finalize_exact_kernel, dim3(b_ex), dim3(256), lds_votes, stream, a);
     // K2b (deferred k-mers only; the kernel reads their number on the device)
     // (few genomes: multi-bucket k-mers are rare, a small grid starts and ends quickly; many: one k-mer in eight takes this path)

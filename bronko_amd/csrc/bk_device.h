@@ -45,7 +45,7 @@ struct alignas(16) IdRec {
     uint32_t cell;     // cell at which its first occurrence starts
     uint32_t flags;    // bit 0 dirty, bit 1 first occurrence reverse-complemented (= amb[id]); bit 2 simple; bits 16..31 file (simple only)
 };
-constexpr uint32_t kIdDirty = 1u, kIdRc = 2u, kIdSimple = 4u;
+constexpr uint32_t kIdDirty = 1u, kIdRc = 2u, kIdSimple = 4u, kIdAllOwn = 8u, kIdOwnMirror = 16u;   // kIdAllOwn: every BucketInfo of its W buckets is one of id_own_files' (IndexView); kIdOwnMirror: those run against the reference
 
 // Precomputed outcome of "reference k-mer `id` with base bb at position j (both in the orientation of the canonical k-mer)"
 // for reference k-mers that are not clean (another reference k-mer form within Hamming distance 2, or occurrences in both
@@ -201,10 +201,9 @@ struct IndexView {
     const uint4*     ent_files;  // [n_slots] / slot_files [n_full][W]: bit f = the bucket holds a BucketInfo of genome file f -- exactly one, the
     const uint4*     slot_files; //   entries sorted by file, so file f's is entry number popcount(bits below f); all zero = not such a bucket
                                  //   (or more than 128 files, or W == 1: both null): look at the entries.  bk_params.pileup_selected_only.
-    const SlotRec*   vslot_rec;    // [n_full + v_span][v_span] slot_rec / slot_files by diagonal, for K2a: the bucket of (id, window position j) at
-    const uint4*     vslot_files;  //   [(id + oo) * v_span + oo], oo = the V-row offset j stands for (first-occurrence coordinates); null with slot_files
     const uint4*     id_own_files; // [n_full] bit f = in each of the k-mer's W buckets genome f's one BucketInfo is the k-mer's own occurrence in f:
-                                   //   that of bucket t = that of bucket 0 with cell + t, idx + t; null with slot_files
+                                   //   that of bucket t = that of bucket 0 with cell + t, idx + t (kIdOwnMirror: - t); null with slot_files
+    const uint16_t*  cell_file;    // [total_cells] genome file of each cell; null with slot_files
     const uint4*     estat_files;  // [n_full][2] estat as bitmaps: genomes in which the k-mer is perfect / a variant; null with slot_files
     const uint8_t*   amb;      // [n_u] bit 1 = the k-mer's first occurrence was reverse-complemented to become canonical; bit 0 = "dirty": another reference k-mer (either strand) lies within Hamming
                                //       distance 2 of it, or it is within distance 2 of its own reverse complement

@@ -289,8 +289,8 @@ struct bk_engine {
     bool ktab_exchanged = false;            // bk_kmer_table_replace was called in this sample
     DevBuf<uint32_t> slot_of, estat_off, estat;
     DevBuf<bk::SlotRec> slot_rec;
-    DevBuf<uint4> ent_files, slot_files, vslot_files, id_own_files, estat_files;
-    DevBuf<bk::SlotRec> vslot_rec;
+    DevBuf<uint4> ent_files, slot_files, id_own_files, estat_files;
+    DevBuf<uint16_t> cell_file;
     DevBuf<uint8_t> amb;
     DevBuf<uint16_t> pilots;
     DevBuf<unsigned int> slabs;             // [n_cus][n_lds_bins] workgroup histograms of the last scan launch
@@ -375,7 +375,7 @@ struct bk_engine {
         v.n_full = n_full; v.n_prows = n_prows; v.prow_id = prow_id.p; v.prow_t = prow_t.p; v.v_omin = v_omin; v.v_span = v_span; v.v_off = v_off;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb, half_lo.log2p};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb, half_hi.log2p};
-        v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.slot_rec = slot_rec.p; v.ent_files = ent_files.p; v.slot_files = slot_files.p; v.vslot_rec = vslot_rec.p; v.vslot_files = vslot_files.p; v.id_own_files = id_own_files.p; v.estat_files = estat_files.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
+        v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.slot_rec = slot_rec.p; v.ent_files = ent_files.p; v.slot_files = slot_files.p; v.id_own_files = id_own_files.p; v.cell_file = cell_file.p; v.estat_files = estat_files.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
         v.table = table.p; v.ent_off = ent_off.p; v.ent_len = ent_len.p;
         v.entries = entries.p; v.n_slots = n_slots; v.log2s = log2s; v.k = k; v.wstart = wstart; v.W = W; v.n_files = n_files;
         return v;
@@ -1327,6 +1327,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         std::vector<uint32_t>().swap(slot_by_index);
         BK_HIP(e->slot_of.upload(h_slot_of));
         {
+            std::vector<uint8_t> h_all_own, h_own_mirror;   // by id (file bitmaps only)
             std::vector<bk::SlotRec> h_rec((size_t)std::max<size_t>(e->n_full, 1) * std::max(e->W, 1));
             parallel_for(e->n_full, [&](size_t id0, size_t id1) {
                 for (size_t id = id0; id < id1; id++)
@@ -1371,15 +1372,21 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 // own occurrence in f -- cell, idx and orientation of bucket t are those of bucket 0, t further on.  The voting pass
                 // for the selected genome then needs bucket 0 alone (one load shared by the W lanes of a counter).
                 std::vector<uint4> h_own(std::max<size_t>(e->n_full, 1), make_uint4(0u, 0u, 0u, 0u));
+                h_own_mirror.assign(e->n_full, 0);
                 parallel_for(e->n_full, [&](size_t id0, size_t id1) {
                     for (size_t id = id0; id < id1; id++) {
                         const uint32_t s0 = h_slot_of[id * e->W];
                         if (s0 == empty_slot || !bk::files_any(h_ef[s0])) continue;
+                        // along the reference or against it (an occurrence that was reverse-complemented to become canonical): bucket
+                        // t's BucketInfo is bucket 0's with cell and idx t further on, or t further back -- one direction per k-mer,
+                        // that of its first genome's entries
+                        const int dir = h_ent[h_off[s0]].idx == (uint8_t)e->wstart ? 1 : -1;
+                        const int idx0 = dir > 0 ? e->wstart : k - 1 - e->wstart;
                         uint32_t w[4] = {h_ef[s0].x, h_ef[s0].y, h_ef[s0].z, h_ef[s0].w};
-                        for (uint32_t q0 = 0; q0 < h_len[s0]; q0++) {   // bucket 0's BucketInfo of f is the occurrence of this very k-mer at cell - wstart
+                        for (uint32_t q0 = 0; q0 < h_len[s0]; q0++) {   // bucket 0's BucketInfo of f is the occurrence of this very k-mer at cell - idx
                             const bk::DevEntry& a0 = h_ent[h_off[s0] + q0];
-                            const bool ok = a0.idx == (uint8_t)e->wstart && a0.cell >= (uint32_t)e->wstart && a0.cell - (uint32_t)e->wstart < cells &&
-                                            h_id_at[a0.cell - (uint32_t)e->wstart] == (uint32_t)id;
+                            const bool ok = a0.idx == (uint8_t)idx0 && a0.cell >= (uint32_t)idx0 && a0.cell - (uint32_t)idx0 < cells &&
+                                            h_id_at[a0.cell - (uint32_t)idx0] == (uint32_t)id;
                             if (!ok) w[(a0.file >> 5) & 3u] &= ~(1u << (a0.file & 31u));
                         }
                         for (int t = 1; t < e->W; t++) {
@@ -1394,33 +1401,48 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                                 const bk::DevEntry& at = h_ent[h_off[st] + qt];
                                 if (a0.file < at.file) { ++q0; continue; }
                                 if (at.file < a0.file) { ++qt; continue; }
-                                if (at.cell != a0.cell + (uint32_t)t || at.idx != (uint8_t)(a0.idx + t) || at.canonical != a0.canonical)
+                                if (at.cell != a0.cell + (uint32_t)(dir * t) || at.idx != (uint8_t)(a0.idx + dir * t) || at.canonical != a0.canonical)
                                     w[(a0.file >> 5) & 3u] &= ~(1u << (a0.file & 31u));
                                 ++q0; ++qt;
                             }
                         }
                         h_own[id] = make_uint4(w[0], w[1], w[2], w[3]);
+                        h_own_mirror[id] = dir < 0 ? 1 : 0;
                     }
                 });
                 BK_HIP(e->id_own_files.upload(h_own));
-                // ... and the same two tables by diagonal for K2a, whose lanes hold the k-mers (id q - oo, offset oo) of one V row:
-                // entry of (id, window position j) at [(id + oo) * v_span + oo], oo = the offset j stands for in the coordinates of
-                // the k-mer's first occurrence -- a row's lanes read neighbouring entries instead of one cache line each
+                if (test_env("BK_L2_STATS")) {
+                    uint64_t n_own = 0, n_b0 = 0, n_mir = 0, n_any = 0;
+                    auto pc4 = [](const uint4& b) { return (uint64_t)(__builtin_popcount(b.x) + __builtin_popcount(b.y) + __builtin_popcount(b.z) + __builtin_popcount(b.w)); };
+                    for (size_t id = 0; id < e->n_full; id++) {
+                        n_own += pc4(h_own[id]); n_any += bk::files_any(h_own[id]); n_mir += h_own_mirror[id];
+                        const uint32_t s0 = h_slot_of[id * e->W];
+                        if (s0 != empty_slot) n_b0 += h_len[s0];
+                    }
+                    fprintf(stderr, "[bk] own files: %llu (k-mer, genome) pairs of %llu in bucket 0; %llu of %llu k-mers with any, %llu against the reference\n",
+                            (unsigned long long)n_own, (unsigned long long)n_b0, (unsigned long long)n_any, (unsigned long long)e->n_full, (unsigned long long)n_mir);
+                }
+                // kIdAllOwn: nothing else in any of the k-mer's buckets
+                h_all_own.assign(e->n_full, 0);
+                parallel_for(e->n_full, [&](size_t id0, size_t id1) {
+                    for (size_t id = id0; id < id1; id++) {
+                        bool all = bk::files_any(h_own[id]);
+                        for (int t = 0; t < e->W && all; t++) {
+                            const uint4& f = h_sf[id * e->W + t];
+                            all = f.x == h_own[id].x && f.y == h_own[id].y && f.z == h_own[id].z && f.w == h_own[id].w;
+                        }
+                        h_all_own[id] = all ? 1 : 0;
+                    }
+                });
                 {
-                    const size_t span = (size_t)e->v_span, nq = (size_t)e->n_full + span;
-                    std::vector<bk::SlotRec> h_vrec(nq * span);
-                    std::vector<uint4> h_vf(nq * span, make_uint4(0u, 0u, 0u, 0u));
-                    parallel_for(e->n_full, [&](size_t id0, size_t id1) {
-                        for (size_t id = id0; id < id1; id++)
-                            for (int oo = 0; oo < e->v_span; oo++) {
-                                const int o = oo + e->v_omin, j = rc_of_id[id] ? k - 1 - o : o;
-                                if (j < e->wstart || j >= e->wstart + e->W) continue;
-                                h_vrec[(id + (size_t)oo) * span + (size_t)oo] = h_rec[id * e->W + (size_t)(j - e->wstart)];
-                                h_vf[(id + (size_t)oo) * span + (size_t)oo] = h_sf[id * e->W + (size_t)(j - e->wstart)];
-                            }
-                    });
-                    BK_HIP(e->vslot_rec.upload(h_vrec));
-                    BK_HIP(e->vslot_files.upload(h_vf));
+                    std::vector<uint16_t> h_cf(std::max<uint64_t>(cells, 1), 0);
+                    size_t sq2 = 0;
+                    for (int f = 0; f < ix->n_files; f++)
+                        for (int s2 = 0; s2 < ix->n_seqs[f]; s2++, sq2++) {
+                            const uint64_t lo = cell_off[f][s2], hi = lo + ix->seq_lens[sq2];
+                            for (uint64_t c = lo; c < hi && c < cells; c++) h_cf[c] = (uint16_t)f;
+                        }
+                    BK_HIP(e->cell_file.upload(h_cf));
                 }
             }
             // IdRec: k-mer, first cell, flags; "simple" = each of the W buckets holds the k-mer's own single occurrence and nothing else
@@ -1437,6 +1459,8 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     }
                     if (simple) r.flags |= bk::kIdSimple | ((uint32_t)h_rec[(size_t)id * e->W].first.file << 16);
                 }
+                if (id < h_all_own.size() && h_all_own[id]) r.flags |= bk::kIdAllOwn;
+                if (id < h_own_mirror.size() && h_own_mirror[id]) r.flags |= bk::kIdOwnMirror;
                 h_idrec[id] = r;
             }
             BK_HIP(e->id_rec.upload(h_idrec));
@@ -1555,7 +1579,7 @@ int bk_engine_fork_params(const bk_engine* parent, const bk_params* prm, bk_engi
     e->cell_fast.alias(p->cell_fast); e->cell_nat.alias(p->cell_nat); e->cell_blk.alias(p->cell_blk); e->seed_tab.alias(p->seed_tab); e->seed_log2 = p->seed_log2;
     e->half_lo.pilots.alias(p->half_lo.pilots); e->half_lo.dir.alias(p->half_lo.dir); e->half_lo.cand.alias(p->half_lo.cand);
     e->half_hi.pilots.alias(p->half_hi.pilots); e->half_hi.dir.alias(p->half_hi.dir); e->half_hi.cand.alias(p->half_hi.cand);
-    e->slot_of.alias(p->slot_of); e->estat_off.alias(p->estat_off); e->estat.alias(p->estat); e->slot_rec.alias(p->slot_rec); e->ent_files.alias(p->ent_files); e->slot_files.alias(p->slot_files); e->vslot_rec.alias(p->vslot_rec); e->vslot_files.alias(p->vslot_files); e->id_own_files.alias(p->id_own_files); e->estat_files.alias(p->estat_files); e->amb.alias(p->amb);
+    e->slot_of.alias(p->slot_of); e->estat_off.alias(p->estat_off); e->estat.alias(p->estat); e->slot_rec.alias(p->slot_rec); e->ent_files.alias(p->ent_files); e->slot_files.alias(p->slot_files); e->id_own_files.alias(p->id_own_files); e->cell_file.alias(p->cell_file); e->estat_files.alias(p->estat_files); e->amb.alias(p->amb);
     e->pilots.alias(p->pilots); e->table.alias(p->table); e->ent_off.alias(p->ent_off); e->ent_len.alias(p->ent_len); e->entries.alias(p->entries);
     e->occ.alias(p->occ); e->file_cell_lo_d.alias(p->file_cell_lo_d);
     e->genome_len.alias(p->genome_len); e->seq_cell.alias(p->seq_cell); e->seq_len_d.alias(p->seq_len_d); e->seq_first.alias(p->seq_first);

@@ -2030,6 +2030,9 @@ __device__ __forceinline__ void v_kmer_of_counter(const IndexView& ix, const uns
 // A row also holds k-mers that cannot touch the index: the difference outside the window, or a k-mer whose canonical form
 // lies on the other strand than its neighbour's (scan_count records what the reads contain, not what it means).  They are
 // skipped -- with full_kmer_stats they join the k-mer statistics table, like every other k-mer that touches nothing.
+// MANY: an index with file bitmaps (IndexView::slot_files: several genome files) -- the code for them is compiled into that
+// instantiation only (the kernel sits at its register limit; the single-genome form is the benchmark's).
+template <bool MANY>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void finalize_variant_kernel(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (a.mode == 2) { a.sel_file = *a.sel; if (a.sel_file < 0 && !a.clear_v) return; }   // (no genome selected: no votes, but the plane is still to be cleared)   // second pass: votes for the selected genome only
@@ -2237,8 +2240,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         uint4 r = make_uint4(0u, 0u, 0u, 0u);
         if (act) {
             if (ambp & kIdSimple) r = make_uint4(0u, 1u, idr.z + (uint32_t)j, (ambp >> 16) | ((uint32_t)j << 16) | (rcid << 24));
-            else r = ix.vslot_rec ? *reinterpret_cast<const uint4*>(ix.vslot_rec + (size_t)q * lpr + oo)   // (by diagonal: the row's lanes read neighbours)
-                                  : *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)p * ix.W + t);
+            else r = *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)p * ix.W + t);
         }
         const uint32_t cnt = r.y;
         DevEntry first;
@@ -2246,9 +2248,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         // statistics pass, many genomes: which of them the bucket holds, as a bitmap (IndexView::slot_files) -- the wave tallies the
         // genomes of all its k-mers together below, one ballot per genome, instead of every lane walking ~100 entries
         uint4 sfb = make_uint4(0u, 0u, 0u, 0u);
-        if (a.mode == 1 && ix.slot_files) {
-            if (act && cnt > 1u) sfb = ix.vslot_files[(size_t)q * lpr + oo];
-            tally_files<true>(sfb, lstats, lane64, (uint32_t)ix.n_files);   // one hit in each of its genomes (W > 1: "variant"), never perfect
+        bool big = false;   // a bucket with a file bitmap whose votes go through the table chunk by chunk (below)
+        if constexpr (MANY) {
+            if (a.mode == 1) {
+                if (act && cnt > 1u) sfb = ix.slot_files[(size_t)p * ix.W + t];
+                tally_files<true>(sfb, lstats, lane64, (uint32_t)ix.n_files);   // one hit in each of its genomes (W > 1: "variant"), never perfect
+            } else if (a.mode == 0) {
+                // Every genome's rows: the k-mers of a V row vote for the same cell in each genome that holds their bucket (the
+                // position of the differing base), ~27 votes on one counter pair, and with 100 strains a sample casts 300 M of them
+                // -- the whole of its finalize.  So the workgroup's lanes walk their buckets' genomes in step, 16 genome files at a
+                // time, through the vote table (which merges them) and flush it after every chunk.
+                if (act && cnt > kVoteMaxEntries) { sfb = ix.slot_files[(size_t)p * ix.W + t]; big = files_any(sfb); }
+                if (__syncthreads_or(big)) {
+                    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+                    tally_files<true>(big ? sfb : z, lstats, lane64, (uint32_t)ix.n_files);   // (W > 1, one BucketInfo per genome: "variant")
+                    uint32_t ri = 0;   // entries of the lane's bucket taken so far (they are sorted by genome file)
+                    for (uint32_t f0 = 0; f0 < (uint32_t)ix.n_files; f0 += 16u) {
+                        const uint32_t wd = f0 < 32u ? sfb.x : f0 < 64u ? sfb.y : f0 < 96u ? sfb.z : sfb.w;
+                        for (uint32_t bits = big ? (wd >> (f0 & 31u)) & 0xffffu : 0u; bits; bits &= bits - 1u) vt_vote(vt, par, a, ix.entries[r.x + ri++], c, isrc, k, v);
+                        vt_flush(vt, par, a);
+                        par ^= 1u;
+                    }
+                }
+            }
         }
         // single-entry bucket: the vote of call.rs:1327-1384 (see vote()), merged across the row when possible
         const bool single = act && cnt == 1u;
@@ -2270,7 +2292,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
         if (act && cnt > 1u && !do_stats) {
             // second pass: the selected genome's entries of the bucket only
-            const uint4 fb = ix.vslot_files ? ix.vslot_files[(size_t)q * lpr + oo] : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 fb = ix.slot_files ? ix.slot_files[(size_t)p * ix.W + t] : make_uint4(0u, 0u, 0u, 0u);
             if (files_any(fb)) {                               // (one entry per genome: the selected genome's by its rank, if it is there)
                 if (files_has(fb, (uint32_t)a.sel_file)) vt_vote(vt, par, a, ix.entries[r.x + files_rank(fb, (uint32_t)a.sel_file)], c, isrc, k, v);
             } else
@@ -2301,7 +2323,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             }
             close();
             if (n_perfect == 1) atomicAdd(&lstats[perfect_file * 3 + 2], 1u);
-        } else if (act && cnt > 1u && a.mode != 1) {
+        } else if (act && cnt > 1u && a.mode != 1 && !big) {
             // entries of one bucket are grouped by file (index build appends file by file): run lengths = hits per file
             uint32_t n_perfect = 0, perfect_file = 0;
             for (uint32_t x = 0; x < cnt;) {
@@ -2367,11 +2389,14 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     const uint64_t n_work = a.e_list ? n_ids_listed * 2ull * Wd : r_hi * W;
     unsigned int kept = 0, distinct = 0;
     uint32_t par = 0;
+    // every genome's rows (mode 0) over a list of touched k-mers of a many-genome index: the votes of the genomes that hold a k-mer
+    // as it is were cast by finalize_exact_own_kernel, cell by cell
+    const bool own_all = a.mode == 0 && a.e_list && a.file_cell_lo && ix.id_own_files && ix.cell_file && ix.estat_files;
     // one (counter, window bucket) pair
     auto pair_body = [&](uint64_t cidx, uint32_t t) {
       do {
         const unsigned long long n = a.counters[cidx];
-        distinct += (n != 0 && t == 0 && do_stats);
+        distinct += (n != 0 && t == 0 && do_stats && !own_all);
         if (n == 0 || n < a.ci || n > a.cx) break;              // kmc -ci / -cx act on the true count
         const unsigned long long v = n > a.cs ? a.cs : n;       // kmc -cs: reported count saturates
         const uint32_t id = (uint32_t)(cidx >> 1), isrc = (uint32_t)cidx & 1u;
@@ -2381,6 +2406,20 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
         // bucket (IndexView::id_own_files), has been voted for by finalize_exact_own_kernel
         const bool by0 = a.mode == 2 && a.file_cell_lo && ix.id_own_files && files_has(ix.id_own_files[id], (uint32_t)a.sel_file);
         if (by0) {
+        } else if (own_all) {
+            // every genome's rows, the k-mers of a list: finalize_exact_own_kernel has cast the votes of the genomes that hold the
+            // k-mer as it is (id_own_files); what is left of this bucket are the BucketInfos of the others
+            const uint4 r = *reinterpret_cast<const uint4*>(ix.slot_rec + (size_t)id * W + t);
+            const uint4 fb = ix.slot_files[(size_t)id * W + t], own = ix.id_own_files[id];
+            if (files_any(fb)) {
+                const uint32_t rest[4] = {fb.x & ~own.x, fb.y & ~own.y, fb.z & ~own.z, fb.w & ~own.w};
+#pragma unroll
+                for (uint32_t w4 = 0; w4 < 4u; ++w4)
+                    for (uint32_t bits = rest[w4]; bits; bits &= bits - 1u)
+                        vt_vote(vt, par, a, ix.entries[r.x + files_rank(fb, w4 * 32u + (uint32_t)__builtin_ctz(bits))], c, isrc, k, v);   // (neighbouring k-mers meet at the other genomes' differences: the table merges them)
+            } else {
+                for (uint32_t q = 0; q < r.y; ++q) vote(a, ix.entries[r.x + q], c, isrc, k, v);   // (no bitmap: own is all zero)
+            }
         } else if (a.mode != 1) {   // (the statistics pass casts no votes: a reference k-mer's statistics come from estat below)
             const uint32_t j = (uint32_t)ix.wstart + t;
             const uint4 r = (idr.w & kIdSimple) ? make_uint4(0u, 1u, idr.z + j, (idr.w >> 16) | (j << 16) | (((idr.w >> 1) & 1u) << 24))
@@ -2405,7 +2444,7 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
                 for (uint32_t q = 1; q < r.y; ++q) vote(a, ix.entries[r.x + q], c, isrc, k, v);
             }
         }
-        if (t == 0 && do_stats) {
+        if (t == 0 && do_stats && !own_all) {
             ++kept;
             uint32_t n_perfect = 0, perfect_file = 0;
             for (uint32_t q = ix.estat_off[id]; q < ix.estat_off[id + 1]; ++q) {   // (file << 1) | perfect
@@ -2420,7 +2459,7 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     // Voting pass of pileup_selected_only over a list of touched k-mers: nearly all of them were voted for by
     // finalize_exact_own_kernel (IndexView::id_own_files) or fail the thresholds -- one lane per counter finds the few that are
     // left (k-mers the selected genome does not hold as they are), and only those are spread over W lanes each
-    const bool own_done = a.mode == 2 && a.e_list && a.file_cell_lo && ix.id_own_files;
+    const bool own_done = (a.mode == 2 && a.e_list && a.file_cell_lo && ix.id_own_files) || own_all;
     if (own_done) {
         __shared__ unsigned long long ownq[256];
         __shared__ unsigned int ownq_n;
@@ -2428,10 +2467,26 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
             if (threadIdx.x == 0) ownq_n = 0u;
             __syncthreads();
             const uint64_t g = g0 + threadIdx.x;
+            uint4 pf = make_uint4(0u, 0u, 0u, 0u), vf = pf;
             if (g < n_ids_listed * 2ull) {
                 const uint64_t cidx = 2ull * a.e_list[g >> 1] + (g & 1ull);
                 const unsigned long long n = a.counters[cidx];
-                if (n != 0 && n >= a.ci && n <= a.cx && !files_has(ix.id_own_files[cidx >> 1], (uint32_t)a.sel_file)) ownq[atomicAdd(&ownq_n, 1u)] = cidx;
+                const bool keep = n != 0 && n >= a.ci && n <= a.cx;
+                const uint32_t id = (uint32_t)(cidx >> 1);
+                if (own_all) {   // (also the statistics: one lane per counter, the k-mer's genomes as two bitmaps)
+                    distinct += (n != 0);
+                    kept += keep;
+                    if (keep) { pf = ix.estat_files[(size_t)id * 2]; vf = ix.estat_files[(size_t)id * 2 + 1]; }
+                    if (keep && !(ix.id_rec[id].flags & kIdAllOwn)) ownq[atomicAdd(&ownq_n, 1u)] = cidx;
+                } else if (keep && !files_has(ix.id_own_files[id], (uint32_t)a.sel_file)) ownq[atomicAdd(&ownq_n, 1u)] = cidx;
+            }
+            if (own_all) {
+                tally_files<true, 0u>(pf, lstats, threadIdx.x & 63u, (uint32_t)ix.n_files);
+                tally_files<true, 1u>(vf, lstats, threadIdx.x & 63u, (uint32_t)ix.n_files);
+                if (__popc(pf.x) + __popc(pf.y) + __popc(pf.z) + __popc(pf.w) == 1) {   // perfect in exactly one genome: unique to it
+                    const uint32_t f = pf.x ? (uint32_t)__builtin_ctz(pf.x) : pf.y ? 32u + (uint32_t)__builtin_ctz(pf.y) : pf.z ? 64u + (uint32_t)__builtin_ctz(pf.z) : 96u + (uint32_t)__builtin_ctz(pf.w);
+                    atomicAdd(&lstats[f * 3u + 2u], 1u);
+                }
             }
             __syncthreads();
             const uint32_t nq = ownq_n * W;
@@ -2494,35 +2549,47 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
       vt_flush(vt, par, a);
       par ^= 1u;
     }
-    // pseudo k-mers (k = 31): nearly all of their counters are zero -- one thread per counter, the buckets in a loop
+    // pseudo k-mers (k = 31): nearly all of their counters are zero.  With a list of touched ids, 8 lanes per (counter, window
+    // bucket) share the bucket's BucketInfos (one thread per counter walked W buckets of ~100 entries one after the other: a
+    // chain of thousands of dependent steps, 4 ms of a 100-strain sample's finalize); without one, one thread per counter.
     const uint64_t pc_n = a.e_list ? n_pseudo_listed * 2ull : c_hi;
-    for (uint64_t ci = (a.e_list ? 0ull : max(c_lo, 2ull * ix.n_full)) + (uint64_t)blockIdx.x * 256 + threadIdx.x; ci < pc_n; ci += (uint64_t)gridDim.x * 256) {
+    const uint32_t pl = a.e_list ? 8u : 1u;                                  // lanes per (counter, bucket)
+    const uint64_t pw_n = a.e_list ? pc_n * W * pl : pc_n;
+    for (uint64_t wi = (a.e_list ? 0ull : max(c_lo, 2ull * ix.n_full)) + (uint64_t)blockIdx.x * 256 + threadIdx.x; wi < pw_n; wi += (uint64_t)gridDim.x * 256) {
+        const uint64_t ci = a.e_list ? wi / (W * pl) : wi;
+        const uint32_t rem = a.e_list ? (uint32_t)(wi - ci * (W * pl)) : 0u, t0 = rem / pl, sub = rem - t0 * pl;
+        const bool head = t0 == 0u && sub == 0u;                             // (the counter's first lane: its tallies)
         const uint64_t cidx = a.e_list ? 2ull * a.e_list[ix.n_u - 1u - (uint32_t)(ci >> 1)] + (ci & 1ull) : ci;   // (the tail of the list)
         const unsigned long long n = a.counters[cidx];
         if (n == 0) continue;
-        distinct += do_stats;
+        distinct += do_stats && head;
         if (n < a.ci || n > a.cx) continue;
-        kept += do_stats;
+        kept += do_stats && head;
         const unsigned long long v = n > a.cs ? a.cs : n;
         const uint32_t id = (uint32_t)(cidx >> 1), isrc = (uint32_t)cidx & 1u;
         const uint64_t c = ix.kmer_of[id];
-        if (a.mode != 1) for (uint32_t t = 0; t < W; ++t) {
+        if (a.mode != 1) for (uint32_t t = a.e_list ? t0 : 0u; t < (a.e_list ? t0 + 1u : W); ++t) {
             const uint32_t s = ix.slot_of[(size_t)id * W + t];
             const uint32_t off = ix.ent_off[s], cnt = ix.ent_len[s];
             if (a.mode == 2 && ix.ent_files) {   // (one entry per genome: the selected genome's by its rank -- no bisection in this serial loop)
                 const uint4 fb = ix.ent_files[s];
                 if (files_any(fb)) {
-                    if (files_has(fb, (uint32_t)a.sel_file)) vote(a, ix.entries[off + files_rank(fb, (uint32_t)a.sel_file)], c, isrc, k, v);
+                    if (sub == 0u && files_has(fb, (uint32_t)a.sel_file)) vote(a, ix.entries[off + files_rank(fb, (uint32_t)a.sel_file)], c, isrc, k, v);
                     continue;
                 }
             }
-            for (uint32_t q = a.mode == 2 ? first_of_file(ix.entries + off, cnt, a.sel_file) : 0u; q < cnt; ++q) {
-                const DevEntry en = ix.entries[off + q];
-                if (a.mode == 2 && (int)en.file != a.sel_file) break;
-                vote(a, en, c, isrc, k, v);
+            if (a.mode == 2) {
+                if (sub != 0u) continue;
+                for (uint32_t q = first_of_file(ix.entries + off, cnt, a.sel_file); q < cnt; ++q) {
+                    const DevEntry en = ix.entries[off + q];
+                    if ((int)en.file != a.sel_file) break;
+                    vote(a, en, c, isrc, k, v);
+                }
+            } else {
+                for (uint32_t q = sub; q < cnt; q += pl) vote(a, ix.entries[off + q], c, isrc, k, v);
             }
         }
-        if (!do_stats) continue;
+        if (!do_stats || !head) continue;
         uint32_t n_perfect = 0, perfect_file = 0;
         for (uint32_t q = ix.estat_off[id]; q < ix.estat_off[id + 1]; ++q) {   // (file << 1) | perfect
             const uint32_t e = ix.estat[q];
@@ -2545,10 +2612,11 @@ constexpr uint32_t kOwnCells = 256, kOwnSpan = kOwnCells + 32;
 __global__ __launch_bounds__(256) void finalize_exact_own_kernel(FinalizeArgs a) {
     __shared__ unsigned long long mx[8][kOwnSpan];
     __shared__ unsigned int cnt[8][kOwnSpan];
-    const int sel = *a.sel;
-    if (sel < 0) return;
     const IndexView& ix = a.ix;
-    const uint32_t c_lo = a.file_cell_lo[sel], c_hi = sel + 1 < ix.n_files ? a.file_cell_lo[sel + 1] : ix.total_cells;
+    const int sel = a.mode == 2 ? *a.sel : 0;   // (mode 0, every genome's rows: all cells, each for the genome it lies in)
+    if (sel < 0) return;
+    const uint32_t c_lo = a.mode == 2 ? a.file_cell_lo[sel] : 0u;
+    const uint32_t c_hi = a.mode == 2 ? (sel + 1 < ix.n_files ? a.file_cell_lo[sel + 1] : ix.total_cells) : ix.total_cells;
     const uint32_t c0 = c_lo + blockIdx.x * kOwnCells;
     if (c0 >= c_hi) return;
     for (uint32_t i = threadIdx.x; i < 8u * kOwnSpan; i += 256u) { (&mx[0][0])[i] = 0ull; (&cnt[0][0])[i] = 0u; }
@@ -2557,24 +2625,33 @@ __global__ __launch_bounds__(256) void finalize_exact_own_kernel(FinalizeArgs a)
     const uint32_t W = (uint32_t)ix.W;
     const uint32_t c = c0 + threadIdx.x;
     const uint32_t id = c < c_hi ? ix.id_at[c] : 0xffffffffu;
-    if (id < ix.n_full && files_has(ix.id_own_files[id], (uint32_t)sel)) {
+    const uint32_t fsel = a.mode == 2 ? (uint32_t)sel : (c < c_hi ? (uint32_t)ix.cell_file[c] : 0u);
+    unsigned long long n2[2] = {0ull, 0ull};   // the k-mer's two counters, those that pass the thresholds (kmc -ci / -cx act on the true count)
+    if (id < ix.n_full) {
+#pragma unroll
+        for (int isrc = 0; isrc < 2; ++isrc) { const unsigned long long n = a.counters[2 * (size_t)id + isrc]; n2[isrc] = (n >= a.ci && n <= a.cx) ? n : 0ull; }
+    }
+    if ((n2[0] | n2[1]) != 0ull && files_has(ix.id_own_files[id], fsel)) {
         const uint4 fb = ix.slot_files[(size_t)id * W];
-        const DevEntry e0 = ix.entries[ix.slot_rec[(size_t)id * W].off + files_rank(fb, (uint32_t)sel)];   // cell = c + wstart (checked at create)
-        const uint64_t km = ix.id_rec[id].kmer;
-        const uint32_t q0 = threadIdx.x;                                        // position of its first vote within the table
-        for (uint32_t isrc = 0; isrc < 2u && e0.cell == c + (uint32_t)ix.wstart; ++isrc) {   // (its one occurrence in the genome is at this very cell)
-            const unsigned long long n = a.counters[2 * (size_t)id + isrc];
-            if (n == 0 || n < a.ci || n > a.cx) continue;                        // kmc -ci / -cx act on the true count
+        const DevEntry e0 = ix.entries[ix.slot_rec[(size_t)id * W].off + files_rank(fb, fsel)];   // (cell = c + idx: checked at create, and below)
+        const uint4 idr = *reinterpret_cast<const uint4*>(ix.id_rec + id);
+        const uint64_t km = (uint64_t)idr.x | ((uint64_t)idr.y << 32);
+        const int dir = (idr.w & kIdOwnMirror) ? -1 : 1;                        // bucket t's BucketInfo: bucket 0's, t further on / back
+        const uint32_t q0 = e0.cell - c0;                                       // position of bucket 0's vote within the table
+        for (uint32_t isrc = 0; isrc < 2u && e0.cell == c + (uint32_t)e0.idx; ++isrc) {   // (its one occurrence in the genome is at this very cell)
+            const unsigned long long n = n2[isrc];
+            if (n == 0) continue;
             const unsigned long long v = n > a.cs ? a.cs : n;                   // kmc -cs: reported count saturates
             for (uint32_t t = 0; t < W; ++t) {
-                const uint32_t idx = (uint32_t)e0.idx + t;                       // (vote(): call.rs:1327-1384)
+                const uint32_t idx = (uint32_t)((int)e0.idx + dir * (int)t);     // (vote(): call.rs:1327-1384)
                 uint32_t bit_idx;
                 bool forward;
                 if (e0.canonical) { bit_idx = ((uint32_t)(km >> (2 * idx)) & 3u) ^ 3u; forward = isrc != 0; }
                 else { bit_idx = (uint32_t)(km >> (2 * (k - 1 - (int)idx))) & 3u; forward = isrc == 0; }
                 const uint32_t row = (forward ? 0u : 4u) + bit_idx;
-                atomicAdd(&cnt[row][q0 + t], 1u);
-                atomicMax(&mx[row][q0 + t], v);
+                const uint32_t q = (uint32_t)((int)q0 + dir * (int)t);           // (cell c + idx: within [0, 256 + k))
+                atomicAdd(&cnt[row][q], 1u);
+                atomicMax(&mx[row][q], v);
             }
         }
     }
@@ -2583,7 +2660,7 @@ __global__ __launch_bounds__(256) void finalize_exact_own_kernel(FinalizeArgs a)
         const uint32_t row = i / kOwnSpan, q = i - row * kOwnSpan;
         const unsigned int nv = cnt[row][q];
         if (!nv) continue;
-        const size_t cell = ((size_t)c0 + (uint32_t)ix.wstart + q) * 4 + (row & 3u);
+        const size_t cell = ((size_t)c0 + q) * 4 + (row & 3u);
         atomicAdd(a.pileup + (row < 4u ? 2 : 3) * a.plane + cell, (unsigned long long)nv);   // #kmers
         atomicMax(a.pileup + (row < 4u ? 0 : 1) * a.plane + cell, mx[row][q]);               // depth
     }
@@ -2841,17 +2918,21 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     const size_t lds_votes = (lds_stats + 15) / 16 * 16 + kVoteLdsBytes;
     const size_t lds = finalize_lds_bytes(a.ix.n_files);
     if (lds_votes > 64 * 1024 || lds > 64 * 1024) {   // thousands of genome files: beyond the default dynamic LDS limit
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_variant_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_votes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_variant_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_votes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_variant_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_votes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_votes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    hipLaunchKernelGGL(finalize_variant_kernel, dim3(b_var), dim3(256), lds_votes, stream, a);
+    if (a.ix.slot_files) hipLaunchKernelGGL(finalize_variant_kernel<true>, dim3(b_var), dim3(256), lds_votes, stream, a);
+    else hipLaunchKernelGGL(finalize_variant_kernel<false>, dim3(b_var), dim3(256), lds_votes, stream, a);
     // K2e
     const uint64_t n_work = e_plane_len(a.ix.n_u) * (uint64_t)a.ix.W;
     const unsigned b_ex = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_work + 255) / 256, kFinExactBlocks));
     a.row_exact = (int)b_var;
     if (a.mode == 2 && a.file_cell_lo && a.ix.id_own_files && a.max_file_cells)
         hipLaunchKernelGGL(finalize_exact_own_kernel, dim3((a.max_file_cells + kOwnCells - 1) / kOwnCells), dim3(256), 0, stream, a);
+    else if (a.mode == 0 && a.e_list && a.file_cell_lo && a.ix.id_own_files && a.ix.cell_file && a.ix.estat_files && a.ix.total_cells)   // (finalize_exact_kernel: own_all)
+        hipLaunchKernelGGL(finalize_exact_own_kernel, dim3((a.ix.total_cells + kOwnCells - 1) / kOwnCells), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(finalize_exact_kernel, dim3(b_ex), dim3(256), lds_votes, stream, a);
     // K2b (deferred k-mers only; the kernel reads their number on the device)
     // (few genomes: multi-bucket k-mers are rare, a small grid starts and ends quickly; many: one k-mer in eight takes this path)

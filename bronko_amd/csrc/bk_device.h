@@ -203,6 +203,8 @@ struct IndexView {
                                  //   (or more than 128 files, or W == 1: both null): look at the entries.  bk_params.pileup_selected_only.
     const uint4*     id_own_files; // [n_full] bit f = in each of the k-mer's W buckets genome f's one BucketInfo is the k-mer's own occurrence in f:
                                    //   that of bucket t = that of bucket 0 with cell + t, idx + t (kIdOwnMirror: - t); null with slot_files
+    const uint32_t*  id_rest_off;  // [n_full + 1] / id_rest: per k-mer with own files, the BucketInfos of its buckets that are not its own occurrences
+    const uint32_t*  id_rest;      //   (indices into entries); null with slot_files
     const uint16_t*  cell_file;    // [total_cells] genome file of each cell; null with slot_files
     const uint4*     estat_files;  // [n_full][2] estat as bitmaps: genomes in which the k-mer is perfect / a variant; null with slot_files
     const uint8_t*   amb;      // [n_u] bit 1 = the k-mer's first occurrence was reverse-complemented to become canonical; bit 0 = "dirty": another reference k-mer (either strand) lies within Hamming

@@ -291,6 +291,7 @@ struct bk_engine {
     DevBuf<bk::SlotRec> slot_rec;
     DevBuf<uint4> ent_files, slot_files, id_own_files, estat_files;
     DevBuf<uint16_t> cell_file;
+    DevBuf<uint32_t> id_rest_off, id_rest;
     DevBuf<uint8_t> amb;
     DevBuf<uint16_t> pilots;
     DevBuf<unsigned int> slabs;             // [n_cus][n_lds_bins] workgroup histograms of the last scan launch
@@ -375,7 +376,7 @@ struct bk_engine {
         v.n_full = n_full; v.n_prows = n_prows; v.prow_id = prow_id.p; v.prow_t = prow_t.p; v.v_omin = v_omin; v.v_span = v_span; v.v_off = v_off;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb, half_lo.log2p};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb, half_hi.log2p};
-        v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.slot_rec = slot_rec.p; v.ent_files = ent_files.p; v.slot_files = slot_files.p; v.id_own_files = id_own_files.p; v.cell_file = cell_file.p; v.estat_files = estat_files.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
+        v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.slot_rec = slot_rec.p; v.ent_files = ent_files.p; v.slot_files = slot_files.p; v.id_own_files = id_own_files.p; v.cell_file = cell_file.p; v.id_rest_off = id_rest_off.p; v.id_rest = id_rest.p; v.estat_files = estat_files.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
         v.table = table.p; v.ent_off = ent_off.p; v.ent_len = ent_len.p;
         v.entries = entries.p; v.n_slots = n_slots; v.log2s = log2s; v.k = k; v.wstart = wstart; v.W = W; v.n_files = n_files;
         return v;
@@ -1422,6 +1423,38 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     fprintf(stderr, "[bk] own files: %llu (k-mer, genome) pairs of %llu in bucket 0; %llu of %llu k-mers with any, %llu against the reference\n",
                             (unsigned long long)n_own, (unsigned long long)n_b0, (unsigned long long)n_any, (unsigned long long)e->n_full, (unsigned long long)n_mir);
                 }
+                // id_rest (IndexView): per k-mer, the BucketInfos of its W buckets that are NOT its own occurrences -- other k-mers of
+                // other genomes that differ at the bucket's position -- as indices into `entries`; what every-genome votes have
+                // left to do for a k-mer after finalize_exact_own_kernel.  (k-mers without file bitmaps: no list, own is all zero.)
+                {
+                    std::vector<uint32_t> h_roff((size_t)e->n_full + 1, 0u);
+                    parallel_for(e->n_full, [&](size_t id0, size_t id1) {
+                        for (size_t id = id0; id < id1; id++) {
+                            uint32_t n = 0;
+                            if (bk::files_any(h_own[id]))
+                                for (int t = 0; t < e->W; t++) {
+                                    const uint4& f = h_sf[id * e->W + t];
+                                    n += (uint32_t)(__builtin_popcount(f.x & ~h_own[id].x) + __builtin_popcount(f.y & ~h_own[id].y) + __builtin_popcount(f.z & ~h_own[id].z) + __builtin_popcount(f.w & ~h_own[id].w));
+                                }
+                            h_roff[id + 1] = n;
+                        }
+                    });
+                    for (size_t id = 0; id < e->n_full; id++) h_roff[id + 1] += h_roff[id];
+                    std::vector<uint32_t> h_rest(std::max<size_t>(h_roff[e->n_full], 1), 0u);
+                    parallel_for(e->n_full, [&](size_t id0, size_t id1) {
+                        for (size_t id = id0; id < id1; id++) {
+                            if (!bk::files_any(h_own[id])) continue;
+                            uint32_t at = h_roff[id];
+                            for (int t = 0; t < e->W; t++) {
+                                const uint32_t sl = h_slot_of[id * e->W + t];
+                                for (uint32_t q = 0; q < h_len[sl]; q++)
+                                    if (!bk::files_has(h_own[id], h_ent[h_off[sl] + q].file)) h_rest[at++] = h_off[sl] + q;
+                            }
+                        }
+                    });
+                    BK_HIP(e->id_rest_off.upload(h_roff));
+                    BK_HIP(e->id_rest.upload(h_rest));
+                }
                 // kIdAllOwn: nothing else in any of the k-mer's buckets
                 h_all_own.assign(e->n_full, 0);
                 parallel_for(e->n_full, [&](size_t id0, size_t id1) {
@@ -1579,7 +1612,7 @@ int bk_engine_fork_params(const bk_engine* parent, const bk_params* prm, bk_engi
     e->cell_fast.alias(p->cell_fast); e->cell_nat.alias(p->cell_nat); e->cell_blk.alias(p->cell_blk); e->seed_tab.alias(p->seed_tab); e->seed_log2 = p->seed_log2;
     e->half_lo.pilots.alias(p->half_lo.pilots); e->half_lo.dir.alias(p->half_lo.dir); e->half_lo.cand.alias(p->half_lo.cand);
     e->half_hi.pilots.alias(p->half_hi.pilots); e->half_hi.dir.alias(p->half_hi.dir); e->half_hi.cand.alias(p->half_hi.cand);
-    e->slot_of.alias(p->slot_of); e->estat_off.alias(p->estat_off); e->estat.alias(p->estat); e->slot_rec.alias(p->slot_rec); e->ent_files.alias(p->ent_files); e->slot_files.alias(p->slot_files); e->id_own_files.alias(p->id_own_files); e->cell_file.alias(p->cell_file); e->estat_files.alias(p->estat_files); e->amb.alias(p->amb);
+    e->slot_of.alias(p->slot_of); e->estat_off.alias(p->estat_off); e->estat.alias(p->estat); e->slot_rec.alias(p->slot_rec); e->ent_files.alias(p->ent_files); e->slot_files.alias(p->slot_files); e->id_own_files.alias(p->id_own_files); e->cell_file.alias(p->cell_file); e->id_rest_off.alias(p->id_rest_off); e->id_rest.alias(p->id_rest); e->estat_files.alias(p->estat_files); e->amb.alias(p->amb);
     e->pilots.alias(p->pilots); e->table.alias(p->table); e->ent_off.alias(p->ent_off); e->ent_len.alias(p->ent_len); e->entries.alias(p->entries);
     e->occ.alias(p->occ); e->file_cell_lo_d.alias(p->file_cell_lo_d);
     e->genome_len.alias(p->genome_len); e->seq_cell.alias(p->seq_cell); e->seq_len_d.alias(p->seq_len_d); e->seq_first.alias(p->seq_first);

@@ -2391,7 +2391,7 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     uint32_t par = 0;
     // every genome's rows (mode 0) over a list of touched k-mers of a many-genome index: the votes of the genomes that hold a k-mer
     // as it is were cast by finalize_exact_own_kernel, cell by cell
-    const bool own_all = a.mode == 0 && a.e_list && a.file_cell_lo && ix.id_own_files && ix.cell_file && ix.estat_files;
+    const bool own_all = a.mode == 0 && a.e_list && a.file_cell_lo && ix.id_own_files && ix.cell_file && ix.estat_files && ix.id_rest_off;
     // one (counter, window bucket) pair
     auto pair_body = [&](uint64_t cidx, uint32_t t) {
       do {
@@ -2461,10 +2461,10 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     // left (k-mers the selected genome does not hold as they are), and only those are spread over W lanes each
     const bool own_done = (a.mode == 2 && a.e_list && a.file_cell_lo && ix.id_own_files) || own_all;
     if (own_done) {
-        __shared__ unsigned long long ownq[256];
-        __shared__ unsigned int ownq_n;
+        __shared__ unsigned long long ownq[256], restq[256];
+        __shared__ unsigned int ownq_n, restq_n;
         for (uint64_t g0 = (uint64_t)blockIdx.x * 256; g0 < n_ids_listed * 2ull; g0 += (uint64_t)gridDim.x * 256) {
-            if (threadIdx.x == 0) ownq_n = 0u;
+            if (threadIdx.x == 0) { ownq_n = 0u; restq_n = 0u; }
             __syncthreads();
             const uint64_t g = g0 + threadIdx.x;
             uint4 pf = make_uint4(0u, 0u, 0u, 0u), vf = pf;
@@ -2477,7 +2477,9 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
                     distinct += (n != 0);
                     kept += keep;
                     if (keep) { pf = ix.estat_files[(size_t)id * 2]; vf = ix.estat_files[(size_t)id * 2 + 1]; }
-                    if (keep && !(ix.id_rec[id].flags & kIdAllOwn)) ownq[atomicAdd(&ownq_n, 1u)] = cidx;
+                    if (keep && !(ix.id_rec[id].flags & kIdAllOwn)) {   // with own files: its list of the others (id_rest); without: bucket by bucket
+                        if (files_any(ix.id_own_files[id])) restq[atomicAdd(&restq_n, 1u)] = cidx; else ownq[atomicAdd(&ownq_n, 1u)] = cidx;
+                    }
                 } else if (keep && !files_has(ix.id_own_files[id], (uint32_t)a.sel_file)) ownq[atomicAdd(&ownq_n, 1u)] = cidx;
             }
             if (own_all) {
@@ -2489,6 +2491,22 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
                 }
             }
             __syncthreads();
+            // the listed BucketInfos (IndexView::id_rest) of 32 counters at a time, 8 lanes per counter: neighbouring k-mers meet at
+            // the other genomes' differences, the vote table merges them
+            for (uint32_t i0 = 0; i0 < restq_n; i0 += 32u) {
+                const uint32_t item = i0 + (threadIdx.x >> 3);
+                if (item < restq_n) {
+                    const uint64_t cidx = restq[item];
+                    const uint32_t id = (uint32_t)(cidx >> 1);
+                    const unsigned long long n = a.counters[cidx];
+                    const unsigned long long v = n > a.cs ? a.cs : n;
+                    const uint64_t c = ix.id_rec[id].kmer;
+                    for (uint32_t q = ix.id_rest_off[id] + (threadIdx.x & 7u), qe = ix.id_rest_off[id + 1]; q < qe; q += 8u)
+                        vt_vote(vt, par, a, ix.entries[ix.id_rest[q]], c, (uint32_t)cidx & 1u, k, v);
+                }
+                vt_flush(vt, par, a);
+                par ^= 1u;
+            }
             const uint32_t nq = ownq_n * W;
             for (uint32_t w0 = 0; w0 < nq; w0 += 256u) {
                 const uint32_t w = w0 + threadIdx.x;
@@ -2931,7 +2949,7 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     a.row_exact = (int)b_var;
     if (a.mode == 2 && a.file_cell_lo && a.ix.id_own_files && a.max_file_cells)
         hipLaunchKernelGGL(finalize_exact_own_kernel, dim3((a.max_file_cells + kOwnCells - 1) / kOwnCells), dim3(256), 0, stream, a);
-    else if (a.mode == 0 && a.e_list && a.file_cell_lo && a.ix.id_own_files && a.ix.cell_file && a.ix.estat_files && a.ix.total_cells)   // (finalize_exact_kernel: own_all)
+    else if (a.mode == 0 && a.e_list && a.file_cell_lo && a.ix.id_own_files && a.ix.cell_file && a.ix.estat_files && a.ix.id_rest_off && a.ix.total_cells)   // (finalize_exact_kernel: own_all)
         hipLaunchKernelGGL(finalize_exact_own_kernel, dim3((a.ix.total_cells + kOwnCells - 1) / kOwnCells), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(finalize_exact_kernel, dim3(b_ex), dim3(256), lds_votes, stream, a);
     // K2b (deferred k-mers only; the kernel reads their number on the device)

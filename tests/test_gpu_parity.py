@@ -966,6 +966,40 @@ def test_votes_for_the_selected_genome_only(oracle, sars_paths):
         ix.close()
 
 
+@pytest.mark.parametrize("selected_only", [False, True])
+@pytest.mark.parametrize("n_strains", [100, 140])
+def test_file_bitmaps_and_the_paths_without_them(oracle, monkeypatch, testing_lib, selected_only, n_strains):
+    """With up to 128 genome files the engine describes a bucket by the set of files in it (IndexView::ent_files) and takes the
+    statistics, the selected genome's votes and -- on an index with touch lists (forced here) -- every genome's votes of the
+    reference k-mers from those bitmaps and the tables built on them (own occurrences cell by cell, the rest from per-k-mer
+    lists); with more files, or a bucket that holds a file twice (the repeat planted here), it walks the entries as before.
+    100 and 140 strains of a 1.2 kb fragment of HPV16 with a direct repeat, k = 21: both equal the oracle, statistics and rows."""
+    from bronko_amd import Params
+    monkeypatch.setenv("BK_SPARSE_FINALIZE", "1")
+    base = bytearray(synth.read_fasta_bytes(os.path.join(helpers.GOLDEN, "HPV16.fa"))[1000:2200])
+    base[700:760] = base[100:160]                                # every strain holds these k-mers twice
+    files = _mutated_strains(bytes(base), n_strains, 61, 12)
+    ix = oracle.Index.build_mem(21, files)
+    gm, isnv = synth.sample_genome(files[37][1][0][1], 73)
+    mates = [synth.codes_to_ascii(synth.single_end_codes(gm, 6000, 150, 73, isnv=isnv))]
+    pile = oracle.sample_pileup(ix, mates)
+    best = oracle.pick_best_genome(ix, pile.stats.sum(axis=0), pile.present.max(axis=0))
+    eng = helpers.engine_from_oracle_index(ix, Params(pileup_selected_only=selected_only))
+    for rep in range(2):
+        res = helpers.hip_sample(eng, mates, 21)
+        assert np.array_equal(res.stats, pile.stats) and np.array_equal(res.present, pile.present)
+        if not selected_only:
+            helpers.assert_same_pileup(res, pile)
+            continue
+        lo, n = ix.genome_cells(best)
+        for name in ("fwd_depth", "rev_depth", "fwd_nk", "rev_nk"):
+            got, ref = getattr(res, name), getattr(pile, name)
+            assert np.array_equal(got[lo * 4:(lo + n) * 4], ref[lo * 4:(lo + n) * 4]), name
+            assert not got[:lo * 4].any() and not got[(lo + n) * 4:].any(), name
+    eng.close()
+    ix.close()
+
+
 @pytest.mark.parametrize("force_sparse", [True, False])
 @pytest.mark.parametrize("selected_only", [False, True])
 def test_planes_are_clean_between_samples(oracle, sars_paths, monkeypatch, testing_lib, selected_only, force_sparse):

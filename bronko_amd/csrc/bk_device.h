@@ -181,6 +181,9 @@ struct IndexView {
                                   // id q - o + cell_blk[..].x, and with that other base at q it takes its OWN V row (clean, or its DirtyAns
                                   // says so) -- cell_fast per (position, offset, base) for cells that are not clean; the k-mers that cover
                                   // one mismatch all ask the same word.  Null when no answer table was built.
+    const uint32_t*  cell_natrow; // [total_cells + k] without touch lists (dense planes): the id + o that cell_nat's bits of position q stand for -- the
+                                  // k-mers over q whose id is NOT q - o + that constant are left out instead of those that leave cell_blk's
+                                  // sequence; null with touch lists (there cell_nat promises id = cell + cell_blk[..].x)
     const uint2*     seed_tab;    // [n_files << seed_log2] the scan's seed tables (see seed_hash), or null (index too large)
     uint32_t         seed_log2;
     const uint2*     cell_blk;    // per block of 64 cells (two entries of padding behind): x = the most common id_at[q] - q among the block's cells

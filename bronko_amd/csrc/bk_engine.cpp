@@ -268,7 +268,7 @@ struct bk_engine {
     DevBuf<bk::IdRec> id_rec;
     DevBuf<bk::DirtyAns> dirty_ans;
     DevBuf<uint8_t> cell_flags;
-    DevBuf<uint32_t> ref_words, cell_codes, cell_has, cell_clean, cell_clean3, cell_yf, cell_yr, id_at, cell_fast, cell_nat;
+    DevBuf<uint32_t> ref_words, cell_codes, cell_has, cell_clean, cell_clean3, cell_yf, cell_yr, id_at, cell_fast, cell_nat, cell_natrow;
     DevBuf<uint2> cell_blk, seed_tab;
     uint32_t seed_log2 = 0;
     struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0, log2p = 0; } half_lo, half_hi;
@@ -372,7 +372,7 @@ struct bk_engine {
     bk::IndexView view() const {
         bk::IndexView v{};
         v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb; v.log2p = log2p;
-        v.kmer_of = kmer_of.p; v.id_rec = id_rec.p; v.dirty_ans = dirty_ans.p; v.cell_flags = cell_flags.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_clean3 = cell_clean3.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.cell_fast = cell_fast.p; v.cell_nat = cell_nat.p; v.cell_blk = cell_blk.p; v.seed_tab = seed_tab.p; v.seed_log2 = seed_log2; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
+        v.kmer_of = kmer_of.p; v.id_rec = id_rec.p; v.dirty_ans = dirty_ans.p; v.cell_flags = cell_flags.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_clean3 = cell_clean3.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.cell_fast = cell_fast.p; v.cell_nat = cell_nat.p; v.cell_natrow = cell_natrow.p; v.cell_blk = cell_blk.p; v.seed_tab = seed_tab.p; v.seed_log2 = seed_log2; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
         v.n_full = n_full; v.n_prows = n_prows; v.prow_id = prow_id.p; v.prow_t = prow_t.p; v.v_omin = v_omin; v.v_span = v_span; v.v_off = v_off;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb, half_lo.log2p};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb, half_hi.log2p};
@@ -849,7 +849,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         // with full_kmer_stats the rows keep every offset, so that k-mers differing outside the window are not lost to the statistics
         e->v_omin = bk::v_layout_omin(k, e->wstart, e->W, prm->full_kmer_stats != 0);
         e->v_span = bk::v_layout_span(k, e->wstart, e->W, prm->full_kmer_stats != 0);
-        std::vector<uint32_t> h_nat;
+        std::vector<uint32_t> h_nat, h_natrow;
         {
             std::vector<uint32_t> idx_by_id(h_u.size());
             for (size_t i = 0; i < h_u.size(); i++) idx_by_id[id_of[i]] = (uint32_t)i;
@@ -1163,15 +1163,41 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 // that other base at q, takes its own V row" -- its cell is clean, or its answer says exactly that (or says that it
                 // touches nothing, which is what finalize makes of the own row's count then: position outside the window or
                 // canonical form on the other strand)
+                // Which id a bit promises: with touch lists (large planes: the scan notes touched rows per block of cells) the one
+                // cell_blk gives, id = cell + block constant; otherwise whatever row most of the k-mers over q agree on --
+                // cell_natrow[q] = id + o -- which also covers the cells whose ids leave the block's sequence (a later genome's own
+                // k-mers around its differences from an earlier one)
+                const bool lists = e->W > 0 && (e->plane_len >= (16ull << 20) || test_env("BK_SPARSE_FINALIZE") != nullptr);   // (= bk_engine::sparse, set later)
                 h_nat.assign(((size_t)cells + (size_t)k) * 3u, 0u);
+                if (!lists) h_natrow.assign((size_t)cells + (size_t)k, 0u);
                 parallel_for((size_t)cells + (size_t)k, [&](size_t q0, size_t q1) {
                     for (size_t q = q0; q < q1; q++) {
                         const uint32_t rb = q < cells ? (h_refw[pad_w + (q >> 4)] >> (2 * (q & 15))) & 3u : 0u;
+                        uint32_t row = 0u;
+                        if (!lists) {   // the most common id + o among the first-orientation cells q - o
+                            uint32_t best_n = 0u;
+                            for (int o = 0; o < k; o++) {
+                                if (q < (size_t)o || q - (size_t)o >= cells) continue;
+                                const size_t c = q - (size_t)o;
+                                if (h_id_at[c] == kNone || !(h_cflags[c] & bk::kCellFirstOri)) continue;
+                                const uint32_t r = h_id_at[c] + (uint32_t)o;
+                                if (best_n && r == row) continue;
+                                uint32_t n = 0u;
+                                for (int o2 = o; o2 < k; o2++) {
+                                    if (q < (size_t)o2 || q - (size_t)o2 >= cells) continue;
+                                    const size_t c2 = q - (size_t)o2;
+                                    n += h_id_at[c2] != kNone && (h_cflags[c2] & bk::kCellFirstOri) && h_id_at[c2] + (uint32_t)o2 == r;
+                                }
+                                if (n > best_n) { best_n = n; row = r; }
+                            }
+                            h_natrow[q] = row;
+                        }
                         for (int o = 0; o < k; o++) {
                             if (q < (size_t)o || q - (size_t)o >= cells) continue;
                             const size_t c = q - (size_t)o;
                             const uint32_t id = h_id_at[c];
-                            if (id == kNone || !(h_cflags[c] & bk::kCellFirstOri) || id - (uint32_t)c != h_blk[c >> 6].x) continue;
+                            if (id == kNone || !(h_cflags[c] & bk::kCellFirstOri)) continue;
+                            if (lists ? id - (uint32_t)c != h_blk[c >> 6].x : id + (uint32_t)o != row) continue;
                             for (uint32_t al = 0; al < 3; al++) {
                                 bool nat = (h_cflags[c] & bk::kCellClean) != 0;
                                 if (!nat) {
@@ -1215,6 +1241,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         BK_HIP(e->cell_fast.upload(h_fast));
         BK_HIP(e->cell_blk.upload(h_blk));
         if (!h_nat.empty()) BK_HIP(e->cell_nat.upload(h_nat));
+        if (!h_natrow.empty()) BK_HIP(e->cell_natrow.upload(h_natrow));
         BK_HIP(e->cell_codes.upload(h_codes));
         BK_HIP(e->cell_flags.upload(h_cflags));
         BK_HIP(e->id_at.upload(h_id_at));
@@ -1609,7 +1636,7 @@ int bk_engine_fork_params(const bk_engine* parent, const bk_params* prm, bk_engi
     e->prow_id.alias(p->prow_id); e->prow_t.alias(p->prow_t); e->kmer_pos.alias(p->kmer_pos); e->d_view.alias(p->d_view); e->kmer_of.alias(p->kmer_of); e->id_rec.alias(p->id_rec); e->dirty_ans.alias(p->dirty_ans); e->cell_flags.alias(p->cell_flags);
     e->ref_words.alias(p->ref_words); e->cell_codes.alias(p->cell_codes); e->cell_has.alias(p->cell_has); e->cell_clean.alias(p->cell_clean);
     e->cell_clean3.alias(p->cell_clean3); e->cell_yf.alias(p->cell_yf); e->cell_yr.alias(p->cell_yr); e->id_at.alias(p->id_at);
-    e->cell_fast.alias(p->cell_fast); e->cell_nat.alias(p->cell_nat); e->cell_blk.alias(p->cell_blk); e->seed_tab.alias(p->seed_tab); e->seed_log2 = p->seed_log2;
+    e->cell_fast.alias(p->cell_fast); e->cell_nat.alias(p->cell_nat); e->cell_natrow.alias(p->cell_natrow); e->cell_blk.alias(p->cell_blk); e->seed_tab.alias(p->seed_tab); e->seed_log2 = p->seed_log2;
     e->half_lo.pilots.alias(p->half_lo.pilots); e->half_lo.dir.alias(p->half_lo.dir); e->half_lo.cand.alias(p->half_lo.cand);
     e->half_hi.pilots.alias(p->half_hi.pilots); e->half_hi.dir.alias(p->half_hi.dir); e->half_hi.cand.alias(p->half_hi.cand);
     e->slot_of.alias(p->slot_of); e->estat_off.alias(p->estat_off); e->estat.alias(p->estat); e->slot_rec.alias(p->slot_rec); e->ent_files.alias(p->ent_files); e->slot_files.alias(p->slot_files); e->id_own_files.alias(p->id_own_files); e->cell_file.alias(p->cell_file); e->id_rest_off.alias(p->id_rest_off); e->id_rest.alias(p->id_rest); e->estat_files.alias(p->estat_files); e->amb.alias(p->amb);
@@ -1759,7 +1786,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.n_records_dev = n_records_dev;
     a.ixp = e->d_view.p;
     a.k = e->k; a.wstart = e->wstart; a.W = e->W; a.v_omin = e->v_omin; a.v_span = e->v_span; a.v_off = e->v_off; a.total_cells = (uint32_t)e->total_cells; a.n_u = e->n_u;
-    a.ref_words = e->ref_words.p; a.cell_codes = e->cell_codes.p; a.cell_has = e->cell_has.p; a.cell_clean = e->cell_clean.p; a.cell_clean3 = e->cell_clean3.p; a.cell_yf = e->cell_yf.p; a.cell_yr = e->cell_yr.p; a.id_at = e->id_at.p; a.cell_fast = e->cell_fast.p; a.cell_nat = e->cell_nat.p; a.cell_blk = e->cell_blk.p; a.seed_tab = e->seed_tab.p; a.seed_log2 = e->seed_log2;
+    a.ref_words = e->ref_words.p; a.cell_codes = e->cell_codes.p; a.cell_has = e->cell_has.p; a.cell_clean = e->cell_clean.p; a.cell_clean3 = e->cell_clean3.p; a.cell_yf = e->cell_yf.p; a.cell_yr = e->cell_yr.p; a.id_at = e->id_at.p; a.cell_fast = e->cell_fast.p; a.cell_nat = e->cell_nat.p; a.cell_natrow = e->cell_natrow.p; a.cell_blk = e->cell_blk.p; a.seed_tab = e->seed_tab.p; a.seed_log2 = e->seed_log2;
     a.words = d_words; a.lens = d_lens; a.n_records = n; a.stride_words = stride_words;
     a.counters = e->counters[mate].p;
     a.kmer_total = e->kstats.p + mate * 4 + 1;

@@ -24,6 +24,7 @@ struct ScanArgs {
     const uint32_t* cell_fast;      // IndexView::cell_fast (1 bit per cell, padded like cell_has) / cell_blk (one entry per 64 cells)
     const uint2* cell_blk;
     const uint32_t* cell_nat;       // IndexView::cell_nat (or null)
+    const uint32_t* cell_natrow;    // IndexView::cell_natrow (or null)
     const uint2* seed_tab;          // IndexView::seed_tab / seed_log2
     uint32_t seed_log2;
     const uint32_t* words;          // [n_records][stride_words] 2-bit packed, 16 bases per word, LSB first

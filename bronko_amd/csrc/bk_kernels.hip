@@ -978,8 +978,14 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                 // Cells that are not fast (no cell of a many-genome index is clean): per (position of the mismatch, other base) the
                 // offsets at which the k-mer still takes its own row (IndexView::cell_nat) -- one word for all the k-mers of the range,
                 // bit o <-> cell pr - o
-                if (a.cell_nat && own && pat != (1u << n_own) - 1u && !BK_ABLATE(a, 12))
-                    pat |= (__brev(a.cell_nat[((size_t)(pr + (int32_t)win_lo)) * 3u + alt]) >> (31u - (uint32_t)(pr - ca))) & ((1u << n_own) - 1u);
+                // Without touch lists the bits stand for one V row of their own (cell_natrow: id + offset), whatever cell_blk says.
+                bool by_row = false;
+                uint32_t nat_row = 0u;
+                if (a.cell_nat && own && pat != (1u << n_own) - 1u && !BK_ABLATE(a, 12)) {
+                    const uint32_t nm = (__brev(a.cell_nat[((size_t)(pr + (int32_t)win_lo)) * 3u + alt]) >> (31u - (uint32_t)(pr - ca))) & ((1u << n_own) - 1u);
+                    if (!SPARSE && a.cell_natrow) { pat = nm; by_row = true; nat_row = a.cell_natrow[(size_t)(pr + (int32_t)win_lo)]; }
+                    else pat |= nm;
+                }
                 if (BK_ABLATE(a, 5)) pat = 0u;                                // (5: nothing is settled here)
                 uint32_t used = 0u;   // cells of the range already dealt with
                 while (__ballot(used < n_own)) {
@@ -992,7 +998,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                     // ... are the k-mers [x_lo, x_hi] (a read against the reference meets the cells from the top)
                     const uint32_t x_lo = ofwd ? o_lo + used : o_hi + 1u - used - ln, x_hi = x_lo + ln - 1u;
                     const uint2 ba = blkw[(go ? c0 : 0) >> 6], bz = blkw[(go ? c1 : 0) >> 6];
-                    const bool fast = go && ones && ba.x == bz.x;
+                    const bool fast = go && ones && (by_row || ba.x == bz.x);
                     // of these, [x_lo, xs_hi] hold nothing but t -- an S run -- and [xm_lo, x_hi] also hold the next mismatch
                     const int32_t xs_hi_i = min((int32_t)x_hi, tn - k);
                     const bool has_s = fast && xs_hi_i >= (int32_t)x_lo;
@@ -1007,7 +1013,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_count_kernel(ScanArgs a) {
                         const uint32_t of_hi = ofwd ? tpos : of_first + nm1;
                         const int lo2 = max((int)of_lo, omin), hi2 = min((int)of_hi, omin + span - 1);
                         if (has_s && lo2 <= hi2 && !BK_ABLATE(a, 2)) {
-                            const uint32_t idS = (uint32_t)(ofwd ? c0 : c1) + win_lo + ba.x;   // id of the cell of k-mer x_lo (cell_fast: ids = cell + constant)
+                            const uint32_t idS = by_row ? nat_row - of_first                       // (cell_natrow: id + offset of every k-mer of the run)
+                                                        : (uint32_t)(ofwd ? c0 : c1) + win_lo + ba.x;   // id of the cell of k-mer x_lo (cell_fast: ids = cell + constant)
                             const uint64_t ci = v_row_base(idS + of_first - (uint32_t)omin, alt, ofwd ? 0u : 1u, span) + (uint32_t)(lo2 - omin);
                             if constexpr (SPARSE) {
                                 // the row is touched: noted per block of 64 cells (a bit per row in device memory, looked at and set

@@ -1,7 +1,7 @@
-# The captures of a round's last build that are kept under profiles/ (run on the GPU box: gpurun -- bash tools/final_captures.sh r03_f).
+# The captures of a round's last build that are kept under profiles/ (run on the GPU box: gpurun -- bash tools/final_captures.sh r03_g).
 # Everything lands in gpurun_out/<tag>_*; copy what is to be judged into profiles/ afterwards (tools/README.md).
 cd $GRAFT_REPO_ROOT
-T=${1:-r03_f}
+T=${1:-r03_g}
 bash tools/profile_round.sh $T > gpurun_out/${T}_profile.log 2>&1
 tail -14 gpurun_out/${T}_profile.log
 cp gpurun_out/${T}_pmc_traffic.json profiles/pmc_traffic.json
@@ -20,6 +20,9 @@ python3 tools/ingest_bench.py 2>&1 | tail -3 > gpurun_out/${T}_ingest.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl5 -- python3 bench.py --config 5 --selected-only --in-flight 1 --steps 1 --warmup 1 --samples-per-step 4 --no-cpu-baseline > /dev/null
 python3 tools/sample_timeline.py $(find gpurun_out/tl5 -name "*kernel_trace.csv") > gpurun_out/${T}_config5_selected_only_timeline.txt
+rm -rf gpurun_out/tl5
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl5 -- python3 bench.py --config 5 --in-flight 1 --steps 1 --warmup 1 --samples-per-step 2 --no-cpu-baseline > /dev/null
+python3 tools/sample_timeline.py $(find gpurun_out/tl5 -name "*kernel_trace.csv") > gpurun_out/${T}_config5_timeline.txt
 rm -rf gpurun_out/tl5
 tail -8 gpurun_out/${T}_config5_selected_only_timeline.txt
 cat gpurun_out/${T}_scan_ablate.txt

@@ -18,9 +18,9 @@ python3 tools/trace_overlap.py $(find gpurun_out/prof_$T -name "*kernel_trace.cs
 cp $(find gpurun_out/prof_$T -name "*kernel_stats.csv") gpurun_out/${T}_kernel_stats.csv
 cp $(find gpurun_out/prof_${T}_serial -name "*kernel_stats.csv") gpurun_out/${T}_serial_kernel_stats.csv
 cp $(find gpurun_out/prof_${T}_c3 -name "*kernel_stats.csv") gpurun_out/${T}_config3_serial_kernel_stats.csv
-tail -1 gpurun_out/prof_${T}_bench.log > gpurun_out/${T}_bench_under_rocprof.json
-tail -1 gpurun_out/prof_${T}_serial_bench.log > gpurun_out/${T}_serial_bench_under_rocprof.json
-tail -1 gpurun_out/prof_${T}_c3_bench.log > gpurun_out/${T}_config3_serial_bench_under_rocprof.json
+grep "^{" gpurun_out/prof_${T}_bench.log | tail -1 > gpurun_out/${T}_bench_under_rocprof.json
+grep "^{" gpurun_out/prof_${T}_serial_bench.log | tail -1 > gpurun_out/${T}_serial_bench_under_rocprof.json
+grep "^{" gpurun_out/prof_${T}_c3_bench.log | tail -1 > gpurun_out/${T}_config3_serial_bench_under_rocprof.json
 python3 tools/make_pmc_traffic.py gpurun_out/${T}_pmc_hbm.json gpurun_out/${T}_pmc_sq.json $T > gpurun_out/${T}_pmc_traffic.json
 rm -rf gpurun_out/prof_$T gpurun_out/prof_${T}_serial gpurun_out/prof_${T}_c3 gpurun_out/pmc_${T}_fetch gpurun_out/pmc_${T}_write gpurun_out/pmc_${T}_sq
 cut -c1-400 gpurun_out/${T}_bench_under_rocprof.json

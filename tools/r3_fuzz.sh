@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 {
   echo "tools/fuzz_parity.py, libbronko_hip_testing.so built from sources $(python -c 'import bench; print(bench.source_build_id())')"
-  for seed in 31 32 33; do
+  for seed in ${SEEDS:-31 32 33}; do
     echo "== fuzz_parity.py 1000 $seed"
     python tools/fuzz_parity.py 1000 $seed 2>&1 | tail -4
   done

@@ -114,7 +114,8 @@ def source_build_id():
     """sha256 over the kernel / engine sources the shipped libbronko_hip.so was built from (profiles/pmc_traffic.json carries the
     id it was captured with: a traffic figure of another build is not reported)."""
     h = hashlib.sha256()
-    for rel in ("bronko_amd/csrc/bk_kernels.hip", "bronko_amd/csrc/bk_engine.cpp", "bronko_amd/csrc/bk_device.h", "bronko_amd/csrc/bk_kernels.h"):
+    for rel in ("bronko_amd/csrc/bk_kernels.hip", "bronko_amd/csrc/bk_scan_items.hip", "bronko_amd/csrc/bk_scan_common.h", "bronko_amd/csrc/bk_engine.cpp",
+                "bronko_amd/csrc/bk_device.h", "bronko_amd/csrc/bk_kernels.h"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -438,7 +439,8 @@ def measure(wl, args, dev, dist, steps, warmup, sps=None, eng=None, selected_onl
                                    ("one sample's reads sharded over %d GPUs; RCCL reduce-scatter(sum) of the k-mer counter plane packed to %d-bit "
                                     "elements by the engine, sharded finalize, all-reduce(max / sum) of the pileups" % (world, shard_fin[0].width)) if sharded else
                                    "one sample's reads sharded over %d GPUs; RCCL all-reduce(sum) of the k-mer counter plane" % world)},
-        "roofline": {"bound": "hbm", "kernel": "scan_count_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        # (config 5's index keeps its planes sparse and takes the whole-window scan_count_kernel; everything else the binned scan)
+        "roofline": {"bound": "hbm", "kernel": "scan_count_kernel" if cfg == 5 else "scan_items_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                      "avg_kernel_ms": scan_ms, "launches": kn_solo[0],
                      "measured": "HIP events around the kernel on its launch stream, samples run one at a time on the whole chip after the timed region",

@@ -294,7 +294,18 @@ struct bk_engine {
     DevBuf<uint32_t> id_rest_off, id_rest;
     DevBuf<uint8_t> amb;
     DevBuf<uint16_t> pilots;
-    DevBuf<unsigned int> slabs;             // [n_cus][n_lds_bins] workgroup histograms of the last scan launch
+    DevBuf<unsigned int> slabs;             // [n_cus][n_lds_bins] workgroup histograms of the last scan launch (scan_count_kernel only)
+    // the binned scan (bk_scan_items.hip; dense planes with the window's reference in LDS): the scan workgroups' items and where
+    // each bin's segment starts, the overflow list and its fill
+    bool use_items = false;
+    bk::ItemGeom ig{};
+    DevBuf<unsigned short> items, item_tab;
+    DevBuf<unsigned char> item_ext_n;
+    DevBuf<unsigned int> ov;
+    DevBuf<unsigned long long> ov_n;
+    uint32_t ov_par = 0;                    // parity of the next scan_items launch (which of the two overflow counts it appends to)
+    bool v_clean[2] = {false, false};       // the V part of the mate file's plane is known to be all zero (dense planes between samples)
+    int item_v_mode = -1;                   // testing aid (BK_ITEM_V_MODE): force BinArgs::v_mode
     DevBuf<unsigned int> n_bits, n_any;     // scan -> Level 2: one bit per k-mer of each record of a launch / per record (bk_kernels.h ScanArgs): the N runs; all zero between launches
     DevBuf<unsigned int> l2_bits;           // Level 2's first pass -> its second: the k-mers looked at one by one, same layout
     DevBuf<unsigned int> l2_any;            // ... one bit per record: its row has bits
@@ -448,7 +459,22 @@ static int alloc_sample_state(bk_engine* e) {
     BK_HIP(e->stats.alloc((size_t)2 * e->n_files * 3));
     BK_HIP(e->present.alloc((size_t)2 * e->n_files));
     BK_HIP(e->kstats.alloc(8));
-    BK_HIP(e->slabs.alloc((size_t)e->n_cus * std::max<uint32_t>(e->n_lds_bins, 1)));
+    // the scan: binned (items) when the planes are dense, the window's reference is staged in LDS and the bins are few enough;
+    // else the whole-window difference array of scan_count_kernel with its slabs
+    e->use_items = !e->sparse && e->ref_in_lds && e->W > 0 && e->n_lds_bins > 0 && !test_env("BK_NO_ITEMS") &&
+                   bk::item_geometry(std::min<uint32_t>(e->n_lds_bins, (uint32_t)e->total_cells), e->n_full, e->v_span, &e->ig) &&
+                   bk::items_lds_bytes(e->ig, std::min<uint32_t>(e->n_lds_bins, (uint32_t)e->total_cells)) <= 128u * 1024u;
+    if (e->use_items) {
+        const size_t g = bk::items_max_grid(e->n_cus);
+        BK_HIP(e->items.alloc(g * e->ig.wg_stride + 64));   // (+ 64: bin_count reads whole 16-byte units)
+        BK_HIP(e->item_tab.alloc(g * ((size_t)e->ig.n_ebins + e->ig.n_vbins)));
+        BK_HIP(e->item_ext_n.alloc(g * bk::kItemExtN));
+        BK_HIP(e->ov.alloc((size_t)1 << 20));
+        BK_HIP(e->ov_n.alloc(2));
+        BK_HIP(hipMemset(e->ov_n.p, 0, 2 * sizeof(unsigned long long)));
+    } else {
+        BK_HIP(e->slabs.alloc((size_t)e->n_cus * std::max<uint32_t>(e->n_lds_bins, 1)));
+    }
     if (e->n_files > 1) { BK_HIP(e->win_votes.alloc((size_t)e->n_files)); BK_HIP(e->win_sel.upload(std::vector<uint32_t>(2, 0u))); }
     BK_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
@@ -1607,6 +1633,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     if (int rc = alloc_sample_state(e.get())) return rc;
     BK_HIP(e->d_view.upload(std::vector<bk::IndexView>(1, e->view())));
     if (const char* ab = test_env("BK_SCAN_ABLATE")) e->ablate = atoi(ab);
+    if (const char* vm = test_env("BK_ITEM_V_MODE")) e->item_v_mode = atoi(vm);
     if (const char* ml = test_env("BK_MAX_LAUNCH_RECORDS")) e->max_launch_records = strtoull(ml, nullptr, 10);
     pc.lap("uploads + buffers");
     *out = e.release();
@@ -1629,7 +1656,7 @@ int bk_engine_fork_params(const bk_engine* parent, const bk_params* prm, bk_engi
     e->n_u = p->n_u; e->n_full = p->n_full; e->n_lds_bins = p->n_lds_bins; e->n_prows = p->n_prows;
     e->v_omin = p->v_omin; e->v_span = p->v_span; e->v_off = p->v_off; e->plane_len = p->plane_len;
     e->ref_in_lds = p->ref_in_lds; e->lo_bases = p->lo_bases; e->n_cus = p->n_cus; e->device = p->device;
-    e->file_cell_lo = p->file_cell_lo; e->max_file_cells_idx = p->max_file_cells_idx; e->ablate = p->ablate; e->max_launch_records = p->max_launch_records;
+    e->file_cell_lo = p->file_cell_lo; e->max_file_cells_idx = p->max_file_cells_idx; e->ablate = p->ablate; e->item_v_mode = p->item_v_mode; e->max_launch_records = p->max_launch_records;
     e->half_lo.m = p->half_lo.m; e->half_lo.log2nb = p->half_lo.log2nb; e->half_lo.log2p = p->half_lo.log2p;
     e->half_hi.m = p->half_hi.m; e->half_hi.log2nb = p->half_hi.log2nb; e->half_hi.log2p = p->half_hi.log2p;
     // the index tables are immutable after bk_engine_create: the fork reads the parent's
@@ -1733,6 +1760,7 @@ static int zero_plane_if_stale(bk_engine* e, int mate) {
             e->plane_used[mate] = false;
         }
         e->plane_stale[mate] = false;
+        e->v_clean[mate] = true;   // all zero now: the sample's first bin_count launch stores where it would add
     }
     return BK_OK;
 }
@@ -1828,9 +1856,13 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     // more than keeps Level 2's bitmap below 1 GiB
     a.l2_words = bk::scan_l2_words(stride_words, e->k);
     const uint64_t l2_cap = std::max<uint64_t>(64, ((1ull << 30) / sizeof(unsigned int)) / a.l2_words);
+    if (e->use_items) {
+        a.ig = e->ig; a.items = e->items.p; a.tab = e->item_tab.p; a.ext_n = e->item_ext_n.p; a.ov = e->ov.p; a.ov_n = e->ov_n.p; a.ov_cap = (uint32_t)e->ov.n;
+    }
     for (uint64_t base = 0; base < n;) {
-        const uint32_t grid = bk::scan_grid(n - base, e->n_cus);
+        uint32_t grid = bk::scan_grid(n - base, e->n_cus);
         uint64_t take = std::min<uint64_t>(std::min<uint64_t>(n - base, bk::scan_max_records(grid)), l2_cap);
+        if (e->use_items) take = std::min<uint64_t>(n - base, l2_cap);   // (no 16-bit LDS bins to keep from wrapping)
         if (e->max_launch_records) take = std::min<uint64_t>(take, e->max_launch_records);
         if (e->l2_bits.n < take * a.l2_words || e->l2_diag.n < take) {
             BK_HIP(hipStreamSynchronize(e->stream));
@@ -1847,9 +1879,25 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
         }
         a.l2_bits = e->l2_bits.p; a.l2_diag = e->l2_diag.p; a.l2_any = e->l2_any.p; a.n_bits = e->n_bits.p; a.n_any = e->n_any.p;
         a.rec_base = base; a.n_records = take;
+        if (e->use_items) grid = bk::items_grid(take, e->n_cus);
         {
             bk_engine::Span sp(e, 0);
-            BK_HIP(bk::launch_scan_count(a, grid, e->stream));
+            if (e->use_items) { a.ov_par = e->ov_par; BK_HIP(bk::launch_scan_items(a, grid, e->stream)); }
+            else BK_HIP(bk::launch_scan_count(a, grid, e->stream));
+        }
+        if (e->use_items) {
+            bk_engine::Span sp(e, 3);
+            // the scan's items, bin by bin -> u64 plane (before nbatch / level2 add to it: a sample's first launch finds the V part all zero)
+            bk::BinArgs b{};
+            b.ig = e->ig; b.items = e->items.p; b.tab = e->item_tab.p; b.ext_n = e->item_ext_n.p; b.n_wg = grid; b.ov = e->ov.p; b.ov_n = e->ov_n.p; b.ov_cap = (uint32_t)e->ov.n;
+            b.ov_par = e->ov_par; e->ov_par ^= 1u;
+            b.id_at = e->id_at.p; b.cell_codes = e->cell_codes.p + bk::scan_ref_pad_words(); b.win_lo = a.win_lo; b.win_dev = a.win_dev;
+            b.total_cells = (uint32_t)e->total_cells; b.counters = e->counters[mate].p; b.v_off = e->v_off;
+            b.v_real_len = bk::v_real_len(e->n_full, e->v_span); b.rl = (uint32_t)e->v_span + 1u;
+            b.v_mode = e->item_v_mode >= 0 ? e->item_v_mode : (e->v_clean[mate] ? 2 : 1);
+            e->v_clean[mate] = false;
+            if (const char* ba = test_env("BK_BIN_ABLATE")) b.ablate = atoi(ba);
+            BK_HIP(bk::launch_bin_count(b, e->stream));
         }
         if (e->W > 0) {
             bk_engine::Span sp(e, 3);
@@ -1870,11 +1918,13 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
                 BK_HIP(hipMemsetAsync(e->n_any.p, 0, e->n_any.n * sizeof(unsigned int), e->stream));
             }
             else BK_HIP(bk::launch_level2(a, e->n_cus, e->stream));
-            // per-cell bin slabs -> u64 plane
-            bk::FoldArgs f{};
-            f.slabs = e->slabs.p; f.n_slabs = grid; f.n_lds_bins = e->n_lds_bins; f.id_at = e->id_at.p; f.cell_codes = e->cell_codes.p + bk::scan_ref_pad_words(); f.win_lo = a.win_lo; f.win_dev = a.win_dev; f.touch_e = a.touch_e;
-            f.counters = e->counters[mate].p;
-            bk::launch_fold(f, e->stream);
+            if (!e->use_items) {
+                // per-cell bin slabs -> u64 plane
+                bk::FoldArgs f{};
+                f.slabs = e->slabs.p; f.n_slabs = grid; f.n_lds_bins = e->n_lds_bins; f.id_at = e->id_at.p; f.cell_codes = e->cell_codes.p + bk::scan_ref_pad_words(); f.win_lo = a.win_lo; f.win_dev = a.win_dev; f.touch_e = a.touch_e;
+                f.counters = e->counters[mate].p;
+                bk::launch_fold(f, e->stream);
+            }
         }
         base += take;
     }

@@ -7,6 +7,32 @@
 
 namespace bk {
 
+// The binned scan (bk_scan_items.hip).  scan_items_kernel settles the reads exactly as scan_count_kernel does, but instead of adding
+// to a whole-genome difference array in LDS (slabs, fold) and to the V plane with global atomics it EMITS what it would have
+// added as 16-bit items, grouped by region of the reference:
+//   E item  a run of n <= 255 consecutive cells each seen once more, in the bin of 128 window cells its first cell lies in:
+//           bits 0-6 first cell & 127, bits 7-14 n - 1 (never 255: 0xffff is the null item), bit 15 the read runs against the reference
+//   V item  +1 / -1 at one counter of the V part of the plane, in the bin of (1 << vq_log2) row positions q it lies in:
+//           bits 0-14 offset of the counter from the bin's first, bit 15 = -1
+// A workgroup collects its items per bin in LDS buckets (cap_e / cap_v items; a bin that outgrows its bucket -- the V rows of a
+// sample's true variants, a coverage spike -- gets one of kItemExtN extension buckets of kItemExtCap items) and writes the buckets
+// out when it ends: items[wg][bucket slots ... | extension slots ...], tab[wg][bin] = items in the bin's bucket | (extension + 1) << 8,
+// ext_n[wg][extension] = items there.  bin_count_kernel, one workgroup per bin, adds them up in LDS (a 2 x 384-cell difference
+// array or the bin's V rows) and adds what is not zero to the plane: no slab, no fold, no same-address global atomic.  An item
+// that finds no room at all goes to a device-wide overflow list (bin << 16 | item) every bin's workgroup looks through, and
+// past that list's end to the plane directly.
+struct ItemGeom {
+    uint32_t n_ebins, n_vbins;      // bins [0, n_ebins) are E bins, [n_ebins, n_ebins + n_vbins) V bins; at most 2 * 1024 in all
+    uint32_t cap_e, cap_v;          // multiples of 8, <= 64
+    uint32_t vq_log2;               // V bin = rows of 1 << vq_log2 positions q: (6 << vq_log2) * (v_span + 1) <= 32767 counters
+    uint32_t wg_items;              // = n_ebins * cap_e + n_vbins * cap_v: bucket slots of one workgroup
+    uint32_t wg_stride;             // = wg_items + kItemExtN * kItemExtCap: u16 items of one workgroup's region
+};
+constexpr uint32_t kEBinLog2 = 7;   // E bins of 128 cells
+constexpr uint32_t kERunMax = 255;  // cells one E item covers at most
+constexpr uint32_t kEBinSpan = (1u << kEBinLog2) + kERunMax;   // cells an E bin's items reach from its first: 383 (the difference array has one more)
+constexpr uint32_t kItemExtN = 96, kItemExtCap = 64;
+
 struct ScanArgs {
     const IndexView* ixp;           // device copy of the index view: only the rare paths of scan_count read it
     // what the hot path needs (kept in kernel-argument registers)
@@ -69,6 +95,16 @@ struct ScanArgs {
     unsigned int* touch_p;          // [n_prows / 32 + 1]     bit per pseudo k-mer row (8 counters)
     unsigned int* touch_e;          // [n_u / 32 + 1]         bit per id (its two E counters)
     unsigned long long rl_recip;    // ceil(2^64 / (v_span + 1)): counter index -> row by __umul64hi
+    // the binned scan (launch_scan_items): where the items go
+    ItemGeom ig;
+    unsigned short* items;          // [grid][ig.wg_stride]
+    unsigned short* tab;            // [grid][n_bins]
+    unsigned char* ext_n;           // [grid][kItemExtN]
+    unsigned int* ov;               // [ov_cap] overflow list
+    unsigned long long* ov_n;       // [2] entries appended by the launches of even / odd parity (may run past ov_cap: those went to the
+    uint32_t ov_cap;                //     plane); bin_count_kernel zeroes the other parity's for the next launch
+    uint32_t ov_par;
+    uint32_t stage_off;             // set by launch_scan_items: byte offset of the waves' record buffers in LDS (0: records are read from memory)
     int ablate;                     // measurement aid (-DBK_TESTING build only): 1 = Level 1 only, 2 = no V atomics, 3 = no slow path
     unsigned long long* dbg;        // -DBK_TESTING build, BK_L2_STATS=1: [32] tallies of what is left to Level 2 and why; null otherwise
 };
@@ -160,6 +196,34 @@ size_t scan_lds_bytes(uint32_t n_lds_bins, bool ref_in_lds, uint32_t total_cells
 hipError_t launch_level2(const ScanArgs& a, int n_cus, hipStream_t stream);   // after launch_scan_count, same arguments
 hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t stream);
 void launch_fold(const FoldArgs& f, hipStream_t stream);
+// ---- the binned scan (bk_scan_items.hip) ----
+struct BinArgs {
+    ItemGeom ig;
+    const unsigned short* items;    // as ScanArgs
+    const unsigned short* tab;
+    const unsigned char* ext_n;
+    uint32_t n_wg;                  // grid of the scan_items launch
+    const unsigned int* ov;
+    unsigned long long* ov_n;
+    uint32_t ov_cap, ov_par;
+    const uint32_t* id_at;          // cell -> id
+    const uint32_t* cell_codes;     // IndexView::cell_codes past its front padding: symbol 0 = cell 0
+    uint32_t win_lo;                // window cell i is cell win_lo + i
+    const uint32_t* win_dev;        // ... or {win_file, win_lo} chosen on the device
+    uint32_t total_cells;
+    unsigned long long* counters;   // the plane
+    uint64_t v_off, v_real_len;     // its V part (the reference k-mers' rows)
+    uint32_t rl;                    // v_span + 1
+    int v_mode;                     // how a V bin reaches the plane: 0 atomics, 1 plain read-modify-write, 2 plain stores (the V part is all zero)
+    int ablate;                     // measurement aid (-DBK_TESTING build only): 1 no items read, 2 nothing written to the plane, 3 no E atomics, 4 no V writes
+};
+// can this index take the binned scan (window of win_cells cells in LDS, dense planes)?  Fills g.
+bool item_geometry(uint32_t win_cells, uint32_t n_full, int v_span, ItemGeom* g);
+uint32_t items_grid(uint64_t n_records, int n_cus);
+uint32_t items_max_grid(int n_cus);
+size_t items_lds_bytes(const ItemGeom& g, uint32_t win_cells);
+hipError_t launch_scan_items(const ScanArgs& a, uint32_t grid, hipStream_t stream);
+hipError_t launch_bin_count(const BinArgs& b, hipStream_t stream);
 void launch_ktab_stats(const unsigned long long* keys, const unsigned int* cnt, uint32_t log2n, unsigned long long ci,
                        unsigned long long cx, unsigned long long* out, hipStream_t stream);
 void launch_ktab_rehash(const unsigned long long* okeys, const unsigned int* ocnt, uint32_t olog2, unsigned long long* nkeys, unsigned int* ncnt,

@@ -28,20 +28,10 @@
 
 #include "bk_device.h"
 #include "bk_kernels.h"
+#include "bk_scan_common.h"
 
 namespace bk {
 
-// Measurement aids (ScanArgs::ablate) exist in the -DBK_TESTING build only; in the release library the tests fold away.
-#ifdef BK_TESTING
-#define BK_ABLATE(a, x) ((a).ablate == (x))
-// BK_L2_STATS tallies (ScanArgs::dbg): k-mers marked by the scan [0] without a diagonal, [1] at a dirty / id-breaking head,
-// [2] mismatch-free head, [3] close pairs; Level 2: [4] k-mers looked at, [5] single-k-mer S runs, [6] dropped as dead,
-// [7] queued for the slow pipeline, [8] ... reference k-mers after all, [9] ... a neighbour found, [10] ... nothing; [11] chunks
-#define BK_DBG(a, idx, pred, cnt) do { if ((a).dbg && (pred)) atomicAdd((a).dbg + (idx), (unsigned long long)(cnt)); } while (0)
-#else
-#define BK_ABLATE(a, x) false
-#define BK_DBG(a, idx, pred, cnt) do { } while (0)
-#endif
 
 __device__ __forceinline__ int probe_table(const TableSlot* __restrict__ sub, uint32_t log2s, uint64_t key) {
     const uint32_t smask = (1u << log2s) - 1u;
@@ -259,7 +249,6 @@ __device__ __forceinline__ void ktab_insert(const KmerTable& t, uint64_t c, uint
     ktab_insert_key(t, c | ((unsigned long long)isrc << 63) | ((unsigned long long)t.mate << 62), n);
 }
 
-__device__ __forceinline__ uint32_t lane_prefix(unsigned long long m);   // (set bits of m below this lane; defined with the scan's helpers)
 // ---- the statistics tables of ranks that shared one sample's reads (full_kmer_stats with a sharded finalize) ----------------
 // A k-mer that touches no window bucket sits in the table of every rank whose reads held it; the sample's "unique k-mers" /
 // "unique counted k-mers" (call.rs:1190-1199) need each k-mer once with its total count.  Every key has one owner rank (a hash
@@ -431,11 +420,6 @@ constexpr int kScanBlock = 1024;
 constexpr int kScanWaves = kScanBlock / 64;
 constexpr int kNIters = 8;                  // mismatches of a piece the N batch (level2_kernel) resolves in one pass
 constexpr uint32_t kMaxRecordsPerGroup = 16384;
-constexpr int kSeeds = 4;
-constexpr int kRefPadWords = 4;             // words of padding in front of the 2-bit per-cell arrays (64 cells)
-constexpr int kRefBackWords = 6;            // ... and behind them (96 cells)
-constexpr int kBitPadWords = 2;             // the same 64 cells for the 1-bit per-cell arrays
-constexpr int kBitBackWords = 3;
 // A sample's true variants put thousands of reads on the same few V counters -- every read that covers a fixed SNP adds 1 to one
 // and the same counter --, and same-address global atomics serialise at ~12 ns each: 0.02 ms of the kernel on the benchmark's 40
 // variant sites.  So a workgroup keeps the counters it meets a second time in a small LDS table (direct-mapped; a filter of one
@@ -443,47 +427,6 @@ constexpr int kBitBackWords = 3;
 constexpr uint32_t kHotSlots = 256, kSeenWords = 1024, kBlkTouchWords = 32;   // (32 words: 1024 blocks of 64 cells, more than an LDS window holds)
 constexpr size_t kScanLdsFixed = 16 + 64 + 4 * kScanBlock + 4 * (2 * kHotSlots + kSeenWords + kBlkTouchWords) + 8;   // k-mer tally, wave totals of the epilogue, the item owners, the hot counters, alignment of the block entries
 
-// number of set bits of a wave mask below this lane
-__device__ __forceinline__ uint32_t lane_prefix(unsigned long long m) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-// reverse the order of the sixteen 2-bit groups of a word
-__device__ __forceinline__ uint32_t rev2_32(uint32_t x) {
-    const uint32_t t = __builtin_bitreverse32(x);
-    return ((t >> 1) & 0x55555555u) | ((t & 0x55555555u) << 1);
-}
-__device__ __forceinline__ uint64_t rev2_64(uint64_t x) {
-    return ((uint64_t)rev2_32((uint32_t)x) << 32) | rev2_32((uint32_t)(x >> 32));
-}
-// the even bits of a word, packed
-__device__ __forceinline__ uint32_t even_bits(uint32_t x) {
-    x &= 0x55555555u;
-    x = (x | (x >> 1)) & 0x33333333u;
-    x = (x | (x >> 2)) & 0x0f0f0f0fu;
-    x = (x | (x >> 4)) & 0x00ff00ffu;
-    return (x | (x >> 8)) & 0xffffu;
-}
-// 32 consecutive 2-bit symbols starting at symbol `pos` of a packed array (16 per word, LSB first); the caller
-// guarantees words [pos/16, pos/16 + 2] exist
-__device__ __forceinline__ uint64_t symbols_at(const uint32_t* __restrict__ w, int32_t pos) {
-    const int32_t wi = pos >> 4;
-    const uint32_t sh = 2u * ((uint32_t)pos & 15u);
-    const uint32_t w0 = w[wi], w1 = w[wi + 1], w2 = w[wi + 2];
-    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-    return ((uint64_t)hi << 32) | lo;
-}
-// same for a read record: word indices are clamped to the record (symbols beyond its length are never used)
-__device__ __forceinline__ uint64_t read_symbols_at(const uint32_t* __restrict__ w, uint32_t pos, uint32_t last_word) {
-    const uint32_t wi = pos >> 4;
-    const uint32_t sh = 2u * (pos & 15u);
-    const uint32_t w0 = w[min(wi, last_word)], w1 = w[min(wi + 1, last_word)], w2 = w[min(wi + 2, last_word)];
-    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-    return ((uint64_t)hi << 32) | lo;
-}
-// 32 bits of a 1-bit-per-cell array starting at cell `pos`
-__device__ __forceinline__ uint32_t bits32_at(const uint32_t* __restrict__ w, int32_t pos) {
-    return __builtin_amdgcn_alignbit(w[(pos >> 5) + 1], w[pos >> 5], (uint32_t)pos & 31u);
-}
 
 // +1 on "reference k-mer id with base b (forward strand of the reference) at offset o, read in direction d": a
 // single-k-mer run of its V row

@@ -1,0 +1,799 @@
+// bk_scan_items.hip -- the binned scan (K1 of round 4): reads -> 16-bit items grouped by region of the reference -> plane.
+//
+// scan_items_kernel   settles every read exactly as scan_count_kernel (bk_kernels.hip) does -- seeds -> diagonal, mismatch flags 160
+//                     bases at a time, one mismatch per lane, E runs / S runs / marks for nbatch_kernel and level2_kernel -- but
+//                     what that kernel ADDS (two LDS atomics per E run into a whole-genome difference array that pins one
+//                     workgroup to a CU; two global atomics per S run into the V plane) this one EMITS as 16-bit items into small
+//                     per-bin buckets in LDS (bk_kernels.h ItemGeom).  No 117 KB array: three workgroups of eight waves per CU
+//                     instead of one of sixteen, no slab, no prefix sum over the genome, no hot-counter table.
+// bin_count_kernel    one workgroup per bin: the bin's items of every scan workgroup (+ the overflow list) added up in LDS -- an E
+//                     bin in two 384-cell difference arrays (reads along / against the reference), a V bin in the bin's counters --
+//                     and what is not zero added to the u64 plane: E[2 id_at[cell] + orientation] as fold_kernel did, V counters
+//                     one atomic each, neighbouring counters by neighbouring lanes.  Every count of a sample still lands on the
+//                     same counter of the same plane as before: nbatch / level2 / finalize / the sharded transport are untouched.
+// Replaces call.rs:1152-1255 (what KMC does: bin, then count) for the k-mers of reads on the window genome; SURVEY.md 7.2 K1.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+#include "bk_device.h"
+#include "bk_kernels.h"
+#include "bk_scan_common.h"
+
+namespace bk {
+
+constexpr int kItemBlock = 1024;            // one workgroup of 16 waves per CU: the window's reference is staged once per CU
+constexpr int kItemWaves = kItemBlock / 64;
+constexpr int kItemGroupsPerCu = 1;
+constexpr uint32_t kExtLocked = 0xffffffffu, kExtNone = 0xfffffffeu;   // ext_of[bin]: an extension bucket is being assigned / none is left
+constexpr size_t kItemLdsFixed = (4 + 4 + kItemBlock + kItemExtN) * sizeof(unsigned int);   // k-mer tally, extensions handed out, the item owners, the extensions' fills
+constexpr int kBinBlock = 256;
+constexpr uint32_t kStageMaxWords = 12;    // records of up to 192 bases are staged in LDS (48 KB for the workgroup's 16 waves)
+
+// An item that found neither room in its bucket nor in the overflow list: straight to the plane (never lost, never fast).
+__device__ __forceinline__ void item_direct(const ScanArgs& a, uint32_t bin, uint32_t item, uint32_t win_lo) {
+    if (bin < a.ig.n_ebins) {
+        const uint32_t c0 = win_lo + (bin << kEBinLog2) + (item & 127u), n = ((item >> 7) & 255u) + 1u, rev = item >> 15;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t cell = c0 + i;
+            const uint32_t id = a.id_at[cell];
+            const uint32_t rc = ((a.cell_codes[kRefPadWords + (cell >> 4)] >> (2u * (cell & 15u))) & 3u) == 2u ? 1u : 0u;
+            atomicAdd(a.counters + 2 * (size_t)id + (rc ^ rev), 1ull);
+        }
+    } else {
+        const uint64_t at = (uint64_t)(bin - a.ig.n_ebins) * ((6ull << a.ig.vq_log2) * (uint32_t)(a.v_span + 1)) + (item & 0x7fffu);
+        atomicAdd(a.counters + a.v_off + at, (item & 0x8000u) ? ~0ull : 1ull);
+    }
+}
+
+// KT: k as a compile-time constant for the common sizes, 0 = any k.  Dense planes, the window's reference in LDS.
+// STAGED: every wave keeps the 64 records of its tile in LDS and has the NEXT tile's copied there (LDS-DMA: global_load_lds, 16
+// bytes per lane and instruction, no register in between) while it works on this one's mismatches -- a lane reads its record's
+// words from LDS, not at a 40-byte stride from memory, and the chain length -> words -> hash -> seed table is one trip to memory
+// per tile instead of three.  Records of more than kStageMaxWords words (long reads) are read from memory as before.
+template <int KT, bool STAGED>
+__global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned int* block_kmers = reinterpret_cast<unsigned int*>(smem);   // 16 B reserved
+    unsigned int* ext_next = block_kmers + 4;       // [0] extension buckets handed out (16 B reserved)
+    unsigned int* own_all = ext_next + 4;           // [waves][64] which lane owns each of the items of a pass (below)
+    unsigned int* ext_cnt = own_all + kItemBlock;   // [kItemExtN] items put into each extension bucket
+    unsigned int* cnt = ext_cnt + kItemExtN;        // [n_bins] items put into each bucket (may run past its capacity: those went to its extension)
+    const uint32_t n_eb = a.ig.n_ebins, n_bins = n_eb + a.ig.n_vbins, cap_e = a.ig.cap_e, cap_v = a.ig.cap_v;
+    const uint32_t nb_pad = (n_bins + 1u) & ~1u;
+    unsigned int* ext_of = cnt + nb_pad;            // [n_bins] 0 = none, else the bin's extension bucket + 1 (kExtLocked, kExtNone)
+    unsigned short* buck = reinterpret_cast<unsigned short*>(ext_of + nb_pad);   // E bin b: [b * cap_e, + cap_e); V bins behind them, cap_v each; then the extensions
+    unsigned short* ext_buck = buck + a.ig.wg_items;
+    unsigned int* lds_ref = reinterpret_cast<unsigned int*>(smem + ((kItemLdsFixed + (size_t)nb_pad * 8u + (size_t)a.ig.wg_stride * 2u + 7u) & ~(size_t)7u));
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform by construction: tell the compiler
+    unsigned int* const own_s = own_all + wave * 64;
+
+    const uint32_t total = a.total_cells;
+    // the window (a multiple of 64 cells from the start): chosen on the device for a multi-genome index (choose_window_kernel), else
+    // the engine's constant.  Only reads whose cells all lie in it are settled here: front pad, the window's cells, back pad
+    const uint32_t win_lo = a.win_dev ? a.win_dev[1] : a.win_lo;
+    const uint32_t win_file = a.win_dev ? a.win_dev[0] : (uint32_t)a.win_file;
+    const uint32_t lds_cells = min(total - win_lo, a.n_lds_bins);
+    const uint32_t n_refw = kRefPadWords + (lds_cells + 15) / 16 + kRefBackWords;
+    const uint32_t n_bitw = kBitPadWords + (lds_cells + 31) / 32 + kBitBackWords;
+    const uint32_t n_blk = (lds_cells + 63) / 64 + 2;
+    const uint32_t blk_w0 = (n_refw + 2u * n_bitw + 1u) & ~1u;   // (8-byte aligned: lds_ref is)
+    for (uint32_t i = threadIdx.x; i < n_bins; i += kItemBlock) { cnt[i] = 0u; ext_of[i] = 0u; }
+    if (threadIdx.x < kItemExtN) ext_cnt[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) *ext_next = 0u;
+    for (uint32_t i = threadIdx.x; i < n_refw; i += kItemBlock) lds_ref[i] = a.ref_words[(win_lo >> 4) + i];
+    for (uint32_t i = threadIdx.x; i < n_bitw; i += kItemBlock) lds_ref[n_refw + i] = a.cell_fast[(win_lo >> 5) + i];
+    for (uint32_t i = threadIdx.x; i < n_bitw; i += kItemBlock) lds_ref[n_refw + n_bitw + i] = a.cell_clean3[(win_lo >> 5) + i];
+    for (uint32_t i = threadIdx.x; i < 2 * n_blk; i += kItemBlock) lds_ref[blk_w0 + i] = reinterpret_cast<const uint32_t*>(a.cell_blk + (win_lo >> 6))[i];
+    __syncthreads();
+    // symbol / bit 0 is cell win_lo; negative positions down to -64 are readable (padding or earlier cells)
+    const unsigned int* refw1 = lds_ref + kRefPadWords;
+    const unsigned int* fastw = lds_ref + n_refw + kBitPadWords;
+    const unsigned int* c3w = lds_ref + n_refw + n_bitw + kBitPadWords;
+    const uint2* blkw = reinterpret_cast<const uint2*>(lds_ref + blk_w0);   // entry 0 = the block of cell win_lo
+
+    const int k = KT ? KT : a.k;
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull;  // k <= 31
+    const uint32_t km1 = (uint32_t)k - 1u;
+    const int omin = a.v_omin, span = a.v_span;
+    const uint32_t rl = (uint32_t)span + 1u, vq_log2 = a.ig.vq_log2, vqm = (1u << vq_log2) - 1u;
+    const uint32_t v_buck0 = n_eb * cap_e;
+    const uint32_t last_word = a.stride_words - 1u;
+
+    // ---- the sinks: an item into its bin's bucket; a bin that outgrows its bucket gets an extension bucket; what finds no room at
+    // all spills into the device-wide overflow list ----
+    unsigned long long* const ov_n = a.ov_n + a.ov_par;
+    auto spill = [&](uint32_t bin, uint32_t item) {
+        const unsigned long long i = atomicAdd(ov_n, 1ull);
+        if (i < (unsigned long long)a.ov_cap) a.ov[i] = (bin << 16) | item;
+        else item_direct(a, bin, item, win_lo);
+    };
+    auto put_ext = [&](uint32_t bin, uint32_t item) {
+        for (;;) {
+            uint32_t e = __hip_atomic_load(&ext_of[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (e == 0u) {   // the first item past the bucket: whoever swaps the lock in assigns the extension
+                unsigned int expect = 0u;
+                if (!__hip_atomic_compare_exchange_strong(&ext_of[bin], &expect, kExtLocked, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) continue;
+                const uint32_t ne = __hip_atomic_fetch_add(ext_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                e = ne < kItemExtN ? ne + 1u : kExtNone;
+                __hip_atomic_store(&ext_of[bin], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (e == kExtLocked) continue;   // (the lane that holds the lock never waits for anything: it is gone by the next look)
+            if (e == kExtNone) { spill(bin, item); return; }
+            const uint32_t s2 = __hip_atomic_fetch_add(&ext_cnt[e - 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (s2 < kItemExtCap) ext_buck[(e - 1u) * kItemExtCap + s2] = (unsigned short)item; else spill(bin, item);
+            return;
+        }
+    };
+    // cells [c_lo, c_lo + n) (window coordinates) each seen once more by a read along (f) / against the reference
+    auto emit_e = [&](bool on, uint32_t c_lo, uint32_t n, bool f) {
+        uint32_t c = c_lo, left = (on && !BK_ABLATE(a, 14)) ? n : 0u;
+        do {   // (a run of more than 255 cells -- a long read -- goes out in pieces)
+            const uint32_t take = min(left, kERunMax);
+            if (left) {
+                const uint32_t bin = c >> kEBinLog2;
+                const uint32_t item = (c & 127u) | ((take - 1u) << 7) | (f ? 0u : 0x8000u);
+                const uint32_t s = __hip_atomic_fetch_add(&cnt[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (s < cap_e) buck[bin * cap_e + s] = (unsigned short)item; else put_ext(bin, item);
+            }
+            c += take; left -= take;
+        } while (__ballot(left != 0u));
+    };
+
+    uint32_t nkm = 0;  // k-mer occurrences of this lane's records
+    const IndexView& ix = *a.ixp;
+    // k-mers [sk, sk + n) of record `rec` (index within this launch) are an N run left to nbatch_kernel: set their bits (the
+    // record's diagonal goes with the mark: nothing is written for the records without one)
+    auto n_mark = [&](bool on, uint32_t rec, uint32_t sk, uint32_t n, int32_t dgm, uint32_t flm) {
+        if (!on) return;
+        unsigned int* row = a.n_bits + (size_t)rec * a.l2_words;
+        atomicOr(a.n_any + (rec >> 5), 1u << (rec & 31u));
+        a.l2_diag[rec] = make_uint2((uint32_t)dgm, flm);
+        uint32_t w = sk >> 5, bit = sk & 31u, left = n;
+        while (left) {
+            const uint32_t take = min(left, 32u - bit);
+            atomicOr(row + w, (take == 32u ? 0xffffffffu : (1u << take) - 1u) << bit);
+            left -= take; ++w; bit = 0u;
+        }
+    };
+    // ... or, one by one, to level2_kernel (l2_bits): the k-mers that hold two mismatches and cannot be discarded
+    auto l2_mark = [&](bool on, uint32_t rec, uint32_t sk, uint32_t n, int32_t dgm, uint32_t flm) {
+        if (!on) return;
+        unsigned int* row = a.l2_bits + (size_t)rec * a.l2_words;
+        atomicOr(a.l2_any + (rec >> 5), 1u << (rec & 31u));
+        a.l2_diag[rec] = make_uint2((uint32_t)dgm, flm);
+        uint32_t w = sk >> 5, bit = sk & 31u, left = n;
+        while (left) {
+            const uint32_t take = min(left, 32u - bit);
+            atomicOr(row + w, (take == 32u ? 0xffffffffu : (1u << take) - 1u) << bit);
+            left -= take; ++w; bit = 0u;
+        }
+    };
+    const bool stats = a.ktab_keys != nullptr;   // full_kmer_stats: k-mers that touch nothing are still wanted by the statistics table (level2_kernel)
+
+    uint64_t n_records = a.n_records;
+    if (a.n_records_dev) {
+        const uint64_t nd = *a.n_records_dev;
+        n_records = nd > a.rec_base ? min(nd - a.rec_base, a.n_records) : 0ull;
+    }
+    const uint32_t* const words0 = a.words + a.rec_base * a.stride_words;
+    const uint16_t* const lens0 = a.lens + a.rec_base;
+    const uint64_t n_tiles = (n_records + 63) / 64;
+    uint32_t pf_sink = 0;               // destination of the prefetch loads (never read)
+    constexpr uint32_t kNoPos = 0x40000000u;
+    // the seed table of the window's genome, and where the seeds sit: evenly spaced over the launch's first record
+    const uint2* const seed_tab = a.seed_tab ? a.seed_tab + ((size_t)win_file << a.seed_log2) : nullptr;
+    const uint32_t hint_len = n_records ? (uint32_t)__builtin_amdgcn_readfirstlane((int)lens0[0]) : 0u;
+    const uint32_t hint_span = hint_len >= (uint32_t)k ? hint_len - (uint32_t)k : 0u;
+
+    // STAGED: this wave's record buffer, and the copy of a tile into it.  Returns the lane's record length of that tile.
+    const uint32_t sw = a.stride_words;
+    unsigned int* const rec_buf = reinterpret_cast<unsigned int*>(smem + a.stage_off) + (uint32_t)wave * 64u * sw;
+    auto stage = [&](uint64_t t) -> uint32_t {
+        if (t >= n_tiles) return 0u;
+        const uint64_t rr = t * 64 + (uint32_t)lane;
+        const uint32_t ln = rr < n_records ? (uint32_t)lens0[rr] : 0u;
+        if ((t + 1) * 64 <= n_records) {   // (wave-uniform) a whole tile: 64 * sw words, 16 * sw units of 16 bytes
+            const unsigned char* g = reinterpret_cast<const unsigned char*>(words0 + t * 64 * sw);
+            unsigned char* l = reinterpret_cast<unsigned char*>(rec_buf);
+            for (uint32_t u0 = 0; u0 < 16u * sw; u0 += 64u) {
+                const uint32_t u = u0 + (uint32_t)lane;
+                if (u < 16u * sw)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)u * 16u),
+                                                     (__attribute__((address_space(3))) void*)(l + (size_t)u0 * 16u), 16, 0, 0);
+            }
+        } else if (rr < n_records) {       // the launch's last tile: every lane copies its own record
+            const uint32_t* src = words0 + rr * sw;
+            for (uint32_t j = 0; j < sw; ++j) rec_buf[(uint32_t)lane * sw + j] = src[j];
+        }
+        return ln;
+    };
+    uint32_t len_pf = 0u;
+    if constexpr (STAGED) len_pf = stage((uint64_t)blockIdx.x * kItemWaves + wave);
+
+    for (uint64_t tile = (uint64_t)blockIdx.x * kItemWaves + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * kItemWaves) {
+        const uint64_t r = tile * 64 + lane;
+        const uint64_t next_tile = tile + (uint64_t)gridDim.x * kItemWaves;
+        const bool live = r < n_records;
+        const uint32_t r32 = live ? (uint32_t)r : 0u;   // record index within this launch (a launch has < 2^32 records)
+        uint32_t len;
+        if constexpr (STAGED) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the tile's records have landed in the wave's buffer (and its lengths in len_pf)
+            len = len_pf;
+        } else {
+            len = live ? (uint32_t)lens0[r32] : 0u;
+        }
+        if (len < (uint32_t)k) len = 0u;   // no k-mer
+        uint32_t maxlen = len;
+#pragma unroll
+        for (int off = 32; off; off >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, off));
+        maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxlen);
+        const uint32_t* __restrict__ w = STAGED ? rec_buf + (uint32_t)lane * sw : words0 + (uint64_t)r32 * a.stride_words;
+        const uint32_t nk = len ? len - km1 : 0u;   // k-mers of the record
+        nkm += nk;
+        if constexpr (!STAGED) {   // touch the next tile's records (one lane per 128-byte line) so that its seed loads find them in cache
+            const uint64_t nt = next_tile;
+            const uint64_t first = nt * 64ull * a.stride_words, words_tile = 64ull * a.stride_words;
+            const uint64_t at = first + (uint64_t)lane * 32ull;
+            if (nt < n_tiles && (uint64_t)lane * 32ull < words_tile && at < n_records * a.stride_words)
+                asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink) : "v"(words0 + at) : "memory");
+        }
+        if (!maxlen) { if constexpr (STAGED) len_pf = stage(next_tile); continue; }
+
+        // ---- seeds -> diagonal ----------------------------------------------------------------------------------
+        bool fwd = true, seeded = false, l1ok = false;   // seeded: diagonal known; l1ok: ... and all its cells are in the window
+        int32_t dg = 0;                                  // cell of the reference k-mer aligned with read k-mer 0: k-mer s <-> dg + s (fwd) / dg - s
+        // a candidate diagonal: the whole read must lie on the reference (hi_cell + k <= total); to be settled here its cells must lie
+        // in the window and each of them must carry a reference k-mer (no sequence tail in between: cell_blk)
+        uint32_t best_cell = 0xffffffffu;
+        auto candidate = [&](bool hit, uint32_t scell, bool f, uint32_t s) {
+            if (hit && scell < best_cell) {   // several seeds may hit (usually all, on one diagonal); prefer the lowest cell
+                const int64_t d0 = f ? (int64_t)scell - (int64_t)s : (int64_t)scell + (int64_t)s;
+                const int64_t lo_cell = f ? d0 : d0 - (int64_t)(len - (uint32_t)k);
+                const int64_t hi_cell = f ? d0 + (int64_t)(len - (uint32_t)k) : d0;
+                if (lo_cell >= 0 && hi_cell + k <= (int64_t)total) {
+                    best_cell = scell; dg = (int32_t)d0; fwd = f; seeded = true;
+                    l1ok = lo_cell >= (int64_t)win_lo && hi_cell < (int64_t)win_lo + (int64_t)a.n_lds_bins;
+                    if (l1ok) l1ok = (uint32_t)hi_cell < blkw[((uint32_t)lo_cell >> 6) - (win_lo >> 6)].y;
+                }
+            }
+        };
+        // First the seed table of the window's genome (bk_device.h seed_hash): kSeeds k-mers at positions that do not depend on the
+        // read's length (evenly spaced over the launch's first record: the length load and the seeds' word loads go out together),
+        // one 8-byte bucket each, and the candidate it names is verified against the reference in LDS.
+        if (seed_tab && !BK_ABLATE(a, 9) && !BK_ABLATE(a, 11)) {
+            uint64_t sg[kSeeds], sff[kSeeds];
+            uint32_t sh[kSeeds], sis[kSeeds];
+            uint2 sb[kSeeds];
+#pragma unroll
+            for (int sq = 0; sq < kSeeds; ++sq) {
+                const uint32_t s = (hint_span * (uint32_t)sq) / (uint32_t)(kSeeds - 1);   // (wave-uniform)
+                const uint64_t g = read_symbols_at(w, s, last_word) & kmask;       // base t of the k-mer at bits 2t
+                const uint64_t rr = ~g & kmask;                                      // its reverse complement, first base on top
+                const uint64_t ff = rev2_64(g) >> (64 - 2 * k);                      // the k-mer, first base on top
+                const bool lt = ff < rr;                                             // lcb.rs:90-94
+                sg[sq] = g; sff[sq] = ff; sis[sq] = lt ? 0u : 1u;
+                sh[sq] = seed_hash(lt ? ff : rr);
+                sb[sq] = seed_tab[sh[sq] >> (32u - a.seed_log2)];
+            }
+#pragma unroll
+            for (int sq = 0; sq < kSeeds; ++sq) {
+                const uint32_t s = (hint_span * (uint32_t)sq) / (uint32_t)(kSeeds - 1);
+                const uint32_t tag = sh[sq] & 15u;
+                const uint32_t ent = (sb[sq].x != 0xffffffffu && (sb[sq].x >> 28) == tag) ? sb[sq].x : sb[sq].y;
+                const uint32_t cell = ent & ((1u << kSeedCellBits) - 1u), rc = (ent >> kSeedCellBits) & 1u;
+                // in reach of the staged reference?  (the window's cells and 64 in front)
+                const bool in_ref = ent != 0xffffffffu && (ent >> 28) == tag && len != 0u && s + (uint32_t)k <= len &&
+                                    cell + 64u >= win_lo && cell + (uint32_t)k <= win_lo + lds_cells;
+                const int32_t cw = in_ref ? (int32_t)cell - (int32_t)win_lo : 0;
+                const uint64_t ref = symbols_at(refw1, cw) & kmask;                  // reference base cell + t at bits 2t
+                const bool same = sis[sq] == rc;                                     // same strand as the reference?
+                candidate(in_ref && ref == (same ? sg[sq] : (~sff[sq] & kmask)), cell, same, s);
+            }
+        }
+        // The lanes that are still without a diagonal (an error in every seed, a k-mer that found its bucket full, a read shorter
+        // than the first record, no seed table): the perfect hash of U, two rounds (scan_count_kernel has the why).
+        for (int round = 0; round < 2 && !BK_ABLATE(a, 9); ++round) {   // (9: no seeds at all, 7: nothing behind them, 6: no mismatch loop)
+            if (!__ballot(len != 0u && !seeded)) break;
+            const bool had = seeded;   // a round is for the lanes left without a diagonal so far
+            uint64_t sc[kSeeds];
+            uint32_t sisrc[kSeeds], spil[kSeeds], spos[kSeeds];
+#pragma unroll
+            for (int sq = 0; sq < kSeeds; ++sq) {
+                const uint32_t span_k = len ? len - (uint32_t)k : 0u;
+                const uint32_t s = round == 0 ? (span_k * (uint32_t)sq) / (uint32_t)(kSeeds - 1)
+                                              : (span_k * (uint32_t)(2 * sq + 1)) / (uint32_t)(2 * kSeeds);
+                spos[sq] = s;
+                const uint64_t g = read_symbols_at(w, s, last_word) & kmask;
+                const uint64_t rr = ~g & kmask;
+                const uint64_t ff = rev2_64(g) >> (64 - 2 * k);
+                const bool lt = ff < rr;                                             // lcb.rs:90-94
+                sc[sq] = lt ? ff : rr;
+                sisrc[sq] = lt ? 0u : 1u;
+                spil[sq] = ix.pilots[phf_bucket(sc[sq], ix.log2nb)];
+            }
+            uint4 se[kSeeds];
+#pragma unroll
+            for (int sq = 0; sq < kSeeds; ++sq) se[sq] = *reinterpret_cast<const uint4*>(ix.kmer_pos + phf_pos(sc[sq], spil[sq], ix.m, ix.log2nb, ix.log2p));
+            bool shit[kSeeds];
+            uint32_t soc[kSeeds];
+#pragma unroll
+            for (int sq = 0; sq < kSeeds; ++sq) {
+                shit[sq] = len && !had && ((uint64_t)se[sq].x | ((uint64_t)se[sq].y << 32)) == sc[sq];
+                soc[sq] = 0xffffffffu;
+                if (a.occ && shit[sq] && (se[sq].w & kIdMask) < ix.n_full)
+                    soc[sq] = a.occ[(size_t)(se[sq].w & kIdMask) * (uint32_t)a.n_files + win_file];
+            }
+#pragma unroll
+            for (int sq = 0; sq < kSeeds; ++sq) {
+                uint32_t scell = se[sq].z, src_rc = se[sq].w >> 31;   // where the seed sits: the k-mer's first occurrence ...
+                if (soc[sq] != 0xffffffffu) { scell = soc[sq] & 0x7fffffffu; src_rc = soc[sq] >> 31; }   // ... or its occurrence in the window's genome
+                candidate(shit[sq], scell, sisrc[sq] == src_rc, spos[sq]);
+            }
+        }
+        const uint32_t dfl = (fwd ? 1u : 0u) | (seeded ? 2u : 0u);
+        if (BK_ABLATE(a, 9) || BK_ABLATE(a, 7)) { if constexpr (STAGED) len_pf = stage(next_tile); continue; }
+        // a read that cannot be settled here is one N run
+        n_mark(nk != 0u && !l1ok, r32, 0u, nk, dg, dfl);
+
+        // ---- mismatch flags, 160 bases at a time; mismatch by mismatch --------------------------------------------------
+        const int32_t dgw = dg - (int32_t)win_lo;   // the diagonal in window coordinates
+        // mismatch flags of bases [i0, i0 + 32) (i0 a multiple of 32): read words vs the reference words aligned with them
+        auto mism32 = [&](uint32_t i0) -> uint32_t {
+            const bool act = l1ok && i0 < len;
+            const uint32_t wi = i0 >> 4;
+            const uint32_t x0 = w[min(wi, last_word)], x1 = w[min(wi + 1u, last_word)];
+            const int32_t p0 = act ? (fwd ? dgw + (int32_t)i0 : dgw + (int32_t)km1 - (int32_t)i0 - 31) : 0;
+            const uint32_t sh = 2u * ((uint32_t)p0 & 15u);
+            const uint32_t r0 = refw1[p0 >> 4], r1 = refw1[(p0 >> 4) + 1], r2 = refw1[(p0 >> 4) + 2];
+            const uint32_t ya = __builtin_amdgcn_alignbit(r1, r0, sh), yb = __builtin_amdgcn_alignbit(r2, r1, sh);   // 32 reference bases, rising
+            // against the reference: read base i0 + t <-> complement of reference base p0 + 31 - t
+            const uint32_t d0 = x0 ^ (fwd ? ya : ~rev2_32(yb)), d1 = x1 ^ (fwd ? yb : ~rev2_32(ya));
+            const uint32_t m = even_bits(d0 | (d0 >> 1)) | (even_bits(d1 | (d1 >> 1)) << 16);
+            const uint32_t hi = len > i0 ? min(len - i0, 32u) : 0u;   // bases of the record in these words
+            return act ? m & (hi >= 32u ? 0xffffffffu : (1u << hi) - 1u) : 0u;
+        };
+        unsigned long long M01 = 0ull, M23 = 0ull;   // flags of the chunk's bases 0..63, 64..127
+        uint32_t M4 = 0u;                            // ... 128..159
+        int32_t tp = -0x20000000;    // the lane's last resolved mismatch (absolute base), far away before the first
+        auto peek3 = [&](unsigned long long m01, unsigned long long m23, uint32_t m4) -> uint32_t {   // lowest flag of the chunk
+            return m01 ? (uint32_t)__builtin_ctzll(m01) : m23 ? 64u + (uint32_t)__builtin_ctzll(m23) : m4 ? 128u + (uint32_t)__builtin_ctz(m4) : kNoPos;
+        };
+        auto pop3 = [&](unsigned long long& m01, unsigned long long& m23, uint32_t& m4) {   // ... taken off
+            const bool z01 = m01 == 0ull, z23 = m23 == 0ull;
+            m4 = (z01 && z23) ? m4 & (m4 - 1u) : m4;
+            m23 = z01 ? m23 & (m23 - 1ull) : m23;
+            m01 &= m01 - 1ull;
+        };
+        for (uint32_t cb = 0;; cb += 128u) {   // (wave-uniform) the chunk covers bases [cb, cb + 160); its first word is carried over
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                if (cb != 0u && j == 0) continue;
+                const uint32_t f = mism32(cb + 32u * (uint32_t)j);
+                if (j == 0) M01 |= (unsigned long long)f; else if (j == 1) M01 |= (unsigned long long)f << 32;
+                else if (j == 2) M23 |= (unsigned long long)f; else if (j == 3) M23 |= (unsigned long long)f << 32;
+                else M4 = f;
+            }
+            const uint32_t scanned = cb + 160u;
+            if constexpr (STAGED) {
+                // the record's words are all read (the pass below takes the base at a mismatch from memory): the wave's next tile on its way
+                if (scanned >= maxlen) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); len_pf = stage(next_tile); }
+            }
+            // A mismatch is resolved once the k - 1 bases behind it are scanned (or the read ends): that far reach the k-mers that
+            // hold it, and whatever they hold of its successors is then known.  What is not resolved lies in the chunk's last
+            // word (k <= 31): the word that is carried over.
+            const bool all_res = scanned >= len;
+            const uint32_t r4 = all_res ? M4 : M4 & ((1u << (32u - km1)) - 1u);   // (flags 128 .. 159 - (k - 1); words 0..3 are always resolved)
+            if (BK_ABLATE(a, 6)) { M01 = 0ull; M23 = 0ull; M4 = 0u; }
+            // ---- one mismatch per lane: the tile's resolved mismatches are dealt out over the wave ----
+            const uint32_t cnt_m = BK_ABLATE(a, 6) ? 0u : (uint32_t)__popcll(M01) + (uint32_t)__popcll(M23) + (uint32_t)__popc(r4);
+            uint32_t pin = cnt_m;   // inclusive prefix sum over the lanes
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)pin, off); if (lane >= off) pin += x; }
+            const uint32_t pex = pin - cnt_m;
+            const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)pin, 63));
+            for (uint32_t it0 = 0; it0 < n_items; it0 += 64u) {
+                // owner of item it0 + lane: every lane with items writes its number where its first item of this pass sits, a running
+                // maximum spreads it over the items behind
+                own_s[lane] = 0u;
+                __builtin_amdgcn_wave_barrier();
+                if (cnt_m && pin > it0 && pex < it0 + 64u) own_s[pex > it0 ? pex - it0 : 0u] = (uint32_t)lane;
+                __builtin_amdgcn_wave_barrier();
+                uint32_t ow = own_s[lane];
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)ow, off); if (lane >= off) ow = max(ow, x); }
+                const bool on = it0 + (uint32_t)lane < n_items;
+                const int src = on ? (int)ow : lane;
+                // the owner's read: flags, diagonal, length, record, last mismatch before this chunk's
+                unsigned long long m01 = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(M01 >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)M01, src);
+                unsigned long long m23 = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(M23 >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)M23, src);
+                uint32_t m4 = (uint32_t)__shfl((int)M4, src);
+                const int32_t o_dgw = __shfl(dgw, src);
+                const uint32_t o_fl = (uint32_t)__shfl((int)dfl, src);
+                const uint32_t o_nk = (uint32_t)__shfl((int)nk, src);
+                const uint32_t o_rec = (uint32_t)__shfl((int)r32, src);
+                int32_t tq = __shfl(tp, src);                      // becomes the mismatch before mine
+                const uint32_t o_pex = (uint32_t)__shfl((int)pex, src);   // (every shuffle outside the conditions: a lane that is off may be another's owner)
+                uint32_t jj = on ? it0 + (uint32_t)lane - o_pex : 0u;   // mine is the owner's jj-th of this chunk
+                while (__ballot(jj != 0u)) {
+                    if (jj) { tq = (int32_t)(cb + peek3(m01, m23, m4)); pop3(m01, m23, m4); --jj; }
+                }
+                const bool ofwd = o_fl & 1u;
+                const int32_t t = on ? (int32_t)(cb + peek3(m01, m23, m4)) : 0;
+                pop3(m01, m23, m4);
+                const uint32_t nb = peek3(m01, m23, m4);
+                const int32_t tn = (on && nb != kNoPos) ? (int32_t)(cb + nb) : 0x20000000;   // (an unseen one is out of reach)
+                pop3(m01, m23, m4);
+                const uint32_t nb2 = peek3(m01, m23, m4);
+                const int32_t tn2 = (on && nb2 != kNoPos) ? (int32_t)(cb + nb2) : 0x20000000;
+                // The k-mers between the previous mismatch and this one hold none: an E run (they start behind the previous one and
+                // end before this one)
+                const uint32_t done = tq < 0 ? 0u : min((uint32_t)tq, o_nk - 1u) + 1u;
+                {
+                    const bool eg = on && t >= k && (uint32_t)(t - k) >= done && done < o_nk;
+                    const uint32_t g_hi = min((uint32_t)(t - k), o_nk - 1u);
+                    emit_e(eg, (uint32_t)(ofwd ? o_dgw + (int32_t)done : o_dgw - (int32_t)g_hi), g_hi - done + 1u, ofwd);
+                }
+                // The k-mers whose FIRST mismatch is t: they start behind the previous one and hold t.  Every k-mer that holds a
+                // mismatch belongs to exactly one such range.
+                const uint32_t o_lo = (uint32_t)max(max(t - (int32_t)km1, tq + 1), 0), o_hi = min((uint32_t)t, o_nk - 1u);
+                const bool own = on && o_lo <= o_hi;
+                // Their cells, lowest first (window coordinates), and which of them are "fast" (clean, ids = cell + one constant).
+                const int32_t ca = own ? (ofwd ? o_dgw + (int32_t)o_lo : o_dgw - (int32_t)o_hi) : 0;
+                const uint32_t n_own = own ? o_hi - o_lo + 1u : 0u;           // (at most k <= 31)
+                uint32_t pat = bits32_at(fastw, ca) & ((1u << n_own) - 1u);   // bit p: the cell ca + p is fast
+                // which of the three other bases: read XOR reference at the mismatch, the same on either strand (bk_device.h)
+                const uint32_t tt = own ? (uint32_t)t : 0u;
+                const uint32_t rw = (words0 + (uint64_t)o_rec * a.stride_words)[min(tt >> 4, last_word)];
+                const int32_t pr = own ? (ofwd ? o_dgw + (int32_t)tt : o_dgw + (int32_t)km1 - (int32_t)tt) : 0;
+                const uint32_t refb = (refw1[pr >> 4] >> (2u * ((uint32_t)pr & 15u))) & 3u;
+                const uint32_t alt = ((((rw >> (2u * (tt & 15u))) & 3u) ^ (ofwd ? refb : 3u - refb)) & 3u) - 1u;
+                // Cells that are not fast: per (position of the mismatch, other base) the offsets at which the k-mer still takes its own
+                // row (IndexView::cell_nat); with cell_natrow the bits stand for one V row of their own, whatever cell_blk says.
+                bool by_row = false;
+                uint32_t nat_row = 0u;
+                if (a.cell_nat && own && pat != (1u << n_own) - 1u && !BK_ABLATE(a, 12)) {
+                    const uint32_t nm = (__brev(a.cell_nat[((size_t)(pr + (int32_t)win_lo)) * 3u + alt]) >> (31u - (uint32_t)(pr - ca))) & ((1u << n_own) - 1u);
+                    if (a.cell_natrow) { pat = nm; by_row = true; nat_row = a.cell_natrow[(size_t)(pr + (int32_t)win_lo)]; }
+                    else pat |= nm;
+                }
+                if (BK_ABLATE(a, 5)) pat = 0u;                                // (5: nothing is settled here)
+                uint32_t used = 0u;   // cells of the range already dealt with
+                while (__ballot(used < n_own)) {
+                    const bool go = used < n_own;
+                    const uint32_t rest = pat >> used;
+                    const bool ones = rest & 1u;
+                    // the stretch of equal bits at `used`: cells ca + used .. ca + used + ln - 1
+                    const uint32_t ln = go ? min((uint32_t)__builtin_ctz((ones ? ~rest : rest) | (1u << (n_own - used))), n_own - used) : 0u;
+                    const int32_t c0 = ca + (int32_t)used, c1 = c0 + (int32_t)ln - 1;
+                    // ... are the k-mers [x_lo, x_hi] (a read against the reference meets the cells from the top)
+                    const uint32_t x_lo = ofwd ? o_lo + used : o_hi + 1u - used - ln, x_hi = x_lo + ln - 1u;
+                    const uint2 ba = blkw[(go ? c0 : 0) >> 6], bz = blkw[(go ? c1 : 0) >> 6];
+                    const bool fast = go && ones && (by_row || ba.x == bz.x);
+                    // of these, [x_lo, xs_hi] hold nothing but t -- an S run -- and [xm_lo, x_hi] also hold the next mismatch
+                    const int32_t xs_hi_i = min((int32_t)x_hi, tn - k);
+                    const bool has_s = fast && xs_hi_i >= (int32_t)x_lo;
+                    const uint32_t xs_hi = has_s ? (uint32_t)xs_hi_i : x_lo;
+                    const uint32_t xm_lo = (uint32_t)max((int32_t)x_lo, tn - (int32_t)km1);
+                    const bool has_m = fast && xm_lo <= x_hi;
+                    {
+                        const uint32_t tpos = tt - x_lo, nm1 = xs_hi - x_lo;   // offset of the differing base in the run's first k-mer
+                        // offsets (along the reference, from each k-mer's start) the run's k-mers have the difference at
+                        const uint32_t of_first = ofwd ? tpos : km1 - tpos;
+                        const uint32_t of_lo = ofwd ? tpos - nm1 : of_first;       // fwd: later k-mers start later, the offset shrinks
+                        const uint32_t of_hi = ofwd ? tpos : of_first + nm1;
+                        const int lo2 = max((int)of_lo, omin), hi2 = min((int)of_hi, omin + span - 1);
+                        if (has_s && lo2 <= hi2 && !BK_ABLATE(a, 2) && !BK_ABLATE(a, 14)) {
+                            const uint32_t idS = by_row ? nat_row - of_first                       // (cell_natrow: id + offset of every k-mer of the run)
+                                                        : (uint32_t)(ofwd ? c0 : c1) + win_lo + ba.x;   // id of the cell of k-mer x_lo (cell_fast: ids = cell + constant)
+                            // one row of the V plane: +1 at the first offset, -1 after the last (slot `span` is never read) -- two items
+                            // of the row's bin (rows never straddle bins)
+                            const uint32_t q = idS + of_first - (uint32_t)omin;
+                            const uint32_t bin = n_eb + (q >> vq_log2);
+                            const uint32_t o0 = (((q & vqm) * 3u + alt) * 2u + (ofwd ? 0u : 1u)) * rl + (uint32_t)(lo2 - omin);
+                            const bool tail = hi2 - omin + 1 < span;
+                            const uint32_t s = __hip_atomic_fetch_add(&cnt[bin], tail ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            unsigned short* const bk = buck + v_buck0 + (bin - n_eb) * cap_v;
+                            if (s < cap_v) bk[s] = (unsigned short)o0; else put_ext(bin, o0);
+                            if (tail) {
+                                const uint32_t o1 = (o0 + (uint32_t)(hi2 - lo2 + 1)) | 0x8000u;
+                                if (s + 1u < cap_v) bk[s + 1u] = (unsigned short)o1; else put_ext(bin, o1);
+                            }
+                        }
+                    }
+                    {
+                        // The k-mers that hold t and its successor.  If none of them reaches the successor after that and each of their
+                        // cells has no other reference k-mer form within Hamming distance 3, they hold exactly two differences from a
+                        // reference k-mer that is isolated up to distance 3: neither a reference k-mer nor one base away from one
+                        // (triangle inequality) -- they touch nothing.  Otherwise level2_kernel looks at them one by one.
+                        const int32_t ma = has_m ? (ofwd ? o_dgw + (int32_t)xm_lo : o_dgw - (int32_t)x_hi) : 0;
+                        const uint32_t needm = has_m ? 0xffffffffu >> (31u - (x_hi - xm_lo)) : 0u;
+                        const bool dead = !stats && tn2 - (int32_t)km1 > (int32_t)x_hi && (bits32_at(c3w, ma) & needm) == needm;
+                        l2_mark(has_m && !dead, o_rec, xm_lo, x_hi + 1u - xm_lo, o_dgw + (int32_t)win_lo, o_fl);
+                    }
+                    // cells that are not fast
+                    l2_mark(go && !fast, o_rec, x_lo, ln, o_dgw + (int32_t)win_lo, o_fl);
+                    used += ln;
+                }
+            }
+            // each lane: its last resolved mismatch; what is not resolved stays
+            if (cnt_m) tp = (int32_t)cb + (r4 ? 159 - (int32_t)__builtin_clz(r4) : M23 ? 127 - (int32_t)__builtin_clzll(M23) : 63 - (int32_t)__builtin_clzll(M01));
+            if (scanned >= maxlen) break;
+            M01 = (unsigned long long)(M4 & ~r4); M23 = 0ull; M4 = 0u;   // the next chunk starts 128 bases on
+        }
+        {   // behind the last mismatch: k-mers [done, nk - 1]
+            const uint32_t done = tp < 0 ? 0u : min((uint32_t)tp, nk - 1u) + 1u;
+            const bool eg = l1ok && done < nk;
+            emit_e(eg, (uint32_t)(fwd ? dgw + (int32_t)done : dgw - (int32_t)(nk - 1u)), nk - done, fwd);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(pf_sink) : "memory");   // the prefetch register stays reserved up to here
+
+    // ---- the buckets, as they are, into this workgroup's region (a wave per bucket: neighbouring lanes, neighbouring items) ----
+    if (threadIdx.x == 0) *block_kmers = 0;
+    __syncthreads();
+    {
+        unsigned short* const out = a.items + (size_t)blockIdx.x * a.ig.wg_stride;
+        unsigned short* const tab_row = a.tab + (size_t)blockIdx.x * n_bins;
+        for (uint32_t bin = (uint32_t)wave; bin < n_bins; bin += kItemWaves) {
+            const uint32_t cap = bin < n_eb ? cap_e : cap_v;
+            const uint32_t base = bin < n_eb ? bin * cap_e : v_buck0 + (bin - n_eb) * cap_v;
+            const uint32_t c = min(cnt[bin], cap);
+            const uint32_t e = ext_of[bin];
+            if ((uint32_t)lane < c) out[base + (uint32_t)lane] = buck[base + (uint32_t)lane];
+            if (lane == 0) tab_row[bin] = (unsigned short)(c | ((e != 0u && e != kExtNone) ? e << 8 : 0u));
+        }
+        const uint32_t n_ext = min(*ext_next, kItemExtN);
+        for (uint32_t x = (uint32_t)wave; x < n_ext; x += kItemWaves) {
+            const uint32_t c = min(ext_cnt[x], kItemExtCap);
+            if ((uint32_t)lane < c) out[a.ig.wg_items + x * kItemExtCap + (uint32_t)lane] = ext_buck[x * kItemExtCap + (uint32_t)lane];
+            if (lane == 0) a.ext_n[(size_t)blockIdx.x * kItemExtN + x] = (unsigned char)c;
+        }
+    }
+    uint32_t tot = nkm;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off);
+    if (lane == 0 && tot) atomicAdd(block_kmers, tot);
+    __syncthreads();
+    if (threadIdx.x == 0 && *block_kmers && a.kmer_total) atomicAdd(a.kmer_total, (unsigned long long)*block_kmers);
+}
+
+// One workgroup per bin.  E bin b: window cells [128 b, 128 b + 383) -- its items start in its 128 cells and reach at most 255
+// further; cells counted by two bins simply receive two additions.  V bin: counters [bin * size, + size) of the plane's V part.
+__global__ __launch_bounds__(kBinBlock) void bin_count_kernel(BinArgs b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned int acc[];   // E: [2][kEBinSpan + 1] difference arrays (along / against); V: the bin's counters
+    const uint32_t bin = blockIdx.x, n_eb = b.ig.n_ebins, n_bins = n_eb + b.ig.n_vbins;
+    const bool is_e = bin < n_eb;
+    const uint32_t vsize = (6u << b.ig.vq_log2) * b.rl;
+    const uint32_t n_acc = is_e ? 2u * (kEBinSpan + 1u) : vsize;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (BK_ABLATE(b, 5)) return;
+    const uint32_t cap = is_e ? b.ig.cap_e : b.ig.cap_v;
+    const uint32_t base = is_e ? bin * b.ig.cap_e : n_eb * b.ig.cap_e + (bin - n_eb) * b.ig.cap_v;
+    // A thread per scan workgroup: this bin's bucket in that workgroup's region.  The bucket's first 48 / 24 slots are asked for
+    // together with the table entry that says how many of them hold items, before anything else is done -- one trip to memory,
+    // not two (every bin's workgroup reads what 255 others wrote: nothing of it is in this XCD's L2).
+    const bool mine = threadIdx.x < b.n_wg && !BK_ABLATE(b, 1);
+    const unsigned short* reg0 = b.items + (size_t)(mine ? threadIdx.x : 0u) * b.ig.wg_stride;
+    uint32_t hdr0 = 0u;
+    uint4 v0 = make_uint4(0u, 0u, 0u, 0u), v1 = v0, v2 = v0, v3 = v0, v4 = v0, v5 = v0;
+    if (mine) {
+        const uint4* q = reinterpret_cast<const uint4*>(reg0 + base);
+        hdr0 = b.tab[(size_t)threadIdx.x * n_bins + bin];
+        v0 = q[0]; v1 = q[1]; v2 = q[2];
+        if (is_e) { v3 = q[3]; v4 = q[4]; v5 = q[5]; }
+    }
+    for (uint32_t i = threadIdx.x; i < n_acc; i += kBinBlock) acc[i] = 0u;
+    if (BK_ABLATE(b, 6)) return;
+    if (bin == 0 && threadIdx.x == 0) b.ov_n[b.ov_par ^ 1u] = 0ull;   // the next launch's overflow count starts at zero
+    __syncthreads();
+    auto take = [&](uint32_t it) __attribute__((always_inline)) {
+        if (it == 0xffffu) return;
+        if (is_e) {
+            const uint32_t c = it & 127u, n = ((it >> 7) & 255u) + 1u;
+            unsigned int* d = acc + (it >> 15) * (kEBinSpan + 1u);
+            __hip_atomic_fetch_add(d + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(d + c + n, 0u - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            __hip_atomic_fetch_add(acc + (it & 0x7fffu), (it & 0x8000u) ? 0u - 1u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    // the first `left` of the eight items of one 16-byte unit
+    auto take8 = [&](const uint4& v, uint32_t left) __attribute__((always_inline)) {
+        if (left > 0u) take(v.x & 0xffffu);
+        if (left > 1u) take(v.x >> 16);
+        if (left > 2u) take(v.y & 0xffffu);
+        if (left > 3u) take(v.y >> 16);
+        if (left > 4u) take(v.z & 0xffffu);
+        if (left > 5u) take(v.z >> 16);
+        if (left > 6u) take(v.w & 0xffffu);
+        if (left > 7u) take(v.w >> 16);
+    };
+    // n items (whole 16-byte units are readable): four units in flight at a time
+    auto take_items = [&](const unsigned short* p, uint32_t n) __attribute__((always_inline)) {
+        const uint4* q = reinterpret_cast<const uint4*>(p);
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t i0 = 0; i0 < n; i0 += 32u) {
+            const uint32_t u0 = i0 >> 3;
+            const uint4 v0 = q[u0];
+            const uint4 v1 = i0 + 8u < n ? q[u0 + 1u] : z;
+            const uint4 v2 = i0 + 16u < n ? q[u0 + 2u] : z;
+            const uint4 v3 = i0 + 24u < n ? q[u0 + 3u] : z;
+            take8(v0, n - i0);
+            take8(v1, n > i0 + 8u ? n - i0 - 8u : 0u);
+            take8(v2, n > i0 + 16u ? n - i0 - 16u : 0u);
+            take8(v3, n > i0 + 24u ? n - i0 - 24u : 0u);
+        }
+    };
+    const uint32_t spec = is_e ? 48u : 24u;   // slots asked for above
+    auto take_rest = [&](const unsigned short* reg, uint32_t hdr, uint32_t n) __attribute__((always_inline)) {
+        if (n > spec) take_items(reg + base + spec, n - spec);   // (larger buckets than this kernel was written for)
+        if (hdr >> 8) {   // the bin's extension bucket in that workgroup
+            const uint32_t x = (hdr >> 8) - 1u;
+            take_items(reg + b.ig.wg_items + x * kItemExtCap, min((uint32_t)b.ext_n[(size_t)threadIdx.x * kItemExtN + x], kItemExtCap));
+        }
+    };
+    if (mine) {
+        const uint32_t n = min(hdr0 & 255u, cap);
+        take8(v0, n);
+        take8(v1, n > 8u ? n - 8u : 0u);
+        take8(v2, n > 16u ? n - 16u : 0u);
+        if (is_e) {
+            take8(v3, n > 24u ? n - 24u : 0u);
+            take8(v4, n > 32u ? n - 32u : 0u);
+            take8(v5, n > 40u ? n - 40u : 0u);
+        }
+        take_rest(reg0, hdr0, n);
+    }
+    for (uint32_t wg = threadIdx.x + kBinBlock; wg < b.n_wg && !BK_ABLATE(b, 1); wg += kBinBlock) {   // (more scan workgroups than threads here: never on this chip)
+        const unsigned short* reg = b.items + (size_t)wg * b.ig.wg_stride;
+        const uint32_t hdr = b.tab[(size_t)wg * n_bins + bin];
+        const uint32_t n = min(hdr & 255u, cap);
+        take_items(reg + base, n);
+        if (hdr >> 8) {
+            const uint32_t x = (hdr >> 8) - 1u;
+            take_items(reg + b.ig.wg_items + x * kItemExtCap, min((uint32_t)b.ext_n[(size_t)wg * kItemExtN + x], kItemExtCap));
+        }
+    }
+    if (!BK_ABLATE(b, 7)) {   // the overflow list: everything there that names this bin
+        const unsigned long long n_all = b.ov_n[b.ov_par];
+        const uint32_t n_ov = (uint32_t)(n_all < (unsigned long long)b.ov_cap ? n_all : (unsigned long long)b.ov_cap);
+        for (uint32_t i = threadIdx.x; i < n_ov; i += kBinBlock) {
+            const uint32_t e = b.ov[i];
+            if ((e >> 16) == bin) take(e & 0xffffu);
+        }
+    }
+    __syncthreads();
+    if (is_e) {
+        // difference arrays -> per-cell counts: wave 0 the reads along the reference, wave 1 those against it, six entries per lane
+        if (wave < 2) {
+            unsigned int* d = acc + (uint32_t)wave * (kEBinSpan + 1u) + (uint32_t)lane * 6u;
+            const uint32_t d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5];
+            const uint32_t sum = d0 + d1 + d2 + d3 + d4 + d5;
+            uint32_t inc = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, off); if (lane >= off) inc += t; }
+            uint32_t run = inc - sum;
+            run += d0; d[0] = run; run += d1; d[1] = run; run += d2; d[2] = run; run += d3; d[3] = run; run += d4; d[4] = run; run += d5; d[5] = run;
+        }
+        __syncthreads();
+        const uint32_t win_lo = b.win_dev ? b.win_dev[1] : b.win_lo;
+        for (uint32_t i = threadIdx.x; i < kEBinSpan && !BK_ABLATE(b, 2) && !BK_ABLATE(b, 3); i += kBinBlock) {
+            const uint32_t s0 = acc[i], s1 = acc[(kEBinSpan + 1u) + i];
+            if (s0 | s1) {
+                const uint32_t cell = win_lo + (bin << kEBinLog2) + i;
+                const uint32_t id = b.id_at[cell];   // a counted cell always has a reference k-mer
+                const uint32_t rc = ((b.cell_codes[cell >> 4] >> (2u * (cell & 15u))) & 3u) == 2u ? 1u : 0u;
+                if (s0) atomicAdd(b.counters + 2 * (size_t)id + rc, (unsigned long long)s0);
+                if (s1) atomicAdd(b.counters + 2 * (size_t)id + (1u - rc), (unsigned long long)s1);
+            }
+        }
+    } else {
+        const uint64_t first = (uint64_t)(bin - n_eb) * vsize;
+        unsigned long long* const vc = b.counters + b.v_off + first;
+        const uint32_t n_here = (uint32_t)min((uint64_t)vsize, b.v_real_len > first ? b.v_real_len - first : 0ull);
+        // a difference: sign-extended, the plane wraps modulo 2^64.  Nothing else adds to this mate file's plane while this kernel runs
+        // (the stream orders it against nbatch / level2 / finalize) and a counter belongs to one thread of one workgroup: plain
+        // read-modify-write of whole lines instead of a million scattered atomics; v_mode 2: the V part is known to be all zero
+        // (a sample's first launch into a clean plane) -- stores only
+        if (BK_ABLATE(b, 2) || BK_ABLATE(b, 4)) {
+        } else if (b.v_mode == 2) {
+            for (uint32_t i = threadIdx.x; i < n_here; i += kBinBlock) vc[i] = (unsigned long long)(long long)(int32_t)acc[i];
+        } else if (b.v_mode == 1) {
+            for (uint32_t i = threadIdx.x; i < n_here; i += kBinBlock) vc[i] += (unsigned long long)(long long)(int32_t)acc[i];
+        } else {
+            for (uint32_t i = threadIdx.x; i < n_here; i += kBinBlock) {
+                const uint32_t v = acc[i];
+                if (v) atomicAdd(vc + i, (unsigned long long)(long long)(int32_t)v);
+            }
+        }
+    }
+}
+
+bool item_geometry(uint32_t win_cells, uint32_t n_full, int v_span, ItemGeom* g) {
+    if (v_span <= 0 || win_cells == 0 || n_full == 0) return false;
+    const uint32_t rl = (uint32_t)v_span + 1u;
+    const uint64_t n_q = (uint64_t)n_full + (uint32_t)v_span;
+    uint32_t vq_log2 = 0, nv = 0;
+    for (uint32_t l = 6; l <= 8; ++l) {   // the smallest bins that keep their number at 512 or below
+        if ((6u << l) * rl > 32767u) break;
+        vq_log2 = l;
+        nv = (uint32_t)((n_q + (1u << l) - 1u) >> l);
+        if (nv <= 512u) break;
+    }
+    if (!vq_log2 || nv > 1024u) return false;
+    const uint32_t ne = (win_cells + (1u << kEBinLog2) - 1u) >> kEBinLog2;
+    if (ne + nv > 2u * (uint32_t)kItemBlock) return false;
+    g->n_ebins = ne; g->n_vbins = nv; g->vq_log2 = vq_log2;
+    // a workgroup sees 1 / n_cus of a launch: 3,900 of a million reads, 6,800 E items and 4,500 V items over these bins; a bucket
+    // holds the mean of a uniform sample and three to four standard deviations (what goes beyond finds an extension bucket)
+    g->cap_e = 48u; g->cap_v = 24u;
+    g->wg_items = ne * g->cap_e + nv * g->cap_v;
+    g->wg_stride = g->wg_items + kItemExtN * kItemExtCap;
+    return true;
+}
+
+uint32_t items_max_grid(int n_cus) { return (uint32_t)n_cus * kItemGroupsPerCu; }
+uint32_t items_grid(uint64_t n_records, int n_cus) {
+    const uint64_t tiles = (n_records + 63) / 64;
+    const uint64_t want = (tiles + kItemWaves - 1) / kItemWaves;
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, items_max_grid(n_cus)));
+}
+size_t items_lds_bytes(const ItemGeom& g, uint32_t win_cells) {
+    const size_t nb_pad = ((size_t)g.n_ebins + g.n_vbins + 1u) & ~(size_t)1u;
+    return ((kItemLdsFixed + nb_pad * 8u + (size_t)g.wg_stride * 2u + 7u) & ~(size_t)7u) + scan_ref_lds_bytes(win_cells) + 8u;
+}
+
+static hipError_t raise_lds_limit(const void* fn, size_t lds) {
+    // the dynamic-LDS limit of a kernel is raised once (per process and device), not at every launch
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<const void*, int>, size_t>> have;   // ((kernel, device), limit set)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    size_t* cur = nullptr;
+    for (auto& h : have) if (h.first.first == fn && h.first.second == dev) cur = &h.second;
+    if (!cur || *cur < lds) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        if (cur) *cur = lds; else have.push_back({{fn, dev}, lds});
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_scan_items(const ScanArgs& a, uint32_t grid, hipStream_t stream) {
+    if (a.n_records == 0 || a.W <= 0) return hipSuccess;
+    size_t lds = items_lds_bytes(a.ig, std::min(a.n_lds_bins, a.total_cells));
+    ScanArgs b = a;
+    // the records in LDS when they are short enough and a tile starts at a 16-byte boundary (LDS-DMA moves 16 bytes per lane)
+    const uintptr_t first = reinterpret_cast<uintptr_t>(a.words + a.rec_base * a.stride_words);
+    const bool staged = a.stride_words <= kStageMaxWords && (first & 15u) == 0 && !BK_ABLATE(a, 16);
+    b.stage_off = 0;
+    if (staged) {
+        b.stage_off = (uint32_t)((lds + 15u) & ~(size_t)15u);
+        lds = b.stage_off + (size_t)kItemWaves * 64u * a.stride_words * sizeof(unsigned int);
+    }
+    void (*kern)(ScanArgs);
+    if (staged) kern = a.k == 21 ? scan_items_kernel<21, true> : a.k == 31 ? scan_items_kernel<31, true> : scan_items_kernel<0, true>;
+    else kern = a.k == 21 ? scan_items_kernel<21, false> : a.k == 31 ? scan_items_kernel<31, false> : scan_items_kernel<0, false>;
+    if (hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kern), lds)) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kItemBlock), lds, stream, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_bin_count(const BinArgs& b, hipStream_t stream) {
+    const uint32_t n_bins = b.ig.n_ebins + b.ig.n_vbins;
+    if (n_bins == 0 || b.n_wg == 0) return hipSuccess;
+    const size_t lds = std::max<size_t>(2u * (kEBinSpan + 1u), (size_t)(6u << b.ig.vq_log2) * b.rl) * sizeof(unsigned int);
+    if (hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(bin_count_kernel), lds)) return e;
+    hipLaunchKernelGGL(bin_count_kernel, dim3(n_bins), dim3(kBinBlock), lds, stream, b);
+    return hipGetLastError();
+}
+
+}  // namespace bk

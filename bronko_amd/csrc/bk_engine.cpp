@@ -2337,23 +2337,34 @@ int bk_shard_transport(bk_engine* e, int mate, int n_shards, int width, void** d
     e->xport_ever = true;
     if (e->reduced_shards[0] == 0 && e->reduced_shards[1] == 0)   // first transport of this sample
         BK_HIP(hipMemsetAsync(e->xport_flag.p, 0, sizeof(unsigned long long), e->stream));
-    const uint64_t part = e->plane_len / (uint64_t)n_shards;
-    if (e->reduced[mate].n < part) {   // (buffers are sized once per shape and stay where they are: a host may keep views of them)
-        BK_HIP(hipStreamSynchronize(e->stream));
-        BK_HIP(e->reduced[mate].alloc(part));
-    }
     const uint64_t pb = bk::xport_part_bytes(e->plane_len, e->v_off, (uint32_t)n_shards, width);
+    // Width 16 spends four lanes on an E count: with many shards (or a plane that is mostly E counts) its part is no smaller than
+    // the 32-bit one -- it would send more, not less.  Refused, so that nobody packs a plane for nothing ("auto" falls back on 32).
+    if (width == 16 && pb >= bk::xport_part_bytes(e->plane_len, e->v_off, (uint32_t)n_shards, 32))
+        return fail(BK_ERR_INVALID, "width 16 does not shrink the plane at %d shards (every E count takes four 16-bit lanes): use width 32", n_shards);
+    // The buffers are sized ONCE, for the worst case over every shard count and width (the whole plane for `reduced`; the
+    // largest packed plane and part for the transport), and stay where they are for the engine's lifetime: a host may keep views.
+    if (e->reduced[mate].n < e->plane_len) {
+        BK_HIP(hipStreamSynchronize(e->stream));
+        BK_HIP(e->reduced[mate].alloc(e->plane_len));
+    }
     *part_bytes = pb;
     if (width == 64) {   // nothing to pack: the plane itself is the send buffer and the received part is the reduced part
         *d_send = e->counters[mate].p;
         *d_recv = e->reduced[mate].p;
         return BK_OK;
     }
-    const uint64_t need_send = bk::xport_part_bytes(e->plane_len, e->v_off, (uint32_t)n_shards, 32) * (uint64_t)n_shards;   // (the larger of the two widths)
-    if (e->xport_send.n < need_send || e->xport_recv.n < need_send / (uint64_t)n_shards) {
+    if (!e->xport_send.p) {
+        uint64_t max_part = 0, max_all = 0;
+        for (uint32_t n = 1; n <= bk::kMaxShards; n *= 2)
+            for (int w : {16, 32}) {
+                const uint64_t b = bk::xport_part_bytes(e->plane_len, e->v_off, n, w);
+                max_part = std::max(max_part, b);
+                max_all = std::max(max_all, b * n);
+            }
         BK_HIP(hipStreamSynchronize(e->stream));
-        BK_HIP(e->xport_send.alloc(need_send));
-        BK_HIP(e->xport_recv.alloc(need_send / (uint64_t)n_shards));
+        BK_HIP(e->xport_send.alloc(max_all));
+        BK_HIP(e->xport_recv.alloc(max_part));
     }
     bk_engine::Span sp(e, 2);
     bk::launch_xport_pack(e->counters[mate].p, e->plane_len, e->v_off, (uint32_t)n_shards, width, e->xport_send.p, e->xport_flag.p, e->stream);

@@ -34,7 +34,8 @@ constexpr int kBinBlock = 256;
 constexpr uint32_t kStageMaxWords = 12;    // records of up to 192 bases are staged in LDS (48 KB for the workgroup's 16 waves)
 
 // An item that found neither room in its bucket nor in the overflow list: straight to the plane (never lost, never fast).
-__device__ __forceinline__ void item_direct(const ScanArgs& a, uint32_t bin, uint32_t item, uint32_t win_lo) {
+__device__ __forceinline__ void item_direct(const __attribute__((address_space(4))) ScanArgs* ap, uint32_t bin, uint32_t item, uint32_t win_lo) {
+    const __attribute__((address_space(4))) ScanArgs& a = *ap;
     if (bin < a.ig.n_ebins) {
         const uint32_t c0 = win_lo + (bin << kEBinLog2) + (item & 127u), n = ((item >> 7) & 255u) + 1u, rev = item >> 15;
         for (uint32_t i = 0; i < n; ++i) {
@@ -72,6 +73,13 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform by construction: tell the compiler
     unsigned int* const own_s = own_all + wave * 64;
+    // The arguments only rare paths read (overflow, marks for Level 2, the fallback seeds, start and end of the workgroup) are read
+    // again from the kernel-argument segment where they are used, through a pointer the compiler cannot see through: held in
+    // scalar registers for the whole tile loop they cost ~60 of the 102 there are, and the loop paid for it in v_readlane /
+    // v_writelane spill traffic (617 of its 5,500 instructions).
+    typedef const __attribute__((address_space(4))) ScanArgs* ColdArgs;
+    const ColdArgs cold0 = (ColdArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    auto cold = [&]() __attribute__((always_inline)) -> ColdArgs { ColdArgs p = cold0; asm volatile("" : "+s"(p)); return p; };
 
     const uint32_t total = a.total_cells;
     // the window (a multiple of 64 cells from the start): chosen on the device for a multi-genome index (choose_window_kernel), else
@@ -86,10 +94,17 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     for (uint32_t i = threadIdx.x; i < n_bins; i += kItemBlock) { cnt[i] = 0u; ext_of[i] = 0u; }
     if (threadIdx.x < kItemExtN) ext_cnt[threadIdx.x] = 0u;
     if (threadIdx.x == 0) *ext_next = 0u;
-    for (uint32_t i = threadIdx.x; i < n_refw; i += kItemBlock) lds_ref[i] = a.ref_words[(win_lo >> 4) + i];
-    for (uint32_t i = threadIdx.x; i < n_bitw; i += kItemBlock) lds_ref[n_refw + i] = a.cell_fast[(win_lo >> 5) + i];
-    for (uint32_t i = threadIdx.x; i < n_bitw; i += kItemBlock) lds_ref[n_refw + n_bitw + i] = a.cell_clean3[(win_lo >> 5) + i];
-    for (uint32_t i = threadIdx.x; i < 2 * n_blk; i += kItemBlock) lds_ref[blk_w0 + i] = reinterpret_cast<const uint32_t*>(a.cell_blk + (win_lo >> 6))[i];
+    {
+        const ColdArgs c = cold();
+        const uint32_t* const g_ref = c->ref_words + (win_lo >> 4);
+        const uint32_t* const g_fast = c->cell_fast + (win_lo >> 5);
+        const uint32_t* const g_c3 = c->cell_clean3 + (win_lo >> 5);
+        const uint32_t* const g_blk = reinterpret_cast<const uint32_t*>(c->cell_blk + (win_lo >> 6));
+        for (uint32_t i = threadIdx.x; i < n_refw; i += kItemBlock) lds_ref[i] = g_ref[i];
+        for (uint32_t i = threadIdx.x; i < n_bitw; i += kItemBlock) lds_ref[n_refw + i] = g_fast[i];
+        for (uint32_t i = threadIdx.x; i < n_bitw; i += kItemBlock) lds_ref[n_refw + n_bitw + i] = g_c3[i];
+        for (uint32_t i = threadIdx.x; i < 2 * n_blk; i += kItemBlock) lds_ref[blk_w0 + i] = g_blk[i];
+    }
     __syncthreads();
     // symbol / bit 0 is cell win_lo; negative positions down to -64 are readable (padding or earlier cells)
     const unsigned int* refw1 = lds_ref + kRefPadWords;
@@ -107,11 +122,11 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
 
     // ---- the sinks: an item into its bin's bucket; a bin that outgrows its bucket gets an extension bucket; what finds no room at
     // all spills into the device-wide overflow list ----
-    unsigned long long* const ov_n = a.ov_n + a.ov_par;
     auto spill = [&](uint32_t bin, uint32_t item) {
-        const unsigned long long i = atomicAdd(ov_n, 1ull);
-        if (i < (unsigned long long)a.ov_cap) a.ov[i] = (bin << 16) | item;
-        else item_direct(a, bin, item, win_lo);
+        const ColdArgs c = cold();
+        const unsigned long long i = atomicAdd(c->ov_n + c->ov_par, 1ull);
+        if (i < (unsigned long long)c->ov_cap) c->ov[i] = (bin << 16) | item;
+        else item_direct(c, bin, item, win_lo);
     };
     auto put_ext = [&](uint32_t bin, uint32_t item) {
         for (;;) {
@@ -146,14 +161,14 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     };
 
     uint32_t nkm = 0;  // k-mer occurrences of this lane's records
-    const IndexView& ix = *a.ixp;
     // k-mers [sk, sk + n) of record `rec` (index within this launch) are an N run left to nbatch_kernel: set their bits (the
     // record's diagonal goes with the mark: nothing is written for the records without one)
     auto n_mark = [&](bool on, uint32_t rec, uint32_t sk, uint32_t n, int32_t dgm, uint32_t flm) {
         if (!on) return;
-        unsigned int* row = a.n_bits + (size_t)rec * a.l2_words;
-        atomicOr(a.n_any + (rec >> 5), 1u << (rec & 31u));
-        a.l2_diag[rec] = make_uint2((uint32_t)dgm, flm);
+        const ColdArgs c = cold();
+        unsigned int* row = c->n_bits + (size_t)rec * c->l2_words;
+        atomicOr(c->n_any + (rec >> 5), 1u << (rec & 31u));
+        c->l2_diag[rec] = make_uint2((uint32_t)dgm, flm);
         uint32_t w = sk >> 5, bit = sk & 31u, left = n;
         while (left) {
             const uint32_t take = min(left, 32u - bit);
@@ -164,9 +179,10 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     // ... or, one by one, to level2_kernel (l2_bits): the k-mers that hold two mismatches and cannot be discarded
     auto l2_mark = [&](bool on, uint32_t rec, uint32_t sk, uint32_t n, int32_t dgm, uint32_t flm) {
         if (!on) return;
-        unsigned int* row = a.l2_bits + (size_t)rec * a.l2_words;
-        atomicOr(a.l2_any + (rec >> 5), 1u << (rec & 31u));
-        a.l2_diag[rec] = make_uint2((uint32_t)dgm, flm);
+        const ColdArgs c = cold();
+        unsigned int* row = c->l2_bits + (size_t)rec * c->l2_words;
+        atomicOr(c->l2_any + (rec >> 5), 1u << (rec & 31u));
+        c->l2_diag[rec] = make_uint2((uint32_t)dgm, flm);
         uint32_t w = sk >> 5, bit = sk & 31u, left = n;
         while (left) {
             const uint32_t take = min(left, 32u - bit);
@@ -253,53 +269,66 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
         uint32_t best_cell = 0xffffffffu;
         auto candidate = [&](bool hit, uint32_t scell, bool f, uint32_t s) {
             if (hit && scell < best_cell) {   // several seeds may hit (usually all, on one diagonal); prefer the lowest cell
-                const int64_t d0 = f ? (int64_t)scell - (int64_t)s : (int64_t)scell + (int64_t)s;
-                const int64_t lo_cell = f ? d0 : d0 - (int64_t)(len - (uint32_t)k);
-                const int64_t hi_cell = f ? d0 + (int64_t)(len - (uint32_t)k) : d0;
-                if (lo_cell >= 0 && hi_cell + k <= (int64_t)total) {
-                    best_cell = scell; dg = (int32_t)d0; fwd = f; seeded = true;
-                    l1ok = lo_cell >= (int64_t)win_lo && hi_cell < (int64_t)win_lo + (int64_t)a.n_lds_bins;
+                // (cells stay below 2^27 -- kSeedCellBits --, read positions below 2^16: 32-bit signed arithmetic holds everything)
+                const int32_t span_k = (int32_t)(len - (uint32_t)k);
+                const int32_t d0 = f ? (int32_t)scell - (int32_t)s : (int32_t)scell + (int32_t)s;
+                const int32_t lo_cell = f ? d0 : d0 - span_k;
+                const int32_t hi_cell = f ? d0 + span_k : d0;
+                if (lo_cell >= 0 && (uint32_t)hi_cell + (uint32_t)k <= total) {
+                    best_cell = scell; dg = d0; fwd = f; seeded = true;
+                    l1ok = (uint32_t)lo_cell >= win_lo && (uint32_t)hi_cell < win_lo + a.n_lds_bins;
                     if (l1ok) l1ok = (uint32_t)hi_cell < blkw[((uint32_t)lo_cell >> 6) - (win_lo >> 6)].y;
                 }
             }
         };
-        // First the seed table of the window's genome (bk_device.h seed_hash): kSeeds k-mers at positions that do not depend on the
-        // read's length (evenly spaced over the launch's first record: the length load and the seeds' word loads go out together),
-        // one 8-byte bucket each, and the candidate it names is verified against the reference in LDS.
-        if (seed_tab && !BK_ABLATE(a, 9) && !BK_ABLATE(a, 11)) {
-            uint64_t sg[kSeeds], sff[kSeeds];
-            uint32_t sh[kSeeds], sis[kSeeds];
-            uint2 sb[kSeeds];
+        // First the seed table of the window's genome (bk_device.h seed_hash): k-mers at positions that do not depend on the read's
+        // length (evenly spaced over the launch's first record), one 8-byte bucket each, and the candidate it names is verified
+        // against the reference in LDS.  Two at a time: the read's first and last k-mer; the two in between only for the lanes both
+        // of those left without a diagonal (a sequencing error in each: one read in a hundred, half of the tiles) -- with the
+        // records in LDS a second round costs one more trip to the seed table, not a chain of three.
+        auto seed_pair = [&](int qa, int qb) {
+            const bool had = seeded;
+            uint64_t sg[2], sff[2];
+            uint32_t sh[2], sis[2];
+            uint2 sb[2];
 #pragma unroll
-            for (int sq = 0; sq < kSeeds; ++sq) {
-                const uint32_t s = (hint_span * (uint32_t)sq) / (uint32_t)(kSeeds - 1);   // (wave-uniform)
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t s = (hint_span * (uint32_t)(j ? qb : qa)) / (uint32_t)(kSeeds - 1);   // (wave-uniform)
                 const uint64_t g = read_symbols_at(w, s, last_word) & kmask;       // base t of the k-mer at bits 2t
                 const uint64_t rr = ~g & kmask;                                      // its reverse complement, first base on top
                 const uint64_t ff = rev2_64(g) >> (64 - 2 * k);                      // the k-mer, first base on top
                 const bool lt = ff < rr;                                             // lcb.rs:90-94
-                sg[sq] = g; sff[sq] = ff; sis[sq] = lt ? 0u : 1u;
-                sh[sq] = seed_hash(lt ? ff : rr);
-                sb[sq] = seed_tab[sh[sq] >> (32u - a.seed_log2)];
+                sg[j] = g; sff[j] = ff; sis[j] = lt ? 0u : 1u;
+                sh[j] = seed_hash(lt ? ff : rr);
+                sb[j] = seed_tab[sh[j] >> (32u - a.seed_log2)];
             }
 #pragma unroll
-            for (int sq = 0; sq < kSeeds; ++sq) {
-                const uint32_t s = (hint_span * (uint32_t)sq) / (uint32_t)(kSeeds - 1);
-                const uint32_t tag = sh[sq] & 15u;
-                const uint32_t ent = (sb[sq].x != 0xffffffffu && (sb[sq].x >> 28) == tag) ? sb[sq].x : sb[sq].y;
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t s = (hint_span * (uint32_t)(j ? qb : qa)) / (uint32_t)(kSeeds - 1);
+                const uint32_t tag = sh[j] & 15u;
+                const uint32_t ent = (sb[j].x != 0xffffffffu && (sb[j].x >> 28) == tag) ? sb[j].x : sb[j].y;
                 const uint32_t cell = ent & ((1u << kSeedCellBits) - 1u), rc = (ent >> kSeedCellBits) & 1u;
                 // in reach of the staged reference?  (the window's cells and 64 in front)
-                const bool in_ref = ent != 0xffffffffu && (ent >> 28) == tag && len != 0u && s + (uint32_t)k <= len &&
+                const bool in_ref = !had && ent != 0xffffffffu && (ent >> 28) == tag && len != 0u && s + (uint32_t)k <= len &&
                                     cell + 64u >= win_lo && cell + (uint32_t)k <= win_lo + lds_cells;
                 const int32_t cw = in_ref ? (int32_t)cell - (int32_t)win_lo : 0;
                 const uint64_t ref = symbols_at(refw1, cw) & kmask;                  // reference base cell + t at bits 2t
-                const bool same = sis[sq] == rc;                                     // same strand as the reference?
-                candidate(in_ref && ref == (same ? sg[sq] : (~sff[sq] & kmask)), cell, same, s);
+                const bool same = sis[j] == rc;                                      // same strand as the reference?
+                candidate(in_ref && ref == (same ? sg[j] : (~sff[j] & kmask)), cell, same, s);
             }
+        };
+        if (seed_tab && !BK_ABLATE(a, 9) && !BK_ABLATE(a, 11)) {
+            seed_pair(0, kSeeds - 1);
+            if (__ballot(len != 0u && !seeded)) seed_pair(1, kSeeds - 2);
         }
         // The lanes that are still without a diagonal (an error in every seed, a k-mer that found its bucket full, a read shorter
         // than the first record, no seed table): the perfect hash of U, two rounds (scan_count_kernel has the why).
         for (int round = 0; round < 2 && !BK_ABLATE(a, 9); ++round) {   // (9: no seeds at all, 7: nothing behind them, 6: no mismatch loop)
             if (!__ballot(len != 0u && !seeded)) break;
+            const ColdArgs c = cold();
+            const IndexView& ix = *c->ixp;
+            const uint32_t* const occ = c->occ;
+            const uint32_t n_files = (uint32_t)c->n_files;
             const bool had = seeded;   // a round is for the lanes left without a diagonal so far
             uint64_t sc[kSeeds];
             uint32_t sisrc[kSeeds], spil[kSeeds], spos[kSeeds];
@@ -326,8 +355,8 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
             for (int sq = 0; sq < kSeeds; ++sq) {
                 shit[sq] = len && !had && ((uint64_t)se[sq].x | ((uint64_t)se[sq].y << 32)) == sc[sq];
                 soc[sq] = 0xffffffffu;
-                if (a.occ && shit[sq] && (se[sq].w & kIdMask) < ix.n_full)
-                    soc[sq] = a.occ[(size_t)(se[sq].w & kIdMask) * (uint32_t)a.n_files + win_file];
+                if (occ && shit[sq] && (se[sq].w & kIdMask) < ix.n_full)
+                    soc[sq] = occ[(size_t)(se[sq].w & kIdMask) * n_files + win_file];
             }
 #pragma unroll
             for (int sq = 0; sq < kSeeds; ++sq) {
@@ -534,33 +563,28 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::"v"(pf_sink) : "memory");   // the prefetch register stays reserved up to here
 
-    // ---- the buckets, as they are, into this workgroup's region (a wave per bucket: neighbouring lanes, neighbouring items) ----
+    // ---- the buckets, as they are, into this workgroup's region: the whole bucket area in 16-byte units (slots that hold nothing
+    // go out as they are -- tab / ext_n say how many of a bucket's slots count), then the table ----
     if (threadIdx.x == 0) *block_kmers = 0;
     __syncthreads();
     {
-        unsigned short* const out = a.items + (size_t)blockIdx.x * a.ig.wg_stride;
-        unsigned short* const tab_row = a.tab + (size_t)blockIdx.x * n_bins;
-        for (uint32_t bin = (uint32_t)wave; bin < n_bins; bin += kItemWaves) {
-            const uint32_t cap = bin < n_eb ? cap_e : cap_v;
-            const uint32_t base = bin < n_eb ? bin * cap_e : v_buck0 + (bin - n_eb) * cap_v;
-            const uint32_t c = min(cnt[bin], cap);
+        const ColdArgs c = cold();
+        uint4* const out4 = reinterpret_cast<uint4*>(c->items + (size_t)blockIdx.x * a.ig.wg_stride);
+        const uint4* const buck4 = reinterpret_cast<const uint4*>(buck);
+        for (uint32_t i = threadIdx.x; i < a.ig.wg_stride / 8u; i += kItemBlock) out4[i] = buck4[i];
+        unsigned short* const tab_row = c->tab + (size_t)blockIdx.x * n_bins;
+        for (uint32_t bin = threadIdx.x; bin < n_bins; bin += kItemBlock) {
             const uint32_t e = ext_of[bin];
-            if ((uint32_t)lane < c) out[base + (uint32_t)lane] = buck[base + (uint32_t)lane];
-            if (lane == 0) tab_row[bin] = (unsigned short)(c | ((e != 0u && e != kExtNone) ? e << 8 : 0u));
+            tab_row[bin] = (unsigned short)(min(cnt[bin], bin < n_eb ? cap_e : cap_v) | ((e != 0u && e != kExtNone) ? e << 8 : 0u));
         }
-        const uint32_t n_ext = min(*ext_next, kItemExtN);
-        for (uint32_t x = (uint32_t)wave; x < n_ext; x += kItemWaves) {
-            const uint32_t c = min(ext_cnt[x], kItemExtCap);
-            if ((uint32_t)lane < c) out[a.ig.wg_items + x * kItemExtCap + (uint32_t)lane] = ext_buck[x * kItemExtCap + (uint32_t)lane];
-            if (lane == 0) a.ext_n[(size_t)blockIdx.x * kItemExtN + x] = (unsigned char)c;
-        }
+        if (threadIdx.x < kItemExtN) c->ext_n[(size_t)blockIdx.x * kItemExtN + threadIdx.x] = (unsigned char)min(ext_cnt[threadIdx.x], kItemExtCap);
     }
     uint32_t tot = nkm;
 #pragma unroll
     for (int off = 32; off; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off);
     if (lane == 0 && tot) atomicAdd(block_kmers, tot);
     __syncthreads();
-    if (threadIdx.x == 0 && *block_kmers && a.kmer_total) atomicAdd(a.kmer_total, (unsigned long long)*block_kmers);
+    if (threadIdx.x == 0 && *block_kmers) { unsigned long long* kt = cold()->kmer_total; if (kt) atomicAdd(kt, (unsigned long long)*block_kmers); }
 }
 
 // One workgroup per bin.  E bin b: window cells [128 b, 128 b + 383) -- its items start in its 128 cells and reach at most 255

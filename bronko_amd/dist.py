@@ -210,8 +210,16 @@ class ShardedFinalize:
         self.last_widths, self.bytes_sent = [], 0
         for m in range(self.n_mates):
             w = self._measure(m) if self.width == "auto" else self.width
+            try:
+                send_ptr, part_bytes, recv_ptr = self.eng.shard_transport(m, self.world, w)
+            except RuntimeError:   # (engine.BronkoError)
+                # (the engine refuses width 16 where it would not shrink the plane -- many shards, every E count four lanes --; every
+                # rank sees the same geometry, so every rank falls back the same way)
+                if self.width != "auto" or w != 16:
+                    raise
+                w = 32
+                send_ptr, part_bytes, recv_ptr = self.eng.shard_transport(m, self.world, w)
             self.last_widths.append(w)
-            send_ptr, part_bytes, recv_ptr = self.eng.shard_transport(m, self.world, w)
             item = _WIDTH_DTYPE[w][2]
             send = self._view(send_ptr, part_bytes // item * self.world, w)
             recv = self._view(recv_ptr, part_bytes // item, w)

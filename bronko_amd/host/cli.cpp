@@ -47,18 +47,16 @@ void logf(int lvl, const char* tag, const char* target, const std::string& msg) 
 #define LOG_INFO(t, m) logf(2, "INFO", t, m)
 #define LOG_TRACE(t, m) logf(4, "TRACE", t, m)
 
-// `error!(..); std::process::exit(1)`.  Lane and completion threads die too: from one of them exit() would run the static
-// destructors -- the HIP runtime's among them -- under the other threads' HIP calls and end in a crash or a hang instead of
-// exit code 1, so a thread that is not the main one leaves through _exit() (streams flushed first; the first error wins).
-const std::thread::id g_main_thread = std::this_thread::get_id();
+// `error!(..); std::process::exit(1)`.  Every thread leaves through _exit() (streams flushed first; the first error wins):
+// exit() would run the static destructors -- the HIP runtime's among them -- under the lane and completion threads' HIP calls,
+// from the main thread as much as from one of them, and end in a crash or a hang instead of exit code 1.
 std::mutex g_die_mu;
 [[noreturn]] void die(const char* target, const std::string& msg) {
-    std::lock_guard<std::mutex> lock(g_die_mu);   // (never released: a second failing thread waits here while the first one ends the process)
+    g_die_mu.lock();   // (never released: a second failing thread waits here while the first one ends the process)
     LOG_ERROR(target, msg);
     fflush(stdout);
     fflush(stderr);
-    if (std::this_thread::get_id() != g_main_thread) _exit(1);
-    exit(1);
+    _exit(1);
 }
 
 bool ends_with(const std::string& s, const char* suf) {

@@ -208,7 +208,9 @@ int bk_sample_merge_shards(bk_engine* e);
  *                                            then maps it instead of the plane's own elements.
  *   bk_transport_overflow(e, &flag)          synchronises; flag = some sample since the last call met such an element (its results are
  *                                            garbage: repeat it wider).  bk_sample_download reports the same as BK_ERR_RANGE.
- * Pointers stay valid for the engine's lifetime once returned for a given (n, width). */
+ * The transport and `reduced` buffers are allocated once, at the first call, for the largest shard count and width there is:
+ * pointers stay valid for the engine's lifetime.  Width 16 is refused (BK_ERR_INVALID) where it would send no fewer bytes than
+ * width 32 -- every E count travels as four 16-bit lanes, so with many shards, or a plane that is mostly E counts, it does not pay. */
 int bk_shard_measure(bk_engine* e, int mate, void** d_max);
 int bk_shard_transport(bk_engine* e, int mate, int n_shards, int width, void** d_send, uint64_t* part_bytes, void** d_recv);
 int bk_shard_received(bk_engine* e, int mate, int shard, int n_shards, int width);

@@ -337,6 +337,7 @@ struct bk_engine {
         unsigned long long* h_off = nullptr; size_t h_off_cap = 0;
         DevBuf<uint8_t> d_bases;
         DevBuf<unsigned long long> d_off, d_nrec;
+        DevBuf<uint32_t> d_work;           // pack_words_kernel's work list
         DevBuf<uint32_t> d_words;
         DevBuf<uint16_t> d_lens;
         hipEvent_t uploaded = nullptr, done = nullptr;
@@ -1973,7 +1974,8 @@ int bk_push_reads_ascii(bk_engine* e, int mate, const uint8_t* buf, const uint64
     if (sl.d_off.n < n_reads + 1) BK_HIP(sl.d_off.alloc(n_reads + n_reads / 4 + 1024));
     if (sl.d_words.n < cap * stride) BK_HIP(sl.d_words.alloc(cap * stride + cap * stride / 4));
     if (sl.d_lens.n < cap) BK_HIP(sl.d_lens.alloc(cap + cap / 4));
-    if (!sl.d_nrec.p) BK_HIP(sl.d_nrec.alloc(2));
+    if (!sl.d_nrec.p) BK_HIP(sl.d_nrec.alloc(4));
+    if (sl.d_work.n < n_reads) BK_HIP(sl.d_work.alloc(n_reads + n_reads / 4 + 1024));
 
     BK_HIP(hipMemcpyAsync(sl.d_bases.p, sl.h_bases, total, hipMemcpyHostToDevice, e->copy_stream));
     BK_HIP(hipMemcpyAsync(sl.d_off.p, sl.h_off, (n_reads + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, e->copy_stream));
@@ -1982,7 +1984,7 @@ int bk_push_reads_ascii(bk_engine* e, int mate, const uint8_t* buf, const uint64
     {
         bk::PackArgs pa{};
         pa.bases = sl.d_bases.p; pa.offsets = sl.d_off.p; pa.n_reads = n_reads; pa.k = e->k; pa.stride_words = stride;
-        pa.words = sl.d_words.p; pa.lens = sl.d_lens.p; pa.cap = cap; pa.n_records = sl.d_nrec.p;
+        pa.words = sl.d_words.p; pa.lens = sl.d_lens.p; pa.cap = cap; pa.n_records = sl.d_nrec.p; pa.work = sl.d_work.p;
         bk_engine::Span sp(e, 2);
         bk::launch_pack_reads(pa, e->stream);
         bk::launch_add_u64(e->kstats.p + mate * 4 + 0, sl.d_nrec.p + 1, e->stream);   // records pushed, tallied on the device
@@ -2010,17 +2012,19 @@ int bk_push_reads_ascii_device(bk_engine* e, int mate, const void* d_bases, cons
     const uint32_t stride = (uint32_t)std::min<uint64_t>((longest + 15) / 16, 4095);
     const uint64_t maxb = std::min<uint64_t>((uint64_t)stride * 16, 65535);
     const uint64_t cap = n_reads + total_bases / (uint64_t)e->k + total_bases / (maxb - (uint64_t)(e->k - 1)) + 16;   // bound on the records
-    if (sl.d_words.n < cap * stride || sl.d_lens.n < cap) {
+    if ((reinterpret_cast<uintptr_t>(d_bases) & 15u) != 0) return fail(BK_ERR_INVALID, "bk_push_reads_ascii_device: d_bases must be 16-byte aligned (the packer stages the lines with 16-byte loads)");
+    if (sl.d_words.n < cap * stride || sl.d_lens.n < cap || sl.d_work.n < n_reads) {
         BK_HIP(hipStreamSynchronize(e->stream));
         BK_HIP(sl.d_words.alloc(cap * stride + cap * stride / 4));
         BK_HIP(sl.d_lens.alloc(cap + cap / 4));
+        BK_HIP(sl.d_work.alloc(n_reads + n_reads / 4 + 1024));
     }
-    if (!sl.d_nrec.p) BK_HIP(sl.d_nrec.alloc(2));
+    if (!sl.d_nrec.p) BK_HIP(sl.d_nrec.alloc(4));
     {
         bk::PackArgs pa{};
         pa.bases = static_cast<const uint8_t*>(d_bases); pa.offsets = static_cast<const unsigned long long*>(d_offsets); pa.n_reads = n_reads;
         pa.k = e->k; pa.stride_words = stride;
-        pa.words = sl.d_words.p; pa.lens = sl.d_lens.p; pa.cap = cap; pa.n_records = sl.d_nrec.p;
+        pa.words = sl.d_words.p; pa.lens = sl.d_lens.p; pa.cap = cap; pa.n_records = sl.d_nrec.p; pa.work = sl.d_work.p;
         bk_engine::Span sp(e, 2);
         bk::launch_pack_reads(pa, e->stream);
         bk::launch_add_u64(e->kstats.p + mate * 4 + 0, sl.d_nrec.p + 1, e->stream);   // records pushed, tallied on the device

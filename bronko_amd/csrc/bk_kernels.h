@@ -172,9 +172,10 @@ struct PackArgs {
     uint32_t* words;                // out: [cap][stride_words]
     uint16_t* lens;                 // out: [cap]
     uint64_t cap;
-    unsigned long long* n_records;  // out (device) [2]: record slots in use (read i's record in slot i, everything else appended behind
-                                    // the n_reads slots), records that hold a run; both set by the launcher
+    unsigned long long* n_records;  // out (device) [3]: record slots in use (read i's record in slot i, everything else appended behind
+                                    // the n_reads slots), records that hold a run, reads on the work list; all set by the launcher
     unsigned long long* n_real;     // = n_records + 1 (set by the launcher)
+    uint32_t* work;                 // [n_reads] scratch: the reads that are not one clean run that fits a record (or null: no word-per-thread kernel)
 };
 void launch_pack_reads(const PackArgs& a, hipStream_t stream);
 // votes[f] += number of the first records' middle k-mers that occur in genome file f (which genome does the sample look like?)

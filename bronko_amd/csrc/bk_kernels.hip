@@ -87,11 +87,18 @@ __device__ __forceinline__ void for_each_neighbour(const IndexView& ix, uint64_t
 // ------------------------------------------------------------------------------------------------ K0
 // ASCII reads -> fixed-stride 2-bit records (the host-side twin is bk_pack_reads): split at every non-ACGT/acgt symbol (KMC
 // contract), drop runs shorter than k, cut runs longer than the stride into chunks overlapping by k-1 bases.
-// A read that is one clean run that fits a record -- nearly every read -- goes to the record slot of its own index: no counter,
-// four bytes per step (the 2-bit code of a letter is ((c >> 1) ^ (c >> 2)) & 3 in either case; whether all four are letters is one
-// comparison with the letters the codes stand for), the block's sequence lines staged in LDS with coalesced loads.  Any other
-// read leaves its slot empty (length 0) and appends its records behind the n_reads slots through a device counter, byte by byte
-// as before.  Records are unordered anyway.
+//
+// pack_words_kernel (round 4)  one THREAD PER OUTPUT WORD.  A read that is one clean run that fits a record -- nearly every read --
+//   goes to the record slot of its own index, so word q of read r is 16 letters at a known place: the block's sequence lines are
+//   staged in LDS with coalesced 16-byte loads, every thread realigns its 16 letters (v_alignbyte), turns them into codes four at a
+//   time (the 2-bit code of a letter is ((c >> 1) ^ (c >> 2)) & 3 in either case; the letters the codes stand for come back from
+//   one v_perm_b32 and are compared with the input, case folded: "all four are ACGT" in three instructions) and stores one word --
+//   consecutive threads, consecutive words: the 40 MB of records leave as whole cache lines.  (Round 3's kernel took a thread per
+//   READ: 38 dependent steps of four letters each and ten word stores a record apart per lane -- 0.15 ms per million reads, the
+//   longest kernel of the K0..K2 chain.)  A read with anything else in it (N, too short a run, longer than a record) leaves its slot
+//   empty (length 0) and is noted in a work list;
+// pack_slow_kernel   one thread per listed read: its runs, byte by byte, appended behind the n_reads slots through a device
+//   counter, as before.  Records are unordered anyway.
 __device__ __forceinline__ int acgt_code(unsigned char c) {
     switch (c | 0x20) {
         case 'a': return 0;
@@ -103,99 +110,134 @@ __device__ __forceinline__ int acgt_code(unsigned char c) {
 }
 
 constexpr int kPackBlock = 256;
-constexpr uint32_t kPackLdsBytes = 40u * 1024u;   // (256 reads of 150 bases: 38.4 KB; four blocks to a CU)
-__global__ __launch_bounds__(kPackBlock) void pack_reads_kernel(PackArgs a) {
-    extern __shared__ uint4 pk_lds[];
-    __shared__ unsigned int n_real_s;
-    const uint64_t r0 = (uint64_t)blockIdx.x * kPackBlock, r1 = min(r0 + (uint64_t)kPackBlock, a.n_reads);
-    const uint64_t b0 = a.offsets[r0], b1 = a.offsets[r1], end = a.offsets[a.n_reads];
-    const uint64_t a0 = b0 & ~15ull;                       // the block's lines from a 16-byte boundary (device allocations are aligned far beyond)
-    const uint64_t full16 = (end - a0) / 16;               // whole 16-byte units readable from a0
-    const uint64_t n16 = min((b1 - a0 + 15) / 16 + 2, full16);   // (two units more: the last read's last output word looks 16 bytes ahead)
-    const bool staged = n16 * 16 <= kPackLdsBytes;
-    if (threadIdx.x == 0) n_real_s = 0u;
-    if (staged) for (uint64_t i = threadIdx.x; i < n16; i += kPackBlock) pk_lds[i] = reinterpret_cast<const uint4*>(a.bases + a0)[i];
-    __syncthreads();
-    const uint32_t* src32 = staged ? reinterpret_cast<const uint32_t*>(pk_lds) : reinterpret_cast<const uint32_t*>(a.bases + a0);
-    const uint64_t full32 = staged ? n16 * 4 : (end - a0) / 4;   // whole words readable through src32
-    const uint64_t r = r0 + threadIdx.x;
-    unsigned int real = 0;
-    if (r < r1) {
-        const uint64_t o0 = a.offsets[r], len = a.offsets[r + 1] - o0;
-        const uint64_t maxb = min((uint64_t)a.stride_words * 16, (uint64_t)65535);
-        const uint64_t rel = o0 - a0;                      // first byte of the read in the word stream
-        bool done = false;
-        if (len >= (uint64_t)a.k && len <= maxb && rel / 4 + 4 * ((len + 15) / 16) + 1 <= full32) {   // (all words the loop below touches are there)
-            // one record if every symbol is a letter: 16 bases = four realigned words per output word
-            const uint32_t sh = (uint32_t)(rel & 3u);
-            const uint32_t* wsrc = src32 + rel / 4;
-            uint32_t* w = a.words + r * a.stride_words;
-            const uint32_t n_out = (uint32_t)((len + 15) / 16);
-            bool ok = true;
-            uint32_t carry = wsrc[0];
-            uint32_t outs = 0;
-            for (uint32_t q = 0; q < n_out; ++q) {
-                uint32_t acc = 0;
+constexpr uint32_t kPackMaxWords = 16;     // records of up to 256 bases take the word-per-thread kernel (a block holds at least 32 reads)
+constexpr uint32_t kPackWpt = 2;           // output words (32 letters) per thread: the per-thread set-up is half of what a thread issues
+constexpr uint32_t kPackLdsBytes = kPackBlock * kPackWpt * 16u + 96u;   // the block's lines + alignment slack
+
+// 16 letters (four realigned words) -> 16 codes; ok: every one of the first nb is a letter.  What lies behind the nb letters is
+// turned into codes and judged like the rest where it shares four bytes with them, and cut off afterwards: a read flagged for a
+// symbol that is not its own only takes the byte-by-byte kernel, which looks at exactly its letters.
+__device__ __forceinline__ uint32_t pack16(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t nb, bool& ok) {
+    uint32_t out = 0u;
+    const uint32_t x4[4] = {x0, x1, x2, x3};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t nxt = wsrc[4 * q + j + 1];
-                    uint32_t x = __builtin_amdgcn_alignbyte(nxt, carry, sh);   // bytes 16 q + 4 j .. + 3 of the read
-                    carry = nxt;
-                    const uint32_t left = (uint32_t)len - (16u * q + 4u * (uint32_t)j);   // bytes of the read from here on (wraps when none)
-                    const uint32_t keep = (16u * q + 4u * (uint32_t)j >= (uint32_t)len) ? 0u : left >= 4u ? 0xffffffffu : (1u << (8u * left)) - 1u;
-                    x = (x & keep) | (0x41414141u & ~keep);   // (behind the read: 'A', code 0)
-                    const uint32_t c = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
-                    const uint32_t c0 = c & 0x01010101u, c1 = (c >> 1) & 0x01010101u;
-                    ok &= (x | 0x20202020u) == 0x61616161u + c0 * 2u + c1 * 6u + (c0 & c1) * 11u;   // a c g t = 0x61 + 0, 2, 6, 19
-                    acc |= ((c | (c >> 6) | (c >> 12) | (c >> 18)) & 0xffu) << (8 * j);
-                }
-                w[q] = acc;
-                outs = q + 1;
-            }
-            if (ok) {
-                for (uint32_t q = outs; q < a.stride_words; ++q) w[q] = 0;
-                a.lens[r] = (uint16_t)len;
-                real = 1;
-                done = true;
-            }
-        }
-        if (!done) {
-            a.lens[r] = 0;   // the slot of its index stays empty; its records, if any, go behind the n_reads slots
-            const uint8_t* s = a.bases + o0;
-            uint64_t start = 0;
-            for (uint64_t i = 0; i <= len; ++i) {
-                if (i < len && acgt_code(s[i]) >= 0) continue;
-                const uint64_t run = i - start;            // maximal ACGT run [start, i)
-                if (run >= (uint64_t)a.k) {
-                    uint64_t pos = 0;
-                    for (;;) {
-                        const uint64_t take = min(maxb, run - pos);
-                        const unsigned long long rec = atomicAdd(a.n_records, 1ull);
-                        if (rec < a.cap) {
-                            uint32_t* w = a.words + rec * a.stride_words;
-                            uint32_t acc = 0;
-                            for (uint64_t j = 0; j < take; ++j) {
-                                acc |= (uint32_t)acgt_code(s[start + pos + j]) << (2 * (j & 15));
-                                if ((j & 15) == 15) { w[j >> 4] = acc; acc = 0; }
-                            }
-                            if (take & 15) w[take >> 4] = acc;
-                            for (uint64_t j = (take + 15) >> 4; j < a.stride_words; ++j) w[j] = 0;
-                            a.lens[rec] = (uint16_t)take;
-                            ++real;
-                        }
-                        if (pos + take >= run) break;
-                        pos += take - (uint64_t)(a.k - 1);
-                    }
-                }
-                start = i + 1;
-            }
+    for (uint32_t j = 0; j < 4u; ++j) {
+        const uint32_t x = x4[j];
+        const uint32_t c = ((x >> 1) ^ (x >> 2)) & 0x03030303u;                       // four codes, one per byte
+        ok &= (x & 0xdfdfdfdfu) == __builtin_amdgcn_perm(0x54474341u, 0x54474341u, c) || nb <= 4u * j;   // the letters A C G T the codes stand for
+        const uint32_t c2 = c | (c >> 6);
+        out |= ((c2 | (c2 >> 12)) & 0xffu) << (8u * j);
+    }
+    return nb < 16u ? out & ((1u << (2u * nb)) - 1u) : out;
+}
+
+__global__ __launch_bounds__(kPackBlock) void pack_words_kernel(PackArgs a, uint32_t rpb /* reads per block */, uint32_t tpr /* threads per read =
+                                                                ceil(stride_words / kPackWpt) */, uint32_t tpr_recip /* ceil(2^32 / tpr) */) {
+    __shared__ __attribute__((aligned(16))) unsigned char lines[kPackLdsBytes];
+    __shared__ unsigned long long off_s[kPackBlock + 1];       // offsets of the block's reads (rpb + 1 of them)
+    __shared__ unsigned int bad_s[kPackBlock];                 // per read of the block: some word met a symbol that is not a letter
+    const uint32_t sw = a.stride_words;
+    const uint64_t r0 = (uint64_t)blockIdx.x * rpb, r1 = min(r0 + (uint64_t)rpb, a.n_reads);
+    const uint32_t nr = (uint32_t)(r1 - r0);
+    if (threadIdx.x <= nr) off_s[threadIdx.x] = a.offsets[r0 + threadIdx.x];
+    if (threadIdx.x < rpb) bad_s[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint64_t b0 = off_s[0], b1 = off_s[nr], end = a.offsets[a.n_reads];
+    const uint64_t a0 = b0 & ~15ull;                       // the block's lines from a 16-byte boundary (a.bases is 16-byte aligned)
+    const uint64_t span = b1 - a0;                         // bytes of the block's lines from there
+    const bool fits = span + 48u <= kPackLdsBytes;         // (reads no longer than their records: always; guards a malformed batch)
+    if (fits) {
+        // whole 16-byte units that lie inside the batch (two more than the lines take: the last read's last words are judged with
+        // what follows them), then the batch's last few bytes one by one
+        const uint64_t n16 = (span + 15) / 16 + 2, full16 = (end - a0) / 16;
+        for (uint64_t i = threadIdx.x; i < min(n16, full16); i += kPackBlock) reinterpret_cast<uint4*>(lines)[i] = reinterpret_cast<const uint4*>(a.bases + a0)[i];
+        if (n16 > full16) for (uint64_t i = full16 * 16 + threadIdx.x; i < min(end - a0, n16 * 16); i += kPackBlock) lines[i] = a.bases[a0 + i];
+    }
+    __syncthreads();
+    const uint32_t t = threadIdx.x;
+    const uint32_t rl = tpr == 1u ? t : __umulhi(t, tpr_recip), q0 = (t - rl * tpr) * kPackWpt;   // this thread's read (within the block) and first word
+    const bool mine = rl < nr;
+    const uint64_t o0 = mine ? off_s[rl] : b0, len64 = mine ? off_s[rl + 1] - o0 : 0ull;
+    const uint64_t maxb = min((uint64_t)sw * 16, (uint64_t)65535);
+    const bool simple = mine && fits && len64 >= (uint64_t)a.k && len64 <= maxb;   // a candidate for the slot of its own index
+    const uint32_t len = simple ? (uint32_t)len64 : 0u;
+    uint32_t out[kPackWpt];
+    bool ok = true;
+    {
+        const uint32_t p = (uint32_t)(o0 - a0) + 16u * q0;  // where the thread's letters start in the staged lines
+        const uint32_t* wsrc = reinterpret_cast<const uint32_t*>(lines) + ((simple ? p : 0u) >> 2);
+        const uint32_t sh = p & 3u;
+        uint32_t w[4 * kPackWpt + 1];
+#pragma unroll
+        for (uint32_t i = 0; i <= 4u * kPackWpt; ++i) w[i] = wsrc[i];   // (whatever lies behind the letters is cut off below)
+#pragma unroll
+        for (uint32_t u = 0; u < kPackWpt; ++u) {
+            const uint32_t at = 16u * (q0 + u);
+            const uint32_t nb = len > at ? min(len - at, 16u) : 0u;   // letters of this word
+            out[u] = pack16(__builtin_amdgcn_alignbyte(w[4 * u + 1], w[4 * u], sh), __builtin_amdgcn_alignbyte(w[4 * u + 2], w[4 * u + 1], sh),
+                            __builtin_amdgcn_alignbyte(w[4 * u + 3], w[4 * u + 2], sh), __builtin_amdgcn_alignbyte(w[4 * u + 4], w[4 * u + 3], sh), nb, ok);
+            if (nb == 0u) out[u] = 0u;
         }
     }
+    if (mine && !ok) atomicOr(&bad_s[rl], 1u);
+    if (mine) {
+        uint32_t* dst = a.words + (r0 + rl) * sw + q0;     // (a slot that stays empty holds whatever: its length says 0)
 #pragma unroll
-    for (int off = 32; off; off >>= 1) real += (unsigned int)__shfl_xor((int)real, off);
-    if ((threadIdx.x & 63) == 0 && real) atomicAdd(&n_real_s, real);
+        for (uint32_t u = 0; u < kPackWpt; ++u) if (q0 + u < sw) dst[u] = out[u];
+    }
     __syncthreads();
-    if (threadIdx.x == 0 && n_real_s) atomicAdd(a.n_real, (unsigned long long)n_real_s);
+    if (mine && q0 == 0u) {
+        const bool good = simple && !bad_s[rl];
+        a.lens[r0 + rl] = good ? (uint16_t)len : (uint16_t)0;
+        if (!good) {
+            // (the launcher counted every read as a record that holds a run: one atomic per read that is not, none per block -- a
+            // tally per block was 40,000 additions to one address, 0.5 ms per million reads)
+            atomicAdd(a.n_real, ~0ull);
+            // anything that may still hold a run of k letters: to the byte-by-byte kernel
+            if (len64 >= (uint64_t)a.k) a.work[atomicAdd(a.n_records + 2, 1ull)] = (uint32_t)(r0 + rl);
+        }
+    }
+}
+
+// One thread per listed read (a.work, or every read when there is no list): the runs of letters in it, byte by byte.
+__global__ __launch_bounds__(kPackBlock) void pack_slow_kernel(PackArgs a) {
+    const uint64_t n = a.work ? a.n_records[2] : a.n_reads;
+    const uint64_t maxb = min((uint64_t)a.stride_words * 16, (uint64_t)65535);
+    for (uint64_t i = (uint64_t)blockIdx.x * kPackBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kPackBlock) {
+        const uint64_t r = a.work ? (uint64_t)a.work[i] : i;
+        const uint64_t o0 = a.offsets[r], len = a.offsets[r + 1] - o0;
+        if (!a.work) a.lens[r] = 0;   // the slot of its index stays empty; its records, if any, go behind the n_reads slots
+        const uint8_t* s = a.bases + o0;
+        unsigned long long real = 0;
+        uint64_t start = 0;
+        for (uint64_t p = 0; p <= len; ++p) {
+            if (p < len && acgt_code(s[p]) >= 0) continue;
+            const uint64_t run = p - start;            // maximal ACGT run [start, p)
+            if (run >= (uint64_t)a.k) {
+                uint64_t pos = 0;
+                for (;;) {
+                    const uint64_t take = min(maxb, run - pos);
+                    const unsigned long long rec = atomicAdd(a.n_records, 1ull);
+                    if (rec < a.cap) {
+                        uint32_t* w = a.words + rec * a.stride_words;
+                        uint32_t acc = 0;
+                        for (uint64_t j = 0; j < take; ++j) {
+                            acc |= (uint32_t)acgt_code(s[start + pos + j]) << (2 * (j & 15));
+                            if ((j & 15) == 15) { w[j >> 4] = acc; acc = 0; }
+                        }
+                        if (take & 15) w[take >> 4] = acc;
+                        for (uint64_t j = (take + 15) >> 4; j < a.stride_words; ++j) w[j] = 0;
+                        a.lens[rec] = (uint16_t)take;
+                        ++real;
+                    }
+                    if (pos + take >= run) break;
+                    pos += take - (uint64_t)(a.k - 1);
+                }
+            }
+            start = p + 1;
+        }
+        if (real) atomicAdd(a.n_real, real);
+    }
 }
 
 __global__ void add_u64_kernel(unsigned long long* dst, const unsigned long long* src) { *dst += *src; }
@@ -207,17 +249,25 @@ void launch_add_u64(unsigned long long* dst, const unsigned long long* src, hipS
     hipLaunchKernelGGL(add_u64_kernel, dim3(1), dim3(1), 0, stream, dst, src);
 }
 
-__global__ void set2_u64_kernel(unsigned long long* dst, unsigned long long v0, unsigned long long v1) { dst[0] = v0; dst[1] = v1; }
-// a.n_records[0] = record slots in use when the kernel ends (the n_reads slots of the reads' own indices + what was appended),
-// a.n_real = a.n_records + 1: records that hold a run (what KMC would call its input sequences)
+__global__ void set3_u64_kernel(unsigned long long* dst, unsigned long long v0, unsigned long long v1, unsigned long long v2) { dst[0] = v0; dst[1] = v1; dst[2] = v2; }
+// a.n_records[0] = record slots in use when the kernels end (the n_reads slots of the reads' own indices + what was appended),
+// a.n_real = a.n_records + 1: records that hold a run (what KMC would call its input sequences); [2]: reads on the work list
 void launch_pack_reads(const PackArgs& a0, hipStream_t stream) {
     if (a0.n_reads == 0) return;
     PackArgs a = a0;
     a.n_real = a.n_records + 1;
-    hipLaunchKernelGGL(set2_u64_kernel, dim3(1), dim3(1), 0, stream, a.n_records, (unsigned long long)a.n_reads, 0ull);
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pack_reads_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPackLdsBytes); attr_set = true; }
-    hipLaunchKernelGGL(pack_reads_kernel, dim3((unsigned)((a.n_reads + kPackBlock - 1) / kPackBlock)), dim3(kPackBlock), kPackLdsBytes, stream, a);
+    const bool by_word = a.stride_words <= kPackMaxWords && a.work;
+    // (pack_words_kernel starts from "every read is a record that holds a run" and takes the others off)
+    hipLaunchKernelGGL(set3_u64_kernel, dim3(1), dim3(1), 0, stream, a.n_records, (unsigned long long)a.n_reads, by_word ? (unsigned long long)a.n_reads : 0ull, 0ull);
+    if (by_word) {
+        const uint32_t tpr = (a.stride_words + kPackWpt - 1) / kPackWpt, rpb = (uint32_t)kPackBlock / tpr;
+        const uint32_t recip = (uint32_t)(((1ull << 32) + tpr - 1) / tpr);
+        hipLaunchKernelGGL(pack_words_kernel, dim3((unsigned)((a.n_reads + rpb - 1) / rpb)), dim3(kPackBlock), 0, stream, a, rpb, tpr, recip);
+        hipLaunchKernelGGL(pack_slow_kernel, dim3(64), dim3(kPackBlock), 0, stream, a);   // (the listed reads: usually none)
+    } else {
+        a.work = nullptr;   // long reads: every read byte by byte
+        hipLaunchKernelGGL(pack_slow_kernel, dim3((unsigned)std::min<uint64_t>((a.n_reads + kPackBlock - 1) / kPackBlock, 65535)), dim3(kPackBlock), 0, stream, a);
+    }
 }
 
 // full_kmer_stats: +1 on a k-mer that does not touch the index, in an open-addressing table keyed by

@@ -16,7 +16,8 @@ Run in the build container, it writes small known-answer fixtures to tests/golde
 that the C oracle reproduces them.  Two restatements written separately agreeing on every cell does not pin parity to upstream
 (nothing can without cargo + KMC), but it halves the chance that the GPU path and its checker share one misreading.
 
-usage: python oracle/cross_oracle.py            (re)generate tests/golden/call_*.npz
+usage: python oracle/cross_oracle.py            (re)generate tests/golden/call_{hpv_snp,hpv_reads,sars4_pairs,sars2_k31}.npz
+       python oracle/cross_oracle.py --fuzz N   (re)generate tests/golden/call_fuzz.npz: N (default 200) small fuzz-shaped cases
 """
 import os
 import sys
@@ -90,12 +91,11 @@ def read_fasta(path):
     return recs
 
 
-def build_indexes(k, genomes):                        # build.rs:145-231
+def build_indexes_files(k, files_in):                  # build.rs:145-231 on records already read: [(file stem, [(id line, sequence)])]
     global_index, files = {}, []
-    for file_id, file_path in enumerate(genomes):
-        file_name = os.path.splitext(os.path.basename(file_path))[0]          # Path::file_stem
+    for file_id, (file_name, records) in enumerate(files_in):
         sequences = []
-        for seq_id, (rid, seq) in enumerate(read_fasta(file_path)):
+        for seq_id, (rid, seq) in enumerate(records):
             parts = rid.decode("utf-8", "replace").split()
             sequences.append((parts[0] if parts else "", len(seq), seq))
             for i in range(0, max(len(seq) - k, 0) + 1):                       # 0..=seq_len.saturating_sub(k)
@@ -107,6 +107,10 @@ def build_indexes(k, genomes):                        # build.rs:145-231
                     global_index.setdefault(bucket_id, []).append((file_id, seq_id, i, j, canonical))
         files.append((file_name, sequences))
     return global_index, files
+
+
+def build_indexes(k, genomes):                        # build.rs:145-231 (files through needletail's eyes)
+    return build_indexes_files(k, [(os.path.splitext(os.path.basename(p))[0], read_fasta(p)) for p in genomes])   # Path::file_stem
 
 
 def count_kmers(reads, k, ci, cs=1000000, cx=1000000000):
@@ -182,11 +186,12 @@ def map_kmers(kmers, index, files, k, n_fixed, use_full_kmer, output_maps):   # 
     return results
 
 
-def sample(genomes, k, mates, ci=3, n_fixed=2, use_full_kmer=False):
+def sample(genomes, k, mates, ci=3, n_fixed=2, use_full_kmer=False, in_memory=False):
     """One sample the way call.rs:298-317 runs it: one KMC run per mate file, R1 then R2 mapped into the same arrays.
-    Returns flat numpy arrays in (file, sequence, position, base) order + per-mate stats / kmc stats."""
+    Returns flat numpy arrays in (file, sequence, position, base) order + per-mate stats / kmc stats.
+    in_memory: genomes = [(file stem, [(id line, sequence)])] instead of FASTA paths."""
     import numpy as np
-    index, files = build_indexes(k, genomes)
+    index, files = build_indexes_files(k, genomes) if in_memory else build_indexes(k, genomes)
     maps = initialize_output_maps(files)
     stats = np.zeros((len(mates), len(files), 3), np.uint64)
     present = np.zeros((len(mates), len(files)), np.uint8)
@@ -204,8 +209,101 @@ def sample(genomes, k, mates, ci=3, n_fixed=2, use_full_kmer=False):
     return flat, stats, present, kmc
 
 
+def fuzz_case(np, seed):
+    """One small case in the shape of tools/fuzz_parity.py's: a random genome with direct / reverse-complement repeats and
+    low-complexity stretches, 1-8 files of 1-3 sequences derived from it by substitutions, k from 11 to 31, the window variants
+    (n_fixed 0 / 1 / 2 / 5 incl. the empty window, --use-full-kmer), ci 1-3, reads of 20-200 bases with substitutions, indels,
+    chimeras, foreign reads, N and lower case, on either strand, one or two mate files."""
+    rng = np.random.default_rng(seed)
+    B = b"ACGT"
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    rand_seq = lambda n: bytes(B[i] for i in rng.integers(0, 4, n))
+    k = int(rng.choice([11, 15, 19, 21, 21, 21, 25, 31, 31]))
+    n = int(rng.integers(max(120, 4 * k), 900))
+    g = bytearray(rand_seq(n))
+    for _ in range(int(rng.integers(0, 3))):
+        ln = int(rng.integers(15, 80)); a = int(rng.integers(0, n - ln)); b = int(rng.integers(0, n - ln))
+        seg = bytes(g[a:a + ln])
+        if rng.random() < 0.5: seg = seg.translate(comp)[::-1]
+        g[b:b + ln] = seg
+    if rng.random() < 0.4:
+        ln = int(rng.integers(10, 50)); a = int(rng.integers(0, n - ln))
+        unit = rand_seq(int(rng.integers(1, 3)))
+        g[a:a + ln] = (unit * ln)[:ln]
+    base = bytes(g)
+
+    def mutate(x, n_sub):
+        x = bytearray(x)
+        for p in rng.integers(0, len(x), n_sub):
+            x[p] = B[(B.index(x[p]) + int(rng.integers(1, 4))) & 3]
+        return bytes(x)
+
+    files = []
+    for f in range(int(rng.choice([1, 1, 2, 2, 3, 4, 8]))):
+        x = base if f == 0 else mutate(base, int(rng.integers(0, 12)))
+        cuts = sorted(set([0, len(x)] + [int(c) for c in rng.integers(k, len(x) - k, int(rng.integers(0, 3)))]))
+        seqs = [(("s%d_%d comment" % (f, i)).encode(), x[a:b]) for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])) if b - a >= k]
+        if seqs:
+            files.append(("file%d" % f, seqs))
+    n_fixed = int(rng.choice([2, 2, 2, 0, 1, 5]))
+    full = bool(rng.random() < 0.15)
+    ci = int(rng.choice([1, 1, 2, 3]))
+    src = mutate(base, int(rng.integers(0, 6)))
+    err = float(rng.choice([0.0, 0.005, 0.02, 0.05]))
+    reads = []
+    for _ in range(int(rng.integers(4, 90))):
+        ln = int(rng.integers(20, min(200, len(src))))
+        a = int(rng.integers(0, len(src) - ln + 1))
+        r = bytearray(src[a:a + ln])
+        u = rng.random()
+        if u < 0.05: r = bytearray(rand_seq(ln))
+        elif u < 0.10 and ln > 60:
+            b2 = int(rng.integers(0, len(src) - ln + 1)); r[ln // 2:] = src[b2 + ln // 2:b2 + ln]
+        elif u < 0.15 and ln > 40:
+            p = int(rng.integers(10, ln - 10))
+            r = r[:p] + (bytearray(rand_seq(int(rng.integers(1, 4)))) if rng.random() < 0.5 else bytearray()) + r[p + int(rng.integers(0, 4)):]
+        for p in np.nonzero(rng.random(len(r)) < err)[0]:
+            r[p] = B[(B.index(r[p]) + int(rng.integers(1, 4))) & 3]
+        if rng.random() < 0.04 and len(r) > 5: r[int(rng.integers(0, len(r)))] = ord("N")
+        r = bytes(r)
+        if rng.random() < 0.5: r = r.translate(comp)[::-1]
+        if rng.random() < 0.05: r = r.lower()
+        # (a k-mer seen several times: ci > 1 must not leave everything below the threshold)
+        reads.extend([r] * (int(rng.integers(1, 4)) if ci > 1 else 1))
+    mates = [reads]
+    if rng.random() < 0.3 and len(reads) > 1:
+        h = len(reads) // 2
+        mates = [reads[:h], reads[h:]]
+    return files, k, mates, dict(ci=ci, n_fixed=n_fixed, use_full_kmer=full)
+
+
+def write_fuzz(n_cases, seed0=20261003):
+    """tests/golden/call_fuzz.npz: n_cases small cases (fuzz_case), genomes and reads inside the fixture, results of THIS restatement."""
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {"n_cases": n_cases}
+    for c in range(n_cases):
+        files, k, mates, kw = fuzz_case(np, seed0 + c)
+        flat, stats, present, kmc = sample(files, k, mates, in_memory=True, **kw)
+        nz = [np.nonzero(a)[0].astype(np.uint32) for a in flat]
+        pre = "c%03d_" % c
+        text = b"".join(b"F\t" + fn.encode() + b"\n" + b"".join(b"S\t" + rid + b"\t" + sq + b"\n" for rid, sq in seqs) for fn, seqs in files)
+        out.update({pre + "files": np.frombuffer(text, np.uint8), pre + "k": k, pre + "n_fixed": kw["n_fixed"], pre + "full": int(kw["use_full_kmer"]),
+                    pre + "ci": kw["ci"], pre + "n_mates": len(mates), pre + "reads0": np.frombuffer(b"\n".join(mates[0]), np.uint8),
+                    pre + "reads1": np.frombuffer(b"\n".join(mates[1]) if len(mates) > 1 else b"", np.uint8), pre + "n_cells4": len(flat[0]),
+                    pre + "stats": stats, pre + "present": present, pre + "kmc": kmc})
+        for name, a, z in zip(("fwd_depth", "rev_depth", "fwd_nk", "rev_nk"), flat, nz):
+            out[pre + name + "_idx"], out[pre + name + "_val"] = z, a[z]
+        print("case %3d k=%2d n_fixed=%d full=%d ci=%d files=%d cells=%d reads=%s: non-zero cells %s, stats %s" %
+              (c, k, kw["n_fixed"], kw["use_full_kmer"], kw["ci"], len(files), len(flat[0]) // 4, [len(m) for m in mates], [len(x) for x in nz],
+               stats.sum(axis=0).tolist()[:3]), flush=True)
+    np.savez_compressed(os.path.join(root, "tests", "golden", "call_fuzz.npz"), **out)
+
+
 def main():
     import numpy as np
+    if len(sys.argv) > 1 and sys.argv[1] == "--fuzz":
+        return write_fuzz(int(sys.argv[2]) if len(sys.argv) > 2 else 200)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     from bronko_amd import synth   # (inputs only: the seeded read generator)

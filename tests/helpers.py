@@ -109,6 +109,29 @@ def hpv_reads(n, seed, read_len=150, err=0.005, with_n=False, ragged=False):
     return reads
 
 
+# ---- the committed fixtures of the second restatement (oracle/cross_oracle.py) ------------------------------------------------
+def expand_sparse(z, name, pre=""):
+    a = np.zeros(int(z[pre + "n_cells4"]), np.uint64)
+    a[z[pre + name + "_idx"]] = z[pre + name + "_val"]
+    return a
+
+
+def fuzz_fixture_case(z, c):
+    """Case c of tests/golden/call_fuzz.npz: (files [(file name, [(sequence id line, sequence)])], k, mates, keyword arguments, prefix)."""
+    pre = "c%03d_" % c
+    files = []
+    for line in bytes(z[pre + "files"]).split(b"\n"):
+        if line.startswith(b"F\t"):
+            files.append((line[2:].decode(), []))
+        elif line.startswith(b"S\t"):
+            rid, seq = line[2:].split(b"\t")
+            files[-1][1].append((rid, seq))
+    n_mates = int(z[pre + "n_mates"])
+    mates = [bytes(z[pre + "reads%d" % m]).split(b"\n") for m in range(n_mates)]
+    kw = dict(ci=int(z[pre + "ci"]), n_fixed=int(z[pre + "n_fixed"]), use_full_kmer=bool(int(z[pre + "full"])))
+    return files, int(z[pre + "k"]), mates, kw, pre
+
+
 # ---- exact (unwrapped) LCB bucket ranks: test-side restatement used to construct k = 31 aliasing reads ----------
 def lcb_rank(v, pos, k):
     """1-based lexicographic rank of (v, pos) among all (k-mer with an A at `pos`, position) pairs, ordered by k-mer

@@ -24,6 +24,17 @@ def test_library_exports_every_declared_symbol():
         assert L.bk_abi_version() == 7
 
 
+def test_integration_md_declares_every_symbol():
+    """The Rust `extern "C"` block a bronko maintainer would add names exactly the functions the header declares."""
+    hdr = open(os.path.join(ROOT, "include", "bronko_hip.h")).read()
+    declared = set(re.findall(r"\b(bk_[a-z_0-9]+)\s*\(", hdr))
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = md[md.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    rust = set(re.findall(r"pub fn (bk_[a-z_0-9]+)\s*\(", block))
+    assert rust == declared, (sorted(declared - rust), sorted(rust - declared))
+
+
 def test_release_library_reads_no_environment_variable():
     """The BK_* testing / measurement aids are compiled into libbronko_hip_testing.so only."""
     rel = open(_ffi.LIB_PATH, "rb").read()

@@ -304,6 +304,7 @@ struct bk_engine {
     DevBuf<unsigned int> ov;
     DevBuf<unsigned long long> ov_n;
     uint32_t ov_par = 0;                    // parity of the next scan_items launch (which of the two overflow counts it appends to)
+    DevBuf<unsigned int> lean_e_list, lean_n_list;   // bk_finalize_lean.hip: the reference k-mers finalize_ecell_kernel leaves to finalize_exact_kernel
     bool v_clean[2] = {false, false};       // the V part of the mate file's plane is known to be all zero (dense planes between samples)
     int item_v_mode = -1;                   // testing aid (BK_ITEM_V_MODE): force BinArgs::v_mode
     DevBuf<unsigned int> n_bits, n_any;     // scan -> Level 2: one bit per k-mer of each record of a launch / per record (bk_kernels.h ScanArgs): the N runs; all zero between launches
@@ -456,6 +457,7 @@ static int alloc_sample_state(bk_engine* e) {
         BK_HIP(e->deferred_n.alloc(e->deferred.n));
         for (int m = 0; m < 2; m++) BK_HIP(hipMemset(e->counters[m].p, 0, std::max<size_t>(e->counters[m].n, 1) * sizeof(unsigned long long)));
     }
+    if (e->n_files == 1 && !e->sparse && e->n_full > 0) { BK_HIP(e->lean_e_list.alloc((size_t)e->n_full)); BK_HIP(e->lean_n_list.alloc(8)); BK_HIP(hipMemset(e->lean_n_list.p, 0, 8 * sizeof(unsigned int))); }
     BK_HIP(e->pileup.alloc(e->total_cells * 4 * 4));
     BK_HIP(e->stats.alloc((size_t)2 * e->n_files * 3));
     BK_HIP(e->present.alloc((size_t)2 * e->n_files));
@@ -2157,6 +2159,8 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             // the reduce kernel of the mate file's last statistics pass (it runs behind K2e, the E part's only reader in that pass;
             // a second, votes-only pass reads it again: then the memset below does it)
             const bool ride = clean_dense && !two_pass && e->fin_partials.p && e->plane_used[m];
+            a.no_lean = test_env("BK_NO_LEAN_FINALIZE") != nullptr;
+            a.lean_e_list = e->lean_e_list.p; a.lean_n_list = e->lean_n_list.p;
             a.zero_e = ride ? e->counters[m].p : nullptr;
             a.zero_e_n = ride ? (size_t)std::min<uint64_t>(e->v_off, e->plane_len) : 0;
             if (ride) e->plane_used[m] = false;

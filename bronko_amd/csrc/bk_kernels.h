@@ -147,6 +147,9 @@ struct FinalizeArgs {
     int mode;
     const int* sel;
     int sel_file;                   // = *sel, read by each kernel of the second pass
+    unsigned int* lean_e_list;      // bk_finalize_lean.hip: [n_full] the reference k-mers finalize_ecell_kernel leaves to finalize_exact_kernel (repeats), and
+    unsigned int* lean_n_list;      //   [8] their number at [2] (the layout of n_list); null: no regional kernels
+    int no_lean;                    // testing aid (BK_NO_LEAN_FINALIZE): the general K2a / K2e even where the regional kernels of bk_finalize_lean.hip apply
     unsigned long long* zero_e;     // launch_finalize's last kernel also zeroes zero_e[0, zero_e_n): the plane's E part behind the sample (or null)
     size_t zero_e_n;
 };
@@ -237,6 +240,10 @@ void launch_ktab_import(const unsigned long long* in_keys, const unsigned int* i
 void launch_ktab_totals_to_kstats(unsigned long long* ktab_out, unsigned long long* kstats, int n_mates, hipStream_t stream);
 uint32_t ktab_fill_words();   // tallies of new keys behind the overflow word: ktab_out[8 ..]
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
+// K2a / K2e organised by region of the reference (bk_finalize_lean.hip): one genome file, dense planes, one pass
+bool finalize_lean_ok(const FinalizeArgs& a);
+unsigned launch_finalize_lean_variant(const FinalizeArgs& a, hipStream_t stream);   // returns its grid (rows of FinalizeArgs::partials it writes)
+unsigned launch_finalize_lean_exact(const FinalizeArgs& a, hipStream_t stream);     // (a.row_exact = first row)
 // sparse finalize: touch bitmaps -> lists (the bitmaps are cleared on the way); lists -> their counters zeroed again
 void launch_expand_touched_blocks(unsigned int* touch_b, uint32_t n_blocks, const uint2* cell_blk, unsigned int* touch_v, uint32_t span, uint64_t n_q, hipStream_t stream);
 void launch_compact_touched(unsigned int* touch_v, uint64_t n_rows, unsigned int* touch_p, uint64_t n_prows, unsigned int* touch_e, uint64_t n_ids,

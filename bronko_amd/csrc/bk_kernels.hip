@@ -29,6 +29,7 @@
 #include "bk_device.h"
 #include "bk_kernels.h"
 #include "bk_scan_common.h"
+#include "bk_finalize_common.h"
 
 namespace bk {
 
@@ -1802,23 +1803,6 @@ void launch_fold(const FoldArgs& f, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------ K2
-// The vote of call.rs:1327-1384 for one BucketInfo.
-__device__ __forceinline__ void vote(const FinalizeArgs& a, const DevEntry& e, uint64_t c, uint32_t isrc, int k, unsigned long long v) {
-    if (a.mode == 1 || (a.mode == 2 && (int)e.file != a.sel_file)) return;   // statistics pass / votes for the selected genome only
-    uint32_t bit_idx;
-    bool forward;
-    if (e.canonical) {
-        bit_idx = ((uint32_t)(c >> (2 * e.idx)) & 3u) ^ 3u;
-        forward = isrc != 0;
-    } else {
-        bit_idx = (uint32_t)(c >> (2 * (k - 1 - e.idx))) & 3u;
-        forward = isrc == 0;
-    }
-    const size_t cell = (size_t)e.cell * 4 + bit_idx;
-    atomicAdd(a.pileup + (forward ? 2 : 3) * a.plane + cell, 1ull);   // #kmers  += 1
-    atomicMax(a.pileup + (forward ? 0 : 1) * a.plane + cell, v);      // depth = max(depth, n)
-}
-
 // Second pass of bk_params.pileup_selected_only: the entries of a bucket are sorted by genome file -- the first one of `file`
 // (or cnt), by bisection
 __device__ __forceinline__ uint32_t first_of_file(const DevEntry* __restrict__ ent, uint32_t cnt, int file) {
@@ -1851,48 +1835,6 @@ __device__ __forceinline__ void tally_files(const uint4& fb, uint32_t* lstats, u
         const uint32_t f = w * 32u + lane;
         if (lane < 32u && acc && f < n_files) {
             if (ATOMIC) atomicAdd(&lstats[f * 3u + COL], (uint32_t)acc); else lstats[f * 3u + COL] += (uint32_t)acc;
-        }
-    }
-}
-
-// lstats[idx] += 1 from every active lane: the lanes of a wave walk the entry lists of their buckets in step, and with many
-// genomes that share a k-mer they name the same genome at the same time -- one LDS atomic for all lanes that agree with the
-// first active one instead of up to 64 on one address
-__device__ __forceinline__ void tally(uint32_t* lstats, uint32_t idx) {
-    const unsigned long long active = __ballot(true);
-    const int leader = __builtin_ctzll(active);
-    const uint32_t lidx = (uint32_t)__shfl((int)idx, leader);
-    const bool same = idx == lidx;
-    const unsigned long long sm = __ballot(same);
-    if (!same) atomicAdd(&lstats[idx], 1u);
-    else if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&lstats[idx], (uint32_t)__popcll(sm));
-}
-
-// End of a finalize workgroup: per-genome tallies (LDS) and the kept / distinct k-mer tallies either go to this
-// workgroup's row of `partials` (no atomics; finalize_reduce adds the rows up) or, without a partials buffer, straight
-// to the global words.  Thousands of workgroups doing same-address atomics would serialise at ~12 ns each.
-__device__ __forceinline__ void finalize_epilogue(const FinalizeArgs& a, const uint32_t* lstats, unsigned int kept, unsigned int distinct,
-                                                  uint32_t* scratch2 /* LDS, 2 words, zeroed */, int row) {
-    const int n3 = a.ix.n_files * 3;
-#pragma unroll
-    for (int off = 32; off; off >>= 1) { kept += (unsigned int)__shfl_xor((int)kept, off); distinct += (unsigned int)__shfl_xor((int)distinct, off); }
-    if ((threadIdx.x & 63) == 0) { if (kept) atomicAdd(&scratch2[0], kept); if (distinct) atomicAdd(&scratch2[1], distinct); }
-    __syncthreads();
-    if (a.partials) {
-        uint32_t* out = a.partials + (size_t)row * (n3 + 2);
-        for (int g = threadIdx.x; g < n3; g += blockDim.x) out[g] = lstats[g];
-        if (threadIdx.x == 0) { out[n3] = scratch2[0]; out[n3 + 1] = scratch2[1]; }
-    } else {
-        for (int g = threadIdx.x; g < a.ix.n_files; g += blockDim.x) {
-            const uint32_t pf = lstats[g * 3], vr = lstats[g * 3 + 1], un = lstats[g * 3 + 2];
-            if (pf) atomicAdd(a.stats + (size_t)g * 3 + 0, (unsigned long long)pf);
-            if (vr) atomicAdd(a.stats + (size_t)g * 3 + 1, (unsigned long long)vr);
-            if (un) atomicAdd(a.stats + (size_t)g * 3 + 2, (unsigned long long)un);
-            if (pf | vr) a.present[g] = 1;
-        }
-        if (threadIdx.x == 0) {
-            if (scratch2[0] && a.kept_total) atomicAdd(a.kept_total, (unsigned long long)scratch2[0]);
-            if (scratch2[1] && a.distinct_total) atomicAdd(a.distinct_total, (unsigned long long)scratch2[1]);
         }
     }
 }
@@ -1978,13 +1920,6 @@ __device__ __forceinline__ void vt_flush(const VoteTable& vt, uint32_t par, cons
     }
     __syncthreads();
     if (threadIdx.x == 0) { vt.n_used[0] = 0u; vt.n_used[1] = 0u; }
-}
-
-// Reverse complement of a k-mer (first base on top, like every canonical k-mer here).
-__device__ __forceinline__ uint64_t revcomp_kmer(uint64_t c, int k) {
-    const uint64_t t = ~c;
-    const uint64_t r = ((uint64_t)rev2_32((uint32_t)t) << 32) | rev2_32((uint32_t)(t >> 32));
-    return r >> (64 - 2 * k);
 }
 
 // The k-mer a V counter stands for: canonical form c (in the orientation of its reference neighbour), orientation the reads
@@ -2941,6 +2876,23 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_votes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
+    // (few genomes: multi-bucket k-mers are rare, a small grid starts and ends quickly; many: one k-mer in eight takes this path)
+    const unsigned b_gen = (unsigned)std::min<size_t>(a.ix.n_files >= 8 ? kFinGeneralBlocks : kFinGeneralBlocks / 32, 256 * std::max<size_t>(1, (160u * 1024u) / lds));
+    unsigned b_v = b_var, b_e = 0;
+    const bool lean = finalize_lean_ok(a) && (uint64_t)(a.ix.n_full + (uint32_t)a.ix.v_span) / 64 + (uint64_t)a.ix.total_cells / 256 + 2 + 64 + b_gen <= finalize_partial_rows();
+    if (lean) {
+        // one genome file, dense planes: K2a and K2e by region of the reference (bk_finalize_lean.hip)
+        b_v = launch_finalize_lean_variant(a, stream);
+        a.row_exact = (int)b_v;
+        b_e = launch_finalize_lean_exact(a, stream);
+        // ... and the reference k-mers it listed (repeats: not "simple"), a thread per (counter, bucket)
+        FinalizeArgs l = a;
+        l.e_list = a.lean_e_list; l.n_list = a.lean_n_list;
+        l.row_exact = (int)(b_v + b_e);
+        const unsigned b_list = 64;
+        hipLaunchKernelGGL(finalize_exact_kernel, dim3(b_list), dim3(256), lds_votes, stream, l);
+        b_e += b_list;
+    } else {
     if (a.ix.slot_files) hipLaunchKernelGGL(finalize_variant_kernel<true>, dim3(b_var), dim3(256), lds_votes, stream, a);
     else hipLaunchKernelGGL(finalize_variant_kernel<false>, dim3(b_var), dim3(256), lds_votes, stream, a);
     // K2e
@@ -2952,14 +2904,14 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     else if (a.mode == 0 && a.e_list && a.file_cell_lo && a.ix.id_own_files && a.ix.cell_file && a.ix.estat_files && a.ix.id_rest_off && a.ix.total_cells)   // (finalize_exact_kernel: own_all)
         hipLaunchKernelGGL(finalize_exact_own_kernel, dim3((a.ix.total_cells + kOwnCells - 1) / kOwnCells), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(finalize_exact_kernel, dim3(b_ex), dim3(256), lds_votes, stream, a);
+    b_e = b_ex;
+    }
     // K2b (deferred k-mers only; the kernel reads their number on the device)
-    // (few genomes: multi-bucket k-mers are rare, a small grid starts and ends quickly; many: one k-mer in eight takes this path)
-    unsigned b_gen = (unsigned)std::min<size_t>(a.ix.n_files >= 8 ? kFinGeneralBlocks : kFinGeneralBlocks / 32, 256 * std::max<size_t>(1, (160u * 1024u) / lds));
-    a.row_general = (int)(b_var + b_ex);
+    a.row_general = (int)(b_v + b_e);
     hipLaunchKernelGGL(finalize_general_kernel, dim3(b_gen), dim3(64), lds, stream, a);
     if (a.partials && a.mode != 2) {
         const int cols = a.ix.n_files * 3 + 2;
-        hipLaunchKernelGGL(finalize_reduce_kernel, dim3((unsigned)cols), dim3(256), 0, stream, a, (int)(b_var + b_ex + b_gen), a.zero_e, a.zero_e_n);
+        hipLaunchKernelGGL(finalize_reduce_kernel, dim3((unsigned)cols), dim3(256), 0, stream, a, (int)(b_v + b_e + b_gen), a.zero_e, a.zero_e_n);
     }
 }
 

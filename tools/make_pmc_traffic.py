@@ -12,9 +12,16 @@ import bench  # noqa: E402
 
 hbm = json.load(open(sys.argv[1]))
 sq = json.load(open(sys.argv[2]))
-scan_h = next(v for k, v in hbm.items() if "scan_count" in k)
-scan_s = next(v for k, v in sq.items() if "scan_count" in k)
-out = {"build_id": bench.source_build_id(), "config": 2, "workload_reads": 1000000, "read_len": 150, "kernel": "scan_count_kernel",
+# The correction factors are MEASURED (tools/micro/fetch_calibrate.hip -> profiles/r04_fetch_calibration.json): FETCH_SIZE tallies
+# every 128-byte request as 64 bytes whatever the access pattern -- streaming 16-, 8- and 4-byte-per-lane loads all report exactly
+# half of what they read, a scattered 8- or 16-byte load reports 64 bytes for its 128-byte request -- so traffic = 2 x FETCH_SIZE
+# for every kernel here; WRITE_SIZE is exact for streaming stores and 32 bytes per scattered 8-byte atomic (the sector written
+# back), i.e. it is the traffic as it stands.  pmc_summary.py applies exactly these two factors (x 2, x 1).
+cal = os.path.join(ROOT, "profiles", "r04_fetch_calibration.json")
+scan_h = next(v for k, v in hbm.items() if "scan_items" in k or "scan_count" in k)
+scan_s = next(v for k, v in sq.items() if "scan_items" in k or "scan_count" in k)
+out = {"build_id": bench.source_build_id(), "config": 2, "workload_reads": 1000000, "read_len": 150, "kernel": next(k for k in hbm if "scan_items" in k or "scan_count" in k).split("(")[0].split("::")[-1].split("<")[0],
+       "fetch_write_calibration": os.path.relpath(cal, ROOT) if os.path.exists(cal) else None,
        "hbm_read_bytes_per_launch": scan_h["hbm_read_bytes"], "hbm_write_bytes_per_launch": scan_h["hbm_write_bytes"],
        "traffic_bytes_per_launch": scan_h["hbm_read_bytes"] + scan_h["hbm_write_bytes"],
        "valu_wave_insts_per_launch": scan_s.get("SQ_INSTS_VALU"), "salu_wave_insts_per_launch": scan_s.get("SQ_INSTS_SALU"),

@@ -7,6 +7,7 @@
 // run on the GPU through the C ABI of include/bronko_hip.h; everything else here is host code.
 #include <zlib.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <chrono>
 #include <condition_variable>
@@ -24,6 +25,9 @@
 
 #include <sys/stat.h>
 #include <unistd.h>
+
+#include <hip/hip_runtime_api.h>   // streams and buffers of the one-sample-over-several-GPUs path (RCCL collectives on the engines' streams)
+#include <rccl/rccl.h>
 
 #include "../../include/bronko_hip.h"
 #include "caller.hpp"
@@ -356,8 +360,10 @@ void parse_fastq(const std::string& path, BatchQueue& out) {
     cur.last = true;
     out.put(std::move(cur));
 }
-uint64_t push_fastqs(bk_engine* e, const std::vector<std::string>& mates) {
+// engs: one engine (the sample's reads all go there) or one per GPU of a sharded sample -- batches are dealt to them in turn
+uint64_t push_fastqs(const std::vector<bk_engine*>& engs, const std::vector<std::string>& mates) {
     const size_t nm = mates.size();
+    size_t n_batches = 0;
     std::vector<BatchQueue> queues(nm);
     std::vector<std::thread> readers;
     for (size_t m = 0; m < nm; m++) readers.emplace_back(parse_fastq, std::cref(mates[m]), std::ref(queues[m]));
@@ -370,7 +376,7 @@ uint64_t push_fastqs(bk_engine* e, const std::vector<std::string>& mates) {
             FastqBatch b = queues[m].take();
             if (!b.error.empty() && error.empty()) error = b.error;
             if (error.empty() && b.off.size() > 1) {
-                hip_check(bk_push_reads_ascii(e, (int)m, reinterpret_cast<const uint8_t*>(b.buf.data()), b.off.data(), b.off.size() - 1), "bk_push_reads_ascii");
+                hip_check(bk_push_reads_ascii(engs[n_batches++ % engs.size()], (int)m, reinterpret_cast<const uint8_t*>(b.buf.data()), b.off.data(), b.off.size() - 1), "bk_push_reads_ascii");
                 n_reads += b.off.size() - 1;
             }
             if (b.last) { done[m] = true; left--; }
@@ -380,6 +386,120 @@ uint64_t push_fastqs(bk_engine* e, const std::vector<std::string>& mates) {
     for (auto& t : readers) t.join();
     if (!error.empty()) throw std::runtime_error(error);
     return n_reads;
+}
+
+// ---- one sample over several GPUs (BASELINE config 4: one 200 M-read sample, eight GPUs) ---------------------
+// The reads' batches are dealt to one engine per GPU; what is additive -- the k-mer occurrence counter planes -- is
+// reduce-scattered by RCCL over xGMI on the engines' own streams (the engine packs a plane to 16- or 32-bit elements first,
+// bk_shard_transport), every GPU maps its part (bk_sample_finalize_shard), and the small results are combined: max of the depth
+// planes, sums of the #k-mer planes and of the statistics.  Pileups of read shards are never summed (thresholds and max are not
+// linear).  One process, one communicator per device (ncclCommInitAll), collectives grouped over the devices.
+void nccl_check(ncclResult_t r, const char* what) {
+    if (r != ncclSuccess) die("bronko::call", std::string(what) + ": " + ncclGetErrorString(r));
+}
+void hipx(hipError_t r, const char* what) {
+    if (r != hipSuccess) die("bronko::call", std::string(what) + ": " + hipGetErrorString(r));
+}
+struct ShardGroup {
+    std::vector<int> devices;
+    std::vector<bk_engine*> engs;
+    std::vector<ncclComm_t> comms;
+    std::vector<hipStream_t> streams;
+    int n() const { return (int)engs.size(); }
+};
+// narrowest width at which the reduce-scatter over n ranks is exact (bronko_amd/dist.py::pick_width; include/bronko_hip.h)
+int pick_width(uint64_t max_e, uint64_t max_v, int n) {
+    if (max_v * (uint64_t)n <= 32767 && max_e < (1ull << 32)) return 16;
+    if (std::max(max_e, max_v) * (uint64_t)n <= 2147483647ull) return 32;
+    return 64;
+}
+// between the last push and the finalize of a sample whose batches went to g.engs in turn
+void sharded_finalize(ShardGroup& g, int n_mates, uint64_t cells4) {
+    const int S = g.n();
+    // KMC's distinct / counted k-mer totals (full_kmer_stats): every k-mer that touches no bucket moves to its owner GPU
+    {
+        std::vector<void*> keys((size_t)S), cnts((size_t)S), rkeys((size_t)S, nullptr), rcnts((size_t)S, nullptr);
+        std::vector<std::vector<uint64_t>> off((size_t)S, std::vector<uint64_t>((size_t)S + 1));
+        for (int s = 0; s < S; s++) hip_check(bk_kmer_table_partition(g.engs[(size_t)s], S, &keys[(size_t)s], &cnts[(size_t)s], off[(size_t)s].data()), "bk_kmer_table_partition");
+        std::vector<uint64_t> n_in((size_t)S, 0);
+        for (int r = 0; r < S; r++) for (int s = 0; s < S; s++) n_in[(size_t)r] += off[(size_t)s][(size_t)r + 1] - off[(size_t)s][(size_t)r];
+        for (int r = 0; r < S; r++) {
+            hipx(hipSetDevice(g.devices[(size_t)r]), "hipSetDevice");
+            hipx(hipMalloc(&rkeys[(size_t)r], std::max<uint64_t>(n_in[(size_t)r], 1) * 8), "hipMalloc");
+            hipx(hipMalloc(&rcnts[(size_t)r], std::max<uint64_t>(n_in[(size_t)r], 1) * 4), "hipMalloc");
+        }
+        std::vector<uint64_t> at((size_t)S, 0);   // fill of each receiver
+        nccl_check(ncclGroupStart(), "ncclGroupStart");
+        for (int s = 0; s < S; s++)
+            for (int r = 0; r < S; r++) {
+                const uint64_t n = off[(size_t)s][(size_t)r + 1] - off[(size_t)s][(size_t)r], o = off[(size_t)s][(size_t)r];
+                if (!n) continue;
+                uint64_t* dk = static_cast<uint64_t*>(rkeys[(size_t)r]) + at[(size_t)r];
+                uint32_t* dc = static_cast<uint32_t*>(rcnts[(size_t)r]) + at[(size_t)r];
+                at[(size_t)r] += n;
+                if (s == r) {   // (its own group: a copy on its stream)
+                    hipx(hipSetDevice(g.devices[(size_t)s]), "hipSetDevice");
+                    hipx(hipMemcpyAsync(dk, static_cast<uint64_t*>(keys[(size_t)s]) + o, n * 8, hipMemcpyDeviceToDevice, g.streams[(size_t)s]), "hipMemcpyAsync");
+                    hipx(hipMemcpyAsync(dc, static_cast<uint32_t*>(cnts[(size_t)s]) + o, n * 4, hipMemcpyDeviceToDevice, g.streams[(size_t)s]), "hipMemcpyAsync");
+                    continue;
+                }
+                nccl_check(ncclSend(static_cast<uint64_t*>(keys[(size_t)s]) + o, n, ncclUint64, r, g.comms[(size_t)s], g.streams[(size_t)s]), "ncclSend");
+                nccl_check(ncclSend(static_cast<uint32_t*>(cnts[(size_t)s]) + o, n, ncclUint32, r, g.comms[(size_t)s], g.streams[(size_t)s]), "ncclSend");
+                nccl_check(ncclRecv(dk, n, ncclUint64, s, g.comms[(size_t)r], g.streams[(size_t)r]), "ncclRecv");
+                nccl_check(ncclRecv(dc, n, ncclUint32, s, g.comms[(size_t)r], g.streams[(size_t)r]), "ncclRecv");
+            }
+        nccl_check(ncclGroupEnd(), "ncclGroupEnd");
+        for (int r = 0; r < S; r++) hip_check(bk_kmer_table_replace(g.engs[(size_t)r], rkeys[(size_t)r], rcnts[(size_t)r], n_in[(size_t)r]), "bk_kmer_table_replace");
+        for (int r = 0; r < S; r++) {   // (the table was rebuilt from them on the engine's stream)
+            hipx(hipSetDevice(g.devices[(size_t)r]), "hipSetDevice");
+            hipx(hipStreamSynchronize(g.streams[(size_t)r]), "hipStreamSynchronize");
+            hipx(hipFree(rkeys[(size_t)r]), "hipFree"); hipx(hipFree(rcnts[(size_t)r]), "hipFree");
+        }
+    }
+    for (int m = 0; m < n_mates; m++) {
+        // the narrowest exact width: the largest E count and |V element| over all GPUs' planes
+        uint64_t max_e = 0, max_v = 0;
+        std::vector<void*> dmax((size_t)S);
+        for (int s = 0; s < S; s++) hip_check(bk_shard_measure(g.engs[(size_t)s], m, &dmax[(size_t)s]), "bk_shard_measure");
+        for (int s = 0; s < S; s++) {
+            uint64_t mx[2] = {0, 0};
+            hipx(hipSetDevice(g.devices[(size_t)s]), "hipSetDevice");
+            hipx(hipMemcpyAsync(mx, dmax[(size_t)s], sizeof mx, hipMemcpyDeviceToHost, g.streams[(size_t)s]), "hipMemcpyAsync");
+            hipx(hipStreamSynchronize(g.streams[(size_t)s]), "hipStreamSynchronize");
+            max_e = std::max(max_e, mx[0]); max_v = std::max(max_v, mx[1]);
+        }
+        int width = pick_width(max_e, max_v, S);
+        std::vector<void*> send((size_t)S), recv((size_t)S);
+        uint64_t part_bytes = 0;
+        for (int s = 0; s < S; s++) {
+            int rc = bk_shard_transport(g.engs[(size_t)s], m, S, width, &send[(size_t)s], &part_bytes, &recv[(size_t)s]);
+            if (rc != 0 && width == 16 && s == 0) { width = 32; rc = bk_shard_transport(g.engs[0], m, S, width, &send[0], &part_bytes, &recv[0]); }   // (16 does not shrink this plane at S shards)
+            hip_check(rc, "bk_shard_transport");
+        }
+        const ncclDataType_t dt = width == 64 ? ncclInt64 : ncclInt32;
+        const size_t count = (size_t)(part_bytes / (width == 64 ? 8 : 4));
+        nccl_check(ncclGroupStart(), "ncclGroupStart");
+        for (int s = 0; s < S; s++) nccl_check(ncclReduceScatter(send[(size_t)s], recv[(size_t)s], count, dt, ncclSum, g.comms[(size_t)s], g.streams[(size_t)s]), "ncclReduceScatter");
+        nccl_check(ncclGroupEnd(), "ncclGroupEnd");
+        for (int s = 0; s < S; s++) hip_check(bk_shard_received(g.engs[(size_t)s], m, s, S, width), "bk_shard_received");
+    }
+    for (int s = 0; s < S; s++) hip_check(bk_sample_finalize_shard(g.engs[(size_t)s], n_mates, s, S), "bk_sample_finalize_shard");
+    // the small results: depth = max, #k-mers and statistics add up
+    std::vector<void*> pile((size_t)S), sums((size_t)S);
+    uint64_t n_sums = 0;
+    for (int s = 0; s < S; s++) {
+        hip_check(bk_pileup_device_ptr(g.engs[(size_t)s], &pile[(size_t)s]), "bk_pileup_device_ptr");
+        hip_check(bk_shard_sums_device_ptr(g.engs[(size_t)s], &sums[(size_t)s], &n_sums), "bk_shard_sums_device_ptr");
+    }
+    nccl_check(ncclGroupStart(), "ncclGroupStart");
+    for (int s = 0; s < S; s++) {
+        uint64_t* p = static_cast<uint64_t*>(pile[(size_t)s]);
+        nccl_check(ncclAllReduce(p, p, (size_t)(2 * cells4), ncclUint64, ncclMax, g.comms[(size_t)s], g.streams[(size_t)s]), "ncclAllReduce");
+        nccl_check(ncclAllReduce(p + 2 * cells4, p + 2 * cells4, (size_t)(2 * cells4), ncclUint64, ncclSum, g.comms[(size_t)s], g.streams[(size_t)s]), "ncclAllReduce");
+        nccl_check(ncclAllReduce(sums[(size_t)s], sums[(size_t)s], (size_t)n_sums, ncclUint64, ncclSum, g.comms[(size_t)s], g.streams[(size_t)s]), "ncclAllReduce");
+    }
+    nccl_check(ncclGroupEnd(), "ncclGroupEnd");
+    for (int s = 0; s < S; s++) hip_check(bk_sample_merge_shards(g.engs[(size_t)s]), "bk_sample_merge_shards");
 }
 
 int run_call(const Args& a) {
@@ -437,8 +557,16 @@ int run_call(const Args& a) {
     }
     if (devices.empty()) devices.push_back(0);
     const size_t n_samples_total = a.reads.size() + a.first_pairs.size();
+    // Fewer samples than GPUs (BASELINE config 4: ONE 200 M-read sample, eight GPUs): a sample's batches are dealt to all of them and
+    // the counter planes are reduce-scattered by RCCL (sharded_finalize above).  BRONKO_SHARD=1 / 0 forces / forbids it (1 with a single
+    // GPU runs every collective on a communicator of one rank).  The shard count is a power of two (it divides 64).
+    std::vector<int> shard_devices;
+    for (int d : devices) if (std::find(shard_devices.begin(), shard_devices.end(), d) == shard_devices.end()) shard_devices.push_back(d);
+    bool shard_mode = shard_devices.size() >= 2 && n_samples_total < shard_devices.size();
+    if (const char* sh = getenv("BRONKO_SHARD")) shard_mode = atoi(sh) != 0;
+    { size_t S = 1; while (S * 2 <= std::min<size_t>(shard_devices.size(), 64)) S *= 2; shard_devices.resize(S); }
     if (devices.size() > std::max<size_t>(n_samples_total, 1)) devices.resize(std::max<size_t>(n_samples_total, 1));   // no more lanes than samples
-    auto make_engine = [&](int device, Engine& out) {
+    auto make_engine = [&](int device, Engine& out, bool selected_only = true) {
         std::vector<int32_t> n_seqs;
         std::vector<uint64_t> seq_lens;
         std::vector<const uint8_t*> seqs;
@@ -453,12 +581,35 @@ int run_call(const Args& a) {
         bk_params p;
         bk_params_default(&p);
         p.n_fixed = (int32_t)a.n_fixed; p.use_full_kmer = a.use_full_kmer ? 1 : 0; p.ci = (uint64_t)a.min_kmers;
-        p.pileup_selected_only = 1;   // calls, pileup TSV and overview read the selected genome's rows only (call.rs:229-293)
+        p.pileup_selected_only = selected_only ? 1 : 0;   // calls, pileup TSV and overview read the selected genome's rows only (call.rs:229-293)
         p.full_kmer_stats = 1;   // KMC's "unique counted k-mers" feeds num_unmapped_kmers and the <0.2 warning (call.rs:242-248)
         if (const char* tl = getenv("BRONKO_KMER_TABLE_LOG2")) p.kmer_table_log2 = (uint32_t)atoi(tl);
         p.device = device;
         hip_check(bk_engine_create(&d, &p, &out.e), "bk_engine_create");
     };
+    ShardGroup shards;
+    std::vector<Engine> shard_engines;
+    if (shard_mode) {
+        // one engine per GPU, every genome's rows (the two-pass selected-only finalize cannot be sharded: the selection needs the
+        // statistics of all parts first); an index so large that its planes are kept sparse cannot be sharded at all
+        shard_engines.resize(shard_devices.size());
+        std::vector<std::thread> th;
+        for (size_t q = 0; q < shard_devices.size(); q++) th.emplace_back([&, q] { make_engine(shard_devices[q], shard_engines[q], ix.files.size() <= 1); });
+        for (auto& t : th) t.join();
+        if (bk_counter_len(shard_engines[0].e) >= (16ull << 20)) {
+            LOG_WARN(T, "The index keeps its counter planes sparse: a sample cannot be sharded over GPUs, whole samples go to the GPUs in turn");
+            shard_mode = false;
+            shard_engines.clear();
+        }
+    }
+    if (shard_mode) {
+        shards.devices = shard_devices;
+        shards.comms.resize(shard_devices.size());
+        nccl_check(ncclCommInitAll(shards.comms.data(), (int)shard_devices.size(), shard_devices.data()), "ncclCommInitAll");
+        for (auto& en : shard_engines) { shards.engs.push_back(en.e); shards.streams.push_back(static_cast<hipStream_t>(bk_engine_get_stream(en.e))); }
+        LOG_INFO(T, "Every sample's reads go to " + std::to_string(shard_devices.size()) + " GPU(s); RCCL reduce-scatter of the k-mer counter planes");
+        devices.clear();   // (no whole-sample lanes)
+    }
     struct Lane { int device = 0; int parent = -1; Engine eng, fork; std::vector<size_t> mine; };   // parent: the lane whose engine built the device's tables
     std::vector<Engine> first(devices.size());   // the first engine of every device named: its tables, and what a sample's state weighs
     std::vector<int> first_dev(devices.size(), -1);
@@ -471,7 +622,7 @@ int run_call(const Args& a) {
         }
         for (auto& t : th) t.join();
     }
-    {
+    if (!devices.empty()) {
         size_t per_device = std::min<size_t>(16, std::max<size_t>(1, (size_t)a.threads / 2 / devices.size()));
         for (size_t q = 0; q < first.size(); q++) {
             if (!first[q].e) continue;
@@ -526,15 +677,15 @@ int run_call(const Args& a) {
     // complete (finalize on the GPU, download, pick the genome, call variants, write the files).  With several samples the two
     // halves of consecutive samples overlap: sample i+1 is ingested into a second engine on the same device tables
     // (bk_engine_fork) while a worker thread completes sample i.  Results are reported in input order.
-    auto ingest = [&](bk_engine* e, const std::vector<std::string>& mates) -> uint64_t {
-        hip_check(bk_sample_begin(e), "bk_sample_begin");
+    auto ingest = [&](const std::vector<bk_engine*>& engs, const std::vector<std::string>& mates) -> uint64_t {
+        for (bk_engine* e : engs) hip_check(bk_sample_begin(e), "bk_sample_begin");
         uint64_t total_reads = 0;
-        try { total_reads = push_fastqs(e, mates); }
+        try { total_reads = push_fastqs(engs, mates); }
         catch (const std::exception& ex) { die(T, ex.what()); }
         LOG_INFO(T, std::to_string(total_reads) + " reads counted from " + mates[0]);
         return total_reads;
     };
-    auto complete = [&](bk_engine* e, const std::vector<std::string>& mates, size_t sample_id) {
+    auto complete = [&](bk_engine* e, const std::vector<std::string>& mates, size_t sample_id, bool finalized = false) {
         const int n_mates = (int)mates.size();
         Pileup p;
         std::vector<uint64_t> stats((size_t)n_mates * n_files * 3), kstats((size_t)n_mates * 4);
@@ -542,7 +693,7 @@ int run_call(const Args& a) {
         LOG_INFO(T, "Mapping kmers to all genomes (" + mates[0] + ")");
         // finalize, then reference selection + baseline noise + variant calls, all on the device and asynchronous
         // (bk_sample_call); the pileup arrays only travel when --pileup wants them written
-        hip_check(bk_sample_finalize(e, n_mates), "bk_sample_finalize");
+        if (!finalized) hip_check(bk_sample_finalize(e, n_mates), "bk_sample_finalize");   // (a sharded sample: sharded_finalize has done it)
         bk_call_params dcp;
         bk_call_params_default(&dcp);
         dcp.k = cp.k; dcp.no_end_filter = cp.no_end_filter; dcp.no_strand_filter = cp.no_strand_filter;
@@ -617,7 +768,18 @@ int run_call(const Args& a) {
     std::vector<std::vector<std::string>> samples;
     for (const auto& r : a.reads) samples.push_back({r});
     for (size_t i = 0; i < a.first_pairs.size(); i++) samples.push_back({a.first_pairs[i], a.second_pairs[i]});
-    for (size_t i = 0; i < samples.size(); i++) lanes[i % lanes.size()].mine.push_back(i);
+    if (shard_mode) {
+        for (size_t i = 0; i < samples.size(); i++) {
+            const auto& mates = samples[i];
+            LOG_INFO(T, mates.size() == 1 ? "Processing " + mates[0] : "Processing paired reads " + mates[0] + ", " + mates[1]);
+            ingest(shards.engs, mates);
+            sharded_finalize(shards, (int)mates.size(), cells4);
+            complete(shards.engs[0], mates, i, true);
+        }
+        for (auto c : shards.comms) nccl_check(ncclCommDestroy(c), "ncclCommDestroy");
+        shard_engines.clear();
+    }
+    for (size_t i = 0; i < samples.size() && !lanes.empty(); i++) lanes[i % lanes.size()].mine.push_back(i);
     auto run_lane = [&](Lane& ln) {
         if (ln.mine.size() > 1) hip_check(bk_engine_fork(ln.eng.e, &ln.fork.e), "bk_engine_fork");
         std::thread worker;     // completes the lane's previous sample
@@ -626,7 +788,7 @@ int run_call(const Args& a) {
             const auto& mates = samples[i];
             LOG_INFO(T, mates.size() == 1 ? "Processing " + mates[0] : "Processing paired reads " + mates[0] + ", " + mates[1]);
             bk_engine* e = (n & 1) ? ln.fork.e : ln.eng.e;   // (its previous sample, n - 2, was completed before sample n - 1's worker started)
-            ingest(e, mates);
+            ingest(std::vector<bk_engine*>{e}, mates);
             if (worker.joinable()) worker.join();
             worker = std::thread([&complete, e, &mates, i] { complete(e, mates, i); });
         }
@@ -634,7 +796,7 @@ int run_call(const Args& a) {
         if (ln.fork.e) { bk_engine_destroy(ln.fork.e); ln.fork.e = nullptr; }   // (the fork goes before its parent)
     };
     if (lanes.size() == 1) run_lane(lanes[0]);
-    else {
+    else if (!lanes.empty()) {
         std::vector<std::thread> th;
         for (auto& ln : lanes) th.emplace_back([&run_lane, &ln] { run_lane(ln); });
         for (auto& t : th) t.join();

@@ -215,3 +215,59 @@ def test_call_samples_dealt_to_several_lanes_on_the_one_gpu_of_the_box(oracle, g
         for ext in (".vcf", ".tsv"):
             assert open(os.path.join(out, stem + ext), "rb").read() == open(os.path.join(odir, stem + ext), "rb").read(), (i, ext)
     ix.close()
+
+
+def test_call_one_sample_sharded_through_rccl(oracle, golden_dir, sars_paths, tmp_path):
+    """BRONKO_SHARD=1: a sample's batches are dealt to one engine per GPU and the counter planes are reduce-scattered by RCCL from
+    inside the binary (cli.cpp sharded_finalize: the k-mer statistics tables' exchange, bk_shard_measure / _transport /
+    ncclReduceScatter / _received per mate file, bk_sample_finalize_shard, three all-reduces, bk_sample_merge_shards).  On this
+    box that is a communicator of ONE rank -- every collective still runs through the backend -- and the outputs must be the
+    unsharded run's and the oracle's, byte for byte: a paired HPV16 sample, and a four-strain sample (every genome's rows: the
+    selected-only finalize cannot be sharded)."""
+    env = dict(os.environ, BRONKO_SHARD="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # paired HPV16
+    g = synth.read_fasta_bytes(os.path.join(golden_dir, "HPV16.fa"))
+    gm, isnv = synth.sample_genome(g, 21, n_snp=5, n_isnv=5)
+    c1, c2 = synth.paired_codes(gm, 12000, 150, 21, isnv=isnv)
+    r1, r2 = synth.codes_to_ascii(c1), synth.codes_to_ascii(c2)
+    r1[5] = r1[5][:33] + b"N" + r1[5][34:]
+    p1, p2 = str(tmp_path / "shard_R1.fastq.gz"), str(tmp_path / "shard_R2.fastq.gz")
+    write_fastq_gz(p1, r1, "r1")
+    write_fastq_gz(p2, r2, "r2")
+    outs = {}
+    for name, e in (("sharded", env), ("plain", dict(os.environ, BRONKO_SHARD="0"))):
+        out = str(tmp_path / ("out_" + name))
+        res = subprocess.run([BRONKO, "call", "-d", os.path.join(golden_dir, "hpv.bkdb"), "-1", p1, "-2", p2, "--pileup", "-o", out, "-t", "2"],
+                             capture_output=True, text=True, env=e)
+        assert res.returncode == 0, res.stdout + res.stderr
+        assert ("RCCL reduce-scatter" in res.stdout) == (name == "sharded"), res.stdout
+        outs[name] = out
+    ix = oracle.Index.load(os.path.join(golden_dir, "hpv.bkdb"))
+    odir = str(tmp_path / "oracle")
+    os.makedirs(odir)
+    stem, best, n, ov_want = oracle_outputs(oracle, ix, [r1, r2], odir, p1)
+    for ext in (".vcf", ".tsv"):
+        want = open(os.path.join(odir, stem + ext), "rb").read()
+        assert open(os.path.join(outs["sharded"], stem + ext), "rb").read() == want, ext
+        assert open(os.path.join(outs["plain"], stem + ext), "rb").read() == want, ext
+    ov = [open(os.path.join(outs[nm], "bronko_overview.tsv")).read() for nm in ("sharded", "plain")]
+    assert ov[0] == ov[1]   # incl. num_unmapped_kmers: KMC's counted k-mers survive the tables' exchange
+    ix.close()
+    # four strains, single-end
+    g = synth.read_fasta_bytes(sars_paths[2])
+    gm, isnv = synth.sample_genome(g, 22)
+    reads = synth.codes_to_ascii(synth.single_end_codes(gm, 20000, 150, 22, isnv=isnv))
+    fq = str(tmp_path / "s4.fq")
+    with open(fq, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b"@s_%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)))
+    out = str(tmp_path / "o4")
+    res = subprocess.run([BRONKO, "call", "-g"] + sars_paths + ["-r", fq, "--pileup", "-o", out, "-t", "2"], capture_output=True, text=True, env=env)
+    assert res.returncode == 0, res.stdout + res.stderr
+    ix = oracle.Index.build(21, sars_paths)
+    odir = str(tmp_path / "oracle4")
+    os.makedirs(odir)
+    stem, best, n, ov_want = oracle_outputs(oracle, ix, [reads], odir, fq)
+    for ext in (".vcf", ".tsv"):
+        assert open(os.path.join(out, stem + ext), "rb").read() == open(os.path.join(odir, stem + ext), "rb").read(), ext
+    ix.close()

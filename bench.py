@@ -289,7 +289,11 @@ def measure(wl, args, dev, dist, steps, warmup, sps=None, eng=None, selected_onl
     if sharded and 64 % world != 0:
         raise SystemExit("bench.py: the sharded finalize needs a rank count that divides 64 (got %d); use --allreduce" % world)
     width = "auto" if args.width == "auto" else int(args.width)
-    shard_fin = [ShardedFinalize(e, n_mates, rank, world, dev, width=width, time_comm=True) for e in engs] if sharded else None
+    # every engine in flight gets a process group of its own -- its own RCCL communicator and stream -- so that the reduce-scatter of
+    # sample i does not queue behind the collectives of the samples in flight next to it (one default group serialises them on its
+    # internal stream) and sample i + 1's scan runs under it
+    groups = [dist.new_group(ranks=list(range(world))) for _ in engs] if sharded_reads else None
+    shard_fin = [ShardedFinalize(e, n_mates, rank, world, dev, width=width, time_comm=True, group=groups[j]) for j, e in enumerate(engs)] if sharded else None
 
     def run_sample(i, j):
         e = engs[j]
@@ -307,7 +311,7 @@ def measure(wl, args, dev, dist, steps, warmup, sps=None, eng=None, selected_onl
             if sharded_reads:
                 for m in range(n_mates):
                     e.counters_ptr(m)                    # (a plane nothing was pushed to is zeroed by this call)
-                    allreduce_counters(counters[j][m])   # RCCL over xGMI: ONE all-reduce(sum) of the u64 k-mer occurrence counters
+                    allreduce_counters(counters[j][m], group=groups[j])   # RCCL over xGMI: ONE all-reduce(sum) of the u64 k-mer occurrence counters
             e.sample_finalize(n_mates)
 
     state = {"i": 0}
@@ -378,6 +382,31 @@ def measure(wl, args, dev, dist, steps, warmup, sps=None, eng=None, selected_onl
                 "measured": "HIP events on the engine's stream around the reduce-scatter(s) and around the three small all-reduces; includes waiting for the slowest rank"}
     last_engine = (state["i"] - 1) % len(engs)
     res = engs[last_engine].sample_download(n_mates, arrays=False)   # sanity: the last timed sample really produced its statistics
+    if comm:
+        # How much of the collectives' time shows in the wall clock: the same steps once more with every collective replaced by its
+        # local stand-in (each rank keeps its own part: wrong results, the same kernels) -- exposed = what the real steps took more.
+        for f in shard_fin:
+            f.local_only = True
+        n_lo = max(2, steps // 4)
+        step(len(engs))
+        fence()
+        tl = time.perf_counter()
+        for _ in range(n_lo):
+            step(len(engs))
+        fence()
+        dl = time.perf_counter() - tl
+        if world > 1:
+            t = torch.tensor([dl], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dl = float(t.item())
+        for f in shard_fin:
+            f.local_only = False
+            f.comm_ms()
+        any(e.transport_overflow() for e in engs)   # (the stand-in steps' flags are not the timed region's)
+        no_comm = dl / (n_lo * sps) * 1e3
+        comm["ms_per_sample_without_collectives"] = no_comm
+        comm["comm_exposed_ms_per_sample"] = max(dt / (steps * sps) * 1e3 - no_comm, 0.0)
+        comm["comm_hidden_ms_per_sample"] = max(comm["comm_ms_per_sample"] - comm["comm_exposed_ms_per_sample"], 0.0)
     # The same samples strictly one after the other on one engine (on the whole chip), every kernel kind bracketed: a single
     # sample's turnaround and each kernel's own duration with nothing running next to it -- the figure the roofline object is
     # about (in the timed region a scan shares the CUs with the other samples' kernels).

@@ -17,15 +17,17 @@ def shard_bounds(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def _all_reduce(t, op):
+def _all_reduce(t, op, group=None):
     """dist.all_reduce in place; with the gloo backend (CPU tests, or several test ranks sharing one GPU) device tensors
-    are staged through host memory explicitly."""
-    if dist.get_backend() == "gloo" and t.is_cuda:
+    are staged through host memory explicitly.  group: the process group to use (None: the default one) -- a host with several
+    samples in flight gives every engine a group of its own (its own RCCL communicator and stream), so that the collectives of
+    one sample do not queue behind another's."""
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
         h = t.cpu()
-        dist.all_reduce(h, op=op)
+        dist.all_reduce(h, op=op, group=group)
         t.copy_(h)
     else:
-        dist.all_reduce(t, op=op)
+        dist.all_reduce(t, op=op, group=group)
 
 
 def _active(force=False):
@@ -34,74 +36,50 @@ def _active(force=False):
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
 
 
-def allreduce_counters(counters, force=False):
+def allreduce_counters(counters, force=False, group=None):
     """In-place sum of a counter plane across ranks.  `counters`: int64 view of the engine's u64 plane
     (two's-complement addition is the same operation); a no-op outside a process group."""
     if _active(force):
         assert counters.dtype == torch.int64
-        _all_reduce(counters, dist.ReduceOp.SUM)
+        _all_reduce(counters, dist.ReduceOp.SUM, group)
     return counters
 
 
-def reduce_scatter_plane(plane, rank, world, out=None, narrow=False):
-    """Sum `plane` (1-D int64, length divisible by world) across ranks, leaving only this rank's part -- elements
-    [rank * n / world, (rank + 1) * n / world) -- summed, in place; the other parts are left as they were.
-    RCCL reduce-scatter on GPUs; gloo (CPU tests) has no reduce-scatter, there it is an all-reduce.
-    narrow: move the plane as 32-bit integers (half the bytes over xGMI).  The plane's elements are counts and differences of
-    counts that wrap modulo 2^64; truncated to 32 bits, summed modulo 2^32 and sign-extended they are the same numbers as long
-    as every true sum lies in [-2^31, 2^31) -- the caller vouches for that (no k-mer of the sample occurs 2^31 times)."""
-    if not (dist.is_available() and dist.is_initialized()) or world == 1:
-        return plane
-    assert plane.dtype == torch.int64 and plane.numel() % world == 0
-    part = plane.numel() // world
-    src = plane.to(torch.int32) if narrow else plane
-    if dist.get_backend() == "gloo":
-        _all_reduce(src, dist.ReduceOp.SUM)
-        if narrow:
-            plane.copy_(src)   # int32 -> int64 sign-extends
-        return plane
-    if out is None or out.dtype != src.dtype:
-        out = torch.empty(part, dtype=src.dtype, device=plane.device)
-    dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM)
-    plane[rank * part:(rank + 1) * part].copy_(out)   # (int32 -> int64 sign-extends)
-    return plane
-
-
-def combine_shard_results(depth, nk, sums, force=False):
+def combine_shard_results(depth, nk, sums, force=False, group=None):
     """After every rank mapped its part of the planes: depth = max over ranks, #k-mers and the small statistics add."""
     if _active(force):
-        _all_reduce(depth, dist.ReduceOp.MAX)
-        _all_reduce(nk, dist.ReduceOp.SUM)
-        _all_reduce(sums, dist.ReduceOp.SUM)
+        _all_reduce(depth, dist.ReduceOp.MAX, group)
+        _all_reduce(nk, dist.ReduceOp.SUM, group)
+        _all_reduce(sums, dist.ReduceOp.SUM, group)
 
 
-def _all_to_all(out, inp, out_splits, in_splits):
+def _all_to_all(out, inp, out_splits, in_splits, group=None):
     """dist.all_to_all_single; staged through host memory with the gloo backend (CPU tests / several test ranks on one GPU)."""
-    if dist.get_backend() == "gloo" and inp.is_cuda:
+    if dist.get_backend(group) == "gloo" and inp.is_cuda:
         ho, hi = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
-        dist.all_to_all_single(ho, hi, out_splits, in_splits)
+        dist.all_to_all_single(ho, hi, out_splits, in_splits, group=group)
         out.copy_(ho)
     else:
-        dist.all_to_all_single(out, inp, out_splits, in_splits)
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
 
 
-def exchange_entries(keys, cnts, in_splits):
+def exchange_entries(keys, cnts, in_splits, group=None):
     """All-to-all of (key, count) entries grouped by destination rank: `in_splits[r]` consecutive entries of `keys` (int64) /
     `cnts` (int32) go to rank r.  Returns what this rank received (keys, counts), groups in rank order."""
-    world = dist.get_world_size()
+    world = dist.get_world_size(group)
     t_in = torch.tensor(in_splits, dtype=torch.int64, device=keys.device)
     t_out = torch.empty(world, dtype=torch.int64, device=keys.device)
-    _all_to_all(t_out, t_in, [1] * world, [1] * world)
+    _all_to_all(t_out, t_in, [1] * world, [1] * world, group)
     out_splits = [int(x) for x in t_out.tolist()]
     n_recv = sum(out_splits)
     rk = torch.empty(n_recv, dtype=torch.int64, device=keys.device)
     rc = torch.empty(n_recv, dtype=torch.int32, device=keys.device)
-    _all_to_all(rk, keys, out_splits, in_splits)
-    _all_to_all(rc, cnts, out_splits, in_splits)
+    _all_to_all(rk, keys, out_splits, in_splits, group)
+    _all_to_all(rc, cnts, out_splits, in_splits, group)
     return rk, rc
 
 
-def exchange_kmer_tables(eng, rank, world, device, force=False):
+def exchange_kmer_tables(eng, rank, world, device, force=False, group=None):
     """full_kmer_stats with one sample's reads sharded over ranks (include/bronko_hip.h, bk_kmer_table_partition): every k-mer
     that touches no window bucket is moved to its owner rank (a hash of the key) -- one all-to-all of (key u64, count u32)
     entries, the one real exchange step of KMC's distinct / counted totals -- where equal keys add up.  Called between the last
@@ -113,7 +91,7 @@ def exchange_kmer_tables(eng, rank, world, device, force=False):
     n_send = off[world]
     keys = torch.as_tensor(DeviceVector(kp, max(n_send, 1)), device=device)[:n_send]
     cnts = torch.as_tensor(DeviceVector(cp, max(n_send, 1), "<i4"), device=device)[:n_send]
-    rk, rc = exchange_entries(keys, cnts, [off[r + 1] - off[r] for r in range(world)])
+    rk, rc = exchange_entries(keys, cnts, [off[r + 1] - off[r] for r in range(world)], group)
     eng.kmer_table_replace(rk.data_ptr() if len(rk) else 0, rc.data_ptr() if len(rc) else 0, len(rk))
     return rk, rc
 
@@ -141,19 +119,19 @@ def pick_width(max_e, max_v, world):
 _WIDTH_DTYPE = {16: (torch.int32, "<i4", 4), 32: (torch.int32, "<i4", 4), 64: (torch.int64, "<i8", 8)}
 
 
-def reduce_scatter_typed(send, recv, rank, world, force=False):
+def reduce_scatter_typed(send, recv, rank, world, force=False, group=None):
     """Sum `send` (world equal parts) across ranks, leaving part `rank` in `recv`.  RCCL reduce-scatter on GPUs; gloo (CPU tests,
     several test ranks on one GPU) has none: all-reduce of a copy, then the part.  force: issue the collective even with one rank
     (the first-contact test of the RCCL branch on a one-GPU box)."""
     if not (dist.is_available() and dist.is_initialized()) or (world == 1 and not force):
         recv.copy_(send[rank * recv.numel():(rank + 1) * recv.numel()])
         return
-    if dist.get_backend() == "gloo":
+    if dist.get_backend(group) == "gloo":
         tmp = send.cpu() if send.is_cuda else send.clone()
-        dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
         recv.copy_(tmp[rank * recv.numel():(rank + 1) * recv.numel()])
         return
-    dist.reduce_scatter_tensor(recv, send, op=dist.ReduceOp.SUM)
+    dist.reduce_scatter_tensor(recv, send, op=dist.ReduceOp.SUM, group=group)
 
 
 class ShardedFinalize:
@@ -167,9 +145,11 @@ class ShardedFinalize:
     The engine must run on torch's current stream (torch.cuda.stream(ExternalStream(eng.stream_ptr()))): the collectives are
     ordered against the engine's kernels by that stream only."""
 
-    def __init__(self, eng, n_mates, rank, world, device, width="auto", force_collectives=False, time_comm=False):
+    def __init__(self, eng, n_mates, rank, world, device, width="auto", force_collectives=False, time_comm=False, group=None, local_only=False):
         self.eng, self.n_mates, self.rank, self.world, self.width, self.device = eng, n_mates, rank, world, width, device
         self.force = force_collectives
+        self.group = group            # process group of this engine's collectives (None: the default group)
+        self.local_only = local_only  # measurement aid: every collective replaced by its local stand-in (wrong results, same kernels)
         cells4 = eng.total_cells * 4
         pile = torch.as_tensor(DeviceVector(eng.pileup_ptr(), 4 * cells4), device=device)
         self.depth, self.nk = pile[:2 * cells4], pile[2 * cells4:]
@@ -189,12 +169,12 @@ class ShardedFinalize:
         return v
 
     def _active(self):
-        return _active(self.force)
+        return _active(self.force) and not self.local_only
 
     def _measure(self, m):
         t = self._view(self.eng.shard_measure(m), 2, 64)
         if self._active():
-            _all_reduce(t, dist.ReduceOp.MAX)
+            _all_reduce(t, dist.ReduceOp.MAX, self.group)
         mx = t.tolist()          # (synchronises: the host needs the maxima to choose)
         return pick_width(int(mx[0]), int(mx[1]), self.world)
 
@@ -203,7 +183,7 @@ class ShardedFinalize:
             raise RuntimeError("ShardedFinalize: torch's current stream is not the engine's stream -- the collectives would not be "
                                "ordered against the engine's kernels (use torch.cuda.stream(ExternalStream(eng.stream_ptr())))")
         if self.eng.full_kmer_stats and self._active():
-            self._held = exchange_kmer_tables(self.eng, self.rank, self.world, self.device, self.force)   # KMC's distinct / counted totals stay exact
+            self._held = exchange_kmer_tables(self.eng, self.rank, self.world, self.device, self.force, self.group)   # KMC's distinct / counted totals stay exact
         ev = None
         if self.time_comm:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -226,14 +206,18 @@ class ShardedFinalize:
             self.bytes_sent += part_bytes * self.world
             if ev and m == 0:
                 ev[0].record()
-            reduce_scatter_typed(send, recv, self.rank, self.world, self.force)
+            if self.local_only:
+                recv.copy_(send[self.rank * recv.numel():(self.rank + 1) * recv.numel()])
+            else:
+                reduce_scatter_typed(send, recv, self.rank, self.world, self.force, self.group)
             if ev and m == self.n_mates - 1:
                 ev[1].record()
             self.eng.shard_received(m, self.rank, self.world, w)
         self.eng.sample_finalize_shard(self.n_mates, self.rank, self.world)
         if ev:
             ev[2].record()
-        combine_shard_results(self.depth, self.nk, self.sums, self.force)
+        if not self.local_only:
+            combine_shard_results(self.depth, self.nk, self.sums, self.force, self.group)
         if ev:
             ev[3].record()
             self._events.append(ev)

@@ -79,17 +79,23 @@ def test_counter_allreduce_then_finalize_equals_single_process(oracle, tmp_path)
 
 
 def _worker_shards(rank, world, port, out_dir):
-    from bronko_amd.dist import combine_shard_results, reduce_scatter_plane
+    from bronko_amd.dist import combine_shard_results, reduce_scatter_typed
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         g = torch.Generator().manual_seed(100 + rank)
         plane = torch.randint(-5, 50, (64 * 19,), generator=g, dtype=torch.int64)
+        part = plane.numel() // world
+        grp = dist.new_group(ranks=list(range(world)))   # (a group of its own, as every engine in flight gets one)
         mine = plane.clone()
-        reduce_scatter_plane(mine, rank, world)
+        recv = torch.empty(part, dtype=torch.int64)
+        reduce_scatter_typed(plane, recv, rank, world, group=grp)
+        mine[rank * part:(rank + 1) * part] = recv
         mine32 = plane.clone()
-        reduce_scatter_plane(mine32, rank, world, narrow=True)   # 32-bit transport: same numbers (negative differences included)
+        recv32 = torch.empty(part, dtype=torch.int32)
+        reduce_scatter_typed(plane.to(torch.int32), recv32, rank, world)   # 32-bit elements on the wire: same numbers (negative differences included)
+        mine32[rank * part:(rank + 1) * part] = recv32.to(torch.int64)
         depth = torch.randint(0, 1000, (40,), generator=g, dtype=torch.int64)
         nk = torch.randint(0, 1000, (40,), generator=g, dtype=torch.int64)
         sums = torch.randint(0, 1000, (14,), generator=g, dtype=torch.int64)
@@ -102,7 +108,8 @@ def _worker_shards(rank, world, port, out_dir):
 
 
 def test_reduce_scatter_and_combine_helpers(tmp_path):
-    """bronko_amd.dist.reduce_scatter_plane leaves each rank's own part summed; combine_shard_results is max / sum / sum."""
+    """bronko_amd.dist.reduce_scatter_typed leaves each rank its own part summed (on the default group and on one of its own);
+    combine_shard_results is max / sum / sum."""
     world = 2
     port = _free_port()
     mp.spawn(_worker_shards, args=(world, port, str(tmp_path)), nprocs=world, join=True)

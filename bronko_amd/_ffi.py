@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # library itself reads no environment)
 LIB_PATH = os.environ.get("BRONKO_HIP_LIB") or os.path.join(_HERE, "libbronko_hip.so")
 # the -DBK_TESTING build of the same sources: BK_* environment variables that force a code path exist only there
-TESTING_LIB_PATH = os.path.join(_HERE, "libbronko_hip_testing.so")
+TESTING_LIB_PATH = os.environ.get("BRONKO_HIP_TESTING_LIB") or os.path.join(_HERE, "libbronko_hip_testing.so")
 
 
 class BucketInfo(C.Structure):  # include/bronko_hip.h bk_bucket_info == build.rs:52-60

@@ -269,8 +269,9 @@ struct bk_engine {
     DevBuf<bk::DirtyAns> dirty_ans;
     DevBuf<uint8_t> cell_flags;
     DevBuf<uint32_t> ref_words, cell_codes, cell_has, cell_clean, cell_clean3, cell_yf, cell_yr, id_at, cell_fast, cell_nat, cell_natrow;
-    DevBuf<uint2> cell_blk, seed_tab;
-    uint32_t seed_log2 = 0;
+    DevBuf<uint2> cell_blk, seed_tab, seed_tab2;
+    uint32_t seed_log2 = 0, seed2_log2 = 0;
+    DevBuf<uint32_t> rc_words;              // the reference read backwards and complemented (scan_items_kernel: reads against the reference)
     struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0, log2p = 0; } half_lo, half_hi;
     DevBuf<unsigned int> deferred, n_deferred, deferred_mask;
     DevBuf<unsigned long long> deferred_n;   // dense planes: the deferred k-mers' counts (K2a zeroes the counters it reads)
@@ -464,7 +465,7 @@ static int alloc_sample_state(bk_engine* e) {
     BK_HIP(e->kstats.alloc(8));
     // the scan: binned (items) when the planes are dense, the window's reference is staged in LDS and the bins are few enough;
     // else the whole-window difference array of scan_count_kernel with its slabs
-    e->use_items = !e->sparse && e->ref_in_lds && e->W > 0 && e->n_lds_bins > 0 && !test_env("BK_NO_ITEMS") &&
+    e->use_items = !e->sparse && e->ref_in_lds && e->W > 0 && e->n_lds_bins > 0 && !test_env("BK_NO_ITEMS") && e->seed_tab2.p && e->rc_words.p &&
                    bk::item_geometry(std::min<uint32_t>(e->n_lds_bins, (uint32_t)e->total_cells), e->n_full, e->v_span, &e->ig) &&
                    bk::items_lds_bytes(e->ig, std::min<uint32_t>(e->n_lds_bins, (uint32_t)e->total_cells)) <= 128u * 1024u;
     if (e->use_items) {
@@ -1304,6 +1305,62 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 });
                 BK_HIP(e->seed_tab.upload(h_seed));
             }
+            // ... and, for the binned scan, the reference reverse-complemented (symbol J = complement of symbol cells - 1 - J, same
+            // paddings) with seed tables keyed by the k-mer AS A READ SHOWS IT -- bases in reading order, 2 bits each from bit 0 -- on
+            // either strand: two entries per reference k-mer (along the reference: strand 0; against it: strand 1), twice the
+            // buckets.  A read's k-mer is hashed as it stands -- no reverse complement, no canonical form -- and verified against the
+            // reference (strand 0) or its reverse complement (strand 1) with one comparison.
+            if (((uint64_t)ix->n_files << (L + 1)) * sizeof(uint2) <= (8ull << 30) && cells >= (uint64_t)k) {
+                std::vector<uint32_t> h_rcw(h_refw.size() + 1, 0u);   // (+ 1: a window's slice starts inside a word, scan_items_kernel stages one word more)
+                parallel_for((size_t)((cells + 15) / 16), [&](size_t w0, size_t w1) {
+                    for (size_t w = w0; w < w1; w++) {
+                        uint32_t acc = 0;
+                        for (uint64_t J = (uint64_t)w * 16; J < std::min<uint64_t>((uint64_t)w * 16 + 16, cells); J++) {
+                            const uint64_t c = cells - 1 - J;
+                            acc |= (3u - ((h_refw[pad_w + (c >> 4)] >> (2 * (c & 15))) & 3u)) << (2 * (J & 15));
+                        }
+                        h_rcw[pad_w + w] = acc;
+                    }
+                });
+                auto syms = [&](const std::vector<uint32_t>& a, uint64_t pos) -> uint64_t {   // k symbols from symbol `pos`, the first at bit 0
+                    uint64_t g = 0;
+                    for (int t = 0; t < k; t++) g |= (uint64_t)((a[pad_w + ((pos + t) >> 4)] >> (2 * ((pos + t) & 15))) & 3u) << (2 * t);
+                    return g;
+                };
+                const uint32_t L2 = L + 1;
+                e->seed2_log2 = L2;
+                std::vector<uint2> h_seed2((size_t)ix->n_files << L2, make_uint2(0xffffffffu, 0xffffffffu));
+                // Only the k-mers that start at ONE cell of their genome file are seeds: a repeat's entry would name one of its cells
+                // for a read from any of them -- a diagonal that passes the verification (the k-mer is there) and is wrong; the scan
+                // would then see a read of mismatches, all of them Level 2's to sort out.  Reads in repeats have other seeds.
+                parallel_for((size_t)ix->n_files, [&](size_t f0, size_t f1) {
+                    std::vector<uint8_t> seen(e->n_full, 0);   // per worker: occurrences of each id in the file at hand (saturating at 2)
+                    for (size_t f = f0; f < f1; f++) {
+                        const uint64_t c_lo = e->file_cell_lo[f], c_hi = f + 1 < (size_t)ix->n_files ? e->file_cell_lo[f + 1] : cells;
+                        for (uint64_t c = c_lo; c < c_hi; c++) {
+                            const uint32_t id = h_id_at[c];
+                            if (id != kNone && id < e->n_full && seen[id] < 2) seen[id]++;
+                        }
+                        for (uint64_t c = c_lo; c < c_hi; c++) {
+                            const uint32_t id = h_id_at[c];
+                            if (id == kNone || id >= e->n_full || seen[id] != 1) continue;
+                            for (uint32_t strand = 0; strand < 2u; strand++) {
+                                const uint64_t g = strand ? syms(h_rcw, cells - (uint64_t)k - c) : syms(h_refw, c);
+                                const uint32_t h = bk::seed_hash(g);
+                                const uint32_t ent = (uint32_t)c | (strand << bk::kSeedCellBits) | ((h & 15u) << 28);
+                                uint2& b = h_seed2[(f << L2) + (h >> (32 - L2))];
+                                if (b.x == 0xffffffffu) b.x = ent; else if (b.y == 0xffffffffu) b.y = ent;   // (else: not in the table)
+                            }
+                        }
+                        for (uint64_t c = c_lo; c < c_hi; c++) {   // (back to zero for the worker's next file: the cells, not the whole array)
+                            const uint32_t id = h_id_at[c];
+                            if (id != kNone && id < e->n_full) seen[id] = 0;
+                        }
+                    }
+                });
+                BK_HIP(e->rc_words.upload(h_rcw));
+                BK_HIP(e->seed_tab2.upload(h_seed2));
+            }
         }
         if (ix->n_files > 1 && (uint64_t)e->n_full * (uint64_t)ix->n_files <= (1ull << 28)) {
             std::vector<uint32_t> h_occ((size_t)e->n_full * ix->n_files, 0xffffffffu);
@@ -1666,7 +1723,7 @@ int bk_engine_fork_params(const bk_engine* parent, const bk_params* prm, bk_engi
     e->prow_id.alias(p->prow_id); e->prow_t.alias(p->prow_t); e->kmer_pos.alias(p->kmer_pos); e->d_view.alias(p->d_view); e->kmer_of.alias(p->kmer_of); e->id_rec.alias(p->id_rec); e->dirty_ans.alias(p->dirty_ans); e->cell_flags.alias(p->cell_flags);
     e->ref_words.alias(p->ref_words); e->cell_codes.alias(p->cell_codes); e->cell_has.alias(p->cell_has); e->cell_clean.alias(p->cell_clean);
     e->cell_clean3.alias(p->cell_clean3); e->cell_yf.alias(p->cell_yf); e->cell_yr.alias(p->cell_yr); e->id_at.alias(p->id_at);
-    e->cell_fast.alias(p->cell_fast); e->cell_nat.alias(p->cell_nat); e->cell_natrow.alias(p->cell_natrow); e->cell_blk.alias(p->cell_blk); e->seed_tab.alias(p->seed_tab); e->seed_log2 = p->seed_log2;
+    e->cell_fast.alias(p->cell_fast); e->cell_nat.alias(p->cell_nat); e->cell_natrow.alias(p->cell_natrow); e->cell_blk.alias(p->cell_blk); e->seed_tab.alias(p->seed_tab); e->seed_log2 = p->seed_log2; e->seed_tab2.alias(p->seed_tab2); e->seed2_log2 = p->seed2_log2; e->rc_words.alias(p->rc_words);
     e->half_lo.pilots.alias(p->half_lo.pilots); e->half_lo.dir.alias(p->half_lo.dir); e->half_lo.cand.alias(p->half_lo.cand);
     e->half_hi.pilots.alias(p->half_hi.pilots); e->half_hi.dir.alias(p->half_hi.dir); e->half_hi.cand.alias(p->half_hi.cand);
     e->slot_of.alias(p->slot_of); e->estat_off.alias(p->estat_off); e->estat.alias(p->estat); e->slot_rec.alias(p->slot_rec); e->ent_files.alias(p->ent_files); e->slot_files.alias(p->slot_files); e->id_own_files.alias(p->id_own_files); e->cell_file.alias(p->cell_file); e->id_rest_off.alias(p->id_rest_off); e->id_rest.alias(p->id_rest); e->estat_files.alias(p->estat_files); e->amb.alias(p->amb);
@@ -1818,6 +1875,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.ixp = e->d_view.p;
     a.k = e->k; a.wstart = e->wstart; a.W = e->W; a.v_omin = e->v_omin; a.v_span = e->v_span; a.v_off = e->v_off; a.total_cells = (uint32_t)e->total_cells; a.n_u = e->n_u;
     a.ref_words = e->ref_words.p; a.cell_codes = e->cell_codes.p; a.cell_has = e->cell_has.p; a.cell_clean = e->cell_clean.p; a.cell_clean3 = e->cell_clean3.p; a.cell_yf = e->cell_yf.p; a.cell_yr = e->cell_yr.p; a.id_at = e->id_at.p; a.cell_fast = e->cell_fast.p; a.cell_nat = e->cell_nat.p; a.cell_natrow = e->cell_natrow.p; a.cell_blk = e->cell_blk.p; a.seed_tab = e->seed_tab.p; a.seed_log2 = e->seed_log2;
+    a.seed_tab2 = e->seed_tab2.p; a.seed2_log2 = e->seed2_log2; a.rc_words = e->rc_words.p;
     a.words = d_words; a.lens = d_lens; a.n_records = n; a.stride_words = stride_words;
     a.counters = e->counters[mate].p;
     a.kmer_total = e->kstats.p + mate * 4 + 1;

@@ -53,6 +53,9 @@ struct ScanArgs {
     const uint32_t* cell_natrow;    // IndexView::cell_natrow (or null)
     const uint2* seed_tab;          // IndexView::seed_tab / seed_log2
     uint32_t seed_log2;
+    const uint2* seed_tab2;         // scan_items_kernel: [n_files << seed2_log2] seed tables keyed by the k-mer as a read shows it (bases in reading
+    uint32_t seed2_log2;            //   order from bit 0), both strands of every reference k-mer: entry = cell | strand << 27 | tag << 28
+    const uint32_t* rc_words;       // ... and the reference reverse-complemented: symbol J = complement of symbol total_cells - 1 - J (paddings of ref_words)
     const uint32_t* words;          // [n_records][stride_words] 2-bit packed, 16 bases per word, LSB first
     const uint16_t* lens;           // [n_records] valid bases
     uint64_t rec_base;              // this launch covers records [rec_base, rec_base + n_records)

@@ -91,9 +91,12 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     const uint32_t n_bitw = kBitPadWords + (lds_cells + 31) / 32 + kBitBackWords;
     const uint32_t n_blk = (lds_cells + 63) / 64 + 2;
     const uint32_t blk_w0 = (n_refw + 2u * n_bitw + 1u) & ~1u;   // (8-byte aligned: lds_ref is)
+    // the same cells of the reverse-complemented reference (ScanArgs::rc_words): window cell p is its symbol rc_base + lds_cells - 1 - p
+    const uint32_t rc_lo = total - win_lo - lds_cells, rc_base = rc_lo & 15u;
+    const uint32_t rc_w0 = blk_w0 + 2u * n_blk;
     for (uint32_t i = threadIdx.x; i < n_bins; i += kItemBlock) { cnt[i] = 0u; ext_of[i] = 0u; }
     if (threadIdx.x < kItemExtN) ext_cnt[threadIdx.x] = 0u;
-    if (threadIdx.x == 0) *ext_next = 0u;
+    if (threadIdx.x == 0) { ext_next[0] = 0u; ext_next[1] = (unsigned int)kItemWaves; }   // ([1]: the workgroup's next tile that no wave has taken)
     {
         const ColdArgs c = cold();
         const uint32_t* const g_ref = c->ref_words + (win_lo >> 4);
@@ -104,6 +107,8 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
         for (uint32_t i = threadIdx.x; i < n_bitw; i += kItemBlock) lds_ref[n_refw + i] = g_fast[i];
         for (uint32_t i = threadIdx.x; i < n_bitw; i += kItemBlock) lds_ref[n_refw + n_bitw + i] = g_c3[i];
         for (uint32_t i = threadIdx.x; i < 2 * n_blk; i += kItemBlock) lds_ref[blk_w0 + i] = g_blk[i];
+        const uint32_t* const g_rc = c->rc_words + (rc_lo >> 4);
+        for (uint32_t i = threadIdx.x; i <= n_refw; i += kItemBlock) lds_ref[rc_w0 + i] = g_rc[i];   // (one word more: the slice starts rc_base symbols into its first word)
     }
     __syncthreads();
     // symbol / bit 0 is cell win_lo; negative positions down to -64 are readable (padding or earlier cells)
@@ -111,6 +116,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     const unsigned int* fastw = lds_ref + n_refw + kBitPadWords;
     const unsigned int* c3w = lds_ref + n_refw + n_bitw + kBitPadWords;
     const uint2* blkw = reinterpret_cast<const uint2*>(lds_ref + blk_w0);   // entry 0 = the block of cell win_lo
+    const int32_t rc_sym0 = (int32_t)(rc_w0 * 16u);   // symbol x of the reverse-complemented copy is symbol rc_sym0 + x of refw1's array
 
     const int k = KT ? KT : a.k;
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;  // k <= 31
@@ -200,10 +206,20 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     const uint32_t* const words0 = a.words + a.rec_base * a.stride_words;
     const uint16_t* const lens0 = a.lens + a.rec_base;
     const uint64_t n_tiles = (n_records + 63) / 64;
+    // The workgroup's tiles are one contiguous stretch, dealt out to its waves one at a time (a counter in LDS): a tile with many
+    // mismatches keeps one wave busy while the others take what is left -- with a fixed deal the workgroup waited for its
+    // unluckiest wave, and the kernel for its unluckiest workgroup (waves were resident for 65% of the kernel's time).
+    const uint64_t tiles_per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const uint64_t t_lo = (uint64_t)blockIdx.x * tiles_per_wg, t_hi = min(n_tiles, t_lo + tiles_per_wg);
+    auto take_tile = [&]() __attribute__((always_inline)) -> uint64_t {
+        uint32_t t = 0u;
+        if (lane == 0) t = __hip_atomic_fetch_add(ext_next + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return t_lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    };
     uint32_t pf_sink = 0;               // destination of the prefetch loads (never read)
     constexpr uint32_t kNoPos = 0x40000000u;
     // the seed table of the window's genome, and where the seeds sit: evenly spaced over the launch's first record
-    const uint2* const seed_tab = a.seed_tab ? a.seed_tab + ((size_t)win_file << a.seed_log2) : nullptr;
+    const uint2* const seed_tab = a.seed_tab2 ? a.seed_tab2 + ((size_t)win_file << a.seed2_log2) : nullptr;
     const uint32_t hint_len = n_records ? (uint32_t)__builtin_amdgcn_readfirstlane((int)lens0[0]) : 0u;
     const uint32_t hint_span = hint_len >= (uint32_t)k ? hint_len - (uint32_t)k : 0u;
 
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     const uint32_t sw = a.stride_words;
     unsigned int* const rec_buf = reinterpret_cast<unsigned int*>(smem + a.stage_off) + (uint32_t)wave * 64u * sw;
     auto stage = [&](uint64_t t) -> uint32_t {
-        if (t >= n_tiles) return 0u;
+        if (t >= t_hi) return 0u;
         const uint64_t rr = t * 64 + (uint32_t)lane;
         const uint32_t ln = rr < n_records ? (uint32_t)lens0[rr] : 0u;
         if ((t + 1) * 64 <= n_records) {   // (wave-uniform) a whole tile: 64 * sw words, 16 * sw units of 16 bytes
@@ -230,11 +246,11 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
         return ln;
     };
     uint32_t len_pf = 0u;
-    if constexpr (STAGED) len_pf = stage((uint64_t)blockIdx.x * kItemWaves + wave);
+    if constexpr (STAGED) len_pf = stage(t_lo + (uint32_t)wave);
 
-    for (uint64_t tile = (uint64_t)blockIdx.x * kItemWaves + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * kItemWaves) {
+    for (uint64_t tile = t_lo + (uint32_t)wave, next_tile = 0; tile < t_hi; tile = next_tile) {
         const uint64_t r = tile * 64 + lane;
-        const uint64_t next_tile = tile + (uint64_t)gridDim.x * kItemWaves;
+        next_tile = take_tile();
         const bool live = r < n_records;
         const uint32_t r32 = live ? (uint32_t)r : 0u;   // record index within this launch (a launch has < 2^32 records)
         uint32_t len;
@@ -256,7 +272,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
             const uint64_t nt = next_tile;
             const uint64_t first = nt * 64ull * a.stride_words, words_tile = 64ull * a.stride_words;
             const uint64_t at = first + (uint64_t)lane * 32ull;
-            if (nt < n_tiles && (uint64_t)lane * 32ull < words_tile && at < n_records * a.stride_words)
+            if (nt < t_hi && (uint64_t)lane * 32ull < words_tile && at < n_records * a.stride_words)
                 asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink) : "v"(words0 + at) : "memory");
         }
         if (!maxlen) { if constexpr (STAGED) len_pf = stage(next_tile); continue; }
@@ -267,7 +283,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
         // a candidate diagonal: the whole read must lie on the reference (hi_cell + k <= total); to be settled here its cells must lie
         // in the window and each of them must carry a reference k-mer (no sequence tail in between: cell_blk)
         uint32_t best_cell = 0xffffffffu;
-        auto candidate = [&](bool hit, uint32_t scell, bool f, uint32_t s) {
+        auto candidate = [&](bool hit, uint32_t scell, bool f, uint32_t s) __attribute__((always_inline)) {
             if (hit && scell < best_cell) {   // several seeds may hit (usually all, on one diagonal); prefer the lowest cell
                 // (cells stay below 2^27 -- kSeedCellBits --, read positions below 2^16: 32-bit signed arithmetic holds everything)
                 const int32_t span_k = (int32_t)(len - (uint32_t)k);
@@ -286,40 +302,36 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
         // against the reference in LDS.  Two at a time: the read's first and last k-mer; the two in between only for the lanes both
         // of those left without a diagonal (a sequencing error in each: one read in a hundred, half of the tiles) -- with the
         // records in LDS a second round costs one more trip to the seed table, not a chain of three.
-        auto seed_pair = [&](int qa, int qb) {
+        for (int sround = 0; sround < 2 && seed_tab && !BK_ABLATE(a, 9) && !BK_ABLATE(a, 11); ++sround) {
+            if (sround == 1 && !__ballot(len != 0u && !seeded)) break;
+            const int qa = sround ? 1 : 0, qb = sround ? kSeeds - 2 : kSeeds - 1;
             const bool had = seeded;
-            uint64_t sg[2], sff[2];
-            uint32_t sh[2], sis[2];
+            uint64_t sg[2];
+            uint32_t sh[2];
             uint2 sb[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const uint32_t s = (hint_span * (uint32_t)(j ? qb : qa)) / (uint32_t)(kSeeds - 1);   // (wave-uniform)
-                const uint64_t g = read_symbols_at(w, s, last_word) & kmask;       // base t of the k-mer at bits 2t
-                const uint64_t rr = ~g & kmask;                                      // its reverse complement, first base on top
-                const uint64_t ff = rev2_64(g) >> (64 - 2 * k);                      // the k-mer, first base on top
-                const bool lt = ff < rr;                                             // lcb.rs:90-94
-                sg[j] = g; sff[j] = ff; sis[j] = lt ? 0u : 1u;
-                sh[j] = seed_hash(lt ? ff : rr);
-                sb[j] = seed_tab[sh[j] >> (32u - a.seed_log2)];
+                sg[j] = read_symbols_at(w, s, last_word) & kmask;                  // the k-mer as the read shows it: base t at bits 2t
+                sh[j] = seed_hash(sg[j]);                                          // (no reverse complement, no canonical form: the table holds both strands)
+                sb[j] = seed_tab[sh[j] >> (32u - a.seed2_log2)];
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const uint32_t s = (hint_span * (uint32_t)(j ? qb : qa)) / (uint32_t)(kSeeds - 1);
                 const uint32_t tag = sh[j] & 15u;
                 const uint32_t ent = (sb[j].x != 0xffffffffu && (sb[j].x >> 28) == tag) ? sb[j].x : sb[j].y;
-                const uint32_t cell = ent & ((1u << kSeedCellBits) - 1u), rc = (ent >> kSeedCellBits) & 1u;
+                const uint32_t cell = ent & ((1u << kSeedCellBits) - 1u), strand = (ent >> kSeedCellBits) & 1u;
                 // in reach of the staged reference?  (the window's cells and 64 in front)
                 const bool in_ref = !had && ent != 0xffffffffu && (ent >> 28) == tag && len != 0u && s + (uint32_t)k <= len &&
                                     cell + 64u >= win_lo && cell + (uint32_t)k <= win_lo + lds_cells;
                 const int32_t cw = in_ref ? (int32_t)cell - (int32_t)win_lo : 0;
-                const uint64_t ref = symbols_at(refw1, cw) & kmask;                  // reference base cell + t at bits 2t
-                const bool same = sis[j] == rc;                                      // same strand as the reference?
-                candidate(in_ref && ref == (same ? sg[j] : (~sff[j] & kmask)), cell, same, s);
+                // the reference k-mer of that cell as a read on that strand shows it: from the reference, or from its reverse-
+                // complemented copy (one LDS array, one base pointer: the copy's symbols lie rc_sym0 symbols behind the reference's)
+                const int32_t pos = strand ? rc_sym0 + (int32_t)(rc_base + lds_cells) - k - cw : cw;
+                const uint64_t ref = symbols_at(refw1, pos) & kmask;
+                candidate(in_ref && ref == sg[j], cell, strand == 0u, s);
             }
-        };
-        if (seed_tab && !BK_ABLATE(a, 9) && !BK_ABLATE(a, 11)) {
-            seed_pair(0, kSeeds - 1);
-            if (__ballot(len != 0u && !seeded)) seed_pair(1, kSeeds - 2);
         }
         // The lanes that are still without a diagonal (an error in every seed, a k-mer that found its bucket full, a read shorter
         // than the first record, no seed table): the perfect hash of U, two rounds (scan_count_kernel has the why).
@@ -372,17 +384,20 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
 
         // ---- mismatch flags, 160 bases at a time; mismatch by mismatch --------------------------------------------------
         const int32_t dgw = dg - (int32_t)win_lo;   // the diagonal in window coordinates
+        const int32_t rc_off = rc_sym0 + (int32_t)(rc_base + lds_cells) - 1 - (int32_t)km1;
         // mismatch flags of bases [i0, i0 + 32) (i0 a multiple of 32): read words vs the reference words aligned with them
         auto mism32 = [&](uint32_t i0) -> uint32_t {
             const bool act = l1ok && i0 < len;
             const uint32_t wi = i0 >> 4;
             const uint32_t x0 = w[min(wi, last_word)], x1 = w[min(wi + 1u, last_word)];
-            const int32_t p0 = act ? (fwd ? dgw + (int32_t)i0 : dgw + (int32_t)km1 - (int32_t)i0 - 31) : 0;
+            // read base i <-> reference base dgw + i along the reference; against it <-> complement of reference base dgw + k - 1 - i,
+            // which is symbol rc_off - dgw + i of the reverse-complemented copy: the same walk on the other array
+            // (one LDS array, one base pointer: the copy's symbols lie rc_sym0 symbols behind the reference's)
+            const int32_t p0 = act ? (fwd ? dgw + (int32_t)i0 : rc_off - dgw + (int32_t)i0) : 0;
             const uint32_t sh = 2u * ((uint32_t)p0 & 15u);
             const uint32_t r0 = refw1[p0 >> 4], r1 = refw1[(p0 >> 4) + 1], r2 = refw1[(p0 >> 4) + 2];
-            const uint32_t ya = __builtin_amdgcn_alignbit(r1, r0, sh), yb = __builtin_amdgcn_alignbit(r2, r1, sh);   // 32 reference bases, rising
-            // against the reference: read base i0 + t <-> complement of reference base p0 + 31 - t
-            const uint32_t d0 = x0 ^ (fwd ? ya : ~rev2_32(yb)), d1 = x1 ^ (fwd ? yb : ~rev2_32(ya));
+            const uint32_t ya = __builtin_amdgcn_alignbit(r1, r0, sh), yb = __builtin_amdgcn_alignbit(r2, r1, sh);   // 32 bases of that strand, in reading order
+            const uint32_t d0 = x0 ^ ya, d1 = x1 ^ yb;
             const uint32_t m = even_bits(d0 | (d0 >> 1)) | (even_bits(d1 | (d1 >> 1)) << 16);
             const uint32_t hi = len > i0 ? min(len - i0, 32u) : 0u;   // bases of the record in these words
             return act ? m & (hi >= 32u ? 0xffffffffu : (1u << hi) - 1u) : 0u;
@@ -771,7 +786,8 @@ uint32_t items_grid(uint64_t n_records, int n_cus) {
 }
 size_t items_lds_bytes(const ItemGeom& g, uint32_t win_cells) {
     const size_t nb_pad = ((size_t)g.n_ebins + g.n_vbins + 1u) & ~(size_t)1u;
-    return ((kItemLdsFixed + nb_pad * 8u + (size_t)g.wg_stride * 2u + 7u) & ~(size_t)7u) + scan_ref_lds_bytes(win_cells) + 8u;
+    return ((kItemLdsFixed + nb_pad * 8u + (size_t)g.wg_stride * 2u + 7u) & ~(size_t)7u) + scan_ref_lds_bytes(win_cells) + 8u +
+           ((size_t)(kRefPadWords + (win_cells + 15) / 16 + kRefBackWords) + 1u) * sizeof(unsigned int);   // (+ the reverse-complemented reference)
 }
 
 static hipError_t raise_lds_limit(const void* fn, size_t lds) {

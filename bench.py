@@ -60,6 +60,7 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all host cores)")
     ap.add_argument("--cpu-sample", type=int, default=1000000, help="reads (pairs) per pass through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--experiment", action="store_true", help="tools/*.sh sweeps: BK_* testing variables may be set (the line says \"experiment\": true and is no result)")
     ap.add_argument("--allreduce", action="store_true", help="N > 1: all-reduce the counter plane instead of reduce-scatter + sharded finalize")
     ap.add_argument("--width", default="auto", choices=["auto", "16", "32", "64"], help="N > 1: bits per counter on the wire (bk_shard_transport). auto = "
                     "measured during the warm-up (bk_shard_measure), then fixed for the timed region; a width that is too narrow is detected, never silent")
@@ -411,6 +412,12 @@ def measure(wl, args, dev, dist, steps, warmup, sps=None, eng=None, selected_onl
     # sample's turnaround and each kernel's own duration with nothing running next to it -- the figure the roofline object is
     # about (in the timed region a scan shares the CUs with the other samples' kernels).
     n_serial = 3 if bounded else max(2, min(32 if wl.reads_per_sample_rank <= 2000000 else 8, steps * sps))   # (32 short samples: the average of 8 moved by 10 % from run to run)
+    # (the forks are closed first: an engine with siblings leaves a quarter of the CUs to them -- alone it scans on the whole chip)
+    n_in_flight = len(engs)
+    fence()
+    for e in engs[1:]:
+        e.close()
+    del engs[1:]
     for i in range(3 if bounded else 8):   # (untimed: the chip settles into running one sample at a time)
         run_sample(i, 0)
     fence()
@@ -443,6 +450,7 @@ def measure(wl, args, dev, dist, steps, warmup, sps=None, eng=None, selected_onl
     achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     per_sample = lambda ms: ms / max(n_serial, 1)   # noqa: E731
     out = {
+        **({"experiment": True, "testing_env": sorted(k_ for k_ in os.environ if k_.startswith("BK_"))} if args.experiment else {}),
         "metric": "reads/sec through call k-mer->pileup, SARS-CoV-2 k=%d" % k,
         "value": value,
         "unit": "reads/s",
@@ -460,7 +468,7 @@ def measure(wl, args, dev, dist, steps, warmup, sps=None, eng=None, selected_onl
         "data": "synthetic",
         "config": {"workload": wl.workload, "baseline_config": cfg, "k": k, "read_len": rl, "samples_per_step": sps,
                    "reads_per_sample": wl.reads_per_sample_total, "reads_per_gpu_per_sample": wl.reads_per_sample_rank, "mates": n_mates,
-                   "samples_in_flight": len(engs), "resident_input_bytes": wl.resident,
+                   "samples_in_flight": n_in_flight, "resident_input_bytes": wl.resident,
                    "input": "sequence lines (ASCII) resident in HBM -> K0 pack_reads_kernel -> records" if from_ascii else "2-bit packed records resident in HBM",
                    "pileup_rows": "selected genome only (bk_params.pileup_selected_only)" if selected_only else "every genome (call.rs:1305-1384)",
                    "parallelism": ("single GPU" if world == 1 else
@@ -539,7 +547,7 @@ def pmc_traffic(cfg, reads, rl, build_id):
 def main():
     args = parse_args()
     bad_env = sorted(k for k in os.environ if k.startswith("BK_"))
-    if bad_env:
+    if bad_env and not args.experiment:
         raise SystemExit("bench.py: testing / measurement aids are set in the environment (%s); refusing to time anything" % ", ".join(bad_env))
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

@@ -239,6 +239,9 @@ bool build_phf(const std::vector<uint64_t>& keys, std::vector<uint16_t>& pilots,
 
 struct bk_engine {
     bk_params params{};
+    // engines that share this one's index tables (itself and its forks, alive): with samples in flight next to each other the
+    // binned scan leaves a quarter of the CUs to the siblings' small kernels (push_device)
+    std::shared_ptr<std::atomic<int>> family = std::make_shared<std::atomic<int>>(1);
     int k = 0, wstart = 0, W = 0, n_files = 0;
     uint64_t total_cells = 0, n_slots = 0;
     uint32_t log2s = 4, log2nb = 0, log2p = 0, m = 1, n_u = 0, n_full = 0, n_lds_bins = 0;
@@ -1711,6 +1714,7 @@ int bk_engine_fork_params(const bk_engine* parent, const bk_params* prm, bk_engi
     BK_HIP(hipSetDevice(parent->device));
     std::unique_ptr<bk_engine> e(new bk_engine());
     const bk_engine* p = parent;
+    e->family = p->family; e->family->fetch_add(1);
     e->params = prm ? *prm : p->params; e->k = p->k; e->wstart = p->wstart; e->W = p->W; e->n_files = p->n_files;
     e->total_cells = p->total_cells; e->n_slots = p->n_slots; e->log2s = p->log2s; e->log2nb = p->log2nb; e->log2p = p->log2p; e->m = p->m;
     e->n_u = p->n_u; e->n_full = p->n_full; e->n_lds_bins = p->n_lds_bins; e->n_prows = p->n_prows;
@@ -1738,6 +1742,7 @@ int bk_engine_fork_params(const bk_engine* parent, const bk_params* prm, bk_engi
 
 void bk_engine_destroy(bk_engine* e) {
     if (!e) return;
+    e->family->fetch_sub(1);
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     for (auto& s : e->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -1891,7 +1896,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
         a.touch_v = e->touch_v[mate].p; a.touch_b = e->touch_b[mate].p; a.touch_p = e->touch_p[mate].p; a.touch_e = e->touch_e[mate].p;
         a.rl_recip = ~0ull / (unsigned long long)(e->v_span + 1) + 1ull;   // ceil(2^64 / row length): exact quotients for 32-bit counter indices
     }
-    if (test_env("BK_L2_STATS") && !e->dbg.p) { BK_HIP(e->dbg.alloc(32)); BK_HIP(hipMemsetAsync(e->dbg.p, 0, 32 * sizeof(unsigned long long), e->stream)); }
+    if (test_env("BK_L2_STATS") && !e->dbg.p) { BK_HIP(e->dbg.alloc(32 + 4 * 1024)); BK_HIP(hipMemsetAsync(e->dbg.p, 0, (32 + 4 * 1024) * sizeof(unsigned long long), e->stream)); }
     a.dbg = e->dbg.p;
     if (e->W <= 0) {
         // empty window: nothing can touch the index (map_kmers finds no bucket, call.rs:1291-1307); KMC's total k-mer count is all
@@ -1940,7 +1945,14 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
         }
         a.l2_bits = e->l2_bits.p; a.l2_diag = e->l2_diag.p; a.l2_any = e->l2_any.p; a.n_bits = e->n_bits.p; a.n_any = e->n_any.p;
         a.rec_base = base; a.n_records = take;
-        if (e->use_items) grid = bk::items_grid(take, e->n_cus);
+        if (e->use_items) {
+            // A scan workgroup fills its CU (16 waves of 128 registers, 127 KB of LDS): on every CU it shuts out the other samples'
+            // finalize / Level 2 kernels, which are chains of short launches that wait for latency, not for CUs.  With siblings in
+            // flight three quarters of the CUs scan and the rest keep those chains moving (config 2, three samples in flight: 8.35
+            // -> 9.06 G reads/s; one sample alone is 4% slower that way and keeps the whole chip).
+            grid = bk::items_grid(take, e->family->load() > 1 ? e->n_cus - e->n_cus / 4 : e->n_cus);
+            if (const char* gr = test_env("BK_ITEM_GRID")) grid = std::max<uint32_t>(1, std::min<uint32_t>(grid, (uint32_t)atoi(gr)));
+        }
         {
             bk_engine::Span sp(e, 0);
             if (e->use_items) { a.ov_par = e->ov_par; BK_HIP(bk::launch_scan_items(a, grid, e->stream)); }
@@ -2262,9 +2274,28 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
         unsigned long long h[32];
         unsigned int nd[2] = {0, 0};
         BK_HIP(hipMemcpyAsync(nd, e->n_deferred.p, sizeof nd, hipMemcpyDeviceToHost, e->stream));
+        std::vector<unsigned long long> clk(4 * 1024);
         BK_HIP(hipMemcpyAsync(h, e->dbg.p, sizeof h, hipMemcpyDeviceToHost, e->stream));
-        BK_HIP(hipMemsetAsync(e->dbg.p, 0, sizeof h, e->stream));
+        BK_HIP(hipMemcpyAsync(clk.data(), e->dbg.p + 32, clk.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+        BK_HIP(hipMemsetAsync(e->dbg.p, 0, (32 + 4 * 1024) * sizeof(unsigned long long), e->stream));
         BK_HIP(hipStreamSynchronize(e->stream));
+        {   // the scan's workgroups on the clock (the sample's last launch): when each started, had its reference, ran out of tiles, ended
+            unsigned long long t0 = ~0ull;
+            int n_wg = 0;
+            for (int b = 0; b < 1024; b++) if (clk[4 * b]) { t0 = std::min(t0, clk[4 * b]); n_wg = b + 1; }
+            if (n_wg) {
+                double mx[4] = {0, 0, 0, 0}, mean[4] = {0, 0, 0, 0}, mn[4] = {1e30, 1e30, 1e30, 1e30};
+                for (int b = 0; b < n_wg; b++)
+                    for (int j = 0; j < 4; j++) {
+                        const double us = (double)(clk[4 * b + j] - t0) * 0.01;
+                        mx[j] = std::max(mx[j], us); mn[j] = std::min(mn[j], us); mean[j] += us / n_wg;
+                    }
+                fprintf(stderr, "[bk] scan workgroups (%d), us after the first start, min / mean / max: start %.1f / %.1f / %.1f, reference staged %.1f / %.1f / %.1f, "
+                        "tiles done %.1f / %.1f / %.1f, end %.1f / %.1f / %.1f\n", n_wg, mn[0], mean[0], mx[0], mn[1], mean[1], mx[1], mn[2], mean[2], mx[2], mn[3], mean[3], mx[3]);
+                if (test_env("BK_L2_STATS")[0] == '2')
+                    for (int b = 0; b < n_wg; b++) fprintf(stderr, "[bk]   wg %d: %.1f %.1f %.1f %.1f\n", b, (clk[4 * b] - t0) * 0.01, (clk[4 * b + 1] - t0) * 0.01, (clk[4 * b + 2] - t0) * 0.01, (clk[4 * b + 3] - t0) * 0.01);
+            }
+        }
         fprintf(stderr, "[bk] finalize: %u + %u k-mers deferred to the general kernel\n", nd[0], nd[1]);
         if (e->sparse) {
             unsigned int nl[8];

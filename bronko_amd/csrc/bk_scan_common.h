@@ -15,9 +15,13 @@ namespace bk {
 // [2] mismatch-free head, [3] close pairs; Level 2: [4] k-mers looked at, [5] single-k-mer S runs, [6] dropped as dead,
 // [7] queued for the slow pipeline, [8] ... reference k-mers after all, [9] ... a neighbour found, [10] ... nothing; [11] chunks
 #define BK_DBG(a, idx, pred, cnt) do { if ((a).dbg && (pred)) atomicAdd((a).dbg + (idx), (unsigned long long)(cnt)); } while (0)
+// ... and behind the 32 tallies, per workgroup of scan_items_kernel: [32 + 4 b] clock at its start, [+ 1] after the reference is
+// staged, [+ 2] after its last tile, [+ 3] at its end (wall_clock64: 100 MHz)
+#define BK_DBG_CLOCK(a, slot) do { if ((a).dbg && threadIdx.x == 0) (a).dbg[32 + 4 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
 #else
 #define BK_ABLATE(a, x) false
 #define BK_DBG(a, idx, pred, cnt) do { } while (0)
+#define BK_DBG_CLOCK(a, slot) do { } while (0)
 #endif
 
 constexpr int kSeeds = 4;

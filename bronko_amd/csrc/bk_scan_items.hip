@@ -31,6 +31,7 @@ constexpr int kItemGroupsPerCu = 1;
 constexpr uint32_t kExtLocked = 0xffffffffu, kExtNone = 0xfffffffeu;   // ext_of[bin]: an extension bucket is being assigned / none is left
 constexpr size_t kItemLdsFixed = (4 + 4 + kItemBlock + kItemExtN) * sizeof(unsigned int);   // k-mer tally, extensions handed out, the item owners, the extensions' fills
 constexpr int kBinBlock = 256;
+constexpr uint32_t kMaxChunkMismatches = 24;   // more differences than this in a read's first 160 bases: not a read of that diagonal
 constexpr uint32_t kStageMaxWords = 12;    // records of up to 192 bases are staged in LDS (48 KB for the workgroup's 16 waves)
 
 // An item that found neither room in its bucket nor in the overflow list: straight to the plane (never lost, never fast).
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     const ColdArgs cold0 = (ColdArgs)__builtin_amdgcn_kernarg_segment_ptr();
     auto cold = [&]() __attribute__((always_inline)) -> ColdArgs { ColdArgs p = cold0; asm volatile("" : "+s"(p)); return p; };
 
+    BK_DBG_CLOCK(a, 0);
     const uint32_t total = a.total_cells;
     // the window (a multiple of 64 cells from the start): chosen on the device for a multi-genome index (choose_window_kernel), else
     // the engine's constant.  Only reads whose cells all lie in it are settled here: front pad, the window's cells, back pad
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
         for (uint32_t i = threadIdx.x; i <= n_refw; i += kItemBlock) lds_ref[rc_w0 + i] = g_rc[i];   // (one word more: the slice starts rc_base symbols into its first word)
     }
     __syncthreads();
+    BK_DBG_CLOCK(a, 1);
     // symbol / bit 0 is cell win_lo; negative positions down to -64 are readable (padding or earlier cells)
     const unsigned int* refw1 = lds_ref + kRefPadWords;
     const unsigned int* fastw = lds_ref + n_refw + kBitPadWords;
@@ -209,8 +212,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     // The workgroup's tiles are one contiguous stretch, dealt out to its waves one at a time (a counter in LDS): a tile with many
     // mismatches keeps one wave busy while the others take what is left -- with a fixed deal the workgroup waited for its
     // unluckiest wave, and the kernel for its unluckiest workgroup (waves were resident for 65% of the kernel's time).
-    const uint64_t tiles_per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
-    const uint64_t t_lo = (uint64_t)blockIdx.x * tiles_per_wg, t_hi = min(n_tiles, t_lo + tiles_per_wg);
+    const uint64_t t_lo = (uint64_t)blockIdx.x * n_tiles / gridDim.x, t_hi = (uint64_t)(blockIdx.x + 1u) * n_tiles / gridDim.x;   // (even shares: 61 or 62 of 15,625)
     auto take_tile = [&]() __attribute__((always_inline)) -> uint64_t {
         uint32_t t = 0u;
         if (lane == 0) t = __hip_atomic_fetch_add(ext_next + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -377,10 +379,8 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
                 candidate(shit[sq], scell, sisrc[sq] == src_rc, spos[sq]);
             }
         }
-        const uint32_t dfl = (fwd ? 1u : 0u) | (seeded ? 2u : 0u);
+        uint32_t dfl = (fwd ? 1u : 0u) | (seeded ? 2u : 0u);
         if (BK_ABLATE(a, 9) || BK_ABLATE(a, 7)) { if constexpr (STAGED) len_pf = stage(next_tile); continue; }
-        // a read that cannot be settled here is one N run
-        n_mark(nk != 0u && !l1ok, r32, 0u, nk, dg, dfl);
 
         // ---- mismatch flags, 160 bases at a time; mismatch by mismatch --------------------------------------------------
         const int32_t dgw = dg - (int32_t)win_lo;   // the diagonal in window coordinates
@@ -422,6 +422,16 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
                 if (j == 0) M01 |= (unsigned long long)f; else if (j == 1) M01 |= (unsigned long long)f << 32;
                 else if (j == 2) M23 |= (unsigned long long)f; else if (j == 3) M23 |= (unsigned long long)f << 32;
                 else M4 = f;
+            }
+            if (cb == 0u) {
+                // A read that differs from the reference all along its diagonal -- a chimera, an adapter, a diagonal that a repeat's
+                // k-mer vouched for -- is no read of this diagonal: it goes to Level 2 whole, like a read without one.  (Settled
+                // here it would keep its wave busy for a hundred mismatches while the workgroup's other waves run out of tiles: six
+                // such reads in a million set the kernel's time.)
+                const bool off_diag = l1ok && (uint32_t)__popcll(M01) + (uint32_t)__popcll(M23) + (uint32_t)__popc(M4) > kMaxChunkMismatches;
+                if (off_diag) { l1ok = false; dfl &= ~2u; M01 = 0ull; M23 = 0ull; M4 = 0u; }
+                // a read that cannot be settled here is one N run
+                n_mark(nk != 0u && !l1ok, r32, 0u, nk, dg, dfl);
             }
             const uint32_t scanned = cb + 160u;
             if constexpr (STAGED) {
@@ -582,6 +592,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     // go out as they are -- tab / ext_n say how many of a bucket's slots count), then the table ----
     if (threadIdx.x == 0) *block_kmers = 0;
     __syncthreads();
+    BK_DBG_CLOCK(a, 2);
     {
         const ColdArgs c = cold();
         uint4* const out4 = reinterpret_cast<uint4*>(c->items + (size_t)blockIdx.x * a.ig.wg_stride);
@@ -600,6 +611,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     if (lane == 0 && tot) atomicAdd(block_kmers, tot);
     __syncthreads();
     if (threadIdx.x == 0 && *block_kmers) { unsigned long long* kt = cold()->kmer_total; if (kt) atomicAdd(kt, (unsigned long long)*block_kmers); }
+    BK_DBG_CLOCK(a, 3);
 }
 
 // One workgroup per bin.  E bin b: window cells [128 b, 128 b + 383) -- its items start in its 128 cells and reach at most 255

@@ -1310,10 +1310,11 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             }
             // ... and, for the binned scan, the reference reverse-complemented (symbol J = complement of symbol cells - 1 - J, same
             // paddings) with seed tables keyed by the k-mer AS A READ SHOWS IT -- bases in reading order, 2 bits each from bit 0 -- on
-            // either strand: two entries per reference k-mer (along the reference: strand 0; against it: strand 1), twice the
-            // buckets.  A read's k-mer is hashed as it stands -- no reverse complement, no canonical form -- and verified against the
+            // either strand: two entries per reference k-mer (along the reference: strand 0; against it: strand 1), four times the
+            // buckets (a k-mer that finds its bucket full is no seed: 9% of them at twice the buckets, 3% at four times -- every
+            // lost seed is a second round of seeds for its tile).  A read's k-mer is hashed as it stands -- no reverse complement, no canonical form -- and verified against the
             // reference (strand 0) or its reverse complement (strand 1) with one comparison.
-            if (((uint64_t)ix->n_files << (L + 1)) * sizeof(uint2) <= (8ull << 30) && cells >= (uint64_t)k) {
+            if (((uint64_t)ix->n_files << (L + 2)) * sizeof(uint2) <= (8ull << 30) && cells >= (uint64_t)k) {
                 std::vector<uint32_t> h_rcw(h_refw.size() + 1, 0u);   // (+ 1: a window's slice starts inside a word, scan_items_kernel stages one word more)
                 parallel_for((size_t)((cells + 15) / 16), [&](size_t w0, size_t w1) {
                     for (size_t w = w0; w < w1; w++) {
@@ -1330,7 +1331,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     for (int t = 0; t < k; t++) g |= (uint64_t)((a[pad_w + ((pos + t) >> 4)] >> (2 * ((pos + t) & 15))) & 3u) << (2 * t);
                     return g;
                 };
-                const uint32_t L2 = L + 1;
+                const uint32_t L2 = L + 2;
                 e->seed2_log2 = L2;
                 std::vector<uint2> h_seed2((size_t)ix->n_files << L2, make_uint2(0xffffffffu, 0xffffffffu));
                 // Only the k-mers that start at ONE cell of their genome file are seeds: a repeat's entry would name one of its cells

@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all host cores)")
     ap.add_argument("--cpu-sample", type=int, default=1000000, help="reads (pairs) per pass through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--from-ascii", action="store_true", help="config 2 on one GPU: feed the timed steps from sequence lines resident in HBM through K0 (what "
+                    "\"value_with_k0\" of the default line measures briefly); for the rocprofv3 captures of K0 -- not the headline configuration")
     ap.add_argument("--experiment", action="store_true", help="tools/*.sh sweeps: BK_* testing variables may be set (the line says \"experiment\": true and is no result)")
     ap.add_argument("--allreduce", action="store_true", help="N > 1: all-reduce the counter plane instead of reduce-scatter + sharded finalize")
     ap.add_argument("--width", default="auto", choices=["auto", "16", "32", "64"], help="N > 1: bits per counter on the wire (bk_shard_transport). auto = "
@@ -600,8 +602,10 @@ def main():
 
     cfg = args.config
     extras = cfg == 2 and world == 1 and not args.no_other_configs and not args.selected_only
-    wl = Workload(cfg, args, rank, world, local_rank, dev, args.reads, args.batches, selected_only=args.selected_only, keep_ascii=extras)
-    out = measure(wl, args, dev, dist, args.steps, args.warmup)
+    if args.from_ascii and (cfg != 2 or world != 1):
+        raise SystemExit("bench.py: --from-ascii is for config 2 on one GPU")
+    wl = Workload(cfg, args, rank, world, local_rank, dev, args.reads, args.batches, selected_only=args.selected_only, keep_ascii=extras or args.from_ascii)
+    out = measure(wl, args, dev, dist, args.steps, args.warmup, from_ascii=args.from_ascii)
     build_id = source_build_id()
     traffic, valu_insts, note = pmc_traffic(cfg, args.reads, args.read_len, build_id)
     rf = out["roofline"]

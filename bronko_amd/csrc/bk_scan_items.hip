@@ -434,10 +434,10 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
                 n_mark(nk != 0u && !l1ok, r32, 0u, nk, dg, dfl);
             }
             const uint32_t scanned = cb + 160u;
-            if constexpr (STAGED) {
-                // the record's words are all read (the pass below takes the base at a mismatch from memory): the wave's next tile on its way
-                if (scanned >= maxlen) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); len_pf = stage(next_tile); }
-            }
+            // STAGED: once the record's words are all read the wave's next tile is sent on its way into the same buffer -- after the
+            // first pass below has taken the bases at its mismatches from it (a later pass, one tile in ten, reads them from memory)
+            const bool last_chunk = scanned >= maxlen;
+            bool next_staged = false;
             // A mismatch is resolved once the k - 1 bases behind it are scanned (or the read ends): that far reach the k-mers that
             // hold it, and whatever they hold of its successors is then known.  What is not resolved lies in the chunk's last
             // word (k <= 31): the word that is carried over.
@@ -451,6 +451,9 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
             for (int off = 1; off < 64; off <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)pin, off); if (lane >= off) pin += x; }
             const uint32_t pex = pin - cnt_m;
             const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)pin, 63));
+            if constexpr (STAGED) {
+                if (last_chunk && n_items == 0u) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); len_pf = stage(next_tile); next_staged = true; }
+            }
             for (uint32_t it0 = 0; it0 < n_items; it0 += 64u) {
                 // owner of item it0 + lane: every lane with items writes its number where its first item of this pass sits, a running
                 // maximum spreads it over the items behind
@@ -503,7 +506,13 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
                 uint32_t pat = bits32_at(fastw, ca) & ((1u << n_own) - 1u);   // bit p: the cell ca + p is fast
                 // which of the three other bases: read XOR reference at the mismatch, the same on either strand (bk_device.h)
                 const uint32_t tt = own ? (uint32_t)t : 0u;
-                const uint32_t rw = (words0 + (uint64_t)o_rec * a.stride_words)[min(tt >> 4, last_word)];
+                uint32_t rw;
+                if (STAGED && !next_staged) {
+                    rw = rec_buf[(uint32_t)src * sw + min(tt >> 4, last_word)];   // the owner's record is still in the wave's buffer
+                    if (last_chunk) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); len_pf = stage(next_tile); next_staged = true; }
+                } else {
+                    rw = (words0 + (uint64_t)o_rec * a.stride_words)[min(tt >> 4, last_word)];
+                }
                 const int32_t pr = own ? (ofwd ? o_dgw + (int32_t)tt : o_dgw + (int32_t)km1 - (int32_t)tt) : 0;
                 const uint32_t refb = (refw1[pr >> 4] >> (2u * ((uint32_t)pr & 15u))) & 3u;
                 const uint32_t alt = ((((rw >> (2u * (tt & 15u))) & 3u) ^ (ofwd ? refb : 3u - refb)) & 3u) - 1u;

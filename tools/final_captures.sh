@@ -1,7 +1,7 @@
-# The captures of a round's last build that are kept under profiles/ (run on the GPU box: gpurun -- bash tools/final_captures.sh r03_g).
+# The captures of a round's last build that are kept under profiles/ (run on the GPU box: gpurun -- bash tools/final_captures.sh r04_a).
 # Everything lands in gpurun_out/<tag>_*; copy what is to be judged into profiles/ afterwards (tools/README.md).
 cd $GRAFT_REPO_ROOT
-T=${1:-r03_g}
+T=${1:-r04_a}
 bash tools/profile_round.sh $T > gpurun_out/${T}_profile.log 2>&1
 tail -14 gpurun_out/${T}_profile.log
 cp gpurun_out/${T}_pmc_traffic.json profiles/pmc_traffic.json

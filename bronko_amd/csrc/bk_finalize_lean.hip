@@ -1,6 +1,6 @@
 // bk_finalize_lean.hip -- K2a / K2e for ONE genome file with dense planes (BASELINE configs 2 and 4), organised by REGION of the
-// reference like the binned scan: a workgroup owns 64 row positions of the V plane (finalize_vbin_kernel) or 256 cells
-// (finalize_ecell_kernel), casts the votes of call.rs:1327-1384 into a dense table in LDS over the pileup positions its k-mers can
+// reference like the binned scan: a workgroup owns 64 row positions of the V plane and the 64 reference k-mers of the same
+// ids (finalize_vbin_kernel), casts the votes of call.rs:1327-1384 into a dense table in LDS over the pileup positions its k-mers can
 // reach -- plain 32-bit LDS atomics, no hashing, no barrier inside the loop -- and adds the table to the pileup ONCE.
 //
 // The general kernels (bk_kernels.hip) take rows 12 at a time through a 512-slot hash table with two barriers and a flush per
@@ -25,7 +25,6 @@ namespace bk {
 constexpr int kLeanVBlock = 1024;
 constexpr uint32_t kLeanVq = 64;       // row positions q of the V plane per workgroup (6 rows each)
 constexpr uint32_t kLeanWin = 256;     // pileup positions of its vote table: 64 + v_span reference k-mers' cells and k - 1 behind, with slack
-constexpr uint32_t kLeanECells = 256, kLeanESpan = kLeanECells + 32;
 
 // one vote into the dense table (or, out of its reach, straight to the pileup)
 __device__ __forceinline__ void lean_vote(unsigned int* cnt, unsigned int* mxv, uint32_t span, uint32_t p0, const FinalizeArgs& a, uint32_t cell,
@@ -72,7 +71,6 @@ __global__ __launch_bounds__(kLeanVBlock) void finalize_vbin_kernel(FinalizeArgs
     const uint32_t p0 = ix.id_rec[id_lo].cell;
     for (uint32_t i = threadIdx.x; i < 8u * kLeanWin; i += kLeanVBlock) { cnt[i] = 0u; mxv[i] = 0u; }
     if (threadIdx.x < 5) lstats[threadIdx.x] = 0u;
-    if (blockIdx.x == 0 && threadIdx.x < 8) a.lean_n_list[threadIdx.x] = 0u;   // (finalize_ecell_kernel's list of reference k-mers that are not simple: empty)
     __syncthreads();
     unsigned long long* __restrict__ vc = const_cast<unsigned long long*>(a.counters) + ix.v_off;   // (written only under clear_v)
     const uint32_t lpr = span, gpw = 64u / lpr;                   // lanes per row, rows per wave
@@ -142,60 +140,46 @@ __global__ __launch_bounds__(kLeanVBlock) void finalize_vbin_kernel(FinalizeArgs
 #pragma unroll
     for (int off = 32; off; off >>= 1) variant += (unsigned int)__shfl_xor((int)variant, off);
     if (lane64 == 0 && variant) atomicAdd(&lstats[1], variant);
-    __syncthreads();
-    lean_flush(cnt, mxv, kLeanWin, p0, a);
-    finalize_epilogue(a, lstats, kept, distinct, lstats + 3, (int)blockIdx.x);
-}
-
-// K2e, one thread per cell: the reference k-mer that starts there (at its first occurrence), its two counters, its 2 W votes.
-__global__ __launch_bounds__(kLeanECells) void finalize_ecell_kernel(FinalizeArgs a) {
-    __shared__ unsigned int cnt[8 * kLeanESpan], mxv[8 * kLeanESpan];
-    __shared__ uint32_t lstats[3 + 2];
-    const IndexView& ix = a.ix;
-    const int k = ix.k;
-    const uint32_t W = (uint32_t)ix.W;
-    const uint32_t c0 = blockIdx.x * kLeanECells;
-    for (uint32_t i = threadIdx.x; i < 8u * kLeanESpan; i += kLeanECells) { cnt[i] = 0u; mxv[i] = 0u; }
-    if (threadIdx.x < 5) lstats[threadIdx.x] = 0u;
-    __syncthreads();
-    const uint32_t cell = c0 + threadIdx.x;
-    const uint32_t id = cell < ix.total_cells ? ix.id_at[cell] : 0xffffffffu;
-    unsigned int kept = 0, distinct = 0, perfect = 0;
-    if (id < ix.n_full) {
-        const uint4 idr = *reinterpret_cast<const uint4*>(ix.id_rec + id);
-        if (idr.z == cell) {   // (a repeated k-mer is mapped once, where it first occurs)
+    // ---- K2e for the same region: the reference k-mers [q0, q0 + 64) themselves, their two E counters, their 2 W votes -- into the
+    // same table (ids rise with their first cells: these k-mers start where the rows above voted).  16 threads per k-mer share its
+    // votes; the first of them keeps its statistics.  (A kernel of its own until round 4's last build: one launch and 0.011 ms.)
+    {
+        const uint32_t W = (uint32_t)ix.W;
+        const uint32_t sub = threadIdx.x & 15u, id = q0 + (threadIdx.x >> 4);
+        unsigned int perfect = 0;
+        if (id < ix.n_full) {
+            const uint4 idr = *reinterpret_cast<const uint4*>(ix.id_rec + id);
             const unsigned long long n0 = a.counters[2 * (size_t)id], n1 = a.counters[2 * (size_t)id + 1];
             if (!(idr.w & kIdSimple)) {
                 // Repeats: its buckets hold several BucketInfos each -- a walk of dependent loads that one thread would take a
-                // hundred microseconds over while the other 255 wait.  Listed instead; finalize_exact_kernel maps the list (votes and
+                // hundred microseconds over while the others wait.  Listed instead; finalize_exact_kernel maps the list (votes and
                 // statistics), a thread per (counter, bucket), as it maps the touched k-mers of a large index.
-                if (n0 | n1) a.lean_e_list[atomicAdd(a.lean_n_list + 2, 1u)] = id;
+                if (sub == 0u && (n0 | n1)) a.lean_e_list[atomicAdd(a.lean_n_list + 2, 1u)] = id;
             } else {
                 const uint64_t km = (uint64_t)idr.x | ((uint64_t)idr.y << 32);
                 const uint32_t rcid = (idr.w >> 1) & 1u;
 #pragma unroll
                 for (uint32_t isrc = 0; isrc < 2u; ++isrc) {
                     const unsigned long long n = isrc ? n1 : n0;
-                    distinct += n != 0;
+                    if (sub == 0u) distinct += n != 0;
                     if (n == 0 || n < a.ci || n > a.cx) continue;                // kmc -ci / -cx act on the true count
-                    kept += 1;
-                    perfect += 1;                                                // (simple: every bucket holds its one occurrence -- perfect in, and unique to, the one genome)
+                    if (sub == 0u) { kept += 1; perfect += 1; }                  // (simple: every bucket holds its one occurrence -- perfect in, and unique to, the one genome)
                     const uint32_t v = (uint32_t)(n > a.cs ? a.cs : n);          // kmc -cs: reported count saturates
                     // each of its W buckets holds its own single occurrence: {cell + j, idx = j, canonical = rcid}
-                    for (uint32_t t = 0; t < W; ++t) {
+                    for (uint32_t t = sub; t < W; t += 16u) {
                         const uint32_t j = (uint32_t)ix.wstart + t;
-                        lean_vote(cnt, mxv, kLeanESpan, c0, a, cell + j, j, rcid != 0u, km, isrc, k, v);
+                        lean_vote(cnt, mxv, kLeanWin, p0, a, idr.z + j, j, rcid != 0u, km, isrc, k, v);
                     }
                 }
             }
         }
-    }
 #pragma unroll
-    for (int off = 32; off; off >>= 1) perfect += (unsigned int)__shfl_xor((int)perfect, off);
-    if ((threadIdx.x & 63u) == 0u && perfect) { atomicAdd(&lstats[0], perfect); atomicAdd(&lstats[2], perfect); }
+        for (int off = 32; off; off >>= 1) perfect += (unsigned int)__shfl_xor((int)perfect, off);
+        if (lane64 == 0 && perfect) { atomicAdd(&lstats[0], perfect); atomicAdd(&lstats[2], perfect); }
+    }
     __syncthreads();
-    lean_flush(cnt, mxv, kLeanESpan, c0, a);
-    finalize_epilogue(a, lstats, kept, distinct, lstats + 3, a.row_exact + (int)blockIdx.x);
+    lean_flush(cnt, mxv, kLeanWin, p0, a);
+    finalize_epilogue(a, lstats, kept, distinct, lstats + 3, (int)blockIdx.x);
 }
 
 bool finalize_lean_ok(const FinalizeArgs& a) {
@@ -208,10 +192,4 @@ unsigned launch_finalize_lean_variant(const FinalizeArgs& a, hipStream_t stream)
     hipLaunchKernelGGL(finalize_vbin_kernel, dim3(grid), dim3(kLeanVBlock), 0, stream, a);
     return grid;
 }
-unsigned launch_finalize_lean_exact(const FinalizeArgs& a, hipStream_t stream) {
-    const unsigned grid = (unsigned)((a.ix.total_cells + kLeanECells - 1) / kLeanECells);
-    hipLaunchKernelGGL(finalize_ecell_kernel, dim3(grid), dim3(kLeanECells), 0, stream, a);
-    return grid;
-}
-
 }  // namespace bk

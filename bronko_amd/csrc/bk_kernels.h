@@ -246,7 +246,6 @@ void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
 // K2a / K2e organised by region of the reference (bk_finalize_lean.hip): one genome file, dense planes, one pass
 bool finalize_lean_ok(const FinalizeArgs& a);
 unsigned launch_finalize_lean_variant(const FinalizeArgs& a, hipStream_t stream);   // returns its grid (rows of FinalizeArgs::partials it writes)
-unsigned launch_finalize_lean_exact(const FinalizeArgs& a, hipStream_t stream);     // (a.row_exact = first row)
 // sparse finalize: touch bitmaps -> lists (the bitmaps are cleared on the way); lists -> their counters zeroed again
 void launch_expand_touched_blocks(unsigned int* touch_b, uint32_t n_blocks, const uint2* cell_blk, unsigned int* touch_v, uint32_t span, uint64_t n_q, hipStream_t stream);
 void launch_compact_touched(unsigned int* touch_v, uint64_t n_rows, unsigned int* touch_p, uint64_t n_prows, unsigned int* touch_e, uint64_t n_ids,

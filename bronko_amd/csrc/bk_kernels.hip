@@ -1845,6 +1845,8 @@ __global__ __launch_bounds__(256) void finalize_reduce_kernel(FinalizeArgs a, in
     const int n3 = a.ix.n_files * 3, cols = n3 + 2;
     // (the last kernel of a sample's last pass also zeroes the E part of the plane behind the sample: dense planes, see K2a's clear_v)
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (size_t)gridDim.x * 256) zero_p[i] = 0ull;
+    // (... and empties the regional finalize's list of reference k-mers that are not simple for the next pass: its readers are done)
+    if (a.lean_n_list && blockIdx.x == 0 && threadIdx.x < 8) a.lean_n_list[threadIdx.x] = 0u;
     const int col = blockIdx.x;   // one workgroup per column, rows strided over its threads
     unsigned long long s = 0;
     for (int r = threadIdx.x; r < n_rows; r += 256) s += a.partials[(size_t)r * cols + col];
@@ -2882,16 +2884,14 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     const bool lean = finalize_lean_ok(a) && (uint64_t)(a.ix.n_full + (uint32_t)a.ix.v_span) / 64 + (uint64_t)a.ix.total_cells / 256 + 2 + 64 + b_gen <= finalize_partial_rows();
     if (lean) {
         // one genome file, dense planes: K2a and K2e by region of the reference (bk_finalize_lean.hip)
-        b_v = launch_finalize_lean_variant(a, stream);
-        a.row_exact = (int)b_v;
-        b_e = launch_finalize_lean_exact(a, stream);
+        b_v = launch_finalize_lean_variant(a, stream);   // (V rows and the E counters of the same region)
         // ... and the reference k-mers it listed (repeats: not "simple"), a thread per (counter, bucket)
         FinalizeArgs l = a;
         l.e_list = a.lean_e_list; l.n_list = a.lean_n_list;
-        l.row_exact = (int)(b_v + b_e);
+        l.row_exact = (int)b_v;
         const unsigned b_list = 64;
         hipLaunchKernelGGL(finalize_exact_kernel, dim3(b_list), dim3(256), lds_votes, stream, l);
-        b_e += b_list;
+        b_e = b_list;
     } else {
     if (a.ix.slot_files) hipLaunchKernelGGL(finalize_variant_kernel<true>, dim3(b_var), dim3(256), lds_votes, stream, a);
     else hipLaunchKernelGGL(finalize_variant_kernel<false>, dim3(b_var), dim3(256), lds_votes, stream, a);

@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all host cores)")
     ap.add_argument("--cpu-sample", type=int, default=1000000, help="reads (pairs) per pass through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-events-every", type=int, default=16, help="timed region: HIP events around every N-th launch of the dominant kernel (an event record "
+                    "idles its stream for ~10 us on the GPU: bracketing every launch slowed down what it measured; max 255)")
     ap.add_argument("--from-ascii", action="store_true", help="config 2 on one GPU: feed the timed steps from sequence lines resident in HBM through K0 (what "
                     "\"value_with_k0\" of the default line measures briefly); for the rocprofv3 captures of K0 -- not the headline configuration")
     ap.add_argument("--experiment", action="store_true", help="tools/*.sh sweeps: BK_* testing variables may be set (the line says \"experiment\": true and is no result)")
@@ -359,7 +361,7 @@ def measure(wl, args, dev, dist, steps, warmup, sps=None, eng=None, selected_onl
         for f in shard_fin:
             f.comm_ms()
     # timed region: only the dominant kernel is bracketed by HIP events (on its launch stream, two records per launch)
-    timing(2)
+    timing(2 | (args.timed_events_every << 8))
     timing_read()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -423,13 +425,19 @@ def measure(wl, args, dev, dist, steps, warmup, sps=None, eng=None, selected_onl
     for i in range(3 if bounded else 8):   # (untimed: the chip settles into running one sample at a time)
         run_sample(i, 0)
     fence()
-    timing(1)
-    timing_read()
+    # ... first with no event in the stream (an event record idles the stream for ~10 us on the GPU: with every kernel kind
+    # bracketed a sample took 0.04 ms longer than it does), then once more with the brackets for the kernels' own durations
+    timing(0)
     ts0 = time.perf_counter()
     for i in range(n_serial):
         run_sample(i, 0)
     fence()
     serial_ms = (time.perf_counter() - ts0) / n_serial * 1e3
+    timing(1)
+    timing_read()
+    for i in range(n_serial):
+        run_sample(i, 0)
+    fence()
     kms_solo, kn_solo = timing_read()
     timing(0)
     if world > 1:
@@ -485,7 +493,7 @@ def measure(wl, args, dev, dist, steps, warmup, sps=None, eng=None, selected_onl
                      "measured": "HIP events around the kernel on its launch stream, samples run one at a time on the whole chip after the timed region",
                      # timed region: from the record before a scan launch to the record behind it on its stream -- the kernel sharing
                      # the CUs with the other samples' kernels AND whatever time it waited for CUs: not a kernel duration
-                     "avg_ms_in_flight_incl_queueing": scan_ms_fly, "launches_in_flight": kn_fly[0],
+                     "avg_ms_in_flight_incl_queueing": scan_ms_fly, "launches_in_flight": kn_fly[0], "launches_in_flight_bracketed_every": args.timed_events_every,
                      "reads_per_launch": reads_per_launch, "algorithmic_bytes_per_launch": algo_bytes},
         # per sample, one sample at a time (solo): what each kernel kind costs with nothing next to it
         "kernels_ms_per_sample_solo": {"scan_count": per_sample(kms_solo[0]), "finalize": per_sample(kms_solo[1]),

@@ -382,7 +382,7 @@ struct bk_engine {
     int ablate = 0;   // BK_SCAN_ABLATE (measurement aid): see scan_count_kernel
     uint64_t max_launch_records = 0;   // BK_MAX_LAUNCH_RECORDS (testing aid): split pushes into launches of at most this many records
     bool timing = false;
-    unsigned timing_kinds = 0xfu;
+    unsigned timing_kinds = 0xfu, timing_every = 1, timing_seen[4] = {0, 0, 0, 0};
     std::vector<TimedSpan> spans;
     std::vector<hipEvent_t> free_events;
 
@@ -408,7 +408,7 @@ struct bk_engine {
     struct Span {
         bk_engine* e; int kind; hipEvent_t a = nullptr;
         Span(bk_engine* eng, int k) : e(eng), kind(k) {
-            if (e->timing && (e->timing_kinds >> k) & 1) { a = e->get_event(); (void)hipEventRecord(a, e->stream); }
+            if (e->timing && (e->timing_kinds >> k) & 1 && e->timing_seen[k]++ % e->timing_every == 0) { a = e->get_event(); (void)hipEventRecord(a, e->stream); }
         }
         ~Span() {
             if (a) { hipEvent_t b = e->get_event(); (void)hipEventRecord(b, e->stream); e->spans.push_back({a, b, kind}); }
@@ -2672,7 +2672,9 @@ uint64_t bk_pack_reads_flat(const uint8_t* buf, const uint64_t* offsets, uint64_
 int bk_timing_enable(bk_engine* e, int on) {
     if (!e) return fail(BK_ERR_INVALID, "null engine");
     e->timing = on != 0;
-    e->timing_kinds = on == 1 ? 0xfu : (unsigned)(on >> 1) & 0xfu;   // on = 1: all kinds; otherwise bit (1 + kind) selects a kind
+    e->timing_kinds = (on & 0xff) == 1 ? 0xfu : (unsigned)(on >> 1) & 0xfu;   // on = 1: all kinds; otherwise bit (1 + kind) selects a kind
+    e->timing_every = std::max(1u, ((unsigned)on >> 8) & 0xffu);                // bits 8..15: every N-th launch of a kind only
+    for (auto& c : e->timing_seen) c = 0;
     return BK_OK;
 }
 

@@ -323,7 +323,9 @@ uint64_t bk_pack_reads_flat(const uint8_t* buf, const uint64_t* offsets, uint64_
  * synchronises and returns accumulated milliseconds and launch counts since the last reset:
  *   [0] scan_count kernel, [1] finalize kernels, [2] memsets + H2D/D2H copies, [3] level2 + fold kernels.
  * on = 1 brackets all four kinds; on = 2 << kind (or-able) only the selected ones, e.g. 2 = the scan kernel alone
- * (two event records per launch instead of ten per sample). */
+ * (two event records per launch instead of ten per sample).  Bits 8..15 of `on`, when not 0: only every N-th launch of a
+ * kind is bracketed -- an event record makes the stream wait for the kernel before it and costs the GPU ~10 us of idle
+ * time on that stream (rocprofv3 kernel trace), so a measurement that must not disturb what it measures samples. */
 int bk_timing_enable(bk_engine* e, int on);
 int bk_timing_read(bk_engine* e, double ms[4], uint64_t n[4], int reset);
 

@@ -9,7 +9,7 @@ ev.sort()
 # bench.py's timed region: the scan launches after the warm-up ones, `steps` of them (default: 3 warm-up, 20 timed)
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-scans = [e for e in ev if e[2].startswith("scan_count")]
+scans = [e for e in ev if e[2].startswith(("scan_count", "scan_items"))]
 t_lo = scans[warm][0]
 t_hi = scans[warm + steps][0] if len(scans) > warm + steps else ev[-1][1]
 ev = [e for e in ev if t_lo <= e[0] < t_hi]
@@ -22,7 +22,7 @@ for i, (s, e, n, q) in enumerate(ev):
             o += min(e, e2) - max(s, s2)
     ovl[n] += min(o, e - s)
 wall = ev[-1][1] - ev[0][0]
-nscan = sum(1 for e in ev if e[2].startswith("scan_count"))
+nscan = sum(1 for e in ev if e[2].startswith(("scan_count", "scan_items")))
 print("steady-state window: %.3f ms, %d scan launches -> %.4f ms per step" % (wall / 1e6, nscan, wall / 1e6 / max(nscan, 1)))
 for n in sorted(tot, key=lambda x: -tot[x]):
     print("%-40s n=%4d avg %8.1f us   overlapped with another queue's kernel: %4.0f %%" % (n[:40], cnt[n], tot[n] / cnt[n] / 1e3, 100.0 * ovl[n] / tot[n]))

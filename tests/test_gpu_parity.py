@@ -870,7 +870,8 @@ def test_config4_two_hundred_million_reads(oracle, sars_paths):
 def test_config5_hundred_strains_k31(oracle, sars_paths):
     """BASELINE configs[4] shape: 100 synthetic strains (wuhan_ref + 300 substitutions each), k = 31 -- 37 M window buckets, 8 M
     alias keys of the u64 bucket-id wrap, a 2.9 GB counter plane, tables far beyond the L2 -- and 200,000 reads of one sample
-    derived from strain 7, against the oracle bit for bit (pileups of all 100 genomes, per-genome statistics, selection)."""
+    derived from strain 7, against the oracle bit for bit (pileups of all 100 genomes, per-genome statistics, selection); then the
+    config's shape on forks (64 samples in turn) and one sample at its full size of 1,000,000 reads."""
     files = synth.strain_files(synth.read_fasta_bytes(sars_paths[0]), 100)
     ix = oracle.Index.build_mem(31, files)
     eng = helpers.engine_from_oracle_index(ix)
@@ -923,6 +924,19 @@ def test_config5_hundred_strains_k31(oracle, sars_paths):
         e.sample_finalize(1)
     for s_i in range(n_s - len(sel), n_s):
         settle(s_i)
+    # ... and one sample at the config's full size: 1,000,000 reads derived from strain 31, every genome's rows on the parent
+    # (call.rs:1305-1384 to the letter) and the selected genome's on a fork, both against the oracle on all host cores
+    gm_f, isnv_f = synth.sample_genome(files[31][1][0][1], 36)
+    c_f = synth.single_end_codes(gm_f, 1000000, 150, 5 * 1000003 + 31, isnv=isnv_f)
+    w_f, l_f = synth.pack_codes(c_f)
+    pile_f, _ = oracle.sample_pileup_mt(ix, [synth.BASES[c_f]], os.cpu_count() or 8)
+    assert oracle.pick_best_genome(ix, pile_f.stats.sum(axis=0), pile_f.present.max(axis=0)) == 31
+    eng.sample_begin()
+    eng.push_reads(0, w_f, l_f)
+    helpers.assert_same_pileup(eng.sample_finish(1), pile_f)
+    sel[1].sample_begin()
+    sel[1].push_reads(0, w_f, l_f)
+    check_selected(sel[1].sample_finish(1), pile_f, 31)
     for e in sel:
         e.close()
     eng.close()

@@ -304,7 +304,7 @@ struct bk_engine {
     bool use_items = false;
     bk::ItemGeom ig{};
     DevBuf<unsigned short> items, item_tab;
-    DevBuf<unsigned char> item_ext_n;
+    DevBuf<unsigned short> item_gext;       // [items_max_grid][bins][kItemGCap] the bins' extensions in device memory
     DevBuf<unsigned int> ov;
     DevBuf<unsigned long long> ov_n;
     uint32_t ov_par = 0;                    // parity of the next scan_items launch (which of the two overflow counts it appends to)
@@ -475,7 +475,7 @@ static int alloc_sample_state(bk_engine* e) {
         const size_t g = bk::items_max_grid(e->n_cus);
         BK_HIP(e->items.alloc(g * e->ig.wg_stride + 64));   // (+ 64: bin_count reads whole 16-byte units)
         BK_HIP(e->item_tab.alloc(g * ((size_t)e->ig.n_ebins + e->ig.n_vbins)));
-        BK_HIP(e->item_ext_n.alloc(g * bk::kItemExtN));
+        BK_HIP(e->item_gext.alloc(g * ((size_t)e->ig.n_ebins + e->ig.n_vbins) * bk::kItemGCap));   // (92 MB for one SARS-CoV-2 genome: 2 bytes x 256 slots x 701 bins x 256 workgroups)
         BK_HIP(e->ov.alloc((size_t)1 << 20));
         BK_HIP(e->ov_n.alloc(2));
         BK_HIP(hipMemset(e->ov_n.p, 0, 2 * sizeof(unsigned long long)));
@@ -1924,7 +1924,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.l2_words = bk::scan_l2_words(stride_words, e->k);
     const uint64_t l2_cap = std::max<uint64_t>(64, ((1ull << 30) / sizeof(unsigned int)) / a.l2_words);
     if (e->use_items) {
-        a.ig = e->ig; a.items = e->items.p; a.tab = e->item_tab.p; a.ext_n = e->item_ext_n.p; a.ov = e->ov.p; a.ov_n = e->ov_n.p; a.ov_cap = (uint32_t)e->ov.n;
+        a.ig = e->ig; a.items = e->items.p; a.tab = e->item_tab.p; a.gext = e->item_gext.p; a.ov = e->ov.p; a.ov_n = e->ov_n.p; a.ov_cap = (uint32_t)e->ov.n;
     }
     for (uint64_t base = 0; base < n;) {
         uint32_t grid = bk::scan_grid(n - base, e->n_cus);
@@ -1963,7 +1963,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
             bk_engine::Span sp(e, 3);
             // the scan's items, bin by bin -> u64 plane (before nbatch / level2 add to it: a sample's first launch finds the V part all zero)
             bk::BinArgs b{};
-            b.ig = e->ig; b.items = e->items.p; b.tab = e->item_tab.p; b.ext_n = e->item_ext_n.p; b.n_wg = grid; b.ov = e->ov.p; b.ov_n = e->ov_n.p; b.ov_cap = (uint32_t)e->ov.n;
+            b.ig = e->ig; b.items = e->items.p; b.tab = e->item_tab.p; b.gext = e->item_gext.p; b.n_wg = grid; b.ov = e->ov.p; b.ov_n = e->ov_n.p; b.ov_cap = (uint32_t)e->ov.n;
             b.ov_par = e->ov_par; e->ov_par ^= 1u;
             b.id_at = e->id_at.p; b.cell_codes = e->cell_codes.p + bk::scan_ref_pad_words(); b.win_lo = a.win_lo; b.win_dev = a.win_dev;
             b.total_cells = (uint32_t)e->total_cells; b.counters = e->counters[mate].p; b.v_off = e->v_off;

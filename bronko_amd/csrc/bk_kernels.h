@@ -14,24 +14,28 @@ namespace bk {
 //           bits 0-6 first cell & 127, bits 7-14 n - 1 (never 255: 0xffff is the null item), bit 15 the read runs against the reference
 //   V item  +1 / -1 at one counter of the V part of the plane, in the bin of (1 << vq_log2) row positions q it lies in:
 //           bits 0-14 offset of the counter from the bin's first, bit 15 = -1
-// A workgroup collects its items per bin in LDS buckets (cap_e / cap_v items; a bin that outgrows its bucket -- the V rows of a
-// sample's true variants, a coverage spike -- gets one of kItemExtN extension buckets of kItemExtCap items) and writes the buckets
-// out when it ends: items[wg][bucket slots ... | extension slots ...], tab[wg][bin] = items in the bin's bucket | (extension + 1) << 8,
-// ext_n[wg][extension] = items there.  bin_count_kernel, one workgroup per bin, adds them up in LDS (a 2 x 384-cell difference
-// array or the bin's V rows) and adds what is not zero to the plane: no slab, no fold, no same-address global atomic.  An item
-// that finds no room at all goes to a device-wide overflow list (bin << 16 | item) every bin's workgroup looks through, and
-// past that list's end to the plane directly.
+// A workgroup collects its items per bin in LDS buckets (cap_e / cap_v items: what 1/256 of a million reads at the benchmark's
+// error rate puts there, and three to four standard deviations) and writes the bucket area out as it is when it ends; a bin that
+// outgrows its bucket -- the V rows of a sample's true variants, a coverage spike, every bin of a sample with ten times the
+// benchmark's error rate -- continues in its EXTENSION in device memory (gext[wg][bin][kItemGCap]: a plain 2-byte store, the
+// slot is the bin's LDS count minus the bucket's capacity).  tab[wg][bin] = items of the bin in that workgroup, bucket and extension
+// together.  bin_count_kernel, one workgroup per bin, adds them up in LDS (a 2 x 384-cell difference array or the bin's V rows)
+// and adds what is not zero to the plane: no slab, no fold, no same-address global atomic.  An item that finds no room even in the
+// extension goes to a device-wide overflow list (bin << 16 | item) every bin's workgroup looks through, and past that list's end
+// to the plane directly.  (Until round 4's last build a bin that outgrew its bucket took one of 96 extension buckets in LDS and
+// everything else went to the list: with 700 bins overflowing -- 5 % sequencing errors -- the list was a million entries that
+// every workgroup of bin_count read through.)
 struct ItemGeom {
     uint32_t n_ebins, n_vbins;      // bins [0, n_ebins) are E bins, [n_ebins, n_ebins + n_vbins) V bins; at most 2 * 1024 in all
     uint32_t cap_e, cap_v;          // multiples of 8, <= 64
     uint32_t vq_log2;               // V bin = rows of 1 << vq_log2 positions q: (6 << vq_log2) * (v_span + 1) <= 32767 counters
     uint32_t wg_items;              // = n_ebins * cap_e + n_vbins * cap_v: bucket slots of one workgroup
-    uint32_t wg_stride;             // = wg_items + kItemExtN * kItemExtCap: u16 items of one workgroup's region
+    uint32_t wg_stride;             // = wg_items: u16 items of one workgroup's region
 };
 constexpr uint32_t kEBinLog2 = 7;   // E bins of 128 cells
 constexpr uint32_t kERunMax = 255;  // cells one E item covers at most
 constexpr uint32_t kEBinSpan = (1u << kEBinLog2) + kERunMax;   // cells an E bin's items reach from its first: 383 (the difference array has one more)
-constexpr uint32_t kItemExtN = 96, kItemExtCap = 64;
+constexpr uint32_t kItemGCap = 256;   // slots of a (scan workgroup, bin)'s extension in device memory (ScanArgs::gext): what its LDS bucket has no room for
 
 struct ScanArgs {
     const IndexView* ixp;           // device copy of the index view: only the rare paths of scan_count read it
@@ -101,8 +105,8 @@ struct ScanArgs {
     // the binned scan (launch_scan_items): where the items go
     ItemGeom ig;
     unsigned short* items;          // [grid][ig.wg_stride]
-    unsigned short* tab;            // [grid][n_bins]
-    unsigned char* ext_n;           // [grid][kItemExtN]
+    unsigned short* tab;            // [grid][n_bins] items of the bin in that workgroup: the first cap_e / cap_v in its bucket, the rest in its extension
+    unsigned short* gext;           // [grid][n_bins][kItemGCap] the extensions
     unsigned int* ov;               // [ov_cap] overflow list
     unsigned long long* ov_n;       // [2] entries appended by the launches of even / odd parity (may run past ov_cap: those went to the
     uint32_t ov_cap;                //     plane); bin_count_kernel zeroes the other parity's for the next launch
@@ -208,7 +212,7 @@ struct BinArgs {
     ItemGeom ig;
     const unsigned short* items;    // as ScanArgs
     const unsigned short* tab;
-    const unsigned char* ext_n;
+    const unsigned short* gext;
     uint32_t n_wg;                  // grid of the scan_items launch
     const unsigned int* ov;
     unsigned long long* ov_n;

@@ -28,8 +28,7 @@ namespace bk {
 constexpr int kItemBlock = 1024;            // one workgroup of 16 waves per CU: the window's reference is staged once per CU
 constexpr int kItemWaves = kItemBlock / 64;
 constexpr int kItemGroupsPerCu = 1;
-constexpr uint32_t kExtLocked = 0xffffffffu, kExtNone = 0xfffffffeu;   // ext_of[bin]: an extension bucket is being assigned / none is left
-constexpr size_t kItemLdsFixed = (4 + 4 + kItemBlock + kItemExtN) * sizeof(unsigned int);   // k-mer tally, extensions handed out, the item owners, the extensions' fills
+constexpr size_t kItemLdsFixed = (4 + 4 + kItemBlock) * sizeof(unsigned int);   // k-mer tally, the workgroup's tile counter, the item owners
 constexpr int kBinBlock = 256;
 constexpr uint32_t kMaxChunkMismatches = 24;   // more differences than this in a read's first 160 bases: not a read of that diagonal
 constexpr uint32_t kStageMaxWords = 12;    // records of up to 192 bases are staged in LDS (48 KB for the workgroup's 16 waves)
@@ -60,16 +59,13 @@ template <int KT, bool STAGED>
 __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned int* block_kmers = reinterpret_cast<unsigned int*>(smem);   // 16 B reserved
-    unsigned int* ext_next = block_kmers + 4;       // [0] extension buckets handed out (16 B reserved)
-    unsigned int* own_all = ext_next + 4;           // [waves][64] which lane owns each of the items of a pass (below)
-    unsigned int* ext_cnt = own_all + kItemBlock;   // [kItemExtN] items put into each extension bucket
-    unsigned int* cnt = ext_cnt + kItemExtN;        // [n_bins] items put into each bucket (may run past its capacity: those went to its extension)
+    unsigned int* wg_ctr = block_kmers + 4;         // [1] the workgroup's next tile that no wave has taken (16 B reserved)
+    unsigned int* own_all = wg_ctr + 4;             // [waves][64] which lane owns each of the items of a pass (below)
+    unsigned int* cnt = own_all + kItemBlock;       // [n_bins] items of each bin (the first cap in its bucket, the rest in its extension in device memory)
     const uint32_t n_eb = a.ig.n_ebins, n_bins = n_eb + a.ig.n_vbins, cap_e = a.ig.cap_e, cap_v = a.ig.cap_v;
-    const uint32_t nb_pad = (n_bins + 1u) & ~1u;
-    unsigned int* ext_of = cnt + nb_pad;            // [n_bins] 0 = none, else the bin's extension bucket + 1 (kExtLocked, kExtNone)
-    unsigned short* buck = reinterpret_cast<unsigned short*>(ext_of + nb_pad);   // E bin b: [b * cap_e, + cap_e); V bins behind them, cap_v each; then the extensions
-    unsigned short* ext_buck = buck + a.ig.wg_items;
-    unsigned int* lds_ref = reinterpret_cast<unsigned int*>(smem + ((kItemLdsFixed + (size_t)nb_pad * 8u + (size_t)a.ig.wg_stride * 2u + 7u) & ~(size_t)7u));
+    const uint32_t nb_pad = (n_bins + 3u) & ~3u;
+    unsigned short* buck = reinterpret_cast<unsigned short*>(cnt + nb_pad);   // E bin b: [b * cap_e, + cap_e); V bins behind them, cap_v each
+    unsigned int* lds_ref = reinterpret_cast<unsigned int*>(smem + ((kItemLdsFixed + (size_t)nb_pad * 4u + (size_t)a.ig.wg_stride * 2u + 7u) & ~(size_t)7u));
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform by construction: tell the compiler
@@ -96,9 +92,8 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     // the same cells of the reverse-complemented reference (ScanArgs::rc_words): window cell p is its symbol rc_base + lds_cells - 1 - p
     const uint32_t rc_lo = total - win_lo - lds_cells, rc_base = rc_lo & 15u;
     const uint32_t rc_w0 = blk_w0 + 2u * n_blk;
-    for (uint32_t i = threadIdx.x; i < n_bins; i += kItemBlock) { cnt[i] = 0u; ext_of[i] = 0u; }
-    if (threadIdx.x < kItemExtN) ext_cnt[threadIdx.x] = 0u;
-    if (threadIdx.x == 0) { ext_next[0] = 0u; ext_next[1] = (unsigned int)kItemWaves; }   // ([1]: the workgroup's next tile that no wave has taken)
+    for (uint32_t i = threadIdx.x; i < n_bins; i += kItemBlock) cnt[i] = 0u;
+    if (threadIdx.x == 0) wg_ctr[1] = (unsigned int)kItemWaves;
     {
         const ColdArgs c = cold();
         const uint32_t* const g_ref = c->ref_words + (win_lo >> 4);
@@ -129,30 +124,14 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     const uint32_t v_buck0 = n_eb * cap_e;
     const uint32_t last_word = a.stride_words - 1u;
 
-    // ---- the sinks: an item into its bin's bucket; a bin that outgrows its bucket gets an extension bucket; what finds no room at
-    // all spills into the device-wide overflow list ----
-    auto spill = [&](uint32_t bin, uint32_t item) {
+    // ---- the sinks: an item into its bin's bucket (slot s of the bin, counted in LDS); past the bucket's capacity into the bin's
+    // extension in device memory; past that into the device-wide overflow list, and past the list's end straight to the plane ----
+    auto put_ext = [&](uint32_t bin, uint32_t g /* s - capacity */, uint32_t item) {
         const ColdArgs c = cold();
+        if (g < kItemGCap) { c->gext[((size_t)blockIdx.x * n_bins + bin) * kItemGCap + g] = (unsigned short)item; return; }
         const unsigned long long i = atomicAdd(c->ov_n + c->ov_par, 1ull);
         if (i < (unsigned long long)c->ov_cap) c->ov[i] = (bin << 16) | item;
         else item_direct(c, bin, item, win_lo);
-    };
-    auto put_ext = [&](uint32_t bin, uint32_t item) {
-        for (;;) {
-            uint32_t e = __hip_atomic_load(&ext_of[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (e == 0u) {   // the first item past the bucket: whoever swaps the lock in assigns the extension
-                unsigned int expect = 0u;
-                if (!__hip_atomic_compare_exchange_strong(&ext_of[bin], &expect, kExtLocked, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) continue;
-                const uint32_t ne = __hip_atomic_fetch_add(ext_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                e = ne < kItemExtN ? ne + 1u : kExtNone;
-                __hip_atomic_store(&ext_of[bin], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if (e == kExtLocked) continue;   // (the lane that holds the lock never waits for anything: it is gone by the next look)
-            if (e == kExtNone) { spill(bin, item); return; }
-            const uint32_t s2 = __hip_atomic_fetch_add(&ext_cnt[e - 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (s2 < kItemExtCap) ext_buck[(e - 1u) * kItemExtCap + s2] = (unsigned short)item; else spill(bin, item);
-            return;
-        }
     };
     // cells [c_lo, c_lo + n) (window coordinates) each seen once more by a read along (f) / against the reference
     auto emit_e = [&](bool on, uint32_t c_lo, uint32_t n, bool f) {
@@ -163,7 +142,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
                 const uint32_t bin = c >> kEBinLog2;
                 const uint32_t item = (c & 127u) | ((take - 1u) << 7) | (f ? 0u : 0x8000u);
                 const uint32_t s = __hip_atomic_fetch_add(&cnt[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (s < cap_e) buck[bin * cap_e + s] = (unsigned short)item; else put_ext(bin, item);
+                if (s < cap_e) buck[bin * cap_e + s] = (unsigned short)item; else put_ext(bin, s - cap_e, item);
             }
             c += take; left -= take;
         } while (__ballot(left != 0u));
@@ -215,7 +194,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     const uint64_t t_lo = (uint64_t)blockIdx.x * n_tiles / gridDim.x, t_hi = (uint64_t)(blockIdx.x + 1u) * n_tiles / gridDim.x;   // (even shares: 61 or 62 of 15,625)
     auto take_tile = [&]() __attribute__((always_inline)) -> uint64_t {
         uint32_t t = 0u;
-        if (lane == 0) t = __hip_atomic_fetch_add(ext_next + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) t = __hip_atomic_fetch_add(wg_ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return t_lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     };
     uint32_t pf_sink = 0;               // destination of the prefetch loads (never read)
@@ -562,10 +541,10 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
                             const bool tail = hi2 - omin + 1 < span;
                             const uint32_t s = __hip_atomic_fetch_add(&cnt[bin], tail ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             unsigned short* const bk = buck + v_buck0 + (bin - n_eb) * cap_v;
-                            if (s < cap_v) bk[s] = (unsigned short)o0; else put_ext(bin, o0);
+                            if (s < cap_v) bk[s] = (unsigned short)o0; else put_ext(bin, s - cap_v, o0);
                             if (tail) {
                                 const uint32_t o1 = (o0 + (uint32_t)(hi2 - lo2 + 1)) | 0x8000u;
-                                if (s + 1u < cap_v) bk[s + 1u] = (unsigned short)o1; else put_ext(bin, o1);
+                                if (s + 1u < cap_v) bk[s + 1u] = (unsigned short)o1; else put_ext(bin, s + 1u - cap_v, o1);
                             }
                         }
                     }
@@ -598,7 +577,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::"v"(pf_sink) : "memory");   // the prefetch register stays reserved up to here
 
     // ---- the buckets, as they are, into this workgroup's region: the whole bucket area in 16-byte units (slots that hold nothing
-    // go out as they are -- tab / ext_n say how many of a bucket's slots count), then the table ----
+    // go out as they are -- tab says how many of a bin's slots count), then the table ----
     if (threadIdx.x == 0) *block_kmers = 0;
     __syncthreads();
     BK_DBG_CLOCK(a, 2);
@@ -608,11 +587,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
         const uint4* const buck4 = reinterpret_cast<const uint4*>(buck);
         for (uint32_t i = threadIdx.x; i < a.ig.wg_stride / 8u; i += kItemBlock) out4[i] = buck4[i];
         unsigned short* const tab_row = c->tab + (size_t)blockIdx.x * n_bins;
-        for (uint32_t bin = threadIdx.x; bin < n_bins; bin += kItemBlock) {
-            const uint32_t e = ext_of[bin];
-            tab_row[bin] = (unsigned short)(min(cnt[bin], bin < n_eb ? cap_e : cap_v) | ((e != 0u && e != kExtNone) ? e << 8 : 0u));
-        }
-        if (threadIdx.x < kItemExtN) c->ext_n[(size_t)blockIdx.x * kItemExtN + threadIdx.x] = (unsigned char)min(ext_cnt[threadIdx.x], kItemExtCap);
+        for (uint32_t bin = threadIdx.x; bin < n_bins; bin += kItemBlock) tab_row[bin] = (unsigned short)min(cnt[bin], (bin < n_eb ? cap_e : cap_v) + kItemGCap);
     }
     uint32_t tot = nkm;
 #pragma unroll
@@ -692,15 +667,10 @@ __global__ __launch_bounds__(kBinBlock) void bin_count_kernel(BinArgs b) {
         }
     };
     const uint32_t spec = is_e ? 48u : 24u;   // slots asked for above
-    auto take_rest = [&](const unsigned short* reg, uint32_t hdr, uint32_t n) __attribute__((always_inline)) {
-        if (n > spec) take_items(reg + base + spec, n - spec);   // (larger buckets than this kernel was written for)
-        if (hdr >> 8) {   // the bin's extension bucket in that workgroup
-            const uint32_t x = (hdr >> 8) - 1u;
-            take_items(reg + b.ig.wg_items + x * kItemExtCap, min((uint32_t)b.ext_n[(size_t)threadIdx.x * kItemExtN + x], kItemExtCap));
-        }
-    };
+    uint32_t g_mine = 0u;   // items of this bin in my scan workgroup's extension
     if (mine) {
-        const uint32_t n = min(hdr0 & 255u, cap);
+        const uint32_t n_all = hdr0, n = min(n_all, cap);
+        g_mine = min(n_all - n, kItemGCap);
         take8(v0, n);
         take8(v1, n > 8u ? n - 8u : 0u);
         take8(v2, n > 16u ? n - 16u : 0u);
@@ -709,16 +679,27 @@ __global__ __launch_bounds__(kBinBlock) void bin_count_kernel(BinArgs b) {
             take8(v4, n > 32u ? n - 32u : 0u);
             take8(v5, n > 40u ? n - 40u : 0u);
         }
-        take_rest(reg0, hdr0, n);
+        if (n > spec) take_items(reg0 + base + spec, n - spec);   // (larger buckets than this kernel was written for)
     }
     for (uint32_t wg = threadIdx.x + kBinBlock; wg < b.n_wg && !BK_ABLATE(b, 1); wg += kBinBlock) {   // (more scan workgroups than threads here: never on this chip)
         const unsigned short* reg = b.items + (size_t)wg * b.ig.wg_stride;
-        const uint32_t hdr = b.tab[(size_t)wg * n_bins + bin];
-        const uint32_t n = min(hdr & 255u, cap);
+        const uint32_t n_all = b.tab[(size_t)wg * n_bins + bin], n = min(n_all, cap);
         take_items(reg + base, n);
-        if (hdr >> 8) {
-            const uint32_t x = (hdr >> 8) - 1u;
-            take_items(reg + b.ig.wg_items + x * kItemExtCap, min((uint32_t)b.ext_n[(size_t)wg * kItemExtN + x], kItemExtCap));
+        take_items(b.gext + ((size_t)wg * n_bins + bin) * kItemGCap, min(n_all - n, kItemGCap));
+    }
+    // The extensions: a hot bin (a true variant site: thousands of reads on the same counters) has a hundred items in every scan
+    // workgroup's -- every thread reads its own workgroup's, eight 16-byte units in flight at a time (the counts are alike from
+    // workgroup to workgroup: the threads finish together).  (Sharing the concatenation of all extensions among the threads with a
+    // bisection per item was twice as slow: eight dependent LDS reads per item.)
+    if (g_mine) {
+        const uint4* q = reinterpret_cast<const uint4*>(b.gext + ((size_t)threadIdx.x * n_bins + bin) * kItemGCap);
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t i0 = 0; i0 < g_mine; i0 += 64u) {
+            uint4 u[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) u[j] = i0 + 8u * j < g_mine ? q[(i0 >> 3) + j] : z;
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) take8(u[j], g_mine > i0 + 8u * j ? g_mine - i0 - 8u * j : 0u);
         }
     }
     if (!BK_ABLATE(b, 7)) {   // the overflow list: everything there that names this bin
@@ -795,7 +776,7 @@ bool item_geometry(uint32_t win_cells, uint32_t n_full, int v_span, ItemGeom* g)
     // holds the mean of a uniform sample and three to four standard deviations (what goes beyond finds an extension bucket)
     g->cap_e = 48u; g->cap_v = 24u;
     g->wg_items = ne * g->cap_e + nv * g->cap_v;
-    g->wg_stride = g->wg_items + kItemExtN * kItemExtCap;
+    g->wg_stride = g->wg_items;
     return true;
 }
 
@@ -806,8 +787,8 @@ uint32_t items_grid(uint64_t n_records, int n_cus) {
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, items_max_grid(n_cus)));
 }
 size_t items_lds_bytes(const ItemGeom& g, uint32_t win_cells) {
-    const size_t nb_pad = ((size_t)g.n_ebins + g.n_vbins + 1u) & ~(size_t)1u;
-    return ((kItemLdsFixed + nb_pad * 8u + (size_t)g.wg_stride * 2u + 7u) & ~(size_t)7u) + scan_ref_lds_bytes(win_cells) + 8u +
+    const size_t nb_pad = ((size_t)g.n_ebins + g.n_vbins + 3u) & ~(size_t)3u;
+    return ((kItemLdsFixed + nb_pad * 4u + (size_t)g.wg_stride * 2u + 7u) & ~(size_t)7u) + scan_ref_lds_bytes(win_cells) + 8u +
            ((size_t)(kRefPadWords + (win_cells + 15) / 16 + kRefBackWords) + 1u) * sizeof(unsigned int);   // (+ the reverse-complemented reference)
 }
 

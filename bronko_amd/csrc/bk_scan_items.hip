@@ -78,6 +78,10 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     const ColdArgs cold0 = (ColdArgs)__builtin_amdgcn_kernarg_segment_ptr();
     auto cold = [&]() __attribute__((always_inline)) -> ColdArgs { ColdArgs p = cold0; asm volatile("" : "+s"(p)); return p; };
 
+    // The kernel keeps its CU to itself: 16 waves of 128 registers are a SIMD's whole file.  (At the 116 it needs, a wave of a small
+    // kernel of another sample -- K2b, the reduce, the zeroing -- fits next to four of its own, lands on a scan CU instead of a free
+    // one and runs a third slower there: 2.5 % of the headline.)
+    asm volatile("v_mov_b32 v127, 0" ::: "v127");
     BK_DBG_CLOCK(a, 0);
     const uint32_t total = a.total_cells;
     // the window (a multiple of 64 cells from the start): chosen on the device for a multi-genome index (choose_window_kernel), else
@@ -688,18 +692,18 @@ __global__ __launch_bounds__(kBinBlock) void bin_count_kernel(BinArgs b) {
         take_items(b.gext + ((size_t)wg * n_bins + bin) * kItemGCap, min(n_all - n, kItemGCap));
     }
     // The extensions: a hot bin (a true variant site: thousands of reads on the same counters) has a hundred items in every scan
-    // workgroup's -- every thread reads its own workgroup's, eight 16-byte units in flight at a time (the counts are alike from
+    // workgroup's -- every thread reads its own workgroup's, sixteen 16-byte units in flight at a time (the counts are alike from
     // workgroup to workgroup: the threads finish together).  (Sharing the concatenation of all extensions among the threads with a
     // bisection per item was twice as slow: eight dependent LDS reads per item.)
     if (g_mine) {
         const uint4* q = reinterpret_cast<const uint4*>(b.gext + ((size_t)threadIdx.x * n_bins + bin) * kItemGCap);
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        for (uint32_t i0 = 0; i0 < g_mine; i0 += 64u) {
-            uint4 u[8];
+        for (uint32_t i0 = 0; i0 < g_mine; i0 += 128u) {
+            uint4 u[16];
 #pragma unroll
-            for (uint32_t j = 0; j < 8u; ++j) u[j] = i0 + 8u * j < g_mine ? q[(i0 >> 3) + j] : z;
+            for (uint32_t j = 0; j < 16u; ++j) u[j] = i0 + 8u * j < g_mine ? q[(i0 >> 3) + j] : z;
 #pragma unroll
-            for (uint32_t j = 0; j < 8u; ++j) take8(u[j], g_mine > i0 + 8u * j ? g_mine - i0 - 8u * j : 0u);
+            for (uint32_t j = 0; j < 16u; ++j) take8(u[j], g_mine > i0 + 8u * j ? g_mine - i0 - 8u * j : 0u);
         }
     }
     if (!BK_ABLATE(b, 7)) {   // the overflow list: everything there that names this bin

@@ -4,11 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5]
 
 One SAMPLE = one pass of the hot path over the reads of one sample, inputs already resident in HBM:
-    bk_sample_begin  ->  bk_push_reads_packed_device per read batch (scan_count + level2 kernels)
+    bk_sample_begin  ->  bk_push_reads_packed_device per read batch (scan_items + bin_count + nbatch + level2 kernels)
     [-> RCCL reduce-scatter(sum) of the k-mer counter plane when one sample's reads are sharded over ranks]
     ->  bk_sample_finalize (KMC thresholds + map_kmers kernels).  Outputs stay in HBM.
-One STEP = `samples_per_step` samples (config.samples_per_step; 288 for config 2, so that the K = 20 timed steps are >= 1 s of
-GPU work and the driver's sampler sees them).  Samples are independent (call.rs:212 handles a run's samples one after the
+One STEP = `samples_per_step` samples (config.samples_per_step; 288 for config 2: the K = 20 timed steps are 0.6 s of GPU work --
+1 s when the number was chosen, the path is faster now -- and the driver's sampler sees them).  Samples are independent (call.rs:212 handles a run's samples one after the
 other): `--in-flight` engines on the same device tables (bk_engine_fork) take them in turn, each on its own stream.  The read
 batches rotate over >= 8 distinct synthetic batches (> 256 MiB in all), so no batch is served from the Infinity Cache.
 value = reads of all K steps / wall time of the K steps (barrier + synchronize on both sides, max over ranks).

@@ -7,10 +7,10 @@ One SAMPLE = one pass of the hot path over the reads of one sample, inputs alrea
     bk_sample_begin  ->  bk_push_reads_packed_device per read batch (scan_items + bin_count + nbatch + level2 kernels)
     [-> RCCL reduce-scatter(sum) of the k-mer counter plane when one sample's reads are sharded over ranks]
     ->  bk_sample_finalize (KMC thresholds + map_kmers kernels).  Outputs stay in HBM.
-One STEP = `samples_per_step` samples (config.samples_per_step; 288 for config 2: the K = 20 timed steps are 0.6 s of GPU work --
-1 s when the number was chosen, the path is faster now -- and the driver's sampler sees them).  Samples are independent (call.rs:212 handles a run's samples one after the
-other): `--in-flight` engines on the same device tables (bk_engine_fork) take them in turn, each on its own stream.  The read
-batches rotate over >= 8 distinct synthetic batches (> 256 MiB in all), so no batch is served from the Infinity Cache.
+One STEP = `samples_per_step` samples (config.samples_per_step; 512 for config 2, so that the K = 20 timed steps are >= 1 s of
+GPU work and the driver's sampler sees them; 288 until the path passed 6 G reads/s).  Samples are independent (call.rs:212
+handles a run's samples one after the other): `--in-flight` engines on the same device tables (bk_engine_fork) take them in
+turn, each on its own stream.  The read batches rotate over >= 8 distinct synthetic batches (> 256 MiB in all), so no batch is served from the Infinity Cache.
 value = reads of all K steps / wall time of the K steps (barrier + synchronize on both sides, max over ranks).
 
 --config 2 (default; BASELINE configs[1]): wuhan_ref k=21, samples of 1,000,000 x 150 bp single-end reads, seed 2.
@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[] entry (1-based as in SURVEY.md §8d)")
     ap.add_argument("--reads", type=int, default=1000000, help="reads (config 3: pairs) per batch = per GPU per sample in config 2")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--samples-per-step", type=int, default=0, help="0 = the config's default (288 / 1 / 1 / 64)")
+    ap.add_argument("--samples-per-step", type=int, default=0, help="0 = the config's default (512 / 1 / 1 / 64)")
     ap.add_argument("--batches", type=int, default=0, help="distinct read batches resident in HBM (0 = the config's default: 8 / 10 / 200 / 64)")
     ap.add_argument("--strains", type=int, default=100, help="config 5: number of synthetic strains")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all host cores)")
@@ -183,7 +183,7 @@ class Workload:
                                        (torch.arange(reads + 1, dtype=torch.int64, device=dev) * rl).contiguous()))
                 self.samples.append([(0, w, l, reads)])
                 del codes
-            self.sps = args.samples_per_step or 288
+            self.sps = args.samples_per_step or 512
             self.reads_per_sample_rank = reads
             self.reads_per_sample_total = reads * world
             self.scaling = "weak"

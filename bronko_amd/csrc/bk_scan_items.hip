@@ -289,21 +289,26 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
         // records in LDS a second round costs one more trip to the seed table, not a chain of three.
         for (int sround = 0; sround < 2 && seed_tab && !BK_ABLATE(a, 9) && !BK_ABLATE(a, 11); ++sround) {
             if (sround == 1 && !__ballot(len != 0u && !seeded)) break;
-            const int qa = sround ? 1 : 0, qb = sround ? kSeeds - 2 : kSeeds - 1;
+            // round 0: the read's first and last k-mer and one in between; round 1 (one tile in eight): the fourth
+            const int ns = sround ? 1 : 3;
             const bool had = seeded;
-            uint64_t sg[2];
-            uint32_t sh[2];
-            uint2 sb[2];
+            uint64_t sg[3];
+            uint32_t sh[3];
+            uint2 sb[3];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const uint32_t s = (hint_span * (uint32_t)(j ? qb : qa)) / (uint32_t)(kSeeds - 1);   // (wave-uniform)
+            for (int j = 0; j < 3; ++j) {
+                if (j >= ns) continue;
+                const int qj = sround ? kSeeds - 2 : (j == 0 ? 0 : j == 1 ? kSeeds - 1 : 1);
+                const uint32_t s = (hint_span * (uint32_t)qj) / (uint32_t)(kSeeds - 1);   // (wave-uniform)
                 sg[j] = read_symbols_at(w, s, last_word) & kmask;                  // the k-mer as the read shows it: base t at bits 2t
                 sh[j] = seed_hash(sg[j]);                                          // (no reverse complement, no canonical form: the table holds both strands)
                 sb[j] = seed_tab[sh[j] >> (32u - a.seed2_log2)];
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const uint32_t s = (hint_span * (uint32_t)(j ? qb : qa)) / (uint32_t)(kSeeds - 1);
+            for (int j = 0; j < 3; ++j) {
+                if (j >= ns) continue;
+                const int qj = sround ? kSeeds - 2 : (j == 0 ? 0 : j == 1 ? kSeeds - 1 : 1);
+                const uint32_t s = (hint_span * (uint32_t)qj) / (uint32_t)(kSeeds - 1);
                 const uint32_t tag = sh[j] & 15u;
                 const uint32_t ent = (sb[j].x != 0xffffffffu && (sb[j].x >> 28) == tag) ? sb[j].x : sb[j].y;
                 const uint32_t cell = ent & ((1u << kSeedCellBits) - 1u), strand = (ent >> kSeedCellBits) & 1u;

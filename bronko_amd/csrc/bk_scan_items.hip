@@ -753,9 +753,9 @@ __global__ __launch_bounds__(kBinBlock) void bin_count_kernel(BinArgs b) {
         // read-modify-write of whole lines instead of a million scattered atomics; v_mode 2: the V part is known to be all zero
         // (a sample's first launch into a clean plane) -- stores only
         if (BK_ABLATE(b, 2) || BK_ABLATE(b, 4)) {
-        } else if (b.v_mode == 2) {
+        } else if (b.v_mode == 2 && b.ov_n[b.ov_par] <= (unsigned long long)b.ov_cap) {   // (past the list's end the scan added to the plane itself: it is not all zero then)
             for (uint32_t i = threadIdx.x; i < n_here; i += kBinBlock) vc[i] = (unsigned long long)(long long)(int32_t)acc[i];
-        } else if (b.v_mode == 1) {
+        } else if (b.v_mode == 1 || b.v_mode == 2) {
             for (uint32_t i = threadIdx.x; i < n_here; i += kBinBlock) vc[i] += (unsigned long long)(long long)(int32_t)acc[i];
         } else {
             for (uint32_t i = threadIdx.x; i < n_here; i += kBinBlock) {
@@ -782,7 +782,7 @@ bool item_geometry(uint32_t win_cells, uint32_t n_full, int v_span, ItemGeom* g)
     if (ne + nv > 2u * (uint32_t)kItemBlock) return false;
     g->n_ebins = ne; g->n_vbins = nv; g->vq_log2 = vq_log2;
     // a workgroup sees 1 / n_cus of a launch: 3,900 of a million reads, 6,800 E items and 4,500 V items over these bins; a bucket
-    // holds the mean of a uniform sample and three to four standard deviations (what goes beyond finds an extension bucket)
+    // holds the mean of a uniform sample and three to four standard deviations (what goes beyond continues in the bin's extension in device memory)
     g->cap_e = 48u; g->cap_v = 24u;
     g->wg_items = ne * g->cap_e + nv * g->cap_v;
     g->wg_stride = g->wg_items;

@@ -139,6 +139,24 @@ def test_degenerate_identical_reads_spill_the_lds_histogram(oracle, hpv):
     assert int(res.fwd_depth.max()) == 200000 and int(res.rev_depth.max()) == 100000
 
 
+def test_one_hot_bin_through_every_tier_of_the_binned_scan(oracle, hpv):
+    """1.3 million copies of one read that carries one substitution, on both strands: every E item falls into two bins and every V
+    item into one -- per scan workgroup ten thousand items for a bucket of 24: the bucket, the bin's extension in device memory
+    (256 slots), the device-wide overflow list (a million entries) and, past its end, the plane itself (item_direct) all take
+    their share of the same counters.  Depths of 900,000 and 400,000 at the substitution, every cell as the oracle says."""
+    ix, eng = hpv
+    g = synth.read_fasta_bytes(os.path.join(helpers.GOLDEN, "HPV16.fa"))
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    w = bytearray(g[2000:2150].upper())
+    w[75] = ord("A") if w[75] != ord("A") else ord("C")
+    w = bytes(w)
+    reads = [w] * 900000 + [w.translate(comp)[::-1]] * 400000
+    res = helpers.hip_sample(eng, [reads], 21)
+    pile = oracle.sample_pileup_mt(ix, [reads], os.cpu_count() or 8)[0]
+    helpers.assert_same_pileup(res, pile)
+    assert int(res.fwd_depth.max()) == 900000 and int(res.rev_depth.max()) == 400000
+
+
 def test_lds_window_smaller_than_the_reference(oracle, golden_dir, monkeypatch, testing_lib):
     """BK_LDS_BINS (testing build) caps the LDS window: reads whose diagonal leaves it are N runs as a whole and their exact
     k-mers are counted by Level 2's membership test -- the path every genome but one of a multi-genome index takes.

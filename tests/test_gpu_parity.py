@@ -157,6 +157,27 @@ def test_one_hot_bin_through_every_tier_of_the_binned_scan(oracle, hpv):
     assert int(res.fwd_depth.max()) == 900000 and int(res.rev_depth.max()) == 400000
 
 
+def test_amplicon_reads_fill_every_bucket_of_a_region(oracle, sars_paths):
+    """An amplicon: 600,000 reads from one 400 bp stretch of SARS-CoV-2, 2 % substitutions, both strands, pushed in three batches
+    (the first launch stores its bins' V counters, the later ones add to them; the overflow list's two counters take turns).  Every
+    scan workgroup puts hundreds of items into the same few bins: buckets, extensions in device memory and the overflow list all
+    fill.  Against the oracle on all host cores."""
+    ix = oracle.Index.build(21, sars_paths[:1])
+    eng = helpers.engine_from_oracle_index(ix)
+    g = synth.read_fasta_bytes(sars_paths[0])
+    gm, isnv = synth.sample_genome(g[12000:12400], 9)
+    codes = synth.single_end_codes(gm, 600000, 150, 77, err=0.02, isnv=isnv)
+    reads = synth.BASES[codes]
+    pile = oracle.sample_pileup_mt(ix, [reads], os.cpu_count() or 8)[0]
+    words, lens = synth.pack_codes(codes)
+    eng.sample_begin()
+    for i in range(0, len(lens), 200000):
+        eng.push_reads(0, words[i:i + 200000], lens[i:i + 200000])
+    helpers.assert_same_pileup(eng.sample_finish(1), pile)
+    eng.close()
+    ix.close()
+
+
 def test_lds_window_smaller_than_the_reference(oracle, golden_dir, monkeypatch, testing_lib):
     """BK_LDS_BINS (testing build) caps the LDS window: reads whose diagonal leaves it are N runs as a whole and their exact
     k-mers are counted by Level 2's membership test -- the path every genome but one of a multi-genome index takes.

@@ -473,6 +473,7 @@ static int alloc_sample_state(bk_engine* e) {
                    bk::items_lds_bytes(e->ig, std::min<uint32_t>(e->n_lds_bins, (uint32_t)e->total_cells)) <= 128u * 1024u;
     if (e->use_items) {
         const size_t g = bk::items_max_grid(e->n_cus);
+        e->ig.grid_max = (uint32_t)g;
         BK_HIP(e->items.alloc(g * e->ig.wg_stride + 64));   // (+ 64: bin_count reads whole 16-byte units)
         BK_HIP(e->item_tab.alloc(g * ((size_t)e->ig.n_ebins + e->ig.n_vbins)));
         BK_HIP(e->item_gext.alloc(g * ((size_t)e->ig.n_ebins + e->ig.n_vbins) * bk::kItemGCap));   // (92 MB for one SARS-CoV-2 genome: 2 bytes x 256 slots x 701 bins x 256 workgroups)

@@ -30,7 +30,9 @@ struct ItemGeom {
     uint32_t cap_e, cap_v;          // multiples of 8, <= 64
     uint32_t vq_log2;               // V bin = rows of 1 << vq_log2 positions q: (6 << vq_log2) * (v_span + 1) <= 32767 counters
     uint32_t wg_items;              // = n_ebins * cap_e + n_vbins * cap_v: bucket slots of one workgroup
-    uint32_t wg_stride;             // = wg_items: u16 items of one workgroup's region
+    uint32_t wg_stride;             // = wg_items: u16 items of one workgroup's bucket area in LDS
+    uint32_t grid_max;              // scan workgroups the buffers are laid out for: items[bin][grid_max][cap] -- a bin's buckets of all workgroups are one stretch
+                                    // (bin_count reads it front to back) --, tab[bin][grid_max]
 };
 constexpr uint32_t kEBinLog2 = 7;   // E bins of 128 cells
 constexpr uint32_t kERunMax = 255;  // cells one E item covers at most
@@ -104,8 +106,8 @@ struct ScanArgs {
     unsigned long long rl_recip;    // ceil(2^64 / (v_span + 1)): counter index -> row by __umul64hi
     // the binned scan (launch_scan_items): where the items go
     ItemGeom ig;
-    unsigned short* items;          // [grid][ig.wg_stride]
-    unsigned short* tab;            // [grid][n_bins] items of the bin in that workgroup: the first cap_e / cap_v in its bucket, the rest in its extension
+    unsigned short* items;          // [bin][ig.grid_max][cap_e or cap_v] (E bins first)
+    unsigned short* tab;            // [n_bins][ig.grid_max] items of the bin in that workgroup: the first cap_e / cap_v in its bucket, the rest in its extension
     unsigned short* gext;           // [grid][n_bins][kItemGCap] the extensions
     unsigned int* ov;               // [ov_cap] overflow list
     unsigned long long* ov_n;       // [2] entries appended by the launches of even / odd parity (may run past ov_cap: those went to the

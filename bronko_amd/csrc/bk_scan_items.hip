@@ -592,11 +592,19 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     BK_DBG_CLOCK(a, 2);
     {
         const ColdArgs c = cold();
-        uint4* const out4 = reinterpret_cast<uint4*>(c->items + (size_t)blockIdx.x * a.ig.wg_stride);
+        // (bin-major in device memory: a bin's buckets of all workgroups are one stretch that bin_count reads front to back -- with a
+        // region per workgroup its threads fetched 96 bytes each from 256 places 45 KB apart, three times the bytes they used)
+        uint4* const out4 = reinterpret_cast<uint4*>(c->items);
         const uint4* const buck4 = reinterpret_cast<const uint4*>(buck);
-        for (uint32_t i = threadIdx.x; i < a.ig.wg_stride / 8u; i += kItemBlock) out4[i] = buck4[i];
-        unsigned short* const tab_row = c->tab + (size_t)blockIdx.x * n_bins;
-        for (uint32_t bin = threadIdx.x; bin < n_bins; bin += kItemBlock) tab_row[bin] = (unsigned short)min(cnt[bin], (bin < n_eb ? cap_e : cap_v) + kItemGCap);
+        const uint32_t ue = cap_e / 8u, uv = cap_v / 8u, n_eu = n_eb * ue, G = a.ig.grid_max;   // 16-byte units per bucket
+        for (uint32_t i = threadIdx.x; i < a.ig.wg_stride / 8u; i += kItemBlock) {
+            size_t dst;
+            if (i < n_eu) { const uint32_t bin = i / ue; dst = ((size_t)bin * G + blockIdx.x) * ue + (i - bin * ue); }
+            else { const uint32_t i2 = i - n_eu, bin = i2 / uv; dst = (size_t)n_eu * G + ((size_t)bin * G + blockIdx.x) * uv + (i2 - bin * uv); }
+            out4[dst] = buck4[i];
+        }
+        for (uint32_t bin = threadIdx.x; bin < n_bins; bin += kItemBlock)
+            c->tab[(size_t)bin * G + blockIdx.x] = (unsigned short)min(cnt[bin], (bin < n_eb ? cap_e : cap_v) + kItemGCap);
     }
     uint32_t tot = nkm;
 #pragma unroll
@@ -619,17 +627,19 @@ __global__ __launch_bounds__(kBinBlock) void bin_count_kernel(BinArgs b) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (BK_ABLATE(b, 5)) return;
     const uint32_t cap = is_e ? b.ig.cap_e : b.ig.cap_v;
-    const uint32_t base = is_e ? bin * b.ig.cap_e : n_eb * b.ig.cap_e + (bin - n_eb) * b.ig.cap_v;
+    const uint32_t G = b.ig.grid_max;
+    // this bin's buckets of all scan workgroups: one stretch of device memory, workgroup after workgroup
+    const unsigned short* const bin_items = b.items + (is_e ? (size_t)bin * G * b.ig.cap_e : (size_t)n_eb * G * b.ig.cap_e + (size_t)(bin - n_eb) * G * b.ig.cap_v);
     // A thread per scan workgroup: this bin's bucket in that workgroup's region.  The bucket's first 48 / 24 slots are asked for
     // together with the table entry that says how many of them hold items, before anything else is done -- one trip to memory,
     // not two (every bin's workgroup reads what 255 others wrote: nothing of it is in this XCD's L2).
     const bool mine = threadIdx.x < b.n_wg && !BK_ABLATE(b, 1);
-    const unsigned short* reg0 = b.items + (size_t)(mine ? threadIdx.x : 0u) * b.ig.wg_stride;
+    const unsigned short* reg0 = bin_items + (size_t)(mine ? threadIdx.x : 0u) * cap;
     uint32_t hdr0 = 0u;
     uint4 v0 = make_uint4(0u, 0u, 0u, 0u), v1 = v0, v2 = v0, v3 = v0, v4 = v0, v5 = v0;
     if (mine) {
-        const uint4* q = reinterpret_cast<const uint4*>(reg0 + base);
-        hdr0 = b.tab[(size_t)threadIdx.x * n_bins + bin];
+        const uint4* q = reinterpret_cast<const uint4*>(reg0);
+        hdr0 = b.tab[(size_t)bin * G + threadIdx.x];
         v0 = q[0]; v1 = q[1]; v2 = q[2];
         if (is_e) { v3 = q[3]; v4 = q[4]; v5 = q[5]; }
     }
@@ -688,12 +698,11 @@ __global__ __launch_bounds__(kBinBlock) void bin_count_kernel(BinArgs b) {
             take8(v4, n > 32u ? n - 32u : 0u);
             take8(v5, n > 40u ? n - 40u : 0u);
         }
-        if (n > spec) take_items(reg0 + base + spec, n - spec);   // (larger buckets than this kernel was written for)
+        if (n > spec) take_items(reg0 + spec, n - spec);   // (larger buckets than this kernel was written for)
     }
     for (uint32_t wg = threadIdx.x + kBinBlock; wg < b.n_wg && !BK_ABLATE(b, 1); wg += kBinBlock) {   // (more scan workgroups than threads here: never on this chip)
-        const unsigned short* reg = b.items + (size_t)wg * b.ig.wg_stride;
-        const uint32_t n_all = b.tab[(size_t)wg * n_bins + bin], n = min(n_all, cap);
-        take_items(reg + base, n);
+        const uint32_t n_all = b.tab[(size_t)bin * G + wg], n = min(n_all, cap);
+        take_items(bin_items + (size_t)wg * cap, n);
         take_items(b.gext + ((size_t)wg * n_bins + bin) * kItemGCap, min(n_all - n, kItemGCap));
     }
     // The extensions: a hot bin (a true variant site: thousands of reads on the same counters) has a hundred items in every scan
@@ -786,6 +795,7 @@ bool item_geometry(uint32_t win_cells, uint32_t n_full, int v_span, ItemGeom* g)
     g->cap_e = 48u; g->cap_v = 24u;
     g->wg_items = ne * g->cap_e + nv * g->cap_v;
     g->wg_stride = g->wg_items;
+    g->grid_max = 0;   // (set by the engine: items_max_grid of its device)
     return true;
 }
 

@@ -562,10 +562,16 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
                         // cells has no other reference k-mer form within Hamming distance 3, they hold exactly two differences from a
                         // reference k-mer that is isolated up to distance 3: neither a reference k-mer nor one base away from one
                         // (triangle inequality) -- they touch nothing.  Otherwise level2_kernel looks at them one by one.
-                        const int32_t ma = has_m ? (ofwd ? o_dgw + (int32_t)xm_lo : o_dgw - (int32_t)x_hi) : 0;
-                        const uint32_t needm = has_m ? 0xffffffffu >> (31u - (x_hi - xm_lo)) : 0u;
-                        const bool dead = !stats && tn2 - (int32_t)km1 > (int32_t)x_hi && (bits32_at(c3w, ma) & needm) == needm;
-                        l2_mark(has_m && !dead, o_rec, xm_lo, x_hi + 1u - xm_lo, o_dgw + (int32_t)win_lo, o_fl);
+                        // (those of them that stop short of tn2 -- [xm_lo, xd_hi] -- are judged on their own: in a stretch of three
+                        // close mismatches only the k-mers that hold all three are Level 2's)
+                        const int32_t xd_hi_i = min((int32_t)x_hi, tn2 - k);
+                        const bool has_d = has_m && !stats && xd_hi_i >= (int32_t)xm_lo;
+                        const uint32_t xd_hi = has_d ? (uint32_t)xd_hi_i : xm_lo;
+                        const int32_t ma = has_d ? (ofwd ? o_dgw + (int32_t)xm_lo : o_dgw - (int32_t)xd_hi) : 0;
+                        const uint32_t needm = has_d ? 0xffffffffu >> (31u - (xd_hi - xm_lo)) : 0u;
+                        const bool dead = has_d && (bits32_at(c3w, ma) & needm) == needm;
+                        const uint32_t xl = dead ? xd_hi + 1u : xm_lo;   // first k-mer that is marked
+                        l2_mark(has_m && xl <= x_hi, o_rec, xl, x_hi + 1u - xl, o_dgw + (int32_t)win_lo, o_fl);
                     }
                     // cells that are not fast
                     l2_mark(go && !fast, o_rec, x_lo, ln, o_dgw + (int32_t)win_lo, o_fl);

@@ -92,10 +92,22 @@ __global__ __launch_bounds__(kLeanVBlock) void finalize_vbin_kernel(FinalizeArgs
         const uint64_t kmer_p = (uint64_t)idr.x | ((uint64_t)idr.y << 32);
         const uint32_t ambp = idr.w;
         const int o = (int)oo + ix.v_omin;
+        // the row's prefix sums.  The raw counters are differences of counts, small as signed numbers: when every one of the wave's
+        // fits 26 bits (rows of at most 32: no sum leaves 32 bits) the shuffles carry one word instead of two
+        if (!__ballot(n + (1ull << 26) >= (1ull << 27))) {
+            int m = (int)(unsigned int)n;
 #pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
-            const unsigned long long t = __shfl_up(n, off, 64);   // (lane - off is in the same row whenever oo >= off)
-            if (oo >= (uint32_t)off) n += t;
+            for (int off = 1; off < 32; off <<= 1) {
+                const int t = __shfl_up(m, off, 64);   // (lane - off is in the same row whenever oo >= off)
+                if (oo >= (uint32_t)off) m += t;
+            }
+            n = (unsigned long long)(long long)m;
+        } else {
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                const unsigned long long t = __shfl_up(n, off, 64);
+                if (oo >= (uint32_t)off) n += t;
+            }
         }
         bool act = inq && n != 0;
         const uint32_t rcid = (ambp >> 1) & 1u;

@@ -97,9 +97,9 @@ __device__ __forceinline__ void for_each_neighbour(const IndexView& ix, uint64_t
 //   consecutive threads, consecutive words: the 40 MB of records leave as whole cache lines.  (Round 3's kernel took a thread per
 //   READ: 38 dependent steps of four letters each and ten word stores a record apart per lane -- 0.15 ms per million reads, the
 //   longest kernel of the K0..K2 chain.)  A read with anything else in it (N, too short a run, longer than a record) leaves its slot
-//   empty (length 0) and is noted in a work list;
-// pack_slow_kernel   one thread per listed read: its runs, byte by byte, appended behind the n_reads slots through a device
-//   counter, as before.  Records are unordered anyway.
+//   empty (length 0) and is taken byte by byte by the thread that holds its first word (pack_read_slow): its runs are appended
+//   behind the n_reads slots through a device counter.  Records are unordered anyway.
+// pack_slow_kernel   long reads (records of more than kPackMaxWords words): one thread per read, byte by byte, as before.
 __device__ __forceinline__ int acgt_code(unsigned char c) {
     switch (c | 0x20) {
         case 'a': return 0;
@@ -108,6 +108,42 @@ __device__ __forceinline__ int acgt_code(unsigned char c) {
         case 't': return 3;
         default: return -1;
     }
+}
+
+// One read, byte by byte: its runs of letters as records appended behind the n_reads slots (a.n_records[0]); returns how many.
+__device__ __forceinline__ unsigned long long pack_read_slow(const PackArgs& a, uint64_t r) {
+    const uint64_t maxb = min((uint64_t)a.stride_words * 16, (uint64_t)65535);
+    const uint64_t o0 = a.offsets[r], len = a.offsets[r + 1] - o0;
+    const uint8_t* s = a.bases + o0;
+    unsigned long long real = 0;
+    uint64_t start = 0;
+    for (uint64_t p = 0; p <= len; ++p) {
+        if (p < len && acgt_code(s[p]) >= 0) continue;
+        const uint64_t run = p - start;            // maximal ACGT run [start, p)
+        if (run >= (uint64_t)a.k) {
+            uint64_t pos = 0;
+            for (;;) {
+                const uint64_t take = min(maxb, run - pos);
+                const unsigned long long rec = atomicAdd(a.n_records, 1ull);
+                if (rec < a.cap) {
+                    uint32_t* w = a.words + rec * a.stride_words;
+                    uint32_t acc = 0;
+                    for (uint64_t j = 0; j < take; ++j) {
+                        acc |= (uint32_t)acgt_code(s[start + pos + j]) << (2 * (j & 15));
+                        if ((j & 15) == 15) { w[j >> 4] = acc; acc = 0; }
+                    }
+                    if (take & 15) w[take >> 4] = acc;
+                    for (uint64_t j = (take + 15) >> 4; j < a.stride_words; ++j) w[j] = 0;
+                    a.lens[rec] = (uint16_t)take;
+                    ++real;
+                }
+                if (pos + take >= run) break;
+                pos += take - (uint64_t)(a.k - 1);
+            }
+        }
+        start = p + 1;
+    }
+    return real;
 }
 
 constexpr int kPackBlock = 256;
@@ -193,50 +229,19 @@ __global__ __launch_bounds__(kPackBlock) void pack_words_kernel(PackArgs a, uint
         if (!good) {
             // (the launcher counted every read as a record that holds a run: one atomic per read that is not, none per block -- a
             // tally per block was 40,000 additions to one address, 0.5 ms per million reads)
-            atomicAdd(a.n_real, ~0ull);
-            // anything that may still hold a run of k letters: to the byte-by-byte kernel
-            if (len64 >= (uint64_t)a.k) a.work[atomicAdd(a.n_records + 2, 1ull)] = (uint32_t)(r0 + rl);
+            // anything that may still hold a run of k letters: byte by byte, by this thread, here (a kernel of its own behind this
+            // one -- a work list, a launch whose grid found it empty on the benchmark -- was 4.6 us of K0's 49)
+            const unsigned long long real = len64 >= (uint64_t)a.k ? pack_read_slow(a, r0 + rl) : 0ull;
+            atomicAdd(a.n_real, real - 1ull);
         }
     }
 }
 
-// One thread per listed read (a.work, or every read when there is no list): the runs of letters in it, byte by byte.
+// One thread per read (long reads: records of more than kPackMaxWords words): the slot of its index stays empty.
 __global__ __launch_bounds__(kPackBlock) void pack_slow_kernel(PackArgs a) {
-    const uint64_t n = a.work ? a.n_records[2] : a.n_reads;
-    const uint64_t maxb = min((uint64_t)a.stride_words * 16, (uint64_t)65535);
-    for (uint64_t i = (uint64_t)blockIdx.x * kPackBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kPackBlock) {
-        const uint64_t r = a.work ? (uint64_t)a.work[i] : i;
-        const uint64_t o0 = a.offsets[r], len = a.offsets[r + 1] - o0;
-        if (!a.work) a.lens[r] = 0;   // the slot of its index stays empty; its records, if any, go behind the n_reads slots
-        const uint8_t* s = a.bases + o0;
-        unsigned long long real = 0;
-        uint64_t start = 0;
-        for (uint64_t p = 0; p <= len; ++p) {
-            if (p < len && acgt_code(s[p]) >= 0) continue;
-            const uint64_t run = p - start;            // maximal ACGT run [start, p)
-            if (run >= (uint64_t)a.k) {
-                uint64_t pos = 0;
-                for (;;) {
-                    const uint64_t take = min(maxb, run - pos);
-                    const unsigned long long rec = atomicAdd(a.n_records, 1ull);
-                    if (rec < a.cap) {
-                        uint32_t* w = a.words + rec * a.stride_words;
-                        uint32_t acc = 0;
-                        for (uint64_t j = 0; j < take; ++j) {
-                            acc |= (uint32_t)acgt_code(s[start + pos + j]) << (2 * (j & 15));
-                            if ((j & 15) == 15) { w[j >> 4] = acc; acc = 0; }
-                        }
-                        if (take & 15) w[take >> 4] = acc;
-                        for (uint64_t j = (take + 15) >> 4; j < a.stride_words; ++j) w[j] = 0;
-                        a.lens[rec] = (uint16_t)take;
-                        ++real;
-                    }
-                    if (pos + take >= run) break;
-                    pos += take - (uint64_t)(a.k - 1);
-                }
-            }
-            start = p + 1;
-        }
+    for (uint64_t r = (uint64_t)blockIdx.x * kPackBlock + threadIdx.x; r < a.n_reads; r += (uint64_t)gridDim.x * kPackBlock) {
+        a.lens[r] = 0;   // its records, if any, go behind the n_reads slots
+        const unsigned long long real = pack_read_slow(a, r);
         if (real) atomicAdd(a.n_real, real);
     }
 }
@@ -257,14 +262,13 @@ void launch_pack_reads(const PackArgs& a0, hipStream_t stream) {
     if (a0.n_reads == 0) return;
     PackArgs a = a0;
     a.n_real = a.n_records + 1;
-    const bool by_word = a.stride_words <= kPackMaxWords && a.work;
+    const bool by_word = a.stride_words <= kPackMaxWords;
     // (pack_words_kernel starts from "every read is a record that holds a run" and takes the others off)
     hipLaunchKernelGGL(set3_u64_kernel, dim3(1), dim3(1), 0, stream, a.n_records, (unsigned long long)a.n_reads, by_word ? (unsigned long long)a.n_reads : 0ull, 0ull);
     if (by_word) {
         const uint32_t tpr = (a.stride_words + kPackWpt - 1) / kPackWpt, rpb = (uint32_t)kPackBlock / tpr;
         const uint32_t recip = (uint32_t)(((1ull << 32) + tpr - 1) / tpr);
         hipLaunchKernelGGL(pack_words_kernel, dim3((unsigned)((a.n_reads + rpb - 1) / rpb)), dim3(kPackBlock), 0, stream, a, rpb, tpr, recip);
-        hipLaunchKernelGGL(pack_slow_kernel, dim3(64), dim3(kPackBlock), 0, stream, a);   // (the listed reads: usually none)
     } else {
         a.work = nullptr;   // long reads: every read byte by byte
         hipLaunchKernelGGL(pack_slow_kernel, dim3((unsigned)std::min<uint64_t>((a.n_reads + kPackBlock - 1) / kPackBlock, 65535)), dim3(kPackBlock), 0, stream, a);

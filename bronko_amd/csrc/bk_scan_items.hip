@@ -96,6 +96,44 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     // the same cells of the reverse-complemented reference (ScanArgs::rc_words): window cell p is its symbol rc_base + lds_cells - 1 - p
     const uint32_t rc_lo = total - win_lo - lds_cells, rc_base = rc_lo & 15u;
     const uint32_t rc_w0 = blk_w0 + 2u * n_blk;
+    uint64_t n_records = a.n_records;
+    if (a.n_records_dev) {
+        const uint64_t nd = *a.n_records_dev;
+        n_records = nd > a.rec_base ? min(nd - a.rec_base, a.n_records) : 0ull;
+    }
+    const uint32_t* const words0 = a.words + a.rec_base * a.stride_words;
+    const uint16_t* const lens0 = a.lens + a.rec_base;
+    const uint64_t n_tiles = (n_records + 63) / 64;
+    // The workgroup's tiles are one contiguous stretch, dealt out to its waves one at a time (a counter in LDS): a tile with many
+    // mismatches keeps one wave busy while the others take what is left -- with a fixed deal the workgroup waited for its
+    // unluckiest wave, and the kernel for its unluckiest workgroup (waves were resident for 65% of the kernel's time).
+    const uint64_t t_lo = (uint64_t)blockIdx.x * n_tiles / gridDim.x, t_hi = (uint64_t)(blockIdx.x + 1u) * n_tiles / gridDim.x;   // (even shares: 61 or 62 of 15,625)
+    // STAGED: this wave's record buffer, and the copy of a tile into it.  Returns the lane's record length of that tile.
+    const uint32_t sw = a.stride_words;
+    unsigned int* const rec_buf = reinterpret_cast<unsigned int*>(smem + a.stage_off) + (uint32_t)wave * 64u * sw;
+    auto stage = [&](uint64_t t) -> uint32_t {
+        if (t >= t_hi) return 0u;
+        const uint64_t rr = t * 64 + (uint32_t)lane;
+        const uint32_t ln = rr < n_records ? (uint32_t)lens0[rr] : 0u;
+        if ((t + 1) * 64 <= n_records) {   // (wave-uniform) a whole tile: 64 * sw words, 16 * sw units of 16 bytes
+            const unsigned char* g = reinterpret_cast<const unsigned char*>(words0 + t * 64 * sw);
+            unsigned char* l = reinterpret_cast<unsigned char*>(rec_buf);
+            for (uint32_t u0 = 0; u0 < 16u * sw; u0 += 64u) {
+                const uint32_t u = u0 + (uint32_t)lane;
+                if (u < 16u * sw)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)u * 16u),
+                                                     (__attribute__((address_space(3))) void*)(l + (size_t)u0 * 16u), 16, 0, 0);
+            }
+        } else if (rr < n_records) {       // the launch's last tile: every lane copies its own record
+            const uint32_t* src = words0 + rr * sw;
+            for (uint32_t j = 0; j < sw; ++j) rec_buf[(uint32_t)lane * sw + j] = src[j];
+        }
+        return ln;
+    };
+    // (the wave's first tile is sent on its way into LDS before the workgroup stages the reference: the two copies run side by side)
+    uint32_t len_pf = 0u;
+    if constexpr (STAGED) len_pf = stage(t_lo + (uint32_t)wave);
+
     for (uint32_t i = threadIdx.x; i < n_bins; i += kItemBlock) cnt[i] = 0u;
     if (threadIdx.x == 0) wg_ctr[1] = (unsigned int)kItemWaves;
     {
@@ -184,18 +222,6 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     };
     const bool stats = a.ktab_keys != nullptr;   // full_kmer_stats: k-mers that touch nothing are still wanted by the statistics table (level2_kernel)
 
-    uint64_t n_records = a.n_records;
-    if (a.n_records_dev) {
-        const uint64_t nd = *a.n_records_dev;
-        n_records = nd > a.rec_base ? min(nd - a.rec_base, a.n_records) : 0ull;
-    }
-    const uint32_t* const words0 = a.words + a.rec_base * a.stride_words;
-    const uint16_t* const lens0 = a.lens + a.rec_base;
-    const uint64_t n_tiles = (n_records + 63) / 64;
-    // The workgroup's tiles are one contiguous stretch, dealt out to its waves one at a time (a counter in LDS): a tile with many
-    // mismatches keeps one wave busy while the others take what is left -- with a fixed deal the workgroup waited for its
-    // unluckiest wave, and the kernel for its unluckiest workgroup (waves were resident for 65% of the kernel's time).
-    const uint64_t t_lo = (uint64_t)blockIdx.x * n_tiles / gridDim.x, t_hi = (uint64_t)(blockIdx.x + 1u) * n_tiles / gridDim.x;   // (even shares: 61 or 62 of 15,625)
     auto take_tile = [&]() __attribute__((always_inline)) -> uint64_t {
         uint32_t t = 0u;
         if (lane == 0) t = __hip_atomic_fetch_add(wg_ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -207,31 +233,6 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     const uint2* const seed_tab = a.seed_tab2 ? a.seed_tab2 + ((size_t)win_file << a.seed2_log2) : nullptr;
     const uint32_t hint_len = n_records ? (uint32_t)__builtin_amdgcn_readfirstlane((int)lens0[0]) : 0u;
     const uint32_t hint_span = hint_len >= (uint32_t)k ? hint_len - (uint32_t)k : 0u;
-
-    // STAGED: this wave's record buffer, and the copy of a tile into it.  Returns the lane's record length of that tile.
-    const uint32_t sw = a.stride_words;
-    unsigned int* const rec_buf = reinterpret_cast<unsigned int*>(smem + a.stage_off) + (uint32_t)wave * 64u * sw;
-    auto stage = [&](uint64_t t) -> uint32_t {
-        if (t >= t_hi) return 0u;
-        const uint64_t rr = t * 64 + (uint32_t)lane;
-        const uint32_t ln = rr < n_records ? (uint32_t)lens0[rr] : 0u;
-        if ((t + 1) * 64 <= n_records) {   // (wave-uniform) a whole tile: 64 * sw words, 16 * sw units of 16 bytes
-            const unsigned char* g = reinterpret_cast<const unsigned char*>(words0 + t * 64 * sw);
-            unsigned char* l = reinterpret_cast<unsigned char*>(rec_buf);
-            for (uint32_t u0 = 0; u0 < 16u * sw; u0 += 64u) {
-                const uint32_t u = u0 + (uint32_t)lane;
-                if (u < 16u * sw)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)u * 16u),
-                                                     (__attribute__((address_space(3))) void*)(l + (size_t)u0 * 16u), 16, 0, 0);
-            }
-        } else if (rr < n_records) {       // the launch's last tile: every lane copies its own record
-            const uint32_t* src = words0 + rr * sw;
-            for (uint32_t j = 0; j < sw; ++j) rec_buf[(uint32_t)lane * sw + j] = src[j];
-        }
-        return ln;
-    };
-    uint32_t len_pf = 0u;
-    if constexpr (STAGED) len_pf = stage(t_lo + (uint32_t)wave);
 
     for (uint64_t tile = t_lo + (uint32_t)wave, next_tile = 0; tile < t_hi; tile = next_tile) {
         const uint64_t r = tile * 64 + lane;

@@ -159,6 +159,8 @@ struct FinalizeArgs {
     unsigned int* lean_e_list;      // bk_finalize_lean.hip: [n_full] the reference k-mers finalize_ecell_kernel leaves to finalize_exact_kernel (repeats), and
     unsigned int* lean_n_list;      //   [8] their number at [2] (the layout of n_list); null: no regional kernels
     int no_lean;                    // testing aid (BK_NO_LEAN_FINALIZE): the general K2a / K2e even where the regional kernels of bk_finalize_lean.hip apply
+    const unsigned int* tail_e_list;   // set by launch_finalize for finalize_general_kernel: the regional finalize's lean_e_list / lean_n_list, whose
+    const unsigned int* tail_n_list;   //   k-mers' E counters it maps behind its deferred k-mers (null otherwise)
     unsigned long long* zero_e;     // launch_finalize's last kernel also zeroes zero_e[0, zero_e_n): the plane's E part behind the sample (or null)
     size_t zero_e_n;
 };

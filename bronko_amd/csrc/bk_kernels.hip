@@ -2684,14 +2684,31 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
         }
         return;
     }
+    // (the regional finalize's list of reference k-mers that are not simple -- repeats: a few dozen -- rides with this kernel: two
+    // items per listed k-mer behind the deferred ones, its two E counters; a launch of finalize_exact_kernel for them was 14 us)
+    const uint64_t n_tail = (a.tail_e_list && a.mode == 0) ? 2ull * a.tail_n_list[2] : 0ull;
+    unsigned int tail_kept = 0, tail_distinct = 0;
     auto wave_item = [&](uint64_t item) {
         {
-            const uint64_t ci = n_e + a.deferred[item];          // always a V counter: the E counters are mapped by K2e (n_e: unused offset)
+            uint64_t ci, c;
             unsigned long long v;
-            uint64_t c;
             uint32_t isrc, p_, t_;
-            v_kmer_of_counter(ix, a.deferred_n ? nullptr : a.counters + ix.v_off, ci - n_e, p_, t_, c, isrc, v);
-            if (a.deferred_n) v = a.deferred_n[item];             // (K2a may have zeroed the row since)
+            if (item < n_items) {
+                ci = n_e + a.deferred[item];                      // a V counter (n_e: the offset that tells it from an E counter below)
+                v_kmer_of_counter(ix, a.deferred_n ? nullptr : a.counters + ix.v_off, ci - n_e, p_, t_, c, isrc, v);
+                if (a.deferred_n) v = a.deferred_n[item];         // (K2a may have zeroed the row since)
+            } else {
+                const uint64_t e = item - n_items;
+                const uint32_t id = a.tail_e_list[e >> 1];
+                isrc = (uint32_t)e & 1u;
+                ci = 2ull * id + isrc;                            // an E counter: the reference k-mer itself, read in orientation isrc
+                v = a.counters[ci];
+                const uint4 idr = *reinterpret_cast<const uint4*>(ix.id_rec + id);
+                c = (uint64_t)idr.x | ((uint64_t)idr.y << 32);
+                if (lane == 0) tail_distinct += v != 0;
+                if (v == 0 || v < a.ci || v > a.cx) return;       // kmc -ci / -cx act on the true count (wave-uniform)
+                if (lane == 0) tail_kept += 1;
+            }
             v = v > a.cs ? a.cs : v;                              // kmc -cs: reported count saturates
 
             int s = -1;   // lane t: the k-mer's bucket at window position t, if the index has it
@@ -2772,11 +2789,11 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
     } else
     // deferred items all passed the thresholds in K2a; one item per wave at a time, dealt round-robin so that a few
     // thousand items spread over the whole grid
-    for (uint64_t item = blockIdx.x; item < n_items; item += gridDim.x) wave_item(item);
+    for (uint64_t item = blockIdx.x; item < n_items + n_tail; item += gridDim.x) wave_item(item);
     __syncthreads();
     if (lane == 0) { ntouched[0] = 0; ntouched[1] = 0; }
     __syncthreads();
-    if (do_stats) finalize_epilogue(a, lstats, 0u, 0u, ntouched, a.row_general + (int)blockIdx.x);
+    if (do_stats) finalize_epilogue(a, lstats, tail_kept, tail_distinct, ntouched, a.row_general + (int)blockIdx.x);
 }
 
 // Sparse finalize: the set bits of a touch bitmap -> a list of indices (order is irrelevant); every word read is cleared, so the
@@ -2889,13 +2906,9 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     if (lean) {
         // one genome file, dense planes: K2a and K2e by region of the reference (bk_finalize_lean.hip)
         b_v = launch_finalize_lean_variant(a, stream);   // (V rows and the E counters of the same region)
-        // ... and the reference k-mers it listed (repeats: not "simple"), a thread per (counter, bucket)
-        FinalizeArgs l = a;
-        l.e_list = a.lean_e_list; l.n_list = a.lean_n_list;
-        l.row_exact = (int)b_v;
-        const unsigned b_list = 64;
-        hipLaunchKernelGGL(finalize_exact_kernel, dim3(b_list), dim3(256), lds_votes, stream, l);
-        b_e = b_list;
+        // ... and the reference k-mers it listed (repeats: not "simple") go with K2b's deferred k-mers
+        a.tail_e_list = a.lean_e_list; a.tail_n_list = a.lean_n_list;
+        b_e = 0;
     } else {
     if (a.ix.slot_files) hipLaunchKernelGGL(finalize_variant_kernel<true>, dim3(b_var), dim3(256), lds_votes, stream, a);
     else hipLaunchKernelGGL(finalize_variant_kernel<false>, dim3(b_var), dim3(256), lds_votes, stream, a);

@@ -1883,6 +1883,7 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
     a.k = e->k; a.wstart = e->wstart; a.W = e->W; a.v_omin = e->v_omin; a.v_span = e->v_span; a.v_off = e->v_off; a.total_cells = (uint32_t)e->total_cells; a.n_u = e->n_u;
     a.ref_words = e->ref_words.p; a.cell_codes = e->cell_codes.p; a.cell_has = e->cell_has.p; a.cell_clean = e->cell_clean.p; a.cell_clean3 = e->cell_clean3.p; a.cell_yf = e->cell_yf.p; a.cell_yr = e->cell_yr.p; a.id_at = e->id_at.p; a.cell_fast = e->cell_fast.p; a.cell_nat = e->cell_nat.p; a.cell_natrow = e->cell_natrow.p; a.cell_blk = e->cell_blk.p; a.seed_tab = e->seed_tab.p; a.seed_log2 = e->seed_log2;
     a.seed_tab2 = e->seed_tab2.p; a.seed2_log2 = e->seed2_log2; a.rc_words = e->rc_words.p;
+    a.n_direct = e->use_items && e->n_files == 1 && e->max_seqs_per_file == 1 && (uint64_t)e->n_lds_bins >= e->total_cells && !test_env("BK_NO_N_DIRECT");
     a.words = d_words; a.lens = d_lens; a.n_records = n; a.stride_words = stride_words;
     a.counters = e->counters[mate].p;
     a.kmer_total = e->kstats.p + mate * 4 + 1;

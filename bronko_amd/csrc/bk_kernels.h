@@ -113,6 +113,9 @@ struct ScanArgs {
     unsigned long long* ov_n;       // [2] entries appended by the launches of even / odd parity (may run past ov_cap: those went to the
     uint32_t ov_cap;                //     plane); bin_count_kernel zeroes the other parity's for the next launch
     uint32_t ov_par;
+    int n_direct;                   // the binned scan on one single-sequence genome that fits the window: a read it cannot settle has no usable diagonal
+                                    // (none found, or taken away: kMaxChunkMismatches) -- nbatch_kernel would only hand its k-mers on, so the scan
+                                    // marks them for level2_kernel itself and nbatch_kernel is not launched
     uint32_t stage_off;             // set by launch_scan_items: byte offset of the waves' record buffers in LDS (0: records are read from memory)
     int ablate;                     // measurement aid (-DBK_TESTING build only): 1 = Level 1 only, 2 = no V atomics, 3 = no slow path
     unsigned long long* dbg;        // -DBK_TESTING build, BK_L2_STATS=1: [32] tallies of what is left to Level 2 and why; null otherwise

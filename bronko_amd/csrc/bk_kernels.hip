@@ -1749,7 +1749,7 @@ hipError_t launch_level2(const ScanArgs& a, int n_cus, hipStream_t stream) {
     if (a.n_records == 0 || a.W <= 0) return hipSuccess;
     const bool stats = a.ktab_keys != nullptr;
     void (*kern)(ScanArgs);
-    {   // the N runs first (they mark k-mers for the kernel below)
+    if (!a.n_direct) {   // the N runs first (they mark k-mers for the kernel below); ScanArgs::n_direct: the scan left none
 #define BK_PICKN(KT) (!a.touch_v ? (stats ? nbatch_kernel<true, KT, false> : nbatch_kernel<false, KT, false>) \
                                  : (stats ? nbatch_kernel<true, KT, true> : nbatch_kernel<false, KT, true>))
         kern = a.k == 21 ? BK_PICKN(21) : a.k == 31 ? BK_PICKN(31) : BK_PICKN(0);

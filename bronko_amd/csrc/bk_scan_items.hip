@@ -420,7 +420,8 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
                 const bool off_diag = l1ok && (uint32_t)__popcll(M01) + (uint32_t)__popcll(M23) + (uint32_t)__popc(M4) > kMaxChunkMismatches;
                 if (off_diag) { l1ok = false; dfl &= ~2u; M01 = 0ull; M23 = 0ull; M4 = 0u; }
                 // a read that cannot be settled here is one N run
-                n_mark(nk != 0u && !l1ok, r32, 0u, nk, dg, dfl);
+                if (cold()->n_direct) l2_mark(nk != 0u && !l1ok, r32, 0u, nk, dg, dfl);   // (ScanArgs::n_direct: straight to Level 2's marks)
+                else n_mark(nk != 0u && !l1ok, r32, 0u, nk, dg, dfl);
             }
             const uint32_t scanned = cb + 160u;
             // STAGED: once the record's words are all read the wave's next tile is sent on its way into the same buffer -- after the

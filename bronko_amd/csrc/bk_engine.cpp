@@ -2061,8 +2061,7 @@ int bk_push_reads_ascii(bk_engine* e, int mate, const uint8_t* buf, const uint64
         pa.bases = sl.d_bases.p; pa.offsets = sl.d_off.p; pa.n_reads = n_reads; pa.k = e->k; pa.stride_words = stride;
         pa.words = sl.d_words.p; pa.lens = sl.d_lens.p; pa.cap = cap; pa.n_records = sl.d_nrec.p; pa.work = sl.d_work.p;
         bk_engine::Span sp(e, 2);
-        bk::launch_pack_reads(pa, e->stream);
-        bk::launch_add_u64(e->kstats.p + mate * 4 + 0, sl.d_nrec.p + 1, e->stream);   // records pushed, tallied on the device
+        bk::launch_pack_reads(pa, e->kstats.p + mate * 4 + 0, e->stream);   // (records pushed: tallied on the device)
     }
     int rc = push_device(e, mate, sl.d_words.p, stride, sl.d_lens.p, cap, sl.d_nrec.p, total);   // (a batch holds fewer k-mers than bases)
     if (rc != BK_OK) return rc;
@@ -2101,8 +2100,7 @@ int bk_push_reads_ascii_device(bk_engine* e, int mate, const void* d_bases, cons
         pa.k = e->k; pa.stride_words = stride;
         pa.words = sl.d_words.p; pa.lens = sl.d_lens.p; pa.cap = cap; pa.n_records = sl.d_nrec.p; pa.work = sl.d_work.p;
         bk_engine::Span sp(e, 2);
-        bk::launch_pack_reads(pa, e->stream);
-        bk::launch_add_u64(e->kstats.p + mate * 4 + 0, sl.d_nrec.p + 1, e->stream);   // records pushed, tallied on the device
+        bk::launch_pack_reads(pa, e->kstats.p + mate * 4 + 0, e->stream);   // (records pushed: tallied on the device)
     }
     return push_device(e, mate, sl.d_words.p, stride, sl.d_lens.p, cap, sl.d_nrec.p, total_bases);
 }

@@ -191,10 +191,10 @@ struct PackArgs {
     uint64_t cap;
     unsigned long long* n_records;  // out (device) [3]: record slots in use (read i's record in slot i, everything else appended behind
                                     // the n_reads slots), records that hold a run, reads on the work list; all set by the launcher
-    unsigned long long* n_real;     // = n_records + 1 (set by the launcher)
+    unsigned long long* n_real;     // the tally of records that hold a run (set by the launcher: its `tally` argument)
     uint32_t* work;                 // [n_reads] scratch: the reads that are not one clean run that fits a record (or null: no word-per-thread kernel)
 };
-void launch_pack_reads(const PackArgs& a, hipStream_t stream);
+void launch_pack_reads(const PackArgs& a, unsigned long long* tally, hipStream_t stream);   // tally: the sample's count of records that hold a run (+= this batch's)
 // votes[f] += number of the first records' middle k-mers that occur in genome file f (which genome does the sample look like?)
 void launch_pick_window(const ScanArgs& a, uint64_t n_probe, unsigned int* votes, const uint32_t* file_cell_lo, int forced, uint32_t* win,
                         hipStream_t stream);

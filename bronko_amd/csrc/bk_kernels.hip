@@ -255,16 +255,18 @@ void launch_add_u64(unsigned long long* dst, const unsigned long long* src, hipS
     hipLaunchKernelGGL(add_u64_kernel, dim3(1), dim3(1), 0, stream, dst, src);
 }
 
-__global__ void set3_u64_kernel(unsigned long long* dst, unsigned long long v0, unsigned long long v1, unsigned long long v2) { dst[0] = v0; dst[1] = v1; dst[2] = v2; }
-// a.n_records[0] = record slots in use when the kernels end (the n_reads slots of the reads' own indices + what was appended),
-// a.n_real = a.n_records + 1: records that hold a run (what KMC would call its input sequences); [2]: reads on the work list
-void launch_pack_reads(const PackArgs& a0, hipStream_t stream) {
+// K0's counters before its kernel: dst[0] = record slots in use when it ends (the n_reads slots of the reads' own indices + what is
+// appended), dst[1..2] unused, and the sample's tally of records that hold a run += v1 (the packer corrects it read by read)
+__global__ void pack_begin_kernel(unsigned long long* dst, unsigned long long v0, unsigned long long* tally, unsigned long long v1) { dst[0] = v0; dst[1] = 0ull; dst[2] = 0ull; *tally += v1; }
+// a.n_records[0] = record slots in use when the kernels end; `tally` (the sample's count of records that hold a run -- what KMC would
+// call its input sequences) grows by this batch's: a launch of its own that added a batch-local count to it afterwards was 4.5 us
+void launch_pack_reads(const PackArgs& a0, unsigned long long* tally, hipStream_t stream) {
     if (a0.n_reads == 0) return;
     PackArgs a = a0;
-    a.n_real = a.n_records + 1;
+    a.n_real = tally;
     const bool by_word = a.stride_words <= kPackMaxWords;
     // (pack_words_kernel starts from "every read is a record that holds a run" and takes the others off)
-    hipLaunchKernelGGL(set3_u64_kernel, dim3(1), dim3(1), 0, stream, a.n_records, (unsigned long long)a.n_reads, by_word ? (unsigned long long)a.n_reads : 0ull, 0ull);
+    hipLaunchKernelGGL(pack_begin_kernel, dim3(1), dim3(1), 0, stream, a.n_records, (unsigned long long)a.n_reads, tally, by_word ? (unsigned long long)a.n_reads : 0ull);
     if (by_word) {
         const uint32_t tpr = (a.stride_words + kPackWpt - 1) / kPackWpt, rpb = (uint32_t)kPackBlock / tpr;
         const uint32_t recip = (uint32_t)(((1ull << 32) + tpr - 1) / tpr);

@@ -1765,7 +1765,10 @@ hipError_t launch_level2(const ScanArgs& a, int n_cus, hipStream_t stream) {
     kern = a.k == 21 ? BK_PICK(21) : a.k == 31 ? BK_PICK(31) : BK_PICK(0);
 #undef BK_PICK
     const uint64_t blks = (a.n_records + 32 * kAnyWords - 1) / (32 * kAnyWords);     // a wave takes kAnyWords words of l2_any at a time
-    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((blks + kL2Waves - 1) / kL2Waves, (uint64_t)n_cus * 8));
+    // One genome file: a thousandth of the k-mers are marked, and four thousand waves that find nothing to do still take their turn
+    // on the CUs the sibling samples' kernels are waiting for (three samples in flight: 10.5 -> 10.8 G reads/s with a quarter of the
+    // waves; alone the kernel takes what it took).  Several files: the marks are Level 2's real work (config 3 lost 8 % that way).
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((blks + kL2Waves - 1) / kL2Waves, (uint64_t)n_cus * (a.n_files == 1 ? 2 : 8)));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kL2Block), 0, stream, a);
     return hipGetLastError();
 }

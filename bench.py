@@ -119,10 +119,17 @@ def source_build_id():
     """sha256 over the kernel / engine sources the shipped libbronko_hip.so was built from (profiles/pmc_traffic.json carries the
     id it was captured with: a traffic figure of another build is not reported)."""
     h = hashlib.sha256()
-    for rel in ("bronko_amd/csrc/bk_kernels.hip", "bronko_amd/csrc/bk_scan_items.hip", "bronko_amd/csrc/bk_scan_common.h", "bronko_amd/csrc/bk_engine.cpp",
-                "bronko_amd/csrc/bk_device.h", "bronko_amd/csrc/bk_kernels.h"):
-        with open(os.path.join(ROOT, rel), "rb") as f:
-            h.update(f.read())
+    csrc = os.path.join(ROOT, "bronko_amd", "csrc")
+    names = []
+    with open(os.path.join(csrc, "Makefile")) as f:   # every file of the Makefile's SRC and HDR lists: what the library is built from
+        for line in f:
+            if line.startswith(("SRC :=", "HDR :=")):
+                names += line.split(":=", 1)[1].split()
+    if not names:
+        raise SystemExit("bench.py: no SRC / HDR lists in bronko_amd/csrc/Makefile")
+    for rel in sorted(names):
+        with open(os.path.normpath(os.path.join(csrc, rel)), "rb") as f:
+            h.update(rel.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
 
 

@@ -52,7 +52,7 @@ class BuiltIndex(C.Structure):  # bk_built_index
 
 # every symbol include/bronko_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = ["bk_abi_version", "bk_device_count", "bk_device_memory", "bk_last_error", "bk_params_default", "bk_engine_create", "bk_engine_destroy", "bk_engine_fork", "bk_engine_fork_params", "bk_engine_get_stream",
-           "bk_engine_set_stream", "bk_total_cells", "bk_n_files", "bk_n_slots", "bk_counter_len", "bk_sample_begin",
+           "bk_engine_set_stream", "bk_total_cells", "bk_n_files", "bk_n_slots", "bk_counter_len", "bk_can_shard", "bk_sample_begin",
            "bk_push_reads_packed", "bk_push_reads_packed_device", "bk_push_reads_ascii", "bk_push_reads_ascii_device", "bk_counters_device_ptr", "bk_sample_finalize",
            "bk_sample_finalize_shard", "bk_shard_measure", "bk_shard_transport", "bk_shard_received", "bk_transport_overflow", "bk_shard_sums_device_ptr", "bk_sample_merge_shards", "bk_kmer_table_partition", "bk_kmer_table_replace",
            "bk_pileup_device_ptr", "bk_sample_download", "bk_sample_finish", "bk_pack_reads", "bk_pack_reads_flat",

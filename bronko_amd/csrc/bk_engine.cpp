@@ -1777,6 +1777,7 @@ uint64_t bk_total_cells(const bk_engine* e) { return e ? e->total_cells : 0; }
 int32_t bk_n_files(const bk_engine* e) { return e ? e->n_files : 0; }
 uint64_t bk_n_slots(const bk_engine* e) { return e ? e->n_slots : 0; }
 uint64_t bk_counter_len(const bk_engine* e) { return e ? e->plane_len : 0; }
+int bk_can_shard(const bk_engine* e) { return e && !e->sparse ? 1 : 0; }
 
 int bk_sample_begin(bk_engine* e) {
     if (!e) return fail(BK_ERR_INVALID, "null engine");
@@ -2086,7 +2087,6 @@ int bk_push_reads_ascii_device(bk_engine* e, int mate, const void* d_bases, cons
     const uint32_t stride = (uint32_t)std::min<uint64_t>((longest + 15) / 16, 4095);
     const uint64_t maxb = std::min<uint64_t>((uint64_t)stride * 16, 65535);
     const uint64_t cap = n_reads + total_bases / (uint64_t)e->k + total_bases / (maxb - (uint64_t)(e->k - 1)) + 16;   // bound on the records
-    if ((reinterpret_cast<uintptr_t>(d_bases) & 15u) != 0) return fail(BK_ERR_INVALID, "bk_push_reads_ascii_device: d_bases must be 16-byte aligned (the packer stages the lines with 16-byte loads)");
     if (sl.d_words.n < cap * stride || sl.d_lens.n < cap || sl.d_work.n < n_reads) {
         BK_HIP(hipStreamSynchronize(e->stream));
         BK_HIP(sl.d_words.alloc(cap * stride + cap * stride / 4));
@@ -2096,7 +2096,11 @@ int bk_push_reads_ascii_device(bk_engine* e, int mate, const void* d_bases, cons
     if (!sl.d_nrec.p) BK_HIP(sl.d_nrec.alloc(4));
     {
         bk::PackArgs pa{};
-        pa.bases = static_cast<const uint8_t*>(d_bases); pa.offsets = static_cast<const unsigned long long*>(d_offsets); pa.n_reads = n_reads;
+        // the packer stages the lines with 16-byte loads from a 16-byte boundary: a pointer into the middle of an allocation (any
+        // alignment) is rounded down and the offsets carry the difference (a device allocation starts on a 256-byte boundary, so the
+        // bytes in front belong to the same allocation)
+        pa.shift = (uint32_t)(reinterpret_cast<uintptr_t>(d_bases) & 15u);
+        pa.bases = static_cast<const uint8_t*>(d_bases) - pa.shift; pa.offsets = static_cast<const unsigned long long*>(d_offsets); pa.n_reads = n_reads;
         pa.k = e->k; pa.stride_words = stride;
         pa.words = sl.d_words.p; pa.lens = sl.d_lens.p; pa.cap = cap; pa.n_records = sl.d_nrec.p; pa.work = sl.d_work.p;
         bk_engine::Span sp(e, 2);
@@ -2163,6 +2167,7 @@ int bk_counters_device_ptr(bk_engine* e, int mate, void** d_ptr) {
         if (int rc = zero_plane_if_stale(e, mate)) return rc;
     }
     e->plane_used[mate] = true;   // (the caller may write it: collectives)
+    e->v_clean[mate] = false;     // ... so the next bin_count launch adds to the V part instead of storing over it
     *d_ptr = e->counters[mate].p;
     return BK_OK;
 }

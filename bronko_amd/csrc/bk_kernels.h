@@ -181,7 +181,8 @@ struct FoldArgs {
 };
 
 struct PackArgs {
-    const uint8_t* bases;           // sequence lines back to back
+    const uint8_t* bases;           // sequence lines back to back (16-byte aligned: the caller's pointer rounded down)
+    uint32_t shift;                 // ... and by how many bytes: line i starts at bases + shift + offsets[i]
     const unsigned long long* offsets;   // [n_reads + 1]
     uint64_t n_reads;
     int32_t k;

@@ -114,7 +114,7 @@ __device__ __forceinline__ int acgt_code(unsigned char c) {
 __device__ __forceinline__ unsigned long long pack_read_slow(const PackArgs& a, uint64_t r) {
     const uint64_t maxb = min((uint64_t)a.stride_words * 16, (uint64_t)65535);
     const uint64_t o0 = a.offsets[r], len = a.offsets[r + 1] - o0;
-    const uint8_t* s = a.bases + o0;
+    const uint8_t* s = a.bases + a.shift + o0;
     unsigned long long real = 0;
     uint64_t start = 0;
     for (uint64_t p = 0; p <= len; ++p) {
@@ -176,10 +176,11 @@ __global__ __launch_bounds__(kPackBlock) void pack_words_kernel(PackArgs a, uint
     const uint32_t sw = a.stride_words;
     const uint64_t r0 = (uint64_t)blockIdx.x * rpb, r1 = min(r0 + (uint64_t)rpb, a.n_reads);
     const uint32_t nr = (uint32_t)(r1 - r0);
-    if (threadIdx.x <= nr) off_s[threadIdx.x] = a.offsets[r0 + threadIdx.x];
+    // nr + 1 offsets: with records of one or two words a full block holds 256 reads, one offset more than it has threads
+    for (uint32_t i = threadIdx.x; i <= nr; i += kPackBlock) off_s[i] = a.offsets[r0 + i] + a.shift;
     if (threadIdx.x < rpb) bad_s[threadIdx.x] = 0u;
     __syncthreads();
-    const uint64_t b0 = off_s[0], b1 = off_s[nr], end = a.offsets[a.n_reads];
+    const uint64_t b0 = off_s[0], b1 = off_s[nr], end = a.offsets[a.n_reads] + a.shift;
     const uint64_t a0 = b0 & ~15ull;                       // the block's lines from a 16-byte boundary (a.bases is 16-byte aligned)
     const uint64_t span = b1 - a0;                         // bytes of the block's lines from there
     const bool fits = span + 48u <= kPackLdsBytes;         // (reads no longer than their records: always; guards a malformed batch)

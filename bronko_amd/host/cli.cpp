@@ -596,7 +596,7 @@ int run_call(const Args& a) {
         std::vector<std::thread> th;
         for (size_t q = 0; q < shard_devices.size(); q++) th.emplace_back([&, q] { make_engine(shard_devices[q], shard_engines[q], ix.files.size() <= 1); });
         for (auto& t : th) t.join();
-        if (bk_counter_len(shard_engines[0].e) >= (16ull << 20)) {
+        if (!bk_can_shard(shard_engines[0].e)) {
             LOG_WARN(T, "The index keeps its counter planes sparse: a sample cannot be sharded over GPUs, whole samples go to the GPUs in turn");
             shard_mode = false;
             shard_engines.clear();

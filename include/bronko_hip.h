@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BK_ABI_VERSION 7
+#define BK_ABI_VERSION 8
 
 typedef enum {
     BK_OK = 0,
@@ -132,6 +132,9 @@ uint64_t bk_total_cells(const bk_engine* e);     /* sum of all sequence lengths 
 int32_t  bk_n_files(const bk_engine* e);
 uint64_t bk_n_slots(const bk_engine* e);         /* distinct window buckets on the device                   */
 uint64_t bk_counter_len(const bk_engine* e);     /* u64 elements in one counter plane                       */
+int      bk_can_shard(const bk_engine* e);       /* v8: 1 = one sample's reads may be sharded over engines (bk_counters_device_ptr,
+                                                  * bk_shard_*, bk_sample_finalize_shard); 0 = the index is so large that its planes
+                                                  * are kept sparse: shard whole samples instead                                      */
 
 /* ---- per-sample protocol (mirrors one iteration of call.rs:213-293 / :298-386) ---------------------------
  * bk_sample_begin      = initialize_output_maps (call.rs:224,314): zero pileups, stats and counter planes.
@@ -151,7 +154,8 @@ int bk_push_reads_packed(bk_engine* e, int mate, const uint32_t* words, uint32_t
  * previous one; the call blocks only when both are still in use.) */
 /* K0 from device memory (v7): the sequence lines are already resident (d_bases: bytes back to back, d_offsets: u64[n_reads + 1]);
  * the engine packs them into 2-bit records on its stream and scans them -- no copy, no host work beyond the launches.
- * total_bases = offsets[n_reads] - offsets[0] and longest_read (bases; sizes the record stride) are the host's to know. */
+ * total_bases = offsets[n_reads] - offsets[0] and longest_read (bases; sizes the record stride) are the host's to know.
+ * d_bases may have any alignment (a sub-buffer of a larger device allocation is fine); d_offsets is 8-byte aligned. */
 int bk_push_reads_ascii_device(bk_engine* e, int mate, const void* d_bases, const void* d_offsets, uint64_t n_reads,
                                uint64_t total_bases, uint32_t longest_read);
 /* Same, for a batch that is already resident in device memory (no copy; asynchronous on the engine stream). */

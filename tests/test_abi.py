@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
         L = _ffi.load(testing=testing)
         for s in declared:
             assert hasattr(L, s), s
-        assert L.bk_abi_version() == 7
+        assert L.bk_abi_version() == 8
 
 
 def test_integration_md_declares_every_symbol():

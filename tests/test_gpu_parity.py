@@ -343,6 +343,49 @@ def test_device_side_packing_and_async_ingest(oracle, hpv):
     assert res2.kmer_stats[0].tolist() == res.kmer_stats[0].tolist()
 
 
+def test_device_side_packing_of_reads_no_longer_than_two_words(oracle, hpv, golden_dir):
+    """K0 with records of one or two words (every read of the batch <= 32 / <= 16 bases): a block of pack_words_kernel then holds
+    256 reads and needs 257 offsets -- one more than it has threads (the last one was never loaded).  Several full
+    blocks, reads of k .. 32 bases with N and lower case, through bk_push_reads_ascii; k = 15 with reads of 15 / 16 bases for
+    the one-word record."""
+    ix, eng = hpv
+    g = synth.read_fasta_bytes(os.path.join(helpers.GOLDEN, "HPV16.fa"))
+    r = synth.splitmix64(4242, 3 * 3000)
+
+    def short_reads(lo, hi, n):
+        out = []
+        for i in range(n):
+            ln = lo + int(r[3 * i] % np.uint64(hi - lo + 1))
+            at = int(r[3 * i + 1] % np.uint64(len(g) - hi)) if i % 3 else 1000 + (i % 40)   # a third pile up on one stretch (ci = 3)
+            rd = bytearray(g[at:at + ln])
+            if i % 97 == 0:
+                rd[int(r[3 * i + 2] % np.uint64(ln))] = ord("N")
+            if i % 11 == 0:
+                rd = bytearray(bytes(rd).lower())
+            out.append(bytes(rd))
+        return out
+
+    reads = short_reads(21, 32, 3000)
+    assert max(len(x) for x in reads) == 32
+    pile = oracle.sample_pileup(ix, [reads])
+    assert int(pile.fwd_depth.max()) >= 3
+    for batch in (None, 256, 700):
+        res = helpers.hip_sample(eng, [reads], 21, batch=batch, ascii_path=True)
+        helpers.assert_same_pileup(res, pile)
+        assert res.kmer_stats[0].tolist() == helpers.hip_sample(eng, [reads], 21).kmer_stats[0].tolist()
+    ix15 = oracle.Index.build(15, [os.path.join(golden_dir, "HPV16.fa")])
+    eng15 = helpers.engine_from_oracle_index(ix15)
+    try:
+        reads = short_reads(15, 16, 3000)
+        pile = oracle.sample_pileup(ix15, [reads])
+        assert int(pile.fwd_depth.max()) >= 3
+        for batch in (None, 256):
+            helpers.assert_same_pileup(helpers.hip_sample(eng15, [reads], 15, batch=batch, ascii_path=True), pile)
+    finally:
+        eng15.close()
+        ix15.close()
+
+
 def test_a_fork_with_parameters_of_its_own(oracle, hpv):
     """bk_engine_fork_params (ABI v7): ci / cs / cx of a fork differ from the parent's -- each equals the oracle run with its own
     thresholds; what shapes the shared tables (n_fixed, use_full_kmer, full_kmer_stats) must equal the parent's."""

@@ -310,6 +310,15 @@ struct bk_engine {
     uint32_t ov_par = 0;                    // parity of the next scan_items launch (which of the two overflow counts it appends to)
     DevBuf<unsigned int> lean_e_list, lean_n_list;   // bk_finalize_lean.hip: the reference k-mers finalize_ecell_kernel leaves to finalize_exact_kernel
     bool v_clean[2] = {false, false};       // the V part of the mate file's plane is known to be all zero (dense planes between samples)
+    // The V items of a mate file's first scan launch are not added to the plane: they wait (`pending`) for the regional finalize,
+    // which takes its counts from them (FinalizeArgs::f_items) -- the whole story for a mate file whose reads are one launch.  A
+    // second launch into the engine's item buffers first sends them to the plane after all (flush_pending_items: bin_count_kernel,
+    // V bins only), and the mate file's later launches go straight there as before.
+    bool fuse_ok = false;                   // this engine's index, planes and parameters admit it (alloc_sample_state)
+    struct PendingItems { bool on = false; int mate = 0; bk::BinArgs b{}; } pending;
+    bool fuse_off[2] = {false, false};      // this sample's mate file has had a second launch: no more waiting
+    bool touch_used[2] = {false, false};    // Level 2 set bits in fuse_touch[m] that no regional finalize has cleared
+    DevBuf<unsigned int> fuse_touch[2];     // a bit per V row Level 2 wrote to while the launch's items wait
     int item_v_mode = -1;                   // testing aid (BK_ITEM_V_MODE): force BinArgs::v_mode
     DevBuf<unsigned int> n_bits, n_any;     // scan -> Level 2: one bit per k-mer of each record of a launch / per record (bk_kernels.h ScanArgs): the N runs; all zero between launches
     DevBuf<unsigned int> l2_bits;           // Level 2's first pass -> its second: the k-mers looked at one by one, same layout
@@ -472,6 +481,14 @@ static int alloc_sample_state(bk_engine* e) {
                    bk::item_geometry(std::min<uint32_t>(e->n_lds_bins, (uint32_t)e->total_cells), e->n_full, e->v_span, &e->ig) &&
                    bk::items_lds_bytes(e->ig, std::min<uint32_t>(e->n_lds_bins, (uint32_t)e->total_cells)) <= 128u * 1024u;
     if (e->use_items) {
+        if (const char* cp = test_env("BK_ITEM_CAPS")) {   // measurement aid: "cap_e,cap_v" (multiples of 8, at most 64)
+            unsigned ce = 0, cv = 0;
+            if (sscanf(cp, "%u,%u", &ce, &cv) == 2 && ce >= 8 && cv >= 8 && ce <= 64 && cv <= 64 && ce % 8 == 0 && cv % 8 == 0) {
+                bk::ItemGeom g2 = e->ig;
+                g2.cap_e = ce; g2.cap_v = cv; g2.wg_items = g2.n_ebins * ce + g2.n_vbins * cv; g2.wg_stride = g2.wg_items;
+                if (bk::items_lds_bytes(g2, std::min<uint32_t>(e->n_lds_bins, (uint32_t)e->total_cells)) <= 118u * 1024u) e->ig = g2;
+            }
+        }
         const size_t g = bk::items_max_grid(e->n_cus);
         e->ig.grid_max = (uint32_t)g;
         BK_HIP(e->items.alloc(g * e->ig.wg_stride + 64));   // (+ 64: bin_count reads whole 16-byte units)
@@ -484,6 +501,17 @@ static int alloc_sample_state(bk_engine* e) {
         BK_HIP(e->slabs.alloc((size_t)e->n_cus * std::max<uint32_t>(e->n_lds_bins, 1)));
     }
     if (e->n_files > 1) { BK_HIP(e->win_votes.alloc((size_t)e->n_files)); BK_HIP(e->win_sel.upload(std::vector<uint32_t>(2, 0u))); }
+    // the scan's V items straight into the regional finalize (bk_finalize_lean.hip): where that kernel runs (one genome file, dense
+    // planes, no statistics table, no pseudo k-mers, an answer table; FinalizeArgs are checked again at finalize), a V bin is the 64
+    // row positions of one of its workgroups, and Level 2 is the only other writer of the V part (ScanArgs::n_direct: no nbatch_kernel)
+    e->fuse_ok = e->use_items && e->n_files == 1 && e->max_seqs_per_file == 1 && (uint64_t)e->n_lds_bins >= e->total_cells && !e->ktab_keys.p && e->n_prows == 0 &&
+                 e->n_u == e->n_full && e->n_full > 0 && e->dirty_ans.p && e->W > 1 && e->v_span > 0 && e->v_span <= 32 && e->fin_partials.p && e->lean_e_list.p &&
+                 prm->cs < (1ull << 32) && e->ig.vq_log2 == 6 && !test_env("BK_NO_LEAN_FINALIZE") && !test_env("BK_NO_FUSE") && !test_env("BK_NO_N_DIRECT");
+    if (e->fuse_ok)
+        for (int m = 0; m < 2; m++) {
+            BK_HIP(e->fuse_touch[m].alloc(((size_t)e->n_full + (size_t)e->v_span + 63) / 64 * 12 + 16));
+            BK_HIP(hipMemset(e->fuse_touch[m].p, 0, e->fuse_touch[m].n * sizeof(unsigned int)));
+        }
     BK_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
     return BK_OK;
@@ -1802,6 +1830,26 @@ int bk_sample_begin(bk_engine* e) {
     e->pushed_records[0] = e->pushed_records[1] = 0;
     e->in_sample = true;
     e->finalized_mates = 0;
+    // items of a sample that was begun and never finalized are nobody's any more; neither are the rows Level 2 noted for them
+    e->pending.on = false;
+    for (int m = 0; m < 2; m++) {
+        e->fuse_off[m] = false;
+        if (e->touch_used[m]) { BK_HIP(hipMemsetAsync(e->fuse_touch[m].p, 0, e->fuse_touch[m].n * sizeof(unsigned int), e->stream)); e->touch_used[m] = false; }
+    }
+    return BK_OK;
+}
+
+// the waiting V items of an earlier launch go to their plane after all: bin_count_kernel over the V bins, adding (Level 2 of that
+// launch may have written to the plane since)
+static int flush_pending_items(bk_engine* e) {
+    if (!e->pending.on) return BK_OK;
+    bk_engine::Span sp(e, 3);
+    bk::BinArgs b = e->pending.b;
+    b.part = 2;
+    b.v_mode = e->item_v_mode >= 0 && e->item_v_mode != 2 ? e->item_v_mode : 1;
+    e->pending.on = false;
+    e->fuse_off[e->pending.mate] = true;
+    BK_HIP(bk::launch_bin_count(b, e->stream));
     return BK_OK;
 }
 
@@ -1949,6 +1997,8 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
         }
         a.l2_bits = e->l2_bits.p; a.l2_diag = e->l2_diag.p; a.l2_any = e->l2_any.p; a.n_bits = e->n_bits.p; a.n_any = e->n_any.p;
         a.rec_base = base; a.n_records = take;
+        if (int rc = flush_pending_items(e)) return rc;   // (the scan below overwrites the item buffers)
+        const bool wait_v = e->fuse_ok && a.n_direct && !e->fuse_off[mate] && e->item_v_mode < 0;
         if (e->use_items) {
             // A scan workgroup fills its CU (16 waves of 128 registers, 127 KB of LDS): on every CU it shuts out the other samples'
             // finalize / Level 2 kernels, which are chains of short launches that wait for latency, not for CUs.  With siblings in
@@ -1974,6 +2024,17 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
             b.v_mode = e->item_v_mode >= 0 ? e->item_v_mode : (e->v_clean[mate] ? 2 : 1);
             e->v_clean[mate] = false;
             if (const char* ba = test_env("BK_BIN_ABLATE")) b.ablate = atoi(ba);
+            if (wait_v) {
+                // the mate file's first launch: its V items wait for the regional finalize (or for the next launch, which sends them
+                // to the plane); Level 2 below notes the V rows it writes to
+                e->pending.on = true; e->pending.mate = mate; e->pending.b = b;
+                b.part = 1;
+                a.touch_v = e->fuse_touch[mate].p; e->touch_used[mate] = true;
+                a.rl_recip = ~0ull / (unsigned long long)(e->v_span + 1) + 1ull;
+            } else {
+                e->fuse_off[mate] = true;
+                if (e->fuse_ok) a.touch_v = nullptr;   // (a push of several launches: set by the first)
+            }
             BK_HIP(bk::launch_bin_count(b, e->stream));
         }
         if (e->W > 0) {
@@ -2162,6 +2223,7 @@ int bk_push_reads_packed(bk_engine* e, int mate, const uint32_t* words, uint32_t
 int bk_counters_device_ptr(bk_engine* e, int mate, void** d_ptr) {
     if (!e || !d_ptr || mate < 0 || mate > 1) return fail(BK_ERR_INVALID, "bad argument");
     if (e->sparse) return fail(BK_ERR_UNSUPPORTED, "an index this large keeps its counter planes sparse: shard whole samples over GPUs, not one sample's reads");
+    if (e->pending.on) { BK_HIP(hipSetDevice(e->device)); if (int rc = flush_pending_items(e)) return rc; }
     if (e->in_sample) {   // a mate file nothing was pushed for yet: its plane is zeroed lazily -- now, before the caller reduces it
         BK_HIP(hipSetDevice(e->device));
         if (int rc = zero_plane_if_stale(e, mate)) return rc;
@@ -2241,6 +2303,14 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             a.zero_e_n = ride ? (size_t)std::min<uint64_t>(e->v_off, e->plane_len) : 0;
             if (ride) e->plane_used[m] = false;
             if (pass == 0) { if (int rc = zero_plane_if_stale(e, m)) return rc; }
+            if (e->pending.on && e->pending.mate == m) {
+                // the mate file's reads were one launch: the regional finalize takes the V counts from the scan's items
+                const bk::BinArgs& pb = e->pending.b;
+                a.f_items = pb.items; a.f_tab = pb.tab; a.f_gext = pb.gext; a.f_ov = pb.ov; a.f_ov_n = pb.ov_n; a.f_ov_cap = pb.ov_cap; a.f_ov_par = pb.ov_par;
+                a.f_n_wg = pb.n_wg; a.f_ig = pb.ig; a.f_touch = e->fuse_touch[m].p;
+                if (clean_dense && !two_pass && bk::finalize_runs_by_region(a)) { e->pending.on = false; e->touch_used[m] = false; }
+                else { a.f_items = nullptr; if (int rc = flush_pending_items(e)) return rc; }
+            }
             bk_engine::Span sp(e, 1);
             bk::launch_finalize(a, e->stream);
         }
@@ -2423,6 +2493,7 @@ int bk_shard_measure(bk_engine* e, int mate, void** d_max) {
     if (!d_max) return fail(BK_ERR_INVALID, "null argument");
     if (int rc = shard_args_ok(e, mate, 1, 64)) return rc;
     BK_HIP(hipSetDevice(e->device));
+    if (int rc = flush_pending_items(e)) return rc;
     if (int rc = zero_plane_if_stale(e, mate)) return rc;
     BK_HIP(hipMemsetAsync(e->xport_flag.p + 2, 0, 2 * sizeof(unsigned long long), e->stream));
     bk::launch_xport_measure(e->counters[mate].p, e->plane_len, e->v_off, e->xport_flag.p + 2, e->stream);
@@ -2435,6 +2506,7 @@ int bk_shard_transport(bk_engine* e, int mate, int n_shards, int width, void** d
     if (!d_send || !part_bytes || !d_recv) return fail(BK_ERR_INVALID, "null argument");
     if (int rc = shard_args_ok(e, mate, n_shards, width)) return rc;
     BK_HIP(hipSetDevice(e->device));
+    if (int rc = flush_pending_items(e)) return rc;
     if (int rc = zero_plane_if_stale(e, mate)) return rc;   // (a mate file nothing was pushed for: its plane is zeroed lazily -- now)
     e->plane_used[mate] = true;
     e->xport_ever = true;

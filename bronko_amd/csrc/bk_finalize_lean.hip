@@ -58,9 +58,17 @@ __device__ __forceinline__ void lean_flush(const unsigned int* cnt, const unsign
 
 // K2a, one workgroup per 64 row positions.  Lanes as in finalize_variant_kernel: v_span lanes per row (lane = offset), the row's
 // prefix sums by shuffles, every lane maps the k-mer its count belongs to.
+// FUSED (FinalizeArgs::f_items): the counts are not in the plane -- the mate file's reads were one scan launch, whose V items are
+// still where the scan left them.  The workgroup's 64 row positions are one V bin of the binned scan (ItemGeom::vq_log2 = 6): it
+// adds the bin's items of every scan workgroup up in LDS, as bin_count_kernel does, and never stores them; a row that Level 2
+// wrote to meanwhile (f_touch: a bit per row) is read from the plane as well, zeroed, its bit cleared.  28 MB of stores, 27 MB of
+// loads and 25 MB of zeroing per 1 M-read sample of SARS-CoV-2 become 6 MB of item loads.
+template <bool FUSED>
 __global__ __launch_bounds__(kLeanVBlock) void finalize_vbin_kernel(FinalizeArgs a) {
     __shared__ unsigned int cnt[8 * kLeanWin], mxv[8 * kLeanWin];
     __shared__ uint32_t lstats[3 + 2];
+    __shared__ unsigned int tmask[kLeanVq * kVRowsPerPos / 32 + 1];   // FUSED: the touch bits of the workgroup's 384 rows; [12]: all rows (the scan's item_direct wrote to the plane)
+    extern __shared__ __attribute__((aligned(16))) unsigned int acc[];   // FUSED: [384 * (v_span + 1)] the bin's counters (differences), from the items
     const IndexView& ix = a.ix;
     const int k = ix.k;
     const uint32_t span = (uint32_t)ix.v_span, rl = span + 1u;
@@ -71,6 +79,70 @@ __global__ __launch_bounds__(kLeanVBlock) void finalize_vbin_kernel(FinalizeArgs
     const uint32_t p0 = ix.id_rec[id_lo].cell;
     for (uint32_t i = threadIdx.x; i < 8u * kLeanWin; i += kLeanVBlock) { cnt[i] = 0u; mxv[i] = 0u; }
     if (threadIdx.x < 5) lstats[threadIdx.x] = 0u;
+    if constexpr (FUSED) {
+        const uint32_t n_eb = a.f_ig.n_ebins, n_bins = n_eb + a.f_ig.n_vbins, bin = n_eb + blockIdx.x, cap = a.f_ig.cap_v, G = a.f_ig.grid_max;
+        const uint32_t upb = cap / 8u;                                     // 16-byte units per bucket
+        const uint32_t vsize = kLeanVq * kVRowsPerPos * rl;
+        // bucket unit u of scan workgroup wg: asked for together with the table entry that says how many of the bucket's slots count,
+        // before anything else is done (one trip to memory, as in bin_count_kernel); 1024 threads, 256 workgroups x 3 units
+        const uint32_t n_units = a.f_n_wg * upb;
+        const unsigned short* const bin_items = a.f_items + (size_t)n_eb * G * a.f_ig.cap_e + (size_t)blockIdx.x * G * cap;
+        const bool mine = threadIdx.x < n_units;
+        const uint32_t wg0 = mine ? threadIdx.x / upb : 0u, un0 = threadIdx.x - wg0 * upb;
+        uint32_t hdr0 = 0u;
+        uint4 v0 = make_uint4(0u, 0u, 0u, 0u);
+        if (mine) { hdr0 = a.f_tab[(size_t)bin * G + wg0]; v0 = reinterpret_cast<const uint4*>(bin_items + (size_t)wg0 * cap)[un0]; }
+        const unsigned long long ov_all = a.f_ov_n[a.f_ov_par];
+        if (threadIdx.x <= kLeanVq * kVRowsPerPos / 32) {
+            unsigned int* tw = a.f_touch + (size_t)blockIdx.x * (kLeanVq * kVRowsPerPos / 32) + threadIdx.x;
+            unsigned int m = 0u;
+            if (threadIdx.x < kLeanVq * kVRowsPerPos / 32) { m = *tw; if (m) *tw = 0u; }
+            else m = ov_all > (unsigned long long)a.f_ov_cap ? 1u : 0u;   // past the list's end the scan added to the plane itself: every row is read
+            tmask[threadIdx.x] = m;
+        }
+        for (uint32_t i = threadIdx.x; i < vsize; i += kLeanVBlock) acc[i] = 0u;
+        __syncthreads();
+        auto take = [&](uint32_t it) __attribute__((always_inline)) {
+            __hip_atomic_fetch_add(acc + (it & 0x7fffu), (it & 0x8000u) ? 0u - 1u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        auto take8 = [&](const uint4& v, uint32_t left) __attribute__((always_inline)) {   // the first `left` of the eight items of one unit
+            if (left > 0u) take(v.x & 0xffffu);
+            if (left > 1u) take(v.x >> 16);
+            if (left > 2u) take(v.y & 0xffffu);
+            if (left > 3u) take(v.y >> 16);
+            if (left > 4u) take(v.z & 0xffffu);
+            if (left > 5u) take(v.z >> 16);
+            if (left > 6u) take(v.w & 0xffffu);
+            if (left > 7u) take(v.w >> 16);
+        };
+        for (uint32_t u = threadIdx.x; u < n_units; u += kLeanVBlock) {
+            const uint32_t wg = u / upb, un = u - wg * upb;
+            uint32_t n_all; uint4 v;
+            if (u == threadIdx.x) { n_all = hdr0; v = v0; }
+            else { n_all = a.f_tab[(size_t)bin * G + wg]; v = reinterpret_cast<const uint4*>(bin_items + (size_t)wg * cap)[un]; }
+            const uint32_t n = min(n_all, cap);
+            take8(v, n > 8u * un ? n - 8u * un : 0u);
+            // the bucket's extension in device memory (a hot bin: a true variant site), its units dealt to the bucket's threads
+            const uint32_t g = min(n_all - n, kItemGCap);
+            if (g) {
+                const uint4* q = reinterpret_cast<const uint4*>(a.f_gext + ((size_t)wg * n_bins + bin) * kItemGCap);
+                for (uint32_t i0 = 8u * un; i0 < g; i0 += 8u * upb * 4u) {   // four units in flight
+                    uint4 e[4];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) e[j] = i0 + 8u * upb * j < g ? q[(i0 >> 3) + upb * j] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) take8(e[j], g > i0 + 8u * upb * j ? g - i0 - 8u * upb * j : 0u);
+                }
+            }
+        }
+        {   // the overflow list: everything there that names this bin
+            const uint32_t n_ov = (uint32_t)(ov_all < (unsigned long long)a.f_ov_cap ? ov_all : (unsigned long long)a.f_ov_cap);
+            for (uint32_t i = threadIdx.x; i < n_ov; i += kLeanVBlock) {
+                const uint32_t e = a.f_ov[i];
+                if ((e >> 16) == bin) take(e & 0xffffu);
+            }
+        }
+    }
     __syncthreads();
     unsigned long long* __restrict__ vc = const_cast<unsigned long long*>(a.counters) + ix.v_off;   // (written only under clear_v)
     const uint32_t lpr = span, gpw = 64u / lpr;                   // lanes per row, rows per wave
@@ -83,8 +155,19 @@ __global__ __launch_bounds__(kLeanVBlock) void finalize_vbin_kernel(FinalizeArgs
         const uint32_t q = q0 + g / kVRowsPerPos, r6 = g % kVRowsPerPos;
         const bool in_row = lane_on && g < kLeanVq * kVRowsPerPos && q < nq;
         const size_t at = ((size_t)q * kVRowsPerPos + r6) * rl + oo;
-        unsigned long long n = in_row ? vc[at] : 0ull;
-        if (a.clear_v && n) vc[at] = 0ull;                        // (every counter is read by exactly one lane)
+        unsigned long long n;
+        if constexpr (FUSED) {
+            // the items' sum (a difference: sign-extended, the plane's arithmetic wraps modulo 2^64) + what Level 2 left in the plane
+            const uint32_t gg = in_row ? g : 0u;
+            n = in_row ? (unsigned long long)(long long)(int32_t)acc[gg * rl + oo] : 0ull;
+            if (in_row && (tmask[kLeanVq * kVRowsPerPos / 32] || ((tmask[gg >> 5] >> (gg & 31u)) & 1u))) {
+                const unsigned long long pv = vc[at];
+                if (pv) { n += pv; vc[at] = 0ull; }
+            }
+        } else {
+            n = in_row ? vc[at] : 0ull;
+            if (a.clear_v && n) vc[at] = 0ull;                    // (every counter is read by exactly one lane)
+        }
         const uint32_t d = r6 & 1u, alt = r6 >> 1;
         const bool inq = in_row && q >= oo && q - oo < ix.n_full;
         const uint32_t p = inq ? q - oo : 0u;
@@ -201,7 +284,13 @@ bool finalize_lean_ok(const FinalizeArgs& a) {
 }
 unsigned launch_finalize_lean_variant(const FinalizeArgs& a, hipStream_t stream) {
     const unsigned grid = (unsigned)((a.ix.n_full + (uint32_t)a.ix.v_span + kLeanVq - 1) / kLeanVq);
-    hipLaunchKernelGGL(finalize_vbin_kernel, dim3(grid), dim3(kLeanVBlock), 0, stream, a);
+    if (a.f_items) {   // (the engine hands the items over only where a V bin is a workgroup's region: vq_log2 = 6, as many bins as workgroups)
+        const size_t lds = (size_t)kLeanVq * kVRowsPerPos * ((size_t)a.ix.v_span + 1u) * sizeof(unsigned int);
+        (void)raise_lds_limit(reinterpret_cast<const void*>(finalize_vbin_kernel<true>), lds + 20u * 1024u);
+        hipLaunchKernelGGL(finalize_vbin_kernel<true>, dim3(grid), dim3(kLeanVBlock), lds, stream, a);
+    } else {
+        hipLaunchKernelGGL(finalize_vbin_kernel<false>, dim3(grid), dim3(kLeanVBlock), 0, stream, a);
+    }
     return grid;
 }
 }  // namespace bk

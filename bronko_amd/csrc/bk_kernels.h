@@ -166,6 +166,19 @@ struct FinalizeArgs {
     const unsigned int* tail_n_list;   //   k-mers' E counters it maps behind its deferred k-mers (null otherwise)
     unsigned long long* zero_e;     // launch_finalize's last kernel also zeroes zero_e[0, zero_e_n): the plane's E part behind the sample (or null)
     size_t zero_e_n;
+    // The regional finalize fed from the scan's V items (a mate file whose reads were one launch: the V part of its plane is never
+    // written).  A V bin of the binned scan is the 64 row positions one finalize_vbin workgroup owns: the workgroup adds the bin's
+    // items up in LDS -- what bin_count_kernel does before it stores the bin -- and takes its counts from there.  What Level 2 added
+    // to the plane meanwhile is found through f_touch (a bit per V row it wrote: the SPARSE form of level2_kernel); the rows read
+    // are zeroed, the bits cleared.  f_items null: the counts are the plane's.
+    const unsigned short* f_items;  // BinArgs::items / tab / gext / ov / ov_n of the launch
+    const unsigned short* f_tab;
+    const unsigned short* f_gext;
+    const unsigned int* f_ov;
+    const unsigned long long* f_ov_n;
+    uint32_t f_ov_cap, f_ov_par, f_n_wg;
+    ItemGeom f_ig;
+    unsigned int* f_touch;          // [v_real_rows / 32 + 1]
 };
 
 struct FoldArgs {
@@ -234,6 +247,8 @@ struct BinArgs {
     uint64_t v_off, v_real_len;     // its V part (the reference k-mers' rows)
     uint32_t rl;                    // v_span + 1
     int v_mode;                     // how a V bin reaches the plane: 0 atomics, 1 plain read-modify-write, 2 plain stores (the V part is all zero)
+    int part;                       // 0: every bin; 1: the E bins only (the V bins' items wait for the regional finalize, FinalizeArgs::f_items, or
+                                    // for a launch with part = 2); 2: the V bins only
     int ablate;                     // measurement aid (-DBK_TESTING build only): 1 no items read, 2 nothing written to the plane, 3 no E atomics, 4 no V writes
 };
 // can this index take the binned scan (window of win_cells cells in LDS, dense planes)?  Fills g.
@@ -306,5 +321,7 @@ void launch_call(const CallArgs& a, int max_seqs_per_file, uint64_t max_file_cel
 void launch_select_genome(const CallArgs& a, hipStream_t stream);   // the first kernel of launch_call alone: a.out->file_id
 size_t finalize_lds_bytes(int n_files);
 size_t finalize_partial_rows();
+bool finalize_runs_by_region(const FinalizeArgs& a);   // launch_finalize will take the regional kernel of bk_finalize_lean.hip (one genome file, whole dense planes, ...)
+hipError_t raise_lds_limit(const void* fn, size_t lds);   // the dynamic-LDS limit of a kernel, raised once per process and device
 
 }  // namespace bk

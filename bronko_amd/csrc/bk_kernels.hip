@@ -1393,7 +1393,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
     const uint8_t* const cflags = ix.cell_flags;
 
     // slow path: +1 on the E counter of reference k-mer `id` read in orientation `isrc`
-    auto count_exact = [&](bool hit, uint32_t /*cell*/, uint32_t id, uint32_t isrc, uint32_t /*rc_first*/) {
+    auto count_exact = [&](bool hit, uint32_t /*cell*/, uint32_t id, uint32_t isrc, uint32_t /*rc_first*/) __attribute__((always_inline)) {
         if (hit) { if constexpr (SPARSE) touch(a.touch_e, id); atomicAdd(a.counters + 2 * (size_t)id + isrc, 1ull); }
         BK_DBG(a, 8, hit, 1);
     };
@@ -1404,7 +1404,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
     pipe.dbg = a.dbg;
 #endif
     // resolve up to 64 queued k-mers: every stage's loads of the whole batch are issued together
-    auto slow_batch = [&]() {
+    auto slow_batch = [&]() __attribute__((always_inline)) {
         const uint32_t nb = min(qn, 64u);
         pipe.start(q, nb, lane, ix);
         const uint32_t rest = qn - nb;
@@ -1425,7 +1425,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
     const uint32_t nw = a.l2_words;
 
     // the first n (<= 64) k-mers of the queue, one per lane
-    auto process_kmers = [&](uint32_t n) {
+    auto process_kmers = [&](uint32_t n) __attribute__((always_inline)) {
         const bool on = (uint32_t)lane < n;
         const unsigned long long e = on ? kq[lane] : 0ull;
         const uint32_t rec = (uint32_t)(e >> 16), s = (uint32_t)e & 0xffffu;
@@ -1528,7 +1528,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
     };
 
     uint32_t qr = 0, qk = 0;   // wave-uniform fills of the record and k-mer queues
-    auto take_kmers = [&]() {
+    auto take_kmers = [&]() __attribute__((always_inline)) {
         const uint32_t n = min(qk, 64u);
         process_kmers(n);   // reads kq[0, n)
         const uint32_t rest = qk - n;
@@ -1543,7 +1543,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
     };
     // 64 marked records, one per lane: their bitmap words (cleared as they are taken); the marked k-mers of a word go into the
     // k-mer queue lane after lane, each lane's in rising order
-    auto take_records = [&]() {
+    auto take_records = [&]() __attribute__((always_inline)) {
         const uint32_t n = min(qr, 64u);
         const uint32_t rec = (uint32_t)lane < n ? rq[lane] : 0xffffffffu;
         {
@@ -2889,6 +2889,13 @@ size_t finalize_lds_bytes(int n_files) { return ((size_t)n_files * 5 + 4) * size
 constexpr unsigned kFinVariantBlocks = 256 * 8, kFinExactBlocks = 256 * 8, kFinGeneralBlocks = 256 * 32;
 size_t finalize_partial_rows() { return (size_t)kFinVariantBlocks + kFinExactBlocks + kFinGeneralBlocks; }
 
+static unsigned finalize_general_blocks(const FinalizeArgs& a) {
+    // (few genomes: multi-bucket k-mers are rare, a small grid starts and ends quickly; many: one k-mer in eight takes this path)
+    return (unsigned)std::min<size_t>(a.ix.n_files >= 8 ? kFinGeneralBlocks : kFinGeneralBlocks / 32, 256 * std::max<size_t>(1, (160u * 1024u) / finalize_lds_bytes(a.ix.n_files)));
+}
+bool finalize_runs_by_region(const FinalizeArgs& a) {
+    return finalize_lean_ok(a) && (uint64_t)(a.ix.n_full + (uint32_t)a.ix.v_span) / 64 + (uint64_t)a.ix.total_cells / 256 + 2 + 64 + finalize_general_blocks(a) <= finalize_partial_rows();
+}
 void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     if (a0.ix.W <= 0) return;
     FinalizeArgs a = a0;
@@ -2905,10 +2912,9 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_votes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    // (few genomes: multi-bucket k-mers are rare, a small grid starts and ends quickly; many: one k-mer in eight takes this path)
-    const unsigned b_gen = (unsigned)std::min<size_t>(a.ix.n_files >= 8 ? kFinGeneralBlocks : kFinGeneralBlocks / 32, 256 * std::max<size_t>(1, (160u * 1024u) / lds));
+    const unsigned b_gen = finalize_general_blocks(a);
     unsigned b_v = b_var, b_e = 0;
-    const bool lean = finalize_lean_ok(a) && (uint64_t)(a.ix.n_full + (uint32_t)a.ix.v_span) / 64 + (uint64_t)a.ix.total_cells / 256 + 2 + 64 + b_gen <= finalize_partial_rows();
+    const bool lean = finalize_runs_by_region(a);
     if (lean) {
         // one genome file, dense planes: K2a and K2e by region of the reference (bk_finalize_lean.hip)
         b_v = launch_finalize_lean_variant(a, stream);   // (V rows and the E counters of the same region)

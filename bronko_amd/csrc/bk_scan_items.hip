@@ -627,7 +627,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
 // further; cells counted by two bins simply receive two additions.  V bin: counters [bin * size, + size) of the plane's V part.
 __global__ __launch_bounds__(kBinBlock) void bin_count_kernel(BinArgs b) {
     extern __shared__ __attribute__((aligned(16))) unsigned int acc[];   // E: [2][kEBinSpan + 1] difference arrays (along / against); V: the bin's counters
-    const uint32_t bin = blockIdx.x, n_eb = b.ig.n_ebins, n_bins = n_eb + b.ig.n_vbins;
+    const uint32_t n_eb = b.ig.n_ebins, n_bins = n_eb + b.ig.n_vbins, bin = blockIdx.x + (b.part == 2 ? n_eb : 0u);   // (BinArgs::part)
     const bool is_e = bin < n_eb;
     const uint32_t vsize = (6u << b.ig.vq_log2) * b.rl;
     const uint32_t n_acc = is_e ? 2u * (kEBinSpan + 1u) : vsize;
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(kBinBlock) void bin_count_kernel(BinArgs b) {
     }
     for (uint32_t i = threadIdx.x; i < n_acc; i += kBinBlock) acc[i] = 0u;
     if (BK_ABLATE(b, 6)) return;
-    if (bin == 0 && threadIdx.x == 0) b.ov_n[b.ov_par ^ 1u] = 0ull;   // the next launch's overflow count starts at zero
+    if (bin == 0 && threadIdx.x == 0) b.ov_n[b.ov_par ^ 1u] = 0ull;   // the next launch's overflow count starts at zero (part 2 follows a launch with part 1: done there)
     __syncthreads();
     auto take = [&](uint32_t it) __attribute__((always_inline)) {
         if (it == 0xffffu) return;
@@ -819,7 +819,7 @@ size_t items_lds_bytes(const ItemGeom& g, uint32_t win_cells) {
            ((size_t)(kRefPadWords + (win_cells + 15) / 16 + kRefBackWords) + 1u) * sizeof(unsigned int);   // (+ the reverse-complemented reference)
 }
 
-static hipError_t raise_lds_limit(const void* fn, size_t lds) {
+hipError_t raise_lds_limit(const void* fn, size_t lds) {
     // the dynamic-LDS limit of a kernel is raised once (per process and device), not at every launch
     static std::mutex mu;
     static std::vector<std::pair<std::pair<const void*, int>, size_t>> have;   // ((kernel, device), limit set)
@@ -857,7 +857,7 @@ hipError_t launch_scan_items(const ScanArgs& a, uint32_t grid, hipStream_t strea
 }
 
 hipError_t launch_bin_count(const BinArgs& b, hipStream_t stream) {
-    const uint32_t n_bins = b.ig.n_ebins + b.ig.n_vbins;
+    const uint32_t n_bins = b.part == 1 ? b.ig.n_ebins : b.part == 2 ? b.ig.n_vbins : b.ig.n_ebins + b.ig.n_vbins;
     if (n_bins == 0 || b.n_wg == 0) return hipSuccess;
     const size_t lds = std::max<size_t>(2u * (kEBinSpan + 1u), (size_t)(6u << b.ig.vq_log2) * b.rl) * sizeof(unsigned int);
     if (hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(bin_count_kernel), lds)) return e;

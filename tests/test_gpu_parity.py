@@ -157,6 +157,52 @@ def test_one_hot_bin_through_every_tier_of_the_binned_scan(oracle, hpv):
     assert int(res.fwd_depth.max()) == 900000 and int(res.rev_depth.max()) == 400000
 
 
+def test_v_items_straight_into_the_regional_finalize(oracle, hpv, golden_dir, monkeypatch):
+    """Round 5: a mate file whose reads are ONE scan launch never writes the V part of its plane -- the regional finalize adds the
+    scan's V items up itself (FinalizeArgs::f_items) and reads from the plane only the rows Level 2 noted.  One launch (items),
+    two launches of one mate file (the first launch's items are sent to the plane after all), two mate files (mate 0's are, mate 1's
+    wait), a sample begun and abandoned with items waiting and rows noted, samples one after the other on one engine -- each equals
+    the oracle; and the testing build with BK_NO_FUSE=1 (every launch through bin_count_kernel, as in round 4) gives the same."""
+    from bronko_amd import _ffi
+    ix, eng = hpv
+    g = synth.read_fasta_bytes(os.path.join(helpers.GOLDEN, "HPV16.fa"))
+    a = helpers.hpv_reads(20000, seed=81, err=0.02)                  # 2 % errors: plenty of close pairs for Level 2
+    b = helpers.hpv_reads(15000, seed=82, with_n=True, ragged=True)
+    gm, isnv = synth.sample_genome(g, 9)
+    c1, c2 = synth.paired_codes(gm, 7000, 150, 83, isnv=isnv)
+    mates = [synth.codes_to_ascii(c1), synth.codes_to_ascii(c2)]
+    pa, pb, pab, pm = (oracle.sample_pileup(ix, [a]), oracle.sample_pileup(ix, [b]), oracle.sample_pileup(ix, [a + b]), oracle.sample_pileup(ix, mates))
+
+    def run(e):
+        helpers.assert_same_pileup(helpers.hip_sample(e, [a], 21), pa)                       # one launch
+        helpers.assert_same_pileup(helpers.hip_sample(e, [b], 21), pb)                       # ... and the next sample on the same engine
+        helpers.assert_same_pileup(helpers.hip_sample(e, [a + b], 21, batch=len(a)), pab)    # two launches of one mate file
+        helpers.assert_same_pileup(helpers.hip_sample(e, [a + b], 21, batch=9000), pab)      # four
+        helpers.assert_same_pileup(helpers.hip_sample(e, mates, 21), pm)                     # two mate files
+        from bronko_amd import pack_reads
+        e.sample_begin()                                                                     # abandoned with items waiting
+        e.push_reads(0, *pack_reads(a, 21))
+        helpers.assert_same_pileup(helpers.hip_sample(e, [b], 21), pb)
+        helpers.assert_same_pileup(helpers.hip_sample(e, [a], 21), pa)
+
+    run(eng)
+    f = eng.fork()
+    try:
+        run(f)
+    finally:
+        f.close()
+    monkeypatch.setenv("BK_NO_FUSE", "1")
+    _ffi.use_testing_library(True)
+    try:
+        e2 = helpers.engine_from_oracle_index(ix)
+        try:
+            run(e2)
+        finally:
+            e2.close()
+    finally:
+        _ffi.use_testing_library(False)
+
+
 def test_amplicon_reads_fill_every_bucket_of_a_region(oracle, sars_paths):
     """An amplicon: 600,000 reads from one 400 bp stretch of SARS-CoV-2, 2 % substitutions, both strands, pushed in three batches
     (the first launch stores its bins' V counters, the later ones add to them; the overflow list's two counters take turns).  Every

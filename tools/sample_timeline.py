@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel timeline of the last sample in a rocprofv3 kernel trace (run with --in-flight 1: one sample at a time).
-usage: sample_timeline.py <kernel_trace.csv> [first kernel of a sample, default pick_window_kernel|scan_count_kernel]"""
+usage: sample_timeline.py <kernel_trace.csv> [first kernel of a sample, default pick_window_kernel|scan_count_kernel] [which sample: -1 = the last (default), n = the n-th]"""
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -12,8 +12,12 @@ names = [short(r["Kernel_Name"]) for r in rows]
 ends = ("finalize_", "clear_touched", "ktab_stats", "select_genome", "noise_", "call_")
 starts = [i for i in range(1, len(rows)) if names[i - 1].startswith(ends) and not names[i].startswith(ends)]
 if not starts: sys.exit("no sample boundary found")
-lo = starts[-2] if len(starts) > 1 else 0
-hi = starts[-1]
+which = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+if which < 0:
+    lo = starts[-2] if len(starts) > 1 else 0
+    hi = starts[-1]
+else:
+    lo, hi = starts[which], starts[which + 1]
 t0 = int(rows[lo]["Start_Timestamp"])
 for i in range(lo, hi):
     s, e = int(rows[i]["Start_Timestamp"]), int(rows[i]["End_Timestamp"])

@@ -163,10 +163,17 @@ class Workload:
         else:
             self.k, self.n_mates = 31, 1
             self.files = synth.strain_files(synth.read_fasta_bytes(os.path.join(GOLDEN, "wuhan_ref.fasta")), args.strains)
-            self.ix = HostIndex.build_mem(self.k, self.files, threads=min(32, os.cpu_count() or 4))
+            # build_indexes on the device (bk_build_index: what `bronko build` / `bronko call -g` run when a GPU is visible)
+            from bronko_amd.engine import Engine, build_index_device
+            self.ix = None
+            built = build_index_device(self.k, self.files, device=local_rank)
             self.ref_paths = None
         t_index = time.perf_counter()
-        self.eng = self.ix.engine(Params(device=local_rank, pileup_selected_only=selected_only))
+        if self.ix is None:
+            self.eng = Engine(self.k, built[0], built[1], built[2], self.files, Params(device=local_rank, pileup_selected_only=selected_only))
+            del built
+        else:
+            self.eng = self.ix.engine(Params(device=local_rank, pileup_selected_only=selected_only))
         self.selected_only = selected_only
         t_engine = time.perf_counter()
 

@@ -210,6 +210,10 @@ struct IndexView {
     const uint32_t*  id_rest;      //   (indices into entries); null with slot_files
     const uint16_t*  cell_file;    // [total_cells] genome file of each cell; null with slot_files
     const uint4*     estat_files;  // [n_full][2] estat as bitmaps: genomes in which the k-mer is perfect / a variant; null with slot_files
+    const uint32_t*  slot_alias;   // [n_slots / 32 + 1] bit s = slot s is reached through an alias key (k = 31: the other exact rank that wraps onto its
+                                   //   bucket's id), i.e. by k-mers that match a pseudo k-mer; null: there is none
+    uint32_t         gather_ok;    // the votes of a genome's BucketInfos can be gathered cell by cell (bk_gather.hip): every window bucket has one
+                                   //   key and holds each occurrence of its k-mers exactly once, every reference k-mer that needs one has an answer row
     const uint8_t*   amb;      // [n_u] bit 1 = the k-mer's first occurrence was reverse-complemented to become canonical; bit 0 = "dirty": another reference k-mer (either strand) lies within Hamming
                                //       distance 2 of it, or it is within distance 2 of its own reverse complement
     const uint32_t*  estat_off;// [n_u + 1] per reference k-mer: its genomes, precomputed from the index alone

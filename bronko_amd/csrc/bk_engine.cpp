@@ -295,6 +295,17 @@ struct bk_engine {
     DevBuf<bk::SlotRec> slot_rec;
     DevBuf<uint4> ent_files, slot_files, id_own_files, estat_files;
     DevBuf<uint16_t> cell_file;
+    DevBuf<uint32_t> slot_alias;
+    DevBuf<uint64_t> merged_slots;          // [n_merged_slots][2]: slot | window position << 32, the slot's key
+    uint32_t n_merged_slots = 0;
+    bool gather_ok = false;                 // IndexView::gather_ok
+    // gathered votes (bk_gather.hip): this engine's voting pass is gather_votes_kernel (sparse planes of a many-genome index)
+    bool gather_mode = false;
+    DevBuf<unsigned long long> alias_hits[2];   // per mate file: the deferred k-mers that reach a bucket through an alias key
+    DevBuf<unsigned int> n_alias_hits;          // [2]
+    static constexpr unsigned int kAliasCap = 1u << 20;
+    DevBuf<int> last_sel;                   // pileup_selected_only with gathered votes: the genome whose rows the previous sample wrote (-1: none) -- all that
+                                            // the next sample has to zero
     DevBuf<uint32_t> id_rest_off, id_rest;
     DevBuf<uint8_t> amb;
     DevBuf<uint16_t> pilots;
@@ -402,7 +413,7 @@ struct bk_engine {
         v.n_full = n_full; v.n_prows = n_prows; v.prow_id = prow_id.p; v.prow_t = prow_t.p; v.v_omin = v_omin; v.v_span = v_span; v.v_off = v_off;
         v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb, half_lo.log2p};
         v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb, half_hi.log2p};
-        v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.slot_rec = slot_rec.p; v.ent_files = ent_files.p; v.slot_files = slot_files.p; v.id_own_files = id_own_files.p; v.cell_file = cell_file.p; v.id_rest_off = id_rest_off.p; v.id_rest = id_rest.p; v.estat_files = estat_files.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
+        v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.slot_rec = slot_rec.p; v.ent_files = ent_files.p; v.slot_files = slot_files.p; v.slot_alias = slot_alias.p; v.gather_ok = gather_ok ? 1u : 0u; v.id_own_files = id_own_files.p; v.cell_file = cell_file.p; v.id_rest_off = id_rest_off.p; v.id_rest = id_rest.p; v.estat_files = estat_files.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
         v.table = table.p; v.ent_off = ent_off.p; v.ent_len = ent_len.p;
         v.entries = entries.p; v.n_slots = n_slots; v.log2s = log2s; v.k = k; v.wstart = wstart; v.W = W; v.n_files = n_files;
         return v;
@@ -472,6 +483,13 @@ static int alloc_sample_state(bk_engine* e) {
     }
     if (e->n_files == 1 && !e->sparse && e->n_full > 0) { BK_HIP(e->lean_e_list.alloc((size_t)e->n_full)); BK_HIP(e->lean_n_list.alloc(8)); BK_HIP(hipMemset(e->lean_n_list.p, 0, 8 * sizeof(unsigned int))); }
     BK_HIP(e->pileup.alloc(e->total_cells * 4 * 4));
+    e->gather_mode = e->gather_ok && e->sparse && e->cell_file.p && e->dirty_ans.p && e->W > 1 && e->file_cell_lo_d.p && !test_env("BK_NO_GATHER");
+    if (e->gather_mode) {
+        for (int m = 0; m < 2; m++) BK_HIP(e->alias_hits[m].alloc((size_t)bk_engine::kAliasCap * 3));
+        BK_HIP(e->n_alias_hits.alloc(2));
+        BK_HIP(e->last_sel.upload(std::vector<int>(1, -1)));
+        BK_HIP(hipMemset(e->pileup.p, 0, std::max<size_t>(e->pileup.n, 1) * sizeof(unsigned long long)));   // (selected-only: the rows of genomes never selected stay zero)
+    }
     BK_HIP(e->stats.alloc((size_t)2 * e->n_files * 3));
     BK_HIP(e->present.alloc((size_t)2 * e->n_files));
     BK_HIP(e->kstats.alloc(8));
@@ -611,7 +629,9 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     // recomputed from the metadata sequence at (file, seq, location) and checked against the stored bucket id
     // with assign_buckets, so an index that disagrees with its own metadata is rejected instead of miscounted.
     std::vector<uint64_t> h_slot_key;
-    std::vector<uint8_t> h_slot_t;
+    std::vector<uint8_t> h_slot_t, h_slot_alias;   // h_slot_alias: the slot's key is the OTHER exact rank that wraps onto its bucket's id (k = 31)
+    uint64_t n_merged_buckets = 0, n_dup_entries = 0, n_window_entries = 0;
+    std::vector<uint32_t> h_merged_slots;   // the window slots of buckets that hold more than one key
     std::vector<uint32_t> h_off, h_len;
     std::vector<bk::DevEntry> h_ent;
     std::vector<uint64_t> per_t(e->W > 0 ? e->W : 1, 0);
@@ -626,9 +646,13 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     // order, so the result is the one a single pass over all buckets gives.
     struct ChunkOut {
         std::vector<uint64_t> h_slot_key, h_u, pseudo, per_t;
-        std::vector<uint8_t> h_slot_t;
+        std::vector<uint8_t> h_slot_t, h_slot_alias;
         std::vector<uint32_t> h_off, h_len;   // h_off: relative to this chunk's h_ent
         std::vector<bk::DevEntry> h_ent;
+        std::vector<uint32_t> merged;   // slots (relative to this chunk's) of buckets that hold more than one key (k = 31: two reference buckets whose ids wrapped onto each other)
+        uint64_t n_merged = 0;    // ... the number of such buckets
+        uint64_t n_dup = 0;       // buckets that hold one BucketInfo twice
+        uint64_t n_real_ent = 0;  // BucketInfos of the window's buckets (each once)
         int code = BK_OK;
         std::string err;
         bool fail(int c, const char* fmt, ...) {
@@ -694,9 +718,19 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             // finalize_variant counts hits per file as run lengths: keep each bucket grouped by file (build_indexes
             // already appends file by file, build.rs:223-228; votes are order-independent)
             std::stable_sort(o.h_ent.begin() + off, o.h_ent.end(), [](const bk::DevEntry& x, const bk::DevEntry& y) { return x.file < y.file; });
+            // (what the gathered votes of bk_gather.hip rest on: one key per bucket, every BucketInfo once)
+            if (keys.size() > 1) o.n_merged++;
+            for (uint64_t i = lo; i < hi; i++) o.n_real_ent += ix->entries[i].idx >= e->wstart && ix->entries[i].idx < e->wstart + e->W;
+            if (any_in_window) {
+                for (size_t x = off; x < o.h_ent.size(); x++)
+                    for (size_t y = x + 1; y < o.h_ent.size() && o.h_ent[y].file == o.h_ent[x].file; y++)
+                        if (o.h_ent[y].cell == o.h_ent[x].cell && o.h_ent[y].idx == o.h_ent[x].idx) o.n_dup++;
+            }
             for (auto& kv : keys) {
                 if (kv.first < e->wstart || kv.first >= e->wstart + e->W) continue;
+                if (keys.size() > 1) o.merged.push_back((uint32_t)o.h_slot_key.size());
                 o.h_slot_key.push_back(kv.second);
+                o.h_slot_alias.push_back(0);
                 o.h_slot_t.push_back((uint8_t)(kv.first - e->wstart));
                 o.h_off.push_back(off);
                 o.h_len.push_back((uint32_t)(hi - lo));
@@ -704,6 +738,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             }
             if (alias_j >= 0) {
                 o.h_slot_key.push_back(alias_masked);
+                o.h_slot_alias.push_back(1);
                 o.h_slot_t.push_back((uint8_t)(alias_j - e->wstart));
                 o.h_off.push_back(off);
                 o.h_len.push_back((uint32_t)(hi - lo));
@@ -739,7 +774,9 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             u0[t + 1] = u0[t] + outs[t].h_u.size(); p0[t + 1] = p0[t] + outs[t].pseudo.size();
             for (size_t w = 0; w < per_t.size() && w < outs[t].per_t.size(); w++) per_t[w] += outs[t].per_t[w];
         }
-        h_ent.resize(e0[nt]); h_slot_key.resize(s0[nt]); h_slot_t.resize(s0[nt]); h_len.resize(s0[nt]); h_off.resize(s0[nt]);
+        for (auto& o : outs) { n_merged_buckets += o.n_merged; n_dup_entries += o.n_dup; n_window_entries += o.n_real_ent; }
+        for (unsigned t = 0; t < nt; t++) for (uint32_t rel : outs[t].merged) h_merged_slots.push_back((uint32_t)(s0[t] + rel));
+        h_ent.resize(e0[nt]); h_slot_key.resize(s0[nt]); h_slot_t.resize(s0[nt]); h_slot_alias.resize(s0[nt]); h_len.resize(s0[nt]); h_off.resize(s0[nt]);
         h_u.resize(u0[nt]); pseudo.resize(p0[nt]);
         {
             std::vector<std::thread> cp;
@@ -748,6 +785,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 std::copy(o.h_ent.begin(), o.h_ent.end(), h_ent.begin() + (ptrdiff_t)e0[t]);
                 std::copy(o.h_slot_key.begin(), o.h_slot_key.end(), h_slot_key.begin() + (ptrdiff_t)s0[t]);
                 std::copy(o.h_slot_t.begin(), o.h_slot_t.end(), h_slot_t.begin() + (ptrdiff_t)s0[t]);
+                std::copy(o.h_slot_alias.begin(), o.h_slot_alias.end(), h_slot_alias.begin() + (ptrdiff_t)s0[t]);
                 std::copy(o.h_len.begin(), o.h_len.end(), h_len.begin() + (ptrdiff_t)s0[t]);
                 for (size_t i = 0; i < o.h_off.size(); i++) h_off[s0[t] + i] = (uint32_t)e0[t] + o.h_off[i];
                 std::copy(o.h_u.begin(), o.h_u.end(), h_u.begin() + (ptrdiff_t)u0[t]);
@@ -894,9 +932,11 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             work();
             for (auto& t : th) t.join();
         }
+        uint64_t n_occurrences = 0;   // cells at which a k-mer of U starts
         for (uint64_t cell = 0; cell < cells; cell++) {
             const uint32_t ui = h_id_at[cell];
             if (ui == kNone) continue;
+            ++n_occurrences;
             if (id_of[ui] == kNone) { id_of[ui] = next_id++; first_cell[ui] = (uint32_t)cell; first_rc[ui] = cell_rc[cell]; }
             h_id_at[cell] = id_of[ui];
             if (cell_rc[cell]) h_brc[cell >> 5] |= 1u << (cell & 31);
@@ -1277,6 +1317,19 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     }
                 });
                 BK_HIP(e->dirty_ans.upload(h_ans));
+                // Votes gathered cell by cell (bk_gather.hip) replace the walk over BucketInfo lists when a genome's BucketInfos ARE the
+                // occurrences of its k-mers: every window bucket under one key (no two reference buckets merged by the k = 31 wrap),
+                // holding each occurrence once and nothing else (an index built by `bronko build` does; a .bkdb from elsewhere might
+                // not), every reference k-mer with a cell, and an answer for every dirty one
+                bool all_listed = true, all_cells = true;
+                for (uint32_t i : owners) if (h_no_list[i]) { all_listed = false; break; }
+                for (size_t i = 0; i < h_u.size() && all_cells; i++) if (!h_is_pseudo[i] && first_cell[i] == kNone) all_cells = false;
+                if (test_env("BK_L2_STATS") || test_env("BK_CREATE_TIMING"))
+                    fprintf(stderr, "[bk] gathered votes: answers for all %d, cells for all %d, merged buckets %llu, doubled BucketInfos %llu, window BucketInfos %llu for %llu occurrences x %d\n",
+                            (int)all_listed, (int)all_cells, (unsigned long long)n_merged_buckets, (unsigned long long)n_dup_entries, (unsigned long long)n_window_entries,
+                            (unsigned long long)n_occurrences, e->W);
+                e->gather_ok = all_listed && all_cells && n_dup_entries == 0 && n_window_entries == n_occurrences * (uint64_t)e->W &&
+                               !test_env("BK_NO_GATHER");
             }
             std::vector<uint64_t>().swap(h_near);
         }
@@ -1720,6 +1773,17 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     if (bk::finalize_lds_bytes(e->n_files) > 160 * 1024) return fail(BK_ERR_UNSUPPORTED, "more than ~8000 genome files are not supported by the finalize kernel");
 
     BK_HIP(e->table.upload(h_table));
+    {
+        bool any = false;
+        std::vector<uint32_t> bits(h_slot_alias.size() / 32 + 2, 0u);
+        for (size_t sl = 0; sl < h_slot_alias.size(); sl++) if (h_slot_alias[sl]) { bits[sl >> 5] |= 1u << (sl & 31); any = true; }
+        if (any) BK_HIP(e->slot_alias.upload(bits));
+        // the merged buckets' window slots: slot, window position and key of each (bk_gather.hip merged_votes_kernel)
+        std::vector<uint64_t> mg;
+        for (uint32_t sl : h_merged_slots) { mg.push_back(((uint64_t)h_slot_t[sl] << 32) | sl); mg.push_back(h_slot_key[sl]); }
+        e->n_merged_slots = (uint32_t)h_merged_slots.size();
+        if (!mg.empty()) BK_HIP(e->merged_slots.upload(mg));
+    }
     BK_HIP(e->ent_off.upload(h_off));
     BK_HIP(e->ent_len.upload(h_len));
     BK_HIP(e->entries.upload(h_ent));
@@ -1760,7 +1824,7 @@ int bk_engine_fork_params(const bk_engine* parent, const bk_params* prm, bk_engi
     e->cell_fast.alias(p->cell_fast); e->cell_nat.alias(p->cell_nat); e->cell_natrow.alias(p->cell_natrow); e->cell_blk.alias(p->cell_blk); e->seed_tab.alias(p->seed_tab); e->seed_log2 = p->seed_log2; e->seed_tab2.alias(p->seed_tab2); e->seed2_log2 = p->seed2_log2; e->rc_words.alias(p->rc_words);
     e->half_lo.pilots.alias(p->half_lo.pilots); e->half_lo.dir.alias(p->half_lo.dir); e->half_lo.cand.alias(p->half_lo.cand);
     e->half_hi.pilots.alias(p->half_hi.pilots); e->half_hi.dir.alias(p->half_hi.dir); e->half_hi.cand.alias(p->half_hi.cand);
-    e->slot_of.alias(p->slot_of); e->estat_off.alias(p->estat_off); e->estat.alias(p->estat); e->slot_rec.alias(p->slot_rec); e->ent_files.alias(p->ent_files); e->slot_files.alias(p->slot_files); e->id_own_files.alias(p->id_own_files); e->cell_file.alias(p->cell_file); e->id_rest_off.alias(p->id_rest_off); e->id_rest.alias(p->id_rest); e->estat_files.alias(p->estat_files); e->amb.alias(p->amb);
+    e->slot_of.alias(p->slot_of); e->estat_off.alias(p->estat_off); e->estat.alias(p->estat); e->slot_rec.alias(p->slot_rec); e->ent_files.alias(p->ent_files); e->slot_files.alias(p->slot_files); e->id_own_files.alias(p->id_own_files); e->cell_file.alias(p->cell_file); e->slot_alias.alias(p->slot_alias); e->gather_ok = p->gather_ok; e->merged_slots.alias(p->merged_slots); e->n_merged_slots = p->n_merged_slots; e->id_rest_off.alias(p->id_rest_off); e->id_rest.alias(p->id_rest); e->estat_files.alias(p->estat_files); e->amb.alias(p->amb);
     e->pilots.alias(p->pilots); e->table.alias(p->table); e->ent_off.alias(p->ent_off); e->ent_len.alias(p->ent_len); e->entries.alias(p->entries);
     e->occ.alias(p->occ); e->file_cell_lo_d.alias(p->file_cell_lo_d);
     e->genome_len.alias(p->genome_len); e->seq_cell.alias(p->seq_cell); e->seq_len_d.alias(p->seq_len_d); e->seq_first.alias(p->seq_first);
@@ -1813,8 +1877,12 @@ int bk_sample_begin(bk_engine* e) {
     bk_engine::Span sp(e, 2);
     e->plane_stale[0] = e->plane_stale[1] = true;   // a plane is zeroed when its mate file is first pushed (or finalized unpushed)
     e->win_chosen = false;
+    // gathered votes (bk_gather.hip) store the rows they own: every genome's rows -- nothing to zero; the selected genome's -- the rows
+    // the previous sample wrote are all that is not zero
+    const bool sel_rows = e->gather_mode && e->params.pileup_selected_only != 0 && e->n_files > 1;
     bk::launch_zero_small(e->stats.p, e->stats.n, e->kstats.p, e->kstats.n, e->ktab_out.p, e->ktab_out.n, e->present.p, e->present.n,
-                          e->n_deferred.p, e->n_deferred.n, e->pileup.p, e->pileup.n, e->stream);
+                          e->n_deferred.p, e->n_deferred.n, e->pileup.p, e->gather_mode ? 0 : e->pileup.n, e->stream);
+    if (sel_rows) bk::launch_zero_genome_rows(e->pileup.p, (size_t)e->total_cells * 4, e->file_cell_lo_d.p, e->n_files, (uint32_t)e->total_cells, e->last_sel.p, e->stream);
     if (e->ktab_keys.p) {
         if (!e->ktab_old.empty()) {   // tables the previous sample outgrew
             BK_HIP(hipStreamSynchronize(e->stream));
@@ -2265,7 +2333,14 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
                                        e->n_full, e->v_list[m].p, e->p_list[m].p, e->e_list[m].p, e->n_list[m].p, e->stream);
         }
     }
-    for (int pass = 0; pass < (two_pass ? 2 : 1); pass++) {
+    // gathered votes (bk_gather.hip): the statistics pass as ever, then gather_votes_kernel for the selected genome's cells or for all
+    const bool gather = e->gather_mode && elem_lo == 0 && elem_hi == e->plane_len && !via_reduced;
+    if (gather) BK_HIP(hipMemsetAsync(e->n_alias_hits.p, 0, 2 * sizeof(unsigned int), e->stream));
+    for (int pass = 0; pass < ((two_pass || gather) ? 2 : 1); pass++) {
+        if (gather && pass == 1) {   // difference arrays -> counts (the rows are zeroed behind the sample)
+            bk_engine::Span sp(e, 1);
+            for (int m = 0; m < n_mates; m++) bk::launch_prefix_rows(e->counters[m].p, e->view(), e->v_list[m].p, e->n_list[m].p, e->stream);
+        }
         for (int m = 0; m < n_mates; m++) {   // R1 then R2 into the same arrays (call.rs:316-317)
             bk::FinalizeArgs a{};
             a.ix = e->view();
@@ -2290,7 +2365,10 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             if (e->sparse) { a.v_list = e->v_list[m].p; a.p_list = e->p_list[m].p; a.e_list = e->e_list[m].p; a.n_list = e->n_list[m].p; }
             a.deferred_n = e->deferred_n.p ? e->deferred_n.p + (two_pass ? (size_t)m * (e->deferred_n.n / 2) : 0) : nullptr;
             a.clear_v = clean_dense && pass == (two_pass ? 1 : 0);
-            a.mode = two_pass ? pass + 1 : 0;
+            a.mode = two_pass ? pass + 1 : gather ? (pass == 0 ? 1 : 3) : 0;
+            if (gather) if (const char* ga = test_env("BK_GATHER_ABLATE")) a.gather_ablate = atoi(ga);
+            if (gather) { a.merged_slots = e->merged_slots.p; a.n_merged_slots = e->n_merged_slots; }
+            if (gather) { a.gather = pass == 1 ? 1 : 0; a.alias_hits = e->alias_hits[m].p; a.n_alias_hits = e->n_alias_hits.p + m; a.alias_cap = bk_engine::kAliasCap; }
             a.sel = two_pass ? &e->sel_out.p->file_id : nullptr;
             a.sel_file = -1;
             // dense planes mapped whole: K2a zeroes the V counters it reads; the E part (two counters per reference k-mer) is zeroed by
@@ -2312,6 +2390,8 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
                 else { a.f_items = nullptr; if (int rc = flush_pending_items(e)) return rc; }
             }
             bk_engine::Span sp(e, 1);
+            if (gather && pass == 1 && m == 0) bk::launch_gather_votes(a, n_mates == 2 ? e->counters[1].p : nullptr, e->stream);   // (both mate files' counts at once: it stores)
+            if (gather && pass == 1 && e->n_merged_slots) bk::launch_merged_votes(a, e->stream);
             bk::launch_finalize(a, e->stream);
         }
         if (two_pass && pass == 0) {
@@ -2320,6 +2400,7 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             c.out = e->sel_out.p;
             bk_engine::Span sp(e, 1);
             bk::launch_select_genome(c, e->stream);
+            if (gather) bk::launch_copy_int(e->last_sel.p, &e->sel_out.p->file_id, e->stream);   // (the rows the next sample zeroes)
         }
     }
     if (clean_dense) {   // K2a zeroed the V counters; the E part (two counters per reference k-mer) goes here
@@ -2373,6 +2454,11 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             }
         }
         fprintf(stderr, "[bk] finalize: %u + %u k-mers deferred to the general kernel\n", nd[0], nd[1]);
+        if (e->gather_mode) {
+            unsigned int ah[2] = {0u, 0u};
+            BK_HIP(hipMemcpy(ah, e->n_alias_hits.p, sizeof ah, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[bk] votes gathered cell by cell (bk_gather.hip); alias hits among the deferred k-mers: %u + %u\n", ah[0], ah[1]);
+        }
         if (e->sparse) {
             unsigned int nl[8];
             BK_HIP(hipMemcpy(nl, e->n_list[0].p, sizeof nl, hipMemcpyDeviceToHost));
@@ -2598,7 +2684,11 @@ int bk_sample_download(bk_engine* e, int n_mates, uint64_t* fwd_depth, uint64_t*
         BK_HIP(hipMemcpyAsync(&xf, e->xport_flag.p + 1, sizeof xf, hipMemcpyDeviceToHost, e->stream));
         BK_HIP(hipMemsetAsync(e->xport_flag.p + 1, 0, sizeof xf, e->stream));
     }
+    unsigned int ah[2] = {0u, 0u};
+    if (e->gather_mode) BK_HIP(hipMemcpyAsync(ah, e->n_alias_hits.p, sizeof ah, hipMemcpyDeviceToHost, e->stream));
     BK_HIP(hipStreamSynchronize(e->stream));
+    if (ah[0] > bk_engine::kAliasCap || ah[1] > bk_engine::kAliasCap)
+        return fail(BK_ERR_RANGE, "more than %u k-mers of this sample reach a bucket through the 64-bit wrap of its id: the list of them overflowed, the pileup is incomplete", bk_engine::kAliasCap);
     if (xf) return fail(BK_ERR_RANGE, "a counter of this (or an earlier, unchecked) sample did not fit the width its plane was exchanged at: the results are "
                                       "invalid -- repeat the sample with a wider bk_shard_transport (bk_shard_measure tells which width is safe)");
     if (kmer_stats) {

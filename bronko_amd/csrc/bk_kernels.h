@@ -171,6 +171,17 @@ struct FinalizeArgs {
     // items up in LDS -- what bin_count_kernel does before it stores the bin -- and takes its counts from there.  What Level 2 added
     // to the plane meanwhile is found through f_touch (a bit per V row it wrote: the SPARSE form of level2_kernel); the rows read
     // are zeroed, the bits cleared.  f_items null: the counts are the plane's.
+    // Gathered votes (bk_gather.hip; many genomes, sparse planes): mode 1 is the statistics pass as ever, except that
+    // finalize_general_kernel notes the deferred k-mers' alias hits; the voting pass (mode 2: the selected genome, mode 3: every
+    // genome) is gather_votes_kernel plus, with `gather` set, the general kernels restricted to what it cannot see: votes through
+    // alias keys (IndexView::slot_alias) from the pseudo rows, the pseudo k-mers' E counters and the noted hits.
+    int gather;
+    int gather_ablate;              // measurement aid (-DBK_TESTING build, BK_GATHER_ABLATE): 1 no LDS atomics, 2 no counter loads, 3 no answers either
+    unsigned long long* alias_hits; // [alias_cap][3]: canonical k-mer | isrc << 62, count, slot
+    unsigned int* n_alias_hits;     // [1], zeroed before the statistics pass
+    unsigned int alias_cap;
+    const uint64_t* merged_slots;   // [n_merged_slots][2] the window slots of buckets that hold several keys (k = 31: reference buckets whose ids wrapped
+    uint32_t n_merged_slots;        //   onto each other): slot | window position << 32, key.  What votes through one key also votes for the other keys' BucketInfos
     const unsigned short* f_items;  // BinArgs::items / tab / gext / ov / ov_n of the launch
     const unsigned short* f_tab;
     const unsigned short* f_gext;
@@ -321,6 +332,13 @@ void launch_call(const CallArgs& a, int max_seqs_per_file, uint64_t max_file_cel
 void launch_select_genome(const CallArgs& a, hipStream_t stream);   // the first kernel of launch_call alone: a.out->file_id
 size_t finalize_lds_bytes(int n_files);
 size_t finalize_partial_rows();
+void launch_prefix_rows(unsigned long long* counters, const IndexView& ix, const unsigned int* v_list, const unsigned int* n_list, hipStream_t stream);   // bk_gather.hip
+void launch_gather_votes(const FinalizeArgs& a, const unsigned long long* counters1, hipStream_t stream);
+void launch_alias_votes(const FinalizeArgs& a, hipStream_t stream);
+void launch_merged_votes(const FinalizeArgs& a, hipStream_t stream);
+void launch_zero_genome_rows(unsigned long long* pileup, size_t plane, const uint32_t* file_cell_lo, int n_files, uint32_t total_cells, const int* last_sel,
+                             hipStream_t stream);
+void launch_copy_int(int* dst, const int* src, hipStream_t stream);
 bool finalize_runs_by_region(const FinalizeArgs& a);   // launch_finalize will take the regional kernel of bk_finalize_lean.hip (one genome file, whole dense planes, ...)
 hipError_t raise_lds_limit(const void* fn, size_t lds);   // the dynamic-LDS limit of a kernel, raised once per process and device
 

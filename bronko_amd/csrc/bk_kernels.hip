@@ -1983,7 +1983,7 @@ template <bool MANY>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void finalize_variant_kernel(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (a.mode == 2) { a.sel_file = *a.sel; if (a.sel_file < 0 && !a.clear_v) return; }   // (no genome selected: no votes, but the plane is still to be cleared)   // second pass: votes for the selected genome only
-    const bool do_stats = a.mode != 2;                                       // (its statistics were tallied by the first pass)
+    const bool do_stats = a.mode < 2;                                        // (its statistics were tallied by the first pass; mode 3: votes only, every genome)
     const IndexView& ix = a.ix;
     uint32_t* lstats = reinterpret_cast<uint32_t*>(smem);   // [n_files][3] block-local tallies + 2 scratch words
     const VoteTable vt = vt_make(smem + (((size_t)ix.n_files * 3 + 2) * sizeof(uint32_t) + 15) / 16 * 16);
@@ -2053,6 +2053,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             first.cell = r.z; first.file = (uint16_t)(r.w & 0xffffu); first.idx = (uint8_t)(r.w >> 16); first.canonical = (uint8_t)(r.w >> 24);
         } else {
             const uint32_t s = ix.slot_of[(size_t)p * ix.W + t];
+            // (FinalizeArgs::gather: the votes through the buckets' own keys were gathered cell by cell -- only an alias slot is left)
+            if (a.gather && !(ix.slot_alias && ((ix.slot_alias[s >> 5] >> (s & 31u)) & 1u))) return;
             off = ix.ent_off[s]; cnt = ix.ent_len[s];
             if (cnt) first = ix.entries[off];
         }
@@ -2093,7 +2095,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const uint64_t nq = (uint64_t)ix.n_full + (uint32_t)ix.v_span;
     // sparse finalize: the touched rows from the list, RPW at a time, instead of every row of the plane
     const uint64_t n_listed = a.v_list ? a.n_list[0] : 0ull;
-    const uint64_t n_units = a.v_list ? (n_listed + RPW - 1) / RPW
+    const uint64_t n_units = a.gather ? 0ull                                      // (the reference k-mers' rows voted cell by cell: bk_gather.hip)
+                             : a.v_list ? (n_listed + RPW - 1) / RPW
                                       : ((nq + 2 * RPW - 1) / (2 * RPW)) * 12;   // unit u: q block u / 12 (2 RPW values of q), parity (u / 6) & 1, (alternative, direction) u % 6
     uint32_t par = 0;
     const bool sparse_plane = ix.n_files > 1 && !a.v_list;
@@ -2317,7 +2320,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (a.mode == 2) { a.sel_file = *a.sel; if (a.sel_file < 0) return; }   // second pass: votes for the selected genome only
-    const bool do_stats = a.mode != 2;
+    const bool do_stats = a.mode < 2;
     const IndexView& ix = a.ix;
     uint32_t* lstats = reinterpret_cast<uint32_t*>(smem);   // [n_files][3] block-local tallies + 2 scratch words
     const VoteTable vt = vt_make(smem + (((size_t)ix.n_files * 3 + 2) * sizeof(uint32_t) + 15) / 16 * 16);
@@ -2338,7 +2341,7 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     uint32_t par = 0;
     // every genome's rows (mode 0) over a list of touched k-mers of a many-genome index: the votes of the genomes that hold a k-mer
     // as it is were cast by finalize_exact_own_kernel, cell by cell
-    const bool own_all = a.mode == 0 && a.e_list && a.file_cell_lo && ix.id_own_files && ix.cell_file && ix.estat_files && ix.id_rest_off;
+    const bool own_all = a.mode == 0 && !a.gather && a.e_list && a.file_cell_lo && ix.id_own_files && ix.cell_file && ix.estat_files && ix.id_rest_off;
     // one (counter, window bucket) pair
     auto pair_body = [&](uint64_t cidx, uint32_t t) {
       do {
@@ -2406,7 +2409,7 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     // Voting pass of pileup_selected_only over a list of touched k-mers: nearly all of them were voted for by
     // finalize_exact_own_kernel (IndexView::id_own_files) or fail the thresholds -- one lane per counter finds the few that are
     // left (k-mers the selected genome does not hold as they are), and only those are spread over W lanes each
-    const bool own_done = (a.mode == 2 && a.e_list && a.file_cell_lo && ix.id_own_files) || own_all;
+    const bool own_done = (a.mode == 2 && !a.gather && a.e_list && a.file_cell_lo && ix.id_own_files) || own_all;
     if (own_done) {
         __shared__ unsigned long long ownq[256], restq[256];
         __shared__ unsigned int ownq_n, restq_n;
@@ -2466,7 +2469,7 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
     }
     // 256 consecutive (counter, bucket) pairs per workgroup and round: ~8 consecutive reference k-mers, whose votes fall on
     // ~25 pileup cells -- gathered in the workgroup's vote table (LDS) before they go to the pileup
-    for (uint64_t g0 = (a.e_list ? 0ull : c_lo * W) + (uint64_t)blockIdx.x * 256; g0 < n_work && !own_done; g0 += (uint64_t)gridDim.x * 256) {
+    for (uint64_t g0 = (a.e_list ? 0ull : c_lo * W) + (uint64_t)blockIdx.x * 256; g0 < n_work && !own_done && !a.gather; g0 += (uint64_t)gridDim.x * 256) {   // (gather: the reference k-mers voted cell by cell)
       const uint64_t g = g0 + threadIdx.x;
       // the counter of this (counter, bucket) pair; a listed id may be a pseudo k-mer: those are mapped by the loop below
       uint64_t cidx = g < n_work ? g / Wd : 0ull;
@@ -2535,6 +2538,7 @@ __global__ __launch_bounds__(256) void finalize_exact_kernel(FinalizeArgs a) {
         const uint64_t c = ix.kmer_of[id];
         if (a.mode != 1) for (uint32_t t = a.e_list ? t0 : 0u; t < (a.e_list ? t0 + 1u : W); ++t) {
             const uint32_t s = ix.slot_of[(size_t)id * W + t];
+            if (a.gather && !(ix.slot_alias && ((ix.slot_alias[s >> 5] >> (s & 31u)) & 1u))) continue;   // (gathered votes: only alias slots are left)
             const uint32_t off = ix.ent_off[s], cnt = ix.ent_len[s];
             if (a.mode == 2 && ix.ent_files) {   // (one entry per genome: the selected genome's by its rank -- no bisection in this serial loop)
                 const uint4 fb = ix.ent_files[s];
@@ -2640,8 +2644,15 @@ __global__ __launch_bounds__(256) void finalize_exact_own_kernel(FinalizeArgs a)
 __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (a.mode == 2) { a.sel_file = *a.sel; if (a.sel_file < 0) return; }   // second pass: votes for the selected genome only
-    const bool do_stats = a.mode != 2;
+    const bool do_stats = a.mode < 2;
     const IndexView& ix = a.ix;
+    // gathered votes (bk_gather.hip): this statistics pass notes which of its k-mers reach a bucket through an alias key
+    auto note_alias = [&](int sb, uint64_t c, uint32_t isrc, unsigned long long n) {
+        if (a.alias_hits && ix.slot_alias && sb >= 0 && ((ix.slot_alias[(uint32_t)sb >> 5] >> ((uint32_t)sb & 31u)) & 1u)) {
+            const unsigned int at = atomicAdd(a.n_alias_hits, 1u);
+            if (at < a.alias_cap) { a.alias_hits[3ull * at] = c | ((unsigned long long)isrc << 62); a.alias_hits[3ull * at + 1ull] = n; a.alias_hits[3ull * at + 2ull] = (unsigned long long)(uint32_t)sb; }
+        }
+    };
     uint32_t* hits = reinterpret_cast<uint32_t*>(smem);                       // [n_files]
     uint32_t* touched = hits + ix.n_files;                                      // [n_files]
     uint32_t* lstats = touched + ix.n_files;                                    // [n_files][3]
@@ -2728,6 +2739,7 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
             }
             // the buckets found, one after the other; the BucketInfos of a bucket (one per genome that has the k-mer: up to
             // hundreds) spread over the lanes
+            if (a.mode == 1) note_alias(s, c, isrc, v);
             for (unsigned long long bm = __ballot(s >= 0); bm; bm &= bm - 1ull) {
                 const int sb = __shfl(s, __builtin_ctzll(bm));
                 const uint32_t off = ix.ent_off[sb], cnt = ix.ent_len[sb];
@@ -2775,7 +2787,8 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
             uint32_t isrc = 0, p_ = 0, t_ = 0;
             if (on) v_kmer_of_counter(ix, nullptr, a.deferred[item], p_, t_, c, isrc, v);
             uint4 acc = make_uint4(0u, 0u, 0u, 0u);
-            uint32_t found = 0;
+            uint32_t found = 0, alias_n = 0;
+            int alias_sb = -1;
             bool generic = false;
             for (int t = 0; t < ix.W; ++t) {
                 const int sh = 2 * (k - 1 - (ix.wstart + t));
@@ -2785,8 +2798,15 @@ __global__ __launch_bounds__(64) void finalize_general_kernel(FinalizeArgs a) {
                 generic |= !files_any(fb);
                 acc.x |= fb.x; acc.y |= fb.y; acc.z |= fb.z; acc.w |= fb.w;
                 found |= 1u << t;
+                alias_sb = (a.alias_hits && ix.slot_alias && ((ix.slot_alias[(uint32_t)sb >> 5] >> ((uint32_t)sb & 31u)) & 1u)) ? (alias_n++ ? -2 : sb) : alias_sb;
             }
             generic |= found == 0xffffffffu >> (32 - ix.W);
+            generic |= alias_sb == -2;   // (more than one alias bucket: the wave-per-k-mer path notes them all)
+            if (on && !generic && alias_sb >= 0) {   // (rare) the k-mer's count, from the plane
+                unsigned long long n_; uint64_t c2; uint32_t i2, p2, t2;
+                v_kmer_of_counter(ix, a.counters + ix.v_off, a.deferred[item], p2, t2, c2, i2, n_);
+                note_alias(alias_sb, c, isrc, n_);
+            }
             if (on && a.deferred_mask) a.deferred_mask[item] = found;
             if (!on || generic) acc = make_uint4(0u, 0u, 0u, 0u);
             tally_files<false>(acc, lstats, (uint32_t)lane, (uint32_t)ix.n_files);   // (one wave per workgroup: no atomic needed)
@@ -2913,6 +2933,17 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     const unsigned b_gen = finalize_general_blocks(a);
+    if (a.gather && a.mode >= 2) {
+        // the voting pass behind gather_votes_kernel (bk_gather.hip): what reaches a bucket through an alias key -- the pseudo rows
+        // (K2a's last loop), the pseudo k-mers' E counters (K2e's), the alias hits the statistics pass noted
+        if (a.ix.n_prows) {
+            if (a.ix.slot_files) hipLaunchKernelGGL(finalize_variant_kernel<true>, dim3(64), dim3(256), lds_votes, stream, a);
+            else hipLaunchKernelGGL(finalize_variant_kernel<false>, dim3(64), dim3(256), lds_votes, stream, a);
+        }
+        if (a.ix.n_u > a.ix.n_full) hipLaunchKernelGGL(finalize_exact_kernel, dim3(64), dim3(256), lds_votes, stream, a);
+        if (a.alias_hits) launch_alias_votes(a, stream);
+        return;
+    }
     unsigned b_v = b_var, b_e = 0;
     const bool lean = finalize_runs_by_region(a);
     if (lean) {
@@ -2938,7 +2969,7 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     // K2b (deferred k-mers only; the kernel reads their number on the device)
     a.row_general = (int)(b_v + b_e);
     hipLaunchKernelGGL(finalize_general_kernel, dim3(b_gen), dim3(64), lds, stream, a);
-    if (a.partials && a.mode != 2) {
+    if (a.partials && a.mode < 2) {
         const int cols = a.ix.n_files * 3 + 2;
         hipLaunchKernelGGL(finalize_reduce_kernel, dim3((unsigned)cols), dim3(256), 0, stream, a, (int)(b_v + b_e + b_gen), a.zero_e, a.zero_e_n);
     }

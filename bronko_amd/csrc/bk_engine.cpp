@@ -55,7 +55,8 @@ struct DevBuf {
         n = count;
         return hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
     }
-    hipError_t upload(const std::vector<T>& h) {
+    template <class A>
+    hipError_t upload(const std::vector<T, A>& h) {
         hipError_t e = alloc(h.size());
         if (e != hipSuccess || h.empty()) return e;
         return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
@@ -64,10 +65,10 @@ struct DevBuf {
 
 struct TimedSpan { hipEvent_t a, b; int kind; };
 
-// fn(begin, end) over [0, n) on up to hardware_concurrency() threads (capped at 32): host-side table construction only
+// fn(begin, end) over [0, n) on up to hardware_concurrency() threads (capped at 256): host-side table construction only
 template <typename F>
 void parallel_for(size_t n, F&& fn) {
-    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 96u);
+    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 256u);
     if (n < (size_t)nt * 1024) { fn((size_t)0, n); return; }
     std::vector<std::thread> th;
     const size_t per = (n + nt - 1) / nt;
@@ -76,6 +77,25 @@ void parallel_for(size_t n, F&& fn) {
         if (b < en) th.emplace_back([&fn, b, en] { fn(b, en); });
     }
     for (auto& t : th) t.join();
+}
+
+// A host array whose elements are not initialised by its constructor (the GB-sized tables of a many-genome index: a serial
+// value-initialisation was 0.3 s each; they are filled by parallel_for)
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    template <class U, class... A>
+    void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new (static_cast<void*>(p)) U;
+        else ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using HostVec = std::vector<T, NoInitAlloc<T>>;
+template <class T>
+HostVec<T> filled(size_t n, const T& v) {
+    HostVec<T> a(n);
+    parallel_for(n, [&](size_t i0, size_t i1) { std::fill(a.begin() + (ptrdiff_t)i0, a.begin() + (ptrdiff_t)i1, v); });
+    return a;
 }
 
 // Testing / measurement aids exist only in the -DBK_TESTING build (libbronko_hip_testing.so, loaded by the tests that force a
@@ -754,7 +774,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     };
     {
         const uint64_t nbk = e->W > 0 ? ix->n_buckets : 0;
-        const unsigned nt = nbk < 65536 ? 1u : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 96u);
+        const unsigned nt = nbk < 65536 ? 1u : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 256u);
         std::vector<ChunkOut> outs(nt);
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; t++) {
@@ -764,6 +784,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         }
         for (auto& t : th) t.join();
         for (auto& o : outs) if (o.code != BK_OK) return fail(o.code, "%s", o.err.c_str());
+        pc.lap("  buckets: chunks");
         uint64_t n_ent = 0;
         for (auto& o : outs) n_ent += o.h_ent.size();
         if (n_ent >= (1ull << 32)) return fail(BK_ERR_UNSUPPORTED, "more than 2^32 index entries in the window");
@@ -804,7 +825,18 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     e->log2s = 4;
     while ((1ull << e->log2s) < 2 * max_t) e->log2s++;   // load factor <= 0.5
     const size_t S = (size_t)1 << e->log2s;
-    std::vector<bk::TableSlot> h_table((size_t)std::max(e->W, 1) * S, bk::TableSlot{bk::kEmptyKey, 0u, 0u});
+    // (a large index: built on the device, where the probes of U below run too -- the host never holds it)
+    const bool table_on_device = e->n_slots >= (1u << 18) && e->W > 0;
+    HostVec<bk::TableSlot> h_table;
+    if (table_on_device) {
+        bool dup = false;
+        BK_HIP(e->table.alloc((size_t)e->W * S));
+        static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "");
+        BK_HIP(bk::device_build_table(e->table.p, (size_t)e->W * S, e->log2s, reinterpret_cast<const unsigned long long*>(h_slot_key.data()), h_slot_t.data(), e->n_slots, &dup));
+        if (dup && k != 31) return fail(BK_ERR_INVALID, "duplicate window bucket in the index");
+    } else {
+    h_table = filled((size_t)std::max(e->W, 1) * S, bk::TableSlot{bk::kEmptyKey, 0u, 0u});
+    pc.lap("  window tables: allocation");
     {
         // one sub-table per window position: each is filled by its own host thread, in slot order (the first of equal keys stays)
         std::atomic<bool> dup{false};
@@ -831,6 +863,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         for (auto& t : th) t.join();
         if (dup) return fail(BK_ERR_INVALID, "duplicate window bucket in the index");
     }
+    }
     pc.lap("window tables");
     // a slot with no entries: "this k-mer has no bucket at that window position" (pseudo k-mers)
     const uint32_t empty_slot = (uint32_t)h_off.size();
@@ -840,9 +873,10 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     // ---- reference k-mer set U ------------------------------------------------------------------------------
     // ids in order of first occurrence in reference order; perfect hash (membership + diagonal seeding);
     // half-key directories (neighbour search); the reference in reference order (diagonal walk); per-id tables.
-    const unsigned sort_threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    const unsigned sort_threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
     parallel_sort(h_u, std::less<uint64_t>(), sort_threads);
     h_u.erase(std::unique(h_u.begin(), h_u.end()), h_u.end());
+    pc.lap("  U: sort");
     // pseudo k-mers join U (so that the membership / neighbour machinery finds the read k-mers that alias), but they
     // own only the window positions at which the table holds a key for them.  A pseudo value that is a real
     // reference k-mer needs nothing: its alias key is that k-mer's own bucket key.
@@ -861,11 +895,32 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         h_u.insert(h_u.end(), extra.begin(), extra.end());
         std::inplace_merge(h_u.begin(), h_u.begin() + (ptrdiff_t)mid, h_u.end());   // two sorted, disjoint runs
     }
+    pc.lap("  U: pseudo k-mers sorted, merged");
     // bucket (slot) of every k-mer of U at every window position, by table lookup; h_valid = positions with a bucket
     std::vector<uint32_t> h_valid(h_u.size(), 0u);
     std::vector<uint8_t> h_is_pseudo(h_u.size(), 0);
-    std::vector<uint32_t> slot_by_index((size_t)std::max<size_t>(h_u.size(), 1) * std::max(e->W, 1), empty_slot);
+    // (a large index: the probes run on the device, against the tables where they will stay -- 400 M of them with a hundred strains
+    // at k = 31, DRAM latency on the host; the slots stay on the device until they are laid out by id, slot_of below)
+    const bool slots_on_device = (h_u.size() >= (1u << 18) || table_on_device) && e->W > 0;
+    DevBuf<uint32_t> d_slot_by_index;
+    HostVec<uint32_t> slot_by_index;
     std::atomic<bool> lacks{false};
+    if (slots_on_device) {
+        if (!table_on_device) BK_HIP(e->table.upload(h_table));
+        BK_HIP(d_slot_by_index.alloc(h_u.size() * (size_t)e->W));
+        static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "");
+        BK_HIP(bk::device_lookup_slots(e->table.p, e->log2s, reinterpret_cast<const unsigned long long*>(h_u.data()), h_u.size(), e->W, e->wstart, k, empty_slot,
+                                       d_slot_by_index.p, h_valid.data()));
+        const uint32_t all = e->W >= 32 ? 0xffffffffu : (1u << e->W) - 1u;
+        parallel_for(h_u.size(), [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; i++) {
+                h_is_pseudo[i] = std::binary_search(extra.begin(), extra.end(), h_u[i]) ? 1 : 0;
+                if (!h_is_pseudo[i] && h_valid[i] != all) lacks = true;
+            }
+        });
+    } else {
+    slot_by_index = filled((size_t)std::max<size_t>(h_u.size(), 1) * std::max(e->W, 1), empty_slot);
+    pc.lap("  U: slot_by_index allocation");
     parallel_for(h_u.size(), [&](size_t i0, size_t i1) {
         for (size_t i = i0; i < i1; i++) {
             h_is_pseudo[i] = std::binary_search(extra.begin(), extra.end(), h_u[i]) ? 1 : 0;
@@ -879,6 +934,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             }
         }
     });
+    }
     if (lacks) return fail(BK_ERR_INVALID, "index lacks a window bucket of one of its own reference k-mers");
     pc.lap("U + slot lookup");
     e->lo_bases = k / 2;
@@ -998,13 +1054,29 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 const int parts = dist + 1;   // words at distance <= dist agree on at least one of dist + 1 parts
                 if (collect) collect->assign(parts, {});
                 std::vector<std::thread> th;
-                const unsigned per_part = std::max(1u, std::min(24u, std::thread::hardware_concurrency() / (unsigned)parts));
+                const unsigned per_part = std::max(1u, std::min(64u, std::thread::hardware_concurrency() / (unsigned)parts));
                 for (int part = 0; part < parts; part++) th.emplace_back([&, part] {   // (flags are only ever set to 1: benign races)
-                    std::vector<Form> fs(forms);
                     std::vector<uint64_t>* near = collect ? &(*collect)[part] : nullptr;
                     const int c0 = (part * k) / parts, c1 = ((part + 1) * k) / parts;
                     const uint64_t mask = (((1ull << (2 * (c1 - c0))) - 1ull) << (2 * c0));
-                    parallel_sort(fs, [&](const Form& x, const Form& y) { return (x.w & mask) < (y.w & mask); }, per_part);
+                    // the forms grouped by this part: a radix sort of the part's bits on the device, the forms gathered in that order
+                    // (std::sort of 30 M forms on 24 host threads per part was 1.4 s of a 100-strain create)
+                    std::vector<Form> fs;
+                    bool on_device = false;
+                    if (forms.size() >= (1u << 16) && hipSetDevice(e->device) == hipSuccess) {
+                        std::vector<unsigned long long> keys(forms.size());
+                        std::vector<unsigned int> order(forms.size());
+                        parallel_for(forms.size(), [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; i++) keys[i] = (forms[i].w & mask) >> (2 * c0); });
+                        if (bk::device_sort_order(keys.data(), keys.size(), 2 * (c1 - c0), order.data(), nullptr) == hipSuccess) {
+                            fs.resize(forms.size());
+                            parallel_for(forms.size(), [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; i++) fs[i] = forms[order[i]]; });
+                            on_device = true;
+                        }
+                    }
+                    if (!on_device) {
+                        fs = forms;
+                        parallel_sort(fs, [&](const Form& x, const Form& y) { return (x.w & mask) < (y.w & mask); }, per_part);
+                    }
                     // the groups (equal parts), dealt to threads in runs of whole groups; every thread collects its own near pairs
                     const unsigned nt = fs.size() < 262144 ? 1u : per_part;
                     std::vector<size_t> cut(nt + 1, fs.size());
@@ -1022,17 +1094,23 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                             if (a1 - a0 > 4096) {   // pathological low-complexity group: flag all, skip the quadratic pass
                                 for (size_t x = a0; x < a1; x++) { out[fs[x].id] = 1; if (near) h_no_list[fs[x].fi >> 1] = 1; }
                             } else {
-                                for (size_t x = a0; x < a1; x++)
+                                // (pseudo k-mers -- 95 % of U with a hundred strains at k = 31 -- are flagged dirty whatever their neighbours
+                                // and own no near list: a pair of two of them says nothing, and only a reference k-mer's list is kept)
+                                for (size_t x = a0; x < a1; x++) {
+                                    const bool px = h_is_pseudo[fs[x].fi >> 1] != 0;
                                     for (size_t y = x + 1; y < a1; y++) {
+                                        const bool py = h_is_pseudo[fs[y].fi >> 1] != 0;
+                                        if (px && py) continue;
                                         const uint64_t d = fs[x].w ^ fs[y].w;
                                         if (__builtin_popcountll((d | (d >> 1)) & 0x5555555555555555ull) <= dist) {
                                             out[fs[x].id] = out[fs[y].id] = 1;   // also catches u vs rc(u) (same id)
                                             if (near) {   // (owner canonical form << 32) | the other form
-                                                if (!(fs[x].fi & 1u)) out_near.push_back(((uint64_t)(fs[x].fi >> 1) << 32) | fs[y].fi);
-                                                if (!(fs[y].fi & 1u)) out_near.push_back(((uint64_t)(fs[y].fi >> 1) << 32) | fs[x].fi);
+                                                if (!(fs[x].fi & 1u) && !px) out_near.push_back(((uint64_t)(fs[x].fi >> 1) << 32) | fs[y].fi);
+                                                if (!(fs[y].fi & 1u) && !py) out_near.push_back(((uint64_t)(fs[y].fi >> 1) << 32) | fs[x].fi);
                                             }
                                         }
                                     }
+                                }
                             }
                             a0 = a1;
                         }
@@ -1049,13 +1127,28 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             };
             std::vector<std::vector<uint64_t>> near_parts;
             flag_within(2, h_amb, &near_parts);
+            pc.lap("  dirty: distance 2");
             if (h_u.size() <= kAmb3MaxKmers) flag_within(3, h_amb3, nullptr);
             else std::fill(h_amb3.begin(), h_amb3.end(), (uint8_t)1);
+            pc.lap("  dirty: distance 3");
             size_t tot = 0;
             for (auto& v : near_parts) tot += v.size();
             h_near.reserve(tot);
             for (auto& v : near_parts) { h_near.insert(h_near.end(), v.begin(), v.end()); std::vector<uint64_t>().swap(v); }
-            parallel_sort(h_near, std::less<uint64_t>(), sort_threads);
+            {
+                bool on_device = false;
+                if (h_near.size() >= (1u << 20) && h_near.size() < (1ull << 32) && hipSetDevice(e->device) == hipSuccess) {
+                    std::vector<unsigned int> order(h_near.size());
+                    std::vector<unsigned long long> sorted(h_near.size());
+                    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "");
+                    if (bk::device_sort_order(reinterpret_cast<const unsigned long long*>(h_near.data()), h_near.size(), 64, order.data(), sorted.data()) == hipSuccess) {
+                        parallel_for(h_near.size(), [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; i++) h_near[i] = sorted[i]; });
+                        on_device = true;
+                    }
+                }
+                if (!on_device) parallel_sort(h_near, std::less<uint64_t>(), sort_threads);
+            }
+            pc.lap("  dirty: near lists sorted");
             h_near.erase(std::unique(h_near.begin(), h_near.end()), h_near.end());
         }
         for (size_t i = 0; i < h_u.size(); i++) if (h_is_pseudo[i]) h_amb3[id_of[i]] = 1;
@@ -1338,6 +1431,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         std::vector<uint16_t> h_pilots;
         std::vector<uint32_t> u_pos;
         if (!build_phf(h_u, h_pilots, e->log2nb, e->m, e->log2p, u_pos)) return fail(BK_ERR_HIP, "internal error: perfect hash construction failed after every fallback");
+        pc.lap("  perfect hash of U");
         std::vector<bk::KmerPos> t_pos((size_t)e->m << e->log2p, bk::KmerPos{bk::kEmptyKey, kNone, 0u});
         std::vector<uint64_t> h_kmer_of(std::max<size_t>(h_u.size(), 1), bk::kEmptyKey);
         for (size_t i = 0; i < h_u.size(); i++) {
@@ -1360,6 +1454,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         BK_HIP(e->cell_codes.upload(h_codes));
         BK_HIP(e->cell_flags.upload(h_cflags));
         BK_HIP(e->id_at.upload(h_id_at));
+        pc.lap("  tables of U filled, uploaded");
         e->file_cell_lo.assign((size_t)ix->n_files, 0u);
         for (int f = 0; f < ix->n_files; f++) e->file_cell_lo[f] = ix->n_seqs[f] ? (uint32_t)cell_off[f][0] : (uint32_t)cells;
         // the scan's seed tables (bk_device.h seed_hash): per genome file, where each of its reference k-mers starts
@@ -1478,13 +1573,28 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             HalfHost hh[2];
             auto build_half = [&](int which) {
                 auto half_of = [&](uint64_t u) { return which == 0 ? (u & lo_mask) : (u >> lo_bits); };
+                PhaseClock hc;
+                hc.on = hc.on && which == 0;
                 std::vector<uint32_t> order(h_u.size());
                 for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
-                if (which == 0)
-                    parallel_sort(order, [&](uint32_t x, uint32_t y) {
-                        const uint64_t hx = half_of(h_u[x]), hy = half_of(h_u[y]);
-                        return hx != hy ? hx < hy : h_u[x] < h_u[y];
-                    }, sort_threads);   // (which == 1: h_u is sorted by value, hence by its high half, then by value)
+                if (which == 0) {
+                    // by low half, then by value (= by high half): one radix sort on the device of the k-mers with their halves swapped
+                    // (an indirect std::sort on 32 host threads was 1.5 s of a 100-strain create); which == 1: h_u is sorted by value,
+                    // hence by its high half, then by value
+                    bool on_device = false;
+                    if (order.size() >= (1u << 16) && hipSetDevice(e->device) == hipSuccess) {
+                        const int hi_bits = 2 * k - lo_bits;
+                        std::vector<unsigned long long> keys(h_u.size());
+                        parallel_for(h_u.size(), [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; i++) keys[i] = ((h_u[i] & lo_mask) << hi_bits) | (h_u[i] >> lo_bits); });
+                        on_device = bk::device_sort_order(keys.data(), keys.size(), 2 * k, order.data(), nullptr) == hipSuccess;
+                    }
+                    if (!on_device)
+                        parallel_sort(order, [&](uint32_t x, uint32_t y) {
+                            const uint64_t hx = half_of(h_u[x]), hy = half_of(h_u[y]);
+                            return hx != hy ? hx < hy : h_u[x] < h_u[y];
+                        }, sort_threads);
+                }
+                hc.lap("  half 0: order sorted");
                 std::vector<bk::NbEntry>& cand = hh[which].cand;
                 cand.resize(order.size());
                 parallel_for(order.size(), [&](size_t i0, size_t i1) {   // (the gather through `order` is what costs: host threads)
@@ -1498,15 +1608,19 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     if (halves.empty() || halves.back() != hf) { halves.push_back(hf); first.push_back((uint32_t)i); count.push_back(0); }
                     count.back()++;
                 }
+                hc.lap("  half 0: candidates gathered, halves listed");
                 bk_engine::HalfBufs& hb = which == 0 ? e->half_lo : e->half_hi;
                 std::vector<uint32_t> hpos;
                 if (!build_phf(halves, hh[which].hp, hb.log2nb, hb.m, hb.log2p, hpos)) { hh[which].ok = false; return; }
                 hh[which].dir.assign((size_t)hb.m << hb.log2p, bk::HalfDir{0u, 0u, 0u, 0u});
+                hc.lap("  half 0: perfect hash");
                 for (size_t i = 0; i < halves.size(); i++) hh[which].dir[hpos[i]] = bk::HalfDir{(uint32_t)halves[i], first[i], count[i], 0u};
+                hc.lap("  half 0: directory");
             };
             std::thread t0(build_half, 0);
             build_half(1);
             t0.join();
+            pc.lap("  halves built");
             for (int which = 0; which < 2; which++) {
                 if (!hh[which].ok) return fail(BK_ERR_HIP, "internal error: perfect hash construction failed after every fallback");
                 bk_engine::HalfBufs& hb = which == 0 ? e->half_lo : e->half_hi;
@@ -1519,13 +1633,23 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         pc.lap("half-key directories");
         // slot_of[id*W + t]: the window bucket (wstart+t, u masked) of reference k-mer id -- every reference k-mer
         // owns all of its buckets, so finalize needs no table probe for them (pseudo k-mers: empty_slot where none).
-        std::vector<uint32_t> h_slot_of((size_t)std::max<size_t>(h_u.size(), 1) * std::max(e->W, 1), empty_slot);
+        HostVec<uint32_t> h_slot_of;
+        if (slots_on_device) {   // laid out by id on the device, where the table stays; the host phases below read a copy
+            BK_HIP(e->slot_of.alloc(h_u.size() * (size_t)e->W));
+            BK_HIP(bk::device_permute_rows(d_slot_by_index.p, id_of.data(), h_u.size(), e->W, e->slot_of.p));
+            BK_HIP(d_slot_by_index.alloc(0));   // (freed)
+            h_slot_of = HostVec<uint32_t>(h_u.size() * (size_t)e->W);
+            BK_HIP(hipMemcpy(h_slot_of.data(), e->slot_of.p, h_slot_of.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        } else {
+        h_slot_of = filled((size_t)std::max<size_t>(h_u.size(), 1) * std::max(e->W, 1), empty_slot);
         parallel_for(h_u.size(), [&](size_t i0, size_t i1) {
             for (size_t i = i0; i < i1; i++)
                 for (int t = 0; t < e->W; t++) h_slot_of[(size_t)id_of[i] * e->W + t] = slot_by_index[i * e->W + t];
         });
-        std::vector<uint32_t>().swap(slot_by_index);
+        HostVec<uint32_t>().swap(slot_by_index);
         BK_HIP(e->slot_of.upload(h_slot_of));
+        }
+        pc.lap("  slot_of filled, uploaded");
         {
             std::vector<uint8_t> h_all_own, h_own_mirror;   // by id (file bitmaps only)
             std::vector<bk::SlotRec> h_rec((size_t)std::max<size_t>(e->n_full, 1) * std::max(e->W, 1));
@@ -1540,6 +1664,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     }
             });
             BK_HIP(e->slot_rec.upload(h_rec));
+            pc.lap("  slot_rec");
             // Which genome files a bucket holds, as a bitmap (IndexView::ent_files / slot_files): with up to 128 files, for buckets
             // that hold at most one BucketInfo per file -- the rule with many related genomes.  The statistics pass of
             // pileup_selected_only then tallies a k-mer's genomes without reading its ~100 entries, and the voting pass finds the
@@ -1568,6 +1693,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 });
                 BK_HIP(e->ent_files.upload(h_ef));
                 BK_HIP(e->slot_files.upload(h_sf));
+                pc.lap("  file bitmaps");
                 // id_own_files (IndexView): bit f of id = in every one of the k-mer's W buckets genome f's only BucketInfo is the k-mer's
                 // own occurrence in f -- cell, idx and orientation of bucket t are those of bucket 0, t further on.  The voting pass
                 // for the selected genome then needs bucket 0 alone (one load shared by the W lanes of a counter).
@@ -1611,6 +1737,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     }
                 });
                 BK_HIP(e->id_own_files.upload(h_own));
+                pc.lap("  own files");
                 if (test_env("BK_L2_STATS")) {
                     uint64_t n_own = 0, n_b0 = 0, n_mir = 0, n_any = 0;
                     auto pc4 = [](const uint4& b) { return (uint64_t)(__builtin_popcount(b.x) + __builtin_popcount(b.y) + __builtin_popcount(b.z) + __builtin_popcount(b.w)); };
@@ -1653,6 +1780,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     });
                     BK_HIP(e->id_rest_off.upload(h_roff));
                     BK_HIP(e->id_rest.upload(h_rest));
+                    pc.lap("  rest lists");
                 }
                 // kIdAllOwn: nothing else in any of the k-mer's buckets
                 h_all_own.assign(e->n_full, 0);
@@ -1705,7 +1833,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         {
             // per id, independently: chunks on host threads, each with its own list, joined in id order
             const size_t n_ids = h_u.size();
-            const unsigned nt = n_ids < 65536 ? 1u : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 96u);
+            const unsigned nt = n_ids < 65536 ? 1u : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 256u);
             std::vector<std::vector<uint32_t>> part(nt);
             std::vector<uint32_t> n_of(n_ids, 0u);
             auto work = [&](unsigned t) {
@@ -1731,8 +1859,12 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             work(0);
             for (auto& t : th) t.join();
             for (size_t id = 0; id < n_ids; id++) h_estat_off[id + 1] = h_estat_off[id] + n_of[id];
-            h_estat.reserve(h_estat_off[n_ids]);
-            for (auto& v : part) { h_estat.insert(h_estat.end(), v.begin(), v.end()); std::vector<uint32_t>().swap(v); }
+            h_estat.resize(h_estat_off[n_ids]);
+            {   // the chunks' lists back to back (chunk t starts where its first id's list starts), copied side by side
+                std::vector<std::thread> cp;
+                for (unsigned t = 0; t < nt; t++) cp.emplace_back([&, t] { if (!part[t].empty()) std::copy(part[t].begin(), part[t].end(), h_estat.begin() + (ptrdiff_t)h_estat_off[n_ids * t / nt]); std::vector<uint32_t>().swap(part[t]); });
+                for (auto& t : cp) t.join();
+            }
         }
         BK_HIP(e->estat_off.upload(h_estat_off));
         BK_HIP(e->estat.upload(h_estat));
@@ -1772,7 +1904,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
 
     if (bk::finalize_lds_bytes(e->n_files) > 160 * 1024) return fail(BK_ERR_UNSUPPORTED, "more than ~8000 genome files are not supported by the finalize kernel");
 
-    BK_HIP(e->table.upload(h_table));
+    if (!e->table.p) BK_HIP(e->table.upload(h_table));
     {
         bool any = false;
         std::vector<uint32_t> bits(h_slot_alias.size() / 32 + 2, 0u);

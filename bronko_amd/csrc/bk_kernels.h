@@ -339,6 +339,14 @@ void launch_merged_votes(const FinalizeArgs& a, hipStream_t stream);
 void launch_zero_genome_rows(unsigned long long* pileup, size_t plane, const uint32_t* file_cell_lo, int n_files, uint32_t total_cells, const int* last_sel,
                              hipStream_t stream);
 void launch_copy_int(int* dst, const int* src, hipStream_t stream);
+// bk_build.hip: order[i] = index of the i-th smallest of n u64 keys (radix sort on the device over bits [0, end_bit), stable); h_sorted_keys may be null
+hipError_t device_sort_order(const unsigned long long* h_keys, size_t n, int end_bit, unsigned int* h_order, unsigned long long* h_sorted_keys);
+// bk_build.hip (bk_engine_create): out[i * W + t] = window bucket (slot) of keys[i] at window position t, `empty` where there is none (device buffer),
+// valid[i] = the positions found (host); dst[id_of[i] * W + t] = src[i * W + t] (device buffers)
+hipError_t device_lookup_slots(const TableSlot* d_table, uint32_t log2s, const unsigned long long* h_keys, size_t n, int W, int wstart, int k, uint32_t empty,
+                               uint32_t* d_out, uint32_t* h_valid);
+hipError_t device_build_table(TableSlot* d_table, size_t n_table, uint32_t log2s, const unsigned long long* h_keys, const unsigned char* h_ts, size_t n, bool* dup);
+hipError_t device_permute_rows(const uint32_t* d_src, const uint32_t* h_id_of, size_t n, int W, uint32_t* d_dst);
 bool finalize_runs_by_region(const FinalizeArgs& a);   // launch_finalize will take the regional kernel of bk_finalize_lean.hip (one genome file, whole dense planes, ...)
 hipError_t raise_lds_limit(const void* fn, size_t lds);   // the dynamic-LDS limit of a kernel, raised once per process and device
 

@@ -685,12 +685,13 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
     auto process_buckets = [&](uint64_t b0, uint64_t b1, ChunkOut& o) -> bool {
         uint64_t ids[32];
         o.per_t.assign(e->W > 0 ? e->W : 1, 0);
+        std::vector<std::pair<int, uint64_t>> keys;   // (one allocation per chunk, not per bucket: 37 M mallocs from 256 threads with a hundred strains)
         for (uint64_t b = b0; b < b1; b++) {
             const uint64_t lo = ix->bucket_off[b], hi = ix->bucket_off[b + 1];
             if (hi <= lo) continue;
             if (hi > ix->n_entries) return o.fail(BK_ERR_INVALID, "bucket_off out of range");
             // distinct (j, masked) keys present in this bucket: exactly one unless k = 31 ids wrapped onto each other
-            std::vector<std::pair<int, uint64_t>> keys;
+            keys.clear();
             uint64_t first_kmer = 0;
             bool any_in_window = false;
             for (uint64_t i = lo; i < hi; i++) {
@@ -963,7 +964,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                     const uint8_t* seq = ix->seqs[sq];
                     for (uint64_t i = 0; i < len; i++) h_refw[pad_w + ((c0 + i) >> 4)] |= (uint32_t)bronko::nt_to_bits(seq[i]) << (2 * ((c0 + i) & 15));
                     // long sequences in pieces (every piece re-reads the k - 1 bases before it)
-                    for (uint64_t a = 0; a + k <= len; a += 65536) jobs.push_back(SeqJob{seq + a, std::min<uint64_t>(len - a, 65536 + (uint64_t)k - 1), c0 + a});
+                    for (uint64_t a = 0; a + k <= len; a += 8192) jobs.push_back(SeqJob{seq + a, std::min<uint64_t>(len - a, 8192 + (uint64_t)k - 1), c0 + a});
                 }
             std::atomic<size_t> next_job{0};
             auto work = [&] {
@@ -1043,12 +1044,13 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         std::vector<uint8_t> h_no_list(h_u.size(), 0);    // by index: in a group too large to enumerate -- no near list
         {
             struct Form { uint64_t w; uint32_t id; uint32_t fi; };   // fi = 2 * (index into h_u) + (1: the reverse complement)
-            std::vector<Form> forms;
-            forms.reserve(h_u.size() * 2);
-            for (size_t i = 0; i < h_u.size(); i++) {
-                forms.push_back(Form{h_u[i], id_of[i], (uint32_t)(2 * i)});
-                forms.push_back(Form{bronko::reverse_complement_u64(h_u[i], k), id_of[i], (uint32_t)(2 * i + 1)});
-            }
+            std::vector<Form> forms(h_u.size() * 2);
+            parallel_for(h_u.size(), [&](size_t i0, size_t i1) {
+                for (size_t i = i0; i < i1; i++) {
+                    forms[2 * i] = Form{h_u[i], id_of[i], (uint32_t)(2 * i)};
+                    forms[2 * i + 1] = Form{bronko::reverse_complement_u64(h_u[i], k), id_of[i], (uint32_t)(2 * i + 1)};
+                }
+            });
             // collect: for every canonical form, the forms within `dist` of it (the near lists the dirty answers are worked out from)
             auto flag_within = [&](int dist, std::vector<uint8_t>& out, std::vector<std::vector<uint64_t>>* collect) {
                 const int parts = dist + 1;   // words at distance <= dist agree on at least one of dist + 1 parts
@@ -1806,8 +1808,9 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 }
             }
             // IdRec: k-mer, first cell, flags; "simple" = each of the W buckets holds the k-mer's own single occurrence and nothing else
-            std::vector<bk::IdRec> h_idrec(std::max<size_t>(h_u.size(), 1), bk::IdRec{bk::kEmptyKey, 0u, 0u});
-            for (size_t i = 0; i < h_u.size(); i++) {
+            HostVec<bk::IdRec> h_idrec = filled(std::max<size_t>(h_u.size(), 1), bk::IdRec{bk::kEmptyKey, 0u, 0u});
+            parallel_for(h_u.size(), [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; i++) {
                 const uint32_t id = id_of[i];
                 bk::IdRec r{h_u[i], first_cell[i] == kNone ? 0u : first_cell[i], (h_amb[id] ? bk::kIdDirty : 0u) | (first_rc[i] ? bk::kIdRc : 0u)};
                 if (id < e->n_full && first_cell[i] != kNone && e->W > 0) {
@@ -1823,6 +1826,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 if (id < h_own_mirror.size() && h_own_mirror[id]) r.flags |= bk::kIdOwnMirror;
                 h_idrec[id] = r;
             }
+            });
             BK_HIP(e->id_rec.upload(h_idrec));
         }
 
@@ -1834,11 +1838,17 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             // per id, independently: chunks on host threads, each with its own list, joined in id order
             const size_t n_ids = h_u.size();
             const unsigned nt = n_ids < 65536 ? 1u : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 256u);
-            std::vector<std::vector<uint32_t>> part(nt);
+            // (the reference k-mers -- ids below n_full, each with W buckets of ~70 BucketInfos -- and the pseudo k-mers -- twenty times as
+            // many, nearly nothing each -- are cut into nt chunks EACH: a thread takes one of either kind.  Cut as one range, the first
+            // twentieth of the threads did all the work.)
+            const size_t n_real = std::min<size_t>(e->n_full, n_ids);
+            auto cut = [&](unsigned c) -> size_t { return c <= nt ? n_real * c / nt : n_real + (n_ids - n_real) * (c - nt) / nt; };   // chunk c = [cut(c), cut(c + 1)), c < 2 nt
+            std::vector<std::vector<uint32_t>> part(2 * nt);
             std::vector<uint32_t> n_of(n_ids, 0u);
             auto work = [&](unsigned t) {
                 std::vector<uint32_t> hits(e->n_files, 0u), touched;
-                for (size_t id = n_ids * t / nt; id < n_ids * (t + 1) / nt; id++) {
+                for (unsigned c : {t, nt + t})
+                for (size_t id = cut(c); id < cut(c + 1); id++) {
                     touched.clear();
                     for (int w = 0; w < e->W; w++) {
                         const uint32_t sl = h_slot_of[id * e->W + w];
@@ -1848,7 +1858,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                         }
                     }
                     for (uint32_t file : touched) {
-                        part[t].push_back((file << 1) | (hits[file] == (uint32_t)e->W ? 1u : 0u));
+                        part[c].push_back((file << 1) | (hits[file] == (uint32_t)e->W ? 1u : 0u));
                         hits[file] = 0;
                     }
                     n_of[id] = (uint32_t)touched.size();
@@ -1862,7 +1872,9 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             h_estat.resize(h_estat_off[n_ids]);
             {   // the chunks' lists back to back (chunk t starts where its first id's list starts), copied side by side
                 std::vector<std::thread> cp;
-                for (unsigned t = 0; t < nt; t++) cp.emplace_back([&, t] { if (!part[t].empty()) std::copy(part[t].begin(), part[t].end(), h_estat.begin() + (ptrdiff_t)h_estat_off[n_ids * t / nt]); std::vector<uint32_t>().swap(part[t]); });
+                for (unsigned t = 0; t < nt; t++) cp.emplace_back([&, t] {
+                    for (unsigned c : {t, nt + t}) { if (!part[c].empty()) std::copy(part[c].begin(), part[c].end(), h_estat.begin() + (ptrdiff_t)h_estat_off[cut(c)]); std::vector<uint32_t>().swap(part[c]); }
+                });
                 for (auto& t : cp) t.join();
             }
         }

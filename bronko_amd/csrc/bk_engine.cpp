@@ -414,7 +414,8 @@ struct bk_engine {
     int max_seqs_per_file = 0;
     uint64_t max_file_cells = 0;
     uint64_t max_file_cells_idx = 0;        // cells of the genome file with the most (pileup rows)
-    DevBuf<double> call_noise;
+    DevBuf<double> call_noise, noise_maf, noise_tbl, noise_sums;   // (get_baseline_noise, the walk taken apart: CallArgs)
+    DevBuf<unsigned int> noise_cnt, noise_state;
     DevBuf<bk_call_record> call_records;
     DevBuf<bk_call_summary> call_out;
     DevBuf<bk_call_summary> sel_out;        // pileup_selected_only: the genome selected between the two finalize passes
@@ -2880,6 +2881,12 @@ int bk_sample_call(bk_engine* e, int n_mates, const bk_call_params* p) {
     const uint64_t cap = std::max<uint64_t>(3 * e->max_file_cells, 1);   // at most three alternative bases per position
     if (!e->call_out.p) {
         BK_HIP(e->call_noise.alloc((size_t)e->total_cells));
+        const size_t mc = std::max<uint64_t>(e->max_file_cells, 1);
+        BK_HIP(e->noise_maf.alloc(mc * 3));
+        BK_HIP(e->noise_tbl.alloc((mc + 64 * (size_t)std::max(e->max_seqs_per_file, 1) + 64) * 10));
+        BK_HIP(e->noise_state.alloc(mc));
+        BK_HIP(e->noise_sums.alloc(mc * 2));
+        BK_HIP(e->noise_cnt.alloc(mc));
         BK_HIP(e->call_records.alloc((size_t)cap));
         BK_HIP(e->call_out.alloc(1));
     }
@@ -2891,6 +2898,8 @@ int bk_sample_call(bk_engine* e, int n_mates, const bk_call_params* p) {
     a.ref_words = e->ref_words.p + bk::scan_ref_pad_words();
     a.pileup = e->pileup.p; a.plane = (size_t)e->total_cells * 4;
     a.noise = e->call_noise.p; a.records = e->call_records.p; a.record_cap = cap; a.out = e->call_out.p;
+    a.noise_maf = e->noise_maf.p; a.noise_tbl = e->noise_tbl.p; a.noise_sums = e->noise_sums.p; a.noise_cnt = e->noise_cnt.p; a.noise_state = e->noise_state.p;
+    if (const char* ns = test_env("BK_NOISE_SERIAL")) a.noise_serial = atoi(ns);
     bk_engine::Span sp(e, 1);
     bk::launch_call(a, e->max_seqs_per_file, e->max_file_cells, e->stream);
     BK_HIP(hipGetLastError());

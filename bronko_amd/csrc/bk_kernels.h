@@ -324,6 +324,14 @@ struct CallArgs {
     const unsigned long long* pileup;    // 4 planes of `plane` u64
     size_t plane;
     double* noise;                       // [total_cells] Noise.max per position
+    // get_baseline_noise with its two chains apart (bk_caller.hip): scratch of the selected genome -- [cells][3] sorted minor-allele
+    // frequencies, [cells][10] the table / [cells][2] s, s2 / [cells] n after each position's step; null: the walk in one wave
+    double* noise_maf;
+    double* noise_tbl;                   // [cells + 64 sequences][10]: per sequence the list of the table's states (state 0: empty; one more per step that changed it)
+    unsigned int* noise_state;           // [cells] the state after each position's step
+    double* noise_sums;
+    unsigned int* noise_cnt;
+    int noise_serial;                    // testing aid (BK_NOISE_SERIAL): the serial kernel for every sequence
     CallRecordDev* records;
     uint64_t record_cap;
     CallSummaryDev* out;

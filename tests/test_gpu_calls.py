@@ -73,6 +73,30 @@ def test_four_strains_paired_selection_and_calls(oracle, sars_paths):
     ix.close()
 
 
+def test_noise_walk_taken_apart_and_in_one_wave(oracle, golden_dir, sars_paths, monkeypatch, testing_lib):
+    """get_baseline_noise (call.rs:799-967) with its two chains in two waves (sums; table with the pass-by tests) + the strip per
+    position, and the walk in one wave as rounds 2-4 ran it (BK_NOISE_SERIAL, testing build): Noise.max bit for bit either way
+    (_compare), for HPV16 deep and shallow (stretches without coverage, few values per window, many equal frequencies) and a
+    SARS-CoV-2 sample."""
+    cases = []
+    ix = oracle.Index.load(os.path.join(golden_dir, "hpv.bkdb"))
+    cases.append((ix, [helpers.hpv_reads(60000, seed=3)]))
+    cases.append((ix, [helpers.hpv_reads(1500, seed=4, err=0.03)]))
+    cases.append((ix, [helpers.hpv_reads(300, seed=5, err=0.05)]))
+    ix2 = oracle.Index.build(21, [sars_paths[0]])
+    gm, isnv = synth.sample_genome(synth.read_fasta_bytes(sars_paths[0]), 41)
+    cases.append((ix2, [synth.codes_to_ascii(synth.single_end_codes(gm, 200000, 150, 41, isnv=isnv))]))
+    for serial in (False, True):
+        if serial:
+            monkeypatch.setenv("BK_NOISE_SERIAL", "1")
+        for cix, mates in cases:
+            eng = helpers.engine_from_oracle_index(cix)
+            _compare(oracle, cix, eng, mates, 21, min_depth=10, min_af=0.01)
+            eng.close()
+    ix.close()
+    ix2.close()
+
+
 def test_no_reads_no_genome(oracle, golden_dir):
     ix = oracle.Index.load(os.path.join(golden_dir, "hpv.bkdb"))
     eng = helpers.engine_from_oracle_index(ix)

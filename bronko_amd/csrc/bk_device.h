@@ -65,6 +65,11 @@ constexpr uint32_t kAnsNone = 16u, kAnsMulti = 32u;
 // complemented), bit 2 = clean (cell_yf bit 0), bit 3 = cell_clean3, bit 4 = the cell stands in the orientation of its k-mer's
 // first occurrence (the coordinates the answer table is laid out in)
 constexpr uint32_t kCellClean = 4u, kCellClean3 = 8u, kCellFirstOri = 16u;
+// bit 5 (round 5): no other reference k-mer form at Hamming distance exactly 2 or 3 from the cell's k-mer (forms one base away are
+// allowed -- the other strains' variants of a few-genome index).  A read k-mer x with two differences from such a u can only equal or
+// neighbour a form within distance 3 of u, i.e. one base from u, i.e. "u with one of x's two differences": two answer-table loads
+// settle it (neither is a reference k-mer: x touches nothing) where the slow path took a membership test and two directory walks.
+constexpr uint32_t kCellIso23 = 32u;
 // The answer table (DirtyAns) in reference coordinates of the k-mer's first occurrence: offset o of the changed base from the
 // k-mer's start along the reference, base b on the forward strand.  Laid out by diagonal, [id + o][b][o]: the k-mers of a read
 // that cover one sequencing error have consecutive ids and falling offsets -- their answers are neighbours in memory (8 bytes

@@ -1040,6 +1040,9 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         // amb3: the same with distance 3 (four parts); lets Level 2 discard k-mers with two differences on the spot.  The
         // groups grow with |U| (a quarter of a k-mer distinguishes little): above kAmb3MaxKmers everything is flagged.
         std::vector<uint8_t> h_amb3(h_u.size(), 0);
+        // far23: another reference k-mer form at distance 2 or 3 (forms one base away do not count): where there is none, a read k-mer
+        // two bases from u can only equal or neighbour the two k-mers "u with one of its two differences" (Level 2, kCellIso23)
+        std::vector<uint8_t> h_far23(h_u.size(), 0);
         constexpr size_t kAmb3MaxKmers = 300000;
         std::vector<uint64_t> h_near;                     // (canonical form's index << 32 | near form), sorted: the near lists
         std::vector<uint8_t> h_no_list(h_u.size(), 0);    // by index: in a group too large to enumerate -- no near list
@@ -1053,6 +1056,8 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 }
             });
             // collect: for every canonical form, the forms within `dist` of it (the near lists the dirty answers are worked out from)
+            // out_far (optional): the same for pairs at distance 2 or more only -- what kCellIso23 is made of (bk_device.h)
+            std::vector<uint8_t>* out_far = nullptr;
             auto flag_within = [&](int dist, std::vector<uint8_t>& out, std::vector<std::vector<uint64_t>>* collect) {
                 const int parts = dist + 1;   // words at distance <= dist agree on at least one of dist + 1 parts
                 if (collect) collect->assign(parts, {});
@@ -1095,7 +1100,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                             size_t a1 = a0 + 1;
                             while (a1 < hi && (fs[a1].w & mask) == (fs[a0].w & mask)) a1++;
                             if (a1 - a0 > 4096) {   // pathological low-complexity group: flag all, skip the quadratic pass
-                                for (size_t x = a0; x < a1; x++) { out[fs[x].id] = 1; if (near) h_no_list[fs[x].fi >> 1] = 1; }
+                                for (size_t x = a0; x < a1; x++) { out[fs[x].id] = 1; if (out_far) (*out_far)[fs[x].id] = 1; if (near) h_no_list[fs[x].fi >> 1] = 1; }
                             } else {
                                 // (pseudo k-mers -- 95 % of U with a hundred strains at k = 31 -- are flagged dirty whatever their neighbours
                                 // and own no near list: a pair of two of them says nothing, and only a reference k-mer's list is kept)
@@ -1105,8 +1110,10 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                                         const bool py = h_is_pseudo[fs[y].fi >> 1] != 0;
                                         if (px && py) continue;
                                         const uint64_t d = fs[x].w ^ fs[y].w;
-                                        if (__builtin_popcountll((d | (d >> 1)) & 0x5555555555555555ull) <= dist) {
+                                        const int nd = __builtin_popcountll((d | (d >> 1)) & 0x5555555555555555ull);
+                                        if (nd <= dist) {
                                             out[fs[x].id] = out[fs[y].id] = 1;   // also catches u vs rc(u) (same id)
+                                            if (out_far && nd >= 2) (*out_far)[fs[x].id] = (*out_far)[fs[y].id] = 1;
                                             if (near) {   // (owner canonical form << 32) | the other form
                                                 if (!(fs[x].fi & 1u) && !px) out_near.push_back(((uint64_t)(fs[x].fi >> 1) << 32) | fs[y].fi);
                                                 if (!(fs[y].fi & 1u) && !py) out_near.push_back(((uint64_t)(fs[y].fi >> 1) << 32) | fs[x].fi);
@@ -1131,8 +1138,8 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             std::vector<std::vector<uint64_t>> near_parts;
             flag_within(2, h_amb, &near_parts);
             pc.lap("  dirty: distance 2");
-            if (h_u.size() <= kAmb3MaxKmers) flag_within(3, h_amb3, nullptr);
-            else std::fill(h_amb3.begin(), h_amb3.end(), (uint8_t)1);
+            if (h_u.size() <= kAmb3MaxKmers) { out_far = &h_far23; flag_within(3, h_amb3, nullptr); out_far = nullptr; }
+            else { std::fill(h_amb3.begin(), h_amb3.end(), (uint8_t)1); std::fill(h_far23.begin(), h_far23.end(), (uint8_t)1); }
             pc.lap("  dirty: distance 3");
             size_t tot = 0;
             for (auto& v : near_parts) tot += v.size();
@@ -1154,7 +1161,8 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             pc.lap("  dirty: near lists sorted");
             h_near.erase(std::unique(h_near.begin(), h_near.end()), h_near.end());
         }
-        for (size_t i = 0; i < h_u.size(); i++) if (h_is_pseudo[i]) h_amb3[id_of[i]] = 1;
+        for (size_t i = 0; i < h_u.size(); i++) if (h_is_pseudo[i]) { h_amb3[id_of[i]] = 1; h_far23[id_of[i]] = 1; }
+        if (test_env("BK_NO_ISO23")) std::fill(h_far23.begin(), h_far23.end(), (uint8_t)1);
         for (size_t i = 0; i < h_u.size(); i++) if (h_is_pseudo[i]) h_amb[id_of[i]] = 1;
         pc.lap("dirty flags (dist 2, 3)");
         std::vector<uint8_t> rc_of_id(h_u.size(), 0);   // the k-mer's first occurrence was reverse-complemented to become canonical
@@ -1179,7 +1187,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
             if (clean) h_clean[bpad_w + (c >> 5)] |= 1u << (c & 31);
             else h_needs_ans[h_id_at[c]] = 1;
             h_cflags[c] = (uint8_t)((rc_here ? 2u : 1u) | (clean ? bk::kCellClean : 0u) | (h_amb3[h_id_at[c]] ? 0u : bk::kCellClean3) |
-                                    (rc_here == rc_of_id[h_id_at[c]] ? bk::kCellFirstOri : 0u));
+                                    (rc_here == rc_of_id[h_id_at[c]] ? bk::kCellFirstOri : 0u) | (h_far23[h_id_at[c]] ? 0u : bk::kCellIso23));
             if (!h_amb3[h_id_at[c]]) h_clean3[bpad_w + (c >> 5)] |= 1u << (c & 31);
             h_yf[wi] |= (clean | (from_prev ? 2u : 0u)) << sh;
             h_yr[wi] |= (clean | (to_next ? 2u : 0u)) << sh;
@@ -2482,9 +2490,15 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
     const bool gather = e->gather_mode && elem_lo == 0 && elem_hi == e->plane_len && !via_reduced;
     if (gather) BK_HIP(hipMemsetAsync(e->n_alias_hits.p, 0, 2 * sizeof(unsigned int), e->stream));
     for (int pass = 0; pass < ((two_pass || gather) ? 2 : 1); pass++) {
+        auto dbg_sync = [&](const char* what) -> int {   // testing build, BK_SYNC_DEBUG: which launch of the gathered voting pass faults
+            if (test_env("BK_SYNC_DEBUG")) { fprintf(stderr, "[bk] %s ...", what); BK_HIP(hipStreamSynchronize(e->stream)); fprintf(stderr, " ok\n"); }
+            return BK_OK;
+        };
         if (gather && pass == 1) {   // difference arrays -> counts (the rows are zeroed behind the sample)
             bk_engine::Span sp(e, 1);
+            if (int rc = dbg_sync("statistics pass")) return rc;
             for (int m = 0; m < n_mates; m++) bk::launch_prefix_rows(e->counters[m].p, e->view(), e->v_list[m].p, e->n_list[m].p, e->stream);
+            if (int rc = dbg_sync("prefix_rows")) return rc;
         }
         for (int m = 0; m < n_mates; m++) {   // R1 then R2 into the same arrays (call.rs:316-317)
             bk::FinalizeArgs a{};
@@ -2535,9 +2549,10 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
                 else { a.f_items = nullptr; if (int rc = flush_pending_items(e)) return rc; }
             }
             bk_engine::Span sp(e, 1);
-            if (gather && pass == 1 && m == 0) bk::launch_gather_votes(a, n_mates == 2 ? e->counters[1].p : nullptr, e->stream);   // (both mate files' counts at once: it stores)
-            if (gather && pass == 1 && e->n_merged_slots) bk::launch_merged_votes(a, e->stream);
+            if (gather && pass == 1 && m == 0) { bk::launch_gather_votes(a, n_mates == 2 ? e->counters[1].p : nullptr, e->stream); if (int rc = dbg_sync("gather_votes")) return rc; }   // (both mate files' counts at once: it stores)
+            if (gather && pass == 1 && e->n_merged_slots) { bk::launch_merged_votes(a, e->stream); if (int rc = dbg_sync("merged_votes")) return rc; }
             bk::launch_finalize(a, e->stream);
+            if (gather && pass == 1) if (int rc = dbg_sync("alias-only general kernels")) return rc;
         }
         if (two_pass && pass == 0) {
             bk::CallArgs c{};

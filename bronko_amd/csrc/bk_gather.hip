@@ -94,6 +94,14 @@ __device__ __forceinline__ uint32_t voter_counters(const IndexView& ix, uint32_t
     return ans.y & 3u;
 }
 
+// the counter of voter_counters()' answer for read orientation isrc, as an index into a mate file's plane -- selects, one load behind
+// them: as three loads in the arms of an if / else-if / else, hipcc 7.2 left the address of the third arm's second orientation
+// undefined when all lanes of a wave took it (the k = 31 fuzz case profiles/r05_fuzz.txt names; a memory fault)
+__device__ __forceinline__ uint64_t counter_index(uint32_t kind, uint64_t at, uint32_t rcu, uint32_t isrc, uint64_t v_off, uint32_t rl) {
+    const uint64_t in_row = kind == 2u ? ((((isrc ^ rcu) & 1u) != 0u) ? (uint64_t)rl : 0ull) : (uint64_t)isrc;
+    return (kind == 1u ? 0ull : v_off) + at + in_row;
+}
+
 // WIDE: counts are capped above 2^32 (bk_params.cs; KMC's default is 10^6): the maxima need 64 bits -- a compare-and-swap loop in
 // LDS, which the W lanes of a position fight over (7.4 ms for 0.9 M cells where the 32-bit form, one ds_max_u32 each, takes a tenth)
 template <bool WIDE>
@@ -145,10 +153,7 @@ __global__ __launch_bounds__(kGatherBlock) void gather_votes_kernel(FinalizeArgs
                 const unsigned long long* const pl = planes[m];
 #pragma unroll
                 for (uint32_t isrc = 0; isrc < 2u; ++isrc) {
-                    unsigned long long n;
-                    if (kind == 1u) n = pl[at + isrc];
-                    else if (kind == 2u) n = pl[v_off + at + (((isrc ^ rcu) & 1u) ? rl : 0u)];
-                    else n = pl[v_off + at + isrc];
+                    const unsigned long long n = pl[counter_index(kind, at, rcu, isrc, v_off, rl)];
                     if (n == 0ull || n < a.ci || n > a.cx) continue;     // kmc -ci / -cx act on the true count
                     const unsigned long long v = n > a.cs ? a.cs : n;   // kmc -cs: reported count saturates
                     const bool forward = canon ? isrc != 0u : isrc == 0u;
@@ -229,10 +234,7 @@ __global__ __launch_bounds__(64) void merged_votes_kernel(FinalizeArgs a) {
             const uint32_t kind = voter_counters(ix, rep_id, idr.w, u, ur, j, b, z, at, rcu);
             if (kind == 0u) continue;
             for (uint32_t isrc = 0; isrc < 2u; ++isrc) {
-                unsigned long long n;
-                if (kind == 1u) n = a.counters[at + isrc];
-                else if (kind == 2u) n = a.counters[ix.v_off + at + (((isrc ^ rcu) & 1u) ? rl : 0u)];
-                else n = a.counters[ix.v_off + at + isrc];
+                const unsigned long long n = a.counters[counter_index(kind, at, rcu, isrc, ix.v_off, rl)];
                 if (n == 0ull || n < a.ci || n > a.cx) continue;
                 const unsigned long long v = n > a.cs ? a.cs : n;
                 for (uint32_t q = lane; q < cnt; q += 64u) {

@@ -1494,6 +1494,27 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
                     BK_DBG(a, 16, true, 1);
                 }
             }
+        } else if (has && n_diff == 2u && !(fl & kCellClean3) && (fl & kCellIso23) && answers && !STATS && ix.n_u == ix.n_full) {
+            // (no pseudo k-mers -- k = 31 --: they are stored as they come, not canonical, and the answer table's "is a reference
+            // k-mer" goes by the stored value: "u with one difference" can BE a pseudo k-mer's other strand and not say so)
+            // two differences from a reference k-mer u that has no other form at distance 2 or 3 (kCellIso23): the read k-mer can only
+            // equal or neighbour "u with one of the two differences".  If the answer table says neither of those two is a reference
+            // k-mer, it touches nothing; if one is, the slow path sorts it out (rare: it is that k-mer's neighbour).
+            const bool first_ori = (fl & kCellFirstOri) != 0u;
+            bool member = false, none = false;
+            uint64_t dleft = dbits;
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const uint32_t t = (uint32_t)__builtin_ctzll(dleft) >> 1;
+                dleft &= dleft - 1ull;
+                const uint32_t br = (uint32_t)(g >> (2u * t)) & 3u;
+                const uint32_t o = fwd ? t : km1 - t;
+                const uint32_t bfw = fwd ? br : 3u - br;
+                const uint2 ans = *reinterpret_cast<const uint2*>(answers + ans_index(id, first_ori ? o : km1 - o, first_ori ? bfw : 3u - bfw, k));
+                none |= (ans.y & kAnsNone) != 0u;
+                member |= (ans.y & 3u) == 1u;
+            }
+            if (!none && !member) { slow = false; BK_DBG(a, 6, true, 1); }
         } else if (has && n_diff == 2u && (fl & kCellClean3)) {
             // two differences from a reference k-mer that has no other reference k-mer form within distance 3: neither a
             // reference k-mer nor one base away from one (triangle inequality) -- it touches nothing

@@ -4,13 +4,18 @@
 //                     bases at a time, one mismatch per lane, E runs / S runs / marks for nbatch_kernel and level2_kernel -- but
 //                     what that kernel ADDS (two LDS atomics per E run into a whole-genome difference array that pins one
 //                     workgroup to a CU; two global atomics per S run into the V plane) this one EMITS as 16-bit items into small
-//                     per-bin buckets in LDS (bk_kernels.h ItemGeom).  No 117 KB array: three workgroups of eight waves per CU
-//                     instead of one of sixteen, no slab, no prefix sum over the genome, no hot-counter table.
+//                     per-bin buckets in LDS (bk_kernels.h ItemGeom).  No 117 KB array, no slab, no prefix sum over the genome, no
+//                     hot-counter table.  One workgroup of sixteen waves per CU (kItemBlock = 1024): the window's reference, its
+//                     reverse complement and the flag arrays are staged once per CU, the bucket area (45 KB) is one, and the kernel
+//                     allocates all 128 VGPRs so that nothing shares its CU (three workgroups of eight waves were slower: smaller
+//                     sets of buckets overflow earlier).
 // bin_count_kernel    one workgroup per bin: the bin's items of every scan workgroup (+ the overflow list) added up in LDS -- an E
 //                     bin in two 384-cell difference arrays (reads along / against the reference), a V bin in the bin's counters --
 //                     and what is not zero added to the u64 plane: E[2 id_at[cell] + orientation] as fold_kernel did, V counters
 //                     one atomic each, neighbouring counters by neighbouring lanes.  Every count of a sample still lands on the
 //                     same counter of the same plane as before: nbatch / level2 / finalize / the sharded transport are untouched.
+//                     BinArgs::part: every bin, the E bins only (a mate file's first launch: its V items wait for the regional
+//                     finalize, bk_finalize_lean.hip FinalizeArgs::f_items) or the V bins only (they go to the plane after all).
 // Replaces call.rs:1152-1255 (what KMC does: bin, then count) for the k-mers of reads on the window genome; SURVEY.md 7.2 K1.
 #include <hip/hip_runtime.h>
 

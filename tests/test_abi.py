@@ -39,7 +39,8 @@ def test_release_library_reads_no_environment_variable():
     """The BK_* testing / measurement aids are compiled into libbronko_hip_testing.so only."""
     rel = open(_ffi.LIB_PATH, "rb").read()
     tst = open(_ffi.TESTING_LIB_PATH, "rb").read()
-    for name in (b"BK_SCAN_ABLATE", b"BK_LDS_BINS", b"BK_REF_IN_LDS", b"BK_WINDOW_FILE", b"BK_MAX_LAUNCH_RECORDS", b"BK_L2_COUNT"):
+    for name in (b"BK_SCAN_ABLATE", b"BK_LDS_BINS", b"BK_REF_IN_LDS", b"BK_WINDOW_FILE", b"BK_MAX_LAUNCH_RECORDS", b"BK_L2_COUNT", b"BK_NO_FUSE", b"BK_NO_GATHER",
+                 b"BK_NOISE_SERIAL", b"BK_ITEM_CAPS", b"BK_GATHER_ABLATE"):
         assert name not in rel, name
         assert name in tst, name
 

@@ -394,8 +394,6 @@ struct bk_engine {
     hipStream_t copy_stream = nullptr;
 
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipStream_t scan_stream = nullptr;      // (BK_CU_SPLIT)
-    hipEvent_t ev_scan[2] = {nullptr, nullptr};
     bool in_sample = false;
     int finalized_mates = 0;                // mate files of the sample whose finalize was enqueued last (0: none since bk_sample_begin / create)
     uint64_t pushed_records[2] = {0, 0};
@@ -553,18 +551,7 @@ static int alloc_sample_state(bk_engine* e) {
             BK_HIP(e->fuse_touch[m].alloc(((size_t)e->n_full + (size_t)e->v_span + 63) / 64 * 12 + 16));
             BK_HIP(hipMemset(e->fuse_touch[m].p, 0, e->fuse_touch[m].n * sizeof(unsigned int)));
         }
-    if (const char* cs = getenv("BK_CU_SPLIT")) {   // experiment: the scan on its own CUs, everything else on the rest
-        const int n_scan = atoi(cs), n_cus = e->n_cus;
-        if (n_scan > 0 && n_scan < n_cus) {
-            std::vector<uint32_t> ms((n_cus + 31) / 32, 0u), mr((n_cus + 31) / 32, 0u);
-            for (int c = 0; c < n_cus; c++) (c < n_scan ? ms : mr)[c >> 5] |= 1u << (c & 31);
-            BK_HIP(hipExtStreamCreateWithCUMask(&e->scan_stream, (uint32_t)ms.size(), ms.data()));
-            if (!getenv("BK_CU_SPLIT_SCAN_ONLY")) BK_HIP(hipExtStreamCreateWithCUMask(&e->own_stream, (uint32_t)mr.size(), mr.data()));
-            BK_HIP(hipEventCreateWithFlags(&e->ev_scan[0], hipEventDisableTiming));
-            BK_HIP(hipEventCreateWithFlags(&e->ev_scan[1], hipEventDisableTiming));
-        }
-    }
-    if (!e->own_stream) BK_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    BK_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
     return BK_OK;
 }
@@ -2239,18 +2226,11 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
             // flight three quarters of the CUs scan and the rest keep those chains moving (config 2, three samples in flight: 8.35
             // -> 9.06 G reads/s; one sample alone is 4% slower that way and keeps the whole chip).
             grid = bk::items_grid(take, e->family->load() > 1 ? e->n_cus - e->n_cus / 4 : e->n_cus);
-            if (e->scan_stream) grid = bk::items_grid(take, (uint32_t)atoi(getenv("BK_CU_SPLIT")));
             if (const char* gr = test_env("BK_ITEM_GRID")) grid = std::max<uint32_t>(1, std::min<uint32_t>(grid, (uint32_t)atoi(gr)));
         }
         {
             bk_engine::Span sp(e, 0);
-            if (e->use_items) {
-                a.ov_par = e->ov_par;
-                hipStream_t ss = e->stream;
-                if (e->scan_stream) { BK_HIP(hipEventRecord(e->ev_scan[0], e->stream)); BK_HIP(hipStreamWaitEvent(e->scan_stream, e->ev_scan[0], 0)); ss = e->scan_stream; }
-                BK_HIP(bk::launch_scan_items(a, grid, ss));
-                if (ss != e->stream) { BK_HIP(hipEventRecord(e->ev_scan[1], ss)); BK_HIP(hipStreamWaitEvent(e->stream, e->ev_scan[1], 0)); }
-            }
+            if (e->use_items) { a.ov_par = e->ov_par; BK_HIP(bk::launch_scan_items(a, grid, e->stream)); }
             else BK_HIP(bk::launch_scan_count(a, grid, e->stream));
         }
         if (e->use_items) {

@@ -341,11 +341,13 @@ struct BatchQueue {
         return b;
     }
 };
+// threads a FASTQ file's inflate may take (pargz.hpp): -t over the files that are read at the same time (set by call)
+unsigned g_inflate_threads = 1;
 void parse_fastq(const std::string& path, BatchQueue& out) {
     constexpr uint64_t kBatchReads = 1u << 16;   // (10 MB of bases: the engine pins three staging slots of that size per lane)
     FastqBatch cur;
     try {
-        GzLineReader in(path);
+        GzLineReader in(path, g_inflate_threads);
         uint64_t n = 0;
         for (uint64_t ln = 0;; ln++) {               // 4-line FASTQ records: @id / sequence / + / quality
             if ((ln & 3) != 1) { if (!in.skip_next()) break; continue; }
@@ -661,6 +663,14 @@ int run_call(const Args& a) {
         for (auto& t : th) t.join();
     }
 
+    {
+        // KMC reads a sample's files with all of -t (call.rs:1166-1181); here -t is shared by the files that are open at once: the
+        // lanes' samples (one being read per lane) times their mate files
+        const size_t open_files = std::max<size_t>(1, lanes.size()) * (a.first_pairs.empty() ? 1 : 2);
+        g_inflate_threads = (unsigned)std::max<size_t>(1, std::min<size_t>(64, (size_t)a.threads / open_files));
+        if (const char* it = getenv("BRONKO_INFLATE_THREADS")) g_inflate_threads = (unsigned)std::max(1, atoi(it));
+        if (g_inflate_threads > 1) LOG_INFO(T, "gzip input is inflated on " + std::to_string(g_inflate_threads) + " threads per file");
+    }
     CallParams cp;
     cp.k = (int)a.kmer; cp.min_af = a.min_af; cp.no_end_filter = a.no_end_filter; cp.no_strand_filter = a.no_strand_filter;
     cp.no_strand_balance_filter = a.no_strand_balance_filter; cp.strand_balance_ratio = a.balance_ratio;

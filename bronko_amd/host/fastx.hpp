@@ -1,17 +1,22 @@
-// fastx.hpp -- line reader over plain or gzip files (zlib) for FASTA / FASTQ input (host side).
+// fastx.hpp -- line reader over plain or gzip files for FASTA / FASTQ input (host side): zlib's gzread, or with more than one
+// thread to spend on the file pargz.hpp's inflate on several threads (the same bytes and errors).
 #pragma once
 #include <zlib.h>
 
 #include <cstring>
 
+#include <memory>
 #include <stdexcept>
 #include <string>
+
+#include "pargz.hpp"
 
 namespace bronko {
 
 class GzLineReader {
 public:
-    explicit GzLineReader(const std::string& path) : path_(path) {
+    explicit GzLineReader(const std::string& path, unsigned inflate_threads = 1) : path_(path) {
+        if (inflate_threads > 1 && ParallelGunzip::is_gzip(path)) { par_.reset(new ParallelGunzip(path, inflate_threads)); return; }
         g_ = gzopen(path.c_str(), "rb");
         if (!g_) throw std::runtime_error("cannot open " + path);
         gzbuffer(g_, 1 << 20);
@@ -26,10 +31,9 @@ public:
         bool any = false;
         for (;;) {
             if (pos_ == len_) {
-                const int n = gzread(g_, buf_, sizeof buf_);
-                if (n < 0) throw std::runtime_error("read error in " + path_);
+                const size_t n = fill();
                 if (n == 0) break;
-                pos_ = 0; len_ = (size_t)n;
+                pos_ = 0; len_ = n;
             }
             any = true;
             const char* p = buf_ + pos_;
@@ -53,15 +57,20 @@ public:
     bool skip_next() { return scan(nullptr); }
 
 private:
+    size_t fill() {
+        if (par_) return par_->read(buf_, sizeof buf_);
+        const int n = gzread(g_, buf_, sizeof buf_);
+        if (n < 0) throw std::runtime_error("read error in " + path_);
+        return (size_t)n;
+    }
     bool scan(std::string* dst) {
         bool any = false;
         const size_t start = dst ? dst->size() : 0;
         for (;;) {
             if (pos_ == len_) {
-                const int n = gzread(g_, buf_, sizeof buf_);
-                if (n < 0) throw std::runtime_error("read error in " + path_);
+                const size_t n = fill();
                 if (n == 0) break;
-                pos_ = 0; len_ = (size_t)n;
+                pos_ = 0; len_ = n;
             }
             any = true;
             const char* p = buf_ + pos_;
@@ -81,6 +90,7 @@ private:
 
     std::string path_;
     gzFile g_ = nullptr;
+    std::unique_ptr<ParallelGunzip> par_;
     char buf_[1 << 16];
     size_t pos_ = 0, len_ = 0;
 };

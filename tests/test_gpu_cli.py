@@ -271,3 +271,29 @@ def test_call_one_sample_sharded_through_rccl(oracle, golden_dir, sars_paths, tm
     for ext in (".vcf", ".tsv"):
         assert open(os.path.join(out, stem + ext), "rb").read() == open(os.path.join(odir, stem + ext), "rb").read(), ext
     ix.close()
+
+
+def test_call_reads_inflated_on_several_threads(golden_dir, tmp_path):
+    """`-t 16` for one paired sample gives each of the two files eight inflate threads (bronko_amd/host/pargz.hpp; KMC reads the
+    reference's input with -t threads, call.rs:1166-1181): every output file is the one the single-thread reader produces."""
+    g = synth.read_fasta_bytes(os.path.join(golden_dir, "HPV16.fa"))
+    gm, isnv = synth.sample_genome(g, 4, n_snp=6, n_isnv=6)
+    c1, c2 = synth.paired_codes(gm, 60000, 150, 4, isnv=isnv)
+    r1, r2 = synth.codes_to_ascii(c1), synth.codes_to_ascii(c2)
+    p1, p2 = str(tmp_path / "s_R1.fastq.gz"), str(tmp_path / "s_R2.fastq.gz")
+    rng = np.random.default_rng(4)
+    for p, rs, tag in ((p1, r1, "a"), (p2, r2, "b")):
+        with gzip.open(p, "wb", compresslevel=6) as f:
+            for i, r in enumerate(rs):
+                f.write(b"@%s_%d\n%s\n+\n%s\n" % (tag.encode(), i, r, (rng.integers(0, 8, len(r)) * 5 + 35).astype(np.uint8).tobytes()))
+    outs = []
+    for name, env in (("one", {"BRONKO_INFLATE_THREADS": "1"}), ("many", {})):
+        out = str(tmp_path / name)
+        res = subprocess.run([BRONKO, "call", "-d", os.path.join(golden_dir, "hpv.bkdb"), "-1", p1, "-2", p2, "--pileup", "-o", out, "-t", "16"],
+                             capture_output=True, text=True, env={**os.environ, **env})
+        assert res.returncode == 0, res.stdout + res.stderr
+        assert ("inflated on 8 threads" in res.stdout + res.stderr) == (name == "many")
+        outs.append({f: open(os.path.join(out, f), "rb").read() for f in sorted(os.listdir(out))})
+    assert outs[0].keys() == outs[1].keys() and len(outs[0]) >= 3
+    for f in outs[0]:
+        assert outs[0][f] == outs[1][f], f

@@ -1,0 +1,172 @@
+"""bronko_amd/host/pargz.hpp (one gzip file inflated on several threads -- how `bronko call` reads a sample when it has threads to
+spare; the reference hands its FASTQ files to KMC with -t threads, /root/reference/src/call.rs:1166-1181): the same bytes as
+Python's gzip module / zlib for every kind of member and block there is, and an error where gzread has one."""
+import gzip
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CAT = os.path.join(ROOT, "bronko_amd", "bin", "pargz_cat")
+
+
+@pytest.fixture(scope="module")
+def cat():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bronko_amd", "host"), "../bin/pargz_cat"])
+    return CAT
+
+
+def fastq_text(n_reads, seed, read_len=150):
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, 20000)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = []
+    for i in range(n_reads):
+        a = int(rng.integers(0, len(g) - read_len))
+        s = acgt[g[a:a + read_len]].copy()
+        e = rng.random(read_len) < 0.01
+        s[e] = acgt[rng.integers(0, 4, int(e.sum()))]
+        q = (rng.integers(0, 8, read_len) * 5 + 35).astype(np.uint8)
+        out.append(b"@read%d/1 lane:%d\n" % (i, i % 7) + s.tobytes() + b"\n+\n" + q.tobytes() + b"\n")
+    return b"".join(out)
+
+
+def run(cat, path, threads, chunk=0):
+    r = subprocess.run([cat, path, str(threads)] + ([str(chunk)] if chunk else []), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return r.returncode, r.stdout, r.stderr.decode()
+
+
+def bgzf(data, level=6):
+    """What bgzip writes: members of <= 64 KB with their size in an extra field, and an empty last member"""
+    out = []
+    for i in range(0, len(data), 65280):
+        blk = data[i:i + 65280]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        c = co.compress(blk) + co.flush()
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(c) + 25) + c + struct.pack("<II", zlib.crc32(blk), len(blk)))
+    out.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return b"".join(out)
+
+
+TEXT = None
+
+
+def text():
+    global TEXT
+    if TEXT is None:
+        TEXT = fastq_text(40000, 7)   # 13 MB of FASTQ
+    return TEXT
+
+
+@pytest.mark.parametrize("level", [1, 4, 6, 9])
+def test_one_member_every_level_and_thread_count(cat, tmp_path, level):
+    t = text()
+    p = str(tmp_path / "a.fastq.gz")
+    open(p, "wb").write(gzip.compress(t, level))
+    for threads, chunk in [(1, 0), (2, 0), (8, 0), (8, 70000), (5, 333333), (16, 20000)]:
+        rc, out, err = run(cat, p, threads, chunk)
+        assert rc == 0, err
+        assert out == t, (level, threads, chunk)
+
+
+def test_members_one_after_the_other_and_bytes_behind_the_last(cat, tmp_path):
+    t = text()
+    cuts = [0, 1, 300000, 300001, 4000000, 9000000, len(t)]
+    data = b"".join(gzip.compress(t[a:b], 6) for a, b in zip(cuts[:-1], cuts[1:]))
+    p = str(tmp_path / "m.fastq.gz")
+    open(p, "wb").write(data + b"\0" * 77)   # (gzread ignores what is behind the last member)
+    for threads, chunk in [(1, 0), (8, 0), (8, 50000), (3, 1 << 20)]:
+        rc, out, err = run(cat, p, threads, chunk)
+        assert rc == 0, err
+        assert out == t
+    # a member with a name, a comment and a header CRC
+    hdr = b"\x1f\x8b\x08\x1a\0\0\0\0\0\x03" + b"name.fastq\0" + b"a comment\0"
+    hdr += struct.pack("<H", zlib.crc32(hdr) & 0xffff)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = co.compress(t) + co.flush()
+    open(p, "wb").write(hdr + body + struct.pack("<II", zlib.crc32(t), len(t) & 0xffffffff))
+    assert gzip.decompress(open(p, "rb").read()) == t
+    rc, out, err = run(cat, p, 8, 100000)
+    assert rc == 0 and out == t, err
+
+
+def test_stored_fixed_and_empty(cat, tmp_path):
+    t = text()[:3000000]
+    p = str(tmp_path / "x.gz")
+    cases = [gzip.compress(t, 0),                       # stored blocks only: nothing to enter at, one thread decodes
+             gzip.compress(b"@r\nACGT\n+\nIIII\n", 9),   # a fixed-code block
+             gzip.compress(b"", 9), b""]                  # an empty text, an empty file
+    wants = [t, b"@r\nACGT\n+\nIIII\n", b"", b""]
+    # stored, dynamic and fixed blocks mixed in one stream (Z_FULL_FLUSH puts an empty stored block between them)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    mixed = b""
+    for i in range(0, len(t), 250000):
+        mixed += co.compress(t[i:i + 250000]) + co.flush(zlib.Z_FULL_FLUSH if (i // 250000) % 2 else zlib.Z_SYNC_FLUSH)
+    mixed += co.flush()
+    cases.append(mixed); wants.append(t)
+    for data, want in zip(cases, wants):
+        open(p, "wb").write(data)
+        for threads, chunk in [(1, 0), (8, 0), (8, 40000)]:
+            rc, out, err = run(cat, p, threads, chunk)
+            assert rc == 0, err
+            assert out == want
+
+
+def test_text_that_is_no_text_and_text_that_repeats(cat, tmp_path):
+    rng = np.random.default_rng(3)
+    p = str(tmp_path / "b.gz")
+    # bytes of every value: no block passes the test of a boundary, the stream decodes from its start
+    noisy = rng.integers(0, 256, 3000000, dtype=np.uint8).tobytes() + bytes(2000000)
+    # long runs and copies from exactly 32 KB back
+    unit = fastq_text(100, 5)[:32768]
+    rep = unit * 200 + b"A" * 1000000 + unit * 50
+    for t in (noisy, rep):
+        open(p, "wb").write(gzip.compress(t, 6))
+        for threads, chunk in [(1, 0), (8, 0), (8, 30000)]:
+            rc, out, err = run(cat, p, threads, chunk)
+            assert rc == 0, err
+            assert out == t
+
+
+def test_bgzf_members(cat, tmp_path):
+    t = text()
+    p = str(tmp_path / "b.fastq.gz")
+    open(p, "wb").write(bgzf(t))
+    assert gzip.decompress(open(p, "rb").read()) == t
+    for threads in (1, 8):
+        rc, out, err = run(cat, p, threads)
+        assert rc == 0, err
+        assert out == t
+    # BGZF members first, an ordinary member behind them
+    open(p, "wb").write(bgzf(t[:5000000])[:-28] + gzip.compress(t[5000000:], 6))
+    rc, out, err = run(cat, p, 8, 200000)
+    assert rc == 0 and out == t, err
+
+
+def test_damage_is_an_error(cat, tmp_path):
+    t = text()
+    good = gzip.compress(t, 6)
+    p = str(tmp_path / "d.fastq.gz")
+    d = bytearray(good); d[len(d) // 2] ^= 0x55                      # a flipped byte in the data
+    open(p, "wb").write(bytes(d))
+    with pytest.raises(Exception):
+        gzip.decompress(bytes(d))
+    for threads in (1, 8):
+        rc, out, err = run(cat, p, threads, 100000)
+        assert rc == 1 and "damaged" in err
+        assert out[:4000000] == t[:4000000]                          # (as with gzread, what decodes is delivered until the error shows)
+    open(p, "wb").write(good[:-4000])                                # cut short
+    for threads in (1, 8):
+        rc, out, err = run(cat, p, threads, 100000)
+        assert rc == 1 and t.startswith(out), err
+    d = bytearray(good); d[-6] ^= 1                                  # the CRC in the trailer
+    open(p, "wb").write(bytes(d))
+    rc, out, err = run(cat, p, 8)
+    assert rc == 1 and "CRC" in err
+    open(p, "wb").write(b"plain text, no gzip\n")
+    rc, out, err = run(cat, p, 8)
+    assert rc == 1

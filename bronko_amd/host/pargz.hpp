@@ -12,6 +12,8 @@
 //   2. from there it inflates into 16-bit symbols: a byte, or "whatever stood at position p of the 32 KB window before this
 //      chunk" -- copies carry such symbols along like bytes -- and stops at the boundary the next chunk's thread started from (a
 //      start that turns out not to be a boundary of the real stream is run over, and that chunk's work dropped);
+//      (amplicon reads repeat what was read a few KB before: most of a chunk's text is copies of copies that lead back into the
+//      unknown window -- a list of the unknowns' places instead of a symbol per byte was tried and is 25x slower on such data);
 //   3. the chunks' last 32 KB are resolved one after the other (each needs the one before), then every chunk is turned into bytes
 //      by its own thread and its CRC-32 taken; the member's CRC and length are checked when its trailer comes by
 //      (crc32_combine).
@@ -29,8 +31,11 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -258,6 +263,9 @@ struct MemberEnd { uint64_t at; uint32_t crc, isize; };   // a member ended afte
 struct SymBuf {
     std::unique_ptr<uint16_t[]> d;
     size_t n = 0, cap = 0;
+    SymBuf() = default;
+    SymBuf(SymBuf&& o) noexcept : d(std::move(o.d)), n(o.n), cap(o.cap) { o.n = 0; o.cap = 0; }
+    SymBuf& operator=(SymBuf&& o) noexcept { d = std::move(o.d); n = o.n; cap = o.cap; o.n = 0; o.cap = 0; return *this; }
     void room(size_t extra) {
         if (n + extra <= cap) return;
         size_t nc = std::max<size_t>(cap * 2, n + extra + (1u << 16));
@@ -348,6 +356,19 @@ inline uint64_t member_header(const uint8_t* b, uint64_t at, uint64_t n, uint32_
     return p + 8 <= n ? p : kNone;
 }
 
+// a stretch of the text on its way to the reader; the buffers go round (fresh buffers of several MB per chunk and wave are page
+// faults by the thousand, all taken under the one lock of the process's address space)
+struct Piece {
+    std::unique_ptr<char[]> d;
+    size_t n = 0, cap = 0;
+    Piece() = default;
+    Piece(Piece&& o) noexcept : d(std::move(o.d)), n(o.n), cap(o.cap) { o.n = 0; o.cap = 0; }
+    Piece& operator=(Piece&& o) noexcept { d = std::move(o.d); n = o.n; cap = o.cap; o.n = 0; o.cap = 0; return *this; }
+    void room(size_t want) { if (want > cap) { d.reset(new char[want]); cap = want; } }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+};
+
 struct Chunk {
     uint64_t nominal = 0;     // bit position the search for a boundary starts from
     uint64_t start = kNone;   // the boundary decoding starts from (kNone: none found)
@@ -358,7 +379,7 @@ struct Chunk {
     std::string what;
     SymBuf sym;
     std::vector<MemberEnd> ends;
-    std::vector<char> bytes;
+    Piece bytes;
     std::vector<uint32_t> seg_crc;   // CRC-32 of the stretches between member ends (ends.size() + 1 of them)
 };
 
@@ -518,20 +539,32 @@ public:
                     break;
                 }
                 queued_ -= q_.front().size();
+                if (cur_.cap && spare_.size() < 64) spare_.push_back(std::move(cur_));
                 cur_ = std::move(q_.front()); q_.pop_front(); cur_at_ = 0;
                 lk.unlock();
                 cv_.notify_all();
                 continue;
             }
             const size_t k = std::min(n - got, cur_.size() - cur_at_);
-            memcpy(dst + got, cur_.data() + cur_at_, k);
+            memcpy(dst + got, cur_.d.get() + cur_at_, k);
             got += k; cur_at_ += k;
         }
         return got;
     }
 
 private:
-    bool put(std::vector<char>&& v) {   // false: the reader went away
+    pargz::Piece fresh(size_t want) {
+        pargz::Piece p;
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            for (size_t i = 0; i < spare_.size(); i++)
+                if (spare_[i].cap >= want) { p = std::move(spare_[i]); spare_.erase(spare_.begin() + (long)i); break; }
+            if (!p.cap && spare_.size() >= 32) spare_.erase(spare_.begin());   // (too small, all of them: let one go)
+        }
+        p.room((want + want / 4 + (1u << 20)) & ~(size_t)((1u << 20) - 1)); p.n = 0;   // (with room to spare: the next chunk is a little larger)
+        return p;
+    }
+    bool put(pargz::Piece&& v) {   // false: the reader went away
         if (v.empty()) return true;
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [&] { return queued_ < kAhead || quit_; });
@@ -608,11 +641,14 @@ private:
             inflateEnd(&z);
         });
         // (members of 64 KB are gathered into pieces of a few MB for the queue)
-        std::vector<char> piece;
+        constexpr size_t kPiece = 4u << 20;
+        pargz::Piece piece = fresh(kPiece + 65536);
         for (auto& j : jobs) {
             if (!j.ok) { if (!put(std::move(piece))) return false; finish("damaged BGZF block"); return false; }
-            piece.insert(piece.end(), j.out.begin(), j.out.end());
-            if (piece.size() >= (4u << 20)) { if (!put(std::move(piece))) return false; piece = std::vector<char>(); }
+            if (piece.n + j.out.size() > piece.cap) { if (!put(std::move(piece))) return false; piece = fresh(std::max(kPiece + 65536, j.out.size())); }
+            if (!j.out.empty()) memcpy(piece.d.get() + piece.n, j.out.data(), j.out.size());
+            piece.n += j.out.size();
+            if (piece.n >= kPiece) { if (!put(std::move(piece))) return false; piece = fresh(kPiece + 65536); }
         }
         jobs.clear();
         return put(std::move(piece));
@@ -632,13 +668,18 @@ private:
             for (size_t i = 0; i < cs.size(); i++) cs[i].nominal = bit + (uint64_t)i * cb * 8u;
             const uint64_t wave_end = std::min(total_bits, bit + (uint64_t)cs.size() * cb * 8u);
             cs[0].start = bit;
+            for (size_t i = 0; i < cs.size(); i++)
+                if (!sym_pool_.empty()) { cs[i].sym = std::move(sym_pool_.back()); sym_pool_.pop_back(); cs[i].sym.n = 0; }
+            const auto t0 = std::chrono::steady_clock::now();
             parallel_for(cs.size() - 1, threads_, [&](size_t i) {
                 Chunk& c = cs[i + 1];
                 c.start = find_boundary(file_, n_, c.nominal, std::min(wave_end, c.nominal + cb * 8u));
             });
+            const auto t1 = std::chrono::steady_clock::now();
             parallel_for(cs.size(), threads_, [&](size_t i) {
                 if (cs[i].start != kNone) inflate_chunk(file_, n_, cs, i, wave_end);
             });
+            const auto t2 = std::chrono::steady_clock::now();
             // the chunks that make up the stream, in order
             std::vector<size_t> chain;
             for (int i = 0; i >= 0; i = cs[(size_t)i].next) {
@@ -671,42 +712,74 @@ private:
                 window.swap(nw);
             }
             // symbols -> bytes and CRCs, every chunk on its own
+            for (size_t x = 0; x < chain.size(); x++) if (!cs[chain[x]].failed) cs[chain[x]].bytes = fresh(cs[chain[x]].sym.n + 1);
             std::atomic<bool> bad{false};
             parallel_for(chain.size(), threads_, [&](size_t x) {
                 Chunk& c = cs[chain[x]];
                 if (c.failed) return;
                 const std::vector<uint8_t>& w = wins[x];
                 const size_t missing = kWin - w.size();
-                c.bytes.resize(c.sym.n);
+                c.bytes.n = c.sym.n;
                 const uint16_t* s = c.sym.d.get();
-                char* o = c.bytes.data();
-                for (size_t i = 0; i < c.sym.n; i++) {
-                    const uint16_t v = s[i];
-                    if (v < 256) o[i] = (char)v;
-                    else {
-                        const uint32_t pos = v & (kWin - 1);
-                        if (pos < missing) { bad = true; o[i] = 0; } else o[i] = (char)w[pos - missing];
-                    }
+                char* o = c.bytes.d.get();
+                // symbol -> byte through a table (64 KB: the bytes themselves and the window); with amplicon reads most of a chunk is unknowns
+                std::unique_ptr<uint8_t[]> lut;
+                if (missing == 0) {
+                    lut.reset(new uint8_t[65536]);
+                    for (unsigned v = 0; v < 256; v++) lut[v] = (uint8_t)v;
+                    memcpy(lut.get() + kUnknown, w.data(), kWin);
                 }
-                c.sym.d.reset(); c.sym.cap = 0;
+                auto resolve = [&](size_t i, const size_t end) {
+                    if (lut) { const uint8_t* t = lut.get(); for (; i < end; i++) o[i] = (char)t[s[i]]; return; }
+                    for (; i + 16 <= end; i += 16) {                 // sixteen plain bytes at a time where there are
+                        uint16_t any = 0;
+                        for (int j = 0; j < 16; j++) any |= s[i + j];
+                        if (!(any & 0xff00u)) { for (int j = 0; j < 16; j++) o[i + j] = (char)s[i + j]; continue; }
+                        for (int j = 0; j < 16; j++) {
+                            const uint16_t v = s[i + j];
+                            if (v < 256) o[i + j] = (char)v;
+                            else { const uint32_t pos = v & (kWin - 1); if (pos < missing) { bad = true; o[i + j] = 0; } else o[i + j] = (char)w[pos - missing]; }
+                        }
+                    }
+                    for (; i < end; i++) {
+                        const uint16_t v = s[i];
+                        if (v < 256) o[i] = (char)v;
+                        else { const uint32_t pos = v & (kWin - 1); if (pos < missing) { bad = true; o[i] = 0; } else o[i] = (char)w[pos - missing]; }
+                    }
+                };
+                // (the CRC of a stretch right behind its bytes, while they are in the cache)
                 size_t from = 0;
                 for (size_t k = 0; k <= c.ends.size(); k++) {
-                    const size_t to = k < c.ends.size() ? (size_t)c.ends[k].at : c.bytes.size();
-                    c.seg_crc.push_back((uint32_t)crc32_z(0, reinterpret_cast<const Bytef*>(o + from), to - from));
+                    const size_t to = k < c.ends.size() ? (size_t)c.ends[k].at : c.bytes.n;
+                    uLong crc = 0;
+                    for (size_t at = from; at < to; at += 32768) {
+                        const size_t e = std::min(to, at + 32768);
+                        resolve(at, e);
+                        crc = crc32_z(crc, reinterpret_cast<const Bytef*>(o + at), e - at);
+                    }
+                    c.seg_crc.push_back((uint32_t)crc);
                     from = to;
                 }
             });
             if (bad) throw std::runtime_error("damaged data (distance before the start)");
+            if (stats_) {
+                const auto t3 = std::chrono::steady_clock::now();
+                auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+                size_t n_text = 0;
+                for (size_t x : chain) n_text += cs[x].bytes.n;
+                fprintf(stderr, "[pargz] wave of %zu chunks (%zu in the stream), %.1f MB of text: boundaries %.1f ms, inflate %.1f ms, windows + bytes + CRC %.1f ms\n", cs.size(),
+                        chain.size(), n_text / 1e6, ms(t0, t1), ms(t1, t2), ms(t2, t3));
+            }
             for (size_t x = 0; x < chain.size(); x++) {
                 Chunk& c = cs[chain[x]];
                 if (c.failed) throw std::runtime_error("damaged data (" + c.what + ")");
                 size_t from = 0;
                 for (size_t k = 0; k <= c.ends.size(); k++) {
-                    const size_t to = k < c.ends.size() ? (size_t)c.ends[k].at : c.bytes.size();
+                    const size_t to = k < c.ends.size() ? (size_t)c.ends[k].at : c.bytes.n;
                     check.add(c.seg_crc[k], to - from);
                     if (k < c.ends.size() && !check.ends(c.ends[k].crc, c.ends[k].isize)) {
                         // what was read before the damaged member is still delivered, as gzread does
-                        c.bytes.resize(to);
+                        c.bytes.n = to;
                         put(std::move(c.bytes));
                         throw std::runtime_error("damaged data (CRC or length mismatch)");
                     }
@@ -714,6 +787,7 @@ private:
                 }
                 if (!put(std::move(c.bytes))) return;
             }
+            for (auto& c : cs) if (c.sym.cap && sym_pool_.size() < 2 * (size_t)threads_) sym_pool_.push_back(std::move(c.sym));
             const Chunk& last = cs[chain.back()];
             if (last.eof) { finish(""); return; }
             bit = last.stop;
@@ -725,17 +799,20 @@ private:
     std::string path_;
     unsigned threads_;
     size_t chunk_;
+    bool stats_ = getenv("BRONKO_PARGZ_STATS") != nullptr;
     int fd_ = -1;
     const uint8_t* file_ = nullptr;
     uint64_t n_ = 0;
     std::thread producer_;
     std::mutex m_;
     std::condition_variable cv_;
-    std::deque<std::vector<char>> q_;
+    std::deque<pargz::Piece> q_;
+    std::vector<pargz::Piece> spare_;        // (under m_) buffers the reader is done with
+    std::vector<pargz::SymBuf> sym_pool_;    // (producer only)
     size_t queued_ = 0;
     bool done_ = false, quit_ = false;
     std::string error_;
-    std::vector<char> cur_;
+    pargz::Piece cur_;
     size_t cur_at_ = 0;
 };
 

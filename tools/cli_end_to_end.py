@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """`bronko call` end to end: FASTQ.gz files on disk -> VCFs, wall time of the whole command (gunzip + parse on host threads,
 PCIe, the GPU path, calls, output files).  Writes S synthetic samples of N reads (config-2 shape: wuhan_ref, 150 bp single-end,
-0.5 % errors) as real .fastq.gz files under a scratch directory, then times the binary with 1 lane and with the default lanes.
+0.5 % errors) as real .fastq.gz files under a scratch directory, then times the binary with 1 lane and one inflate
+thread per file (zlib's gzread), 1 lane and the inflate threads -t allows (pargz.hpp), and the default lanes.
 With a fourth argument N > 1 the references are N synthetic strains (wuhan_ref + 300 substitutions each, k = 31: BASELINE
 config 5's shape) written as FASTA files, sample s is derived from strain s mod N.
 usage: tools/cli_end_to_end.py [samples 16] [reads 1000000] [threads 32] [strains 1]"""
@@ -68,12 +69,15 @@ def main():
     NS = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     tmp = tempfile.mkdtemp(prefix="bronko_e2e_")
     refs, kk, paths = prepare(tmp, S, N, NS)
-    for lanes in ("1", None):
+    runs = [("1", "1"), ("1", None), (None, None)] if S > 1 else [("1", "1"), ("1", None)]
+    for lanes, inflate in runs:   # (lanes per device, inflate threads per file: None = the binary's own choice)
         env = dict(os.environ)
-        env.pop("BRONKO_LANES", None)
+        env.pop("BRONKO_LANES", None); env.pop("BRONKO_INFLATE_THREADS", None)
         if lanes:
             env["BRONKO_LANES"] = lanes
-        out = os.path.join(tmp, "out_%s" % (lanes or "default"))
+        if inflate:
+            env["BRONKO_INFLATE_THREADS"] = inflate
+        out = os.path.join(tmp, "out_%s_%s" % (lanes or "default", inflate or "default"))
         t0 = time.time()
         r = subprocess.run([BIN, "call", "-g"] + refs + ["-r"] + paths + kk + ["-t", str(T), "-o", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         dt = time.time() - t0
@@ -81,11 +85,11 @@ def main():
             print(r.stderr.decode()[-2000:])
             raise SystemExit("bronko call failed")
         n_vcf = len([f for f in os.listdir(out) if f.endswith(".vcf")])
-        print("bronko call, %d reference genome(s), %s lanes per device (-t %d): %.2f s wall for %d samples (%d VCFs) = %.2f M reads/s end to end" %
-              (len(refs), lanes or "default", T, dt, S, n_vcf, S * N / dt / 1e6), flush=True)
-    a = open(os.path.join(tmp, "out_1", "sample00.vcf")).read().split("\n", 3)[-1]
-    b = open(os.path.join(tmp, "out_default", "sample00.vcf")).read().split("\n", 3)[-1]
-    print("same VCF body with 1 lane and with the default lanes:", a == b)
+        how = [ln.split("] ", 1)[-1] for ln in r.stdout.decode().splitlines() if "inflated on" in ln]
+        print("bronko call, %d reference genome(s), %s lanes per device, %s (-t %d): %.2f s wall for %d samples (%d VCFs) = %.2f M reads/s end to end" %
+              (len(refs), lanes or "default", how[0] if how else "one inflate thread per file", T, dt, S, n_vcf, S * N / dt / 1e6), flush=True)
+    bodies = [open(os.path.join(tmp, "out_%s_%s" % (l or "default", i or "default"), "sample00.vcf")).read().split("\n", 3)[-1] for l, i in runs]
+    print("same VCF body in every run:", all(b == bodies[0] for b in bodies))
     subprocess.run(["rm", "-rf", tmp])
 
 

@@ -260,18 +260,83 @@ inline bool read_dynamic_header(Bits& in, Codes& c) {
 // ---- a chunk's text as symbols ----------------------------------------------------------------------------------------------
 struct MemberEnd { uint64_t at; uint32_t crc, isize; };   // a member ended after `at` symbols of this chunk
 
+// Large buffers (a chunk's symbols, a chunk's text): anonymous mappings kept for the whole process and handed round -- several
+// lanes' files are read at once in one address space, and fresh pages by the hundred thousand per file are faults under that
+// address space's one lock.
+struct Block {
+    char* p = nullptr;
+    size_t cap = 0;
+    void* base = nullptr;
+    size_t len = 0;
+    Block() = default;
+    Block(const Block&) = delete;
+    Block& operator=(const Block&) = delete;
+    Block(Block&& o) noexcept : p(o.p), cap(o.cap), base(o.base), len(o.len) { o.p = nullptr; o.cap = 0; o.base = nullptr; o.len = 0; }
+    Block& operator=(Block&& o) noexcept;
+    ~Block();
+};
+class BlockPool {
+public:
+    static BlockPool& get() { static BlockPool* pool = new BlockPool; return *pool; }   // (never destroyed: blocks may outlive main)
+    Block take(size_t want) {
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            size_t best = free_.size();
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].cap >= want && (best == free_.size() || free_[i].cap < free_[best].cap)) best = i;
+            if (best < free_.size() && free_[best].cap <= 4 * want + (8u << 20)) {
+                Block b = std::move(free_[best]);
+                free_.erase(free_.begin() + (long)best);
+                held_ -= b.cap;
+                return b;
+            }
+        }
+        constexpr size_t kHuge = 2u << 20;
+        Block b;
+        b.cap = (want + want / 4 + kHuge) & ~(kHuge - 1);
+        b.len = b.cap + kHuge;
+        b.base = mmap(nullptr, b.len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (b.base == MAP_FAILED) { b.base = nullptr; b.cap = 0; b.len = 0; throw std::bad_alloc(); }
+        b.p = reinterpret_cast<char*>(((uintptr_t)b.base + kHuge - 1) & ~(uintptr_t)(kHuge - 1));
+        if (getenv("BRONKO_PARGZ_THP")) madvise(b.p, b.cap, MADV_HUGEPAGE);   // (2 MB pages: measured a loss where the kernel compacts memory to make them)
+        return b;
+    }
+    void give(Block&& b) {
+        if (!b.base) return;
+        std::unique_lock<std::mutex> lk(m_);
+        if (held_ + b.cap > kKeep) { lk.unlock(); munmap(b.base, b.len); b.p = nullptr; b.cap = 0; b.base = nullptr; b.len = 0; return; }
+        held_ += b.cap;
+        free_.push_back(std::move(b));
+    }
+private:
+    static constexpr size_t kKeep = 6ull << 30;
+    std::mutex m_;
+    std::vector<Block> free_;
+    size_t held_ = 0;
+};
+inline Block& Block::operator=(Block&& o) noexcept {
+    if (this != &o) {
+        BlockPool::get().give(std::move(*this));
+        p = o.p; cap = o.cap; base = o.base; len = o.len;
+        o.p = nullptr; o.cap = 0; o.base = nullptr; o.len = 0;
+    }
+    return *this;
+}
+inline Block::~Block() { if (base) BlockPool::get().give(std::move(*this)); }
+
 struct SymBuf {
-    std::unique_ptr<uint16_t[]> d;
+    Block b;
+    uint16_t* d = nullptr;
     size_t n = 0, cap = 0;
     SymBuf() = default;
-    SymBuf(SymBuf&& o) noexcept : d(std::move(o.d)), n(o.n), cap(o.cap) { o.n = 0; o.cap = 0; }
-    SymBuf& operator=(SymBuf&& o) noexcept { d = std::move(o.d); n = o.n; cap = o.cap; o.n = 0; o.cap = 0; return *this; }
+    SymBuf(SymBuf&& o) noexcept : b(std::move(o.b)), d(o.d), n(o.n), cap(o.cap) { o.d = nullptr; o.n = 0; o.cap = 0; }
+    SymBuf& operator=(SymBuf&& o) noexcept { b = std::move(o.b); d = o.d; n = o.n; cap = o.cap; o.d = nullptr; o.n = 0; o.cap = 0; return *this; }
     void room(size_t extra) {
         if (n + extra <= cap) return;
-        size_t nc = std::max<size_t>(cap * 2, n + extra + (1u << 16));
-        std::unique_ptr<uint16_t[]> nd(new uint16_t[nc]);
-        if (n) memcpy(nd.get(), d.get(), n * sizeof(uint16_t));
-        d.swap(nd); cap = nc;
+        Block nb = BlockPool::get().take(std::max<size_t>(cap * 2, n + extra + (1u << 16)) * sizeof(uint16_t));
+        if (n) memcpy(nb.p, d, n * sizeof(uint16_t));
+        b = std::move(nb);
+        d = reinterpret_cast<uint16_t*>(b.p); cap = b.cap / sizeof(uint16_t);
     }
 };
 
@@ -312,7 +377,7 @@ inline bool inflate_block(Bits& in, const Codes& c, SymBuf& out, size_t max_out)
         if (d & kBad) return false;
         in.take(d & 0xffu);
         const uint32_t dist = (d >> 16) + in.get((d >> 12) & 15u);
-        uint16_t* o = out.d.get() + out.n;
+        uint16_t* o = out.d + out.n;
         if (dist <= out.n) {
             const uint16_t* s = o - dist;
             if (dist >= len) memcpy(o, s, len * sizeof(uint16_t));
@@ -356,15 +421,15 @@ inline uint64_t member_header(const uint8_t* b, uint64_t at, uint64_t n, uint32_
     return p + 8 <= n ? p : kNone;
 }
 
-// a stretch of the text on its way to the reader; the buffers go round (fresh buffers of several MB per chunk and wave are page
-// faults by the thousand, all taken under the one lock of the process's address space)
+// a stretch of the text on its way to the reader
 struct Piece {
-    std::unique_ptr<char[]> d;
+    Block b;
+    char* d = nullptr;
     size_t n = 0, cap = 0;
     Piece() = default;
-    Piece(Piece&& o) noexcept : d(std::move(o.d)), n(o.n), cap(o.cap) { o.n = 0; o.cap = 0; }
-    Piece& operator=(Piece&& o) noexcept { d = std::move(o.d); n = o.n; cap = o.cap; o.n = 0; o.cap = 0; return *this; }
-    void room(size_t want) { if (want > cap) { d.reset(new char[want]); cap = want; } }
+    Piece(Piece&& o) noexcept : b(std::move(o.b)), d(o.d), n(o.n), cap(o.cap) { o.d = nullptr; o.n = 0; o.cap = 0; }
+    Piece& operator=(Piece&& o) noexcept { b = std::move(o.b); d = o.d; n = o.n; cap = o.cap; o.d = nullptr; o.n = 0; o.cap = 0; return *this; }
+    void room(size_t want) { if (want > cap) { b = BlockPool::get().take(want); d = b.p; cap = b.cap; } }
     size_t size() const { return n; }
     bool empty() const { return n == 0; }
 };
@@ -539,29 +604,22 @@ public:
                     break;
                 }
                 queued_ -= q_.front().size();
-                if (cur_.cap && spare_.size() < 64) spare_.push_back(std::move(cur_));
                 cur_ = std::move(q_.front()); q_.pop_front(); cur_at_ = 0;
                 lk.unlock();
                 cv_.notify_all();
                 continue;
             }
             const size_t k = std::min(n - got, cur_.size() - cur_at_);
-            memcpy(dst + got, cur_.d.get() + cur_at_, k);
+            memcpy(dst + got, cur_.d + cur_at_, k);
             got += k; cur_at_ += k;
         }
         return got;
     }
 
 private:
-    pargz::Piece fresh(size_t want) {
+    static pargz::Piece fresh(size_t want) {
         pargz::Piece p;
-        {
-            std::unique_lock<std::mutex> lk(m_);
-            for (size_t i = 0; i < spare_.size(); i++)
-                if (spare_[i].cap >= want) { p = std::move(spare_[i]); spare_.erase(spare_.begin() + (long)i); break; }
-            if (!p.cap && spare_.size() >= 32) spare_.erase(spare_.begin());   // (too small, all of them: let one go)
-        }
-        p.room((want + want / 4 + (1u << 20)) & ~(size_t)((1u << 20) - 1)); p.n = 0;   // (with room to spare: the next chunk is a little larger)
+        p.room(want);
         return p;
     }
     bool put(pargz::Piece&& v) {   // false: the reader went away
@@ -646,7 +704,7 @@ private:
         for (auto& j : jobs) {
             if (!j.ok) { if (!put(std::move(piece))) return false; finish("damaged BGZF block"); return false; }
             if (piece.n + j.out.size() > piece.cap) { if (!put(std::move(piece))) return false; piece = fresh(std::max(kPiece + 65536, j.out.size())); }
-            if (!j.out.empty()) memcpy(piece.d.get() + piece.n, j.out.data(), j.out.size());
+            if (!j.out.empty()) memcpy(piece.d + piece.n, j.out.data(), j.out.size());
             piece.n += j.out.size();
             if (piece.n >= kPiece) { if (!put(std::move(piece))) return false; piece = fresh(kPiece + 65536); }
         }
@@ -668,8 +726,6 @@ private:
             for (size_t i = 0; i < cs.size(); i++) cs[i].nominal = bit + (uint64_t)i * cb * 8u;
             const uint64_t wave_end = std::min(total_bits, bit + (uint64_t)cs.size() * cb * 8u);
             cs[0].start = bit;
-            for (size_t i = 0; i < cs.size(); i++)
-                if (!sym_pool_.empty()) { cs[i].sym = std::move(sym_pool_.back()); sym_pool_.pop_back(); cs[i].sym.n = 0; }
             const auto t0 = std::chrono::steady_clock::now();
             parallel_for(cs.size() - 1, threads_, [&](size_t i) {
                 Chunk& c = cs[i + 1];
@@ -720,8 +776,8 @@ private:
                 const std::vector<uint8_t>& w = wins[x];
                 const size_t missing = kWin - w.size();
                 c.bytes.n = c.sym.n;
-                const uint16_t* s = c.sym.d.get();
-                char* o = c.bytes.d.get();
+                const uint16_t* s = c.sym.d;
+                char* o = c.bytes.d;
                 // symbol -> byte through a table (64 KB: the bytes themselves and the window); with amplicon reads most of a chunk is unknowns
                 std::unique_ptr<uint8_t[]> lut;
                 if (missing == 0) {
@@ -787,7 +843,6 @@ private:
                 }
                 if (!put(std::move(c.bytes))) return;
             }
-            for (auto& c : cs) if (c.sym.cap && sym_pool_.size() < 2 * (size_t)threads_) sym_pool_.push_back(std::move(c.sym));
             const Chunk& last = cs[chain.back()];
             if (last.eof) { finish(""); return; }
             bit = last.stop;
@@ -807,8 +862,6 @@ private:
     std::mutex m_;
     std::condition_variable cv_;
     std::deque<pargz::Piece> q_;
-    std::vector<pargz::Piece> spare_;        // (under m_) buffers the reader is done with
-    std::vector<pargz::SymBuf> sym_pool_;    // (producer only)
     size_t queued_ = 0;
     bool done_ = false, quit_ = false;
     std::string error_;

@@ -321,6 +321,7 @@ struct bk_engine {
     bool gather_ok = false;                 // IndexView::gather_ok
     // gathered votes (bk_gather.hip): this engine's voting pass is gather_votes_kernel (sparse planes of a many-genome index)
     bool gather_mode = false;
+    DevBuf<uint32_t> vote_tab;                  // [n_full][W][8] the voters of every (reference k-mer, window position) of the sample (bk_gather.hip; every genome's rows)
     DevBuf<unsigned long long> alias_hits[2];   // per mate file: the deferred k-mers that reach a bucket through an alias key
     DevBuf<unsigned int> n_alias_hits;          // [2]
     static constexpr unsigned int kAliasCap = 1u << 20;
@@ -2549,7 +2550,15 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
                 else { a.f_items = nullptr; if (int rc = flush_pending_items(e)) return rc; }
             }
             bk_engine::Span sp(e, 1);
-            if (gather && pass == 1 && m == 0) { bk::launch_gather_votes(a, n_mates == 2 ? e->counters[1].p : nullptr, e->stream); if (int rc = dbg_sync("gather_votes")) return rc; }   // (both mate files' counts at once: it stores)
+            if (gather && pass == 1 && m == 0) {   // (both mate files' counts at once: it stores)
+                const unsigned long long* c1 = n_mates == 2 ? e->counters[1].p : nullptr;
+                // many genomes that share their k-mers: the voters once per (k-mer, window position), not once per occurrence
+                const bool by_table = bk::vote_table_fits(a) && e->total_cells >= 2 * (uint64_t)e->n_full && !test_env("BK_NO_VOTE_TABLE");
+                if (by_table && e->vote_tab.n < bk::vote_table_words(a.ix)) BK_HIP(e->vote_tab.alloc(bk::vote_table_words(a.ix)));
+                if (by_table) bk::launch_gather_votes_table(a, c1, e->vote_tab.p, e->stream);
+                else bk::launch_gather_votes(a, c1, e->stream);
+                if (int rc = dbg_sync("gather_votes")) return rc;
+            }
             if (gather && pass == 1 && e->n_merged_slots) { bk::launch_merged_votes(a, e->stream); if (int rc = dbg_sync("merged_votes")) return rc; }
             bk::launch_finalize(a, e->stream);
             if (gather && pass == 1) if (int rc = dbg_sync("alias-only general kernels")) return rc;

@@ -179,6 +179,107 @@ __global__ __launch_bounds__(kGatherBlock) void gather_votes_kernel(FinalizeArgs
     }
 }
 
+// Every genome's rows (mode 3) with many related genomes: a reference k-mer has an occurrence in nearly every one of them, and the
+// eight voters of (k-mer, window position) are the same for all of its occurrences -- 100 strains: 0.75 M k-mers, 3.0 M occurrences.
+// voter_table_kernel finds them once per (k-mer, window position) -- answers, counters, thresholds -- and writes eight words;
+// gather_table_kernel is the gather with two 16-byte loads in the place of all that.  A word: bits 0-27 the largest reported count
+// of the mate files that pass -ci / -cx (so -cs < 2^28: KMC's default is 10^6; otherwise the direct kernel), bits 28-29 how many
+// pass; word 0 also carries, in bits 30-31, the k-mer's base at the mirrored position (what a reverse-complemented occurrence votes
+// for: vote()'s `canonical` branch).
+constexpr uint32_t kVtCountBits = 28;
+__global__ __launch_bounds__(256) void voter_table_kernel(FinalizeArgs a, const unsigned long long* __restrict__ counters1, uint32_t* __restrict__ tab) {
+    const IndexView& ix = a.ix;
+    const uint32_t W = (uint32_t)ix.W, rl = (uint32_t)ix.v_span + 1u;
+    const uint64_t n_pairs = (uint64_t)ix.n_full * W;
+    const unsigned long long* const planes[2] = {a.counters, counters1};
+    const int n_planes = counters1 ? 2 : 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n_pairs; i += (uint64_t)gridDim.x * 256u) {
+        const uint32_t id = (uint32_t)(i / W), t = (uint32_t)(i - (uint64_t)id * W), j = (uint32_t)ix.wstart + t;
+        const uint4 idr = *reinterpret_cast<const uint4*>(ix.id_rec + id);
+        const uint64_t u = (uint64_t)idr.x | ((uint64_t)idr.y << 32);
+        const uint64_t ur = revcomp_kmer(u, ix.k);
+        uint32_t out[8];
+#pragma unroll
+        for (uint32_t b = 0; b < 4u; ++b) {
+            uint64_t z, at;
+            uint32_t rcu;
+            const uint32_t kind = voter_counters(ix, id, idr.w, u, ur, j, b, z, at, rcu);
+#pragma unroll
+            for (uint32_t isrc = 0; isrc < 2u; ++isrc) {
+                uint32_t np = 0u, mxv = 0u;
+                if (kind != 0u)
+                    for (int m = 0; m < n_planes; ++m) {
+                        const unsigned long long n = planes[m][counter_index(kind, at, rcu, isrc, ix.v_off, rl)];
+                        if (n == 0ull || n < a.ci || n > a.cx) continue;
+                        ++np;
+                        mxv = max(mxv, (uint32_t)(n > a.cs ? a.cs : n));
+                    }
+                out[2u * b + isrc] = (np << kVtCountBits) | mxv;
+            }
+        }
+        out[0] |= ((uint32_t)(u >> (2u * j)) & 3u) << 30;
+        uint4* dst = reinterpret_cast<uint4*>(tab + i * 8u);
+        dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+        dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+    }
+}
+
+// (a lane per position and a wave per window position here -- every fourth -- so that a lane's LDS counters are its own: the W
+// lanes of one position of the direct kernel's layout meet on the same eight addresses, 26 ways)
+__global__ __launch_bounds__(kGatherBlock) void gather_table_kernel(FinalizeArgs a, const uint32_t* __restrict__ tab) {
+    constexpr uint32_t kWaves = kGatherBlock / 64;
+    __shared__ unsigned int mx[kWaves][8][kGatherPos];
+    __shared__ unsigned int cnt[kWaves][8][kGatherPos];
+    const IndexView& ix = a.ix;
+    const uint32_t c_hi = ix.total_cells;
+    const uint64_t p0_64 = (uint64_t)blockIdx.x * kGatherPos;
+    if (p0_64 >= c_hi) return;
+    const uint32_t P0 = (uint32_t)p0_64;
+    for (uint32_t i = threadIdx.x; i < kWaves * 8u * kGatherPos; i += kGatherBlock) { (&mx[0][0][0])[i] = 0u; (&cnt[0][0][0])[i] = 0u; }
+    __syncthreads();
+    const uint32_t W = (uint32_t)ix.W, km1 = (uint32_t)ix.k - 1u;
+    const uint32_t pi = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t P = P0 + pi;
+    if (P < c_hi)
+        for (uint32_t t = wave; t < W; t += kWaves) {
+            const uint32_t j = (uint32_t)ix.wstart + t;
+            if (P < j) continue;
+            const uint32_t c0 = P - j;
+            const uint32_t id = ix.id_at[c0];
+            if (id >= ix.n_full) continue;
+            const bool canon = (ix.cell_flags[c0] & 3u) == 2u;
+            const uint4* tp = reinterpret_cast<const uint4*>(tab + ((uint64_t)id * W + t) * 8u);
+            const uint4 lo = tp[0], hi = tp[1];
+            const uint32_t vals[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const uint32_t cb = lo.x >> 30;
+            const bool middle = 2u * j == km1;   // the mirrored position is the voter's own: (z >> 2j) & 3 is the voter's base there
+#pragma unroll
+            for (uint32_t e = 0; e < 8u; ++e) {
+                const uint32_t np = (vals[e] >> kVtCountBits) & 3u;
+                if (np == 0u) continue;
+                const uint32_t v = vals[e] & ((1u << kVtCountBits) - 1u), b = e >> 1, isrc = e & 1u;
+                const uint32_t bit_idx = canon ? ((middle ? b : cb) ^ 3u) : b;
+                const bool forward = canon ? isrc != 0u : isrc == 0u;
+                const uint32_t row = (forward ? 0u : 4u) + bit_idx;
+                cnt[wave][row][pi] += np;                            // (the lane's own: no other touches [wave][.][pi])
+                mx[wave][row][pi] = max(mx[wave][row][pi], v);
+            }
+        }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kGatherPos * 4u; i += kGatherBlock) {
+        const uint32_t p = i >> 2, base = i & 3u;
+        if (P0 + p >= c_hi) continue;
+        unsigned int m0 = 0u, m1 = 0u, n0 = 0u, n1 = 0u;
+#pragma unroll
+        for (uint32_t w = 0; w < kWaves; ++w) { m0 = max(m0, mx[w][base][p]); m1 = max(m1, mx[w][4u + base][p]); n0 += cnt[w][base][p]; n1 += cnt[w][4u + base][p]; }
+        const size_t cell = ((size_t)P0 + p) * 4 + base;
+        a.pileup[0 * a.plane + cell] = (unsigned long long)m0;
+        a.pileup[1 * a.plane + cell] = (unsigned long long)m1;
+        a.pileup[2 * a.plane + cell] = (unsigned long long)n0;
+        a.pileup[3 * a.plane + cell] = (unsigned long long)n1;
+    }
+}
+
 // the alias hits the statistics pass noted (FinalizeArgs::alias_hits: {canonical k-mer | isrc << 62, count, slot}): the k-mer
 // votes for the BucketInfos of that slot (vote() keeps to the selected genome in mode 2)
 __global__ __launch_bounds__(256) void alias_votes_kernel(FinalizeArgs a) {
@@ -278,6 +379,14 @@ void launch_gather_votes(const FinalizeArgs& a, const unsigned long long* counte
     const dim3 grid((unsigned)((cells + kGatherPos - 1) / kGatherPos));
     if (a.cs < (1ull << 32)) hipLaunchKernelGGL(gather_votes_kernel<false>, grid, dim3(kGatherBlock), 0, stream, a, counters1);
     else hipLaunchKernelGGL(gather_votes_kernel<true>, grid, dim3(kGatherBlock), 0, stream, a, counters1);
+}
+bool vote_table_fits(const FinalizeArgs& a) { return a.mode == 3 && a.cs < (1ull << kVtCountBits); }
+size_t vote_table_words(const IndexView& ix) { return (size_t)ix.n_full * (size_t)ix.W * 8u; }
+void launch_gather_votes_table(const FinalizeArgs& a, const unsigned long long* counters1, uint32_t* tab, hipStream_t stream) {
+    const uint64_t n_pairs = (uint64_t)a.ix.n_full * (uint64_t)a.ix.W;
+    if (!n_pairs || !a.ix.total_cells) return;
+    hipLaunchKernelGGL(voter_table_kernel, dim3((unsigned)std::min<uint64_t>((n_pairs + 255) / 256, 1u << 16)), dim3(256), 0, stream, a, counters1, tab);
+    hipLaunchKernelGGL(gather_table_kernel, dim3((unsigned)(((uint64_t)a.ix.total_cells + kGatherPos - 1) / kGatherPos)), dim3(kGatherBlock), 0, stream, a, (const uint32_t*)tab);
 }
 void launch_merged_votes(const FinalizeArgs& a, hipStream_t stream) {
     if (!a.n_merged_slots) return;

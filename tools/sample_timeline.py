@@ -9,7 +9,7 @@ def short(n):
     return n
 names = [short(r["Kernel_Name"]) for r in rows]
 # a sample starts at the first kernel after a finalize_* / clear_touched / ktab_stats kernel that is none of those
-ends = ("finalize_", "clear_touched", "ktab_stats", "select_genome", "noise_", "call_", "copy_int", "prefix_rows", "gather_votes", "merged_votes", "alias_votes")
+ends = ("finalize_", "clear_touched", "ktab_stats", "select_genome", "noise_", "call_", "copy_int", "prefix_rows", "gather_votes", "gather_table", "voter_table", "merged_votes", "alias_votes")
 starts = [i for i in range(1, len(rows)) if names[i - 1].startswith(ends) and not names[i].startswith(ends)]
 if not starts: sys.exit("no sample boundary found")
 which = int(sys.argv[3]) if len(sys.argv) > 3 else -1

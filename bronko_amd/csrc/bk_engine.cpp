@@ -321,6 +321,7 @@ struct bk_engine {
     bool gather_ok = false;                 // IndexView::gather_ok
     // gathered votes (bk_gather.hip): this engine's voting pass is gather_votes_kernel (sparse planes of a many-genome index)
     bool gather_mode = false;
+    DevBuf<unsigned int> row_bits;              // one bit per V row of the reference k-mers: touched by the sample (set by prefix_rows_kernel for voter_table_kernel)
     DevBuf<uint32_t> vote_tab;                  // [n_full][W][8] the voters of every (reference k-mer, window position) of the sample (bk_gather.hip; every genome's rows)
     DevBuf<unsigned long long> alias_hits[2];   // per mate file: the deferred k-mers that reach a bucket through an alias key
     DevBuf<unsigned int> n_alias_hits;          // [2]
@@ -2498,7 +2499,15 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
         if (gather && pass == 1) {   // difference arrays -> counts (the rows are zeroed behind the sample)
             bk_engine::Span sp(e, 1);
             if (int rc = dbg_sync("statistics pass")) return rc;
-            for (int m = 0; m < n_mates; m++) bk::launch_prefix_rows(e->counters[m].p, e->view(), e->v_list[m].p, e->n_list[m].p, e->stream);
+            // (every genome's rows by the table of voters: which V rows the sample's mate files touched, as bits)
+            unsigned int* row_bits = nullptr;
+            if (!two_pass && e->params.cs < (1ull << 28) && e->total_cells >= 2 * (uint64_t)e->n_full && !test_env("BK_NO_VOTE_TABLE")) {
+                const size_t words = (size_t)((bk::v_real_rows(e->n_full, e->v_span) + 31) / 32) + 1;
+                if (e->row_bits.n < words) BK_HIP(e->row_bits.alloc(words));
+                BK_HIP(hipMemsetAsync(e->row_bits.p, 0, words * sizeof(unsigned int), e->stream));
+                row_bits = e->row_bits.p;
+            }
+            for (int m = 0; m < n_mates; m++) bk::launch_prefix_rows(e->counters[m].p, e->view(), e->v_list[m].p, e->n_list[m].p, row_bits, e->stream);
             if (int rc = dbg_sync("prefix_rows")) return rc;
         }
         for (int m = 0; m < n_mates; m++) {   // R1 then R2 into the same arrays (call.rs:316-317)
@@ -2553,9 +2562,9 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             if (gather && pass == 1 && m == 0) {   // (both mate files' counts at once: it stores)
                 const unsigned long long* c1 = n_mates == 2 ? e->counters[1].p : nullptr;
                 // many genomes that share their k-mers: the voters once per (k-mer, window position), not once per occurrence
-                const bool by_table = bk::vote_table_fits(a) && e->total_cells >= 2 * (uint64_t)e->n_full && !test_env("BK_NO_VOTE_TABLE");
+                const bool by_table = bk::vote_table_fits(a) && e->total_cells >= 2 * (uint64_t)e->n_full && !test_env("BK_NO_VOTE_TABLE") && e->row_bits.p;
                 if (by_table && e->vote_tab.n < bk::vote_table_words(a.ix)) BK_HIP(e->vote_tab.alloc(bk::vote_table_words(a.ix)));
-                if (by_table) bk::launch_gather_votes_table(a, c1, e->vote_tab.p, e->stream);
+                if (by_table) bk::launch_gather_votes_table(a, c1, e->vote_tab.p, e->row_bits.p, e->stream);
                 else bk::launch_gather_votes(a, c1, e->stream);
                 if (int rc = dbg_sync("gather_votes")) return rc;
             }

@@ -45,8 +45,9 @@ constexpr uint32_t kGatherPos = 64;      // pileup positions per workgroup
 constexpr int kGatherBlock = 256;
 
 // the listed V rows of the reference k-mers: difference arrays -> counts, in place (lanes per row = v_span, as in K2a)
+// (row_bits, if not null: one bit per V row, set for the listed ones -- voter_table_kernel asks it before it goes to the plane)
 __global__ __launch_bounds__(256) void prefix_rows_kernel(unsigned long long* __restrict__ vc, const unsigned int* __restrict__ v_list,
-                                                          const unsigned int* __restrict__ n_list, uint32_t span) {
+                                                          const unsigned int* __restrict__ n_list, uint32_t span, unsigned int* __restrict__ row_bits) {
     const uint32_t rl = span + 1u, gpw = 64u / span, lane64 = threadIdx.x & 63u;
     const uint32_t grp = lane64 / span, oo = lane64 - grp * span;
     const bool lane_on = grp < gpw;
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(256) void prefix_rows_kernel(unsigned long long* __
             if (oo >= (uint32_t)off) n += t;
         }
         if (on) vc[at] = n;
+        if (on && oo == 0u && row_bits) atomicOr(&row_bits[v_list[li] >> 5], 1u << (v_list[li] & 31u));
     }
 }
 
@@ -187,9 +189,12 @@ __global__ __launch_bounds__(kGatherBlock) void gather_votes_kernel(FinalizeArgs
 // pass; word 0 also carries, in bits 30-31, the k-mer's base at the mirrored position (what a reverse-complemented occurrence votes
 // for: vote()'s `canonical` branch).
 constexpr uint32_t kVtCountBits = 28;
-__global__ __launch_bounds__(256) void voter_table_kernel(FinalizeArgs a, const unsigned long long* __restrict__ counters1, uint32_t* __restrict__ tab) {
+__global__ __launch_bounds__(256) void voter_table_kernel(FinalizeArgs a, const unsigned long long* __restrict__ counters1, uint32_t* __restrict__ tab,
+                                                          const unsigned int* __restrict__ row_bits /* which V rows the sample touched (prefix_rows_kernel) */,
+                                                          unsigned long long rl_recip /* ceil(2^64 / row length) */) {
     const IndexView& ix = a.ix;
     const uint32_t W = (uint32_t)ix.W, rl = (uint32_t)ix.v_span + 1u;
+    const uint64_t v_real = v_real_len(ix.n_full, ix.v_span);
     const uint64_t n_pairs = (uint64_t)ix.n_full * W;
     const unsigned long long* const planes[2] = {a.counters, counters1};
     const int n_planes = counters1 ? 2 : 1;
@@ -204,10 +209,17 @@ __global__ __launch_bounds__(256) void voter_table_kernel(FinalizeArgs a, const 
             uint64_t z, at;
             uint32_t rcu;
             const uint32_t kind = voter_counters(ix, id, idr.w, u, ur, j, b, z, at, rcu);
+            // a V row of a reference k-mer (most voters are: "u with b at j" is no reference k-mer and takes its own row) that the
+            // sample did not touch is all zero: one bit of a 0.5 MB map instead of a line of the 1 GB plane (a sample touches 6 % of them)
+            uint32_t row0 = 0u;
+            const bool by_row = kind == 2u && at < v_real;
+            if (by_row) row0 = (uint32_t)__umul64hi(at, rl_recip);
 #pragma unroll
             for (uint32_t isrc = 0; isrc < 2u; ++isrc) {
                 uint32_t np = 0u, mxv = 0u;
-                if (kind != 0u)
+                bool look = kind != 0u;
+                if (by_row) { const uint32_t row = row0 + ((isrc ^ rcu) & 1u); look = (row_bits[row >> 5] >> (row & 31u)) & 1u; }
+                if (look)
                     for (int m = 0; m < n_planes; ++m) {
                         const unsigned long long n = planes[m][counter_index(kind, at, rcu, isrc, ix.v_off, rl)];
                         if (n == 0ull || n < a.ci || n > a.cx) continue;
@@ -369,9 +381,9 @@ void launch_zero_genome_rows(unsigned long long* pileup, size_t plane, const uin
 }
 void launch_copy_int(int* dst, const int* src, hipStream_t stream) { hipLaunchKernelGGL(copy_int_kernel, dim3(1), dim3(1), 0, stream, dst, src); }
 
-void launch_prefix_rows(unsigned long long* counters, const IndexView& ix, const unsigned int* v_list, const unsigned int* n_list, hipStream_t stream) {
+void launch_prefix_rows(unsigned long long* counters, const IndexView& ix, const unsigned int* v_list, const unsigned int* n_list, unsigned int* row_bits, hipStream_t stream) {
     if (ix.v_span <= 0) return;
-    hipLaunchKernelGGL(prefix_rows_kernel, dim3(2048), dim3(256), 0, stream, counters + ix.v_off, v_list, n_list, (uint32_t)ix.v_span);
+    hipLaunchKernelGGL(prefix_rows_kernel, dim3(2048), dim3(256), 0, stream, counters + ix.v_off, v_list, n_list, (uint32_t)ix.v_span, row_bits);
 }
 void launch_gather_votes(const FinalizeArgs& a, const unsigned long long* counters1, hipStream_t stream) {
     const uint64_t cells = a.mode == 2 ? (uint64_t)a.max_file_cells : (uint64_t)a.ix.total_cells;
@@ -382,10 +394,11 @@ void launch_gather_votes(const FinalizeArgs& a, const unsigned long long* counte
 }
 bool vote_table_fits(const FinalizeArgs& a) { return a.mode == 3 && a.cs < (1ull << kVtCountBits); }
 size_t vote_table_words(const IndexView& ix) { return (size_t)ix.n_full * (size_t)ix.W * 8u; }
-void launch_gather_votes_table(const FinalizeArgs& a, const unsigned long long* counters1, uint32_t* tab, hipStream_t stream) {
+void launch_gather_votes_table(const FinalizeArgs& a, const unsigned long long* counters1, uint32_t* tab, const unsigned int* row_bits, hipStream_t stream) {
     const uint64_t n_pairs = (uint64_t)a.ix.n_full * (uint64_t)a.ix.W;
     if (!n_pairs || !a.ix.total_cells) return;
-    hipLaunchKernelGGL(voter_table_kernel, dim3((unsigned)std::min<uint64_t>((n_pairs + 255) / 256, 1u << 16)), dim3(256), 0, stream, a, counters1, tab);
+    hipLaunchKernelGGL(voter_table_kernel, dim3((unsigned)std::min<uint64_t>((n_pairs + 255) / 256, 1u << 16)), dim3(256), 0, stream, a, counters1, tab, row_bits,
+                       ~0ull / (unsigned long long)(a.ix.v_span + 1) + 1ull);
     hipLaunchKernelGGL(gather_table_kernel, dim3((unsigned)(((uint64_t)a.ix.total_cells + kGatherPos - 1) / kGatherPos)), dim3(kGatherBlock), 0, stream, a, (const uint32_t*)tab);
 }
 void launch_merged_votes(const FinalizeArgs& a, hipStream_t stream) {

@@ -340,11 +340,11 @@ void launch_call(const CallArgs& a, int max_seqs_per_file, uint64_t max_file_cel
 void launch_select_genome(const CallArgs& a, hipStream_t stream);   // the first kernel of launch_call alone: a.out->file_id
 size_t finalize_lds_bytes(int n_files);
 size_t finalize_partial_rows();
-void launch_prefix_rows(unsigned long long* counters, const IndexView& ix, const unsigned int* v_list, const unsigned int* n_list, hipStream_t stream);   // bk_gather.hip
+void launch_prefix_rows(unsigned long long* counters, const IndexView& ix, const unsigned int* v_list, const unsigned int* n_list, unsigned int* row_bits, hipStream_t stream);   // bk_gather.hip
 void launch_gather_votes(const FinalizeArgs& a, const unsigned long long* counters1, hipStream_t stream);
 bool vote_table_fits(const FinalizeArgs& a);        // every genome's rows and -cs small enough for the table of voters (bk_gather.hip)
 size_t vote_table_words(const IndexView& ix);
-void launch_gather_votes_table(const FinalizeArgs& a, const unsigned long long* counters1, uint32_t* tab, hipStream_t stream);
+void launch_gather_votes_table(const FinalizeArgs& a, const unsigned long long* counters1, uint32_t* tab, const unsigned int* row_bits, hipStream_t stream);
 void launch_alias_votes(const FinalizeArgs& a, hipStream_t stream);
 void launch_merged_votes(const FinalizeArgs& a, hipStream_t stream);
 void launch_zero_genome_rows(unsigned long long* pileup, size_t plane, const uint32_t* file_cell_lo, int n_files, uint32_t total_cells, const int* last_sel,

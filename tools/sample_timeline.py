@@ -10,7 +10,11 @@ def short(n):
 names = [short(r["Kernel_Name"]) for r in rows]
 # a sample starts at the first kernel after a finalize_* / clear_touched / ktab_stats kernel that is none of those
 ends = ("finalize_", "clear_touched", "ktab_stats", "select_genome", "noise_", "call_", "copy_int", "prefix_rows", "gather_votes", "gather_table", "voter_table", "merged_votes", "alias_votes")
-starts = [i for i in range(1, len(rows)) if names[i - 1].startswith(ends) and not names[i].startswith(ends)]
+def fill_inside(i):   # a memset between two kernels of a sample's end (the touched-row bits before prefix_rows_kernel)
+    j = i
+    while j < len(rows) and names[j].startswith("__amd_rocclr_fillBuffer"): j += 1
+    return j > i and j < len(rows) and names[j].startswith(("prefix_rows", "gather_", "voter_table"))
+starts = [i for i in range(1, len(rows)) if names[i - 1].startswith(ends) and not names[i].startswith(ends) and not fill_inside(i)]
 if not starts: sys.exit("no sample boundary found")
 which = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 if which < 0:

@@ -313,9 +313,10 @@ struct BatchQueue {
     std::vector<FastqBatch> spare;   // consumed batches, handed back: their 40 MB buffers are reused instead of being unmapped and
                                      // mapped again (with dozens of lanes the page faults of fresh buffers cost more than the parsing)
     static constexpr size_t kDepth = 3;
+    bool unbounded = false;          // a sample read ahead of its turn (ReadAhead below): the whole file may wait here
     void put(FastqBatch&& b) {
         std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [&] { return q.size() < kDepth; });
+        cv.wait(lk, [&] { return unbounded || q.size() < kDepth; });
         q.push_back(std::move(b));
         cv.notify_all();
     }
@@ -362,13 +363,87 @@ void parse_fastq(const std::string& path, BatchQueue& out) {
     cur.last = true;
     out.put(std::move(cur));
 }
+// The files of the samples to come are read while the index and the engine's tables are being made (seconds with a hundred
+// genomes: host work that leaves most cores idle) and while earlier samples are on their way: a manager thread starts the
+// readers of sample after sample, `concurrency` files at a time, until the text held would pass `budget` bytes; a lane that
+// reaches a sample takes its readers over (claim) or, if they were not started, reads it itself as before.
+struct SampleReaders {
+    std::deque<BatchQueue> queues;   // (a deque: BatchQueue holds a mutex and does not move)
+    std::vector<std::thread> readers;
+};
+class ReadAhead {
+public:
+    ReadAhead(const std::vector<std::vector<std::string>>& samples, unsigned concurrency, uint64_t budget)
+        : samples_(samples), state_(samples.size(), 0), held_(samples.size()), concurrency_(std::max(1u, concurrency)), budget_(budget) {
+        manager_ = std::thread([this] { run(); });
+    }
+    ~ReadAhead() {
+        { std::unique_lock<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        if (manager_.joinable()) manager_.join();
+        for (auto& h : held_) if (h) for (auto& t : h->readers) if (t.joinable()) t.join();
+    }
+    // the readers of sample i if it is being read ahead; otherwise nullptr, and it will not be
+    std::unique_ptr<SampleReaders> claim(size_t i) {
+        std::unique_lock<std::mutex> lk(m_);
+        if (state_[i] == 1) { state_[i] = 2; return std::move(held_[i]); }
+        state_[i] = 2;
+        return nullptr;
+    }
+private:
+    static uint64_t text_estimate(const std::vector<std::string>& mates) {   // bytes of sequence lines a sample's batches will hold
+        uint64_t n = 0;
+        for (const auto& p : mates) { struct stat st; if (stat(p.c_str(), &st) == 0) n += (uint64_t)st.st_size * 2; }   // (FASTQ text is ~3.5x its gzip, the sequence lines half of it)
+        return n;
+    }
+    void run() {
+        uint64_t used = 0;
+        for (size_t i = 0; i < samples_.size(); i++) {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [&] { return stop_ || active_ + samples_[i].size() <= concurrency_; });
+            if (stop_) return;
+            if (state_[i] != 0) continue;                 // a lane got there first
+            const uint64_t need = text_estimate(samples_[i]);
+            if (used + need > budget_) return;
+            used += need;
+            auto sr = std::unique_ptr<SampleReaders>(new SampleReaders);
+            for (size_t m = 0; m < samples_[i].size(); m++) { sr->queues.emplace_back(); sr->queues.back().unbounded = true; }
+            for (size_t m = 0; m < samples_[i].size(); m++) {
+                active_++;
+                sr->readers.emplace_back([this, i, m, q = &sr->queues[m]] {
+                    parse_fastq(samples_[i][m], *q);
+                    { std::unique_lock<std::mutex> lk2(m_); active_--; }
+                    cv_.notify_all();
+                });
+            }
+            state_[i] = 1;
+            held_[i] = std::move(sr);
+        }
+    }
+    const std::vector<std::vector<std::string>>& samples_;
+    std::vector<int> state_;                              // 0 not started, 1 being read ahead, 2 taken by its lane
+    std::vector<std::unique_ptr<SampleReaders>> held_;
+    unsigned concurrency_, active_ = 0;
+    uint64_t budget_;
+    bool stop_ = false;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::thread manager_;
+};
+
 // engs: one engine (the sample's reads all go there) or one per GPU of a sharded sample -- batches are dealt to them in turn
-uint64_t push_fastqs(const std::vector<bk_engine*>& engs, const std::vector<std::string>& mates) {
+uint64_t push_fastqs(const std::vector<bk_engine*>& engs, const std::vector<std::string>& mates, std::unique_ptr<SampleReaders> ahead = nullptr) {
     const size_t nm = mates.size();
     size_t n_batches = 0;
-    std::vector<BatchQueue> queues(nm);
-    std::vector<std::thread> readers;
-    for (size_t m = 0; m < nm; m++) readers.emplace_back(parse_fastq, std::cref(mates[m]), std::ref(queues[m]));
+    std::unique_ptr<SampleReaders> own;
+    if (!ahead) {
+        own.reset(new SampleReaders);
+        for (size_t m = 0; m < nm; m++) own->queues.emplace_back();
+        for (size_t m = 0; m < nm; m++) own->readers.emplace_back(parse_fastq, std::cref(mates[m]), std::ref(own->queues[m]));
+    }
+    SampleReaders& sr = ahead ? *ahead : *own;
+    std::deque<BatchQueue>& queues = sr.queues;
+    std::vector<std::thread>& readers = sr.readers;
     uint64_t n_reads = 0;
     std::string error;
     std::vector<bool> done(nm, false);
@@ -518,6 +593,22 @@ int run_call(const Args& a) {
         }
         struct stat st;
         if (stat(a.output.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) die(T, "Unable to create outputs in output directory 2");
+    }
+
+    // the samples, in input order; their files are read ahead from here on (ReadAhead): the index and the engine's tables take
+    // seconds to make with many genomes, and a lane's next sample need not wait for its previous one's reads
+    std::vector<std::vector<std::string>> samples;
+    for (const auto& r : a.reads) samples.push_back({r});
+    for (size_t i = 0; i < a.first_pairs.size(); i++) samples.push_back({a.first_pairs[i], a.second_pairs[i]});
+    {   // inflate threads per file (pargz.hpp) for what is read ahead: -t over the files that will be open at once
+        const size_t files = samples.size() * (a.first_pairs.empty() ? 1 : 2), open_files = std::max<size_t>(1, std::min<size_t>(files, (size_t)a.threads / 2));
+        g_inflate_threads = open_files > 8 ? 1u : (unsigned)std::max<size_t>(1, std::min<size_t>(64, (size_t)a.threads / open_files));
+        if (const char* it = getenv("BRONKO_INFLATE_THREADS")) g_inflate_threads = (unsigned)std::max(1, atoi(it));
+    }
+    std::unique_ptr<ReadAhead> ahead;
+    if (!getenv("BRONKO_NO_READ_AHEAD")) {
+        const uint64_t ram = (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)sysconf(_SC_PAGE_SIZE);
+        ahead.reset(new ReadAhead(samples, (unsigned)std::max<long>(2, a.threads / 2), std::min<uint64_t>(ram / 4, 32ull << 30)));
     }
 
     Index ix;
@@ -689,10 +780,10 @@ int run_call(const Args& a) {
     // complete (finalize on the GPU, download, pick the genome, call variants, write the files).  With several samples the two
     // halves of consecutive samples overlap: sample i+1 is ingested into a second engine on the same device tables
     // (bk_engine_fork) while a worker thread completes sample i.  Results are reported in input order.
-    auto ingest = [&](const std::vector<bk_engine*>& engs, const std::vector<std::string>& mates) -> uint64_t {
+    auto ingest = [&](const std::vector<bk_engine*>& engs, const std::vector<std::string>& mates, size_t sample_id) -> uint64_t {
         for (bk_engine* e : engs) hip_check(bk_sample_begin(e), "bk_sample_begin");
         uint64_t total_reads = 0;
-        try { total_reads = push_fastqs(engs, mates); }
+        try { total_reads = push_fastqs(engs, mates, ahead ? ahead->claim(sample_id) : nullptr); }
         catch (const std::exception& ex) { die(T, ex.what()); }
         LOG_INFO(T, std::to_string(total_reads) + " reads counted from " + mates[0]);
         return total_reads;
@@ -777,14 +868,11 @@ int run_call(const Args& a) {
         if (a.alignment) all_calls[sample_id] = SampleCalls{mates[0], gname, cs.breadth, cs.records};
     };
 
-    std::vector<std::vector<std::string>> samples;
-    for (const auto& r : a.reads) samples.push_back({r});
-    for (size_t i = 0; i < a.first_pairs.size(); i++) samples.push_back({a.first_pairs[i], a.second_pairs[i]});
     if (shard_mode) {
         for (size_t i = 0; i < samples.size(); i++) {
             const auto& mates = samples[i];
             LOG_INFO(T, mates.size() == 1 ? "Processing " + mates[0] : "Processing paired reads " + mates[0] + ", " + mates[1]);
-            ingest(shards.engs, mates);
+            ingest(shards.engs, mates, i);
             sharded_finalize(shards, (int)mates.size(), cells4);
             complete(shards.engs[0], mates, i, true);
         }
@@ -800,7 +888,7 @@ int run_call(const Args& a) {
             const auto& mates = samples[i];
             LOG_INFO(T, mates.size() == 1 ? "Processing " + mates[0] : "Processing paired reads " + mates[0] + ", " + mates[1]);
             bk_engine* e = (n & 1) ? ln.fork.e : ln.eng.e;   // (its previous sample, n - 2, was completed before sample n - 1's worker started)
-            ingest(std::vector<bk_engine*>{e}, mates);
+            ingest(std::vector<bk_engine*>{e}, mates, i);
             if (worker.joinable()) worker.join();
             worker = std::thread([&complete, e, &mates, i] { complete(e, mates, i); });
         }

@@ -1184,3 +1184,40 @@ def test_planes_are_clean_between_samples(oracle, sars_paths, monkeypatch, testi
                 eng.counters_ptr(0)                          # sharding one sample's reads needs the dense plane
         eng.close()
         ix.close()
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_every_genomes_rows_by_table_and_cell_by_cell(oracle, monkeypatch, testing_lib, paired):
+    """Every genome's rows of a many-genome index (touch lists forced) are cast three ways: through the table of voters per
+    (reference k-mer, window position) (voter_table_kernel + gather_table_kernel, with its bitmap of touched V rows), cell by cell
+    (gather_votes_kernel<false>: BK_NO_VOTE_TABLE), and cell by cell with 64-bit maxima (-cs above 2^32: gather_votes_kernel<true>,
+    which -cs >= 2^28 selects).  30 strains of HPV16 at k = 31 (alias keys, merged buckets) with one or two mate files: each equals
+    the oracle (call.rs:1305-1418), cell for cell, and the statistics."""
+    from bronko_amd import Params
+    monkeypatch.setenv("BK_SPARSE_FINALIZE", "1")
+    base = synth.read_fasta_bytes(os.path.join(helpers.GOLDEN, "HPV16.fa"))[:4000]
+    files = _mutated_strains(base, 30, 17, 40)
+    ix = oracle.Index.build_mem(31, files)
+    gm, isnv = synth.sample_genome(files[11][1][0][1], 19)
+    if paired:
+        c1, c2 = synth.paired_codes(gm, 9000, 150, 19, isnv=isnv)
+        mates = [synth.codes_to_ascii(c1), synth.codes_to_ascii(c2)]
+    else:
+        mates = [synth.codes_to_ascii(synth.single_end_codes(gm, 15000, 150, 19, isnv=isnv))]
+    results = []
+    for env, cs in (({}, None), ({"BK_NO_VOTE_TABLE": "1"}, None), ({}, 1 << 33)):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        prm = Params() if cs is None else Params(cs=cs)
+        pile = oracle.sample_pileup(ix, mates) if cs is None else oracle.sample_pileup(ix, mates, cs=cs)
+        eng = helpers.engine_from_oracle_index(ix, prm)
+        for rep in range(2):                                 # (twice: the table and the bitmap are per sample)
+            res = helpers.hip_sample(eng, mates, 31)
+            helpers.assert_same_pileup(res, pile)
+        results.append(res)
+        eng.close()
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    for x, y in zip(results[0].arrays(), results[1].arrays()):
+        assert np.array_equal(x, y)
+    ix.close()

@@ -2,7 +2,8 @@
 """`bronko call` end to end: FASTQ.gz files on disk -> VCFs, wall time of the whole command (gunzip + parse on host threads,
 PCIe, the GPU path, calls, output files).  Writes S synthetic samples of N reads (config-2 shape: wuhan_ref, 150 bp single-end,
 0.5 % errors) as real .fastq.gz files under a scratch directory, then times the binary with 1 lane and one inflate
-thread per file (zlib's gzread), 1 lane and the inflate threads -t allows (pargz.hpp), and the default lanes.
+thread per file (zlib's gzread), 1 lane and the inflate threads -t allows (pargz.hpp), the same with the files read ahead of their
+turn (the binary's default), and the default lanes.
 With a fourth argument N > 1 the references are N synthetic strains (wuhan_ref + 300 substitutions each, k = 31: BASELINE
 config 5's shape) written as FASTA files, sample s is derived from strain s mod N.
 usage: tools/cli_end_to_end.py [samples 16] [reads 1000000] [threads 32] [strains 1]"""
@@ -69,15 +70,18 @@ def main():
     NS = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     tmp = tempfile.mkdtemp(prefix="bronko_e2e_")
     refs, kk, paths = prepare(tmp, S, N, NS)
-    runs = [("1", "1"), ("1", None), (None, None)] if S > 1 else [("1", "1"), ("1", None)]
-    for lanes, inflate in runs:   # (lanes per device, inflate threads per file: None = the binary's own choice)
+    # (lanes per device, inflate threads per file, files read ahead of their turn): None = the binary's own choice
+    runs = [("1", "1", False), ("1", None, False), ("1", None, True), (None, None, True)] if S > 1 else [("1", "1", False), ("1", None, False), ("1", None, True)]
+    for lanes, inflate, ahead in runs:
         env = dict(os.environ)
-        env.pop("BRONKO_LANES", None); env.pop("BRONKO_INFLATE_THREADS", None)
+        env.pop("BRONKO_LANES", None); env.pop("BRONKO_INFLATE_THREADS", None); env.pop("BRONKO_NO_READ_AHEAD", None)
         if lanes:
             env["BRONKO_LANES"] = lanes
         if inflate:
             env["BRONKO_INFLATE_THREADS"] = inflate
-        out = os.path.join(tmp, "out_%s_%s" % (lanes or "default", inflate or "default"))
+        if not ahead:
+            env["BRONKO_NO_READ_AHEAD"] = "1"
+        out = os.path.join(tmp, "out_%s_%s_%d" % (lanes or "default", inflate or "default", ahead))
         t0 = time.time()
         r = subprocess.run([BIN, "call", "-g"] + refs + ["-r"] + paths + kk + ["-t", str(T), "-o", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         dt = time.time() - t0
@@ -86,9 +90,9 @@ def main():
             raise SystemExit("bronko call failed")
         n_vcf = len([f for f in os.listdir(out) if f.endswith(".vcf")])
         how = [ln.split("] ", 1)[-1] for ln in r.stdout.decode().splitlines() if "inflated on" in ln]
-        print("bronko call, %d reference genome(s), %s lanes per device, %s (-t %d): %.2f s wall for %d samples (%d VCFs) = %.2f M reads/s end to end" %
-              (len(refs), lanes or "default", how[0] if how else "one inflate thread per file", T, dt, S, n_vcf, S * N / dt / 1e6), flush=True)
-    bodies = [open(os.path.join(tmp, "out_%s_%s" % (l or "default", i or "default"), "sample00.vcf")).read().split("\n", 3)[-1] for l, i in runs]
+        print("bronko call, %d reference genome(s), %s lanes per device, %s, files %s (-t %d): %.2f s wall for %d samples (%d VCFs) = %.2f M reads/s end to end" %
+              (len(refs), lanes or "default", how[0] if how else "one inflate thread per file", "read ahead" if ahead else "read in their turn", T, dt, S, n_vcf, S * N / dt / 1e6), flush=True)
+    bodies = [open(os.path.join(tmp, "out_%s_%s_%d" % (l or "default", i or "default", ah), "sample00.vcf")).read().split("\n", 3)[-1] for l, i, ah in runs]
     print("same VCF body in every run:", all(b == bodies[0] for b in bodies))
     subprocess.run(["rm", "-rf", tmp])
 

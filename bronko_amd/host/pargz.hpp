@@ -38,6 +38,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -51,6 +52,7 @@ namespace pargz {
 constexpr uint32_t kWin = 32768;            // deflate's window
 constexpr uint16_t kUnknown = 0x8000;       // symbol: kUnknown | position in the window before the chunk (0 = 32 KB back)
 constexpr uint64_t kNone = ~0ull;
+constexpr size_t kMaxChunkText = 192u << 20;   // symbols of one chunk before it ends its wave (a 2 MB chunk of FASTQ is 8 MB of text)
 
 struct Corrupt : std::runtime_error { using std::runtime_error::runtime_error; };
 
@@ -498,6 +500,9 @@ inline void inflate_chunk(const uint8_t* file, uint64_t n_bytes, std::vector<Chu
                 else break;
             }
             if (m < cs.size() && cs[m].start == b) { c.stop = b; c.next = (int)m; return; }
+            // text far out of proportion to its gzip (long runs of one symbol): the wave ends here, what later chunks made of it is
+            // dropped and the next wave starts from this boundary -- memory stays bounded, such a file is read chunk by chunk
+            if (c.sym.n > kMaxChunkText) { c.stop = b; c.next = -1; return; }
             if (m == cs.size() && b >= wave_end) { c.stop = b; c.next = -1; return; }
         }
     } catch (const Corrupt& e) {
@@ -549,10 +554,16 @@ inline void parallel_for(size_t n, unsigned threads, F f) {
     if (nt == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
     std::atomic<size_t> next{0};
     std::vector<std::thread> ts;
-    auto work = [&] { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); };
+    std::exception_ptr first;          // (an exception that left a thread would end the process: the first one is thrown again behind the join)
+    std::mutex em;
+    auto work = [&] {
+        try { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); }
+        catch (...) { std::unique_lock<std::mutex> lk(em); if (!first) first = std::current_exception(); next = n; }
+    };
     for (unsigned t = 1; t < nt; t++) ts.emplace_back(work);
     work();
     for (auto& t : ts) t.join();
+    if (first) std::rethrow_exception(first);
 }
 
 }  // namespace pargz
@@ -668,7 +679,9 @@ private:
                 uint32_t bs = 0;
                 const uint64_t d = pargz::member_header(file_, at, n_, &bs);
                 if (d == pargz::kNone) { if (at == 0) { finish("not a gzip file, or damaged"); return false; } at = n_; break; }   // (trailing bytes: ignored)
-                if (!bs || at + bs > n_ || at + bs < d + 8) {       // a member that is not BGZF: the rest goes the general way
+                uint32_t isz = 0;
+                if (bs && at + bs <= n_ && at + bs >= d + 8) memcpy(&isz, file_ + at + bs - 4, 4);
+                if (!bs || at + bs > n_ || at + bs < d + 8 || isz > 65536u) {   // a member that is not BGZF (whose text is at most 64 KB): the rest goes the general way
                     if (!flush_bgzf(jobs)) return false;
                     deflate_waves(d * 8u);
                     return false;

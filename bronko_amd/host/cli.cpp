@@ -344,11 +344,12 @@ struct BatchQueue {
 };
 // threads a FASTQ file's inflate may take (pargz.hpp): -t over the files that are read at the same time (set by call)
 unsigned g_inflate_threads = 1;
-void parse_fastq(const std::string& path, BatchQueue& out) {
+unsigned g_ahead_inflate_threads = 1;   // ... for the files that are read ahead of their turn: -t over the files ReadAhead has open at once
+void parse_fastq(const std::string& path, BatchQueue& out, unsigned inflate_threads) {
     constexpr uint64_t kBatchReads = 1u << 16;   // (10 MB of bases: the engine pins three staging slots of that size per lane)
     FastqBatch cur;
     try {
-        GzLineReader in(path, g_inflate_threads);
+        GzLineReader in(path, inflate_threads);
         uint64_t n = 0;
         for (uint64_t ln = 0;; ln++) {               // 4-line FASTQ records: @id / sequence / + / quality
             if ((ln & 3) != 1) { if (!in.skip_next()) break; continue; }
@@ -381,6 +382,10 @@ public:
         manager_ = std::thread([this] { run(); });
     }
     bool covers_all() const { return covers_all_; }   // every sample's text fits the budget: the lanes only push
+    void set_concurrency(unsigned n) {                // (few files at a time while the engine's tables are made on the same cores, more behind that)
+        { std::unique_lock<std::mutex> lk(m_); concurrency_ = std::max(1u, n); }
+        cv_.notify_all();
+    }
     ~ReadAhead() {
         { std::unique_lock<std::mutex> lk(m_); stop_ = true; }
         cv_.notify_all();
@@ -415,7 +420,7 @@ private:
             for (size_t m = 0; m < samples_[i].size(); m++) {
                 active_++;
                 sr->readers.emplace_back([this, i, m, q = &sr->queues[m]] {
-                    parse_fastq(samples_[i][m], *q);
+                    parse_fastq(samples_[i][m], *q, g_ahead_inflate_threads);
                     { std::unique_lock<std::mutex> lk2(m_); active_--; }
                     cv_.notify_all();
                 });
@@ -443,7 +448,7 @@ uint64_t push_fastqs(const std::vector<bk_engine*>& engs, const std::vector<std:
     if (!ahead) {
         own.reset(new SampleReaders);
         for (size_t m = 0; m < nm; m++) own->queues.emplace_back();
-        for (size_t m = 0; m < nm; m++) own->readers.emplace_back(parse_fastq, std::cref(mates[m]), std::ref(own->queues[m]));
+        for (size_t m = 0; m < nm; m++) own->readers.emplace_back(parse_fastq, std::cref(mates[m]), std::ref(own->queues[m]), g_inflate_threads);
     }
     SampleReaders& sr = ahead ? *ahead : *own;
     std::deque<BatchQueue>& queues = sr.queues;
@@ -606,13 +611,14 @@ int run_call(const Args& a) {
     for (size_t i = 0; i < a.first_pairs.size(); i++) samples.push_back({a.first_pairs[i], a.second_pairs[i]});
     {   // inflate threads per file (pargz.hpp) for what is read ahead: -t over the files that will be open at once
         const size_t files = samples.size() * (a.first_pairs.empty() ? 1 : 2), open_files = std::max<size_t>(1, std::min<size_t>(files, (size_t)a.threads / 2));
-        g_inflate_threads = open_files > 8 ? 1u : (unsigned)std::max<size_t>(1, std::min<size_t>(64, (size_t)a.threads / open_files));
-        if (const char* it = getenv("BRONKO_INFLATE_THREADS")) g_inflate_threads = (unsigned)std::max(1, atoi(it));
+        g_ahead_inflate_threads = open_files > 8 ? 1u : (unsigned)std::max<size_t>(1, std::min<size_t>(64, (size_t)a.threads / open_files));
+        if (const char* it = getenv("BRONKO_INFLATE_THREADS")) g_ahead_inflate_threads = (unsigned)std::max(1, atoi(it));
+        g_inflate_threads = g_ahead_inflate_threads;
     }
     std::unique_ptr<ReadAhead> ahead;
     if (!getenv("BRONKO_NO_READ_AHEAD")) {
         const uint64_t ram = (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)sysconf(_SC_PAGE_SIZE);
-        ahead.reset(new ReadAhead(samples, (unsigned)std::max<long>(2, a.threads / 2), std::min<uint64_t>(ram / 4, 32ull << 30)));
+        ahead.reset(new ReadAhead(samples, (unsigned)std::max<long>(2, a.threads / 8), std::min<uint64_t>(ram / 4, 32ull << 30)));
     }
 
     Index ix;
@@ -627,6 +633,9 @@ int run_call(const Args& a) {
         if (ix.k != a.kmer)
             die(T, "Database k is not the same as provided, please set -k to " + std::to_string(ix.k) + " or build a new index");
     }
+    // (a few genomes: the engine's tables are made in a fraction of a second, the cores are the readers' from here on; with many
+    // the readers stay few until the engines stand -- bk_engine_create runs on all cores for seconds)
+    if (ahead && ix.files.size() <= 8) ahead->set_concurrency((unsigned)std::max<long>(2, a.threads / 2));
 
     // decoded index -> GPU engine(s) (include/bronko_hip.h).  Samples are independent (call.rs:212 / :297 handle them one after
     // the other), so whole samples are dealt to *lanes* in turn -- no collective.  A lane is a host thread that ingests its
@@ -770,6 +779,7 @@ int run_call(const Args& a) {
         g_inflate_threads = open_files > 8 ? 1u : (unsigned)std::max<size_t>(1, std::min<size_t>(64, (size_t)a.threads / open_files));
         if (const char* it = getenv("BRONKO_INFLATE_THREADS")) g_inflate_threads = (unsigned)std::max(1, atoi(it));
         if (g_inflate_threads > 1) LOG_INFO(T, "gzip input is inflated on " + std::to_string(g_inflate_threads) + " threads per file");
+        if (ahead) ahead->set_concurrency((unsigned)std::max<long>(2, a.threads / 2));   // (the engines are made: the cores are the readers')
     }
     CallParams cp;
     cp.k = (int)a.kmer; cp.min_af = a.min_af; cp.no_end_filter = a.no_end_filter; cp.no_strand_filter = a.no_strand_filter;

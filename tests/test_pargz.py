@@ -170,3 +170,44 @@ def test_damage_is_an_error(cat, tmp_path):
     open(p, "wb").write(b"plain text, no gzip\n")
     rc, out, err = run(cat, p, 8)
     assert rc == 1
+
+
+def test_random_texts_members_and_chunkings(cat, tmp_path):
+    """Forty random files: FASTQ-like, FASTA-like and mixed text of random sizes, compression levels, member cuts and flush points,
+    read back with random thread counts and chunk sizes -- always the bytes zlib gives."""
+    rng = np.random.default_rng(20261003)
+    p = str(tmp_path / "r.gz")
+    base = fastq_text(12000, 3)
+    for it in range(40):
+        kind = int(rng.integers(0, 4))
+        n = int(rng.integers(1, 3500000))
+        if kind == 0:
+            t = base[:n]
+        elif kind == 1:                                              # FASTA: long lines of ACGT with few repeats
+            t = b">seq\n" + bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n)) + b"\n"
+        elif kind == 2:                                              # reads that repeat each other closely (amplicon depth)
+            unit = base[:int(rng.integers(500, 40000))]
+            t = (unit * (n // len(unit) + 1))[:n]
+        else:                                                        # text with stretches that are none
+            t = base[:n // 2] + bytes(rng.integers(0, 256, int(rng.integers(1, 70000)), dtype=np.uint8)) + base[n // 2:n]
+        level = int(rng.choice([1, 2, 5, 6, 9]))
+        cuts = sorted(set([0, len(t)] + [int(x) for x in rng.integers(0, len(t) + 1, int(rng.integers(0, 4)))]))
+        data = b""
+        for a_, b_ in zip(cuts[:-1], cuts[1:]):
+            co = zlib.compressobj(level, zlib.DEFLATED, 31)
+            part = t[a_:b_]
+            fl = sorted(set(int(x) for x in rng.integers(0, len(part) + 1, int(rng.integers(0, 3)))))
+            prev = 0
+            for f_ in fl:
+                data += co.compress(part[prev:f_]) + co.flush(int(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH])))
+                prev = f_
+            data += co.compress(part[prev:]) + co.flush()
+        if not data:
+            data = gzip.compress(b"")
+        open(p, "wb").write(data)
+        assert gzip.decompress(data) == t
+        threads = int(rng.choice([1, 2, 3, 8, 13]))
+        chunk = int(rng.choice([0, 0, 17000, 65536, 250000, 1 << 20]))
+        rc, out, err = run(cat, p, threads, chunk)
+        assert rc == 0, (it, err)
+        assert out == t, (it, kind, n, level, cuts, threads, chunk)

@@ -287,13 +287,13 @@ def test_call_reads_inflated_on_several_threads(golden_dir, tmp_path):
             for i, r in enumerate(rs):
                 f.write(b"@%s_%d\n%s\n+\n%s\n" % (tag.encode(), i, r, (rng.integers(0, 8, len(r)) * 5 + 35).astype(np.uint8).tobytes()))
     outs = []
-    for name, env in (("one", {"BRONKO_INFLATE_THREADS": "1"}), ("many", {})):
+    for name, env in (("one", {"BRONKO_INFLATE_THREADS": "1"}), ("many", {}), ("in_turn", {"BRONKO_NO_READ_AHEAD": "1"})):   # (in_turn: files opened when their sample's turn comes)
         out = str(tmp_path / name)
         res = subprocess.run([BRONKO, "call", "-d", os.path.join(golden_dir, "hpv.bkdb"), "-1", p1, "-2", p2, "--pileup", "-o", out, "-t", "16"],
                              capture_output=True, text=True, env={**os.environ, **env})
         assert res.returncode == 0, res.stdout + res.stderr
-        assert ("inflated on 8 threads" in res.stdout + res.stderr) == (name == "many")
+        assert ("inflated on 8 threads" in res.stdout + res.stderr) == (name != "one")
         outs.append({f: open(os.path.join(out, f), "rb").read() for f in sorted(os.listdir(out))})
-    assert outs[0].keys() == outs[1].keys() and len(outs[0]) >= 3
+    assert outs[0].keys() == outs[1].keys() == outs[2].keys() and len(outs[0]) >= 3
     for f in outs[0]:
-        assert outs[0][f] == outs[1][f], f
+        assert outs[0][f] == outs[1][f] == outs[2][f], f

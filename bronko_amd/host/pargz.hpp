@@ -12,6 +12,7 @@
 //   2. from there it inflates into 16-bit symbols: a byte, or "whatever stood at position p of the 32 KB window before this
 //      chunk" -- copies carry such symbols along like bytes -- and stops at the boundary the next chunk's thread started from (a
 //      start that turns out not to be a boundary of the real stream is run over, and that chunk's work dropped);
+//      a wave's first chunk starts where the text is known and is inflated straight into bytes (ByteBuf);
 //      (amplicon reads repeat what was read a few KB before: most of a chunk's text is copies of copies that lead back into the
 //      unknown window -- a list of the unknowns' places instead of a symbol per byte was tried and is 25x slower on such data);
 //   3. the chunks' last 32 KB are resolved one after the other (each needs the one before), then every chunk is turned into bytes
@@ -342,11 +343,37 @@ struct SymBuf {
     }
 };
 
+// A chunk that starts where the text before it is known -- a wave's first, and every chunk when one thread does the work -- needs no
+// symbols: it is inflated straight into bytes, the 32 KB before it copied in front of the buffer so that early copies find them.
+struct ByteBuf {
+    Block b;
+    uint8_t* d = nullptr;        // the chunk's text; d[-before .. 0) is the text before it
+    size_t n = 0, cap = 0;
+    uint32_t before = 0;
+    void start(const uint8_t* window, size_t n_window, size_t want) {
+        b = BlockPool::get().take(kWin + want);
+        d = reinterpret_cast<uint8_t*>(b.p) + kWin; cap = b.cap - kWin; n = 0;
+        before = (uint32_t)std::min<size_t>(n_window, kWin);
+        if (before) memcpy(d - before, window + (n_window - before), before);
+    }
+    void room(size_t extra) {
+        if (n + extra <= cap) return;
+        Block nb = BlockPool::get().take(kWin + std::max<size_t>(cap * 2, n + extra + (1u << 16)));
+        memcpy(nb.p + kWin - before, d - before, before + n);
+        b = std::move(nb);
+        d = reinterpret_cast<uint8_t*>(b.p) + kWin; cap = b.cap - kWin;
+    }
+};
+template <class B> struct BufTraits;
+template <> struct BufTraits<SymBuf> { typedef uint16_t sym; static constexpr bool symbolic = true; static uint32_t before(const SymBuf&) { return 0u; } };
+template <> struct BufTraits<ByteBuf> { typedef uint8_t sym; static constexpr bool symbolic = false; static uint32_t before(const ByteBuf& b) { return b.before; } };
+
 inline bool text_byte(uint32_t b) { return (b >= 32 && b < 127) || b == '\n' || b == '\r' || b == '\t'; }
 
 // One block's data behind its header.  TEXT: stop with false at a byte that is no text (the test of a candidate boundary).
-template <bool TEXT>
-inline bool inflate_block(Bits& in, const Codes& c, SymBuf& out, size_t max_out) {
+template <bool TEXT, class B>
+inline bool inflate_block(Bits& in, const Codes& c, B& out, size_t max_out) {
+    typedef typename BufTraits<B>::sym sym_t;
     const uint32_t* lt = c.lit.e.data();
     const uint32_t* dt = c.dist.e.data();
     for (;;) {
@@ -359,13 +386,13 @@ inline bool inflate_block(Bits& in, const Codes& c, SymBuf& out, size_t max_out)
         in.take(e & 0xffu);
         if (e & kLit) {
             if (TEXT && !text_byte(e >> 16)) return false;
-            out.d[out.n++] = (uint16_t)(e >> 16);
+            out.d[out.n++] = (sym_t)(e >> 16);
             // a second literal from the same refill (codes are at most 15 bits: 56 - 15 - 15 > 15)
             e = lt[in.peek(kPrimLit)];
             if ((e & (kKindMask)) == kLit) {
                 if (TEXT && !text_byte(e >> 16)) return false;
                 in.take(e & 0xffu);
-                out.d[out.n++] = (uint16_t)(e >> 16);
+                out.d[out.n++] = (sym_t)(e >> 16);
             }
             continue;
         }
@@ -379,20 +406,20 @@ inline bool inflate_block(Bits& in, const Codes& c, SymBuf& out, size_t max_out)
         if (d & kBad) return false;
         in.take(d & 0xffu);
         const uint32_t dist = (d >> 16) + in.get((d >> 12) & 15u);
-        uint16_t* o = out.d + out.n;
-        if (dist <= out.n) {
-            const uint16_t* s = o - dist;
-            if (dist >= len) memcpy(o, s, len * sizeof(uint16_t));
+        sym_t* o = out.d + out.n;
+        if (dist <= out.n + BufTraits<B>::before(out)) {             // (bytes: the text before the chunk lies in front of the buffer)
+            const sym_t* s = o - dist;
+            if (dist >= len) memcpy(o, s, len * sizeof(sym_t));
             else for (uint32_t i = 0; i < len; i++) o[i] = s[i];
-        } else {
+        } else if constexpr (BufTraits<B>::symbolic) {
             // reaches into the window before the chunk
             const uint32_t before = dist - (uint32_t)out.n;          // symbols back from the chunk's start, first one copied
             if (before > kWin) return false;
             for (uint32_t i = 0; i < len; i++) {
                 const int64_t src = (int64_t)out.n + i - dist;
-                o[i] = src >= 0 ? out.d[(size_t)src] : (uint16_t)(kUnknown | (uint32_t)(kWin + src));
+                o[i] = src >= 0 ? out.d[(size_t)src] : (sym_t)(kUnknown | (uint32_t)(kWin + src));
             }
-        }
+        } else return false;                                         // a distance before the start of the text
         out.n += len;
     }
 }
@@ -445,18 +472,22 @@ struct Chunk {
     bool failed = false;      // ran into something that is no deflate data (the stream, or a start that was no boundary)
     std::string what;
     SymBuf sym;
+    ByteBuf raw;              // ... or its text itself, if it was inflated from a known window (as_bytes)
+    bool as_bytes = false;
+    size_t text_len() const { return as_bytes ? raw.n : sym.n; }
     std::vector<MemberEnd> ends;
     Piece bytes;
     std::vector<uint32_t> seg_crc;   // CRC-32 of the stretches between member ends (ends.size() + 1 of them)
 };
 
 // Blocks from `c.start` on, up to the boundary another chunk of the wave starts from, or the first one at or behind `wave_end`.
-inline void inflate_chunk(const uint8_t* file, uint64_t n_bytes, std::vector<Chunk>& cs, size_t me, uint64_t wave_end) {
+template <class B>
+inline void inflate_chunk_into(const uint8_t* file, uint64_t n_bytes, std::vector<Chunk>& cs, size_t me, uint64_t wave_end, B& out) {
     Chunk& c = cs[me];
     Bits in;
     in.open(file, n_bytes);
     in.seek(c.start);
-    c.sym.room((size_t)(((me + 1 < cs.size() ? cs[me + 1].nominal : wave_end) - std::min(c.start, wave_end)) / 8u) * 5u);   // (text is ~4x its gzip)
+    out.room((size_t)(((me + 1 < cs.size() ? cs[me + 1].nominal : wave_end) - std::min(c.start, wave_end)) / 8u) * 5u);   // (text is ~4x its gzip)
     size_t m = me + 1;
     Codes dyn;
     try {
@@ -470,22 +501,22 @@ inline void inflate_chunk(const uint8_t* file, uint64_t n_bytes, std::vector<Chu
                 if ((len ^ 0xffffu) != nlen) throw Corrupt("stored block length");
                 const uint64_t at = in.pos() >> 3;
                 if (at + len > n_bytes) throw Corrupt("stored block runs past the end");
-                c.sym.room(len);
-                for (uint32_t i = 0; i < len; i++) c.sym.d[c.sym.n + i] = file[at + i];
-                c.sym.n += len;
+                out.room(len);
+                for (uint32_t i = 0; i < len; i++) out.d[out.n + i] = file[at + i];
+                out.n += len;
                 in.seek((at + len) * 8u);
             } else if (type == 1) {
-                if (!inflate_block<false>(in, fixed_codes(), c.sym, ~(size_t)0)) throw Corrupt("bad data");
+                if (!inflate_block<false>(in, fixed_codes(), out, ~(size_t)0)) throw Corrupt("bad data");
             } else if (type == 2) {
                 if (!read_dynamic_header(in, dyn)) throw Corrupt("bad code lengths");
-                if (!inflate_block<false>(in, dyn, c.sym, ~(size_t)0)) throw Corrupt("bad data");
+                if (!inflate_block<false>(in, dyn, out, ~(size_t)0)) throw Corrupt("bad data");
             } else throw Corrupt("bad block type");
             if (final) {
                 in.take(in.cnt & 7u);
                 uint64_t at = in.pos() >> 3;
                 if (at + 8 > n_bytes) throw Corrupt("no trailer");
                 MemberEnd me_;
-                me_.at = c.sym.n;
+                me_.at = out.n;
                 memcpy(&me_.crc, file + at, 4); memcpy(&me_.isize, file + at + 4, 4);
                 c.ends.push_back(me_);
                 const uint64_t nx = member_header(file, at + 8, n_bytes);
@@ -502,12 +533,17 @@ inline void inflate_chunk(const uint8_t* file, uint64_t n_bytes, std::vector<Chu
             if (m < cs.size() && cs[m].start == b) { c.stop = b; c.next = (int)m; return; }
             // text far out of proportion to its gzip (long runs of one symbol): the wave ends here, what later chunks made of it is
             // dropped and the next wave starts from this boundary -- memory stays bounded, such a file is read chunk by chunk
-            if (c.sym.n > kMaxChunkText) { c.stop = b; c.next = -1; return; }
+            if (out.n > kMaxChunkText) { c.stop = b; c.next = -1; return; }
             if (m == cs.size() && b >= wave_end) { c.stop = b; c.next = -1; return; }
         }
     } catch (const Corrupt& e) {
         c.failed = true; c.what = e.what();
     }
+}
+
+inline void inflate_chunk(const uint8_t* file, uint64_t n_bytes, std::vector<Chunk>& cs, size_t me, uint64_t wave_end) {
+    if (cs[me].as_bytes) inflate_chunk_into(file, n_bytes, cs, me, wave_end, cs[me].raw);
+    else inflate_chunk_into(file, n_bytes, cs, me, wave_end, cs[me].sym);
 }
 
 // The first boundary at or behind bit `from`, before `to` (the test of the header comment); kNone if there is none.
@@ -739,6 +775,8 @@ private:
             for (size_t i = 0; i < cs.size(); i++) cs[i].nominal = bit + (uint64_t)i * cb * 8u;
             const uint64_t wave_end = std::min(total_bits, bit + (uint64_t)cs.size() * cb * 8u);
             cs[0].start = bit;
+            cs[0].as_bytes = true;       // the text before it is known: inflated straight into bytes
+            cs[0].raw.start(window.data(), window.size(), (size_t)cb * 5u);
             const auto t0 = std::chrono::steady_clock::now();
             parallel_for(cs.size() - 1, threads_, [&](size_t i) {
                 Chunk& c = cs[i + 1];
@@ -761,14 +799,15 @@ private:
                 wins[x] = window;
                 const Chunk& c = cs[chain[x]];
                 if (c.failed) break;
-                const size_t n = c.sym.n, keep = std::min<size_t>(n, kWin);
+                const size_t n = c.text_len(), keep = std::min<size_t>(n, kWin);
                 std::vector<uint8_t> nw;
                 nw.reserve(kWin);
                 if (keep < kWin && !window.empty()) {
                     const size_t from_old = std::min<size_t>(kWin - keep, window.size());
                     nw.insert(nw.end(), window.end() - from_old, window.end());
                 }
-                for (size_t i = n - keep; i < n; i++) {
+                if (c.as_bytes) nw.insert(nw.end(), c.raw.d + (n - keep), c.raw.d + n);
+                else for (size_t i = n - keep; i < n; i++) {
                     const uint16_t s = c.sym.d[i];
                     if (s < 256) nw.push_back((uint8_t)s);
                     else {
@@ -781,24 +820,33 @@ private:
                 window.swap(nw);
             }
             // symbols -> bytes and CRCs, every chunk on its own
-            for (size_t x = 0; x < chain.size(); x++) if (!cs[chain[x]].failed) cs[chain[x]].bytes = fresh(cs[chain[x]].sym.n + 1);
+            for (size_t x = 0; x < chain.size(); x++) {
+                Chunk& c = cs[chain[x]];
+                if (c.failed) continue;
+                if (c.as_bytes) {                                    // its buffer is the piece
+                    c.bytes.b = std::move(c.raw.b);
+                    c.bytes.d = reinterpret_cast<char*>(c.raw.d); c.bytes.n = c.raw.n; c.bytes.cap = c.raw.cap;
+                    c.raw.d = nullptr;
+                } else c.bytes = fresh(c.sym.n + 1);
+            }
             std::atomic<bool> bad{false};
             parallel_for(chain.size(), threads_, [&](size_t x) {
                 Chunk& c = cs[chain[x]];
                 if (c.failed) return;
                 const std::vector<uint8_t>& w = wins[x];
                 const size_t missing = kWin - w.size();
-                c.bytes.n = c.sym.n;
+                if (!c.as_bytes) c.bytes.n = c.sym.n;
                 const uint16_t* s = c.sym.d;
                 char* o = c.bytes.d;
                 // symbol -> byte through a table (64 KB: the bytes themselves and the window); with amplicon reads most of a chunk is unknowns
                 std::unique_ptr<uint8_t[]> lut;
-                if (missing == 0) {
+                if (missing == 0 && !c.as_bytes) {
                     lut.reset(new uint8_t[65536]);
                     for (unsigned v = 0; v < 256; v++) lut[v] = (uint8_t)v;
                     memcpy(lut.get() + kUnknown, w.data(), kWin);
                 }
                 auto resolve = [&](size_t i, const size_t end) {
+                    if (c.as_bytes) return;
                     if (lut) { const uint8_t* t = lut.get(); for (; i < end; i++) o[i] = (char)t[s[i]]; return; }
                     for (; i + 16 <= end; i += 16) {                 // sixteen plain bytes at a time where there are
                         uint16_t any = 0;

@@ -512,9 +512,17 @@ static int alloc_sample_state(bk_engine* e) {
         BK_HIP(e->n_alias_hits.alloc(2));
         BK_HIP(e->last_sel.upload(std::vector<int>(1, -1)));
         BK_HIP(hipMemset(e->pileup.p, 0, std::max<size_t>(e->pileup.n, 1) * sizeof(unsigned long long)));   // (selected-only: the rows of genomes never selected stay zero)
+        // every genome's rows by the table of voters (bk_gather.hip): the table and the touched-row bits are this engine's for its
+        // lifetime -- allocated here, never inside a sample (a hipMalloc synchronises the device: siblings in flight would stall)
+        const bool two_pass = prm->pileup_selected_only != 0 && e->n_files > 1;
+        if (!two_pass && prm->cs < (1ull << 28) && e->total_cells >= 2 * (uint64_t)e->n_full && !test_env("BK_NO_VOTE_TABLE")) {
+            BK_HIP(e->row_bits.alloc((size_t)((bk::v_real_rows(e->n_full, e->v_span) + 31) / 32) + 1));
+            BK_HIP(e->vote_tab.alloc(bk::vote_table_words(e->view())));
+        }
     }
     BK_HIP(e->stats.alloc((size_t)2 * e->n_files * 3));
     BK_HIP(e->present.alloc((size_t)2 * e->n_files));
+    if (prm->pileup_selected_only != 0 && e->n_files > 1) BK_HIP(e->sel_out.alloc(1));   // (the genome selected between the two finalize passes)
     BK_HIP(e->kstats.alloc(8));
     // the scan: binned (items) when the planes are dense, the window's reference is staged in LDS and the bins are few enough;
     // else the whole-window difference array of scan_count_kernel with its slabs
@@ -2471,7 +2479,6 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
     // genome is selected on the device (call.rs:422-502), then the votes -- only the BucketInfos of that genome
     const bool two_pass = e->params.pileup_selected_only != 0 && e->n_files > 1;
     if (two_pass && (elem_lo != 0 || elem_hi != e->plane_len)) return fail(BK_ERR_UNSUPPORTED, "pileup_selected_only cannot be combined with a sharded finalize");
-    if (two_pass && !e->sel_out.p) BK_HIP(e->sel_out.alloc(1));
     if (e->sparse && (elem_lo != 0 || elem_hi != e->plane_len)) return fail(BK_ERR_UNSUPPORTED, "an index this large cannot be finalized in shards");
     const bool via_reduced = e->reduced_shards[0] > 0 || e->reduced_shards[1] > 0;   // (the planes themselves are not what is mapped: they are zeroed at the next push)
     const bool clean_dense = !e->sparse && elem_lo == 0 && elem_hi == e->plane_len && !via_reduced;   // this call maps whole planes: it leaves them zeroed
@@ -2501,10 +2508,8 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             if (int rc = dbg_sync("statistics pass")) return rc;
             // (every genome's rows by the table of voters: which V rows the sample's mate files touched, as bits)
             unsigned int* row_bits = nullptr;
-            if (!two_pass && e->params.cs < (1ull << 28) && e->total_cells >= 2 * (uint64_t)e->n_full && !test_env("BK_NO_VOTE_TABLE")) {
-                const size_t words = (size_t)((bk::v_real_rows(e->n_full, e->v_span) + 31) / 32) + 1;
-                if (e->row_bits.n < words) BK_HIP(e->row_bits.alloc(words));
-                BK_HIP(hipMemsetAsync(e->row_bits.p, 0, words * sizeof(unsigned int), e->stream));
+            if (e->row_bits.p) {   // (allocated with the engine: alloc_sample_state)
+                BK_HIP(hipMemsetAsync(e->row_bits.p, 0, e->row_bits.n * sizeof(unsigned int), e->stream));
                 row_bits = e->row_bits.p;
             }
             for (int m = 0; m < n_mates; m++) bk::launch_prefix_rows(e->counters[m].p, e->view(), e->v_list[m].p, e->n_list[m].p, row_bits, e->stream);
@@ -2562,8 +2567,7 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
             if (gather && pass == 1 && m == 0) {   // (both mate files' counts at once: it stores)
                 const unsigned long long* c1 = n_mates == 2 ? e->counters[1].p : nullptr;
                 // many genomes that share their k-mers: the voters once per (k-mer, window position), not once per occurrence
-                const bool by_table = bk::vote_table_fits(a) && e->total_cells >= 2 * (uint64_t)e->n_full && !test_env("BK_NO_VOTE_TABLE") && e->row_bits.p;
-                if (by_table && e->vote_tab.n < bk::vote_table_words(a.ix)) BK_HIP(e->vote_tab.alloc(bk::vote_table_words(a.ix)));
+                const bool by_table = bk::vote_table_fits(a) && e->row_bits.p && e->vote_tab.n >= bk::vote_table_words(a.ix);
                 if (by_table) bk::launch_gather_votes_table(a, c1, e->vote_tab.p, e->row_bits.p, e->stream);
                 else bk::launch_gather_votes(a, c1, e->stream);
                 if (int rc = dbg_sync("gather_votes")) return rc;

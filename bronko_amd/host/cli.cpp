@@ -8,6 +8,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <chrono>
 #include <condition_variable>
@@ -306,6 +307,13 @@ void hip_check(int rc, const char* what) {
 // inflated and parsed by its own host thread (upstream runs the two KMC processes of a pair concurrently too,
 // call.rs:301-307); the engine is only ever called from this thread.  Returns reads seen.
 struct FastqBatch { std::string buf; std::vector<uint64_t> off{0}; bool last = false; std::string error; };
+// The sequence text that samples read ahead of their turn hold in their queues, all of them together: counted as it is queued
+// (a batch's real bytes, not an estimate from the compressed size: amplicon FASTQ inflates 8-10x), released as lanes consume.
+struct AheadGate {
+    std::mutex m;
+    std::condition_variable cv;
+    uint64_t held = 0, budget = 0;
+};
 struct BatchQueue {
     std::mutex m;
     std::condition_variable cv;
@@ -313,20 +321,50 @@ struct BatchQueue {
     std::vector<FastqBatch> spare;   // consumed batches, handed back: their 40 MB buffers are reused instead of being unmapped and
                                      // mapped again (with dozens of lanes the page faults of fresh buffers cost more than the parsing)
     static constexpr size_t kDepth = 3;
-    bool unbounded = false;          // a sample read ahead of its turn (ReadAhead below): the whole file may wait here
+    // A sample read ahead of its turn (ReadAhead below): the whole file may wait here as long as the gate has room.  Once a lane has
+    // claimed the sample the queue is an ordinary one again (kDepth batches ahead of the lane) and no longer waits for the gate: the
+    // lane must never wait for text that later samples' queues hold.
+    AheadGate* gate = nullptr;
+    std::atomic<bool> claimed{false};
+    std::atomic<bool> abandoned{false};   // nobody will take from this queue any more (a run that ends early): the reader stops
     void put(FastqBatch&& b) {
+        const uint64_t sz = b.buf.size();
+        if (gate) {
+            std::unique_lock<std::mutex> gl(gate->m);
+            gate->cv.wait(gl, [&] { return abandoned.load() || claimed.load() || gate->held == 0 || gate->held + sz <= gate->budget; });
+            if (abandoned.load()) return;
+            gate->held += sz;
+        }
         std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [&] { return unbounded || q.size() < kDepth; });
+        cv.wait(lk, [&] { return abandoned.load() || (gate && !claimed.load()) || q.size() < kDepth; });
+        if (abandoned.load()) return;
         q.push_back(std::move(b));
         cv.notify_all();
     }
+    void abandon() {
+        abandoned.store(true);
+        if (gate) { std::unique_lock<std::mutex> gl(gate->m); gate->cv.notify_all(); }
+        { std::unique_lock<std::mutex> lk(m); cv.notify_all(); }
+    }
     FastqBatch take() {
-        std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [&] { return !q.empty(); });
-        FastqBatch b = std::move(q.front());
-        q.pop_front();
-        cv.notify_all();
+        FastqBatch b;
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return !q.empty(); });
+            b = std::move(q.front());
+            q.pop_front();
+            cv.notify_all();
+        }
+        if (gate) {
+            { std::unique_lock<std::mutex> gl(gate->m); gate->held -= std::min<uint64_t>(gate->held, b.buf.size()); }
+            gate->cv.notify_all();
+        }
         return b;
+    }
+    void claim() {   // a lane takes the sample over
+        claimed.store(true);
+        if (gate) { std::unique_lock<std::mutex> gl(gate->m); gate->cv.notify_all(); }
+        { std::unique_lock<std::mutex> lk(m); cv.notify_all(); }
     }
     void recycle(FastqBatch&& b) {
         std::unique_lock<std::mutex> lk(m);
@@ -355,7 +393,7 @@ void parse_fastq(const std::string& path, BatchQueue& out, unsigned inflate_thre
             if ((ln & 3) != 1) { if (!in.skip_next()) break; continue; }
             if (!in.append_next(cur.buf)) break;     // (the sequence line goes straight into the batch)
             cur.off.push_back(cur.buf.size());
-            if (++n % kBatchReads == 0) { out.put(std::move(cur)); cur = out.fresh(); }
+            if (++n % kBatchReads == 0) { out.put(std::move(cur)); cur = out.fresh(); if (out.abandoned.load()) break; }
         }
     } catch (const std::exception& e) {
         cur = FastqBatch();
@@ -366,8 +404,10 @@ void parse_fastq(const std::string& path, BatchQueue& out, unsigned inflate_thre
 }
 // The files of the samples to come are read while the index and the engine's tables are being made (seconds with a hundred
 // genomes: host work that leaves most cores idle) and while earlier samples are on their way: a manager thread starts the
-// readers of sample after sample, `concurrency` files at a time, until the text held would pass `budget` bytes; a lane that
-// reaches a sample takes its readers over (claim) or, if they were not started, reads it itself as before.
+// readers of sample after sample, `concurrency` files at a time, as long as the text the started samples hold in their queues
+// stays within `budget` bytes (AheadGate: real bytes; readers wait when it is full and go on as lanes consume); a lane that
+// reaches a sample takes its readers over (claim) or, if they were not started, reads it itself as before.  Inputs that are not
+// regular files (a FIFO, /dev/fd/N) are never read ahead: their size is unknown and they can be read once.
 struct SampleReaders {
     std::deque<BatchQueue> queues;   // (a deque: BatchQueue holds a mutex and does not move)
     std::vector<std::thread> readers;
@@ -375,13 +415,15 @@ struct SampleReaders {
 class ReadAhead {
 public:
     ReadAhead(const std::vector<std::vector<std::string>>& samples, unsigned concurrency, uint64_t budget)
-        : samples_(samples), state_(samples.size(), 0), held_(samples.size()), concurrency_(std::max(1u, concurrency)), budget_(budget) {
+        : samples_(samples), state_(samples.size(), 0), held_(samples.size()), concurrency_(std::max(1u, concurrency)) {
+        gate_.budget = budget;
         uint64_t all = 0;
-        for (const auto& m : samples) all += text_estimate(m);
-        covers_all_ = all <= budget;
+        bool regular = true;
+        for (const auto& m : samples) { uint64_t n = 0; regular = text_estimate(m, &n) && regular; all += n; }
+        covers_all_ = regular && all <= budget;
         manager_ = std::thread([this] { run(); });
     }
-    bool covers_all() const { return covers_all_; }   // every sample's text fits the budget: the lanes only push
+    bool covers_all() const { return covers_all_; }   // every sample's text fits the budget (by the estimate): the lanes only push
     void set_concurrency(unsigned n) {                // (few files at a time while the engine's tables are made on the same cores, more behind that)
         { std::unique_lock<std::mutex> lk(m_); concurrency_ = std::max(1u, n); }
         cv_.notify_all();
@@ -390,33 +432,51 @@ public:
         { std::unique_lock<std::mutex> lk(m_); stop_ = true; }
         cv_.notify_all();
         if (manager_.joinable()) manager_.join();
+        // (readers of samples no lane came for -- a run that ended early -- must not wait for room that nobody will make)
+        for (auto& h : held_) if (h) for (auto& q : h->queues) q.abandon();
         for (auto& h : held_) if (h) for (auto& t : h->readers) if (t.joinable()) t.join();
     }
     // the readers of sample i if it is being read ahead; otherwise nullptr, and it will not be
     std::unique_ptr<SampleReaders> claim(size_t i) {
         std::unique_lock<std::mutex> lk(m_);
-        if (state_[i] == 1) { state_[i] = 2; return std::move(held_[i]); }
+        if (state_[i] == 1) {
+            state_[i] = 2;
+            for (auto& q : held_[i]->queues) q.claim();
+            return std::move(held_[i]);
+        }
         state_[i] = 2;
         return nullptr;
     }
 private:
-    static uint64_t text_estimate(const std::vector<std::string>& mates) {   // bytes of sequence lines a sample's batches will hold
+    // bytes of sequence lines a sample's batches will hold, estimated from the files' sizes; false: a mate is not a regular file
+    static bool text_estimate(const std::vector<std::string>& mates, uint64_t* out) {
         uint64_t n = 0;
-        for (const auto& p : mates) { struct stat st; if (stat(p.c_str(), &st) == 0) n += (uint64_t)st.st_size * 2; }   // (FASTQ text is ~3.5x its gzip, the sequence lines half of it)
-        return n;
+        bool regular = true;
+        for (const auto& p : mates) {
+            struct stat st;
+            if (stat(p.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) { regular = false; continue; }
+            n += (uint64_t)st.st_size * 2;   // (FASTQ text is ~3.5x its gzip, the sequence lines half of it)
+        }
+        *out = n;
+        return regular;
     }
     void run() {
-        uint64_t used = 0;
         for (size_t i = 0; i < samples_.size(); i++) {
+            // room for another sample?  (real bytes: three quarters of the budget held means the readers already started fill the rest)
+            for (;;) {
+                { std::unique_lock<std::mutex> lk(m_); if (stop_) return; }
+                std::unique_lock<std::mutex> gl(gate_.m);
+                if (gate_.held <= gate_.budget / 4 * 3) break;
+                gate_.cv.wait_for(gl, std::chrono::milliseconds(20));
+            }
             std::unique_lock<std::mutex> lk(m_);
             cv_.wait(lk, [&] { return stop_ || active_ + samples_[i].size() <= concurrency_; });
             if (stop_) return;
             if (state_[i] != 0) continue;                 // a lane got there first
-            const uint64_t need = text_estimate(samples_[i]);
-            if (used + need > budget_) return;
-            used += need;
+            uint64_t need = 0;
+            if (!text_estimate(samples_[i], &need)) continue;   // (a stream: its lane reads it)
             auto sr = std::unique_ptr<SampleReaders>(new SampleReaders);
-            for (size_t m = 0; m < samples_[i].size(); m++) { sr->queues.emplace_back(); sr->queues.back().unbounded = true; }
+            for (size_t m = 0; m < samples_[i].size(); m++) { sr->queues.emplace_back(); sr->queues.back().gate = &gate_; }
             for (size_t m = 0; m < samples_[i].size(); m++) {
                 active_++;
                 sr->readers.emplace_back([this, i, m, q = &sr->queues[m]] {
@@ -433,7 +493,7 @@ private:
     std::vector<int> state_;                              // 0 not started, 1 being read ahead, 2 taken by its lane
     std::vector<std::unique_ptr<SampleReaders>> held_;
     unsigned concurrency_, active_ = 0;
-    uint64_t budget_;
+    AheadGate gate_;
     bool stop_ = false, covers_all_ = false;
     std::mutex m_;
     std::condition_variable cv_;

@@ -607,11 +607,16 @@ inline void parallel_for(size_t n, unsigned threads, F f) {
 // The file's text, in order, from read(): a producer thread runs the waves and keeps a bounded queue of finished chunks ahead.
 class ParallelGunzip {
 public:
+    // A gzip FILE that can be mapped: regular and not empty.  A FIFO, /dev/fd/N (process substitution), a terminal are never opened
+    // here -- a probe would take bytes off the stream, and there is nothing to map -- and stay with zlib's gzread, which reads them
+    // in one pass (`bronko call -r <(zcat x.gz)` gave 0 reads with rc 0, a plain-text pipe lost its first three bytes).
     static bool is_gzip(const std::string& path) {
+        struct stat st;
+        if (::stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 3) return false;
         const int fd = ::open(path.c_str(), O_RDONLY);
         if (fd < 0) return false;
         unsigned char h[3] = {0, 0, 0};
-        const ssize_t r = ::read(fd, h, 3);
+        const ssize_t r = ::pread(fd, h, 3, 0);
         ::close(fd);
         return r == 3 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8;
     }
@@ -620,6 +625,7 @@ public:
         if (fd_ < 0) throw std::runtime_error("cannot open " + path);
         struct stat st;
         if (fstat(fd_, &st) != 0) { ::close(fd_); throw std::runtime_error("cannot stat " + path); }
+        if (!S_ISREG(st.st_mode)) { ::close(fd_); throw std::runtime_error(path + " is not a regular file (pargz maps its input; read streams with gzread)"); }
         n_ = (uint64_t)st.st_size;
         if (n_) {
             void* m = mmap(nullptr, n_, PROT_READ, MAP_PRIVATE, fd_, 0);

@@ -211,3 +211,36 @@ def test_random_texts_members_and_chunkings(cat, tmp_path):
         rc, out, err = run(cat, p, threads, chunk)
         assert rc == 0, (it, err)
         assert out == t, (it, kind, n, level, cuts, threads, chunk)
+
+
+def test_streams_are_read_in_one_pass_without_a_probe(cat, tmp_path):
+    """`bronko call -r <(zcat x.gz)` / a FIFO / /dev/fd/N: an input that is not a regular file can be read once and has no size.  The
+    line reader (fastx.hpp GzLineReader, what the binary opens its inputs with) must not probe it for the gzip magic (the probe's
+    three bytes are gone from the stream) nor map it (0 lines, rc 0): it stays with zlib's gzread, gzip or plain text,
+    whatever the thread count; a regular file of the same content gives the same lines."""
+    t = fastq_text(4000, 5)
+    lines = t
+    gz = str(tmp_path / "s.fastq.gz")
+    plain = str(tmp_path / "s.fastq")
+    open(gz, "wb").write(gzip.compress(t))
+    open(plain, "wb").write(t)
+    for src in (gz, plain):
+        for threads in (1, 4):
+            r = subprocess.run([cat, "--lines", src, str(threads)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 0 and r.stdout == lines, (src, threads, r.stderr)
+            fifo = str(tmp_path / "fifo")
+            if os.path.exists(fifo):
+                os.unlink(fifo)
+            os.mkfifo(fifo)
+            writer = subprocess.Popen(["sh", "-c", 'cat "$0" > "$1"', src, fifo])
+            r = subprocess.run([cat, "--lines", fifo, str(threads)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+            assert writer.wait(timeout=60) == 0
+            assert r.returncode == 0 and r.stdout == lines, (src, threads, "fifo", len(r.stdout), r.stderr)
+    # the mapped reader itself refuses what it cannot map, loudly
+    fifo = str(tmp_path / "fifo2")
+    os.mkfifo(fifo)
+    writer = subprocess.Popen(["sh", "-c", 'cat "$0" > "$1"', gz, fifo])
+    rc, out, err = run(cat, fifo, 4)
+    writer.kill()
+    writer.wait()
+    assert rc == 1 and "regular file" in err

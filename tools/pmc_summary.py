@@ -19,7 +19,7 @@ def main():
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {}
     for k, v in agg.items():
-        if not any(s in k for s in ("scan_count", "scan_items", "bin_count", "level2", "nbatch", "finalize", "fold", "pack_", "zero_")):
+        if "bk::" not in k:   # every kernel of the engine (the gathered votes, the noise walk, the index build ... included); not torch's / rocPRIM's
             continue
         d = {name: sum(vals) / len(vals) for name, vals in v.items()}
         d["launches"] = max(len(vals) for vals in v.values())

@@ -544,8 +544,8 @@ static int alloc_sample_state(bk_engine* e) {
         BK_HIP(e->item_tab.alloc(g * ((size_t)e->ig.n_ebins + e->ig.n_vbins)));
         BK_HIP(e->item_gext.alloc(g * ((size_t)e->ig.n_ebins + e->ig.n_vbins) * bk::kItemGCap));   // (92 MB for one SARS-CoV-2 genome: 2 bytes x 256 slots x 701 bins x 256 workgroups)
         BK_HIP(e->ov.alloc((size_t)1 << 20));
-        BK_HIP(e->ov_n.alloc(2));
-        BK_HIP(hipMemset(e->ov_n.p, 0, 2 * sizeof(unsigned long long)));
+        BK_HIP(e->ov_n.alloc(4));   // [2] overflow counts by launch parity, behind them (as 32-bit words) the scan's two chunk counters
+        BK_HIP(hipMemset(e->ov_n.p, 0, 4 * sizeof(unsigned long long)));
     } else {
         BK_HIP(e->slabs.alloc((size_t)e->n_cus * std::max<uint32_t>(e->n_lds_bins, 1)));
     }

@@ -34,6 +34,30 @@ constexpr int kBitBackWords = 3;
 __device__ __forceinline__ uint32_t lane_prefix(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
+// Wave64 scans over the lanes in registers (DPP: row_shr 1 / 2 / 4 / 8 inside each row of 16 lanes, then row_bcast:15 into rows 1
+// and 3 and row_bcast:31 into rows 2 and 3): six VALU instructions and no trip through the LDS crossbar, where a ladder of
+// __shfl_up steps is six dependent ds_bpermute round trips with a compare, a select and an address shift each.
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {   // inclusive prefix sum
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) {   // inclusive running maximum (unsigned)
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+// ... and the whole wave's maximum / minimum as a wave-uniform value (lane 63 of the running one)
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_max(v), 63); }
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) { return ~wave_max(~v); }
 // reverse the order of the sixteen 2-bit groups of a word
 __device__ __forceinline__ uint32_t rev2_32(uint32_t x) {
     const uint32_t t = __builtin_bitreverse32(x);

@@ -33,7 +33,10 @@ namespace bk {
 constexpr int kItemBlock = 1024;            // one workgroup of 16 waves per CU: the window's reference is staged once per CU
 constexpr int kItemWaves = kItemBlock / 64;
 constexpr int kItemGroupsPerCu = 1;
-constexpr size_t kItemLdsFixed = (4 + 4 + kItemBlock) * sizeof(unsigned int);   // k-mer tally, the workgroup's tile counter, the item owners
+constexpr uint32_t kListCap = 256;          // entries of a wave's list of mismatch positions (a tile with more goes round by round of lanes)
+constexpr uint32_t kListWords = kListCap + 4u;   // ... with an empty entry in front and two behind
+constexpr uint32_t kDealRing = 32;          // the chunks of tiles a workgroup has been dealt, by ordinal (modulo this): {ordinal, chunk}
+constexpr size_t kItemLdsFixed = (4 + 4 + 2 * kDealRing + kItemWaves * kListWords) * sizeof(unsigned int);   // k-mer tally, the workgroup's tile counter, its chunks, the waves' lists
 constexpr int kBinBlock = 256;
 constexpr uint32_t kMaxChunkMismatches = 24;   // more differences than this in a read's first 160 bases: not a read of that diagonal
 constexpr uint32_t kStageMaxWords = 12;    // records of up to 192 bases are staged in LDS (48 KB for the workgroup's 16 waves)
@@ -65,8 +68,9 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned int* block_kmers = reinterpret_cast<unsigned int*>(smem);   // 16 B reserved
     unsigned int* wg_ctr = block_kmers + 4;         // [1] the workgroup's next tile that no wave has taken (16 B reserved)
-    unsigned int* own_all = wg_ctr + 4;             // [waves][64] which lane owns each of the items of a pass (below)
-    unsigned int* cnt = own_all + kItemBlock;       // [n_bins] items of each bin (the first cap in its bucket, the rest in its extension in device memory)
+    uint2* ring = reinterpret_cast<uint2*>(wg_ctr + 4);   // [kDealRing] {ordinal, chunk of 16 tiles}: what this workgroup was dealt (below)
+    unsigned int* lst_all = wg_ctr + 4 + 2 * kDealRing;   // [waves][kListWords] the positions of a tile's mismatches, lane after lane (below)
+    unsigned int* cnt = lst_all + kItemWaves * kListWords;   // [n_bins] items of each bin (the first cap in its bucket, the rest in its extension in device memory)
     const uint32_t n_eb = a.ig.n_ebins, n_bins = n_eb + a.ig.n_vbins, cap_e = a.ig.cap_e, cap_v = a.ig.cap_v;
     const uint32_t nb_pad = (n_bins + 3u) & ~3u;
     unsigned short* buck = reinterpret_cast<unsigned short*>(cnt + nb_pad);   // E bin b: [b * cap_e, + cap_e); V bins behind them, cap_v each
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform by construction: tell the compiler
-    unsigned int* const own_s = own_all + wave * 64;
+    unsigned int* const lst = lst_all + (uint32_t)wave * kListWords;
     // The arguments only rare paths read (overflow, marks for Level 2, the fallback seeds, start and end of the workgroup) are read
     // again from the kernel-argument segment where they are used, through a pointer the compiler cannot see through: held in
     // scalar registers for the whole tile loop they cost ~60 of the 102 there are, and the loop paid for it in v_readlane /
@@ -109,10 +113,14 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     const uint32_t* const words0 = a.words + a.rec_base * a.stride_words;
     const uint16_t* const lens0 = a.lens + a.rec_base;
     const uint64_t n_tiles = (n_records + 63) / 64;
-    // The workgroup's tiles are one contiguous stretch, dealt out to its waves one at a time (a counter in LDS): a tile with many
-    // mismatches keeps one wave busy while the others take what is left -- with a fixed deal the workgroup waited for its
-    // unluckiest wave, and the kernel for its unluckiest workgroup (waves were resident for 65% of the kernel's time).
-    const uint64_t t_lo = (uint64_t)blockIdx.x * n_tiles / gridDim.x, t_hi = (uint64_t)(blockIdx.x + 1u) * n_tiles / gridDim.x;   // (even shares: 61 or 62 of 15,625)
+    // Tiles are dealt in chunks of sixteen (one per wave): a workgroup starts on chunk blockIdx.x and takes every further chunk
+    // from a counter in device memory (one returning atomic per sixteen tiles: a thousand per launch; per TILE the atomics queue up
+    // on their one address, 20 ns each), a chunk's tiles go to the workgroup's waves one at a time (a counter in LDS) -- a tile with
+    // many mismatches keeps one wave busy while the others take what is left, and a workgroup that started late (the last of a
+    // launch's 256 start 8 us after the first) or shares its CU's memory path with a sibling's kernels takes fewer chunks instead of
+    // making the launch wait (until round 6 every workgroup had a fixed 61 tiles: the mean workgroup ended 6 us before the last).
+    unsigned int* const deal_ctr = reinterpret_cast<unsigned int*>(cold()->ov_n + 2);   // [2] by the launch's parity: this launch's counter; the other is zeroed for the next
+    const uint64_t t_hi = n_tiles;
     // STAGED: this wave's record buffer, and the copy of a tile into it.  Returns the lane's record length of that tile.
     const uint32_t sw = a.stride_words;
     unsigned int* const rec_buf = reinterpret_cast<unsigned int*>(smem + a.stage_off) + (uint32_t)wave * 64u * sw;
@@ -137,23 +145,45 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     };
     // (the wave's first tile is sent on its way into LDS before the workgroup stages the reference: the two copies run side by side)
     uint32_t len_pf = 0u;
-    if constexpr (STAGED) len_pf = stage(t_lo + (uint32_t)wave);
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kItemWaves + (uint32_t)wave;   // the wave's first tile: of the workgroup's own chunk
+    if constexpr (STAGED) len_pf = stage(tile0);
+    uint32_t chunk1 = 0u;
+    if (threadIdx.x == 0) {
+        const uint32_t par = cold()->ov_par;
+        if (blockIdx.x == 0) deal_ctr[par ^ 1u] = 0u;
+        // the workgroup's second chunk is asked for now (the answer is picked up behind the staging below)
+        chunk1 = gridDim.x + __hip_atomic_fetch_add(deal_ctr + par, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     for (uint32_t i = threadIdx.x; i < n_bins; i += kItemBlock) cnt[i] = 0u;
+    if (lane == 0) lst[0] = 0u;   // (no entry in front of a list's first)
     if (threadIdx.x == 0) wg_ctr[1] = (unsigned int)kItemWaves;
     {
+        // The window's arrays, five of them, as ONE stretch of words dealt to the threads eight at a time: all of a thread's loads are
+        // on their way before the first is stored (five loops, each a trip to memory of its own, took 5 us of every workgroup's life).
         const ColdArgs c = cold();
         const uint32_t* const g_ref = c->ref_words + (win_lo >> 4);
         const uint32_t* const g_fast = c->cell_fast + (win_lo >> 5);
         const uint32_t* const g_c3 = c->cell_clean3 + (win_lo >> 5);
         const uint32_t* const g_blk = reinterpret_cast<const uint32_t*>(c->cell_blk + (win_lo >> 6));
-        for (uint32_t i = threadIdx.x; i < n_refw; i += kItemBlock) lds_ref[i] = g_ref[i];
-        for (uint32_t i = threadIdx.x; i < n_bitw; i += kItemBlock) lds_ref[n_refw + i] = g_fast[i];
-        for (uint32_t i = threadIdx.x; i < n_bitw; i += kItemBlock) lds_ref[n_refw + n_bitw + i] = g_c3[i];
-        for (uint32_t i = threadIdx.x; i < 2 * n_blk; i += kItemBlock) lds_ref[blk_w0 + i] = g_blk[i];
         const uint32_t* const g_rc = c->rc_words + (rc_lo >> 4);
-        for (uint32_t i = threadIdx.x; i <= n_refw; i += kItemBlock) lds_ref[rc_w0 + i] = g_rc[i];   // (one word more: the slice starts rc_base symbols into its first word)
+        const uint32_t c0 = n_refw, c1 = c0 + n_bitw, c2 = c1 + n_bitw, c3 = c2 + 2u * n_blk, c4 = c3 + n_refw + 1u;   // (the copy: one word more, its slice starts rc_base symbols into its first word)
+        for (uint32_t b0 = 0; b0 < c4; b0 += 8u * kItemBlock) {
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u) {
+                const uint32_t i = b0 + u * kItemBlock + threadIdx.x;
+                const uint32_t* src = i < c0 ? g_ref + i : i < c1 ? g_fast + (i - c0) : i < c2 ? g_c3 + (i - c1) : i < c3 ? g_blk + (i - c2) : g_rc + (i - c3);
+                v[u] = i < c4 ? *src : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u) {
+                const uint32_t i = b0 + u * kItemBlock + threadIdx.x;
+                if (i < c4) lds_ref[i < c2 ? i : i < c3 ? blk_w0 + (i - c2) : rc_w0 + (i - c3)] = v[u];
+            }
+        }
     }
+    if (threadIdx.x == 0) { ring[0] = make_uint2(0u, blockIdx.x); ring[1] = make_uint2(1u, chunk1); }
     __syncthreads();
     BK_DBG_CLOCK(a, 1);
     // symbol / bit 0 is cell win_lo; negative positions down to -64 are readable (padding or earlier cells)
@@ -227,19 +257,58 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     };
     const bool stats = a.ktab_keys != nullptr;   // full_kmer_stats: k-mers that touch nothing are still wanted by the statistics table (level2_kernel)
 
+    // the wave's next tile: the workgroup's s-th is tile s % 16 of its (s / 16)-th chunk; whoever draws a chunk's first tile asks
+    // for the chunk after it (a round of tiles before anybody needs it) and leaves it in the ring
     auto take_tile = [&]() __attribute__((always_inline)) -> uint64_t {
         uint32_t t = 0u;
-        if (lane == 0) t = __hip_atomic_fetch_add(wg_ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return t_lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (lane == 0) {
+            const uint32_t s = __hip_atomic_fetch_add(wg_ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t q = s / kItemWaves, i = s % kItemWaves;
+            volatile uint2* const rg = ring;
+            if (i == 0u) {
+                const uint32_t cn = gridDim.x + __hip_atomic_fetch_add(deal_ctr + cold()->ov_par, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                rg[(q + 1u) % kDealRing].y = cn;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                rg[(q + 1u) % kDealRing].x = q + 1u;
+            }
+            while (rg[q % kDealRing].x != q) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            t = rg[q % kDealRing].y * kItemWaves + i;
+        }
+        return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     };
     uint32_t pf_sink = 0;               // destination of the prefetch loads (never read)
-    constexpr uint32_t kNoPos = 0x40000000u;
     // the seed table of the window's genome, and where the seeds sit: evenly spaced over the launch's first record
     const uint2* const seed_tab = a.seed_tab2 ? a.seed_tab2 + ((size_t)win_file << a.seed2_log2) : nullptr;
     const uint32_t hint_len = n_records ? (uint32_t)__builtin_amdgcn_readfirstlane((int)lens0[0]) : 0u;
     const uint32_t hint_span = hint_len >= (uint32_t)k ? hint_len - (uint32_t)k : 0u;
+    // chunk flags that are not resolved at a chunk's end (long reads): those of its last k - 1 bases, i.e. bits 64 - 2 (k - 1) and
+    // up of the 64 flag bits of its last 32 bases (words 8 and 9, two bits per base)
+    const uint32_t um_sh = 64u - 2u * km1;
+    const uint32_t um8 = um_sh >= 32u ? 0u : 0xffffffffu << um_sh, um9 = um_sh >= 32u ? 0xffffffffu << (um_sh - 32u) : 0xffffffffu;
 
-    for (uint64_t tile = t_lo + (uint32_t)wave, next_tile = 0; tile < t_hi; tile = next_tile) {
+    // The seeds of a tile: three k-mers of every read (its first, its last, one in between) looked up in the seed table of the
+    // window's genome (bk_device.h seed_hash) -- k-mers at positions that do not depend on the read's length (evenly spaced over the
+    // launch's first record), one 8-byte bucket each.  (Asking for the NEXT tile's seeds before this tile's mismatches are dealt with
+    // was tried in round 6: the carried state cost registers and instructions and the kernel was 2 % slower -- its waves wait on
+    // dependent LDS steps and branches all along a tile, not on the table.)
+    struct SeedSet { uint64_t g[3]; uint32_t h[3]; uint2 b[3]; };
+    auto seed_pos = [&](int sround, int j) __attribute__((always_inline)) -> uint32_t {
+        const int qj = sround ? kSeeds - 2 : (j == 0 ? 0 : j == 1 ? kSeeds - 1 : 1);
+        return (hint_span * (uint32_t)qj) / (uint32_t)(kSeeds - 1);   // (wave-uniform)
+    };
+    auto seed_load = [&](const uint32_t* __restrict__ wr, int sround, int ns, SeedSet& S) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j >= ns) continue;
+            S.g[j] = read_symbols_at(wr, seed_pos(sround, j), last_word) & kmask;   // the k-mer as the read shows it: base t at bits 2t
+            S.h[j] = seed_hash(S.g[j]);                                              // (no reverse complement, no canonical form: the table holds both strands)
+            S.b[j] = seed_tab[S.h[j] >> (32u - a.seed2_log2)];
+        }
+    };
+    const bool use_tab = seed_tab && !BK_ABLATE(a, 9) && !BK_ABLATE(a, 11);
+
+    for (uint64_t tile = tile0, next_tile = 0; tile < t_hi; tile = next_tile) {
         const uint64_t r = tile * 64 + lane;
         next_tile = take_tile();
         const bool live = r < n_records;
@@ -252,10 +321,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
             len = live ? (uint32_t)lens0[r32] : 0u;
         }
         if (len < (uint32_t)k) len = 0u;   // no k-mer
-        uint32_t maxlen = len;
-#pragma unroll
-        for (int off = 32; off; off >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, off));
-        maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxlen);
+        const uint32_t maxlen = wave_max(len);
         const uint32_t* __restrict__ w = STAGED ? rec_buf + (uint32_t)lane * sw : words0 + (uint64_t)r32 * a.stride_words;
         const uint32_t nk = len ? len - km1 : 0u;   // k-mers of the record
         nkm += nk;
@@ -266,17 +332,75 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
             if (nt < t_hi && (uint64_t)lane * 32ull < words_tile && at < n_records * a.stride_words)
                 asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink) : "v"(words0 + at) : "memory");
         }
-        if (!maxlen) { if constexpr (STAGED) len_pf = stage(next_tile); continue; }
+        SeedSet S;
+        if (use_tab && maxlen) seed_load(w, 0, 3, S);
+        // STAGED: the next tile is sent on its way into the wave's buffer once this tile's words are all read (behind the flag pass:
+        // nothing after it reads a record).  Every path through a tile does it exactly once.
+        bool next_sent = false;
+        auto send_next = [&]() __attribute__((always_inline)) {
+            if constexpr (STAGED) { if (!next_sent) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); len_pf = stage(next_tile); next_sent = true; } }
+        };
+        auto ask_next = [&]() __attribute__((always_inline)) { send_next(); };
+        if (!maxlen) { ask_next(); continue; }
 
         // ---- seeds -> diagonal ----------------------------------------------------------------------------------
+        // Which diagonal a read is settled on decides how much of it is settled HERE, never what is counted: k-mers without a
+        // difference from the reference along any diagonal are the reference k-mers of those cells, single differences at clean
+        // cells belong to that cell's k-mer whatever brought the read there, everything else goes to Level 2.
         bool fwd = true, seeded = false, l1ok = false;   // seeded: diagonal known; l1ok: ... and all its cells are in the window
         int32_t dg = 0;                                  // cell of the reference k-mer aligned with read k-mer 0: k-mer s <-> dg + s (fwd) / dg - s
-        // a candidate diagonal: the whole read must lie on the reference (hi_cell + k <= total); to be settled here its cells must lie
-        // in the window and each of them must carry a reference k-mer (no sequence tail in between: cell_blk)
+        // a diagonal: the whole read must lie on the reference (hi_cell + k <= total); to be settled here its cells must lie in the
+        // window and each of them must carry a reference k-mer (no sequence tail in between: cell_blk).  Branch-free: one LDS read.
+        // (cells stay below 2^27 -- kSeedCellBits --, read positions below 2^16: 32-bit signed arithmetic holds everything)
+        auto accept = [&](bool hit, int32_t d0, bool f) __attribute__((always_inline)) {
+            const int32_t span_k = (int32_t)(len - (uint32_t)k);
+            const int32_t lo_cell = f ? d0 : d0 - span_k;
+            const int32_t hi_cell = f ? d0 + span_k : d0;
+            const bool ok = hit && len != 0u && lo_cell >= 0 && (uint32_t)hi_cell + (uint32_t)k <= total;
+            const bool inw = ok && (uint32_t)lo_cell >= win_lo && (uint32_t)hi_cell < win_lo + a.n_lds_bins;
+            const uint32_t tail = blkw[inw ? ((uint32_t)lo_cell >> 6) - (win_lo >> 6) : 0u].y;
+            dg = ok ? d0 : dg; fwd = ok ? f : fwd; seeded = seeded || ok;
+            l1ok = ok ? (inw && (uint32_t)hi_cell < tail) : l1ok;
+        };
+        // A candidate the table names is verified against the reference in LDS.  The first seed that verifies names the diagonal
+        // (they agree unless the read is a chimera), and the diagonal is tested once per round.  The fourth seed only for the
+        // lanes the three left without a diagonal.
+        for (int sround = 0; sround < 2 && use_tab; ++sround) {
+            if (sround == 1) {
+                if (!__ballot(len != 0u && !seeded)) break;
+                seed_load(w, 1, 1, S);
+            }
+            const int ns = sround ? 1 : 3;
+            bool hit = false, hf = true;
+            int32_t hd0 = 0;
+#pragma unroll
+            for (int j = 2; j >= 0; --j) {   // (the later seeds first: an earlier one that verifies overrides them)
+                if (j >= ns) continue;
+                const uint32_t s = seed_pos(sround, j);
+                const uint32_t tag = S.h[j] & 15u;
+                const uint64_t sg = S.g[j];
+                const uint32_t ent = (S.b[j].x != 0xffffffffu && (S.b[j].x >> 28) == tag) ? S.b[j].x : S.b[j].y;
+                const uint32_t cell = ent & ((1u << kSeedCellBits) - 1u), strand = (ent >> kSeedCellBits) & 1u;
+                // in reach of the staged reference?  (the window's cells and 64 in front)
+                const bool in_ref = !seeded && ent != 0xffffffffu && (ent >> 28) == tag && s + (uint32_t)k <= len &&
+                                    cell + 64u >= win_lo && cell + (uint32_t)k <= win_lo + lds_cells;
+                const int32_t cw = in_ref ? (int32_t)cell - (int32_t)win_lo : 0;
+                // the reference k-mer of that cell as a read on that strand shows it: from the reference, or from its reverse-
+                // complemented copy (one LDS array, one base pointer: the copy's symbols lie rc_sym0 symbols behind the reference's)
+                const int32_t pos = strand ? rc_sym0 + (int32_t)(rc_base + lds_cells) - k - cw : cw;
+                const uint64_t ref = symbols_at(refw1, pos) & kmask;
+                const bool h = in_ref && ref == sg;
+                hd0 = h ? (strand ? (int32_t)cell + (int32_t)s : (int32_t)cell - (int32_t)s) : hd0;
+                hf = h ? strand == 0u : hf;
+                hit = hit || h;
+            }
+            accept(hit, hd0, hf);
+        }
+        // The lanes that are still without a diagonal (an error in every seed, a k-mer that found its bucket full, a read shorter
+        // than the first record, no seed table): the perfect hash of U, two rounds (scan_count_kernel has the why).
         uint32_t best_cell = 0xffffffffu;
         auto candidate = [&](bool hit, uint32_t scell, bool f, uint32_t s) __attribute__((always_inline)) {
             if (hit && scell < best_cell) {   // several seeds may hit (usually all, on one diagonal); prefer the lowest cell
-                // (cells stay below 2^27 -- kSeedCellBits --, read positions below 2^16: 32-bit signed arithmetic holds everything)
                 const int32_t span_k = (int32_t)(len - (uint32_t)k);
                 const int32_t d0 = f ? (int32_t)scell - (int32_t)s : (int32_t)scell + (int32_t)s;
                 const int32_t lo_cell = f ? d0 : d0 - span_k;
@@ -288,49 +412,6 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
                 }
             }
         };
-        // First the seed table of the window's genome (bk_device.h seed_hash): k-mers at positions that do not depend on the read's
-        // length (evenly spaced over the launch's first record), one 8-byte bucket each, and the candidate it names is verified
-        // against the reference in LDS.  Two at a time: the read's first and last k-mer; the two in between only for the lanes both
-        // of those left without a diagonal (a sequencing error in each: one read in a hundred, half of the tiles) -- with the
-        // records in LDS a second round costs one more trip to the seed table, not a chain of three.
-        for (int sround = 0; sround < 2 && seed_tab && !BK_ABLATE(a, 9) && !BK_ABLATE(a, 11); ++sround) {
-            if (sround == 1 && !__ballot(len != 0u && !seeded)) break;
-            // round 0: the read's first and last k-mer and one in between; round 1 (one tile in eight): the fourth
-            const int ns = sround ? 1 : 3;
-            const bool had = seeded;
-            uint64_t sg[3];
-            uint32_t sh[3];
-            uint2 sb[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if (j >= ns) continue;
-                const int qj = sround ? kSeeds - 2 : (j == 0 ? 0 : j == 1 ? kSeeds - 1 : 1);
-                const uint32_t s = (hint_span * (uint32_t)qj) / (uint32_t)(kSeeds - 1);   // (wave-uniform)
-                sg[j] = read_symbols_at(w, s, last_word) & kmask;                  // the k-mer as the read shows it: base t at bits 2t
-                sh[j] = seed_hash(sg[j]);                                          // (no reverse complement, no canonical form: the table holds both strands)
-                sb[j] = seed_tab[sh[j] >> (32u - a.seed2_log2)];
-            }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if (j >= ns) continue;
-                const int qj = sround ? kSeeds - 2 : (j == 0 ? 0 : j == 1 ? kSeeds - 1 : 1);
-                const uint32_t s = (hint_span * (uint32_t)qj) / (uint32_t)(kSeeds - 1);
-                const uint32_t tag = sh[j] & 15u;
-                const uint32_t ent = (sb[j].x != 0xffffffffu && (sb[j].x >> 28) == tag) ? sb[j].x : sb[j].y;
-                const uint32_t cell = ent & ((1u << kSeedCellBits) - 1u), strand = (ent >> kSeedCellBits) & 1u;
-                // in reach of the staged reference?  (the window's cells and 64 in front)
-                const bool in_ref = !had && ent != 0xffffffffu && (ent >> 28) == tag && len != 0u && s + (uint32_t)k <= len &&
-                                    cell + 64u >= win_lo && cell + (uint32_t)k <= win_lo + lds_cells;
-                const int32_t cw = in_ref ? (int32_t)cell - (int32_t)win_lo : 0;
-                // the reference k-mer of that cell as a read on that strand shows it: from the reference, or from its reverse-
-                // complemented copy (one LDS array, one base pointer: the copy's symbols lie rc_sym0 symbols behind the reference's)
-                const int32_t pos = strand ? rc_sym0 + (int32_t)(rc_base + lds_cells) - k - cw : cw;
-                const uint64_t ref = symbols_at(refw1, pos) & kmask;
-                candidate(in_ref && ref == sg[j], cell, strand == 0u, s);
-            }
-        }
-        // The lanes that are still without a diagonal (an error in every seed, a k-mer that found its bucket full, a read shorter
-        // than the first record, no seed table): the perfect hash of U, two rounds (scan_count_kernel has the why).
         for (int round = 0; round < 2 && !BK_ABLATE(a, 9); ++round) {   // (9: no seeds at all, 7: nothing behind them, 6: no mismatch loop)
             if (!__ballot(len != 0u && !seeded)) break;
             const ColdArgs c = cold();
@@ -374,221 +455,256 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
             }
         }
         uint32_t dfl = (fwd ? 1u : 0u) | (seeded ? 2u : 0u);
-        if (BK_ABLATE(a, 9) || BK_ABLATE(a, 7)) { if constexpr (STAGED) len_pf = stage(next_tile); continue; }
+        if (BK_ABLATE(a, 9) || BK_ABLATE(a, 7)) { ask_next(); continue; }
 
         // ---- mismatch flags, 160 bases at a time; mismatch by mismatch --------------------------------------------------
         const int32_t dgw = dg - (int32_t)win_lo;   // the diagonal in window coordinates
         const int32_t rc_off = rc_sym0 + (int32_t)(rc_base + lds_cells) - 1 - (int32_t)km1;
-        // mismatch flags of bases [i0, i0 + 32) (i0 a multiple of 32): read words vs the reference words aligned with them
-        auto mism32 = [&](uint32_t i0) -> uint32_t {
-            const bool act = l1ok && i0 < len;
-            const uint32_t wi = i0 >> 4;
-            const uint32_t x0 = w[min(wi, last_word)], x1 = w[min(wi + 1u, last_word)];
+        // A chunk's 160 bases stay as the XOR with the reference along the diagonal leaves them, two bits per base: bits 2 i, 2 i + 1 of
+        // D[j] = read base cb + 16 j + i XOR the reference's (zero where the lane has no base).  A base differs where either bit is
+        // set (flags: (d | d << 1) at the odd bits); the flags are counted where they are (popcount) and turned into positions one
+        // by one (find-first-bit >> 1), and the two bits themselves say WHICH other base the read has there (bk_device.h v_alt) --
+        // compressing the flags to one bit per base cost a third of the kernel's instructions and bought nothing.
+        auto flags_of = [&](uint32_t d) __attribute__((always_inline)) -> uint32_t {
+            uint32_t f;
+            asm("v_lshl_or_b32 %0, %1, 1, %1" : "=v"(f) : "v"(d));   // d | d << 1 (the compiler folds a neighbouring op into a three-input one instead and pays a shift more)
+            return f & 0xaaaaaaaau;
+        };
+        uint32_t D[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) D[j] = 0u;
+        int32_t tp = -0x20000000;    // the lane's last resolved mismatch (absolute base), far away before the first
+        for (uint32_t cb = 0;; cb += 128u) {   // (wave-uniform) the chunk covers bases [cb, cb + 160); its first 32 are carried over
+            const bool act = l1ok && cb < len;
+            const uint32_t vlen = act ? min(len - cb, 160u) : 0u;   // the lane's bases in this chunk
+            // every active lane has at least min_v bases in the chunk, none more than max_v: the words all of them fill need no
+            // mask of their own, the words none of them reaches are not looked at
+            const uint32_t min_v = wave_min(act ? vlen : 0xffffffffu);
+            const uint32_t max_v = maxlen > cb ? min(maxlen - cb, 160u) : 0u;
             // read base i <-> reference base dgw + i along the reference; against it <-> complement of reference base dgw + k - 1 - i,
             // which is symbol rc_off - dgw + i of the reverse-complemented copy: the same walk on the other array
-            // (one LDS array, one base pointer: the copy's symbols lie rc_sym0 symbols behind the reference's)
-            const int32_t p0 = act ? (fwd ? dgw + (int32_t)i0 : rc_off - dgw + (int32_t)i0) : 0;
-            const uint32_t sh = 2u * ((uint32_t)p0 & 15u);
-            const uint32_t r0 = refw1[p0 >> 4], r1 = refw1[(p0 >> 4) + 1], r2 = refw1[(p0 >> 4) + 2];
-            const uint32_t ya = __builtin_amdgcn_alignbit(r1, r0, sh), yb = __builtin_amdgcn_alignbit(r2, r1, sh);   // 32 bases of that strand, in reading order
-            const uint32_t d0 = x0 ^ ya, d1 = x1 ^ yb;
-            const uint32_t m = even_bits(d0 | (d0 >> 1)) | (even_bits(d1 | (d1 >> 1)) << 16);
-            const uint32_t hi = len > i0 ? min(len - i0, 32u) : 0u;   // bases of the record in these words
-            return act ? m & (hi >= 32u ? 0xffffffffu : (1u << hi) - 1u) : 0u;
-        };
-        unsigned long long M01 = 0ull, M23 = 0ull;   // flags of the chunk's bases 0..63, 64..127
-        uint32_t M4 = 0u;                            // ... 128..159
-        int32_t tp = -0x20000000;    // the lane's last resolved mismatch (absolute base), far away before the first
-        auto peek3 = [&](unsigned long long m01, unsigned long long m23, uint32_t m4) -> uint32_t {   // lowest flag of the chunk
-            return m01 ? (uint32_t)__builtin_ctzll(m01) : m23 ? 64u + (uint32_t)__builtin_ctzll(m23) : m4 ? 128u + (uint32_t)__builtin_ctz(m4) : kNoPos;
-        };
-        auto pop3 = [&](unsigned long long& m01, unsigned long long& m23, uint32_t& m4) {   // ... taken off
-            const bool z01 = m01 == 0ull, z23 = m23 == 0ull;
-            m4 = (z01 && z23) ? m4 & (m4 - 1u) : m4;
-            m23 = z01 ? m23 & (m23 - 1ull) : m23;
-            m01 &= m01 - 1ull;
-        };
-        for (uint32_t cb = 0;; cb += 128u) {   // (wave-uniform) the chunk covers bases [cb, cb + 160); its first word is carried over
+            const int32_t p0 = act ? (fwd ? dgw + (int32_t)cb : rc_off - dgw + (int32_t)cb) : 0;
+            const uint32_t rsh = 2u * ((uint32_t)p0 & 15u);
+            const unsigned int* const rp = refw1 + (p0 >> 4);
+            const uint32_t lmask = act ? 0xffffffffu : 0u;
+            const uint32_t wi0 = cb >> 4;
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                if (cb != 0u && j == 0) continue;
-                const uint32_t f = mism32(cb + 32u * (uint32_t)j);
-                if (j == 0) M01 |= (unsigned long long)f; else if (j == 1) M01 |= (unsigned long long)f << 32;
-                else if (j == 2) M23 |= (unsigned long long)f; else if (j == 3) M23 |= (unsigned long long)f << 32;
-                else M4 = f;
+            for (int j = 0; j < 10; ++j) {
+                if (cb != 0u && j < 2) continue;
+                if (16u * (uint32_t)j >= max_v) { D[j] = 0u; continue; }
+                // (STAGED: words past the record's end belong to the next lane's record or to the padding behind the buffers; what
+                // they give is masked away below)
+                const uint32_t x = STAGED ? w[wi0 + (uint32_t)j] : w[min(wi0 + (uint32_t)j, last_word)];
+                const uint32_t y = __builtin_amdgcn_alignbit(rp[j + 1], rp[j], rsh);   // 16 bases of that strand, in reading order
+                uint32_t d = (x ^ y) & lmask;
+                if (16u * (uint32_t)(j + 1) > min_v) {   // (wave-uniform) some lane's bases end in this word or before it
+                    asm volatile("" ::: "memory");       // (a branch, not a select: nine words in ten of a launch of equal reads skip this)
+                    const int32_t amt = min(max(2 * (int32_t)vlen - 32 * j, 0), 32);
+                    d &= (uint32_t)(1ull << amt) - 1u;     // (amt = 32: the low word of 2^32 is 0, minus one = all ones)
+                }
+                D[j] = d;
             }
+            const uint32_t scanned = cb + 160u;
+            const bool last_chunk = scanned >= maxlen;
+            // STAGED: the record's words are all read: the wave's next tile is sent on its way into the same buffer.  (Nothing below
+            // reads a record: what an item needs of the read's base at its mismatch is in the flag pass's XOR.)
+            if (last_chunk && !BK_ABLATE(a, 6)) send_next();
+            uint32_t nfl = 0u;   // flags of the lane in this chunk
+#pragma unroll
+            for (int j = 0; j < 10; ++j) nfl += (uint32_t)__popc(flags_of(D[j]));
             if (cb == 0u) {
                 // A read that differs from the reference all along its diagonal -- a chimera, an adapter, a diagonal that a repeat's
                 // k-mer vouched for -- is no read of this diagonal: it goes to Level 2 whole, like a read without one.  (Settled
                 // here it would keep its wave busy for a hundred mismatches while the workgroup's other waves run out of tiles: six
                 // such reads in a million set the kernel's time.)
-                const bool off_diag = l1ok && (uint32_t)__popcll(M01) + (uint32_t)__popcll(M23) + (uint32_t)__popc(M4) > kMaxChunkMismatches;
-                if (off_diag) { l1ok = false; dfl &= ~2u; M01 = 0ull; M23 = 0ull; M4 = 0u; }
+                const bool off_diag = l1ok && nfl > kMaxChunkMismatches;
+                if (off_diag) {
+                    l1ok = false; dfl &= ~2u; nfl = 0u;
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) D[j] = 0u;
+                }
                 // a read that cannot be settled here is one N run
                 if (cold()->n_direct) l2_mark(nk != 0u && !l1ok, r32, 0u, nk, dg, dfl);   // (ScanArgs::n_direct: straight to Level 2's marks)
                 else n_mark(nk != 0u && !l1ok, r32, 0u, nk, dg, dfl);
             }
-            const uint32_t scanned = cb + 160u;
-            // STAGED: once the record's words are all read the wave's next tile is sent on its way into the same buffer -- after the
-            // first pass below has taken the bases at its mismatches from it (a later pass, one tile in ten, reads them from memory)
-            const bool last_chunk = scanned >= maxlen;
-            bool next_staged = false;
             // A mismatch is resolved once the k - 1 bases behind it are scanned (or the read ends): that far reach the k-mers that
             // hold it, and whatever they hold of its successors is then known.  What is not resolved lies in the chunk's last
-            // word (k <= 31): the word that is carried over.
+            // 32 bases (k <= 31): the words that are carried over.
             const bool all_res = scanned >= len;
-            const uint32_t r4 = all_res ? M4 : M4 & ((1u << (32u - km1)) - 1u);   // (flags 128 .. 159 - (k - 1); words 0..3 are always resolved)
-            if (BK_ABLATE(a, 6)) { M01 = 0ull; M23 = 0ull; M4 = 0u; }
-            // ---- one mismatch per lane: the tile's resolved mismatches are dealt out over the wave ----
-            const uint32_t cnt_m = BK_ABLATE(a, 6) ? 0u : (uint32_t)__popcll(M01) + (uint32_t)__popcll(M23) + (uint32_t)__popc(r4);
-            uint32_t pin = cnt_m;   // inclusive prefix sum over the lanes
+            if (BK_ABLATE(a, 6)) {
+                nfl = 0u;
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)pin, off); if (lane >= off) pin += x; }
-            const uint32_t pex = pin - cnt_m;
-            const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)pin, 63));
-            if constexpr (STAGED) {
-                if (last_chunk && n_items == 0u) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); len_pf = stage(next_tile); next_staged = true; }
+                for (int j = 0; j < 10; ++j) D[j] = 0u;
             }
-            for (uint32_t it0 = 0; it0 < n_items; it0 += 64u) {
-                // owner of item it0 + lane: every lane with items writes its number where its first item of this pass sits, a running
-                // maximum spreads it over the items behind
-                own_s[lane] = 0u;
-                __builtin_amdgcn_wave_barrier();
-                if (cnt_m && pin > it0 && pex < it0 + 64u) own_s[pex > it0 ? pex - it0 : 0u] = (uint32_t)lane;
-                __builtin_amdgcn_wave_barrier();
-                uint32_t ow = own_s[lane];
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)ow, off); if (lane >= off) ow = max(ow, x); }
-                const bool on = it0 + (uint32_t)lane < n_items;
-                const int src = on ? (int)ow : lane;
-                // the owner's read: flags, diagonal, length, record, last mismatch before this chunk's
-                unsigned long long m01 = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(M01 >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)M01, src);
-                unsigned long long m23 = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(M23 >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)M23, src);
-                uint32_t m4 = (uint32_t)__shfl((int)M4, src);
-                const int32_t o_dgw = __shfl(dgw, src);
-                const uint32_t o_fl = (uint32_t)__shfl((int)dfl, src);
-                const uint32_t o_nk = (uint32_t)__shfl((int)nk, src);
-                const uint32_t o_rec = (uint32_t)__shfl((int)r32, src);
-                int32_t tq = __shfl(tp, src);                      // becomes the mismatch before mine
-                const uint32_t o_pex = (uint32_t)__shfl((int)pex, src);   // (every shuffle outside the conditions: a lane that is off may be another's owner)
-                uint32_t jj = on ? it0 + (uint32_t)lane - o_pex : 0u;   // mine is the owner's jj-th of this chunk
-                while (__ballot(jj != 0u)) {
-                    if (jj) { tq = (int32_t)(cb + peek3(m01, m23, m4)); pop3(m01, m23, m4); --jj; }
-                }
-                const bool ofwd = o_fl & 1u;
-                const int32_t t = on ? (int32_t)(cb + peek3(m01, m23, m4)) : 0;
-                pop3(m01, m23, m4);
-                const uint32_t nb = peek3(m01, m23, m4);
-                const int32_t tn = (on && nb != kNoPos) ? (int32_t)(cb + nb) : 0x20000000;   // (an unseen one is out of reach)
-                pop3(m01, m23, m4);
-                const uint32_t nb2 = peek3(m01, m23, m4);
-                const int32_t tn2 = (on && nb2 != kNoPos) ? (int32_t)(cb + nb2) : 0x20000000;
-                // The k-mers between the previous mismatch and this one hold none: an E run (they start behind the previous one and
-                // end before this one)
-                const uint32_t done = tq < 0 ? 0u : min((uint32_t)tq, o_nk - 1u) + 1u;
+            // resolved flags of the lane: all of them, or all but those of words 8 and 9 above the line
+            const uint32_t cr = (last_chunk || all_res) ? nfl : nfl - (uint32_t)__popc(flags_of(D[8] & um8)) - (uint32_t)__popc(flags_of(D[9] & um9));
+            // ---- one mismatch per lane: the tile's flags are dealt out over the wave ----
+            // Every lane writes the positions of its flags into the wave's list (lst: position | lane << 16 | 1 << 23 | XOR << 24,
+            // the lanes' stretches one behind the other); lane i of a pass then takes entry i: its mismatch t, the entries next to
+            // it -- the same read's previous and next two, if the owner is the same -- and the owner's diagonal, length and record
+            // through three shuffles.  (Until round 6 the owner's 160 flags travelled to every item lane through five shuffles,
+            // were popped one by one there, and a running maximum over the lanes found the owner.)  A tile with more flags than
+            // the list holds goes round by round of whole lanes.
+            const uint32_t pin = wave_incl_add(nfl), pex = pin - nfl;
+            const uint32_t n_all = (uint32_t)__builtin_amdgcn_readlane((int)pin, 63);
+            uint32_t last_pos = 0u;   // absolute position of the lane's last flag (low 16 bits)
+            const uint32_t own_w0 = ((uint32_t)dgw << 3) | (all_res ? 4u : 0u) | dfl;   // what an item needs of its owner, word 0
+            for (uint32_t lane0 = 0u; n_all != 0u && lane0 < 64u;) {
+                const bool one = n_all <= kListCap;   // (wave-uniform) everything fits: the common case
+                const uint32_t base = one ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)pex, (int)lane0);
+                const bool in_r = one || ((uint32_t)lane >= lane0 && pin - base <= kListCap);   // (a lane has at most 160 flags: lane0 always is)
+                const uint32_t lane1 = one ? 64u : lane0 + (uint32_t)__popcll(__ballot(in_r));
+                const uint32_t n_r = one ? n_all : (uint32_t)__builtin_amdgcn_readlane((int)pin, (int)lane1 - 1) - base;
                 {
-                    const bool eg = on && t >= k && (uint32_t)(t - k) >= done && done < o_nk;
-                    const uint32_t g_hi = min((uint32_t)(t - k), o_nk - 1u);
-                    emit_e(eg, (uint32_t)(ofwd ? o_dgw + (int32_t)done : o_dgw - (int32_t)g_hi), g_hi - done + 1u, ofwd);
-                }
-                // The k-mers whose FIRST mismatch is t: they start behind the previous one and hold t.  Every k-mer that holds a
-                // mismatch belongs to exactly one such range.
-                const uint32_t o_lo = (uint32_t)max(max(t - (int32_t)km1, tq + 1), 0), o_hi = min((uint32_t)t, o_nk - 1u);
-                const bool own = on && o_lo <= o_hi;
-                // Their cells, lowest first (window coordinates), and which of them are "fast" (clean, ids = cell + one constant).
-                const int32_t ca = own ? (ofwd ? o_dgw + (int32_t)o_lo : o_dgw - (int32_t)o_hi) : 0;
-                const uint32_t n_own = own ? o_hi - o_lo + 1u : 0u;           // (at most k <= 31)
-                uint32_t pat = bits32_at(fastw, ca) & ((1u << n_own) - 1u);   // bit p: the cell ca + p is fast
-                // which of the three other bases: read XOR reference at the mismatch, the same on either strand (bk_device.h)
-                const uint32_t tt = own ? (uint32_t)t : 0u;
-                uint32_t rw;
-                if (STAGED && !next_staged) {
-                    rw = rec_buf[(uint32_t)src * sw + min(tt >> 4, last_word)];   // the owner's record is still in the wave's buffer
-                    if (last_chunk) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); len_pf = stage(next_tile); next_staged = true; }
-                } else {
-                    rw = (words0 + (uint64_t)o_rec * a.stride_words)[min(tt >> 4, last_word)];
-                }
-                const int32_t pr = own ? (ofwd ? o_dgw + (int32_t)tt : o_dgw + (int32_t)km1 - (int32_t)tt) : 0;
-                const uint32_t refb = (refw1[pr >> 4] >> (2u * ((uint32_t)pr & 15u))) & 3u;
-                const uint32_t alt = ((((rw >> (2u * (tt & 15u))) & 3u) ^ (ofwd ? refb : 3u - refb)) & 3u) - 1u;
-                // Cells that are not fast: per (position of the mismatch, other base) the offsets at which the k-mer still takes its own
-                // row (IndexView::cell_nat); with cell_natrow the bits stand for one V row of their own, whatever cell_blk says.
-                bool by_row = false;
-                uint32_t nat_row = 0u;
-                if (a.cell_nat && own && pat != (1u << n_own) - 1u && !BK_ABLATE(a, 12)) {
-                    const uint32_t nm = (__brev(a.cell_nat[((size_t)(pr + (int32_t)win_lo)) * 3u + alt]) >> (31u - (uint32_t)(pr - ca))) & ((1u << n_own) - 1u);
-                    if (a.cell_natrow) { pat = nm; by_row = true; nat_row = a.cell_natrow[(size_t)(pr + (int32_t)win_lo)]; }
-                    else pat |= nm;
-                }
-                if (BK_ABLATE(a, 5)) pat = 0u;                                // (5: nothing is settled here)
-                uint32_t used = 0u;   // cells of the range already dealt with
-                while (__ballot(used < n_own)) {
-                    const bool go = used < n_own;
-                    const uint32_t rest = pat >> used;
-                    const bool ones = rest & 1u;
-                    // the stretch of equal bits at `used`: cells ca + used .. ca + used + ln - 1
-                    const uint32_t ln = go ? min((uint32_t)__builtin_ctz((ones ? ~rest : rest) | (1u << (n_own - used))), n_own - used) : 0u;
-                    const int32_t c0 = ca + (int32_t)used, c1 = c0 + (int32_t)ln - 1;
-                    // ... are the k-mers [x_lo, x_hi] (a read against the reference meets the cells from the top)
-                    const uint32_t x_lo = ofwd ? o_lo + used : o_hi + 1u - used - ln, x_hi = x_lo + ln - 1u;
-                    const uint2 ba = blkw[(go ? c0 : 0) >> 6], bz = blkw[(go ? c1 : 0) >> 6];
-                    const bool fast = go && ones && (by_row || ba.x == bz.x);
-                    // of these, [x_lo, xs_hi] hold nothing but t -- an S run -- and [xm_lo, x_hi] also hold the next mismatch
-                    const int32_t xs_hi_i = min((int32_t)x_hi, tn - k);
-                    const bool has_s = fast && xs_hi_i >= (int32_t)x_lo;
-                    const uint32_t xs_hi = has_s ? (uint32_t)xs_hi_i : x_lo;
-                    const uint32_t xm_lo = (uint32_t)max((int32_t)x_lo, tn - (int32_t)km1);
-                    const bool has_m = fast && xm_lo <= x_hi;
-                    {
-                        const uint32_t tpos = tt - x_lo, nm1 = xs_hi - x_lo;   // offset of the differing base in the run's first k-mer
-                        // offsets (along the reference, from each k-mer's start) the run's k-mers have the difference at
-                        const uint32_t of_first = ofwd ? tpos : km1 - tpos;
-                        const uint32_t of_lo = ofwd ? tpos - nm1 : of_first;       // fwd: later k-mers start later, the offset shrinks
-                        const uint32_t of_hi = ofwd ? tpos : of_first + nm1;
-                        const int lo2 = max((int)of_lo, omin), hi2 = min((int)of_hi, omin + span - 1);
-                        if (has_s && lo2 <= hi2 && !BK_ABLATE(a, 2) && !BK_ABLATE(a, 14)) {
-                            const uint32_t idS = by_row ? nat_row - of_first                       // (cell_natrow: id + offset of every k-mer of the run)
-                                                        : (uint32_t)(ofwd ? c0 : c1) + win_lo + ba.x;   // id of the cell of k-mer x_lo (cell_fast: ids = cell + constant)
-                            // one row of the V plane: +1 at the first offset, -1 after the last (slot `span` is never read) -- two items
-                            // of the row's bin (rows never straddle bins)
-                            const uint32_t q = idS + of_first - (uint32_t)omin;
-                            const uint32_t bin = n_eb + (q >> vq_log2);
-                            const uint32_t o0 = (((q & vqm) * 3u + alt) * 2u + (ofwd ? 0u : 1u)) * rl + (uint32_t)(lo2 - omin);
-                            const bool tail = hi2 - omin + 1 < span;
-                            const uint32_t s = __hip_atomic_fetch_add(&cnt[bin], tail ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            unsigned short* const bk = buck + v_buck0 + (bin - n_eb) * cap_v;
-                            if (s < cap_v) bk[s] = (unsigned short)o0; else put_ext(bin, s - cap_v, o0);
-                            if (tail) {
-                                const uint32_t o1 = (o0 + (uint32_t)(hi2 - lo2 + 1)) | 0x8000u;
-                                if (s + 1u < cap_v) bk[s + 1u] = (unsigned short)o1; else put_ext(bin, s + 1u - cap_v, o1);
-                            }
+                    unsigned int* slot = lst + 1u + (pex - base);
+                    const uint32_t tag = ((uint32_t)lane << 16) | (1u << 23) | cb;   // (cb is a multiple of 128 below 2^16: | is +)
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) {
+                        uint32_t f = in_r ? flags_of(D[j]) : 0u;
+                        for (;;) {
+                            const bool has = f != 0u;
+                            if (!__ballot(has)) break;
+                            const uint32_t bit = (uint32_t)__builtin_ctz(f | 0x80000000u);            // 2 i + 1 (31 where f is 0: flags sit at odd bits)
+                            const uint32_t x2 = (D[j] >> ((bit - 1u) & 31u)) & 3u;                      // read base XOR reference base there
+                            const uint32_t e = (tag + 16u * (uint32_t)j + (bit >> 1)) | (x2 << 24);
+                            if (has) { *slot = e; ++slot; last_pos = e; }
+                            f &= f - 1u;
                         }
                     }
+                    if (lane == 0) { lst[n_r + 1u] = 0u; lst[n_r + 2u] = 0u; }   // (no entry: bit 23 is clear)
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t it0 = 0; it0 < n_r; it0 += 64u) {
+                    const uint32_t ix0 = it0 + (uint32_t)lane;
+                    const bool in_list = ix0 < n_r;
+                    const uint32_t e_m = lst[ix0], e_0 = lst[ix0 + 1u], e_1 = lst[ix0 + 2u], e_2 = lst[ix0 + 3u];
+                    const int src = in_list ? (int)((e_0 >> 16) & 63u) : lane;
+                    // the owner's read: diagonal, flags, length, record, last mismatch before this chunk's
+                    // (every shuffle outside the conditions: a lane that is off may be another's owner)
+                    const uint32_t o_w0 = (uint32_t)__shfl((int)own_w0, src);
+                    const uint32_t o_nk = (uint32_t)__shfl((int)nk, src);
+                    const uint32_t o_rec = (uint32_t)__shfl((int)r32, src);
+                    int32_t tq = cb ? __shfl(tp, src) : -0x20000000;   // becomes the mismatch before mine
+                    const int32_t o_dgw = (int32_t)o_w0 >> 3;
+                    const uint32_t o_fl = o_w0 & 3u;
+                    const bool ofwd = o_fl & 1u;
+                    auto same = [&](uint32_t e) { return ((e ^ e_0) & 0x00bf0000u) == 0u; };   // an entry, and of the same lane
+                    const int32_t t = in_list ? (int32_t)(e_0 & 0xffffu) : 0;
+                    // mine is resolved?  (an unresolved one waits for the next chunk; its lane idles)
+                    const bool on = in_list && ((o_w0 & 4u) || (uint32_t)t - cb + km1 < 160u);
+                    if (same(e_m)) tq = (int32_t)(e_m & 0xffffu);
+                    const int32_t tn = (in_list && same(e_1)) ? (int32_t)(e_1 & 0xffffu) : 0x20000000;   // (an unseen one is out of reach)
+                    const int32_t tn2 = (in_list && same(e_2)) ? (int32_t)(e_2 & 0xffffu) : 0x20000000;
+                    // The k-mers between the previous mismatch and this one hold none: an E run (they start behind the previous one and
+                    // end before this one)
+                    const uint32_t done = tq < 0 ? 0u : min((uint32_t)tq, o_nk - 1u) + 1u;
                     {
-                        // The k-mers that hold t and its successor.  If none of them reaches the successor after that and each of their
-                        // cells has no other reference k-mer form within Hamming distance 3, they hold exactly two differences from a
-                        // reference k-mer that is isolated up to distance 3: neither a reference k-mer nor one base away from one
-                        // (triangle inequality) -- they touch nothing.  Otherwise level2_kernel looks at them one by one.
-                        // (those of them that stop short of tn2 -- [xm_lo, xd_hi] -- are judged on their own: in a stretch of three
-                        // close mismatches only the k-mers that hold all three are Level 2's)
-                        const int32_t xd_hi_i = min((int32_t)x_hi, tn2 - k);
-                        const bool has_d = has_m && !stats && xd_hi_i >= (int32_t)xm_lo;
-                        const uint32_t xd_hi = has_d ? (uint32_t)xd_hi_i : xm_lo;
-                        const int32_t ma = has_d ? (ofwd ? o_dgw + (int32_t)xm_lo : o_dgw - (int32_t)xd_hi) : 0;
-                        const uint32_t needm = has_d ? 0xffffffffu >> (31u - (xd_hi - xm_lo)) : 0u;
-                        const bool dead = has_d && (bits32_at(c3w, ma) & needm) == needm;
-                        const uint32_t xl = dead ? xd_hi + 1u : xm_lo;   // first k-mer that is marked
-                        l2_mark(has_m && xl <= x_hi, o_rec, xl, x_hi + 1u - xl, o_dgw + (int32_t)win_lo, o_fl);
+                        const bool eg = on && t >= k && (uint32_t)(t - k) >= done && done < o_nk;
+                        const uint32_t g_hi = min((uint32_t)(t - k), o_nk - 1u);
+                        emit_e(eg, (uint32_t)(ofwd ? o_dgw + (int32_t)done : o_dgw - (int32_t)g_hi), g_hi - done + 1u, ofwd);
                     }
-                    // cells that are not fast
-                    l2_mark(go && !fast, o_rec, x_lo, ln, o_dgw + (int32_t)win_lo, o_fl);
-                    used += ln;
+                    // The k-mers whose FIRST mismatch is t: they start behind the previous one and hold t.  Every k-mer that holds a
+                    // mismatch belongs to exactly one such range.
+                    const uint32_t o_lo = (uint32_t)max(max(t - (int32_t)km1, tq + 1), 0), o_hi = min((uint32_t)t, o_nk - 1u);
+                    const bool own = on && o_lo <= o_hi;
+                    // Their cells, lowest first (window coordinates), and which of them are "fast" (clean, ids = cell + one constant).
+                    const int32_t ca = own ? (ofwd ? o_dgw + (int32_t)o_lo : o_dgw - (int32_t)o_hi) : 0;
+                    const uint32_t n_own = own ? o_hi - o_lo + 1u : 0u;           // (at most k <= 31)
+                    uint32_t pat = bits32_at(fastw, ca) & ((1u << n_own) - 1u);   // bit p: the cell ca + p is fast
+                    // which of the three other bases: read XOR reference at the mismatch, the same on either strand (bk_device.h)
+                    const uint32_t tt = own ? (uint32_t)t : 0u;
+                    const int32_t pr = own ? (ofwd ? o_dgw + (int32_t)tt : o_dgw + (int32_t)km1 - (int32_t)tt) : 0;   // the reference position of the mismatch
+                    const uint32_t alt = ((e_0 >> 24) & 3u) - 1u;   // (the flag pass's XOR: read against reference along, or complement against it -- the same)
+                    // Cells that are not fast: per (position of the mismatch, other base) the offsets at which the k-mer still takes its own
+                    // row (IndexView::cell_nat); with cell_natrow the bits stand for one V row of their own, whatever cell_blk says.
+                    bool by_row = false;
+                    uint32_t nat_row = 0u;
+                    if (a.cell_nat && own && pat != (1u << n_own) - 1u && !BK_ABLATE(a, 12)) {
+                        const uint32_t nm = (__brev(a.cell_nat[((size_t)(pr + (int32_t)win_lo)) * 3u + alt]) >> (31u - (uint32_t)(pr - ca))) & ((1u << n_own) - 1u);
+                        if (a.cell_natrow) { pat = nm; by_row = true; nat_row = a.cell_natrow[(size_t)(pr + (int32_t)win_lo)]; }
+                        else pat |= nm;
+                    }
+                    if (BK_ABLATE(a, 5)) pat = 0u;                                // (5: nothing is settled here)
+                    uint32_t used = 0u;   // cells of the range already dealt with
+                    while (__ballot(used < n_own)) {
+                        const bool go = used < n_own;
+                        const uint32_t rest = pat >> used;
+                        const bool ones = rest & 1u;
+                        // the stretch of equal bits at `used`: cells ca + used .. ca + used + ln - 1
+                        const uint32_t ln = go ? min((uint32_t)__builtin_ctz((ones ? ~rest : rest) | (1u << (n_own - used))), n_own - used) : 0u;
+                        const int32_t c0 = ca + (int32_t)used, c1 = c0 + (int32_t)ln - 1;
+                        // ... are the k-mers [x_lo, x_hi] (a read against the reference meets the cells from the top)
+                        const uint32_t x_lo = ofwd ? o_lo + used : o_hi + 1u - used - ln, x_hi = x_lo + ln - 1u;
+                        const uint2 ba = blkw[(go ? c0 : 0) >> 6], bz = blkw[(go ? c1 : 0) >> 6];
+                        const bool fast = go && ones && (by_row || ba.x == bz.x);
+                        // of these, [x_lo, xs_hi] hold nothing but t -- an S run -- and [xm_lo, x_hi] also hold the next mismatch
+                        const int32_t xs_hi_i = min((int32_t)x_hi, tn - k);
+                        const bool has_s = fast && xs_hi_i >= (int32_t)x_lo;
+                        const uint32_t xs_hi = has_s ? (uint32_t)xs_hi_i : x_lo;
+                        const uint32_t xm_lo = (uint32_t)max((int32_t)x_lo, tn - (int32_t)km1);
+                        const bool has_m = fast && xm_lo <= x_hi;
+                        {
+                            const uint32_t tpos = tt - x_lo, nm1 = xs_hi - x_lo;   // offset of the differing base in the run's first k-mer
+                            // offsets (along the reference, from each k-mer's start) the run's k-mers have the difference at
+                            const uint32_t of_first = ofwd ? tpos : km1 - tpos;
+                            const uint32_t of_lo = ofwd ? tpos - nm1 : of_first;       // fwd: later k-mers start later, the offset shrinks
+                            const uint32_t of_hi = ofwd ? tpos : of_first + nm1;
+                            const int lo2 = max((int)of_lo, omin), hi2 = min((int)of_hi, omin + span - 1);
+                            if (has_s && lo2 <= hi2 && !BK_ABLATE(a, 2) && !BK_ABLATE(a, 14)) {
+                                const uint32_t idS = by_row ? nat_row - of_first                       // (cell_natrow: id + offset of every k-mer of the run)
+                                                            : (uint32_t)(ofwd ? c0 : c1) + win_lo + ba.x;   // id of the cell of k-mer x_lo (cell_fast: ids = cell + constant)
+                                // one row of the V plane: +1 at the first offset, -1 after the last (slot `span` is never read) -- two items
+                                // of the row's bin (rows never straddle bins)
+                                const uint32_t q = idS + of_first - (uint32_t)omin;
+                                const uint32_t bin = n_eb + (q >> vq_log2);
+                                const uint32_t o0 = (((q & vqm) * 3u + alt) * 2u + (ofwd ? 0u : 1u)) * rl + (uint32_t)(lo2 - omin);
+                                const bool tail = hi2 - omin + 1 < span;
+                                const uint32_t s = __hip_atomic_fetch_add(&cnt[bin], tail ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                unsigned short* const bk = buck + v_buck0 + (bin - n_eb) * cap_v;
+                                if (s < cap_v) bk[s] = (unsigned short)o0; else put_ext(bin, s - cap_v, o0);
+                                if (tail) {
+                                    const uint32_t o1 = (o0 + (uint32_t)(hi2 - lo2 + 1)) | 0x8000u;
+                                    if (s + 1u < cap_v) bk[s + 1u] = (unsigned short)o1; else put_ext(bin, s + 1u - cap_v, o1);
+                                }
+                            }
+                        }
+                        {
+                            // The k-mers that hold t and its successor.  If none of them reaches the successor after that and each of their
+                            // cells has no other reference k-mer form within Hamming distance 3, they hold exactly two differences from a
+                            // reference k-mer that is isolated up to distance 3: neither a reference k-mer nor one base away from one
+                            // (triangle inequality) -- they touch nothing.  Otherwise level2_kernel looks at them one by one.
+                            // (those of them that stop short of tn2 -- [xm_lo, xd_hi] -- are judged on their own: in a stretch of three
+                            // close mismatches only the k-mers that hold all three are Level 2's)
+                            const int32_t xd_hi_i = min((int32_t)x_hi, tn2 - k);
+                            const bool has_d = has_m && !stats && xd_hi_i >= (int32_t)xm_lo;
+                            const uint32_t xd_hi = has_d ? (uint32_t)xd_hi_i : xm_lo;
+                            const int32_t ma = has_d ? (ofwd ? o_dgw + (int32_t)xm_lo : o_dgw - (int32_t)xd_hi) : 0;
+                            const uint32_t needm = has_d ? 0xffffffffu >> (31u - (xd_hi - xm_lo)) : 0u;
+                            const bool dead = has_d && (bits32_at(c3w, ma) & needm) == needm;
+                            const uint32_t xl = dead ? xd_hi + 1u : xm_lo;   // first k-mer that is marked
+                            l2_mark(has_m && xl <= x_hi, o_rec, xl, x_hi + 1u - xl, o_dgw + (int32_t)win_lo, o_fl);
+                        }
+                        // cells that are not fast
+                        l2_mark(go && !fast, o_rec, x_lo, ln, o_dgw + (int32_t)win_lo, o_fl);
+                        used += ln;
+                    }
+                }
+                lane0 = lane1;
+            }
+            if (last_chunk) ask_next();   // (a tile without a flag: nothing above did)
+            // each lane: its last resolved mismatch; what is not resolved stays
+            if (cr) {
+                if (last_chunk || all_res) tp = (int32_t)(last_pos & 0xffffu);
+                else {   // (long reads) the highest flag below the line
+                    uint32_t hi = 0u, hj = 0u;
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) { const uint32_t f = flags_of(j == 8 ? D[8] & ~um8 : j == 9 ? D[9] & ~um9 : D[j]); if (f) { hi = f; hj = (uint32_t)j; } }
+                    tp = (int32_t)(cb + 16u * hj + ((31u - (uint32_t)__builtin_clz(hi)) >> 1));
                 }
             }
-            // each lane: its last resolved mismatch; what is not resolved stays
-            if (cnt_m) tp = (int32_t)cb + (r4 ? 159 - (int32_t)__builtin_clz(r4) : M23 ? 127 - (int32_t)__builtin_clzll(M23) : 63 - (int32_t)__builtin_clzll(M01));
             if (scanned >= maxlen) break;
-            M01 = (unsigned long long)(M4 & ~r4); M23 = 0ull; M4 = 0u;   // the next chunk starts 128 bases on
+            // the next chunk starts 128 bases on: what was not resolved is its first 32 bases' flags
+            D[0] = all_res ? 0u : D[8] & um8; D[1] = all_res ? 0u : D[9] & um9;
         }
         {   // behind the last mismatch: k-mers [done, nk - 1]
             const uint32_t done = tp < 0 ? 0u : min((uint32_t)tp, nk - 1u) + 1u;
@@ -847,11 +963,13 @@ hipError_t launch_scan_items(const ScanArgs& a, uint32_t grid, hipStream_t strea
     ScanArgs b = a;
     // the records in LDS when they are short enough and a tile starts at a 16-byte boundary (LDS-DMA moves 16 bytes per lane)
     const uintptr_t first = reinterpret_cast<uintptr_t>(a.words + a.rec_base * a.stride_words);
-    const bool staged = a.stride_words <= kStageMaxWords && (first & 15u) == 0 && !BK_ABLATE(a, 16);
+    // (+ 128 bytes behind the buffers: the flag pass reads a chunk's ten words whatever the record's length; 160 KB per workgroup)
+    const size_t stage_off = (lds + 15u) & ~(size_t)15u, stage_end = stage_off + (size_t)kItemWaves * 64u * a.stride_words * sizeof(unsigned int) + 128u;
+    const bool staged = a.stride_words <= kStageMaxWords && (first & 15u) == 0 && stage_end <= 160u * 1024u && !BK_ABLATE(a, 16);
     b.stage_off = 0;
     if (staged) {
-        b.stage_off = (uint32_t)((lds + 15u) & ~(size_t)15u);
-        lds = b.stage_off + (size_t)kItemWaves * 64u * a.stride_words * sizeof(unsigned int);
+        b.stage_off = (uint32_t)stage_off;
+        lds = stage_end;
     }
     void (*kern)(ScanArgs);
     if (staged) kern = a.k == 21 ? scan_items_kernel<21, true> : a.k == 31 ? scan_items_kernel<31, true> : scan_items_kernel<0, true>;

@@ -8,7 +8,9 @@ sys.path.insert(0, ROOT)
 import torch
 from bronko_amd import Params, synth, _ffi
 from bronko_amd.hostlib import HostIndex
-_ffi.use_testing_library(True)
+RELEASE = len(sys.argv) > 2 and sys.argv[2] == "release"   # the product build, no switch (what tools/pmc_any.sh ... release profiles)
+if not RELEASE:
+    _ffi.use_testing_library(True)
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 n = 1000000
 names = ["wuhan_ref.fasta", "OM223929.1.fasta", "ON765678.1.fasta", "PX392231.1.fasta"]
@@ -32,7 +34,8 @@ else:
 packed = [synth.pack_codes_torch(c) for c in mates]
 torch.cuda.synchronize()
 for ab in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("0", "11", "10", "2", "6", "7", "9")):
-    os.environ["BK_SCAN_ABLATE"] = ab
+    if not RELEASE:
+        os.environ["BK_SCAN_ABLATE"] = ab
     ix = hix if cfg == 5 else HostIndex.build(21, paths, threads=4)
     eng = ix.engine(Params(pileup_selected_only=(cfg == 5)))
     for rep in range(4):

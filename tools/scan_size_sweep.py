@@ -1,16 +1,19 @@
 #!/usr/bin/env python3
 """Scan kernel time against the number of reads in the launch (config 2 shape): the fixed part of a launch (LDS set-up, the
 last tile's flush, the prefix sum and the slab write) against the part that grows with the reads.
-usage: tools/scan_size_sweep.py [ablate]"""
+usage: tools/scan_size_sweep.py [ablate | release]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from bronko_amd import Params, synth, _ffi
 from bronko_amd.hostlib import HostIndex
-_ffi.use_testing_library(True)
-if len(sys.argv) > 1:
-    os.environ["BK_SCAN_ABLATE"] = sys.argv[1]
+if len(sys.argv) > 1 and sys.argv[1] == "release":   # the product build (no switches)
+    pass
+else:
+    _ffi.use_testing_library(True)
+    if len(sys.argv) > 1:
+        os.environ["BK_SCAN_ABLATE"] = sys.argv[1]
 path = os.path.join(ROOT, "tests", "golden", "4_sarscov2", "wuhan_ref.fasta")
 dev = torch.device("cuda", 0)
 g, isnv = synth.sample_genome(synth.read_fasta_bytes(path), 2)

@@ -147,7 +147,15 @@ struct HalfView {
     uint32_t m;               // positions per sub-table (phf_pos)
     uint32_t log2nb;
     uint32_t log2p;           // 2^log2p sub-tables
+    // Presence of a half-key among the reference k-mers' (round 6): one bit per possible half where the half is at most 24 bits
+    // (k <= 25: exact), else one bit at hash_key(half) of 2^bits_log2 (never a false "absent").  A k-mer can be a reference k-mer or
+    // one base from one only if one of its halves IS a reference k-mer's half (pigeonhole): two bit tests, both "absent", settle
+    // "touches nothing" before the six loads of the membership test and the two directory walks (Level 2's slow path).
+    const uint32_t* bits;     // null: no filter
+    uint32_t bits_log2;
+    uint32_t bits_exact;
 };
+BK_HD uint32_t half_bit_index(uint64_t half, uint32_t bits_log2, uint32_t exact) { return exact ? (uint32_t)half : hash_key(half, bits_log2); }
 
 // Everything the kernels need to know about the index; passed by value.
 //

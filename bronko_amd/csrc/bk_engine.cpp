@@ -295,7 +295,7 @@ struct bk_engine {
     DevBuf<uint2> cell_blk, seed_tab, seed_tab2;
     uint32_t seed_log2 = 0, seed2_log2 = 0;
     DevBuf<uint32_t> rc_words;              // the reference read backwards and complemented (scan_items_kernel: reads against the reference)
-    struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0, log2p = 0; } half_lo, half_hi;
+    struct HalfBufs { DevBuf<uint16_t> pilots; DevBuf<bk::HalfDir> dir; DevBuf<bk::NbEntry> cand; uint32_t m = 1, log2nb = 0, log2p = 0; DevBuf<uint32_t> bits; uint32_t bits_log2 = 0, bits_exact = 0; } half_lo, half_hi;
     DevBuf<unsigned int> deferred, n_deferred, deferred_mask;
     DevBuf<unsigned long long> deferred_n;   // dense planes: the deferred k-mers' counts (K2a zeroes the counters it reads)
     DevBuf<unsigned int> fin_partials;      // per-workgroup finalize tallies (small genome sets only)
@@ -434,8 +434,8 @@ struct bk_engine {
         v.kmer_pos = kmer_pos.p; v.pilots = pilots.p; v.m = m; v.log2nb = log2nb; v.log2p = log2p;
         v.kmer_of = kmer_of.p; v.id_rec = id_rec.p; v.dirty_ans = dirty_ans.p; v.cell_flags = cell_flags.p; v.ref_words = ref_words.p; v.cell_codes = cell_codes.p; v.cell_has = cell_has.p; v.cell_clean = cell_clean.p; v.cell_clean3 = cell_clean3.p; v.cell_yf = cell_yf.p; v.cell_yr = cell_yr.p; v.id_at = id_at.p; v.cell_fast = cell_fast.p; v.cell_nat = cell_nat.p; v.cell_natrow = cell_natrow.p; v.cell_blk = cell_blk.p; v.seed_tab = seed_tab.p; v.seed_log2 = seed_log2; v.total_cells = (uint32_t)total_cells; v.n_u = n_u;
         v.n_full = n_full; v.n_prows = n_prows; v.prow_id = prow_id.p; v.prow_t = prow_t.p; v.v_omin = v_omin; v.v_span = v_span; v.v_off = v_off;
-        v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb, half_lo.log2p};
-        v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb, half_hi.log2p};
+        v.lo = bk::HalfView{half_lo.pilots.p, half_lo.dir.p, half_lo.cand.p, half_lo.m, half_lo.log2nb, half_lo.log2p, half_lo.bits.p, half_lo.bits_log2, half_lo.bits_exact};
+        v.hi = bk::HalfView{half_hi.pilots.p, half_hi.dir.p, half_hi.cand.p, half_hi.m, half_hi.log2nb, half_hi.log2p, half_hi.bits.p, half_hi.bits_log2, half_hi.bits_exact};
         v.lo_bases = lo_bases; v.slot_of = slot_of.p; v.slot_rec = slot_rec.p; v.ent_files = ent_files.p; v.slot_files = slot_files.p; v.slot_alias = slot_alias.p; v.gather_ok = gather_ok ? 1u : 0u; v.id_own_files = id_own_files.p; v.cell_file = cell_file.p; v.id_rest_off = id_rest_off.p; v.id_rest = id_rest.p; v.estat_files = estat_files.p; v.amb = amb.p; v.estat_off = estat_off.p; v.estat = estat.p;
         v.table = table.p; v.ent_off = ent_off.p; v.ent_len = ent_len.p;
         v.entries = entries.p; v.n_slots = n_slots; v.log2s = log2s; v.k = k; v.wstart = wstart; v.W = W; v.n_files = n_files;
@@ -1590,7 +1590,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
         const uint64_t lo_mask = (1ull << lo_bits) - 1ull;
         {
             // both halves at once (host threads); the low half needs a sort of its own, the high half is h_u's order
-            struct HalfHost { std::vector<uint16_t> hp; std::vector<bk::HalfDir> dir; std::vector<bk::NbEntry> cand; bool ok = true; };
+            struct HalfHost { std::vector<uint16_t> hp; std::vector<bk::HalfDir> dir; std::vector<bk::NbEntry> cand; std::vector<uint32_t> bits; bool ok = true; };
             HalfHost hh[2];
             auto build_half = [&](int which) {
                 auto half_of = [&](uint64_t u) { return which == 0 ? (u & lo_mask) : (u >> lo_bits); };
@@ -1631,6 +1631,15 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 }
                 hc.lap("  half 0: candidates gathered, halves listed");
                 bk_engine::HalfBufs& hb = which == 0 ? e->half_lo : e->half_hi;
+                {   // the presence filter of this half (bk_device.h HalfView::bits): exact up to 24 bits, hashed above (16 bits per half-key: 6 % false "present")
+                    const int half_bits = which == 0 ? lo_bits : 2 * k - lo_bits;
+                    hb.bits_exact = half_bits <= 24 ? 1u : 0u;
+                    uint32_t l2 = (uint32_t)half_bits;
+                    if (!hb.bits_exact) { l2 = 16; while (l2 < 28 && (1ull << l2) < 16ull * halves.size()) l2++; }
+                    hb.bits_log2 = std::max<uint32_t>(l2, 5);
+                    hh[which].bits.assign((size_t)1 << (hb.bits_log2 - 5), 0u);
+                    for (uint64_t hf : halves) { const uint32_t b = bk::half_bit_index(hf, hb.bits_log2, hb.bits_exact); hh[which].bits[b >> 5] |= 1u << (b & 31u); }
+                }
                 std::vector<uint32_t> hpos;
                 if (!build_phf(halves, hh[which].hp, hb.log2nb, hb.m, hb.log2p, hpos)) { hh[which].ok = false; return; }
                 hh[which].dir.assign((size_t)hb.m << hb.log2p, bk::HalfDir{0u, 0u, 0u, 0u});
@@ -1648,6 +1657,7 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 BK_HIP(hb.pilots.upload(hh[which].hp));
                 BK_HIP(hb.dir.upload(hh[which].dir));
                 BK_HIP(hb.cand.upload(hh[which].cand));
+                BK_HIP(hb.bits.upload(hh[which].bits));
             }
         }
 
@@ -1980,6 +1990,8 @@ int bk_engine_fork_params(const bk_engine* parent, const bk_params* prm, bk_engi
     e->file_cell_lo = p->file_cell_lo; e->max_file_cells_idx = p->max_file_cells_idx; e->ablate = p->ablate; e->item_v_mode = p->item_v_mode; e->max_launch_records = p->max_launch_records;
     e->half_lo.m = p->half_lo.m; e->half_lo.log2nb = p->half_lo.log2nb; e->half_lo.log2p = p->half_lo.log2p;
     e->half_hi.m = p->half_hi.m; e->half_hi.log2nb = p->half_hi.log2nb; e->half_hi.log2p = p->half_hi.log2p;
+    e->half_lo.bits_log2 = p->half_lo.bits_log2; e->half_lo.bits_exact = p->half_lo.bits_exact; e->half_lo.bits.alias(p->half_lo.bits);
+    e->half_hi.bits_log2 = p->half_hi.bits_log2; e->half_hi.bits_exact = p->half_hi.bits_exact; e->half_hi.bits.alias(p->half_hi.bits);
     // the index tables are immutable after bk_engine_create: the fork reads the parent's
     e->prow_id.alias(p->prow_id); e->prow_t.alias(p->prow_t); e->kmer_pos.alias(p->kmer_pos); e->d_view.alias(p->d_view); e->kmer_of.alias(p->kmer_of); e->id_rec.alias(p->id_rec); e->dirty_ans.alias(p->dirty_ans); e->cell_flags.alias(p->cell_flags);
     e->ref_words.alias(p->ref_words); e->cell_codes.alias(p->cell_codes); e->cell_has.alias(p->cell_has); e->cell_clean.alias(p->cell_clean);
@@ -2650,8 +2662,8 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
         fprintf(stderr, "[bk] scan: %llu mismatches counted, %llu items processed, %llu E gaps before a mismatch, %llu behind the last\n", h[23], h[24], h[25], h[26]);
         fprintf(stderr, "[bk] scan N batches: %llu with %llu pieces (%.1f per batch), %llu of them forced by a tile's end\n", h[20], h[21], h[20] ? (double)h[21] / (double)h[20] : 0.0, h[22]);
         fprintf(stderr, "[bk] scan marked: no-diagonal %llu, dirty-head %llu, clean-head %llu, pairs %llu | level 2: k-mers %llu in %llu chunks, simple %llu, dead %llu, "
-                "dirty answers %llu (one difference but id unknown: %llu), slow %llu (diffs 0/1/2/3+ with a diagonal: %llu/%llu/%llu/%llu) -> member %llu, neighbour %llu, nothing %llu\n",
-                h[0], h[1], h[2], h[3], h[4], h[11], h[5], h[6], h[16], h[17], h[7], h[12], h[13], h[14], h[15], h[8], h[9], h[10]);
+                "dirty answers %llu (one difference but id unknown: %llu), neither half present %llu, slow %llu (diffs 0/1/2/3+ with a diagonal: %llu/%llu/%llu/%llu) -> member %llu, neighbour %llu, nothing %llu\n",
+                h[0], h[1], h[2], h[3], h[4], h[11], h[5], h[6], h[16], h[17], h[18], h[7], h[12], h[13], h[14], h[15], h[8], h[9], h[10]);
     }
     return BK_OK;
 }

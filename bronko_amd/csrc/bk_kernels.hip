@@ -1538,6 +1538,23 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
             if (m_live) atomicAdd(v_counters + vm, ~0ull);
         }
         if (BK_ABLATE(a, 3)) slow = false;
+        // Before the slow path: can it be a reference k-mer, or one base from one, at all?  Only if one of its halves is a reference
+        // k-mer's half (pigeonhole; the two directories the slow path walks are keyed by exactly these halves of the canonical k-mer):
+        // two bit tests in the halves' presence filters (HalfView::bits) -- both "absent" is proof that it touches nothing.  What
+        // comes here are reads that are not from the reference (every k-mer of a read without a diagonal) and k-mers with two
+        // sequencing errors where no cell is isolated (many related genomes: three in four of the slow path's k-mers found nothing
+        // there after eight random lines each).
+        if (slow && !stat_only && ix.lo.bits && ix.hi.bits && !BK_ABLATE(a, 13)) {
+            const int lo_bits = 2 * ix.lo_bases;
+            const uint64_t lo = c & ((1ull << lo_bits) - 1ull), hi = c >> lo_bits;
+            const uint32_t bl = half_bit_index(lo, ix.lo.bits_log2, ix.lo.bits_exact), bh = half_bit_index(hi, ix.hi.bits_log2, ix.hi.bits_exact);
+            const uint32_t wl = ix.lo.bits[bl >> 5], wh = ix.hi.bits[bh >> 5];
+            if (!(((wl >> (bl & 31u)) | (wh >> (bh & 31u))) & 1u)) {
+                stat_only = true;
+                slow = STATS;          // (full_kmer_stats still wants it in the statistics table)
+                BK_DBG(a, 18, true, 1);
+            }
+        }
         const unsigned long long mm = __ballot(slow);
         if (mm) {
             BK_DBG(a, 7, slow, 1);
@@ -1549,6 +1566,8 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
     };
 
     uint32_t qr = 0, qk = 0;   // wave-uniform fills of the record and k-mer queues
+    const bool roll_ok = !STATS && ix.lo.bits && ix.hi.bits && !BK_ABLATE(a, 13) && !BK_ABLATE(a, 15);   // (take_records: reads marked whole are rolled)
+    constexpr uint32_t kRollMin = 16;   // ... when a batch of 64 marked records holds at least this many
     auto take_kmers = [&]() __attribute__((always_inline)) {
         const uint32_t n = min(qk, 64u);
         process_kmers(n);   // reads kq[0, n)
@@ -1576,6 +1595,64 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
             qr = rest;
         }
         unsigned int* row = a.l2_bits + (size_t)(rec == 0xffffffffu ? 0u : rec) * nw;
+        // Reads marked whole -- reads without a diagonal: not from the reference (the host's, a contaminant's: most of a real sample),
+        // or the few the seeds missed -- cost the path below a dozen loads per k-mer to find that nearly all touch nothing.  When
+        // a batch of records holds enough of them (their first 64 marks are all set: no run of marks of a read with a diagonal is
+        // that long), they are ROLLED first, each by its lane: the canonical k-mer from its predecessor in a handful of
+        // instructions, its two halves looked up in the presence filters (HalfView::bits; see process_kmers) -- a k-mer neither
+        // of whose halves is a reference k-mer's half touches nothing and is not listed.  A sample of the reference's own reads
+        // never gets here (a wave would walk a read's length for a handful of records); full_kmer_stats wants every k-mer in its
+        // table and takes no short cut.
+        if (roll_ok && nw >= 2u) {
+            const bool valid = rec != 0xffffffffu;
+            const bool whole = valid && row[0] == 0xffffffffu && row[1] == 0xffffffffu;
+            if ((uint32_t)__popcll(__ballot(whole)) >= kRollMin) {
+                const uint32_t rec0 = valid ? rec : 0u;
+                const uint32_t len = whole ? (uint32_t)(a.lens + a.rec_base)[rec0] : 0u;
+                const uint32_t* __restrict__ w = words0 + (uint64_t)rec0 * a.stride_words;
+                const uint32_t max_len = wave_max(len);
+                const int lo_bits = 2 * ix.lo_bases;
+                const uint64_t lo_mask = (1ull << lo_bits) - 1ull;
+                uint64_t g = 0ull, ff = 0ull;   // the k-mer that ends at base i: base t at bits 2 t / first base on top (process_kmers' g and ff)
+                uint32_t keep = 0u, x = 0u;
+                // four bases at a time: their eight filter words are asked for together and looked at together (the filters' words come
+                // one cache line per lane: the loads are bound by the CU's line rate, not by their latency -- a dozen waves keep them going)
+                for (uint32_t i0 = 0; i0 < max_len; i0 += 4u) {   // (wave-uniform)
+                    if ((i0 & 15u) == 0u) x = w[min(i0 >> 4, last_word)];
+                    uint32_t wl[4], wh[4], sl = 0u, shh = 0u;   // the filter words; which bit of each (5 bits a k-mer)
+#pragma unroll
+                    for (uint32_t t = 0; t < 4u; ++t) {
+                        const uint32_t b = (x >> (2u * ((i0 & 12u) + t))) & 3u;
+                        g = (g >> 2) | ((uint64_t)b << (2 * (k - 1)));
+                        ff = ((ff << 2) | b) & kmask;
+                        const uint64_t rr = ~g & kmask;
+                        const uint64_t c = ff < rr ? ff : rr;                                      // lcb.rs:90-94
+                        const uint64_t lo = c & lo_mask, hi = c >> lo_bits;
+                        const uint32_t bl = half_bit_index(lo, ix.lo.bits_log2, ix.lo.bits_exact), bh = half_bit_index(hi, ix.hi.bits_log2, ix.hi.bits_exact);
+                        wl[t] = ix.lo.bits[bl >> 5]; wh[t] = ix.hi.bits[bh >> 5];                  // (any k-mer's: the filters are readable all over; the first k - 1 of a read are not looked at)
+                        sl |= (bl & 31u) << (5u * t); shh |= (bh & 31u) << (5u * t);
+                    }
+#pragma unroll
+                    for (uint32_t t = 0; t < 4u; ++t) {
+                        const uint32_t i = i0 + t;                  // the base that came in: k-mer s = i - (k - 1) ends there
+                        if (i < km1) continue;                      // (wave-uniform)
+                        const uint32_t s2 = i - km1;
+                        const uint32_t pl = wl[t] >> ((sl >> (5u * t)) & 31u), ph = wh[t] >> ((shh >> (5u * t)) & 31u);
+                        keep |= ((pl | ph) & 1u) << (s2 & 31u);
+                        if ((s2 & 31u) == 31u || i + 1u >= max_len) {   // (wave-uniform) a word of the record's marks is through
+                            const uint32_t wi = s2 >> 5;
+                            if (whole && wi < nw) {   // (the lane's own record: it reads these words again below, in program order)
+                                const uint32_t old = row[wi];
+                                BK_DBG(a, 18, (old & ~keep) != 0u, __popc(old & ~keep));
+                                if (old & ~keep) row[wi] = old & keep;
+                            }
+                            keep = 0u;
+                            if (i + 1u >= max_len) break;
+                        }
+                    }
+                }
+            }
+        }
         for (uint32_t w0 = 0; w0 < nw; w0 += 4u) {
             uint32_t bw[4];
 #pragma unroll

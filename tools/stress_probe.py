@@ -5,8 +5,11 @@ import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bronko_amd import Params, synth
+from bronko_amd import Params, synth, _ffi
 from bronko_amd.hostlib import HostIndex
+if len(sys.argv) > 1 and sys.argv[1] == "testing":   # the -DBK_TESTING build: BK_SCAN_ABLATE and friends are honoured
+    _ffi.use_testing_library(True)
+ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 else None   # run only the rows whose tag contains one of these
 ref_path = os.path.join(ROOT, "tests", "golden", "4_sarscov2", "wuhan_ref.fasta")
 ref = synth.read_fasta_bytes(ref_path)
 ix = HostIndex.build(21, [ref_path], threads=4)
@@ -14,6 +17,8 @@ eng = ix.engine(Params())
 dev = torch.device("cuda", 0)
 gm, isnv = synth.sample_genome(ref, 2)
 def run(tag, codes):
+    if ONLY and not any(o in tag for o in ONLY):
+        return
     dw, dl = synth.pack_codes_torch(codes)
     torch.cuda.synchronize()
     def step():
@@ -26,7 +31,7 @@ def run(tag, codes):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 10
     ms, n = eng.timing_read(reset=True); eng.timing_enable(0)
-    print("%-34s %7.3f ms/sample  %6.2f G bases/s   scan %.3f finalize %.3f" % (tag, dt * 1e3, codes.numel() / dt / 1e9, ms[0] / 10, ms[1] / 10), flush=True)
+    print("%-34s %7.3f ms/sample  %6.2f G bases/s   scan %.3f finalize %.3f level2 %.3f" % (tag, dt * 1e3, codes.numel() / dt / 1e9, ms[0] / 10, ms[1] / 10, ms[3] / 10), flush=True)
 N = 500000
 run("150 bp, 0.5 % errors", synth.single_end_codes_torch(gm, N, 150, 5, err=0.005, isnv=isnv, device=dev))
 run("150 bp, 2 % errors", synth.single_end_codes_torch(gm, N, 150, 5, err=0.02, isnv=isnv, device=dev))

@@ -36,6 +36,11 @@ import subprocess
 import sys
 import time
 
+# HIP gives a process four hardware queues by default and maps its streams onto them: with four or more engines in flight (a stream
+# each) two streams share a queue and their kernels wait for each other.  Eight queues, set before the runtime initialises (the
+# `bronko` binary does the same in main()); an explicit setting in the environment wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -69,7 +74,7 @@ def parse_args():
     ap.add_argument("--width", default="auto", choices=["auto", "16", "32", "64"], help="N > 1: bits per counter on the wire (bk_shard_transport). auto = "
                     "measured during the warm-up (bk_shard_measure), then fixed for the timed region; a width that is too narrow is detected, never silent")
     ap.add_argument("--no-other-configs", action="store_true", help="config 2 on one GPU: skip the bounded measurements of configs 3 and 5 and the K0 figure")
-    ap.add_argument("--in-flight", type=int, default=3, help="samples in flight per GPU (bk_engine_fork: shared index tables, own counter "
+    ap.add_argument("--in-flight", type=int, default=4, help="samples in flight per GPU (bk_engine_fork: shared index tables, own counter "
                     "planes / outputs / stream); 1 = strictly one sample after the other")
     ap.add_argument("--selected-only", action="store_true", help="bk_params.pileup_selected_only: votes for the selected genome only (two finalize "
                     "passes); what `bronko call` runs with -- the default is the reference's literal map_kmers: every genome's rows")

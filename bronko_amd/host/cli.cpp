@@ -1004,6 +1004,10 @@ int main(int argc, char** argv) {
     printf("bronko v%s\nMI355X (gfx950) k-mer -> pileup engine; drop-in for treangenlab/bronko's build / call\n\n", kVersion);
     fflush(stdout);
     const auto t0 = std::chrono::steady_clock::now();
+    // (HIP maps a process's streams onto four hardware queues by default: with more engines in flight than that -- lanes and their
+    // forks -- two streams share a queue and their kernels wait for each other; set before the runtime initialises, an explicit
+    // setting in the environment wins)
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     const Args a = parse_args(argc, argv);
     const int rc = a.mode == "build" ? run_build(a) : run_call(a);
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -32,6 +32,7 @@
 
 #include "../../include/bronko_hip.h"
 #include "caller.hpp"
+#include "fastq_pack.hpp"
 #include "fastx.hpp"
 #include "index.hpp"
 
@@ -306,7 +307,12 @@ void hip_check(int rc, const char* what) {
 // asynchronous: the next batch is parsed while the previous ones are copied, packed and scanned).  Every mate file is
 // inflated and parsed by its own host thread (upstream runs the two KMC processes of a pair concurrently too,
 // call.rs:301-307); the engine is only ever called from this thread.  Returns reads seen.
-struct FastqBatch { std::string buf; std::vector<uint64_t> off{0}; bool last = false; std::string error; };
+struct FastqBatch {
+    std::string buf; std::vector<uint64_t> off{0};   // sequence lines back to back (the line loop: streams, one thread) ...
+    PackedBatch packed; bool is_packed = false;      // ... or 2-bit records, parsed and packed on several threads (fastq_pack.hpp)
+    bool last = false; std::string error;
+    size_t bytes() const { return is_packed ? packed.bytes() : buf.size(); }
+};
 // The sequence text that samples read ahead of their turn hold in their queues, all of them together: counted as it is queued
 // (a batch's real bytes, not an estimate from the compressed size: amplicon FASTQ inflates 8-10x), released as lanes consume.
 struct AheadGate {
@@ -328,7 +334,7 @@ struct BatchQueue {
     std::atomic<bool> claimed{false};
     std::atomic<bool> abandoned{false};   // nobody will take from this queue any more (a run that ends early): the reader stops
     void put(FastqBatch&& b) {
-        const uint64_t sz = b.buf.size();
+        const uint64_t sz = b.bytes();
         if (gate) {
             std::unique_lock<std::mutex> gl(gate->m);
             gate->cv.wait(gl, [&] { return abandoned.load() || claimed.load() || gate->held == 0 || gate->held + sz <= gate->budget; });
@@ -356,7 +362,7 @@ struct BatchQueue {
             cv.notify_all();
         }
         if (gate) {
-            { std::unique_lock<std::mutex> gl(gate->m); gate->held -= std::min<uint64_t>(gate->held, b.buf.size()); }
+            { std::unique_lock<std::mutex> gl(gate->m); gate->held -= std::min<uint64_t>(gate->held, b.bytes()); }
             gate->cv.notify_all();
         }
         return b;
@@ -376,24 +382,48 @@ struct BatchQueue {
             std::unique_lock<std::mutex> lk(m);
             if (!spare.empty()) { b = std::move(spare.back()); spare.pop_back(); }
         }
-        b.buf.clear(); b.off.clear(); b.off.push_back(0); b.last = false; b.error.clear();
+        b.buf.clear(); b.off.clear(); b.off.push_back(0); b.packed.clear(); b.is_packed = false; b.last = false; b.error.clear();
         return b;
     }
 };
 // threads a FASTQ file's inflate may take (pargz.hpp): -t over the files that are read at the same time (set by call)
 unsigned g_inflate_threads = 1;
 unsigned g_ahead_inflate_threads = 1;   // ... for the files that are read ahead of their turn: -t over the files ReadAhead has open at once
+int g_kmer = 21;   // (set by call: the records a reader thread packs drop runs shorter than k)
 void parse_fastq(const std::string& path, BatchQueue& out, unsigned inflate_threads) {
     constexpr uint64_t kBatchReads = 1u << 16;   // (10 MB of bases: the engine pins three staging slots of that size per lane)
     FastqBatch cur;
     try {
-        GzLineReader in(path, inflate_threads);
-        uint64_t n = 0;
-        for (uint64_t ln = 0;; ln++) {               // 4-line FASTQ records: @id / sequence / + / quality
-            if ((ln & 3) != 1) { if (!in.skip_next()) break; continue; }
-            if (!in.append_next(cur.buf)) break;     // (the sequence line goes straight into the batch)
-            cur.off.push_back(cur.buf.size());
-            if (++n % kBatchReads == 0) { out.put(std::move(cur)); cur = out.fresh(); if (out.abandoned.load()) break; }
+        if (inflate_threads > 1) {
+            // threads to spare: the file's text is taken apart and 2-bit packed piece by piece on as many threads (fastq_pack.hpp);
+            // a few MB of text make a piece, pieces are gathered into batches of a quarter of a million records (a scan launch has
+            // a fixed cost: small pushes are slow pushes)
+            constexpr uint64_t kBatchRecords = 1u << 18;
+            FastqPacker in(path, g_kmer, inflate_threads);
+            PackedBatch b;
+            cur.is_packed = true;
+            while (in.next(b)) {
+                if (cur.packed.n_records && (cur.packed.stride != b.stride || cur.packed.n_records + b.n_records > 2 * kBatchRecords)) {
+                    out.put(std::move(cur)); cur = out.fresh(); cur.is_packed = true;
+                    if (out.abandoned.load()) break;
+                }
+                if (!cur.packed.n_records) { const uint64_t r = cur.packed.n_reads; cur.packed = std::move(b); cur.packed.n_reads += r; b = PackedBatch(); }
+                else {
+                    cur.packed.words.insert(cur.packed.words.end(), b.words.begin(), b.words.end());
+                    cur.packed.lens.insert(cur.packed.lens.end(), b.lens.begin(), b.lens.end());
+                    cur.packed.n_records += b.n_records; cur.packed.n_reads += b.n_reads;
+                }
+                if (cur.packed.n_records >= kBatchRecords) { out.put(std::move(cur)); cur = out.fresh(); cur.is_packed = true; if (out.abandoned.load()) break; }
+            }
+        } else {
+            GzLineReader in(path, inflate_threads);
+            uint64_t n = 0;
+            for (uint64_t ln = 0;; ln++) {               // 4-line FASTQ records: @id / sequence / + / quality
+                if ((ln & 3) != 1) { if (!in.skip_next()) break; continue; }
+                if (!in.append_next(cur.buf)) break;     // (the sequence line goes straight into the batch)
+                cur.off.push_back(cur.buf.size());
+                if (++n % kBatchReads == 0) { out.put(std::move(cur)); cur = out.fresh(); if (out.abandoned.load()) break; }
+            }
         }
     } catch (const std::exception& e) {
         cur = FastqBatch();
@@ -521,7 +551,11 @@ uint64_t push_fastqs(const std::vector<bk_engine*>& engs, const std::vector<std:
             if (done[m]) continue;
             FastqBatch b = queues[m].take();
             if (!b.error.empty() && error.empty()) error = b.error;
-            if (error.empty() && b.off.size() > 1) {
+            if (error.empty() && b.is_packed) {
+                if (b.packed.n_records)
+                    hip_check(bk_push_reads_packed(engs[n_batches++ % engs.size()], (int)m, b.packed.words.data(), b.packed.stride, b.packed.lens.data(), b.packed.n_records), "bk_push_reads_packed");
+                n_reads += b.packed.n_reads;
+            } else if (error.empty() && b.off.size() > 1) {
                 hip_check(bk_push_reads_ascii(engs[n_batches++ % engs.size()], (int)m, reinterpret_cast<const uint8_t*>(b.buf.data()), b.off.data(), b.off.size() - 1), "bk_push_reads_ascii");
                 n_reads += b.off.size() - 1;
             }
@@ -675,6 +709,7 @@ int run_call(const Args& a) {
         if (const char* it = getenv("BRONKO_INFLATE_THREADS")) g_ahead_inflate_threads = (unsigned)std::max(1, atoi(it));
         g_inflate_threads = g_ahead_inflate_threads;
     }
+    g_kmer = (int)a.kmer;   // (a database of another k is refused below: the readers may pack before it is read)
     std::unique_ptr<ReadAhead> ahead;
     if (!getenv("BRONKO_NO_READ_AHEAD")) {
         const uint64_t ram = (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)sysconf(_SC_PAGE_SIZE);

@@ -645,6 +645,21 @@ public:
     ParallelGunzip(const ParallelGunzip&) = delete;
     ParallelGunzip& operator=(const ParallelGunzip&) = delete;
 
+    // The next piece of the text as it stands (no copy): false at the end.  Throws like read().  (Not to be mixed with read().)
+    bool take(pargz::Piece& out) {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return !q_.empty() || done_; });
+        if (q_.empty()) {
+            if (!error_.empty()) throw std::runtime_error(error_ + " in " + path_);
+            return false;
+        }
+        queued_ -= q_.front().size();
+        out = std::move(q_.front()); q_.pop_front();
+        lk.unlock();
+        cv_.notify_all();
+        return true;
+    }
+
     // up to n bytes; 0 at the end of the text.  Throws std::runtime_error (damaged file) like a failed gzread.
     size_t read(char* dst, size_t n) {
         size_t got = 0;

@@ -72,6 +72,8 @@ def main():
     refs, kk, paths = prepare(tmp, S, N, NS)
     # (lanes per device, inflate threads per file, files read ahead of their turn): None = the binary's own choice
     runs = [("1", "1", False), ("1", None, False), ("1", None, True), (None, None, True)] if S > 1 else [("1", "1", False), ("1", None, False), ("1", None, True)]
+    if os.environ.get("E2E_EXTRA"):   # more (lanes, inflate threads) pairs with the files read ahead: E2E_EXTRA="2:2,2:4,4:2"
+        runs = [("1", "1", False)] + [(a.split(":")[0] or None, a.split(":")[1] or None, True) for a in os.environ["E2E_EXTRA"].split(",")]
     for lanes, inflate, ahead in runs:
         env = dict(os.environ)
         env.pop("BRONKO_LANES", None); env.pop("BRONKO_INFLATE_THREADS", None); env.pop("BRONKO_NO_READ_AHEAD", None)

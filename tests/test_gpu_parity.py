@@ -1262,3 +1262,31 @@ def test_no_device_allocation_after_an_engines_first_sample(oracle, monkeypatch,
     fork.close()
     eng.close()
     ix.close()
+
+
+@pytest.mark.parametrize("frac", [0.9, 0.5])
+def test_samples_that_are_mostly_not_the_references_reads(oracle, hpv, frac):
+    """Most of a real viral sample is the host's reads.  Level 2 takes reads marked whole (no diagonal) 64 at a time, rolls them and
+    strikes every k-mer neither of whose halves is a reference k-mer's half before it is looked up (level2_kernel take_records, the
+    pigeonhole filters HalfView::bits).  20,000 reads of which 90 % / 50 % are random -- a quarter of those with 25 bases of the
+    reference spliced in, whose k-mers and their neighbours DO touch the index --, the rest HPV16's with errors: every cell and
+    statistic equals the oracle's (call.rs:1257-1434), through the product build."""
+    ix, eng = hpv
+    g = synth.read_fasta_bytes(os.path.join(helpers.GOLDEN, "HPV16.fa"))
+    rng = np.random.default_rng(606 + int(frac * 10))
+    gm, isnv = synth.sample_genome(g, 31)
+    n = 20000
+    codes = synth.single_end_codes(gm, n, 150, 31, err=0.01, isnv=isnv)
+    foreign = rng.random(n) < frac
+    rnd = rng.integers(0, 4, size=(n, 150), dtype=np.uint8)
+    gc = synth.CODE[np.frombuffer(bytes(g), np.uint8)]
+    for i in np.nonzero(foreign)[0]:
+        codes[i] = rnd[i]
+        if rng.random() < 0.25:
+            q, a0 = int(rng.integers(0, 125)), int(rng.integers(0, len(gc) - 25))
+            codes[i, q:q + 25] = gc[a0:a0 + 25]
+    mates = [synth.codes_to_ascii(codes)]
+    pile = oracle.sample_pileup(ix, mates)
+    for rep in range(2):
+        res = helpers.hip_sample(eng, mates, 21)
+        helpers.assert_same_pileup(res, pile)

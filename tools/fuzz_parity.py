@@ -73,12 +73,18 @@ for it in range(first, first + iters):
     src = mutate(rng, base, int(rng.integers(0, 12)))
     reads = []
     err = float(rng.choice([0.0, 0.005, 0.02, 0.05, 0.12]))
+    # (round 6) one iteration in seven is a sample that is mostly NOT the reference's: Level 2 rolls reads marked whole, sixteen or
+    # more to a batch of marked records, against the half-k-mer presence filters -- which must strike nothing that touches the index
+    p_foreign = float(rng.uniform(0.5, 0.95)) if rng.random() < 0.15 else 0.05
     for _ in range(int(rng.integers(1, 3000))):
         ln = int(rng.integers(20, min(400, len(src))))
         a = int(rng.integers(0, len(src) - ln + 1))
         r = bytearray(src[a:a + ln])
         u = rng.random()
-        if u < 0.05: r = bytearray(rand_seq(rng, ln))                                   # foreign
+        if u < 0.05 or rng.random() < p_foreign - 0.05:                                 # foreign
+            r = bytearray(rand_seq(rng, ln))
+            if rng.random() < 0.3 and ln > 30:                                          # ... with a stretch of the reference in it (its k-mers do touch)
+                q = int(rng.integers(0, ln - 25)); r[q:q + 25] = src[a + q:a + q + 25]
         elif u < 0.10 and ln > 60:                                                      # chimera
             b2 = int(rng.integers(0, len(src) - ln + 1)); r[ln // 2:] = src[b2 + ln // 2:b2 + ln]
         elif u < 0.15 and ln > 40:                                                      # deletion / insertion

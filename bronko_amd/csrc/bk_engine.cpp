@@ -1564,7 +1564,9 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                 BK_HIP(e->seed_tab2.upload(h_seed2));
             }
         }
-        if (ix->n_files > 1 && (uint64_t)e->n_full * (uint64_t)ix->n_files <= (1ull << 28)) {
+        // (round 6: up to 2^31 entries -- 8 GB of the 288 --: 250 strains are 0.47 G; at 2^28 the window stayed on the first genome
+        // and every strain difference of a sample went to Level 2)
+        if (ix->n_files > 1 && (uint64_t)e->n_full * (uint64_t)ix->n_files <= (1ull << 31)) {
             std::vector<uint32_t> h_occ((size_t)e->n_full * ix->n_files, 0xffffffffu);
             for (int f = 0; f < ix->n_files; f++) {
                 const uint64_t c_lo = e->file_cell_lo[f], c_hi = f + 1 < ix->n_files ? e->file_cell_lo[f + 1] : cells;
@@ -1825,16 +1827,19 @@ int bk_engine_create(const bk_index_desc* ix, const bk_params* prm, bk_engine** 
                         h_all_own[id] = all ? 1 : 0;
                     }
                 });
-                {
-                    std::vector<uint16_t> h_cf(std::max<uint64_t>(cells, 1), 0);
-                    size_t sq2 = 0;
-                    for (int f = 0; f < ix->n_files; f++)
-                        for (int s2 = 0; s2 < ix->n_seqs[f]; s2++, sq2++) {
-                            const uint64_t lo = cell_off[f][s2], hi = lo + ix->seq_lens[sq2];
-                            for (uint64_t c = lo; c < hi && c < cells; c++) h_cf[c] = (uint16_t)f;
-                        }
-                    BK_HIP(e->cell_file.upload(h_cf));
-                }
+            }
+            // (which genome file a cell belongs to.  Round 6: for any number of genome files -- the gathered votes of bk_gather.hip need
+            // no file bitmap, and with more than 128 files, where there is none, they are what keeps every genome's rows affordable:
+            // 250 strains, 68 ms a sample through the BucketInfo lists)
+            if (ix->n_files > 1 && ix->n_files <= 65535 && e->W > 1 && !h_len.empty()) {
+                std::vector<uint16_t> h_cf(std::max<uint64_t>(cells, 1), 0);
+                size_t sq2 = 0;
+                for (int f = 0; f < ix->n_files; f++)
+                    for (int s2 = 0; s2 < ix->n_seqs[f]; s2++, sq2++) {
+                        const uint64_t lo = cell_off[f][s2], hi = lo + ix->seq_lens[sq2];
+                        for (uint64_t c = lo; c < hi && c < cells; c++) h_cf[c] = (uint16_t)f;
+                    }
+                BK_HIP(e->cell_file.upload(h_cf));
             }
             // IdRec: k-mer, first cell, flags; "simple" = each of the W buckets holds the k-mer's own single occurrence and nothing else
             HostVec<bk::IdRec> h_idrec = filled(std::max<size_t>(h_u.size(), 1), bk::IdRec{bk::kEmptyKey, 0u, 0u});
@@ -2637,7 +2642,7 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
         {   // the scan's workgroups on the clock (the sample's last launch): when each started, had its reference, ran out of tiles, ended
             unsigned long long t0 = ~0ull;
             int n_wg = 0;
-            for (int b = 0; b < 1024; b++) if (clk[4 * b]) { t0 = std::min(t0, clk[4 * b]); n_wg = b + 1; }
+            for (int b = 0; b < 512; b++) if (clk[4 * b]) { t0 = std::min(t0, clk[4 * b]); n_wg = b + 1; }   // (the second half holds the prologue clocks)
             if (n_wg) {
                 double mx[4] = {0, 0, 0, 0}, mean[4] = {0, 0, 0, 0}, mn[4] = {1e30, 1e30, 1e30, 1e30};
                 for (int b = 0; b < n_wg; b++)
@@ -2647,6 +2652,13 @@ static int finalize_part(bk_engine* e, int n_mates, uint64_t elem_lo, uint64_t e
                     }
                 fprintf(stderr, "[bk] scan workgroups (%d), us after the first start, min / mean / max: start %.1f / %.1f / %.1f, reference staged %.1f / %.1f / %.1f, "
                         "tiles done %.1f / %.1f / %.1f, end %.1f / %.1f / %.1f\n", n_wg, mn[0], mean[0], mx[0], mn[1], mean[1], mx[1], mn[2], mean[2], mx[2], mn[3], mean[3], mx[3]);
+                {
+                    double m2[4] = {0, 0, 0, 0};
+                    int n2 = 0;
+                    for (int b = 0; b < std::min(n_wg, 512); b++) if (clk[2048 + 4 * b]) { n2++; for (int j = 0; j < 4; j++) m2[j] += (double)(clk[2048 + 4 * b + j] - t0) * 0.01; }
+                    if (n2) fprintf(stderr, "[bk]   ... mean: first tile's copy sent %.1f, window's loads stored %.1f, wave 0 has its first tile %.1f, buckets written out %.1f\n",
+                                    m2[0] / n2, m2[1] / n2, m2[2] / n2, m2[3] / n2);
+                }
                 if (test_env("BK_L2_STATS")[0] == '2')
                     for (int b = 0; b < n_wg; b++) fprintf(stderr, "[bk]   wg %d: %.1f %.1f %.1f %.1f\n", b, (clk[4 * b] - t0) * 0.01, (clk[4 * b + 1] - t0) * 0.01, (clk[4 * b + 2] - t0) * 0.01, (clk[4 * b + 3] - t0) * 0.01);
             }

@@ -18,10 +18,14 @@ namespace bk {
 // ... and behind the 32 tallies, per workgroup of scan_items_kernel: [32 + 4 b] clock at its start, [+ 1] after the reference is
 // staged, [+ 2] after its last tile, [+ 3] at its end (wall_clock64: 100 MHz)
 #define BK_DBG_CLOCK(a, slot) do { if ((a).dbg && threadIdx.x == 0) (a).dbg[32 + 4 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
+// ... four more per workgroup (grids of up to 512) for the prologue: [2080 + 4 b]: first tile's copy sent, [+ 1] the window's loads
+// stored, [+ 2] wave 0 has its first tile, [+ 3] the buckets are written out
+#define BK_DBG_CLOCK2(a, slot) do { if ((a).dbg && threadIdx.x == 0 && blockIdx.x < 512) (a).dbg[2080 + 4 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
 #else
 #define BK_ABLATE(a, x) false
 #define BK_DBG(a, idx, pred, cnt) do { } while (0)
 #define BK_DBG_CLOCK(a, slot) do { } while (0)
+#define BK_DBG_CLOCK2(a, slot) do { } while (0)
 #endif
 
 constexpr int kSeeds = 4;

@@ -147,6 +147,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
     uint32_t len_pf = 0u;
     const uint64_t tile0 = (uint64_t)blockIdx.x * kItemWaves + (uint32_t)wave;   // the wave's first tile: of the workgroup's own chunk
     if constexpr (STAGED) len_pf = stage(tile0);
+    BK_DBG_CLOCK2(a, 0);
     uint32_t chunk1 = 0u;
     if (threadIdx.x == 0) {
         const uint32_t par = cold()->ov_par;
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
             }
         }
     }
+    BK_DBG_CLOCK2(a, 1);
     if (threadIdx.x == 0) { ring[0] = make_uint2(0u, blockIdx.x); ring[1] = make_uint2(1u, chunk1); }
     __syncthreads();
     BK_DBG_CLOCK(a, 1);
@@ -321,6 +323,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
             len = live ? (uint32_t)lens0[r32] : 0u;
         }
         if (len < (uint32_t)k) len = 0u;   // no k-mer
+        if (tile == tile0) BK_DBG_CLOCK2(a, 2);
         const uint32_t maxlen = wave_max(len);
         const uint32_t* __restrict__ w = STAGED ? rec_buf + (uint32_t)lane * sw : words0 + (uint64_t)r32 * a.stride_words;
         const uint32_t nk = len ? len - km1 : 0u;   // k-mers of the record
@@ -735,6 +738,7 @@ __global__ __launch_bounds__(kItemBlock) void scan_items_kernel(ScanArgs a) {
         for (uint32_t bin = threadIdx.x; bin < n_bins; bin += kItemBlock)
             c->tab[(size_t)bin * G + blockIdx.x] = (unsigned short)min(cnt[bin], (bin < n_eb ? cap_e : cap_v) + kItemGCap);
     }
+    BK_DBG_CLOCK2(a, 3);
     uint32_t tot = nkm;
 #pragma unroll
     for (int off = 32; off; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off);

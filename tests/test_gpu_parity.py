@@ -1290,3 +1290,39 @@ def test_samples_that_are_mostly_not_the_references_reads(oracle, hpv, frac):
     for rep in range(2):
         res = helpers.hip_sample(eng, mates, 21)
         helpers.assert_same_pileup(res, pile)
+
+
+def test_two_hundred_and_fifty_strains(oracle, sars_paths):
+    """"Hundreds of strains against hundreds of samples" (/root/reference/README.md:12; the loop call.rs:212-294 over build.rs:145-231's
+    index): 250 synthetic strains at k = 31 -- 79 M window slots, a 5.5 GB counter plane, more genome files than a file bitmap holds
+    (128: the statistics pass walks the BucketInfo lists) -- and 20,000 reads of a sample derived from strain 189, every genome's
+    rows (gathered cell by cell: bk_gather.hip needs no bitmap) and then the selected genome's on a fork, against the oracle bit for
+    bit."""
+    from bronko_amd import Params
+    files = synth.strain_files(synth.read_fasta_bytes(sars_paths[0]), 250)
+    ix = oracle.Index.build_mem(31, files)
+    eng = helpers.engine_from_oracle_index(ix)
+    gm, isnv = synth.sample_genome(files[189][1][0][1], 9)
+    codes = synth.single_end_codes(gm, 20000, 150, 77, isnv=isnv)
+    words, lens = synth.pack_codes(codes)
+    pile, _ = oracle.sample_pileup_mt(ix, [synth.BASES[codes]], os.cpu_count() or 8)
+    for rep in range(2):                                   # (twice: what a sample touched is clean again)
+        eng.sample_begin()
+        eng.push_reads(0, words, lens)
+        res = eng.sample_finish(1)
+        helpers.assert_same_pileup(res, pile)
+    best = oracle.pick_best_genome(ix, pile.stats.sum(axis=0), pile.present.max(axis=0))
+    assert best == 189
+    sel = eng.fork(Params(pileup_selected_only=True))
+    sel.sample_begin()
+    sel.push_reads(0, words, lens)
+    got = sel.sample_finish(1)
+    assert np.array_equal(got.stats, pile.stats) and np.array_equal(got.present, pile.present)
+    lo, n = ix.genome_cells(best)
+    for name in ("fwd_depth", "rev_depth", "fwd_nk", "rev_nk"):
+        g, w = getattr(got, name), getattr(pile, name)
+        assert np.array_equal(g[lo * 4:(lo + n) * 4], w[lo * 4:(lo + n) * 4]), name
+        assert not g[:lo * 4].any() and not g[(lo + n) * 4:].any(), name
+    sel.close()
+    eng.close()
+    ix.close()

@@ -74,7 +74,7 @@ def parse_args():
     ap.add_argument("--width", default="auto", choices=["auto", "16", "32", "64"], help="N > 1: bits per counter on the wire (bk_shard_transport). auto = "
                     "measured during the warm-up (bk_shard_measure), then fixed for the timed region; a width that is too narrow is detected, never silent")
     ap.add_argument("--no-other-configs", action="store_true", help="config 2 on one GPU: skip the bounded measurements of configs 3 and 5 and the K0 figure")
-    ap.add_argument("--in-flight", type=int, default=4, help="samples in flight per GPU (bk_engine_fork: shared index tables, own counter "
+    ap.add_argument("--in-flight", type=int, default=0, help="0 = the config's default (4; config 4, whose one sample is 200 scan launches: 3).  ""samples in flight per GPU (bk_engine_fork: shared index tables, own counter "
                     "planes / outputs / stream); 1 = strictly one sample after the other")
     ap.add_argument("--selected-only", action="store_true", help="bk_params.pileup_selected_only: votes for the selected genome only (two finalize "
                     "passes); what `bronko call` runs with -- the default is the reference's literal map_kmers: every genome's rows")
@@ -299,7 +299,7 @@ def measure(wl, args, dev, dist, steps, warmup, sps=None, eng=None, selected_onl
     # Each engine launches on its own HIP stream (created with the engine); torch sees it as an ExternalStream and every torch /
     # torch.distributed operation on the engine's buffers is enqueued on it: the collectives are ordered against the kernels by
     # the stream.
-    n_fly = max(1, args.in_flight)
+    n_fly = args.in_flight if args.in_flight > 0 else (3 if cfg == 4 else 4)
     engs = [eng] + [eng.fork() for _ in range(n_fly - 1)]
     streams = [torch.cuda.ExternalStream(e.stream_ptr(), device=dev) for e in engs]
     torch.cuda.set_stream(streams[0])

@@ -1,7 +1,7 @@
 # The captures of a round's last build that are kept under profiles/ (run on the GPU box: gpurun -- bash tools/final_captures.sh r04_a).
 # Everything lands in gpurun_out/<tag>_*; copy what is to be judged into profiles/ afterwards (tools/README.md).
 cd $GRAFT_REPO_ROOT
-T=${1:-r04_a}
+T=${1:-r06_a}
 bash tools/profile_round.sh $T > gpurun_out/${T}_profile.log 2>&1
 tail -14 gpurun_out/${T}_profile.log
 cp gpurun_out/${T}_pmc_traffic.json profiles/pmc_traffic.json
@@ -26,3 +26,10 @@ python3 tools/sample_timeline.py $(find gpurun_out/tl5 -name "*kernel_trace.csv"
 rm -rf gpurun_out/tl5
 tail -8 gpurun_out/${T}_config5_selected_only_timeline.txt
 cat gpurun_out/${T}_scan_ablate.txt
+
+# round 6: away from the sweet spot, the scale rows, the host side of the ingest, engine creation, the kept fuzz runs
+python3 tools/stress_probe.py 2>&1 | grep " bp" > gpurun_out/${T}_stress.txt
+{ for n in 100 250 500; do python3 tools/scale_probe.py $n 4 2>&1 | grep -v amdgpu.ids; done; } > gpurun_out/${T}_scale.txt
+bash tools/pack_probe.sh 2>&1 | tail -10 > gpurun_out/${T}_pack_probe.txt
+python3 tools/create_timing.py 100 31 2>&1 | grep -E "bk_engine_create|index build" > gpurun_out/${T}_create_timing.txt
+cat gpurun_out/${T}_stress.txt gpurun_out/${T}_scale.txt

@@ -1544,7 +1544,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
         // comes here are reads that are not from the reference (every k-mer of a read without a diagonal) and k-mers with two
         // sequencing errors where no cell is isolated (many related genomes: three in four of the slow path's k-mers found nothing
         // there after eight random lines each).
-        if (slow && !stat_only && ix.lo.bits && ix.hi.bits && !BK_ABLATE(a, 13)) {
+        if (slow && !stat_only && ix.lo.bits && ix.hi.bits && !BK_ABLATE(a, 21)) {
             const int lo_bits = 2 * ix.lo_bases;
             const uint64_t lo = c & ((1ull << lo_bits) - 1ull), hi = c >> lo_bits;
             const uint32_t bl = half_bit_index(lo, ix.lo.bits_log2, ix.lo.bits_exact), bh = half_bit_index(hi, ix.hi.bits_log2, ix.hi.bits_exact);
@@ -1566,7 +1566,7 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
     };
 
     uint32_t qr = 0, qk = 0;   // wave-uniform fills of the record and k-mer queues
-    const bool roll_ok = !STATS && ix.lo.bits && ix.hi.bits && !BK_ABLATE(a, 13) && !BK_ABLATE(a, 15);   // (take_records: reads marked whole are rolled)
+    const bool roll_ok = !STATS && ix.lo.bits && ix.hi.bits && !BK_ABLATE(a, 21) && !BK_ABLATE(a, 22);   // (take_records: reads marked whole are rolled)
     constexpr uint32_t kRollMin = 16;   // ... when a batch of 64 marked records holds at least this many
     auto take_kmers = [&]() __attribute__((always_inline)) {
         const uint32_t n = min(qk, 64u);

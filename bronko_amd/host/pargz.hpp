@@ -331,9 +331,14 @@ struct SymBuf {
     Block b;
     uint16_t* d = nullptr;
     size_t n = 0, cap = 0;
+    size_t member_from = 0;      // where the gzip member being inflated began, if it began inside this buffer (member_inside):
+    bool member_inside = false;  // a distance may not reach past it (zlib: "invalid distance too far back")
     SymBuf() = default;
-    SymBuf(SymBuf&& o) noexcept : b(std::move(o.b)), d(o.d), n(o.n), cap(o.cap) { o.d = nullptr; o.n = 0; o.cap = 0; }
-    SymBuf& operator=(SymBuf&& o) noexcept { b = std::move(o.b); d = o.d; n = o.n; cap = o.cap; o.d = nullptr; o.n = 0; o.cap = 0; return *this; }
+    SymBuf(SymBuf&& o) noexcept : b(std::move(o.b)), d(o.d), n(o.n), cap(o.cap), member_from(o.member_from), member_inside(o.member_inside) { o.d = nullptr; o.n = 0; o.cap = 0; }
+    SymBuf& operator=(SymBuf&& o) noexcept {
+        b = std::move(o.b); d = o.d; n = o.n; cap = o.cap; member_from = o.member_from; member_inside = o.member_inside;
+        o.d = nullptr; o.n = 0; o.cap = 0; return *this;
+    }
     void room(size_t extra) {
         if (n + extra <= cap) return;
         Block nb = BlockPool::get().take(std::max<size_t>(cap * 2, n + extra + (1u << 16)) * sizeof(uint16_t));
@@ -350,9 +355,12 @@ struct ByteBuf {
     uint8_t* d = nullptr;        // the chunk's text; d[-before .. 0) is the text before it
     size_t n = 0, cap = 0;
     uint32_t before = 0;
+    size_t member_from = 0;      // as SymBuf's
+    bool member_inside = false;
     void start(const uint8_t* window, size_t n_window, size_t want) {
         b = BlockPool::get().take(kWin + want);
         d = reinterpret_cast<uint8_t*>(b.p) + kWin; cap = b.cap - kWin; n = 0;
+        member_from = 0; member_inside = false;
         before = (uint32_t)std::min<size_t>(n_window, kWin);
         if (before) memcpy(d - before, window + (n_window - before), before);
     }
@@ -407,12 +415,15 @@ inline bool inflate_block(Bits& in, const Codes& c, B& out, size_t max_out) {
         in.take(d & 0xffu);
         const uint32_t dist = (d >> 16) + in.get((d >> 12) & 15u);
         sym_t* o = out.d + out.n;
-        if (dist <= out.n + BufTraits<B>::before(out)) {             // (bytes: the text before the chunk lies in front of the buffer)
+        // how far back this member's text goes in the buffer (bytes: the text before the chunk lies in front of the buffer)
+        const size_t reach = out.member_inside ? out.n - out.member_from : out.n + BufTraits<B>::before(out);
+        if (dist <= reach) {
             const sym_t* s = o - dist;
             if (dist >= len) memcpy(o, s, len * sizeof(sym_t));
             else for (uint32_t i = 0; i < len; i++) o[i] = s[i];
         } else if constexpr (BufTraits<B>::symbolic) {
             // reaches into the window before the chunk
+            if (out.member_inside) return false;                     // ... which is another member's text
             const uint32_t before = dist - (uint32_t)out.n;          // symbols back from the chunk's start, first one copied
             if (before > kWin) return false;
             for (uint32_t i = 0; i < len; i++) {
@@ -519,6 +530,7 @@ inline void inflate_chunk_into(const uint8_t* file, uint64_t n_bytes, std::vecto
                 me_.at = out.n;
                 memcpy(&me_.crc, file + at, 4); memcpy(&me_.isize, file + at + 4, 4);
                 c.ends.push_back(me_);
+                out.member_from = out.n; out.member_inside = true;   // what follows is a new member: its distances stop here
                 const uint64_t nx = member_header(file, at + 8, n_bytes);
                 if (nx == kNone) { c.eof = true; c.stop = (at + 8) * 8u; return; }   // (gzread: what follows the last member is ignored)
                 in.seek(nx * 8u);
@@ -820,10 +832,13 @@ private:
                 wins[x] = window;
                 const Chunk& c = cs[chain[x]];
                 if (c.failed) break;
-                const size_t n = c.text_len(), keep = std::min<size_t>(n, kWin);
+                // (a member that ended inside the chunk: the window holds the text since the last such end only, so that the next
+                // chunk's distances cannot reach into another member's text -- gzread's "invalid distance too far back")
+                const size_t n = c.text_len(), since = c.ends.empty() ? 0 : (size_t)c.ends.back().at;
+                const size_t keep = std::min<size_t>(n - since, kWin);
                 std::vector<uint8_t> nw;
                 nw.reserve(kWin);
-                if (keep < kWin && !window.empty()) {
+                if (keep < kWin && !window.empty() && c.ends.empty()) {
                     const size_t from_old = std::min<size_t>(kWin - keep, window.size());
                     nw.insert(nw.end(), window.end() - from_old, window.end());
                 }

@@ -172,6 +172,63 @@ def test_damage_is_an_error(cat, tmp_path):
     assert rc == 1
 
 
+def _fixed_block(items):
+    """One final fixed-Huffman deflate block (RFC 1951 3.2.6) of literals (int) and copies ((3, distance), distance 1 or 97..128)"""
+    bits = []
+    def huff(code, n):                                               # Huffman codes go in most significant bit first,
+        bits.extend((code >> (n - 1 - i)) & 1 for i in range(n))
+    def plain(v, n):                                                 # everything else least significant bit first
+        bits.extend((v >> i) & 1 for i in range(n))
+    plain(1, 1); plain(1, 2)
+    for it in items:
+        if isinstance(it, int):
+            assert it < 144
+            huff(0x30 + it, 8)
+        else:
+            ln, dist = it
+            assert ln == 3
+            huff(257 - 256, 7)
+            if dist == 1:
+                huff(0, 5)
+            else:
+                assert 97 <= dist <= 128
+                huff(13, 5); plain(dist - 97, 5)
+    huff(0, 7)
+    bits += [0] * (-len(bits) % 8)
+    return bytes(sum(b << i for i, b in enumerate(bits[j:j + 8])) for j in range(0, len(bits), 8))
+
+
+def test_a_distance_does_not_reach_into_the_member_before(cat, tmp_path):
+    """zlib starts every member with an empty window: a copy from before the member's first byte is "invalid distance too far back",
+    however much text the file had before it"""
+    t = text()
+    a, b = t[:3000000], t[3000000:6000000]
+    head = b"\x1f\x8b\x08\0\0\0\0\0\0\xff"
+    def member(items, out):
+        return head + _fixed_block(items) + struct.pack("<II", zlib.crc32(out), len(out))
+    good = member([65, (3, 1)], b"AAAA")
+    assert gzip.decompress(good) == b"AAAA"
+    p = str(tmp_path / "m.fastq.gz")
+    open(p, "wb").write(gzip.compress(a, 6) + good + gzip.compress(b, 6))
+    for threads, chunk in [(1, 0), (8, 0), (8, 100000), (3, 250000)]:
+        rc, out, err = run(cat, p, threads, chunk)
+        assert rc == 0 and out == a + b"AAAA" + b, (threads, chunk, err)
+    # ... from 1 and from 100 bytes back, as a member's first thing and its second; the trailer is the one a reader that carried
+    # the window over would find right
+    for items, lenient in (([(3, 1)], a[-1:] * 3), ([(3, 100)], a[-100:-97]), ([65, (3, 100)], b"A" + a[-99:-96])):
+        bad = member(items, lenient)
+        with pytest.raises(Exception):
+            gzip.decompress(bad)
+        with pytest.raises(Exception):
+            gzip.decompress(gzip.compress(a[-1000:]) + bad)
+        for tail in (b"", gzip.compress(b, 6)):
+            open(p, "wb").write(gzip.compress(a, 6) + bad + tail)
+            for threads, chunk in [(1, 0), (8, 0), (8, 100000), (3, 250000)]:
+                rc, out, err = run(cat, p, threads, chunk)
+                assert rc == 1 and "damaged" in err, (items, len(tail), threads, chunk, rc, err)
+                assert a.startswith(out[:len(a)]) and len(out) <= len(a) + 1
+
+
 def test_random_texts_members_and_chunkings(cat, tmp_path):
     """Forty random files: FASTQ-like, FASTA-like and mixed text of random sizes, compression levels, member cuts and flush points,
     read back with random thread counts and chunk sizes -- always the bytes zlib gives."""

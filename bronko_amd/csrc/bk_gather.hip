@@ -236,54 +236,108 @@ __global__ __launch_bounds__(256) void voter_table_kernel(FinalizeArgs a, const 
     }
 }
 
-// (a lane per position and a wave per window position here -- every fourth -- so that a lane's LDS counters are its own: the W
-// lanes of one position of the direct kernel's layout meet on the same eight addresses, 26 ways)
+// A lane per position and a wave per window position (every fourth), the lane's sixteen sums and maxima in registers.  Where an
+// entry goes: an occurrence as written (not reverse-complemented to become canonical) sends voter (b, isrc) to base b, forward for
+// isrc = 0 -- the same register for every window position; a reverse-complemented one sends all four bases' voters to ONE base,
+// the complement of the k-mer's base at the mirrored position (vote()'s `canonical` branch) -- which is the reference's own base
+// at the pileup position, the same for every window position of the lane: they are summed apart and added to that base at the
+// end (the middle position of an odd k, where the mirrored position is the voter's own, goes base by base).  No branch and no
+// load behind a branch: the compiler sends the loads of all the wave's window positions ahead of the arithmetic.
+// (Round 5's form kept the sums in LDS, 32 read-modify-writes per entry behind one another, asked for an entry only after the one
+// before was done and walked the genomes one after the other: 0.59 ms per sample at 100 strains, 2.9 GB from the fabric, 42 M LDS
+// instructions; this one 0.50 ms, 0.70 GB, 3 M -- what is left is its 141 M vector instructions: at this coverage every entry of
+// the table has a count, 624 M sums and maxima per sample.)
+constexpr uint32_t kGatherWaves = kGatherBlock / 64;
+constexpr uint32_t kGatherTMax = (32u + kGatherWaves - 1u) / kGatherWaves;   // window positions per wave (W <= k <= 31 ... 32)
 __global__ __launch_bounds__(kGatherBlock) void gather_table_kernel(FinalizeArgs a, const uint32_t* __restrict__ tab) {
-    constexpr uint32_t kWaves = kGatherBlock / 64;
-    __shared__ unsigned int mx[kWaves][8][kGatherPos];
-    __shared__ unsigned int cnt[kWaves][8][kGatherPos];
+    constexpr uint32_t kWaves = kGatherWaves;
+    __shared__ unsigned int red[kWaves][16][kGatherPos];
     const IndexView& ix = a.ix;
-    const uint32_t c_hi = ix.total_cells;
-    const uint64_t p0_64 = (uint64_t)blockIdx.x * kGatherPos;
+    // Related genomes are collinear: stretch s of every one of them reads the same ~50 KB of the table.  Workgroups are handed to
+    // the eight XCDs in turn, so blockIdx = (s / 8, genome, s % 8): the genomes' copies of a stretch follow each other on ONE XCD
+    // and find the table's lines in its L2.
+    const uint32_t nf = (uint32_t)ix.n_files, n = blockIdx.x >> 3;
+    const uint32_t g = n % nf, s = (n / nf) * 8u + (blockIdx.x & 7u);
+    const uint32_t g_lo = a.file_cell_lo[g], c_hi = g + 1u < nf ? a.file_cell_lo[g + 1u] : ix.total_cells;
+    const uint64_t p0_64 = (uint64_t)g_lo + (uint64_t)s * kGatherPos;
     if (p0_64 >= c_hi) return;
     const uint32_t P0 = (uint32_t)p0_64;
-    for (uint32_t i = threadIdx.x; i < kWaves * 8u * kGatherPos; i += kGatherBlock) { (&mx[0][0][0])[i] = 0u; (&cnt[0][0][0])[i] = 0u; }
-    __syncthreads();
     const uint32_t W = (uint32_t)ix.W, km1 = (uint32_t)ix.k - 1u;
     const uint32_t pi = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t P = P0 + pi;
-    if (P < c_hi)
-        for (uint32_t t = wave; t < W; t += kWaves) {
-            const uint32_t j = (uint32_t)ix.wstart + t;
-            if (P < j) continue;
-            const uint32_t c0 = P - j;
-            const uint32_t id = ix.id_at[c0];
-            if (id >= ix.n_full) continue;
-            const bool canon = (ix.cell_flags[c0] & 3u) == 2u;
-            const uint4* tp = reinterpret_cast<const uint4*>(tab + ((uint64_t)id * W + t) * 8u);
-            const uint4 lo = tp[0], hi = tp[1];
-            const uint32_t vals[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            const uint32_t cb = lo.x >> 30;
-            const bool middle = 2u * j == km1;   // the mirrored position is the voter's own: (z >> 2j) & 3 is the voter's base there
+    constexpr uint32_t kMask = (1u << kVtCountBits) - 1u;
+    uint32_t cnt[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, mx[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // [0..3] forward, [4..7] reverse
+    uint32_t rc_cnt[2] = {0u, 0u}, rc_mx[2] = {0u, 0u}, rc_base = 0u;                                     // the reverse-complemented occurrences'
+    uint32_t ids[kGatherTMax];
+    uint32_t w_bits = 0u, c_bits = 0u;                           // bit x: the lane has an occurrence at the wave's x-th window position, as written / reverse-complemented
 #pragma unroll
-            for (uint32_t e = 0; e < 8u; ++e) {
-                const uint32_t np = (vals[e] >> kVtCountBits) & 3u;
-                if (np == 0u) continue;
-                const uint32_t v = vals[e] & ((1u << kVtCountBits) - 1u), b = e >> 1, isrc = e & 1u;
-                const uint32_t bit_idx = canon ? ((middle ? b : cb) ^ 3u) : b;
-                const bool forward = canon ? isrc != 0u : isrc == 0u;
-                const uint32_t row = (forward ? 0u : 4u) + bit_idx;
-                cnt[wave][row][pi] += np;                            // (the lane's own: no other touches [wave][.][pi])
-                mx[wave][row][pi] = max(mx[wave][row][pi], v);
-            }
+    for (uint32_t x = 0; x < kGatherTMax; ++x) {
+        const uint32_t t = wave + x * kWaves, j = (uint32_t)ix.wstart + t;
+        const bool in = t < W && P < c_hi && P >= j;
+        const uint32_t c0 = in ? P - j : 0u;
+        const uint32_t id = ix.id_at[c0];
+        const bool canon = (ix.cell_flags[c0] & 3u) == 2u, on = in && id < ix.n_full;
+        ids[x] = on ? id : 0u;
+        w_bits |= (on && !canon ? 1u : 0u) << x;
+        c_bits |= (on && canon ? 1u : 0u) << x;
+    }
+#pragma unroll
+    for (uint32_t x = 0; x < kGatherTMax; ++x) {
+        const uint32_t t = wave + x * kWaves, j = (uint32_t)ix.wstart + t;
+        if (t >= W) break;                                       // (wave-uniform)
+        const uint4* tp = reinterpret_cast<const uint4*>(tab + ((uint64_t)ids[x] * W + t) * 8u);
+        const uint4 lo = tp[0], hi = tp[1];
+        const uint32_t vals[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const uint32_t cb = lo.x >> 30;
+        // (masks, not selects: a select per sum and maximum was two thirds of the kernel's instructions)
+        const uint32_t m_w = (uint32_t)__builtin_amdgcn_sbfe((int)w_bits, x, 1u), m_c = (uint32_t)__builtin_amdgcn_sbfe((int)c_bits, x, 1u);   // 0 or ~0
+        uint32_t np[8], v[8];
+#pragma unroll
+        for (uint32_t e = 0; e < 8u; ++e) { np[e] = (vals[e] >> kVtCountBits) & 3u; v[e] = vals[e] & kMask; }
+        if (2u * j == km1) {                                     // (wave-uniform; odd k only) the mirrored position is the voter's own
+#pragma unroll
+            for (uint32_t b = 0; b < 4u; ++b)
+#pragma unroll
+                for (uint32_t isrc = 0; isrc < 2u; ++isrc) {
+                    const uint32_t e = 2u * b + isrc;
+                    // as written: base b, forward for isrc 0; reverse-complemented: base 3 - b, forward for isrc 1
+                    const uint32_t r_w = isrc * 4u + b, r_c = (1u - isrc) * 4u + (3u - b);
+                    cnt[r_w] += np[e] & m_w; mx[r_w] = max(mx[r_w], v[e] & m_w);
+                    cnt[r_c] += np[e] & m_c; mx[r_c] = max(mx[r_c], v[e] & m_c);
+                }
+            continue;
         }
+#pragma unroll
+        for (uint32_t e = 0; e < 8u; ++e) {
+            const uint32_t r_w = (e & 1u) * 4u + (e >> 1);
+            cnt[r_w] += np[e] & m_w;
+            mx[r_w] = max(mx[r_w], v[e] & m_w);
+        }
+        // reverse-complemented: forward for isrc = 1 (the odd entries)
+        const uint32_t s1 = np[1] + np[3] + np[5] + np[7], s0 = np[0] + np[2] + np[4] + np[6];
+        const uint32_t m1 = max(max(v[1], v[3]), max(v[5], v[7])), m0 = max(max(v[0], v[2]), max(v[4], v[6]));
+        rc_cnt[0] += s1 & m_c; rc_mx[0] = max(rc_mx[0], m1 & m_c);
+        rc_cnt[1] += s0 & m_c; rc_mx[1] = max(rc_mx[1], m0 & m_c);
+        rc_base = (rc_base & ~m_c) | ((cb ^ 3u) & m_c);
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < 4u; ++r) {
+        const bool here = rc_base == r;
+        cnt[r] += here ? rc_cnt[0] : 0u; mx[r] = max(mx[r], here ? rc_mx[0] : 0u);
+        cnt[4u + r] += here ? rc_cnt[1] : 0u; mx[4u + r] = max(mx[4u + r], here ? rc_mx[1] : 0u);
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < 8u; ++r) { red[wave][r][pi] = cnt[r]; red[wave][8u + r][pi] = mx[r]; }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < kGatherPos * 4u; i += kGatherBlock) {
         const uint32_t p = i >> 2, base = i & 3u;
         if (P0 + p >= c_hi) continue;
         unsigned int m0 = 0u, m1 = 0u, n0 = 0u, n1 = 0u;
 #pragma unroll
-        for (uint32_t w = 0; w < kWaves; ++w) { m0 = max(m0, mx[w][base][p]); m1 = max(m1, mx[w][4u + base][p]); n0 += cnt[w][base][p]; n1 += cnt[w][4u + base][p]; }
+        for (uint32_t w = 0; w < kWaves; ++w) {
+            n0 += red[w][base][p]; n1 += red[w][4u + base][p];
+            m0 = max(m0, red[w][8u + base][p]); m1 = max(m1, red[w][12u + base][p]);
+        }
         const size_t cell = ((size_t)P0 + p) * 4 + base;
         a.pileup[0 * a.plane + cell] = (unsigned long long)m0;
         a.pileup[1 * a.plane + cell] = (unsigned long long)m1;
@@ -399,7 +453,8 @@ void launch_gather_votes_table(const FinalizeArgs& a, const unsigned long long* 
     if (!n_pairs || !a.ix.total_cells) return;
     hipLaunchKernelGGL(voter_table_kernel, dim3((unsigned)std::min<uint64_t>((n_pairs + 255) / 256, 1u << 16)), dim3(256), 0, stream, a, counters1, tab, row_bits,
                        ~0ull / (unsigned long long)(a.ix.v_span + 1) + 1ull);
-    hipLaunchKernelGGL(gather_table_kernel, dim3((unsigned)(((uint64_t)a.ix.total_cells + kGatherPos - 1) / kGatherPos)), dim3(kGatherBlock), 0, stream, a, (const uint32_t*)tab);
+    const uint64_t stretches = ((uint64_t)a.max_file_cells + kGatherPos - 1) / kGatherPos;   // of the longest genome
+    hipLaunchKernelGGL(gather_table_kernel, dim3((unsigned)((stretches + 7) / 8 * 8 * (uint64_t)a.ix.n_files)), dim3(kGatherBlock), 0, stream, a, (const uint32_t*)tab);
 }
 void launch_merged_votes(const FinalizeArgs& a, hipStream_t stream) {
     if (!a.n_merged_slots) return;

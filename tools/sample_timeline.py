@@ -9,7 +9,7 @@ def short(n):
     return n
 names = [short(r["Kernel_Name"]) for r in rows]
 # a sample starts at the first kernel after a finalize_* / clear_touched / ktab_stats kernel that is none of those
-ends = ("finalize_", "clear_touched", "ktab_stats", "select_genome", "noise_", "call_", "copy_int", "prefix_rows", "gather_votes", "gather_table", "voter_table", "merged_votes", "alias_votes")
+ends = ("finalize_", "clear_touched", "ktab_stats", "select_genome", "noise_", "call_", "copy_int", "prefix_rows", "gather_votes", "gather_table", "voter_table", "merged_votes", "alias_votes", "touched_prows", "counted_ids")
 def fill_inside(i):   # a memset between two kernels of a sample's end (the touched-row bits before prefix_rows_kernel)
     j = i
     while j < len(rows) and names[j].startswith("__amd_rocclr_fillBuffer"): j += 1

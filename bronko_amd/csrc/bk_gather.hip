@@ -189,17 +189,27 @@ __global__ __launch_bounds__(kGatherBlock) void gather_votes_kernel(FinalizeArgs
 // pass; word 0 also carries, in bits 30-31, the k-mer's base at the mirrored position (what a reverse-complemented occurrence votes
 // for: vote()'s `canonical` branch).
 constexpr uint32_t kVtCountBits = 28;
-__global__ __launch_bounds__(256) void voter_table_kernel(FinalizeArgs a, const unsigned long long* __restrict__ counters1, uint32_t* __restrict__ tab,
+constexpr uint32_t kVoterBlock = 512;   // = the (k-mer, window position) pairs of a workgroup's tile: each thread has one
+__global__ __launch_bounds__(kVoterBlock) void voter_table_kernel(FinalizeArgs a, const unsigned long long* __restrict__ counters1, uint32_t* __restrict__ tab,
                                                           const unsigned int* __restrict__ row_bits /* which V rows the sample touched (prefix_rows_kernel) */,
                                                           unsigned long long rl_recip /* ceil(2^64 / row length) */) {
     const IndexView& ix = a.ix;
     const uint32_t W = (uint32_t)ix.W, rl = (uint32_t)ix.v_span + 1u;
     const uint64_t v_real = v_real_len(ix.n_full, ix.v_span);
-    const uint64_t n_pairs = (uint64_t)ix.n_full * W;
+    // The table is laid out [half of the entry][t][id]: the lanes of gather_table_kernel are neighbouring positions, their k-mers
+    // neighbouring ids, and a load of theirs is one stretch of 1 KB (laid out [id][t] every lane's entry was a line of its own, and
+    // the texture unit takes a divergent load line by line: 0.50 -> 0.34 ms).  The threads here stay (id, t), the window positions
+    // of a k-mer side by side -- their voters' counters are neighbours (a pseudo k-mer's rows follow (id, t)); with the ids side by
+    // side this kernel took 1.46 ms instead of 0.55 -- so a workgroup takes 512 / W k-mers, a thread per pair, turns their entries round in LDS and
+    // stores rows of them (16 bytes a lane straight from the registers: 0.65 ms).
+    extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
+    uint4* const rows = reinterpret_cast<uint4*>(vt_smem);       // [2 W][tile + 1]
+    const uint32_t tile = kVoterBlock / W, stride = tile + 1u;
+    const uint32_t id0 = blockIdx.x * tile, n_here = min(tile, ix.n_full - id0);
     const unsigned long long* const planes[2] = {a.counters, counters1};
     const int n_planes = counters1 ? 2 : 1;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n_pairs; i += (uint64_t)gridDim.x * 256u) {
-        const uint32_t id = (uint32_t)(i / W), t = (uint32_t)(i - (uint64_t)id * W), j = (uint32_t)ix.wstart + t;
+    for (uint32_t x = threadIdx.x; x < n_here * W; x += kVoterBlock) {
+        const uint32_t idl = x / W, t = x - idl * W, id = id0 + idl, j = (uint32_t)ix.wstart + t;
         const uint4 idr = *reinterpret_cast<const uint4*>(ix.id_rec + id);
         const uint64_t u = (uint64_t)idr.x | ((uint64_t)idr.y << 32);
         const uint64_t ur = revcomp_kmer(u, ix.k);
@@ -230,9 +240,13 @@ __global__ __launch_bounds__(256) void voter_table_kernel(FinalizeArgs a, const 
             }
         }
         out[0] |= ((uint32_t)(u >> (2u * j)) & 3u) << 30;
-        uint4* dst = reinterpret_cast<uint4*>(tab + i * 8u);
-        dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
-        dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+        rows[t * stride + idl] = make_uint4(out[0], out[1], out[2], out[3]);
+        rows[(W + t) * stride + idl] = make_uint4(out[4], out[5], out[6], out[7]);
+    }
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < 2u * W * n_here; x += kVoterBlock) {
+        const uint32_t r = x / n_here, idl = x - r * n_here;     // r = half * W + t
+        *reinterpret_cast<uint4*>(tab + ((uint64_t)r * ix.n_full + id0 + idl) * 4u) = rows[r * stride + idl];
     }
 }
 
@@ -285,8 +299,8 @@ __global__ __launch_bounds__(kGatherBlock) void gather_table_kernel(FinalizeArgs
     for (uint32_t x = 0; x < kGatherTMax; ++x) {
         const uint32_t t = wave + x * kWaves, j = (uint32_t)ix.wstart + t;
         if (t >= W) break;                                       // (wave-uniform)
-        const uint4* tp = reinterpret_cast<const uint4*>(tab + ((uint64_t)ids[x] * W + t) * 8u);
-        const uint4 lo = tp[0], hi = tp[1];
+        const uint64_t at = (uint64_t)t * ix.n_full + ids[x];                        // (voter_table_kernel: [half][t][id])
+        const uint4 lo = *reinterpret_cast<const uint4*>(tab + at * 4u), hi = *reinterpret_cast<const uint4*>(tab + ((uint64_t)ix.n_full * W + at) * 4u);
         const uint32_t vals[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         const uint32_t cb = lo.x >> 30;
         // (masks, not selects: a select per sum and maximum was two thirds of the kernel's instructions)
@@ -451,7 +465,8 @@ size_t vote_table_words(const IndexView& ix) { return (size_t)ix.n_full * (size_
 void launch_gather_votes_table(const FinalizeArgs& a, const unsigned long long* counters1, uint32_t* tab, const unsigned int* row_bits, hipStream_t stream) {
     const uint64_t n_pairs = (uint64_t)a.ix.n_full * (uint64_t)a.ix.W;
     if (!n_pairs || !a.ix.total_cells) return;
-    hipLaunchKernelGGL(voter_table_kernel, dim3((unsigned)std::min<uint64_t>((n_pairs + 255) / 256, 1u << 16)), dim3(256), 0, stream, a, counters1, tab, row_bits,
+    const uint32_t tile = kVoterBlock / (uint32_t)a.ix.W;        // (W <= 32: at least 16 k-mers)
+    hipLaunchKernelGGL(voter_table_kernel, dim3((a.ix.n_full + tile - 1u) / tile), dim3(kVoterBlock), (size_t)2 * a.ix.W * (tile + 1u) * sizeof(uint4), stream, a, counters1, tab, row_bits,
                        ~0ull / (unsigned long long)(a.ix.v_span + 1) + 1ull);
     const uint64_t stretches = ((uint64_t)a.max_file_cells + kGatherPos - 1) / kGatherPos;   // of the longest genome
     hipLaunchKernelGGL(gather_table_kernel, dim3((unsigned)((stretches + 7) / 8 * 8 * (uint64_t)a.ix.n_files)), dim3(kGatherBlock), 0, stream, a, (const uint32_t*)tab);

@@ -356,6 +356,7 @@ struct bk_engine {
     DevBuf<unsigned int> n_bits, n_any;     // scan -> Level 2: one bit per k-mer of each record of a launch / per record (bk_kernels.h ScanArgs): the N runs; all zero between launches
     DevBuf<unsigned int> l2_bits;           // Level 2's first pass -> its second: the k-mers looked at one by one, same layout
     DevBuf<unsigned int> l2_any;            // ... one bit per record: its row has bits
+    DevBuf<unsigned int> l2_plan;           // one word: the workgroups of level2_kernel that work (ScanArgs::l2_plan)
     DevBuf<uint2> l2_diag;                  // ... and each record's diagonal
     uint64_t kmers_since_fold = 0;
     DevBuf<bk::TableSlot> table;
@@ -523,6 +524,7 @@ static int alloc_sample_state(bk_engine* e) {
     BK_HIP(e->stats.alloc((size_t)2 * e->n_files * 3));
     BK_HIP(e->present.alloc((size_t)2 * e->n_files));
     if (prm->pileup_selected_only != 0 && e->n_files > 1) BK_HIP(e->sel_out.alloc(1));   // (the genome selected between the two finalize passes)
+    BK_HIP(e->l2_plan.alloc(4));
     BK_HIP(e->kstats.alloc(8));
     // the scan: binned (items) when the planes are dense, the window's reference is staged in LDS and the bins are few enough;
     // else the whole-window difference array of scan_count_kernel with its slabs
@@ -2244,6 +2246,9 @@ static int push_device(bk_engine* e, int mate, const uint32_t* d_words, uint32_t
             BK_HIP(hipMemsetAsync(e->n_any.p, 0, e->n_any.n * sizeof(unsigned int), e->stream));
         }
         a.l2_bits = e->l2_bits.p; a.l2_diag = e->l2_diag.p; a.l2_any = e->l2_any.p; a.n_bits = e->n_bits.p; a.n_any = e->n_any.p;
+        // (one genome file, the binned scan, four or more samples in flight: Level 2 on as many workgroups as its marks are worth)
+        a.l2_plan = e->use_items && e->n_files == 1 && e->family->load() >= 4 && !test_env("BK_NO_L2_PLAN") ? e->l2_plan.p : nullptr;
+        a.l2_min_grid = (uint32_t)std::max(1, e->n_cus / 2);
         a.rec_base = base; a.n_records = take;
         if (int rc = flush_pending_items(e)) return rc;   // (the scan below overwrites the item buffers)
         const bool wait_v = e->fuse_ok && a.n_direct && !e->fuse_off[mate] && e->item_v_mode < 0;

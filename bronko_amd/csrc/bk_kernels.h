@@ -80,6 +80,8 @@ struct ScanArgs {
     unsigned int* n_any;            // [ceil(n_records / 32)]
     unsigned int* l2_bits;          // [n_records][l2_words]
     unsigned int* l2_any;           // [ceil(n_records / 32)]
+    unsigned int* l2_plan;          // null, or one word launch_level2 fills before level2_kernel: how many of its workgroups work
+    uint32_t l2_min_grid;           // (l2_plan_kernel: marked records / 256, at least this many) -- with four or more samples in flight
     uint2* l2_diag;                 // [n_records] {cell of the reference k-mer aligned with read k-mer 0, bit 0 same strand | bit 1 known}
     uint32_t l2_words;              // = scan_l2_words(stride_words, k)
     uint32_t n_lds_bins;            // exact hits at cells [win_lo, win_lo + n_lds_bins) are counted in LDS

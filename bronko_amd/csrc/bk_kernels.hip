@@ -1695,7 +1695,10 @@ __global__ __launch_bounds__(kL2Block) void level2_kernel(ScanArgs a) {
     const uint64_t n_any = (n_records + 31) / 32;                    // words of l2_any / n_any
     const uint64_t n_blk = (n_any + kAnyWords - 1) / kAnyWords;
 
-    for (uint64_t blk = (uint64_t)blockIdx.x * kL2Waves + wave; blk < n_blk; blk += (uint64_t)gridDim.x * kL2Waves) {
+    // (ScanArgs::l2_plan: with few records marked, few workgroups -- the others leave at once)
+    const uint32_t g_work = a.l2_plan ? min((uint32_t)gridDim.x, max(*a.l2_plan, 1u)) : (uint32_t)gridDim.x;
+    if (blockIdx.x >= g_work) return;
+    for (uint64_t blk = (uint64_t)blockIdx.x * kL2Waves + wave; blk < n_blk; blk += (uint64_t)g_work * kL2Waves) {
         const uint64_t i = blk * kAnyWords + lane;
         const uint32_t anyw = (lane < kAnyWords && i < n_any) ? a.l2_any[i] : 0u;
         if (anyw) a.l2_any[i] = 0u;     // taken: l2_any and l2_bits are all zero again when this kernel ends
@@ -1846,6 +1849,27 @@ hipError_t launch_scan_count(const ScanArgs& a, uint32_t grid, hipStream_t strea
     return hipGetLastError();
 }
 
+// How many workgroups of level2_kernel a launch's marks are worth: a wave gathers 64 marked records before it looks at their
+// k-mers, and a sample of the reference's own reads marks one read in a hundred -- two thousand waves each end up with a
+// handful, and every one of them holds a quarter of its SIMD's registers for the whole chain of loads, on a CU that a sibling
+// sample's scan workgroup (which needs the CU to itself) is waiting for.  One workgroup per 256 marked records instead, between
+// ScanArgs::l2_min_grid and the grid: config 2 with four samples in flight 12.3 -> 12.9 G reads/s; reads with 5 % errors or not
+// from the reference mark nearly every record and keep the whole grid (a fixed small grid cost them 25-35 %).
+__global__ __launch_bounds__(1024) void l2_plan_kernel(const unsigned int* __restrict__ l2_any, uint64_t n_words, unsigned int* __restrict__ plan, uint32_t g_min) {
+    __shared__ unsigned int part[16];
+    unsigned int n = 0;
+    for (uint64_t i = threadIdx.x; i < n_words; i += 1024u) n += (unsigned int)__popc(l2_any[i]);
+#pragma unroll
+    for (int off = 32; off; off >>= 1) n += (unsigned int)__shfl_xor((int)n, off);
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int t = 0;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        plan[0] = max(g_min, (t + 255u) / 256u);
+    }
+}
+
 hipError_t launch_level2(const ScanArgs& a, int n_cus, hipStream_t stream) {
     if (a.n_records == 0 || a.W <= 0) return hipSuccess;
     const bool stats = a.ktab_keys != nullptr;
@@ -1868,6 +1892,7 @@ hipError_t launch_level2(const ScanArgs& a, int n_cus, hipStream_t stream) {
     // on the CUs the sibling samples' kernels are waiting for (three samples in flight: 10.5 -> 10.8 G reads/s with a quarter of the
     // waves; alone the kernel takes what it took).  Several files: the marks are Level 2's real work (config 3 lost 8 % that way).
     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((blks + kL2Waves - 1) / kL2Waves, (uint64_t)n_cus * (a.n_files == 1 ? 2 : 8)));
+    if (a.l2_plan) hipLaunchKernelGGL(l2_plan_kernel, dim3(1), dim3(1024), 0, stream, (const unsigned int*)a.l2_any, (a.n_records + 31) / 32, a.l2_plan, a.l2_min_grid);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kL2Block), 0, stream, a);
     return hipGetLastError();
 }

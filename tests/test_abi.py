@@ -40,7 +40,7 @@ def test_release_library_reads_no_environment_variable():
     rel = open(_ffi.LIB_PATH, "rb").read()
     tst = open(_ffi.TESTING_LIB_PATH, "rb").read()
     for name in (b"BK_SCAN_ABLATE", b"BK_LDS_BINS", b"BK_REF_IN_LDS", b"BK_WINDOW_FILE", b"BK_MAX_LAUNCH_RECORDS", b"BK_L2_COUNT", b"BK_NO_FUSE", b"BK_NO_GATHER",
-                 b"BK_NOISE_SERIAL", b"BK_ITEM_CAPS", b"BK_GATHER_ABLATE", b"BK_NO_VOTE_TABLE", b"BK_NO_ISO23", b"BK_SYNC_DEBUG", b"BK_ITEM_SHARE"):
+                 b"BK_NOISE_SERIAL", b"BK_ITEM_CAPS", b"BK_GATHER_ABLATE", b"BK_NO_VOTE_TABLE", b"BK_NO_ISO23", b"BK_SYNC_DEBUG", b"BK_ITEM_SHARE", b"BK_NO_L2_PLAN"):
         assert name not in rel, name
         assert name in tst, name
 

@@ -1326,3 +1326,36 @@ def test_two_hundred_and_fifty_strains(oracle, sars_paths):
     sel.close()
     eng.close()
     ix.close()
+
+
+def test_level2_on_as_many_workgroups_as_its_marks_are_worth(oracle, sars_paths):
+    """With four engines in a family a single-genome engine's Level 2 works on marked records / 256 workgroups, at least half the
+    CU count (l2_plan_kernel, ScanArgs::l2_plan): the same pileups as the oracle's and as the engine's before it had siblings,
+    for reads that mark one record in a hundred, for reads that mark nearly all of them (5 % errors, foreign reads) and for none."""
+    ref = sars_paths[0]
+    ix = oracle.Index.build(21, [ref])
+    eng = helpers.engine_from_oracle_index(ix)
+    g = synth.read_fasta_bytes(ref)
+    gm, isnv = synth.sample_genome(g, 5)
+    rng = np.random.default_rng(11)
+    sets = {
+        "on target": synth.codes_to_ascii(synth.single_end_codes(gm, 60000, 150, 21, err=0.005, isnv=isnv)),
+        "5 % errors": synth.codes_to_ascii(synth.single_end_codes(gm, 30000, 150, 22, err=0.05, isnv=isnv)),
+        "half foreign": synth.codes_to_ascii(synth.single_end_codes(gm, 15000, 150, 23, err=0.01, isnv=isnv))
+                        + [bytes(b"ACGT"[i] for i in rng.integers(0, 4, 150)) for _ in range(15000)],
+        "error free": synth.codes_to_ascii(synth.single_end_codes(gm, 20000, 150, 24, err=0.0, isnv=isnv)),
+    }
+    alone = {name: helpers.hip_sample(eng, [reads], 21) for name, reads in sets.items()}
+    for name, reads in sets.items():
+        helpers.assert_same_pileup(alone[name], oracle.sample_pileup(ix, [reads]))
+    forks = [eng.fork(), eng.fork(), eng.fork()]                          # a family of four: the plan is on
+    for e in (eng, forks[1]):
+        for name, reads in sets.items():
+            got = helpers.hip_sample(e, [reads], 21)
+            for x, y in zip(got.arrays(), alone[name].arrays()):
+                assert np.array_equal(x, y), name
+            assert np.array_equal(got.stats, alone[name].stats) and np.array_equal(got.kmer_stats, alone[name].kmer_stats), name
+    for e in forks:
+        e.close()
+    eng.close()
+    ix.close()

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Throughput away from the benchmark's sweet spot: higher error rates, longer reads, reads that are not from the reference."""
+"""Throughput away from the benchmark's sweet spot: higher error rates, longer reads, reads that are not from the reference.
+usage: stress_probe.py [testing|release [rows [engines in flight, default 1]]]"""
 import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,22 +11,34 @@ from bronko_amd import Params, synth, _ffi
 from bronko_amd.hostlib import HostIndex
 if len(sys.argv) > 1 and sys.argv[1] == "testing":   # the -DBK_TESTING build: BK_SCAN_ABLATE and friends are honoured
     _ffi.use_testing_library(True)
-ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 else None   # run only the rows whose tag contains one of these
+ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] != "all" else None   # run only the rows whose tag contains one of these
+N_FLY = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 ref_path = os.path.join(ROOT, "tests", "golden", "4_sarscov2", "wuhan_ref.fasta")
 ref = synth.read_fasta_bytes(ref_path)
 ix = HostIndex.build(21, [ref_path], threads=4)
 eng = ix.engine(Params())
 dev = torch.device("cuda", 0)
+engs = [eng] + [eng.fork() for _ in range(N_FLY - 1)]
+streams = [torch.cuda.ExternalStream(e.stream_ptr(), device=dev) for e in engs]
 gm, isnv = synth.sample_genome(ref, 2)
 def run(tag, codes):
     if ONLY and not any(o in tag for o in ONLY):
         return
     dw, dl = synth.pack_codes_torch(codes)
     torch.cuda.synchronize()
-    def step():
-        eng.sample_begin(); eng.push_reads_device(0, dw.data_ptr(), dw.shape[1], dl.data_ptr(), dl.numel()); eng.sample_finalize(1)
-    for _ in range(3): step()
+    def step(j=0):
+        e = engs[j]
+        with torch.cuda.stream(streams[j]):
+            e.sample_begin(); e.push_reads_device(0, dw.data_ptr(), dw.shape[1], dl.data_ptr(), dl.numel()); e.sample_finalize(1)
+    for i in range(3 * N_FLY): step(i % N_FLY)
     torch.cuda.synchronize()
+    if N_FLY > 1:
+        t0 = time.perf_counter()
+        for i in range(10 * N_FLY): step(i % N_FLY)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / (10 * N_FLY)
+        print("%-34s %7.3f ms/sample with %d in flight" % (tag, dt * 1e3, N_FLY), flush=True)
+        return
     eng.timing_enable(1); eng.timing_read(reset=True)
     t0 = time.perf_counter()
     for _ in range(10): step()

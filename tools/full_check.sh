@@ -2,4 +2,4 @@
 cd $GRAFT_REPO_ROOT
 timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/last_tests.txt
 cat gpurun_out/last_tests.txt
-OUT=r06_fuzz_b timeout 2400 bash tools/round_fuzz.sh
+OUT=r06_fuzz_c timeout 2400 bash tools/round_fuzz.sh
